@@ -1,0 +1,207 @@
+/*
+ * imcom_hip.h -- C-ABI of libimcom_hip.so: the MI355X (gfx950) IMCOM postage-stamp path.
+ *
+ * This is the drop-in boundary for the ONE hot path of pyimcom (reference checkout paths below are
+ * relative to src/pyimcom/): per-postage-stamp construction of the PSF-overlap system matrix A and
+ * the target cross-correlation -B/2, the Cholesky / eigen solve T = (A + kappa I)^-1 (-B/2), the
+ * leakage U/C, noise Sigma and kappa maps, and the coaddition epilogue.  Plain C, caller-allocated
+ * buffers, no torch types.  Every entry point returns 0 (IMCOM_OK) or a negative imcom_status;
+ * imcom_last_error() gives the message of the calling thread's last failure.
+ *
+ * Pointers are host or device pointers as selected by `memspace`: with IMCOM_MEM_HOST the library
+ * stages through its own device workspace and the call is synchronous; with IMCOM_MEM_DEVICE the
+ * work is enqueued on the context's stream (imcom_ctx_set_stream) and the call returns immediately
+ * (small per-stamp arrays named "host" below are always host pointers).  One context per GPU and
+ * caller thread; a context is not thread-safe.  There is NO CPU fallback anywhere in this library.
+ *
+ * All matrices are C-order (row-major) float64 unless stated.  N = selected input pixels of a
+ * stamp, m = n2f*n2f output pixels, nv = number of kappa nodes, n_out = target PSFs (1 per call
+ * here; the host mirror loops over n_out as the reference does, lakernel.py:165,291,349).
+ */
+#ifndef IMCOM_HIP_H
+#define IMCOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMCOM_HIP_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    IMCOM_OK = 0,
+    IMCOM_ERR_ARG = -1,         /* bad argument (null pointer, bad size, unaligned layout) */
+    IMCOM_ERR_HIP = -2,         /* a HIP runtime call failed (no device, launch failure, ...) */
+    IMCOM_ERR_NOMEM = -3,       /* device workspace allocation failed */
+    IMCOM_ERR_UNSUPPORTED = -4, /* valid request this build cannot serve */
+    IMCOM_ERR_NUMERIC = -5      /* non-finite input or a factorisation that cannot be repaired */
+} imcom_status;
+
+typedef enum { IMCOM_MEM_HOST = 0, IMCOM_MEM_DEVICE = 1 } imcom_memspace;
+
+typedef struct imcom_ctx imcom_ctx;
+
+/* ------------------------------------------------------------------ library / context --------- */
+int imcom_version(void);
+const char *imcom_last_error(void);
+int imcom_device_count(int *count);
+/* device: HIP device ordinal.  Creates the context's own stream; block->GPU farming uses one
+ * context per GPU (one process per GPU), no inter-GPU traffic (docs/run_README.rst:81-100). */
+int imcom_ctx_create(int device, imcom_ctx **ctx);
+int imcom_ctx_destroy(imcom_ctx *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work; NULL restores
+ * the context's own stream. */
+int imcom_ctx_set_stream(imcom_ctx *ctx, void *hip_stream);
+int imcom_ctx_sync(imcom_ctx *ctx);
+/* Bytes of device workspace currently held by the context (grows on demand, never inside a call
+ * whose sizes were seen before). */
+int imcom_ctx_workspace_bytes(imcom_ctx *ctx, size_t *bytes);
+/* Elapsed device milliseconds spent in the named kernel family since the last reset, measured with
+ * HIP events on the context's stream when profiling is enabled (bench.py's roofline leg).
+ * family: "solve_gemm", "chol_gemm", "chol_diag", "build_A", "build_B", "finalize", "epilogue",
+ *         "eigen", "lakernel1", ... ; launches receives the number of launches accumulated. */
+int imcom_ctx_profile_enable(imcom_ctx *ctx, int on);
+int imcom_ctx_profile_reset(imcom_ctx *ctx);
+int imcom_ctx_profile_get(imcom_ctx *ctx, const char *family, double *ms, long *launches);
+
+/* ------------------------------------------------------------------ native-routine seam --------
+ * Replaces furry_parakeet.pyimcom_croutines.* (imported at lakernel.py:41-47, psfutil.py:37-49),
+ * whose in-tree specification is routine.py.  Outputs are written in place; off-grid points of the
+ * scattered interpolators leave the output element untouched (routine.py:166-167, 231-232). */
+
+/* routine.py:29-122 iD5512C_getw: w[i*10 .. i*10+9] = the 10 taps for fh[i] (fh = frac - 1/2). */
+int imcom_d5512_getw(imcom_ctx *ctx, const double *fh, long n, double *w, int memspace);
+/* routine.py:125-181 iD5512C (sym=0) / 184-253 iD5512C_sym (sym=1; nout must be a square, only the
+ * upper triangle is interpolated and mirrored).  infunc[nlayer][ngy][ngx], fhatout[nlayer][nout]. */
+int imcom_interp_d5512(imcom_ctx *ctx, const double *infunc, int nlayer, int ngy, int ngx,
+                       const double *xpos, const double *ypos, long nout, double *fhatout, int sym,
+                       int memspace);
+/* routine.py:256-338 gridD5512C: infunc[ngy][ngx], xpos[npi][nxo], ypos[npi][nyo],
+ * fhatout[npi][nyo*nxo]; off-grid rows/columns contribute zero weight (306-323). */
+int imcom_grid_d5512(imcom_ctx *ctx, const double *infunc, int ngy, int ngx, const double *xpos,
+                     const double *ypos, long npi, int nxo, int nyo, double *fhatout, int memspace);
+/* routine.py:341-430 lakernel1: per-output-pixel geometric bisection on kappa.
+ * lam[n], mPhalf[m][n] -> kappa[m], Sigma[m], UC[m], T[m][n] (T still to be multiplied by Q^T). */
+int imcom_lakernel1(imcom_ctx *ctx, const double *lam, const double *mPhalf, long m, long n,
+                    double C, double targetleak, double kCmin, double kCmax, int nbis,
+                    double *kappa, double *Sigma, double *UC, double *T, double smax, int memspace);
+/* routine.py:487-588 build_reduced_T_wrap (with lsolve_sps 433-484 inside).
+ * Nflat[m*nv*nv], Dflat[m*nv], Eflat[m*nv*nv], kappa[nv] ascending -> out_*[m], out_w[m*nv]. */
+int imcom_build_reduced_T(imcom_ctx *ctx, const double *Nflat, const double *Dflat,
+                          const double *Eflat, const double *kappa, int nv, long m, double ucmin,
+                          double smax, double *out_kappa, double *out_Sigma, double *out_UC,
+                          double *out_w, int memspace);
+
+/* ------------------------------------------------------------------ LA-kernel seam --------------
+ * Replaces lakernel.CholKernel (lakernel.py:226-394) and lakernel.EigenKernel (141-223) behind the
+ * OutStamp.LAKERNEL registry (coadd.py:839-844, 1091-1093), batched over independent stamps.
+ *
+ *   batch        number of stamps
+ *   n[batch]     HOST array: input pixels per stamp (ragged batches allowed; n[s] == 0 gives the
+ *                lakernel.py:110-119 outputs UC=1, Sigma=0, kappa=1 and no T)
+ *   ldn          row stride (elements) and per-stamp extent of A: A[s] is at A + s*ldn*ldn, row i at
+ *                + i*ldn; likewise B rows / T rows are ldn long.  ldn >= max n.
+ *   m            output pixels per stamp
+ *   A            [batch][ldn][ldn] system matrices (only the leading n[s] x n[s] part is read;
+ *                never modified: coadd.py keeps using outst.sysmata when save_abc is set)
+ *   mBhalf       [batch][m][ldn]  -B/2 in the reference layout (lakernel.py:287)
+ *   C            [batch] HOST: target normalisation (psfutil.py:1290 outovlc)
+ *   kappaC[nv]   HOST: kappa/C nodes, ascending (config KAPPAC); nv==1 -> single-kappa path
+ *   T            [batch][m][ldn] float32 out (reference dtype, lakernel.py:122)
+ *   UC,Sigma,kappa [batch][m] float32 out
+ *   info[batch]  HOST out: 0 ok; >0 = the Cholesky repair of lakernel.py:262-279 was applied
+ *                (value = node index + 1 of the first repaired factorisation)
+ */
+int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A,
+                     const double *mBhalf, const double *C, const double *kappaC, int nv,
+                     double ucmin, double smax, float *T, float *UC, float *Sigma, float *kappa,
+                     int *info, int memspace);
+/* Same contract, eigendecomposition path; nv==1: lakernel.py:154-172, nv>1: 174-223 with nbis
+ * bisections (reference default 13) and the kappa *= C quirk of line 222. */
+int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A,
+                      const double *mBhalf, const double *C, const double *kappaC, int nv,
+                      double ucmin, double smax, int nbis, float *T, float *UC, float *Sigma,
+                      float *kappa, int *info, int memspace);
+/* Batched symmetric eigendecomposition used by the eigen path and by the Cholesky repair
+ * (replaces numpy.linalg.eigh at lakernel.py:162,201,266): lam ascending [batch][ldn],
+ * Q[batch][ldn][ldn] with eigenvectors in columns.  A is not modified. */
+int imcom_eigh(imcom_ctx *ctx, int batch, const int *n, int ldn, const double *A, double *lam,
+               double *Q, int memspace);
+
+/* ------------------------------------------------------------------ stamp / matrix seam ---------
+ * Device-resident replacement of PSFOvl._call_ii_self/_call_ii_cross (psfutil.py:1597-1732,
+ * 1401-1495) + OutStamp A assembly (coadd.py:1027-1068), PSFOvl._call_io_cross (1497-1595) +
+ * B assembly (coadd.py:1075-1082), and OutStamp._perform_coaddition (coadd.py:1294-1363).
+ * These take DEVICE pointers only (except arrays marked HOST). */
+
+/* Geometry shared by the table interpolations (PSFGrp.setup / PSFOvl.setup class attributes,
+ * psfutil.py:568-613, 1065-1089, carried explicitly instead of process-global state). */
+typedef struct {
+    int nsamp;           /* table side (PSFOvl.nsamp); tables are [nsamp][nsamp], UNPADDED: the
+                            6-pixel zero border of np.pad(...,6) is applied by the kernels */
+    double nc;           /* PSFOvl.nc, table centre */
+    double dscale;       /* PSFGrp.dscale: output pixels per table sample */
+    double flat_penalty; /* PSFOvl.flat_penalty */
+} imcom_table_geom;
+
+/* A[s][i][j] for i,j < n[s] (exactly symmetric: lower triangle interpolated, mirrored), with the
+ * padding rows/cols n[s] <= i < ldn set to the identity so the factorisation kernels can run on
+ * whole tiles.
+ *   x,y          [batch][ldn] input pixel positions in output-pixel units (coadd.py:969-972)
+ *   psf          [batch][ldn] int32: stamp-local PSF index of each pixel, < npsf_max
+ *   tables       [ntab][nsamp][nsamp] overlap tables (PSFOvl.ovl_arr entries)
+ *   pair_tab     [batch][npsf_max][npsf_max] int32: table of the ordered PSF pair (p_i,p_j);
+ *                t >= 0 -> tables[t]; t < 0 -> tables[-t-1] flipped in both axes (the np.flip of
+ *                psfutil.py:1658-1665)
+ *   pair_pen     [batch][npsf_max][npsf_max] constant added to every element of the pair's block:
+ *                -flat_penalty/n_in (+flat_penalty for the same exposure), psfutil.py:1482-1486,
+ *                1705-1708
+ */
+int imcom_build_A(imcom_ctx *ctx, int batch, const int *n_host, int ldn, const double *x,
+                  const double *y, const int *psf, const double *tables, int ntab,
+                  const imcom_table_geom *geom, const int *pair_tab, const double *pair_pen,
+                  int npsf_max, double *A);
+/* Bt[s][i][a] = -B/2 transposed (input-pixel-major, the native layout of gridD5512C's output,
+ * routine.py:273) for i < n[s], a < m = n2f*n2f; rows i >= n[s] and columns a >= m up to ldm are
+ * zero.  Output pixel a = iy*n2f + ix sits at (out_x0[s] + ix, out_y0[s] + iy) (coadd.py:879-882).
+ *   io_tab       [batch][npsf_max] int32: input-output overlap table of each stamp-local PSF
+ */
+int imcom_build_B(imcom_ctx *ctx, int batch, const int *n_host, int ldn, const double *x,
+                  const double *y, const int *psf, const double *tables, int ntab,
+                  const imcom_table_geom *geom, const int *io_tab, int npsf_max,
+                  const double *out_x0, const double *out_y0, int n2f, int ldm, double *Bt);
+/* Resident single/multi-kappa Cholesky solve on the layouts produced by imcom_build_A/_B:
+ * A[batch][ldn][ldn] (padding = identity), Bt[batch][ldn][ldm].  Outputs: Tt[batch][ldn][ldm]
+ * float32 (input-pixel-major), UC/Sigma/kappa [batch][m] float32.  Needs ldn, ldm multiples of 128. */
+int imcom_solve_chol_resident(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm,
+                              const double *A, const double *Bt, const double *C_host,
+                              const double *kappaC_host, int nv, double ucmin, double smax,
+                              float *Tt, float *UC, float *Sigma, float *kappa, int *info_host);
+/* coadd.py:1320-1354: fade taper of T (trapezoid, 1222-1292), per-exposure weight sums, Neff and
+ * outimage = T . indata.
+ *   Tt           [batch][ldn][ldm] float32 (tapered in place when fade > 0)
+ *   indata       [batch][n_inframe][ldn] float32 input pixel values (coadd.py:975)
+ *   expo         [batch][ldn] int32 exposure (input image) index of each pixel, < n_expo
+ *   outimage     [batch][n_inframe][m] float32
+ *   Tsum_stamp   [batch][n_expo] float64; Tsum_inpix, Neff [batch][m] float64 (numpy's result dtype)
+ */
+int imcom_coadd_epilogue(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm,
+                         int n2f, int fade, int n2, float *Tt, const float *indata, int n_inframe,
+                         const int *expo, int n_expo, float *outimage, double *Tsum_stamp,
+                         double *Tsum_inpix, double *Neff);
+/* OutStamp.trapezoid (coadd.py:1222-1292) on [batch][n2f][n2f] float32 maps (kappa, Sigma, UC). */
+int imcom_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fade);
+
+/* PSFGrp.accel_pad_and_rfft2 + PSFOvl._build_psfovl (psfutil.py:943-986, 1244-1294): correlation
+ * tables out[p][q] = irfft2(rft(psf1[p]) * conj(rft(psf2[q]))), rolled by nc and cropped to
+ * nsamp x nsamp.  psf1[n1][nsamp][nsamp], psf2[n2][nsamp][nsamp]; pairs[npairs][2] HOST lists the
+ * (p,q) wanted, tables[npairs][nsamp][nsamp]. */
+int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, const double *psf2, int n2,
+                      int nsamp, int nfft, const int *pairs_host, int npairs, double *tables);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMCOM_HIP_H */

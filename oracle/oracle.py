@@ -1,0 +1,501 @@
+"""CPU oracle for the IMCOM postage-stamp path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing
+under pyimcom_amd/ does.  It restates the reference's algorithm (file:line cited per function, paths
+relative to the reference's src/pyimcom/) in NumPy/SciPy (LAPACK potrf/potrs, syevd, pocketfft) plus the
+plain-C routines of oracle/imcom_oracle.c.
+
+Parity status: PINNED -- tests/test_oracle.py checks every function here against golden vectors
+produced by running the reference itself (tests/golden/make_golden.py).  The stamp-driver functions
+restated from coadd.py (select_pixels, assemble_*, trapezoid, perform_coaddition) could not be run in the
+build container (coadd.py needs asdf/astropy/fitsio at import); they are restated from the source text
+and pinned by hand-computed cases and by consistency with the pinned sub-block functions.
+"""
+
+import ctypes as C
+import os
+import subprocess
+from itertools import combinations
+
+import numpy as np
+from scipy.linalg import LinAlgError, cho_solve, cholesky
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile oracle/imcom_oracle.c with gcc (no FMA contraction)."""
+    src = os.path.join(_HERE, "imcom_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+def _c():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _req(a, writable=False):
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous, "need C-contiguous float64"
+    return a
+
+
+# ------------------------------------------------------------------------------------------------ IN-1..4
+def iD5512C_getw(w, fh):
+    """routine.py:29-122."""
+    _c().orc_d5512_getw(_p(_req(w)), C.c_double(fh))
+
+
+def iD5512C(infunc, xpos, ypos, fhatout):
+    """routine.py:125-181."""
+    nlayer, ngy, ngx = infunc.shape
+    _c().orc_interp_d5512(_p(_req(infunc)), nlayer, ngy, ngx, _p(_req(xpos)), _p(_req(ypos)), C.c_long(xpos.size),
+                          _p(_req(fhatout)))
+
+
+def iD5512C_sym(infunc, xpos, ypos, fhatout):
+    """routine.py:184-253."""
+    nlayer, ngy, ngx = infunc.shape
+    _c().orc_interp_d5512_sym(_p(_req(infunc)), nlayer, ngy, ngx, _p(_req(xpos)), _p(_req(ypos)),
+                              C.c_long(xpos.size), _p(_req(fhatout)))
+
+
+def gridD5512C(infunc, xpos, ypos, fhatout):
+    """routine.py:256-338."""
+    ngy, ngx = infunc.shape
+    npi, nxo = xpos.shape
+    nyo = ypos.shape[1]
+    _c().orc_grid_d5512(_p(_req(infunc)), ngy, ngx, _p(_req(xpos)), _p(_req(ypos)), C.c_long(npi), nxo, nyo,
+                        _p(_req(fhatout)))
+
+
+def lakernel1(lam, Q, mPhalf, C_, targetleak, kCmin, kCmax, nbis, kappa, Sigma, UC, T, smax):
+    """routine.py:341-430 (Q unused, as in the reference)."""
+    m, n = mPhalf.shape
+    d = C.c_double
+    _c().orc_lakernel1(_p(_req(lam)), _p(_req(mPhalf)), C.c_long(m), C.c_long(n), d(C_), d(targetleak), d(kCmin),
+                       d(kCmax), int(nbis), _p(_req(kappa)), _p(_req(Sigma)), _p(_req(UC)), _p(_req(T)), d(smax))
+
+
+def lsolve_sps(N, A, x, b):
+    """routine.py:433-484 (A is destroyed)."""
+    _c().orc_lsolve_sps(int(N), _p(_req(A)), _p(_req(x)), _p(_req(b)))
+
+
+def build_reduced_T_wrap(Nflat, Dflat, Eflat, kappa, ucmin, smax, out_kappa, out_Sigma, out_UC, out_w):
+    """routine.py:487-588."""
+    d = C.c_double
+    kappa = np.ascontiguousarray(kappa, dtype=np.float64)
+    _c().orc_build_reduced_T(_p(_req(Nflat)), _p(_req(Dflat)), _p(_req(Eflat)), _p(kappa), int(kappa.size),
+                             C.c_long(out_kappa.size), d(ucmin), d(smax), _p(_req(out_kappa)), _p(_req(out_Sigma)),
+                             _p(_req(out_UC)), _p(_req(out_w)))
+
+
+# ------------------------------------------------------------------------------------------------ CH / EI
+def cholesky_wrapper(AA, A):
+    """lakernel.py:241-279: lower Cholesky; on failure shift by |lambda_min(A)| + 1e-16, retry, restore.
+
+    Returns (L, repaired)."""
+    try:
+        return cholesky(AA, lower=True, check_finite=False), False
+    except LinAlgError:
+        w = np.linalg.eigvalsh(A)
+        di = np.diag_indices(A.shape[0])
+        AA[di] += np.abs(w[0]) + 1e-16
+        L = cholesky(AA, lower=True, check_finite=False)
+        AA[di] -= np.abs(w[0]) + 1e-16
+        return L, True
+
+
+def chol_kernel(A, mBhalf, C_, kappaC, ucmin, smax):
+    """lakernel.CholKernel for ONE target PSF: A [n,n], mBhalf [m,n], C_ scalar.
+
+    Single kappa: lakernel.py:281-323.  Multi kappa: 325-394.  Returns T f32 [m,n], UC, Sigma, kappa f32 [m],
+    info (0, or node+1 of the first repaired factorisation)."""
+    kappaC = np.atleast_1d(np.asarray(kappaC, dtype=np.float64))
+    nv = kappaC.size
+    m, n = mBhalf.shape
+    T = np.zeros((m, n), dtype=np.float32)
+    UC, Sigma, kappa = (np.zeros((m,), dtype=np.float32) for _ in range(3))
+    info = 0
+    if nv == 1:
+        AA = A.flatten()
+        my_kappa = kappaC[0] * C_
+        if my_kappa:
+            AA[:: n + 1] += my_kappa
+        AA = AA.reshape((n, n))
+        L, rep = cholesky_wrapper(AA, A)
+        info = 1 if rep else 0
+        Ti = cho_solve((L, True), mBhalf.T, check_finite=False).T
+        D = np.einsum("ai,ai->a", mBhalf, Ti)
+        N = np.einsum("ai,ai->a", Ti, Ti)
+        kappa[:] = my_kappa
+        Sigma[:] = N
+        UC[:] = 1.0 - (my_kappa * N + D) / C_
+        T[:, :] = Ti
+        return T, UC, Sigma, kappa, info
+    Tpi = np.zeros((nv, m, n))
+    AA = np.copy(A)
+    di = np.diag_indices(n)
+    kappa_arr = kappaC * C_
+    for j in range(nv):
+        AA[di] += kappa_arr[j] - (kappa_arr[j - 1] if j > 0 else 0)
+        L, rep = cholesky_wrapper(AA, A)
+        if rep and info == 0:
+            info = j + 1
+        Tpi[j] = cho_solve((L, True), mBhalf.T, check_finite=False).T
+    Dp = np.einsum("ai,pai->ap", mBhalf, Tpi)
+    Npq = np.einsum("pai,qai->apq", Tpi, Tpi)
+    Epq = np.zeros((m, nv, nv))
+    for p in range(nv):
+        for q in range(p):
+            Epq[:, q, p] = Epq[:, p, q] = Dp[:, q] - kappa_arr[p] * Npq[:, p, q]
+        Epq[:, p, p] = Dp[:, p] - kappa_arr[p] * Npq[:, p, p]
+    ok, oS, oU, ow = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros(m * nv)
+    build_reduced_T_wrap(Npq.flatten(), Dp.flatten() / C_, Epq.flatten() / C_, kappaC, ucmin, smax, ok, oS, oU, ow)
+    kappa[:] = ok * C_
+    Sigma[:] = oS
+    UC[:] = oU
+    T[:, :] = np.einsum("pai,ap->ai", Tpi, ow.reshape((m, nv)))
+    return T, UC, Sigma, kappa, info
+
+
+def eigen_kernel(A, mBhalf, C_, kappaC, ucmin, smax, nbis=13):
+    """lakernel.EigenKernel for ONE target PSF.  Single kappa 154-172; multi kappa 174-223 (incl. the
+    kappa *= C of line 222 on top of kCmin*C, kCmax*C passed at 213-214)."""
+    kappaC = np.atleast_1d(np.asarray(kappaC, dtype=np.float64))
+    m, n = mBhalf.shape
+    T = np.zeros((m, n), dtype=np.float32)
+    UC, Sigma, kappa = (np.zeros((m,), dtype=np.float32) for _ in range(3))
+    lam, Q = np.linalg.eigh(A)
+    mPhalf = mBhalf @ Q
+    if kappaC.size == 1:
+        k = kappaC[0] * C_
+        kappa[:] = k
+        Sigma[:] = np.sum((mPhalf / (lam + k)) ** 2, axis=1)
+        UC[:] = 1 - (lam + 2 * k) / (lam + k) ** 2 @ mPhalf.T**2 / C_
+        T[:, :] = mPhalf / (lam + k) @ Q.T
+        return T, UC, Sigma, kappa, 0
+    tt = np.zeros((m, n))
+    k64, S64, U64 = np.zeros(m), np.zeros(m), np.zeros(m)
+    lakernel1(lam, Q, np.ascontiguousarray(mPhalf), C_, ucmin, kappaC[0] * C_, kappaC[-1] * C_, nbis, k64, S64, U64,
+              tt, smax)
+    kappa[:] = k64  # float32 store, then *= C in float32 as lakernel.py:216-222 does
+    Sigma[:] = S64
+    UC[:] = U64
+    kappa *= C_
+    T[:, :] = tt @ Q.T
+    return T, UC, Sigma, kappa, 0
+
+
+def la_kernel(kind, A, mhalfb, outovlc, n2f, kappaC, ucmin, smax):
+    """_LAKernel.__call__ (lakernel.py:84-138) over n_out target PSFs, incl. the n == 0 case (110-119)."""
+    n_out, m, n = mhalfb.shape
+    shape = (n_out, n2f, n2f)
+    if n == 0:
+        return (np.zeros((n_out, m, 0), np.float32), np.ones(shape, np.float32), np.zeros(shape, np.float32),
+                np.ones(shape, np.float32))
+    fn = {"Cholesky": chol_kernel, "Eigen": eigen_kernel}[kind]
+    T = np.zeros((n_out, m, n), np.float32)
+    UC, Sigma, kappa = (np.zeros((n_out, m), np.float32) for _ in range(3))
+    for k in range(n_out):
+        T[k], UC[k], Sigma[k], kappa[k], _ = fn(A, mhalfb[k], outovlc[k], kappaC, ucmin, smax)
+    return T, UC.reshape(shape), Sigma.reshape(shape), kappa.reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------ PS-1..4
+class Geom:
+    """PSFGrp.setup / PSFOvl.setup constants (psfutil.py:568-613, 1065-1089), psfsplit off."""
+
+    def __init__(self, npixpsf=48, oversamp=8, dtheta_deg=0.025 / 3600, flat_penalty=1e-7):
+        self.oversamp = oversamp
+        self.nsamp = npixpsf * oversamp - 1
+        self.nc = self.nsamp // 2
+        self.nfft = npixpsf * oversamp * 2
+        arcsec = np.pi / 180.0 / 60.0 / 60.0  # config.py:85-98 (Settings.arcsec, pixscale_native = 0.11 arcsec)
+        self.dscale = ((0.11 * arcsec) / arcsec) / oversamp / (dtheta_deg * 3600)  # psfutil.py:610
+        self.flat_penalty = flat_penalty
+        self.yxo = np.mgrid[(1 - self.nsamp) / 2 : (self.nsamp - 1) / 2 : self.nsamp * 1j,
+                            (1 - self.nsamp) / 2 : (self.nsamp - 1) / 2 : self.nsamp * 1j]
+
+
+def pad_and_rfft2(psf_arr, g):
+    """PSFGrp.accel_pad_and_rfft2 (psfutil.py:943-986)."""
+    n_arr = psf_arr.shape[0]
+    pad_m1 = np.zeros((n_arr, g.nsamp, g.nfft))
+    pad_m2 = np.zeros((n_arr, g.nfft, g.nfft // 2 + 1), dtype=np.complex128)
+    pad_m1[:, :, : g.nsamp] = psf_arr
+    pad_m2[:, : g.nsamp, :] = np.fft.rfft(pad_m1, axis=-1)
+    return np.fft.fft(pad_m2, axis=-2)
+
+
+def irfft2_and_extract(ovl_rft, g):
+    """PSFOvl.accel_irfft2_and_extract, live branch (psfutil.py:1226-1227)."""
+    nc = g.nc
+    return np.roll(np.fft.irfft2(ovl_rft), nc, axis=(-2, -1))[..., : 2 * nc + 1, : 2 * nc + 1]
+
+
+def overlap_cross(rft1, rft2, g):
+    """PSFOvl._build_psfovl cross branch (psfutil.py:1259-1265): [n1, n2, nsamp, nsamp]."""
+    out = np.zeros((rft1.shape[0], rft2.shape[0], g.nsamp, g.nsamp))
+    for i in range(rft1.shape[0]):
+        out[i] = irfft2_and_extract(rft1[i] * rft2.conjugate(), g)
+    return out
+
+
+def tri_index(n_psf, i1, i2):
+    """PSFOvl._idx_square2triangle (psfutil.py:1139-1175)."""
+    assert i1 <= i2
+    return (2 * n_psf - i1 + 1) * i1 // 2 + i2 - i1
+
+
+def overlap_self(rft, g):
+    """input self-overlap branch (psfutil.py:1270-1278): triangle storage [n(n+1)/2, nsamp, nsamp]."""
+    n_psf = rft.shape[0]
+    out = np.zeros((n_psf * (n_psf + 1) // 2, g.nsamp, g.nsamp))
+    for i in range(n_psf):
+        start = tri_index(n_psf, i, i)
+        out[start : start + n_psf - i] = irfft2_and_extract(rft[i] * rft[i:].conjugate(), g)
+    return out
+
+
+def overlap_out_C(rft_out, g):
+    """output self-overlap -> C (psfutil.py:1283-1290)."""
+    ovl = irfft2_and_extract(rft_out * rft_out.conjugate(), g)
+    return ovl[:, g.nc, g.nc]
+
+
+def psf_gaussian(n, sigmax, sigmay):
+    """OutPSF.psf_gaussian (psfutil.py:117-146)."""
+    y, x = np.mgrid[(1 - n) / 2 / sigmay : (n - 1) / 2 / sigmay : n * 1j, (1 - n) / 2 / sigmax : (n - 1) / 2 / sigmax : n * 1j]
+    return np.exp(-0.5 * (np.square(x) + np.square(y))) / (2.0 * np.pi * sigmax * sigmay)
+
+
+def psf_simple_airy(n, ldp, obsc=0.0, tophat_conv=0.0, sigma=0.0):
+    """OutPSF.psf_simple_airy (psfutil.py:148-223)."""
+    from scipy.special import jv
+
+    kp = 1 + int(np.ceil(tophat_conv + 6 * sigma))
+    npad = n + 2 * kp
+    y, x = np.mgrid[(1 - npad) / 2 : (npad - 1) / 2 : npad * 1j, (1 - npad) / 2 : (npad - 1) / 2 : npad * 1j]
+    r = np.sqrt(np.square(x) + np.square(y)) / ldp
+    I_ = (np.square(jv(0, np.pi * r) + jv(2, np.pi * r) - obsc**2 * (jv(0, np.pi * r * obsc) + jv(2, np.pi * r * obsc)))
+          / (4.0 * ldp**2 * (1 - obsc**2)) * np.pi)
+    It = np.fft.rfft2(I_)
+    uxa = np.linspace(0, 1 - 1 / npad, npad)
+    uxa[-(npad // 2):] -= 1
+    ux = np.tile(uxa[None, : npad // 2 + 1], (npad, 1))
+    uy = np.tile(uxa[:, None], (1, npad // 2 + 1))
+    It *= (np.exp(-2.0 * np.pi**2 * (np.square(ux * sigma) + np.square(uy * sigma))) * np.sinc(ux * tophat_conv)
+           * np.sinc(uy * tophat_conv))
+    I_ = np.fft.irfft2(It, s=(npad, npad))
+    return I_[kp:-kp, kp:-kp]
+
+
+# ------------------------------------------------------------------------------------------------ PS-5/6
+def subblock_ii_self(ovl_tri, n_psf, g, x1, y1, cnt1, x2=None, y2=None, cnt2=None):
+    """PSFOvl._call_ii_self (psfutil.py:1597-1732).  cnt = pixels per exposure (pix_count); exposures index
+    the group's PSFs directly (idx_blk2grp = identity)."""
+    same = x2 is None
+    if same:
+        x2, y2, cnt2 = x1, y1, cnt1
+    cs1 = np.concatenate([[0], np.cumsum(cnt1)]).astype(int)
+    cs2 = np.concatenate([[0], np.cumsum(cnt2)]).astype(int)
+    res = np.zeros((cs1[-1], cs2[-1]))
+    ddx = x1[:, None] - x2[None, :]
+    ddy = y1[:, None] - y2[None, :]
+    ddx /= g.dscale
+    ddx += g.nc
+    ddy /= g.dscale
+    ddy += g.nc
+    for j in range(len(cnt1)):
+        if cnt1[j] == 0:
+            continue
+        for i in range(0 if not same else j, len(cnt2)):
+            if cnt2[i] == 0:
+                continue
+            tab = ovl_tri[tri_index(n_psf, j, i)] if j <= i else np.flip(ovl_tri[tri_index(n_psf, i, j)])
+            sl = np.s_[cs1[j] : cs1[j + 1], cs2[i] : cs2[i + 1]]
+            out = np.zeros((1, int(cnt1[j]) * int(cnt2[i])))
+            fn = iD5512C_sym if (same and j == i) else iD5512C
+            fn(np.ascontiguousarray(np.pad(tab, 6)).reshape((1, g.nsamp + 12, g.nsamp + 12)),
+               np.ascontiguousarray(ddx[sl].ravel() + 6), np.ascontiguousarray(ddy[sl].ravel() + 6), out)
+            res[sl] = out.reshape((int(cnt1[j]), int(cnt2[i])))
+            if g.flat_penalty != 0.0:
+                res[sl] -= g.flat_penalty / n_psf
+                if j == i:
+                    res[sl] += g.flat_penalty
+            if same and j < i:
+                res[cs2[i] : cs2[i + 1], cs1[j] : cs1[j + 1]] = res[sl].T
+    return res
+
+
+def subblock_ii_cross(ovl, g, x1, y1, cnt1, x2, y2, cnt2):
+    """PSFOvl._call_ii_cross (psfutil.py:1401-1495); ovl [n1, n2, nsamp, nsamp]."""
+    cs1 = np.concatenate([[0], np.cumsum(cnt1)]).astype(int)
+    cs2 = np.concatenate([[0], np.cumsum(cnt2)]).astype(int)
+    res = np.zeros((cs1[-1], cs2[-1]))
+    ddx = x1[:, None] - x2[None, :]
+    ddx /= g.dscale
+    ddx += g.nc
+    ddy = y1[:, None] - y2[None, :]
+    ddy /= g.dscale
+    ddy += g.nc
+    n_in = (ovl.shape[0] * ovl.shape[1]) ** 0.5
+    for j in range(len(cnt1)):
+        if cnt1[j] == 0:
+            continue
+        for i in range(len(cnt2)):
+            if cnt2[i] == 0:
+                continue
+            sl = np.s_[cs1[j] : cs1[j + 1], cs2[i] : cs2[i + 1]]
+            out = np.zeros((1, int(cnt1[j]) * int(cnt2[i])))
+            iD5512C(np.ascontiguousarray(np.pad(ovl[j, i], 6)).reshape((1, g.nsamp + 12, g.nsamp + 12)),
+                    np.ascontiguousarray(ddx[sl].ravel() + 6), np.ascontiguousarray(ddy[sl].ravel() + 6), out)
+            res[sl] = out.reshape((int(cnt1[j]), int(cnt2[i])))
+            if g.flat_penalty != 0.0:
+                res[sl] -= g.flat_penalty / n_in
+                if j == i:
+                    res[sl] += g.flat_penalty
+    return res
+
+
+def subblock_io(ovl_io, g, x_in, y_in, cnt, out_x, out_y, selection=None):
+    """PSFOvl._call_io_cross (psfutil.py:1497-1595); ovl_io [n_in, n_out, nsamp, nsamp];
+    out_x [nxo], out_y [nyo] output pixel coordinates -> res [n_out, nyo*nxo, n_sel]."""
+    cs = np.concatenate([[0], np.cumsum(cnt)]).astype(int)
+    if selection is not None:
+        x_in, y_in = x_in[selection], y_in[selection]
+        cs = np.searchsorted(selection, cs)
+    cnt_ = np.diff(cs)
+    n_outpix = out_x.size * out_y.size
+    res = np.zeros((ovl_io.shape[1], n_outpix, x_in.size))
+    ddx = x_in[:, None] - out_x[None, :]
+    ddx /= g.dscale
+    ddx += g.nc
+    ddy = y_in[:, None] - out_y[None, :]
+    ddy /= g.dscale
+    ddy += g.nc
+    for k in range(ovl_io.shape[1]):
+        for j in range(len(cnt)):
+            if cnt[j] == 0:
+                continue
+            out = np.zeros((int(cnt_[j]), n_outpix))
+            gridD5512C(np.ascontiguousarray(np.pad(ovl_io[j, k], 6)), np.ascontiguousarray(ddx[cs[j] : cs[j + 1], :] + 6),
+                       np.ascontiguousarray(ddy[cs[j] : cs[j + 1], :] + 6), out)
+            res[k, :, cs[j] : cs[j + 1]] = out.T
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ ST-1..4
+def trapezoid(arr, fade_kernel):
+    """OutStamp.trapezoid, default arguments (coadd.py:1222-1282), in place on (..., ny, nx)."""
+    fk2 = fade_kernel * 2
+    if not fk2 > 0:
+        return
+    ny, nx = arr.shape[-2:]
+    it, ir = ny - 1, nx - 1
+    s = np.arange(1, fk2 + 1, dtype=np.float64) / (fk2 + 1)
+    s -= np.sin(2 * np.pi * s) / (2 * np.pi)
+    sT = s[None, :].T
+    arr[..., 0:fk2, :] *= sT
+    arr[..., it : it - fk2 : -1, :] *= sT
+    arr[..., :, 0:fk2] *= s
+    arr[..., :, ir : ir - fk2 : -1] *= s
+
+
+def perform_coaddition(T, indata, expo, n_expo, n2f, n2, fade_kernel):
+    """OutStamp._perform_coaddition (coadd.py:1294-1354) for one stamp.
+
+    T f32 [n_out, m, N] (tapered in place), indata f32 [n_inframe, N], expo[N] = exposure of each pixel
+    (the my_cumsum bookkeeping of 1329-1337 sums T over the pixels of each exposure)."""
+    n_out, m, N = T.shape
+    if fade_kernel > 0:
+        T_view = np.moveaxis(T, 1, -1).reshape((n_out, N, n2f, n2f))
+        trapezoid(T_view, fade_kernel)
+    Tsum_image = np.zeros((n_out, m, n_expo))
+    for e in range(n_expo):
+        Tsum_image[:, :, e] += np.sum(T[:, :, expo == e], axis=2)
+    Tsum_stamp = np.sum(Tsum_image, axis=1) / n2**2
+    Tsum_inpix = np.sum(Tsum_image, axis=2).reshape((n_out, n2f, n2f))
+    Tsum_norm = Tsum_image / np.abs(Tsum_image).sum(axis=2)[:, :, None]
+    Neff = 1.0 / np.sum(np.square(Tsum_norm), axis=2).reshape((n_out, n2f, n2f))
+    if fade_kernel > 0:
+        trapezoid(Neff, fade_kernel)
+    outimage = np.einsum("oaj,ij->oia", T, indata).reshape((n_out, indata.shape[0], n2f, n2f))
+    return outimage, Tsum_stamp, Tsum_inpix, Neff
+
+
+def select_pixels(x, y, pivot, radius):
+    """InStamp.make_selection (coadd.py:716-749): indices with dist^2 < radius^2 from the pivot, or None."""
+    if pivot == (None, None) or radius is None:
+        return None
+    dist_sq = np.zeros(x.shape)
+    if pivot[0] is not None:
+        dist_sq += np.square(x - pivot[0])
+    if pivot[1] is not None:
+        dist_sq += np.square(y - pivot[1])
+    sel = np.where(dist_sq < radius**2)[0]
+    return sel if sel.shape[0] < x.shape[0] else None
+
+
+# ------------------------------------------------------------------------------------------------ stamp level
+def stamp_system(g, x, y, psf, tables_pad, pair_tab, pair_pen, io_tab, out_x0, out_y0, n2f):
+    """A and Bt of ONE stamp from the device-seam description (include/imcom_hip.h: imcom_build_A/_B):
+    element (i,j), i <= j, is the D5512 interpolation of the pair's table at ((x_i-x_j)/dscale+nc+6, ...),
+    mirrored -- which is what the pinned sub-block functions above produce block by block (the A assembly
+    of coadd.py:1027-1068 only copies and transposes sub-blocks)."""
+    from_pad = tables_pad
+    n = x.size
+    ng = from_pad.shape[-1]
+    A = np.zeros((n, n))
+    iu, ju = np.triu_indices(n)
+    code = pair_tab[psf[iu], psf[ju]]
+    pen = pair_pen[psf[iu], psf[ju]]
+    vals = np.zeros(iu.size)
+    for c in np.unique(code):
+        if c < 0:
+            continue
+        sel = np.where(code == c)[0]
+        swap, flip, tab = bool(c & (1 << 29)), bool(c & (1 << 30)), int(c & ((1 << 28) - 1))
+        a, b = (ju[sel], iu[sel]) if swap else (iu[sel], ju[sel])
+        ddx = x[a] - x[b]
+        ddx /= g.dscale
+        ddx += g.nc
+        ddy = y[a] - y[b]
+        ddy /= g.dscale
+        ddy += g.nc
+        t = from_pad[tab]
+        if flip:
+            t = np.ascontiguousarray(np.flip(t))
+        out = np.zeros((1, sel.size))
+        iD5512C(t.reshape((1, ng, ng)), np.ascontiguousarray(ddx + 6), np.ascontiguousarray(ddy + 6), out)
+        vals[sel] = out[0]
+    vals += pen
+    A[iu, ju] = vals
+    A[ju, iu] = vals
+    m = n2f * n2f
+    Bt = np.zeros((n, m))
+    ox = out_x0 + np.arange(n2f, dtype=np.float64)
+    oy = out_y0 + np.arange(n2f, dtype=np.float64)
+    for p in np.unique(psf):
+        sel = np.where(psf == p)[0]
+        ddx = x[sel, None] - ox[None, :]
+        ddx /= g.dscale
+        ddx += g.nc
+        ddy = y[sel, None] - oy[None, :]
+        ddy /= g.dscale
+        ddy += g.nc
+        out = np.zeros((sel.size, m))
+        gridD5512C(np.ascontiguousarray(from_pad[io_tab[p]]), np.ascontiguousarray(ddx + 6), np.ascontiguousarray(ddy + 6), out)
+        Bt[sel] = out
+    return A, Bt

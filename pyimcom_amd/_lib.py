@@ -1,0 +1,155 @@
+"""ctypes binding of libimcom_hip.so (the C-ABI declared in include/imcom_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object is missing or no
+gfx950 device is usable, importing this module or creating a context raises -- loudly.
+"""
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libimcom_hip.so")
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+PAIR_SWAP = 1 << 29  # build_A pair code bits (csrc/interp.hip)
+PAIR_FLIP = 1 << 30
+
+
+class ImcomError(RuntimeError):
+    """A libimcom_hip call returned a negative status."""
+
+    def __init__(self, status, msg):
+        super().__init__(f"libimcom_hip error {status}: {msg}")
+        self.status = status
+
+
+class TableGeom(C.Structure):
+    _fields_ = [("nsamp", C.c_int), ("nc", C.c_double), ("dscale", C.c_double), ("flat_penalty", C.c_double)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' at the repo root, or make -C pyimcom_amd/csrc). "
+            "pyimcom_amd has no CPU fallback."
+        )
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i, _l, _d = C.c_void_p, C.c_int, C.c_long, C.c_double
+_ip = C.POINTER(C.c_int)
+
+# name -> argtypes; every function returns int status except the two noted below
+SIGNATURES = {
+    "imcom_device_count": [_ip],
+    "imcom_ctx_create": [_i, C.POINTER(_vp)],
+    "imcom_ctx_destroy": [_vp],
+    "imcom_ctx_set_stream": [_vp, _vp],
+    "imcom_ctx_sync": [_vp],
+    "imcom_ctx_workspace_bytes": [_vp, C.POINTER(C.c_size_t)],
+    "imcom_ctx_profile_enable": [_vp, _i],
+    "imcom_ctx_profile_reset": [_vp],
+    "imcom_ctx_profile_get": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_l)],
+    "imcom_d5512_getw": [_vp, _vp, _l, _vp, _i],
+    "imcom_interp_d5512": [_vp, _vp, _i, _i, _i, _vp, _vp, _l, _vp, _i, _i],
+    "imcom_grid_d5512": [_vp, _vp, _i, _i, _vp, _vp, _l, _i, _i, _vp, _i],
+    "imcom_lakernel1": [_vp, _vp, _vp, _l, _l, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _d, _i],
+    "imcom_build_reduced_T": [_vp, _vp, _vp, _vp, _vp, _i, _l, _d, _d, _vp, _vp, _vp, _vp, _i],
+    "imcom_solve_chol": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i],
+    "imcom_solve_eigen": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _i],
+    "imcom_eigh": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i],
+    "imcom_build_A": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(TableGeom), _vp, _vp, _i, _vp],
+    "imcom_build_B": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(TableGeom), _vp, _i, _vp, _vp, _i, _i, _vp],
+    "imcom_solve_chol_resident": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp],
+    "imcom_coadd_epilogue": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "imcom_trapezoid_f32": [_vp, _vp, _l, _i, _i],
+    "imcom_psf_overlap": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
+}
+for _name, _args in SIGNATURES.items():
+    _f = getattr(lib, _name)
+    _f.argtypes = _args
+    _f.restype = C.c_int
+lib.imcom_version.argtypes = []
+lib.imcom_version.restype = C.c_int
+lib.imcom_last_error.argtypes = []
+lib.imcom_last_error.restype = C.c_char_p
+
+EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_last_error"])
+
+
+def check(status):
+    if status != 0:
+        raise ImcomError(status, lib.imcom_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    st = lib.imcom_device_count(C.byref(n))
+    return n.value if st == 0 else 0
+
+
+class Context:
+    """One libimcom context = one GPU + one stream + one workspace (not thread-safe)."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        check(lib.imcom_ctx_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise ImcomError(-1, "context already destroyed")
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        check(lib.imcom_ctx_set_stream(self.handle, _vp(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        check(lib.imcom_ctx_sync(self.handle))
+
+    def workspace_bytes(self):
+        b = C.c_size_t(0)
+        check(lib.imcom_ctx_workspace_bytes(self.handle, C.byref(b)))
+        return b.value
+
+    def profile_enable(self, on=True):
+        check(lib.imcom_ctx_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        check(lib.imcom_ctx_profile_reset(self.handle))
+
+    def profile_get(self, family):
+        ms, n = _d(0.0), _l(0)
+        check(lib.imcom_ctx_profile_get(self.handle, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib.imcom_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+_lock = threading.Lock()
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use; raises without a usable gfx950)."""
+    with _lock:
+        ctx = _default.get(device)
+        if ctx is None:
+            ctx = _default[device] = Context(device)
+        return ctx

@@ -1,0 +1,610 @@
+// api.hip -- extern "C" entry points of libimcom_hip.so (see include/imcom_hip.h) and the host-side
+// orchestration of the batched blocked Cholesky solve.
+#include <cmath>
+#include <cstdlib>
+
+#include "common.h"
+#include "launchers.h"
+
+namespace imcom {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ws_reserve(imcom_ctx *ctx, size_t bytes)
+{
+    ctx->ws_used = 0;
+    if (bytes <= ctx->ws_bytes) return IMCOM_OK;
+    if (ctx->ws) {
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        IMCOM_HIP_CHECK(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    const size_t want = align_up(bytes + (bytes >> 3), (size_t)1 << 21);
+    hipError_t e = hipMalloc((void **)&ctx->ws, want);
+    if (e != hipSuccess) {
+        set_error("device workspace of %zu bytes: %s", want, hipGetErrorString(e));
+        return IMCOM_ERR_NOMEM;
+    }
+    ctx->ws_bytes = want;
+    return IMCOM_OK;
+}
+
+void *ws_take(imcom_ctx *ctx, size_t bytes)
+{
+    const size_t off = align_up(ctx->ws_used, 256);
+    if (off + bytes > ctx->ws_bytes) return nullptr;  // callers reserve the exact total first
+    ctx->ws_used = off + bytes;
+    return ctx->ws + off;
+}
+
+struct WsPlan {
+    size_t total = 0;
+    size_t add(size_t bytes) { total = align_up(total, 256) + bytes; return total; }
+};
+
+ProfScope::ProfScope(imcom_ctx *c, const char *fam, long n) : ctx(c), family(fam), launches(n)
+{
+    if (!ctx->profile) return;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+        else hipEventCreate(&e);
+        return e;
+    };
+    start = get();
+    stop = get();
+    hipEventRecord(start, ctx->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!ctx->profile || !start) return;
+    hipEventRecord(stop, ctx->stream);
+    ctx->pending.push_back({family, start, stop, launches});
+}
+
+int profile_collect(imcom_ctx *ctx)
+{
+    if (ctx->pending.empty()) return IMCOM_OK;
+    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        IMCOM_HIP_CHECK(hipEventElapsedTime(&ms, p.start, p.stop));
+        auto &slot = ctx->prof[p.family];
+        slot.ms += ms;
+        slot.launches += p.launches;
+        ctx->event_pool.push_back(p.start);
+        ctx->event_pool.push_back(p.stop);
+    }
+    ctx->pending.clear();
+    return IMCOM_OK;
+}
+
+int pin_reserve(imcom_ctx *ctx, size_t bytes)
+{
+    if (ctx->pin && bytes <= ctx->pin_bytes) return IMCOM_OK;
+    if (ctx->pin) { IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); IMCOM_HIP_CHECK(hipHostFree(ctx->pin)); ctx->pin = nullptr; }
+    IMCOM_HIP_CHECK(hipHostMalloc((void **)&ctx->pin, bytes, hipHostMallocDefault));
+    ctx->pin_bytes = bytes;
+    ctx->pin_used = 0;
+    return IMCOM_OK;
+}
+
+// Small host arrays go through a pinned ring so the async copy never reads caller memory after the
+// call returned; the stream is drained when the ring wraps.
+template <typename T>
+static int upload(imcom_ctx *ctx, T *dst, const T *src_host, size_t count)
+{
+    if (count == 0) return IMCOM_OK;
+    const size_t bytes = count * sizeof(T);
+    if (!ctx->pin) IMCOM_TRY(pin_reserve(ctx, (size_t)4 << 20));
+    if (bytes > ctx->pin_bytes / 4) {  // large: plain synchronous copy
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        IMCOM_HIP_CHECK(hipMemcpy(dst, src_host, bytes, hipMemcpyHostToDevice));
+        return IMCOM_OK;
+    }
+    size_t off = align_up(ctx->pin_used, 64);
+    if (off + bytes > ctx->pin_bytes) {
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        off = 0;
+    }
+    memcpy(ctx->pin + off, src_host, bytes);
+    ctx->pin_used = off + bytes;
+    IMCOM_HIP_CHECK(hipMemcpyAsync(dst, ctx->pin + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return IMCOM_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Batched blocked Cholesky solve on padded, device-resident operands.
+//   A  [batch][Np][Np]   identity-padded, never modified
+//   Bt [batch][Np][mp]   input-pixel-major -B/2, zero padded
+// Produces Tt (float32 [batch][Np][mp]) and the per-pixel maps.
+static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
+{
+    WsPlan p;
+    const size_t nb = Np / NB;
+    p.add((size_t)batch * Np * Np * 8);          // L
+    p.add((size_t)batch * nb * NB * NB * 8);     // Dinv
+    p.add((size_t)nv * batch * Np * mp * 8);     // Y / X per node
+    p.add((size_t)batch * Np * 8);               // dshift
+    p.add((size_t)batch * 4 * 4);                // n, nblk, fail, ninc
+    p.add((size_t)batch * MAX_INC_HOST * 8);     // inc
+    p.add((size_t)batch * 8 * 2);                // kap, C
+    p.add((size_t)nv * 8);                       // kappaC
+    if (nv > 1) {
+        p.add((size_t)batch * m * nv * 8);       // Dp
+        p.add((size_t)batch * m * nv * nv * 8);  // Npq
+        p.add((size_t)batch * m * nv * 8);       // W
+    }
+    return p.total + 4096;
+}
+
+static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m, int mp, const double *A,
+                     const double *Bt, const double *C_host, const double *kappaC_host, int nv, double ucmin,
+                     double smax, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host)
+{
+    const int nbmax_all = Np / NB;
+    double *L = (double *)ws_take(ctx, (size_t)batch * Np * Np * 8);
+    double *Dinv = (double *)ws_take(ctx, (size_t)batch * nbmax_all * NB * NB * 8);
+    const long node_stride = (long)batch * Np * mp;
+    double *Y = (double *)ws_take(ctx, (size_t)nv * node_stride * 8);
+    double *dshift = (double *)ws_take(ctx, (size_t)batch * Np * 8);
+    int *ints = (int *)ws_take(ctx, (size_t)batch * 4 * 4);
+    double *inc = (double *)ws_take(ctx, (size_t)batch * MAX_INC_HOST * 8);
+    double *dbl = (double *)ws_take(ctx, (size_t)batch * 8 * 2);
+    double *kappaC_dev = (double *)ws_take(ctx, (size_t)nv * 8);
+    double *Dp = nullptr, *Npq = nullptr, *W = nullptr;
+    if (nv > 1) {
+        Dp = (double *)ws_take(ctx, (size_t)batch * m * nv * 8);
+        Npq = (double *)ws_take(ctx, (size_t)batch * m * nv * nv * 8);
+        W = (double *)ws_take(ctx, (size_t)batch * m * nv * 8);
+    }
+    if (!L || !Dinv || !Y || !dshift || !ints || !inc || !dbl || !kappaC_dev || (nv > 1 && (!Dp || !Npq || !W))) {
+        set_error("internal: workspace plan too small");
+        return IMCOM_ERR_NOMEM;
+    }
+    int *n_dev = ints, *nblk_dev = ints + batch, *fail_dev = ints + 2 * batch, *ninc_dev = ints + 3 * batch;
+    double *kap_dev = dbl, *C_dev = dbl + batch;
+
+    std::vector<int> nblk(batch), ninc(batch, 0);
+    std::vector<double> inc_h((size_t)batch * MAX_INC_HOST, 0.0), kap_h(batch);
+    int nbmax = 0;
+    for (int s = 0; s < batch; s++) {
+        IMCOM_REQUIRE(n_host[s] >= 0 && n_host[s] <= Np, "n[%d]=%d outside [0,%d]", s, n_host[s], Np);
+        nblk[s] = (n_host[s] + NB - 1) / NB;
+        if (nblk[s] > nbmax) nbmax = nblk[s];
+        info_host[s] = 0;
+    }
+    IMCOM_TRY(upload(ctx, n_dev, n_host, batch));
+    IMCOM_TRY(upload(ctx, nblk_dev, nblk.data(), batch));
+    IMCOM_TRY(upload(ctx, C_dev, C_host, batch));
+    IMCOM_TRY(upload(ctx, kappaC_dev, kappaC_host, nv));
+    IMCOM_HIP_CHECK(hipMemsetAsync(fail_dev, 0, (size_t)batch * 4, ctx->stream));
+
+    for (int p = 0; p < nv; p++) {
+        // diagonal increments applied so far, in the reference's order (lakernel.py:298 / 356)
+        for (int s = 0; s < batch; s++) {
+            const double kp = kappaC_host[p] * C_host[s];
+            double *ih = &inc_h[(size_t)s * MAX_INC_HOST];
+            if (nv == 1) { ih[0] = kp; ninc[s] = (kp != 0.0) ? 1 : 0; }
+            else {
+                const double prev = (p > 0) ? kappaC_host[p - 1] * C_host[s] : 0.0;
+                IMCOM_REQUIRE(ninc[s] < MAX_INC_HOST, "too many diagonal increments");
+                ih[ninc[s]++] = kp - prev;
+            }
+            kap_h[s] = kp;
+        }
+        IMCOM_TRY(upload(ctx, inc, inc_h.data(), inc_h.size()));
+        IMCOM_TRY(upload(ctx, ninc_dev, ninc.data(), batch));
+        IMCOM_TRY(upload(ctx, kap_dev, kap_h.data(), batch));
+        IMCOM_TRY(launch_diag_shift(ctx, A, Np, inc, ninc_dev, dshift, batch));
+
+        for (int k = 0; k < nbmax; k++) {
+            { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_update(ctx, A, L, Np, k, nbmax, batch, nblk_dev, dshift)); }
+            { ProfScope ps(ctx, "chol_diag"); IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, batch, nblk_dev, fail_dev)); }
+            { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, batch, nblk_dev)); }
+        }
+        double *Yp = Y + p * node_stride;
+        for (int k = 0; k < nbmax; k++) {
+            { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, batch, nblk_dev)); }
+            { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, false)); }
+        }
+        for (int k = nbmax - 1; k >= 0; k--) {
+            if (k < nbmax - 1) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, batch, nblk_dev)); }
+            { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, true)); }
+        }
+    }
+    {
+        ProfScope ps(ctx, "finalize");
+        if (nv == 1)
+            IMCOM_TRY(launch_finalize_single(ctx, Y, Bt, Np, mp, m, n_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch));
+        else
+            IMCOM_TRY(launch_multi(ctx, Y, node_stride, Bt, Np, mp, m, n_dev, nv, kappaC_dev, C_dev, ucmin, smax, Dp, Npq, W, Tt, UC, Sigma, kappa, batch));
+    }
+    std::vector<int> fail(batch);
+    IMCOM_HIP_CHECK(hipMemcpyAsync(fail.data(), fail_dev, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < batch; s++)
+        if (fail[s] != 0) {
+            set_error("stamp %d: A + kappa I is not positive definite (pivot %d); the lakernel.py:262-279 repair "
+                      "needs imcom_eigh, which this build does not provide yet", s, fail[s]);
+            return IMCOM_ERR_NUMERIC;
+        }
+    return IMCOM_OK;
+}
+
+static int check_ctx(imcom_ctx *ctx)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { set_error("hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e)); return IMCOM_ERR_HIP; }
+    return IMCOM_OK;
+}
+
+// staging helper: device view of a caller buffer (copy in when host)
+struct Staged {
+    void *dev = nullptr;
+};
+
+}  // namespace imcom
+
+using namespace imcom;
+
+extern "C" {
+
+int imcom_version(void) { return IMCOM_HIP_VERSION; }
+
+const char *imcom_last_error(void) { return g_err; }
+
+int imcom_device_count(int *count)
+{
+    IMCOM_REQUIRE(count, "null count");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return IMCOM_ERR_HIP; }
+    *count = c;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_create(int device, imcom_ctx **out)
+{
+    IMCOM_REQUIRE(out, "null ctx pointer");
+    *out = nullptr;
+    int c = 0;
+    IMCOM_HIP_CHECK(hipGetDeviceCount(&c));
+    IMCOM_REQUIRE(device >= 0 && device < c, "device %d out of range (have %d)", device, c);
+    IMCOM_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    IMCOM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libimcom_hip is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return IMCOM_ERR_UNSUPPORTED;
+    }
+    imcom_ctx *ctx = new imcom_ctx();
+    ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount;
+    IMCOM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_destroy(imcom_ctx *ctx)
+{
+    if (!ctx) return IMCOM_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->pending) { hipEventDestroy(p.start); hipEventDestroy(p.stop); }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->pin) hipHostFree(ctx->pin);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_set_stream(imcom_ctx *ctx, void *hip_stream)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_sync(imcom_ctx *ctx)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+int imcom_ctx_workspace_bytes(imcom_ctx *ctx, size_t *bytes)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(bytes, "null bytes");
+    *bytes = ctx->ws_bytes;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_profile_enable(imcom_ctx *ctx, int on)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_TRY(profile_collect(ctx));
+    ctx->profile = on != 0;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_profile_reset(imcom_ctx *ctx)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_TRY(profile_collect(ctx));
+    ctx->prof.clear();
+    return IMCOM_OK;
+}
+
+int imcom_ctx_profile_get(imcom_ctx *ctx, const char *family, double *ms, long *launches)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(family && ms && launches, "null argument");
+    IMCOM_TRY(profile_collect(ctx));
+    auto it = ctx->prof.find(family);
+    *ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return IMCOM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// native-routine seam: host pointers are staged through the workspace; device pointers used as is.
+#define IMCOM_STAGE_IN(T, name, src, count)                                                   \
+    T *name = (T *)(src);                                                                     \
+    if (host) {                                                                               \
+        name = (T *)ws_take(ctx, (size_t)(count) * sizeof(T));                                \
+        if (!name) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; } \
+        IMCOM_HIP_CHECK(hipMemcpyAsync(name, src, (size_t)(count) * sizeof(T), hipMemcpyHostToDevice, ctx->stream)); \
+    }
+#define IMCOM_STAGE_OUT(T, name, dst, count)                                                  \
+    if (host) {                                                                               \
+        IMCOM_HIP_CHECK(hipMemcpyAsync(dst, name, (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost, ctx->stream)); \
+    }
+
+int imcom_d5512_getw(imcom_ctx *ctx, const double *fh, long n, double *w, int memspace)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(n >= 0 && (n == 0 || (fh && w)), "bad arguments");
+    if (n == 0) return IMCOM_OK;
+    const bool host = memspace == IMCOM_MEM_HOST;
+    if (host) IMCOM_TRY(ws_reserve(ctx, (size_t)n * 11 * 8 + 1024));
+    IMCOM_STAGE_IN(double, fh_d, fh, n);
+    IMCOM_STAGE_IN(double, w_d, w, n * 10);
+    IMCOM_TRY(launch_getw(ctx, fh_d, n, w_d));
+    IMCOM_STAGE_OUT(double, w_d, w, n * 10);
+    if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+int imcom_interp_d5512(imcom_ctx *ctx, const double *infunc, int nlayer, int ngy, int ngx, const double *xpos,
+                       const double *ypos, long nout, double *fhatout, int sym, int memspace)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(infunc && xpos && ypos && fhatout, "null pointer");
+    IMCOM_REQUIRE(nlayer >= 1 && ngy >= 1 && ngx >= 1 && nout >= 0, "bad sizes");
+    if (sym) {
+        long sq = (long)sqrt((double)(nout + 1));
+        IMCOM_REQUIRE(sq * sq <= nout, "iD5512C_sym: nout=%ld smaller than its square side^2", nout);
+    }
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const size_t ntab = (size_t)nlayer * ngy * ngx, no = (size_t)nlayer * nout;
+    if (host) IMCOM_TRY(ws_reserve(ctx, (ntab + 2 * (size_t)nout + no) * 8 + 4096));
+    IMCOM_STAGE_IN(double, f_d, infunc, ntab);
+    IMCOM_STAGE_IN(double, x_d, xpos, nout);
+    IMCOM_STAGE_IN(double, y_d, ypos, nout);
+    IMCOM_STAGE_IN(double, o_d, fhatout, no);  // in-place semantics: untouched elements keep their values
+    { ProfScope ps(ctx, "interp"); IMCOM_TRY(launch_interp(ctx, f_d, nlayer, ngy, ngx, x_d, y_d, nout, o_d, sym)); }
+    IMCOM_STAGE_OUT(double, o_d, fhatout, no);
+    if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+int imcom_grid_d5512(imcom_ctx *ctx, const double *infunc, int ngy, int ngx, const double *xpos, const double *ypos,
+                     long npi, int nxo, int nyo, double *fhatout, int memspace)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(infunc && xpos && ypos && fhatout, "null pointer");
+    IMCOM_REQUIRE(ngy >= 10 && ngx >= 10 && npi >= 0 && nxo >= 1 && nyo >= 1, "bad sizes");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const size_t ntab = (size_t)ngy * ngx, no = (size_t)npi * nxo * nyo;
+    if (host) IMCOM_TRY(ws_reserve(ctx, (ntab + (size_t)npi * (nxo + nyo) + no) * 8 + 4096));
+    IMCOM_STAGE_IN(double, f_d, infunc, ntab);
+    IMCOM_STAGE_IN(double, x_d, xpos, (size_t)npi * nxo);
+    IMCOM_STAGE_IN(double, y_d, ypos, (size_t)npi * nyo);
+    double *o_d = fhatout;
+    if (host) { o_d = (double *)ws_take(ctx, no * 8); if (!o_d) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; } }
+    { ProfScope ps(ctx, "interp"); IMCOM_TRY(launch_grid(ctx, f_d, ngy, ngx, x_d, y_d, npi, nxo, nyo, o_d)); }
+    IMCOM_STAGE_OUT(double, o_d, fhatout, no);
+    if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+int imcom_lakernel1(imcom_ctx *ctx, const double *lam, const double *mPhalf, long m, long n, double C, double targetleak,
+                    double kCmin, double kCmax, int nbis, double *kappa, double *Sigma, double *UC, double *T, double smax,
+                    int memspace)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(lam && mPhalf && kappa && Sigma && UC && T, "null pointer");
+    IMCOM_REQUIRE(m >= 0 && n >= 0 && nbis >= 0, "bad sizes");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    if (host) IMCOM_TRY(ws_reserve(ctx, ((size_t)n + 2 * (size_t)m * n + 3 * (size_t)m) * 8 + 8192));
+    IMCOM_STAGE_IN(double, lam_d, lam, n);
+    IMCOM_STAGE_IN(double, p_d, mPhalf, (size_t)m * n);
+    double *k_d = kappa, *S_d = Sigma, *U_d = UC, *T_d = T;
+    if (host) {
+        k_d = (double *)ws_take(ctx, (size_t)m * 8); S_d = (double *)ws_take(ctx, (size_t)m * 8);
+        U_d = (double *)ws_take(ctx, (size_t)m * 8); T_d = (double *)ws_take(ctx, (size_t)m * n * 8);
+        if (!k_d || !S_d || !U_d || !T_d) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    }
+    { ProfScope ps(ctx, "lakernel1"); IMCOM_TRY(launch_lakernel1(ctx, lam_d, p_d, m, n, n, C, targetleak, kCmin, kCmax, nbis, k_d, S_d, U_d, T_d, n, smax)); }
+    IMCOM_STAGE_OUT(double, k_d, kappa, m);
+    IMCOM_STAGE_OUT(double, S_d, Sigma, m);
+    IMCOM_STAGE_OUT(double, U_d, UC, m);
+    IMCOM_STAGE_OUT(double, T_d, T, (size_t)m * n);
+    if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+int imcom_build_reduced_T(imcom_ctx *ctx, const double *Nflat, const double *Dflat, const double *Eflat, const double *kappa,
+                          int nv, long m, double ucmin, double smax, double *out_kappa, double *out_Sigma, double *out_UC,
+                          double *out_w, int memspace)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(Nflat && Dflat && Eflat && kappa && out_kappa && out_Sigma && out_UC && out_w, "null pointer");
+    IMCOM_REQUIRE(m >= 0 && nv >= 2, "bad sizes (nv must be >= 2, routine.py:537)");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const size_t nv2 = (size_t)nv * nv;
+    if (host) IMCOM_TRY(ws_reserve(ctx, ((size_t)m * (2 * nv2 + 2 * nv + 3) + nv) * 8 + 8192));
+    IMCOM_STAGE_IN(double, N_d, Nflat, (size_t)m * nv2);
+    IMCOM_STAGE_IN(double, D_d, Dflat, (size_t)m * nv);
+    IMCOM_STAGE_IN(double, E_d, Eflat, (size_t)m * nv2);
+    IMCOM_STAGE_IN(double, k_d, kappa, nv);
+    double *ok = out_kappa, *oS = out_Sigma, *oU = out_UC, *ow = out_w;
+    if (host) {
+        ok = (double *)ws_take(ctx, (size_t)m * 8); oS = (double *)ws_take(ctx, (size_t)m * 8);
+        oU = (double *)ws_take(ctx, (size_t)m * 8); ow = (double *)ws_take(ctx, (size_t)m * nv * 8);
+        if (!ok || !oS || !oU || !ow) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    }
+    { ProfScope ps(ctx, "reduced_T"); IMCOM_TRY(launch_build_reduced_T(ctx, N_d, D_d, E_d, k_d, nv, m, ucmin, smax, ok, oS, oU, ow)); }
+    IMCOM_STAGE_OUT(double, ok, out_kappa, m);
+    IMCOM_STAGE_OUT(double, oS, out_Sigma, m);
+    IMCOM_STAGE_OUT(double, oU, out_UC, m);
+    IMCOM_STAGE_OUT(double, ow, out_w, (size_t)m * nv);
+    if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A, const double *mBhalf,
+                     const double *C, const double *kappaC, int nv, double ucmin, double smax, float *T, float *UC,
+                     float *Sigma, float *kappa, int *info, int memspace)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n && C && kappaC && UC && Sigma && kappa && info, "null pointer / empty batch");
+    IMCOM_REQUIRE(m >= 1 && nv >= 1 && ldn >= 0, "bad sizes");
+    int nmax = 0;
+    for (int s = 0; s < batch; s++) {
+        IMCOM_REQUIRE(n[s] >= 0 && n[s] <= ldn, "n[%d]=%d exceeds ldn=%d", s, n[s], ldn);
+        if (n[s] > nmax) nmax = n[s];
+    }
+    IMCOM_REQUIRE(nmax == 0 || (A && mBhalf && T), "null matrix pointer");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const int Np = (int)align_up((size_t)(nmax > 0 ? nmax : 1), NB), mp = (int)align_up((size_t)m, NB);
+    const size_t szA = (size_t)batch * ldn * ldn, szB = (size_t)batch * m * ldn, szM = (size_t)batch * m;
+    WsPlan plan;
+    if (host) { plan.add(szA * 8); plan.add(szB * 8); plan.add(szB * 4); plan.add(szM * 4 * 3); }
+    plan.add((size_t)batch * Np * Np * 8);  // Ap
+    plan.add((size_t)batch * Np * mp * 8);  // Bt
+    plan.add((size_t)batch * Np * mp * 4);  // Tt
+    plan.add((size_t)batch * 4);            // n
+    IMCOM_TRY(ws_reserve(ctx, plan.total + chol_core_bytes(batch, Np, m, mp, nv) + 8192));
+    IMCOM_STAGE_IN(double, A_d, A, szA);
+    IMCOM_STAGE_IN(double, B_d, mBhalf, szB);
+    float *T_d = T, *UC_d = UC, *Sig_d = Sigma, *kap_d = kappa;
+    if (host) {
+        T_d = (float *)ws_take(ctx, szB * 4);
+        UC_d = (float *)ws_take(ctx, szM * 4 * 3);
+        Sig_d = UC_d + szM;
+        kap_d = Sig_d + szM;
+    }
+    double *Ap = (double *)ws_take(ctx, (size_t)batch * Np * Np * 8);
+    double *Bt = (double *)ws_take(ctx, (size_t)batch * Np * mp * 8);
+    float *Tt = (float *)ws_take(ctx, (size_t)batch * Np * mp * 4);
+    int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
+    if (!Ap || !Bt || !Tt || !n_dev || (host && (!T_d || !UC_d))) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    IMCOM_TRY(upload(ctx, n_dev, n, batch));
+    {
+        ProfScope ps(ctx, "pack");
+        IMCOM_TRY(launch_pack_A(ctx, A_d, ldn, n_dev, Ap, Np, batch));
+        IMCOM_TRY(launch_pack_Bt(ctx, B_d, ldn, m, n_dev, Bt, Np, mp, batch));
+    }
+    IMCOM_TRY(chol_core(ctx, batch, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info));
+    if (ldn > 0) { ProfScope ps(ctx, "pack"); IMCOM_TRY(launch_unpack_T(ctx, Tt, Np, mp, n_dev, m, T_d, ldn, batch)); }
+    IMCOM_STAGE_OUT(float, T_d, T, szB);
+    IMCOM_STAGE_OUT(float, UC_d, UC, szM);
+    IMCOM_STAGE_OUT(float, Sig_d, Sigma, szM);
+    IMCOM_STAGE_OUT(float, kap_d, kappa, szM);
+    if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+int imcom_solve_chol_resident(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm, const double *A,
+                              const double *Bt, const double *C_host, const double *kappaC_host, int nv, double ucmin,
+                              double smax, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n_host && A && Bt && C_host && kappaC_host && Tt && UC && Sigma && kappa && info_host, "null pointer");
+    IMCOM_REQUIRE(ldn >= NB && ldn % NB == 0 && ldm % NB == 0 && m >= 1 && m <= ldm && nv >= 1, "ldn=%d / ldm=%d must be multiples of %d", ldn, ldm, NB);
+    IMCOM_TRY(ws_reserve(ctx, chol_core_bytes(batch, ldn, m, ldm, nv)));
+    return chol_core(ctx, batch, n_host, ldn, m, ldm, A, Bt, C_host, kappaC_host, nv, ucmin, smax, Tt, UC, Sigma, kappa, info_host);
+}
+
+// ---------------------------------------------------------------------------------------------
+int imcom_build_A(imcom_ctx *ctx, int batch, const int *n_host, int ldn, const double *x, const double *y, const int *psf,
+                  const double *tables, int ntab, const imcom_table_geom *geom, const int *pair_tab, const double *pair_pen,
+                  int npsf_max, double *A)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n_host && x && y && psf && tables && geom && pair_tab && pair_pen && A, "null pointer");
+    IMCOM_REQUIRE(ldn >= 1 && ntab >= 1 && npsf_max >= 1 && geom->nsamp >= 1 && geom->dscale > 0, "bad sizes");
+    IMCOM_TRY(ws_reserve(ctx, (size_t)batch * 4 + 1024));
+    int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
+    IMCOM_TRY(upload(ctx, n_dev, n_host, batch));
+    ProfScope ps(ctx, "build_A");
+    return launch_build_A(ctx, batch, n_dev, ldn, x, y, psf, tables, geom->nsamp + 12, geom->nc, geom->dscale, pair_tab,
+                          pair_pen, npsf_max, A);
+}
+
+int imcom_build_B(imcom_ctx *ctx, int batch, const int *n_host, int ldn, const double *x, const double *y, const int *psf,
+                  const double *tables, int ntab, const imcom_table_geom *geom, const int *io_tab, int npsf_max,
+                  const double *out_x0, const double *out_y0, int n2f, int ldm, double *Bt)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n_host && x && y && psf && tables && geom && io_tab && out_x0 && out_y0 && Bt, "null pointer");
+    IMCOM_REQUIRE(ldn >= 1 && ntab >= 1 && npsf_max >= 1 && n2f >= 1 && ldm >= n2f * n2f, "bad sizes");
+    IMCOM_TRY(ws_reserve(ctx, (size_t)batch * 4 + 1024));
+    int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
+    IMCOM_TRY(upload(ctx, n_dev, n_host, batch));
+    ProfScope ps(ctx, "build_B");
+    return launch_build_B(ctx, batch, n_dev, ldn, x, y, psf, tables, geom->nsamp + 12, geom->nc, geom->dscale, io_tab,
+                          npsf_max, out_x0, out_y0, n2f, ldm, Bt);
+}
+
+int imcom_coadd_epilogue(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm, int n2f, int fade, int n2,
+                         float *Tt, const float *indata, int n_inframe, const int *expo, int n_expo, float *outimage,
+                         double *Tsum_stamp, double *Tsum_inpix, double *Neff)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n_host && Tt && indata && expo && outimage && Tsum_stamp && Tsum_inpix && Neff, "null pointer");
+    IMCOM_REQUIRE(m == n2f * n2f && m <= ldm && n_inframe >= 1 && n_expo >= 1 && fade >= 0 && n2 >= 1, "bad sizes");
+    IMCOM_TRY(ws_reserve(ctx, (size_t)batch * 4 + (size_t)batch * m * n_expo * 8 + 2048));
+    int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
+    double *Tsum_image = (double *)ws_take(ctx, (size_t)batch * m * n_expo * 8);
+    IMCOM_TRY(upload(ctx, n_dev, n_host, batch));
+    ProfScope ps(ctx, "epilogue");
+    return launch_epilogue(ctx, batch, n_dev, ldn, m, ldm, n2f, fade, n2, Tt, indata, n_inframe, expo, n_expo, outimage,
+                           Tsum_image, Tsum_stamp, Tsum_inpix, Neff);
+}
+
+int imcom_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fade)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(maps && nmaps >= 0 && n2f >= 1 && fade >= 0, "bad arguments");
+    return launch_trapezoid_f32(ctx, maps, nmaps, n2f, fade);
+}
+
+}  // extern "C"

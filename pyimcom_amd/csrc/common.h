@@ -1,0 +1,111 @@
+// common.h -- context, workspace arena, error plumbing and launch helpers of libimcom_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/imcom_hip.h"
+
+namespace imcom {
+
+constexpr int NB = 128;  // block size of the blocked factorisation / solve (MFMA tile = NB x NB)
+constexpr int MAX_INC = 24;  // diagonal increments per stamp (kappa nodes + repair add/restore pairs)
+constexpr int MAX_INC_HOST = MAX_INC;
+
+void set_error(const char *fmt, ...);
+
+#define IMCOM_HIP_CHECK(expr)                                                                  \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            imcom::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                             __LINE__);                                                        \
+            return IMCOM_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+#define IMCOM_REQUIRE(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            imcom::set_error(__VA_ARGS__); \
+            return IMCOM_ERR_ARG;         \
+        }                                 \
+    } while (0)
+
+#define IMCOM_TRY(expr)             \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != IMCOM_OK) return rc__; \
+    } while (0)
+
+struct ProfileSlot {
+    double ms = 0.0;
+    long launches = 0;
+};
+
+struct PendingEvent {
+    std::string family;
+    hipEvent_t start, stop;
+    long launches;
+};
+
+}  // namespace imcom
+
+struct imcom_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // bump-allocated device workspace; reset at the start of every API call that uses it
+    char *ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t ws_used = 0;
+    // pinned host staging for small per-stamp arrays
+    char *pin = nullptr;
+    size_t pin_bytes = 0;
+    size_t pin_used = 0;
+    bool profile = false;
+    std::map<std::string, imcom::ProfileSlot> prof;
+    std::vector<imcom::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+    int cu_count = 256;
+};
+
+namespace imcom {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Reserve `bytes` in the context workspace.  The workspace only grows between calls: ws_reserve()
+// is called once per API call with the total, so pointers handed out by ws_take() stay valid.
+int ws_reserve(imcom_ctx *ctx, size_t bytes);
+void *ws_take(imcom_ctx *ctx, size_t bytes);
+int pin_reserve(imcom_ctx *ctx, size_t bytes);
+void *pin_take(imcom_ctx *ctx, size_t bytes);
+
+// HIP-event bracket around a group of launches of one kernel family (no-op unless profiling is on).
+struct ProfScope {
+    imcom_ctx *ctx;
+    hipEvent_t start = nullptr, stop = nullptr;
+    const char *family;
+    long launches;
+    ProfScope(imcom_ctx *c, const char *fam, long n = 1);
+    ~ProfScope();
+};
+
+int profile_collect(imcom_ctx *ctx);
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return IMCOM_ERR_HIP;
+    }
+    return IMCOM_OK;
+}
+
+}  // namespace imcom

@@ -1,0 +1,405 @@
+// interp.hip -- D5512 (10x10-tap) table interpolation kernels and the A / B builders.
+//
+// Replaces furry_parakeet.pyimcom_croutines.{iD5512C, iD5512C_sym, gridD5512C} (in-tree spec:
+// reference src/pyimcom/routine.py:29-338) and, for the device-resident stamp path,
+// PSFOvl._call_ii_self/_call_ii_cross/_call_io_cross (psfutil.py:1401-1732) + the A/B assembly of
+// OutStamp._build_system_matrices (coadd.py:1027-1082).
+//
+// These kernels are gather + fp64 FMA work: no MFMA.  The B builder is separable (every input pixel
+// sees a regular n2f x n2f grid of output pixels): the x-pass result for the window of table rows the
+// stamp touches is kept in LDS and the y-pass reads it back, 5x fewer table reads than the direct
+// form, in the reference's own summation order (inner sum over x taps, outer over y taps).
+#include "common.h"
+
+namespace imcom {
+
+// routine.py:29-122: taps k and 9-k are even(fh^2) +/- odd(fh^2)*fh, Horner in fh^2.
+__constant__ double D5512_EVEN[5][5] = {
+    {+1.651881673372979740e-05, -3.145538007199505447e-04, +1.793518183780194427e-03,
+     -2.904014557029917318e-03, +6.187591260980151433e-04},
+    {-1.146756217210629335e-04, +2.883845374976550142e-03, -1.857047531896089884e-02,
+     +3.147734488597204311e-02, -6.753293626461192439e-03},
+    {+3.256838096371517067e-04, -9.702063770653997568e-03, +8.678848026470635524e-02,
+     -1.659182651092198924e-01, +3.620560878249733799e-02},
+    {-4.541830837949564726e-04, +1.494862093737218955e-02, -1.668775957435094937e-01,
+     +5.879306056792649171e-01, -1.367845996704077915e-01},
+    {+2.266560930061513573e-04, -7.815848920941316502e-03, +9.686607348538181506e-02,
+     -4.505856722239036105e-01, +6.067135256905490381e-01},
+};
+__constant__ double D5512_ODD[5][5] = {
+    {-3.486978652054735998e-06, +6.753750285320532433e-05, -3.871378836550175566e-04,
+     +6.279918076641771273e-04, -1.338434614116611838e-04},
+    {+3.121412120355294799e-05, -8.040343683015897672e-04, +5.209574765466357636e-03,
+     -8.847326408846412429e-03, +1.898674086370833597e-03},
+    {-1.243658986204533102e-04, +3.804930695189636097e-03, -3.434861846914529643e-02,
+     +6.581033749134083954e-02, -1.436476114189205733e-02},
+    {+2.894406669584551734e-04, -9.794291009695265532e-03, +1.104231510875857830e-01,
+     -3.906954914039130755e-01, +9.092432925988773451e-02},
+    {-4.336085507644610966e-04, +1.537862263741893339e-02, -1.925091434770601628e-01,
+     +8.993141455798455697e-01, -1.213035309579723942e+00},
+};
+
+__device__ __forceinline__ void d5512_getw(double (&w)[10], double fh)
+{
+    const double fh2 = fh * fh;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        double e = D5512_EVEN[k][0], o = D5512_ODD[k][0];
+#pragma unroll
+        for (int c = 1; c < 5; c++) {
+            e = e * fh2 + D5512_EVEN[k][c];
+            o = o * fh2 + D5512_ODD[k][c];
+        }
+        o *= fh;
+        w[k] = e + o;
+        w[9 - k] = e - o;
+    }
+}
+
+// truncation toward zero like np.int32(x); anything absurd is treated as off-grid
+__device__ __forceinline__ int to_cell(double x)
+{
+    return (x > -1.0e9 && x < 1.0e9) ? (int)x : -1000000;
+}
+
+// one 10x10 stencil: f points at tap (0,0); step = +1 (plain table) or -1 (table flipped in both axes,
+// base at its last element): inner sum over x taps, outer over y taps (routine.py:176-180)
+__device__ __forceinline__ double stencil(const double *__restrict__ f, long row_stride, int step,
+                                          const double (&wx)[10], const double (&wy)[10])
+{
+    double out = 0.0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const double *row = f + i * row_stride;
+        double strip = 0.0;
+#pragma unroll
+        for (int j = 0; j < 10; j++) strip += wx[j] * row[j * step];
+        out += strip * wy[i];
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void d5512_getw_kernel(const double *__restrict__ fh, long n, double *__restrict__ w)
+{
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double ww[10];
+    d5512_getw(ww, fh[i]);
+#pragma unroll
+    for (int k = 0; k < 10; k++) w[i * 10 + k] = ww[k];
+}
+
+// routine.py:125-181
+__global__ void interp_d5512_kernel(const double *__restrict__ infunc, int nlayer, int ngy, int ngx,
+                                    const double *__restrict__ xpos, const double *__restrict__ ypos,
+                                    long nout, double *__restrict__ fhatout)
+{
+    long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (p >= nout) return;
+    const double x = xpos[p], y = ypos[p];
+    const int xi = to_cell(x), yi = to_cell(y);
+    if (xi < 4 || xi >= ngx - 5 || yi < 4 || yi >= ngy - 5) return;  // output untouched
+    double wx[10], wy[10];
+    d5512_getw(wx, x - xi - 0.5);
+    d5512_getw(wy, y - yi - 0.5);
+    for (int l = 0; l < nlayer; l++)
+        fhatout[(long)l * nout + p] =
+            stencil(infunc + ((long)l * ngy + (yi - 4)) * ngx + (xi - 4), ngx, 1, wx, wy);
+}
+
+// routine.py:184-253: upper triangle (a <= b) interpolated, lower = copy of upper (even when the
+// upper point was off-grid and kept its previous value, lines 249-253)
+__global__ void interp_d5512_sym_kernel(const double *__restrict__ infunc, int nlayer, int ngy, int ngx,
+                                        const double *__restrict__ xpos,
+                                        const double *__restrict__ ypos, long nout, long sq,
+                                        double *__restrict__ fhatout)
+{
+    long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (t >= sq * sq) return;
+    const long a = t / sq, b = t % sq;
+    if (b < a) return;
+    const long p = a * sq + b, pm = b * sq + a;
+    const double x = xpos[p], y = ypos[p];
+    const int xi = to_cell(x), yi = to_cell(y);
+    const bool on = !(xi < 4 || xi >= ngx - 5 || yi < 4 || yi >= ngy - 5);
+    double wx[10], wy[10];
+    if (on) {
+        d5512_getw(wx, x - xi - 0.5);
+        d5512_getw(wy, y - yi - 0.5);
+    }
+    for (int l = 0; l < nlayer; l++) {
+        double v;
+        if (on) {
+            v = stencil(infunc + ((long)l * ngy + (yi - 4)) * ngx + (xi - 4), ngx, 1, wx, wy);
+            fhatout[(long)l * nout + p] = v;
+        } else
+            v = fhatout[(long)l * nout + p];
+        if (b != a) fhatout[(long)l * nout + pm] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Separable grid interpolation (routine.py:256-338) for one input pixel per workgroup.
+//   xs[nxo], ys[nyo] : table coordinates of the output columns / rows for this pixel
+// LDS: wx[nxo][10], wy[nyo][10], xi[nxo], yi[nyo], tmp[nrows][nxo] (the x-pass of the touched rows).
+// Falls back to the direct 100-tap form when the touched row window does not fit `max_rows`.
+template <typename XF, typename YF>
+__device__ __forceinline__ void grid_pixel(const double *__restrict__ f, int ngy, int ngx, int nxo, int nyo,
+                                           XF xcoord, YF ycoord, double *__restrict__ out, double *sm_d,
+                                           int *sm_i, int max_rows)
+{
+    const int tid = threadIdx.x, nth = blockDim.x;
+    double *wxs = sm_d, *wys = sm_d + 10 * nxo, *tmp = wys + 10 * nyo;
+    int *xis = sm_i, *yis = sm_i + nxo, *red = yis + nyo;  // red[0]=rlo, red[1]=rhi
+    if (tid == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; }
+    __syncthreads();
+    for (int t = tid; t < nxo + nyo; t += nth) {
+        const bool isx = t < nxo;
+        const int idx = isx ? t : t - nxo;
+        const double v = isx ? xcoord(idx) : ycoord(idx);
+        int c = to_cell(v);
+        const int lim = isx ? ngx : ngy;
+        double w[10];
+        if (c < 4 || c >= lim - 5) {  // off the grid: zero weights, cell 4 (routine.py:306-323)
+            c = 4;
+#pragma unroll
+            for (int k = 0; k < 10; k++) w[k] = 0.0;
+            if (!isx) c = -1;  // marker: row window is taken from valid rows only
+        } else {
+            d5512_getw(w, v - c - 0.5);
+            if (!isx) { atomicMin(&red[0], c - 4); atomicMax(&red[1], c + 5); }
+        }
+        double *dst = isx ? wxs + 10 * idx : wys + 10 * idx;
+#pragma unroll
+        for (int k = 0; k < 10; k++) dst[k] = w[k];
+        (isx ? xis : yis)[idx] = c;
+    }
+    __syncthreads();
+    const int rlo = red[0], rhi = red[1];
+    const int nrows = rhi - rlo + 1;
+    if (rhi < rlo) {  // no valid row at all: every output is exactly zero
+        for (int t = tid; t < nxo * nyo; t += nth) out[t] = 0.0;
+        return;
+    }
+    if (nrows <= max_rows) {
+        // x-pass over the touched table rows
+        for (int t = tid; t < nrows * nxo; t += nth) {
+            const int r = t / nxo, ix = t - r * nxo;
+            const double *row = f + (long)(rlo + r) * ngx + (xis[ix] - 4);
+            const double *w = wxs + 10 * ix;
+            double strip = 0.0;
+#pragma unroll
+            for (int j = 0; j < 10; j++) strip += w[j] * row[j];
+            tmp[t] = strip;
+        }
+        __syncthreads();
+        for (int t = tid; t < nxo * nyo; t += nth) {
+            const int iy = t / nxo, ix = t - iy * nxo;
+            const int yc = yis[iy];
+            const double *w = wys + 10 * iy;
+            const int r0 = (yc < 0 ? rlo : yc - 4 - rlo);  // invalid rows carry zero weights
+            double o = 0.0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) o += tmp[(r0 + i) * nxo + ix] * w[i];
+            out[t] = o;
+        }
+    } else {
+        for (int t = tid; t < nxo * nyo; t += nth) {
+            const int iy = t / nxo, ix = t - iy * nxo;
+            const int yc = yis[iy] < 0 ? 4 : yis[iy];
+            const double *w = wys + 10 * iy, *wxp = wxs + 10 * ix;
+            double o = 0.0;
+            for (int i = 0; i < 10; i++) {
+                const double *row = f + (long)(yc - 4 + i) * ngx + (xis[ix] - 4);
+                double strip = 0.0;
+#pragma unroll
+                for (int j = 0; j < 10; j++) strip += wxp[j] * row[j];
+                o += strip * w[i];
+            }
+            out[t] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_d5512_kernel(const double *__restrict__ infunc, int ngy, int ngx,
+                                                         const double *__restrict__ xpos,
+                                                         const double *__restrict__ ypos, long npi, int nxo,
+                                                         int nyo, double *__restrict__ fhatout, int max_rows)
+{
+    extern __shared__ double smem[];
+    const long p = blockIdx.x;
+    if (p >= npi) return;
+    double *sm_d = smem;
+    int *sm_i = (int *)(smem + 10 * (nxo + nyo) + (size_t)max_rows * nxo);
+    const double *xp = xpos + p * nxo, *yp = ypos + p * nyo;
+    grid_pixel(infunc, ngy, ngx, nxo, nyo, [&](int i) { return xp[i]; }, [&](int i) { return yp[i]; },
+               fhatout + p * (long)nxo * nyo, sm_d, sm_i, max_rows);
+}
+
+// ------------------------------------------------------------------------------------------------
+// B builder (psfutil.py:1497-1595): one workgroup per (input pixel, stamp).
+//   ddx = (x_in - x_out[ix]) / dscale + nc (+6 for the zero border), ddy likewise (1536-1541, 1581-1582)
+__global__ __launch_bounds__(256) void build_B_kernel(const int *__restrict__ n, int ldn,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ y,
+                                                      const int *__restrict__ psf,
+                                                      const double *__restrict__ tables, int ng,
+                                                      double nc, double dscale,
+                                                      const int *__restrict__ io_tab, int npsf_max,
+                                                      const double *__restrict__ out_x0,
+                                                      const double *__restrict__ out_y0, int n2f, int ldm,
+                                                      double *__restrict__ Bt, int max_rows)
+{
+    extern __shared__ double smem[];
+    const int s = blockIdx.y, i = blockIdx.x;
+    double *dst = Bt + ((long)s * ldn + i) * ldm;
+    const int m = n2f * n2f;
+    if (i >= n[s]) {  // padding rows are zero
+        for (int t = threadIdx.x; t < ldm; t += blockDim.x) dst[t] = 0.0;
+        return;
+    }
+    const double xin = x[(long)s * ldn + i], yin = y[(long)s * ldn + i];
+    const int tab = io_tab[(long)s * npsf_max + psf[(long)s * ldn + i]];
+    const double *f = tables + (long)tab * ng * ng;
+    const double x0 = out_x0[s], y0 = out_y0[s];
+    double *sm_d = smem;
+    int *sm_i = (int *)(smem + 20 * n2f + (size_t)max_rows * n2f);
+    grid_pixel(f, ng, ng, n2f, n2f,
+               [&](int ix) { double d = xin - (x0 + ix); d /= dscale; d += nc; return d + 6.0; },
+               [&](int iy) { double d = yin - (y0 + iy); d /= dscale; d += nc; return d + 6.0; },
+               dst, sm_d, sm_i, max_rows);
+    for (int t = m + threadIdx.x; t < ldm; t += blockDim.x) dst[t] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A builder (psfutil.py:1401-1495, 1597-1732 + coadd.py:1027-1068).  The reference interpolates the
+// element (i, j) with i before j in the stamp's pixel order and mirrors it; so does this kernel:
+// 16x16 thread tiles over the upper triangle, each thread one element, written to [i][j] and [j][i].
+// pair code: bits 0..27 table index; bit 29 SWAP (the reference evaluated the block from the other
+// stamp's side and transposed it, psfutil.py:1990-1996); bit 30 FLIP (np.flip'ed table, 1658-1665).
+constexpr int PAIR_SWAP = 1 << 29, PAIR_FLIP = 1 << 30, PAIR_MASK = (1 << 28) - 1;
+
+__global__ __launch_bounds__(256) void build_A_kernel(const int *__restrict__ n, int ldn,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ y,
+                                                      const int *__restrict__ psf,
+                                                      const double *__restrict__ tables, int ng, double nc,
+                                                      double dscale, const int *__restrict__ pair_tab,
+                                                      const double *__restrict__ pair_pen, int npsf_max,
+                                                      double *__restrict__ A)
+{
+    const int s = blockIdx.z;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj < ti) return;
+    const int ns = n[s];
+    const int i = ti * 16 + (threadIdx.x >> 4), j = tj * 16 + (threadIdx.x & 15);
+    if (i >= ldn || j >= ldn || j < i) return;
+    double *As = A + (long)s * ldn * ldn;
+    if (i >= ns || j >= ns) {  // identity padding
+        const double v = (i == j) ? 1.0 : 0.0;
+        As[(long)i * ldn + j] = v;
+        As[(long)j * ldn + i] = v;
+        return;
+    }
+    const long base = (long)s * ldn;
+    const int pi = psf[base + i], pj = psf[base + j];
+    const long pidx = ((long)s * npsf_max + pi) * npsf_max + pj;
+    const int code = pair_tab[pidx];
+    double val = 0.0;
+    if (code >= 0) {
+        const bool swap = code & PAIR_SWAP, flip = code & PAIR_FLIP;
+        const int tab = code & PAIR_MASK;
+        double dx = swap ? x[base + j] - x[base + i] : x[base + i] - x[base + j];
+        double dy = swap ? y[base + j] - y[base + i] : y[base + i] - y[base + j];
+        dx /= dscale; dx += nc; dx += 6.0;
+        dy /= dscale; dy += nc; dy += 6.0;
+        const int xi = to_cell(dx), yi = to_cell(dy);
+        if (!(xi < 4 || xi >= ng - 5 || yi < 4 || yi >= ng - 5)) {
+            double wx[10], wy[10];
+            d5512_getw(wx, dx - xi - 0.5);
+            d5512_getw(wy, dy - yi - 0.5);
+            const double *f = tables + (long)tab * ng * ng;
+            const long off = (long)(yi - 4) * ng + (xi - 4);
+            val = flip ? stencil(f + ((long)ng * ng - 1 - off), -(long)ng, -1, wx, wy)
+                       : stencil(f + off, ng, 1, wx, wy);
+        }
+    }
+    val += pair_pen[pidx];
+    As[(long)i * ldn + j] = val;
+    As[(long)j * ldn + i] = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+int launch_getw(imcom_ctx *ctx, const double *fh, long n, double *w)
+{
+    if (n <= 0) return IMCOM_OK;
+    hipLaunchKernelGGL(d5512_getw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, fh, n, w);
+    return check_launch("d5512_getw_kernel");
+}
+
+int launch_interp(imcom_ctx *ctx, const double *infunc, int nlayer, int ngy, int ngx, const double *xpos,
+                  const double *ypos, long nout, double *fhatout, int sym)
+{
+    if (nout <= 0) return IMCOM_OK;
+    if (!sym) {
+        hipLaunchKernelGGL(interp_d5512_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, ctx->stream,
+                           infunc, nlayer, ngy, ngx, xpos, ypos, nout, fhatout);
+        return check_launch("interp_d5512_kernel");
+    }
+    long sq = (long)sqrt((double)(nout + 1));  // routine.py:214
+    hipLaunchKernelGGL(interp_d5512_sym_kernel, dim3((unsigned)((sq * sq + 255) / 256)), dim3(256), 0,
+                       ctx->stream, infunc, nlayer, ngy, ngx, xpos, ypos, nout, sq, fhatout);
+    return check_launch("interp_d5512_sym_kernel");
+}
+
+static int grid_lds(int nxo, int nyo, int *max_rows, size_t *bytes)
+{
+    // budget 96 KB so that at least one more workgroup fits beside it
+    const size_t fixed = (size_t)(10 * (nxo + nyo)) * 8 + (size_t)(nxo + nyo + 4) * 4;
+    const size_t budget = 96 * 1024;
+    long rows = fixed < budget ? (long)((budget - fixed) / ((size_t)nxo * 8)) : 0;
+    if (rows > 4096) rows = 4096;
+    if (rows < 10) rows = 0;  // too wide for the LDS form: direct evaluation
+    *max_rows = (int)rows;
+    *bytes = fixed + (size_t)rows * nxo * 8 + 16;
+    return IMCOM_OK;
+}
+
+int launch_grid(imcom_ctx *ctx, const double *infunc, int ngy, int ngx, const double *xpos, const double *ypos,
+                long npi, int nxo, int nyo, double *fhatout)
+{
+    if (npi <= 0) return IMCOM_OK;
+    int max_rows; size_t bytes;
+    grid_lds(nxo, nyo, &max_rows, &bytes);
+    IMCOM_REQUIRE(bytes <= 160 * 1024, "gridD5512C: output grid %d x %d too large for the LDS form", nxo, nyo);
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)grid_d5512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(grid_d5512_kernel, dim3((unsigned)npi), dim3(256), bytes, ctx->stream, infunc, ngy, ngx,
+                       xpos, ypos, npi, nxo, nyo, fhatout, max_rows);
+    return check_launch("grid_d5512_kernel");
+}
+
+int launch_build_B(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
+                   const int *psf, const double *tables, int ng, double nc, double dscale, const int *io_tab,
+                   int npsf_max, const double *out_x0, const double *out_y0, int n2f, int ldm, double *Bt)
+{
+    int max_rows; size_t bytes;
+    grid_lds(n2f, n2f, &max_rows, &bytes);
+    IMCOM_REQUIRE(bytes <= 160 * 1024, "build_B: n2f=%d too large", n2f);
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)build_B_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(build_B_kernel, dim3(ldn, batch), dim3(256), bytes, ctx->stream, n_dev, ldn, x, y, psf,
+                       tables, ng, nc, dscale, io_tab, npsf_max, out_x0, out_y0, n2f, ldm, Bt, max_rows);
+    return check_launch("build_B_kernel");
+}
+
+int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
+                   const int *psf, const double *tables, int ng, double nc, double dscale, const int *pair_tab,
+                   const double *pair_pen, int npsf_max, double *A)
+{
+    const int nt = (ldn + 15) / 16;
+    hipLaunchKernelGGL(build_A_kernel, dim3(nt, nt, batch), dim3(256), 0, ctx->stream, n_dev, ldn, x, y, psf,
+                       tables, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A);
+    return check_launch("build_A_kernel");
+}
+
+}  // namespace imcom

@@ -1,0 +1,646 @@
+// la_kernels.hip -- the non-GEMM kernels of the LA path: diagonal-block factorisation + inverse,
+// layout packing, the single-/multi-kappa reductions (U/C, Sigma, kappa), lakernel1, the reduced-space
+// kappa search, and the coaddition epilogue.
+//
+// Reference lines restated (src/pyimcom/): lakernel.py:281-394 (CholKernel), routine.py:341-588
+// (lakernel1, lsolve_sps, build_reduced_T_wrap), coadd.py:1222-1292 (trapezoid), 1320-1354
+// (_perform_coaddition).
+#include "common.h"
+
+namespace imcom {
+
+// ------------------------------------------------------------------------------------------------
+// Diagonal block: P[k] (NB x NB, lower part used) -> L[k,k] in place and Linv[k] = L[k,k]^-1.
+// One 128-thread workgroup per stamp; the block lives in LDS (129-word rows: conflict-free column and
+// row walks).  Column-by-column left-looking Cholesky, then one thread per column of the inverse
+// (forward substitution), Linv^T kept in the strict upper triangle of the same LDS image.
+// A non-positive pivot (LAPACK dpotrf's failure, scipy raises LinAlgError: lakernel.py:262-264)
+// records fail[s] = global column + 1 and leaves the block unfinished.
+constexpr int DLD = NB + 1;
+
+__global__ __launch_bounds__(128) void chol_diag_kernel(double *__restrict__ L, double *__restrict__ Dinv,
+                                                        int ldn, int k, const int *__restrict__ nblk,
+                                                        int *__restrict__ fail)
+{
+    extern __shared__ double S[];
+    double *dg = S + NB * DLD;
+    __shared__ double piv;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (k >= nblk[s] || fail[s] != 0) return;
+    double *Lkk = L + (long)s * ldn * ldn + (long)k * NB * ldn + k * NB;
+    for (int r = 0; r < NB; r++) S[r * DLD + tid] = Lkk[(long)r * ldn + tid];
+    __syncthreads();
+    for (int j = 0; j < NB; j++) {
+        double v = 0.0;
+        if (tid >= j) {
+            v = S[tid * DLD + j];
+            const double *ri = S + tid * DLD, *rj = S + j * DLD;
+#pragma unroll 4
+            for (int c = 0; c < j; c++) v -= ri[c] * rj[c];
+        }
+        if (tid == j) piv = v;
+        __syncthreads();
+        const double d = piv;
+        if (!(d > 0.0)) {  // also catches NaN
+            if (tid == 0) fail[s] = k * NB + j + 1;
+            return;
+        }
+        const double ljj = sqrt(d);
+        if (tid == j) { S[j * DLD + j] = ljj; dg[j] = ljj; }
+        else if (tid > j) S[tid * DLD + j] = v / ljj;
+        __syncthreads();
+    }
+    // write L[k,k] (strict upper part zeroed)
+    for (int r = 0; r < NB; r++) Lkk[(long)r * ldn + tid] = (tid <= r) ? S[r * DLD + tid] : 0.0;
+    __syncthreads();
+    // inverse: thread c owns column c; x_l (l > c) is stored at S[c][l] (upper triangle)
+    {
+        const int c = tid;
+        const double xc = 1.0 / dg[c];
+        double *xrow = S + c * DLD;
+        for (int i = 1; i < NB; i++) {
+            // wave-uniform trip count so that S[i][l] is a broadcast read; lanes with c >= i idle
+            const double *li = S + i * DLD;
+            double sum = 0.0;
+            if (c < i) {
+                sum = li[c] * xc;
+                for (int l = c + 1; l < i; l++) sum += li[l] * xrow[l];
+                xrow[i] = -sum / dg[i];
+            }
+        }
+        __syncthreads();
+        double *Di = Dinv + ((long)s * (ldn / NB) + k) * NB * NB;
+        // Linv[r][c] = (r > c) ? S[c][r] : (r == c ? 1/l_cc : 0); write rows coalesced over c = tid
+        for (int r = 0; r < NB; r++) {
+            double v = 0.0;
+            if (r > c) v = S[c * DLD + r];
+            else if (r == c) v = xc;
+            Di[r * NB + c] = v;
+        }
+    }
+}
+
+// diagonal of A + increments, applied the way the reference does: a sequence of in-place adds
+// (lakernel.py:298, 356, 268/277), so the rounding matches; used by chol_update via `shift`.
+__global__ void diag_shift_kernel(const double *__restrict__ A, int ldn, const double *__restrict__ inc,
+                                  const int *__restrict__ ninc, double *__restrict__ dshift, int batch)
+{
+    // dshift[s][i] = ((A_ii + inc0) + inc1 ...) - A_ii is NOT exact in general; we store the full
+    // shifted diagonal instead and chol_update replaces A_ii by it.
+    const int s = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ldn || s >= batch) return;
+    double a = A[(long)s * ldn * ldn + (long)i * ldn + i];
+    const int n = ninc[s];
+    for (int t = 0; t < n; t++) a += inc[s * MAX_INC + t];
+    dshift[(long)s * ldn + i] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout packing for the host LA seam
+__global__ void pack_A_kernel(const double *__restrict__ A, long lda, const int *__restrict__ n,
+                              double *__restrict__ Ap, int ldp)
+{
+    const int s = blockIdx.z;
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ldp) return;
+    const int ns = n[s];
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < ns && j < ns) v = A[(long)s * lda * lda + (long)i * lda + j];
+    Ap[(long)s * ldp * ldp + (long)i * ldp + j] = v;
+}
+
+// mBhalf[s][a][i] ([m][ldb]) -> Bt[s][i][a] ([ldp][ldm]), zero padded
+__global__ __launch_bounds__(256) void pack_Bt_kernel(const double *__restrict__ B, long ldb, int m,
+                                                      const int *__restrict__ n, double *__restrict__ Bt,
+                                                      int ldp, int ldm)
+{
+    __shared__ double tile[32][33];
+    const int s = blockIdx.z;
+    const int i0 = blockIdx.y * 32, a0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int ns = n[s];
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, i = i0 + tx;
+        tile[r][tx] = (a < m && i < ns) ? B[(long)s * m * ldb + (long)a * ldb + i] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, a = a0 + tx;
+        if (i < ldp && a < ldm) Bt[(long)s * ldp * ldm + (long)i * ldm + a] = tile[tx][r];
+    }
+}
+
+// Tt[s][i][a] float32 ([ldp][ldm]) -> T[s][a][i] float32 ([m][ldt]); columns i >= n[s] are zeroed
+__global__ __launch_bounds__(256) void unpack_T_kernel(const float *__restrict__ Tt, int ldp, int ldm,
+                                                       const int *__restrict__ n, int m,
+                                                       float *__restrict__ T, long ldt)
+{
+    __shared__ float tile[32][33];
+    const int s = blockIdx.z;
+    const int i0 = blockIdx.y * 32, a0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ns = n[s];
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, a = a0 + tx;
+        tile[r][tx] = (i < ns && i < ldp && a < ldm) ? Tt[(long)s * ldp * ldm + (long)i * ldm + a] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, i = i0 + tx;
+        if (a < m && i < ldt) T[(long)s * m * ldt + (long)a * ldt + i] = tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// single kappa (lakernel.py:309-317): D_a = sum_i B_ai T_ai, N_a = sum_i T_ai^2 in float64 from the
+// float64 solution X; Tt = float32(X); kappa_a = kappa; Sigma_a = N_a; UC_a = 1 - (kappa N_a + D_a)/C.
+// Workgroup = 64 output pixels x 4 row groups.
+__global__ __launch_bounds__(256) void finalize_single_kernel(const double *__restrict__ X,
+                                                              const double *__restrict__ Bt, int ldn, int ldm,
+                                                              int m, const int *__restrict__ n,
+                                                              const double *__restrict__ kap,
+                                                              const double *__restrict__ Cs,
+                                                              float *__restrict__ Tt, float *__restrict__ UC,
+                                                              float *__restrict__ Sigma,
+                                                              float *__restrict__ kappa)
+{
+    __shared__ double red[2][4][64];
+    const int s = blockIdx.y, a = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int ns = n[s];
+    const long base = (long)s * ldn * ldm;
+    double D = 0.0, N = 0.0;
+    if (a < ldm) {
+        for (int i = rg; i < ns; i += 4) {
+            const double x = X[base + (long)i * ldm + a];
+            const double b = Bt[base + (long)i * ldm + a];
+            Tt[base + (long)i * ldm + a] = (float)x;
+            D += b * x;
+            N += x * x;
+        }
+        // rows beyond n[s] hold no pixels: keep Tt defined for the epilogue
+        for (int i = ns + rg; i < ldn; i += 4) Tt[base + (long)i * ldm + a] = 0.0f;
+    }
+    red[0][rg][threadIdx.x & 63] = D;
+    red[1][rg][threadIdx.x & 63] = N;
+    __syncthreads();
+    if (rg == 0 && a < m) {
+        const int c = threadIdx.x & 63;
+        D = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        N = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        const double k = kap[s], C = Cs[s];
+        if (ns == 0) {  // lakernel.py:110-119
+            UC[(long)s * m + a] = 1.0f; Sigma[(long)s * m + a] = 0.0f; kappa[(long)s * m + a] = 1.0f;
+        } else {
+            kappa[(long)s * m + a] = (float)k;
+            Sigma[(long)s * m + a] = (float)N;
+            UC[(long)s * m + a] = (float)(1.0 - (k * N + D) / C);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// routine.py:433-484 on tiny nv x nv systems held in thread-private arrays
+constexpr int MAXNV = 8;
+
+__device__ inline void lsolve_sps_dev(int N, double *A, double *x, const double *b)
+{
+    double p1[MAXNV];
+    for (int i = 0; i < N; i++) {
+        for (int j = 0; j < i; j++) {
+            double s = 0.0;
+            for (int k = 0; k < j; k++) s += A[i * N + k] * A[j * N + k];
+            A[i * N + j] = (A[i * N + j] - s) / A[j * N + j];
+        }
+        double s = 0.0;
+        for (int k = 0; k < i; k++) s += A[i * N + k] * A[i * N + k];
+        A[i * N + i] = sqrt(A[i * N + i] - s);
+    }
+    for (int i = 0; i < N; i++) {
+        double s = 0.0;
+        for (int j = 0; j < i; j++) s += A[i * N + j] * p1[j];
+        p1[i] = (b[i] - s) / A[i * N + i];
+    }
+    for (int i = N - 1; i >= 0; i--) {
+        double s = 0.0;
+        for (int j = i + 1; j < N; j++) s += A[j * N + i] * x[j];
+        x[i] = (p1[i] - s) / A[i * N + i];
+    }
+}
+
+// routine.py:546-588 for one output pixel
+__device__ inline void reduced_T_pixel(const double *Na, const double *Da, const double *Ea,
+                                       const double *kappa, int nv, double ucmin, double smax,
+                                       double *okappa, double *oS, double *oUC, double *w)
+{
+    double M[MAXNV * MAXNV];
+    int iv = nv - 1;
+    double UC = ucmin * 10, S = smax / 10;
+    while (iv > 0 && ucmin < UC && smax > S) {
+        iv--;
+        S = Na[iv * (nv + 1)];
+        UC = 1.0 - 2.0 * Da[iv] + Ea[iv * (nv + 1)];
+    }
+    double kmid = sqrt(kappa[iv] * kappa[iv + 1]);
+    double factor = pow(kappa[iv + 1] / kappa[iv], 0.25);
+    for (int it = 0; it < 12; it++) {
+        for (int r = 0; r < nv; r++)
+            for (int c = 0; c <= r; c++) M[r * nv + c] = Ea[r + nv * c] + kmid * Na[r + nv * c];
+        lsolve_sps_dev(nv, M, w, Da);
+        S = 0.0;
+        for (int r = 0; r < nv; r++) {
+            double s = 0.0;
+            for (int c = 0; c < nv; c++) s += Na[r + nv * c] * w[c];
+            S += s * w[r];
+        }
+        UC = 1.0 - kmid * S;
+        for (int r = 0; r < nv; r++) UC -= Da[r] * w[r];
+        kmid *= (ucmin < UC && smax > S) ? 1.0 / factor : factor;
+        factor = sqrt(factor);
+    }
+    *okappa = kmid;
+    *oS = S;
+    *oUC = UC;
+}
+
+__global__ void build_reduced_T_kernel(const double *__restrict__ Nflat, const double *__restrict__ Dflat,
+                                       const double *__restrict__ Eflat, const double *__restrict__ kappa,
+                                       int nv, long m, double ucmin, double smax, double *__restrict__ ok,
+                                       double *__restrict__ oS, double *__restrict__ oU,
+                                       double *__restrict__ ow)
+{
+    const long a = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    double Na[MAXNV * MAXNV], Ea[MAXNV * MAXNV], Da[MAXNV], kp[MAXNV], w[MAXNV];
+    const int nv2 = nv * nv;
+    for (int t = 0; t < nv2; t++) { Na[t] = Nflat[a * nv2 + t]; Ea[t] = Eflat[a * nv2 + t]; }
+    for (int t = 0; t < nv; t++) { Da[t] = Dflat[a * nv + t]; kp[t] = kappa[t]; w[t] = 0.0; }
+    double k, S, U;
+    reduced_T_pixel(Na, Da, Ea, kp, nv, ucmin, smax, &k, &S, &U, w);
+    ok[a] = k; oS[a] = S; oU[a] = U;
+    for (int t = 0; t < nv; t++) ow[a * nv + t] = w[t];
+}
+
+// multi-kappa Cholesky (lakernel.py:361-393).  Xs = nv solutions, node p at Xs + p*node_stride.
+// Dp[a][p] = sum_i B_ai X_p,ai ; Npq[a][p][q] = sum_i X_p,ai X_q,ai   (float64)
+__global__ __launch_bounds__(256) void multi_reduce_kernel(const double *__restrict__ Xs, long node_stride,
+                                                           const double *__restrict__ Bt, int ldn, int ldm,
+                                                           int m, const int *__restrict__ n, int nv,
+                                                           double *__restrict__ Dp, double *__restrict__ Npq)
+{
+    __shared__ double red[4][64];
+    const int s = blockIdx.y, c = threadIdx.x & 63, a = blockIdx.x * 64 + c, rg = threadIdx.x >> 6;
+    const int ns = n[s];
+    const long base = (long)s * ldn * ldm;
+    double d[MAXNV], nn[MAXNV * (MAXNV + 1) / 2];
+    for (int p = 0; p < MAXNV; p++) d[p] = 0.0;
+    for (int t = 0; t < MAXNV * (MAXNV + 1) / 2; t++) nn[t] = 0.0;
+    if (a < ldm)
+        for (int i = rg; i < ns; i += 4) {
+            const long off = base + (long)i * ldm + a;
+            const double b = Bt[off];
+            double xv[MAXNV];
+            for (int p = 0; p < nv; p++) xv[p] = Xs[p * node_stride + off];
+            int t = 0;
+            for (int p = 0; p < nv; p++) {
+                d[p] += b * xv[p];
+                for (int q = 0; q <= p; q++) nn[t++] += xv[p] * xv[q];
+            }
+        }
+    // reduce the 4 row groups value by value through LDS
+    const int nd = nv, ntri = nv * (nv + 1) / 2;
+    for (int t = 0; t < nd + ntri; t++) {
+        red[rg][c] = (t < nd) ? d[t] : nn[t - nd];
+        __syncthreads();
+        if (rg == 0 && a < m) {
+            const double v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+            if (t < nd) Dp[((long)s * m + a) * nv + t] = v;
+            else {
+                // triangular index -> (p,q)
+                int tt = t - nd, p = 0;
+                while ((p + 1) * (p + 2) / 2 <= tt) p++;
+                const int q = tt - p * (p + 1) / 2;
+                Npq[(((long)s * m + a) * nv + p) * nv + q] = v;
+                Npq[(((long)s * m + a) * nv + q) * nv + p] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// per pixel: E from D,N (lakernel.py:364-368), reduced-space search, outputs (390-392) and weights
+__global__ void multi_search_kernel(const double *__restrict__ Dp, const double *__restrict__ Npq, int m,
+                                    const int *__restrict__ n, int nv, const double *__restrict__ kappaC,
+                                    const double *__restrict__ Cs, double ucmin, double smax,
+                                    float *__restrict__ UC, float *__restrict__ Sigma,
+                                    float *__restrict__ kappa, double *__restrict__ W)
+{
+    const int s = blockIdx.y;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    const long pa = (long)s * m + a;
+    if (n[s] == 0) {
+        UC[pa] = 1.0f; Sigma[pa] = 0.0f; kappa[pa] = 1.0f;
+        for (int p = 0; p < nv; p++) W[pa * nv + p] = 0.0;
+        return;
+    }
+    const double C = Cs[s];
+    double Na[MAXNV * MAXNV], Ea[MAXNV * MAXNV], Da[MAXNV], kp[MAXNV], w[MAXNV], kar[MAXNV];
+    for (int p = 0; p < nv; p++) { kp[p] = kappaC[p]; kar[p] = kappaC[p] * C; w[p] = 0.0; }
+    for (int t = 0; t < nv * nv; t++) Na[t] = Npq[pa * nv * nv + t];
+    for (int p = 0; p < nv; p++) {
+        const double dpp = Dp[pa * nv + p];
+        for (int q = 0; q < p; q++) {
+            const double e = Dp[pa * nv + q] - kar[p] * Na[p * nv + q];
+            Ea[q * nv + p] = e / C;
+            Ea[p * nv + q] = e / C;
+        }
+        Ea[p * nv + p] = (dpp - kar[p] * Na[p * nv + p]) / C;
+        Da[p] = dpp / C;
+    }
+    double k, S, U;
+    reduced_T_pixel(Na, Da, Ea, kp, nv, ucmin, smax, &k, &S, &U, w);
+    kappa[pa] = (float)(k * C);
+    Sigma[pa] = (float)S;
+    UC[pa] = (float)U;
+    for (int p = 0; p < nv; p++) W[pa * nv + p] = w[p];
+}
+
+// Tt[i][a] = float32( sum_p w[a][p] X_p[i][a] )   (lakernel.py:393)
+__global__ __launch_bounds__(256) void multi_combine_kernel(const double *__restrict__ Xs, long node_stride,
+                                                            int ldn, int ldm, int m,
+                                                            const int *__restrict__ n, int nv,
+                                                            const double *__restrict__ W,
+                                                            float *__restrict__ Tt)
+{
+    const int s = blockIdx.y, a = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    if (a >= ldm) return;
+    const int ns = n[s];
+    const long base = (long)s * ldn * ldm;
+    double w[MAXNV];
+    for (int p = 0; p < nv; p++) w[p] = (a < m) ? W[((long)s * m + a) * nv + p] : 0.0;
+    for (int i = rg; i < ldn; i += 4) {
+        const long off = base + (long)i * ldm + a;
+        double t = 0.0;
+        if (i < ns)
+            for (int p = 0; p < nv; p++) t += Xs[p * node_stride + off] * w[p];
+        Tt[off] = (float)t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// routine.py:341-430 lakernel1: one wave per output pixel, lanes stride over the n eigen-components,
+// DPP/shuffle tree for the two sums of every bisection step.
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void lakernel1_kernel(const double *__restrict__ lam,
+                                                        const double *__restrict__ mPhalf, long m, long n,
+                                                        long ldp, double C, double targetleak, double kCmin,
+                                                        double kCmax, int nbis, double *__restrict__ kappa,
+                                                        double *__restrict__ Sigma, double *__restrict__ UC,
+                                                        double *__restrict__ T, long ldt, double smax)
+{
+    const long a = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (a >= m) return;
+    const double *p = mPhalf + a * ldp;
+    double factor = sqrt(kCmax / kCmin);
+    double kap = sqrt(kCmax * kCmin);
+    for (int it = 0; it <= nbis; it++) {
+        double s1 = 0.0, s2 = 0.0;
+        const bool last = (it == nbis);
+        for (long i = lane; i < n; i += 64) {
+            const double l = lam[i];
+            const double v = p[i] / (l + kap);
+            if (last) T[a * ldt + i] = v;
+            s2 += v * v;
+            s1 += (l + 2.0 * kap) * v * v;
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const double udc = 1.0 - s1 / C;
+        if (last) {
+            if (lane == 0) { Sigma[a] = s2; kappa[a] = kap; UC[a] = udc; }
+        } else {
+            factor = sqrt(factor);
+            kap *= (udc > targetleak && s2 < smax) ? 1.0 / factor : factor;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// coadd.py:1222-1292 trapezoid weights: s_k = k/(2f+1) - sin(2 pi k/(2f+1))/(2 pi), k = 1..2f,
+// applied to the 2f outermost rows (B then T) and columns (L then R), one in-place multiply each.
+__device__ __forceinline__ double taper_1d(int pos, int len, int fade)
+{
+    const int fk2 = 2 * fade;
+    double f = 1.0;
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    if (pos < fk2) {
+        double s = (double)(pos + 1) / (fk2 + 1);
+        s -= sin(two_pi * s) / two_pi;
+        f *= s;
+    }
+    if (pos >= len - fk2) {
+        double s = (double)(len - pos) / (fk2 + 1);
+        s -= sin(two_pi * s) / two_pi;
+        f *= s;
+    }
+    return f;
+}
+
+__device__ __forceinline__ float taper_f32(float v, int iy, int ix, int n2f, int fade)
+{
+    // numpy: float32 array *= float64 factors -> product in float64, rounded to float32, once for the
+    // row pass(es) and once for the column pass(es)
+    const int fk2 = 2 * fade;
+    if (iy < fk2) { double s = (double)(iy + 1) / (fk2 + 1); s -= sin(6.283185307179586 * s) / 6.283185307179586; v = (float)((double)v * s); }
+    if (iy >= n2f - fk2) { double s = (double)(n2f - iy) / (fk2 + 1); s -= sin(6.283185307179586 * s) / 6.283185307179586; v = (float)((double)v * s); }
+    if (ix < fk2) { double s = (double)(ix + 1) / (fk2 + 1); s -= sin(6.283185307179586 * s) / 6.283185307179586; v = (float)((double)v * s); }
+    if (ix >= n2f - fk2) { double s = (double)(n2f - ix) / (fk2 + 1); s -= sin(6.283185307179586 * s) / 6.283185307179586; v = (float)((double)v * s); }
+    return v;
+}
+
+__global__ void trapezoid_f32_kernel(float *__restrict__ maps, long nmaps, int n2f, int fade)
+{
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long m = (long)n2f * n2f;
+    if (t >= nmaps * m) return;
+    const int a = (int)(t % m);
+    maps[t] = taper_f32(maps[t], a / n2f, a % n2f, n2f, fade);
+}
+
+// coadd.py:1320-1354.  Workgroup = 64 output pixels x 4 row groups over the input pixels.
+//   acc layout in LDS: [n_expo + n_inframe][256]
+__global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__ Tt, int ldn, int ldm, int m,
+                                                             int n2f, int fade, const int *__restrict__ n,
+                                                             const float *__restrict__ indata, int n_inframe,
+                                                             const int *__restrict__ expo, int n_expo,
+                                                             float *__restrict__ outimage,
+                                                             double *__restrict__ Tsum_image_part,
+                                                             double *__restrict__ Tsum_inpix,
+                                                             double *__restrict__ Neff)
+{
+    extern __shared__ double accs[];  // [(n_expo + n_inframe)][256]
+    const int s = blockIdx.y, c = threadIdx.x & 63, a = blockIdx.x * 64 + c, rg = threadIdx.x >> 6;
+    const int ns = n[s];
+    const int nacc = n_expo + n_inframe;
+    for (int t = 0; t < nacc; t++) accs[t * 256 + threadIdx.x] = 0.0;
+    const long base = (long)s * ldn * ldm;
+    const int iy = a / n2f, ix = a - iy * n2f;
+    if (a < m) {
+        for (int i = rg; i < ns; i += 4) {
+            float tv = Tt[base + (long)i * ldm + a];
+            if (fade > 0) {
+                tv = taper_f32(tv, iy, ix, n2f, fade);
+                Tt[base + (long)i * ldm + a] = tv;
+            }
+            const int e = expo[(long)s * ldn + i];
+            accs[e * 256 + threadIdx.x] += (double)tv;
+            for (int f = 0; f < n_inframe; f++)
+                accs[(n_expo + f) * 256 + threadIdx.x] += (double)tv * (double)indata[((long)s * n_inframe + f) * ldn + i];
+        }
+    }
+    __syncthreads();
+    if (rg == 0 && a < m) {
+        double tot = 0.0, sabs = 0.0, sq = 0.0;
+        for (int e = 0; e < n_expo; e++) {
+            const double v = accs[e * 256 + c] + accs[e * 256 + 64 + c] + accs[e * 256 + 128 + c] + accs[e * 256 + 192 + c];
+            accs[e * 256 + c] = v;
+            tot += v;
+            sabs += fabs(v);
+            Tsum_image_part[((long)s * m + a) * n_expo + e] = v;
+        }
+        for (int e = 0; e < n_expo; e++) { const double t = accs[e * 256 + c] / sabs; sq += t * t; }
+        double neff = 1.0 / sq;
+        if (fade > 0) { neff *= taper_1d(iy, n2f, fade); neff *= taper_1d(ix, n2f, fade); }
+        Tsum_inpix[(long)s * m + a] = tot;
+        Neff[(long)s * m + a] = neff;
+        for (int f = 0; f < n_inframe; f++) {
+            const int r = (n_expo + f) * 256;
+            outimage[((long)s * n_inframe + f) * m + a] = (float)(accs[r + c] + accs[r + 64 + c] + accs[r + 128 + c] + accs[r + 192 + c]);
+        }
+    }
+}
+
+// Tsum_stamp[s][e] = sum_a Tsum_image[s][a][e] / n2^2   (coadd.py:1339)
+__global__ __launch_bounds__(256) void tsum_stamp_kernel(const double *__restrict__ Tsum_image, int m, int n_expo,
+                                                         int n2, double *__restrict__ Tsum_stamp)
+{
+    __shared__ double red[256];
+    const int s = blockIdx.y, e = blockIdx.x;
+    double v = 0.0;
+    for (int a = threadIdx.x; a < m; a += 256) v += Tsum_image[((long)s * m + a) * n_expo + e];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) Tsum_stamp[(long)s * n_expo + e] = red[0] / ((double)n2 * n2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail)
+{
+    static bool attr_set = false;
+    const size_t bytes = (size_t)(NB * DLD + NB) * sizeof(double);
+    if (!attr_set) {
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(batch), dim3(128), bytes, ctx->stream, L, Dinv, ldn, k, nblk, fail);
+    return check_launch("chol_diag_kernel");
+}
+
+int launch_diag_shift(imcom_ctx *ctx, const double *A, int ldn, const double *inc, const int *ninc, double *dshift, int batch)
+{
+    hipLaunchKernelGGL(diag_shift_kernel, dim3((ldn + 255) / 256, batch), dim3(256), 0, ctx->stream, A, ldn, inc, ninc, dshift, batch);
+    return check_launch("diag_shift_kernel");
+}
+
+int launch_pack_A(imcom_ctx *ctx, const double *A, long lda, const int *n, double *Ap, int ldp, int batch)
+{
+    hipLaunchKernelGGL(pack_A_kernel, dim3((ldp + 255) / 256, ldp, batch), dim3(256), 0, ctx->stream, A, lda, n, Ap, ldp);
+    return check_launch("pack_A_kernel");
+}
+
+int launch_pack_Bt(imcom_ctx *ctx, const double *B, long ldb, int m, const int *n, double *Bt, int ldp, int ldm, int batch)
+{
+    hipLaunchKernelGGL(pack_Bt_kernel, dim3((ldm + 31) / 32, (ldp + 31) / 32, batch), dim3(256), 0, ctx->stream, B, ldb, m, n, Bt, ldp, ldm);
+    return check_launch("pack_Bt_kernel");
+}
+
+int launch_unpack_T(imcom_ctx *ctx, const float *Tt, int ldp, int ldm, const int *n, int m, float *T, long ldt, int batch)
+{
+    if (ldt <= 0) return IMCOM_OK;
+    hipLaunchKernelGGL(unpack_T_kernel, dim3((m + 31) / 32, (unsigned)((ldt + 31) / 32), batch), dim3(256), 0, ctx->stream, Tt, ldp, ldm, n, m, T, ldt);
+    return check_launch("unpack_T_kernel");
+}
+
+int launch_finalize_single(imcom_ctx *ctx, const double *X, const double *Bt, int ldn, int ldm, int m, const int *n,
+                           const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa, int batch)
+{
+    hipLaunchKernelGGL(finalize_single_kernel, dim3(ldm / 64, batch), dim3(256), 0, ctx->stream, X, Bt, ldn, ldm, m, n, kap, Cs, Tt, UC, Sigma, kappa);
+    return check_launch("finalize_single_kernel");
+}
+
+int launch_multi(imcom_ctx *ctx, const double *Xs, long node_stride, const double *Bt, int ldn, int ldm, int m, const int *n,
+                 int nv, const double *kappaC_dev, const double *Cs, double ucmin, double smax, double *Dp, double *Npq,
+                 double *W, float *Tt, float *UC, float *Sigma, float *kappa, int batch)
+{
+    IMCOM_REQUIRE(nv >= 2 && nv <= MAXNV, "multi-kappa: nv=%d outside [2,%d]", nv, MAXNV);
+    hipLaunchKernelGGL(multi_reduce_kernel, dim3(ldm / 64, batch), dim3(256), 0, ctx->stream, Xs, node_stride, Bt, ldn, ldm, m, n, nv, Dp, Npq);
+    IMCOM_TRY(check_launch("multi_reduce_kernel"));
+    hipLaunchKernelGGL(multi_search_kernel, dim3((m + 127) / 128, batch), dim3(128), 0, ctx->stream, Dp, Npq, m, n, nv, kappaC_dev, Cs, ucmin, smax, UC, Sigma, kappa, W);
+    IMCOM_TRY(check_launch("multi_search_kernel"));
+    hipLaunchKernelGGL(multi_combine_kernel, dim3(ldm / 64, batch), dim3(256), 0, ctx->stream, Xs, node_stride, ldn, ldm, m, n, nv, W, Tt);
+    return check_launch("multi_combine_kernel");
+}
+
+int launch_build_reduced_T(imcom_ctx *ctx, const double *Nf, const double *Df, const double *Ef, const double *kappa, int nv,
+                           long m, double ucmin, double smax, double *ok, double *oS, double *oU, double *ow)
+{
+    IMCOM_REQUIRE(nv >= 2 && nv <= MAXNV, "build_reduced_T: nv=%d outside [2,%d]", nv, MAXNV);
+    if (m <= 0) return IMCOM_OK;
+    hipLaunchKernelGGL(build_reduced_T_kernel, dim3((unsigned)((m + 127) / 128)), dim3(128), 0, ctx->stream, Nf, Df, Ef, kappa, nv, m, ucmin, smax, ok, oS, oU, ow);
+    return check_launch("build_reduced_T_kernel");
+}
+
+int launch_lakernel1(imcom_ctx *ctx, const double *lam, const double *mPhalf, long m, long n, long ldp, double C,
+                     double targetleak, double kCmin, double kCmax, int nbis, double *kappa, double *Sigma, double *UC,
+                     double *T, long ldt, double smax)
+{
+    if (m <= 0) return IMCOM_OK;
+    hipLaunchKernelGGL(lakernel1_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, lam, mPhalf, m, n, ldp, C, targetleak, kCmin, kCmax, nbis, kappa, Sigma, UC, T, ldt, smax);
+    return check_launch("lakernel1_kernel");
+}
+
+int launch_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fade)
+{
+    const long tot = nmaps * n2f * n2f;
+    if (tot <= 0 || fade <= 0) return IMCOM_OK;
+    hipLaunchKernelGGL(trapezoid_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, maps, nmaps, n2f, fade);
+    return check_launch("trapezoid_f32_kernel");
+}
+
+int launch_epilogue(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, int m, int ldm, int n2f, int fade, int n2, float *Tt,
+                    const float *indata, int n_inframe, const int *expo, int n_expo, float *outimage, double *Tsum_image,
+                    double *Tsum_stamp, double *Tsum_inpix, double *Neff)
+{
+    const size_t bytes = (size_t)(n_expo + n_inframe) * 256 * sizeof(double);
+    IMCOM_REQUIRE(bytes <= 128 * 1024, "epilogue: n_expo + n_inframe = %d too large", n_expo + n_inframe);
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)coadd_epilogue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(coadd_epilogue_kernel, dim3((m + 63) / 64, batch), dim3(256), bytes, ctx->stream, Tt, ldn, ldm, m, n2f, fade, n_dev, indata, n_inframe, expo, n_expo, outimage, Tsum_image, Tsum_inpix, Neff);
+    IMCOM_TRY(check_launch("coadd_epilogue_kernel"));
+    hipLaunchKernelGGL(tsum_stamp_kernel, dim3(n_expo, batch), dim3(256), 0, ctx->stream, Tsum_image, m, n_expo, n2, Tsum_stamp);
+    return check_launch("tsum_stamp_kernel");
+}
+
+}  // namespace imcom

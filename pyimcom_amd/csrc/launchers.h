@@ -1,0 +1,60 @@
+// launchers.h -- host-side launch functions implemented next to their kernels.
+#pragma once
+#include "common.h"
+
+namespace imcom {
+
+// gemm_f64.hip
+int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int k, int nbmax, int batch,
+                       const int *nblk, const double *dshift);
+int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int k, int nbmax, int batch,
+                     const int *nblk);
+int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
+                     int batch, const int *nblk);
+int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int batch,
+                     const int *nblk);
+int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, int ldm, int k, int batch,
+                      const int *nblk, bool trans);
+int launch_gemm(imcom_ctx *ctx, bool akm, bool bkm, int M, int N, int K, int batch, const double *A, long lda,
+                long strideA, const double *B, long ldb, long strideB, double *C, long ldc, long strideC,
+                double alpha, double beta);
+
+// la_kernels.hip
+int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail);
+int launch_diag_shift(imcom_ctx *ctx, const double *A, int ldn, const double *inc, const int *ninc, double *dshift,
+                      int batch);
+int launch_pack_A(imcom_ctx *ctx, const double *A, long lda, const int *n, double *Ap, int ldp, int batch);
+int launch_pack_Bt(imcom_ctx *ctx, const double *B, long ldb, int m, const int *n, double *Bt, int ldp, int ldm,
+                   int batch);
+int launch_unpack_T(imcom_ctx *ctx, const float *Tt, int ldp, int ldm, const int *n, int m, float *T, long ldt,
+                    int batch);
+int launch_finalize_single(imcom_ctx *ctx, const double *X, const double *Bt, int ldn, int ldm, int m, const int *n,
+                           const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa,
+                           int batch);
+int launch_multi(imcom_ctx *ctx, const double *Xs, long node_stride, const double *Bt, int ldn, int ldm, int m,
+                 const int *n, int nv, const double *kappaC_dev, const double *Cs, double ucmin, double smax,
+                 double *Dp, double *Npq, double *W, float *Tt, float *UC, float *Sigma, float *kappa, int batch);
+int launch_build_reduced_T(imcom_ctx *ctx, const double *Nf, const double *Df, const double *Ef, const double *kappa,
+                           int nv, long m, double ucmin, double smax, double *ok, double *oS, double *oU, double *ow);
+int launch_lakernel1(imcom_ctx *ctx, const double *lam, const double *mPhalf, long m, long n, long ldp, double C,
+                     double targetleak, double kCmin, double kCmax, int nbis, double *kappa, double *Sigma,
+                     double *UC, double *T, long ldt, double smax);
+int launch_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fade);
+int launch_epilogue(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, int m, int ldm, int n2f, int fade, int n2,
+                    float *Tt, const float *indata, int n_inframe, const int *expo, int n_expo, float *outimage,
+                    double *Tsum_image, double *Tsum_stamp, double *Tsum_inpix, double *Neff);
+
+// interp.hip
+int launch_getw(imcom_ctx *ctx, const double *fh, long n, double *w);
+int launch_interp(imcom_ctx *ctx, const double *infunc, int nlayer, int ngy, int ngx, const double *xpos,
+                  const double *ypos, long nout, double *fhatout, int sym);
+int launch_grid(imcom_ctx *ctx, const double *infunc, int ngy, int ngx, const double *xpos, const double *ypos,
+                long npi, int nxo, int nyo, double *fhatout);
+int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
+                   const int *psf, const double *tables, int ng, double nc, double dscale, const int *pair_tab,
+                   const double *pair_pen, int npsf_max, double *A);
+int launch_build_B(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
+                   const int *psf, const double *tables, int ng, double nc, double dscale, const int *io_tab,
+                   int npsf_max, const double *out_x0, const double *out_y0, int n2f, int ldm, double *Bt);
+
+}  // namespace imcom

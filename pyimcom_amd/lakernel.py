@@ -1,0 +1,106 @@
+"""Kernel-class seam: drop-in linear-algebra kernels for ``OutStamp.LAKERNEL``.
+
+Mirrors the contract of the reference's ``_LAKernel`` (src/pyimcom/lakernel.py:50-138, exercised by
+tests/pyimcom/test_la.py:65-90): ``K(outst)`` then ``K()`` reads ``outst.sysmata`` (f64 [N,N], left
+unmodified), ``outst.mhalfb`` (f64 [n_out,m,N]), ``outst.outovlc`` (f64 [n_out]),
+``outst.inpix_cumsum[-1]`` and ``outst.blk.cfg.{n_out,n2f,kappaC_arr,uctarget,sigmamax}``; it writes
+``outst.T`` (f32 [n_out,m,N]) and ``outst.UC/Sigma/kappa`` (f32 [n_out,n2f,n2f]).
+
+Registering::
+
+    from pyimcom.coadd import OutStamp
+    from pyimcom_amd.lakernel import HipCholKernel, HipEigenKernel
+    OutStamp.LAKERNEL["Cholesky"] = HipCholKernel     # or a new key selected by cfg.linear_algebra
+    OutStamp.LAKERNEL["Eigen"] = HipEigenKernel
+
+All arithmetic runs in libimcom_hip (fp64 MFMA); there is no CPU fallback.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import MEM_HOST, check, default_context, lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _HipLAKernel:
+    """Shared constructor / output handling (lakernel.py:68-138)."""
+
+    def __init__(self, outst, ctx=None):
+        self.outst = outst
+        cfg = outst.blk.cfg
+        self.n_out = cfg.n_out
+        self.m = cfg.n2f**2
+        self.n = int(self.outst.inpix_cumsum[-1])
+        self.n2f = cfg.n2f
+        self.kappaC_arr = np.ascontiguousarray(np.atleast_1d(cfg.kappaC_arr), dtype=np.float64)
+        self.nv = self.kappaC_arr.size
+        self.ucmin = float(cfg.uctarget)
+        self.smax = float(cfg.sigmamax)
+        self.ctx = ctx if ctx is not None else default_context()
+        self.info = None
+
+    def _solve(self, A, B, C_, T, UC, Sigma, kappa, info):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def __call__(self):
+        shape = (self.n_out, self.n2f, self.n2f)
+        n, m = self.n, self.m
+        if n == 0:  # lakernel.py:110-119
+            self.outst.T = np.zeros((self.n_out, m, 0), dtype=np.float32)
+            self.outst.UC = np.ones(shape, dtype=np.float32)
+            self.outst.Sigma = np.zeros(shape, dtype=np.float32)
+            self.outst.kappa = np.ones(shape, dtype=np.float32)
+            return
+        A = np.ascontiguousarray(self.outst.sysmata, dtype=np.float64)
+        mBhalf = np.ascontiguousarray(self.outst.mhalfb, dtype=np.float64)
+        Cs = np.ascontiguousarray(np.atleast_1d(self.outst.outovlc), dtype=np.float64)
+        if A.shape != (n, n) or mBhalf.shape != (self.n_out, m, n) or Cs.shape != (self.n_out,):
+            raise ValueError("sysmata / mhalfb / outovlc shapes do not match the stamp")
+        T = np.zeros((self.n_out, m, n), dtype=np.float32)
+        UC = np.zeros((self.n_out, m), dtype=np.float32)
+        Sigma = np.zeros((self.n_out, m), dtype=np.float32)
+        kappa = np.zeros((self.n_out, m), dtype=np.float32)
+        self.info = np.zeros((self.n_out,), dtype=np.int32)
+        # one factorisation per target PSF since kappa = kappaC * C[j_out] (lakernel.py:291-299, 349-353)
+        for j in range(self.n_out):
+            self._solve(A, mBhalf[j], Cs[j : j + 1], T[j], UC[j], Sigma[j], kappa[j], self.info[j : j + 1])
+        self.outst.T = T
+        self.outst.UC = UC.reshape(shape)
+        self.outst.Sigma = Sigma.reshape(shape)
+        self.outst.kappa = kappa.reshape(shape)
+
+
+class HipCholKernel(_HipLAKernel):
+    """Cholesky path: lakernel.CholKernel (lakernel.py:226-394), single- and multi-kappa."""
+
+    def _solve(self, A, B, C_, T, UC, Sigma, kappa, info):
+        n_arr = np.array([self.n], dtype=np.int32)
+        check(lib.imcom_solve_chol(self.ctx.handle, 1, _ptr(n_arr), self.n, self.m, _ptr(A), _ptr(B), _ptr(C_),
+                                   _ptr(self.kappaC_arr), self.nv, self.ucmin, self.smax, _ptr(T), _ptr(UC),
+                                   _ptr(Sigma), _ptr(kappa), _ptr(info), MEM_HOST))
+
+
+class HipEigenKernel(_HipLAKernel):
+    """Eigendecomposition path: lakernel.EigenKernel (lakernel.py:141-223); nbis as line 174."""
+
+    nbis = 13
+
+    def _solve(self, A, B, C_, T, UC, Sigma, kappa, info):
+        n_arr = np.array([self.n], dtype=np.int32)
+        check(lib.imcom_solve_eigen(self.ctx.handle, 1, _ptr(n_arr), self.n, self.m, _ptr(A), _ptr(B), _ptr(C_),
+                                    _ptr(self.kappaC_arr), self.nv, self.ucmin, self.smax, int(self.nbis), _ptr(T),
+                                    _ptr(UC), _ptr(Sigma), _ptr(kappa), _ptr(info), MEM_HOST))
+
+
+LAKERNEL = {"Cholesky": HipCholKernel, "Eigen": HipEigenKernel}
+
+
+def register(outstamp_cls, names=("Cholesky", "Eigen")):
+    """Swap the HIP kernels into ``OutStamp.LAKERNEL`` (coadd.py:839-844) under the given keys."""
+    for name in names:
+        outstamp_cls.LAKERNEL[name] = LAKERNEL[name]

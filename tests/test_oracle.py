@@ -1,0 +1,177 @@
+"""The CPU oracle against golden vectors produced by running the reference (tests/golden/make_golden.py)."""
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.golden.make_golden import cosine_system, gaussian_system
+
+
+def test_getw(golden):
+    g = golden("getw")
+    for fh, w_ref in zip(g["fh"], g["w"]):
+        w = np.zeros(10)
+        orc.iD5512C_getw(w, float(fh))
+        assert np.array_equal(w, w_ref)  # same operation order, no FMA contraction -> bit identical
+    w = np.zeros(10)
+    orc.iD5512C_getw(w, 0.5)  # tests/pyimcom/test_psf.py:55-61: a delta at tap 5
+    assert abs(w[5] - 1) < 1e-8 and np.abs(np.delete(w, 5)).max() < 1e-8
+
+
+def test_interp(golden):
+    g = golden("interp")
+    f = np.full_like(g["f_scatter"], -7.0)
+    orc.iD5512C(g["infunc"], g["x"], g["y"], f)
+    assert np.array_equal(f, g["f_scatter"])
+    assert np.abs(f).max() > 0.98 and (f == -7.0).any()  # off-grid points untouched
+    f = np.full_like(g["f_sym"], -7.0)
+    orc.iD5512C_sym(g["infunc"], g["xs"], g["ys"], f)
+    assert np.array_equal(f, g["f_sym"])
+    f = np.full_like(g["f_grid"], -7.0)
+    orc.gridD5512C(np.ascontiguousarray(g["infunc"][0]), g["xpos"], g["ypos"], f)
+    assert np.array_equal(f, g["f_grid"])
+    f = np.zeros_like(g["f_scatter_b"])
+    orc.iD5512C(g["infunc_b"], g["xb"], g["yb"], f)
+    assert np.array_equal(f, g["f_scatter_b"])
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_lakernel1(golden, tag):
+    g = golden(f"lakernel1_{tag}")
+    A, mB, C = gaussian_system(int(g["n1"]), int(g["m1"]), off=float(g["off"]))
+    lam, Q = np.linalg.eigh(A)
+    mP = np.ascontiguousarray(mB @ Q)
+    assert np.allclose(lam, g["lam"], rtol=0, atol=1e-13)
+    m, n = mP.shape
+    k, S, U, T = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros((m, n))
+    # use the golden lam / mPhalf where stored so that eigh's sign freedom cannot matter
+    if "mPhalf" in g:
+        mP = np.ascontiguousarray(g["mPhalf"])
+    orc.lakernel1(np.ascontiguousarray(g["lam"]), Q, mP, C, 1e-8, 1e-16, 1e16, 53, k, S, U, T, 0.5)
+    if "mPhalf" in g:
+        assert np.array_equal(k, g["kappa"]) and np.array_equal(S, g["Sigma"]) and np.array_equal(U, g["UC"])
+        assert np.array_equal(T, g["T"])
+    else:  # eigenvectors recomputed here: compare at the reference's own C-vs-numba tolerances
+        assert np.abs(k - g["kappa"]).max() < 1e-12 and np.abs(S - g["Sigma"]).max() < 1e-7
+        assert np.abs(U - g["UC"]).max() < 1e-13
+        # known-answer windows of tests/pyimcom/test_routine.py:131-144
+        assert 2.5e-7 < k.min() and k.max() < 3.5e-7
+        assert 0.34 < S.min() and S.max() < 0.38
+        assert 9e-9 < U.min() and U.max() < 1.1e-8
+        assert 0.077 < np.abs(T).max() < 0.079
+
+
+def test_lsolve_sps(golden):
+    g = golden("lsolve_sps")
+    x = np.zeros_like(g["x"])
+    orc.lsolve_sps(g["A"].shape[0], g["A"].copy(), x, g["b"])
+    assert np.array_equal(x, g["x"])
+    assert np.abs(x - np.linalg.solve(g["A"], g["b"])).max() < 1e-10
+
+
+def test_build_reduced_T(golden):
+    g = golden("build_reduced_T")
+    m = g["brt_a_kappa"].size
+    nv = g["kappa_nodes"].size
+    for tag in "abc":
+        ok, oS, oU, ow = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros(m * nv)
+        orc.build_reduced_T_wrap(g["Nflat"], g["Dflat"], g["Eflat"], g["kappa_nodes"], float(g[f"brt_{tag}_ucmin"]),
+                                 float(g[f"brt_{tag}_smax"]), ok, oS, oU, ow)
+        assert np.array_equal(ok, g[f"brt_{tag}_kappa"]) and np.array_equal(ow, g[f"brt_{tag}_w"])
+        assert np.array_equal(oS, g[f"brt_{tag}_Sigma"]) and np.array_equal(oU, g[f"brt_{tag}_UC"])
+
+
+LA_CASES = [
+    ("cos_chol1", "Cholesky", "cos", [1e-2], 1e-4, 0.5, 4), ("cos_cholm", "Cholesky", "cos", [1e-4, 1e-3, 1e-2], 1e-4, 1.0, 4),
+    ("cos_eig1", "Eigen", "cos", [1e-2], 1e-4, 0.5, 4), ("cos_eigm", "Eigen", "cos", [1e-4, 1e-3, 1e-2], 1e-4, 1.0, 4),
+    ("gau_chol1", "Cholesky", "gau", [6e-4], 1e-6, 0.5, 9), ("gau_cholm", "Cholesky", "gau", [1e-5, 1e-4, 1e-3], 1e-6, 0.5, 9),
+    ("gau_eig1", "Eigen", "gau", [6e-4], 1e-6, 0.5, 9), ("gau_eigm", "Eigen", "gau", [1e-5, 1e-4, 1e-3], 1e-6, 0.5, 9),
+]
+
+
+@pytest.mark.parametrize("name,kind,sysn,kC,uct,smax,n2f", LA_CASES)
+def test_la_kernels(golden, name, kind, sysn, kC, uct, smax, n2f):
+    g = golden("lakernel")
+    A, mB, C = g[f"{sysn}_A"], g[f"{sysn}_mBhalf"], np.atleast_1d(g[f"{sysn}_C"])
+    T, UC, Sigma, kappa = orc.la_kernel(kind, A, mB, C, n2f, np.array(kC), uct, smax)
+    # same LAPACK underneath: agreement to rounding (eigen path: eigenvector sign/degeneracy freedom)
+    tolT = 2e-6 * np.abs(g[f"{name}_T"]).max()
+    assert np.abs(T - g[f"{name}_T"]).max() <= tolT
+    assert np.allclose(UC, g[f"{name}_UC"], rtol=2e-5, atol=1e-9)
+    assert np.allclose(Sigma, g[f"{name}_Sigma"], rtol=2e-5, atol=1e-9)
+    assert np.allclose(kappa, g[f"{name}_kappa"], rtol=1e-6, atol=0)
+
+
+def test_la_known_answers(golden):
+    """The range assertions of tests/pyimcom/test_la.py:92-99 and 153-160 on the oracle's outputs."""
+    A, mB, C = cosine_system()
+    T, UC, Sigma, kappa = orc.la_kernel("Eigen", A, mB, np.array([C]), 4, [1e-2], 1e-4, 0.5)
+    for j in range(16):
+        assert (UC.ravel()[j] < 1e-4) if j % 5 == 0 else (0.05 < UC.ravel()[j] < 0.2)
+        assert 0.6 < Sigma.ravel()[j] < 1.0 and 0.002 < kappa.ravel()[j] < 0.004
+    T, UC, Sigma, kappa = orc.la_kernel("Eigen", A, mB, np.array([C]), 4, [1e-4, 1e-3, 1e-2], 1e-4, 1.0)
+    for j in range(16):
+        if j % 5 == 0:
+            assert UC.ravel()[j] < 1e-4 and 5e-4 < kappa.ravel()[j] < 1.5e-3
+        else:
+            assert 0.05 < UC.ravel()[j] < 0.2 and 5e-6 < kappa.ravel()[j] < 1.5e-5
+
+
+def test_repair_and_empty(golden):
+    g = golden("lakernel")
+    A = g["repair_A"]
+    AA = A + g["repair_kappa_abs"] * np.identity(6)
+    L, rep = orc.cholesky_wrapper(AA, A)
+    assert rep and np.allclose(L, g["repair_L"], rtol=0, atol=1e-14)
+    assert np.allclose(AA, g["repair_AA_after"], rtol=0, atol=0)
+    w = np.linalg.eigvalsh(L @ L.T)
+    assert abs(w[0] - 1e-4) < 1e-7  # tests/pyimcom/test_la.py:24
+    T, UC, Sigma, kappa = orc.la_kernel("Cholesky", np.zeros((0, 0)), np.zeros((1, 16, 0)), np.array([1.0]), 4, [1e-3], 1e-4, 0.5)
+    assert T.shape == (1, 16, 0) and np.array_equal(UC, g["empty_UC"]) and np.array_equal(kappa, g["empty_kappa"])
+    assert np.array_equal(Sigma, g["empty_Sigma"])
+
+
+def test_psf_overlap_and_subblocks(golden):
+    g = golden("psfovl")
+    geo = orc.Geom(int(g["npixpsf"]), int(g["oversamp"]), float(g["dtheta_as"]) / 3600.0, float(g["flat_penalty"]))
+    assert geo.nsamp == int(g["nsamp"]) and geo.nc == int(g["nc"]) and geo.nfft == int(g["nfft"])
+    assert geo.dscale == float(g["dscale"])
+    r1, r2, ro = orc.pad_and_rfft2(g["psf1"], geo), orc.pad_and_rfft2(g["psf2"], geo), orc.pad_and_rfft2(g["psfo"], geo)
+    assert np.array_equal(r1, g["rft1"])
+    o_self, o_cross, o_io = orc.overlap_self(r1, geo), orc.overlap_cross(r1, r2, geo), orc.overlap_cross(r1, ro, geo)
+    assert np.array_equal(o_self, g["ovl_self"]) and np.array_equal(o_cross, g["ovl_cross"])
+    assert np.array_equal(o_io, g["ovl_io"]) and np.array_equal(orc.overlap_out_C(ro, geo), g["outovlc"])
+    c1, c2 = g["st1_count"], g["st2_count"]
+    A11 = orc.subblock_ii_self(o_self, 3, geo, g["st1_x"], g["st1_y"], c1)
+    assert np.array_equal(A11, g["A_self_11"]) and np.array_equal(A11, A11.T)
+    assert np.array_equal(orc.subblock_ii_self(o_self, 3, geo, g["st1_x"], g["st1_y"], c1, g["st2_x"], g["st2_y"], c2), g["A_self_12"])
+    assert np.array_equal(orc.subblock_ii_cross(o_cross, geo, g["st1_x"], g["st1_y"], c1, g["st2_x"], g["st2_y"], c2), g["A_cross_12"])
+    ox, oy = g["out_yx"][1, 0, :], g["out_yx"][0, :, 0]
+    assert np.array_equal(orc.subblock_io(o_io, geo, g["st1_x"], g["st1_y"], c1, ox, oy), g["B_io_1all"])
+    assert np.array_equal(orc.subblock_io(o_io, geo, g["st1_x"], g["st1_y"], c1, ox, oy, g["sel1"].astype(int)), g["B_io_1sel"])
+    assert np.array_equal(orc.psf_gaussian(16, 2.5, 2.5), g["gauss_16_25"])
+    assert np.allclose(orc.psf_simple_airy(24, 5.0, obsc=0.31, tophat_conv=4.0, sigma=1.2), g["airy_24"], rtol=0, atol=1e-17)
+
+
+def test_trapezoid_and_coaddition():
+    """coadd.py:1222-1354 restated from the text: hand-computed weights and linear-algebra identities."""
+    a = np.ones((2, 9, 9))
+    orc.trapezoid(a, 2)
+    s = np.arange(1, 5) / 5.0
+    s = s - np.sin(2 * np.pi * s) / (2 * np.pi)
+    assert np.allclose(a[0, 4, :4], s) and np.allclose(a[0, 4, :-5:-1], s) and np.allclose(a[1, :4, 4], s)
+    assert np.isclose(a[0, 0, 0], s[0] ** 2) and np.isclose(a[0, 8, 1], s[0] * s[1]) and a[0, 4, 4] == 1.0
+    rng = np.random.default_rng(5)
+    n2f, n2, N, E = 6, 4, 23, 3
+    T = rng.standard_normal((1, n2f * n2f, N)).astype(np.float32)
+    indata = rng.standard_normal((2, N)).astype(np.float32)
+    expo = np.sort(rng.integers(0, E, N))
+    T0 = T.copy()
+    out, Ts, Tin, Neff = orc.perform_coaddition(T, indata, expo, E, n2f, n2, 1)
+    taper = np.ones((n2f, n2f))
+    orc.trapezoid(taper, 1)
+    Tt = T0[0] * taper.ravel()[:, None]
+    assert np.allclose(out[0, 1].ravel(), Tt @ indata[1], rtol=1e-5, atol=1e-5)
+    assert np.allclose(Tin.ravel(), Tt.sum(axis=1), rtol=1e-5, atol=1e-5)
+    assert np.allclose(Ts[0], [Tt[:, expo == e].sum() / n2**2 for e in range(E)], rtol=1e-5, atol=1e-5)
+    assert (Neff[0, 2:4, 2:4] >= 1 - 1e-9).all() and (Neff[0, 2:4, 2:4] <= E + 1e-9).all()
