@@ -29,6 +29,8 @@ extern "C" {
 #endif
 
 #define IMCOM_HIP_VERSION 100 /* 0.1.0 */
+#define IMCOM_PAIR_SWAP (1 << 29)
+#define IMCOM_PAIR_FLIP (1 << 30)
 
 typedef enum {
     IMCOM_OK = 0,
@@ -51,8 +53,8 @@ int imcom_device_count(int *count);
  * context per GPU (one process per GPU), no inter-GPU traffic (docs/run_README.rst:81-100). */
 int imcom_ctx_create(int device, imcom_ctx **ctx);
 int imcom_ctx_destroy(imcom_ctx *ctx);
-/* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work; NULL restores
- * the context's own stream. */
+/* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work; NULL is the
+ * legacy default stream (torch's default stream).  A fresh context runs on its own stream. */
 int imcom_ctx_set_stream(imcom_ctx *ctx, void *hip_stream);
 int imcom_ctx_sync(imcom_ctx *ctx);
 /* Bytes of device workspace currently held by the context (grows on demand, never inside a call
@@ -139,22 +141,25 @@ int imcom_eigh(imcom_ctx *ctx, int batch, const int *n, int ldn, const double *A
 /* Geometry shared by the table interpolations (PSFGrp.setup / PSFOvl.setup class attributes,
  * psfutil.py:568-613, 1065-1089, carried explicitly instead of process-global state). */
 typedef struct {
-    int nsamp;           /* table side (PSFOvl.nsamp); tables are [nsamp][nsamp], UNPADDED: the
-                            6-pixel zero border of np.pad(...,6) is applied by the kernels */
+    int nsamp;           /* PSFOvl.nsamp.  Tables handed to the builders carry the 6-pixel zero border
+                            of np.pad(..., 6) (psfutil.py:1471-1473, 1580, 1696): [nsamp+12][nsamp+12] */
     double nc;           /* PSFOvl.nc, table centre */
     double dscale;       /* PSFGrp.dscale: output pixels per table sample */
     double flat_penalty; /* PSFOvl.flat_penalty */
 } imcom_table_geom;
 
-/* A[s][i][j] for i,j < n[s] (exactly symmetric: lower triangle interpolated, mirrored), with the
+/* A[s][i][j] for i,j < n[s] (exactly symmetric: the element with i before j is interpolated and
+ * mirrored, as the reference's sub-block assembly does, coadd.py:1038-1068), with the
  * padding rows/cols n[s] <= i < ldn set to the identity so the factorisation kernels can run on
  * whole tiles.
  *   x,y          [batch][ldn] input pixel positions in output-pixel units (coadd.py:969-972)
  *   psf          [batch][ldn] int32: stamp-local PSF index of each pixel, < npsf_max
- *   tables       [ntab][nsamp][nsamp] overlap tables (PSFOvl.ovl_arr entries)
- *   pair_tab     [batch][npsf_max][npsf_max] int32: table of the ordered PSF pair (p_i,p_j);
- *                t >= 0 -> tables[t]; t < 0 -> tables[-t-1] flipped in both axes (the np.flip of
- *                psfutil.py:1658-1665)
+ *   tables       [ntab][nsamp+12][nsamp+12] zero-bordered overlap tables (PSFOvl.ovl_arr entries)
+ *   pair_tab     [batch][npsf_max][npsf_max] int32 code of the ordered PSF pair (p_i,p_j), i before j:
+ *                bits 0..27 table index; bit 30 (IMCOM_PAIR_FLIP) = table flipped in both axes (the
+ *                np.flip of psfutil.py:1658-1665); bit 29 (IMCOM_PAIR_SWAP) = the reference evaluated
+ *                this block from the other stamp's side and transposed it (psfutil.py:1990-1996), i.e.
+ *                interpolate at r_j - r_i; negative = no table (value 0 + penalty)
  *   pair_pen     [batch][npsf_max][npsf_max] constant added to every element of the pair's block:
  *                -flat_penalty/n_in (+flat_penalty for the same exposure), psfutil.py:1482-1486,
  *                1705-1708
@@ -197,7 +202,7 @@ int imcom_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fa
 /* PSFGrp.accel_pad_and_rfft2 + PSFOvl._build_psfovl (psfutil.py:943-986, 1244-1294): correlation
  * tables out[p][q] = irfft2(rft(psf1[p]) * conj(rft(psf2[q]))), rolled by nc and cropped to
  * nsamp x nsamp.  psf1[n1][nsamp][nsamp], psf2[n2][nsamp][nsamp]; pairs[npairs][2] HOST lists the
- * (p,q) wanted, tables[npairs][nsamp][nsamp]. */
+ * (p,q) wanted, tables[npairs][nsamp+12][nsamp+12] (zero border included). */
 int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, const double *psf2, int n2,
                       int nsamp, int nfft, const int *pairs_host, int npairs, double *tables);
 

@@ -37,6 +37,12 @@ def _load():
             "(python -c 'import __graft_entry__ as g; g.build()' at the repo root, or make -C pyimcom_amd/csrc). "
             "pyimcom_amd has no CPU fallback."
         )
+    # torch ships its own HIP runtime under the same SONAME (libamdhip64.so.7).  One process must hold
+    # exactly one HIP runtime, so torch's has to be the first one loaded; libimcom_hip then binds to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     return C.CDLL(LIB_PATH)
 
 

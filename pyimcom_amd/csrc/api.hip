@@ -315,7 +315,7 @@ int imcom_ctx_destroy(imcom_ctx *ctx)
 int imcom_ctx_set_stream(imcom_ctx *ctx, void *hip_stream)
 {
     IMCOM_TRY(check_ctx(ctx));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream, which is what torch's default is
     return IMCOM_OK;
 }
 

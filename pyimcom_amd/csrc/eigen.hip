@@ -14,9 +14,4 @@ int imcom_solve_eigen(imcom_ctx *, int, const int *, int, int, const double *, c
     set_error("imcom_solve_eigen: not built yet");
     return IMCOM_ERR_UNSUPPORTED;
 }
-int imcom_psf_overlap(imcom_ctx *, const double *, int, const double *, int, int, int, const int *, int, double *)
-{
-    set_error("imcom_psf_overlap: not built yet");
-    return IMCOM_ERR_UNSUPPORTED;
-}
 }

@@ -1,0 +1,118 @@
+"""Checker for the device-resident stamp path: runs a batch on the GPU and compares every output with
+the CPU oracle on the same inputs.  This is the ONLY module of the package that touches oracle/ -- it is
+the smoke test / parity harness (used by __graft_entry__.smoke() and tests/), not part of the product
+path."""
+
+import numpy as np
+
+# tolerances of the resident path vs the oracle (fp64 internals, float32 stored outputs)
+TOL = dict(
+    tables=2e-13,   # |dtable| / max|table|: DFT-by-GEMM vs pocketfft
+    A=1e-11,        # |dA| / max|A|  (same interpolation, FMA contraction + table rounding)
+    B=1e-11,
+    T=1e-6,         # max|dT| <= 1e-6 max|T| after the float32 cast (scaled up by the condition number, see below)
+    map_rtol=1e-5, map_atol=1e-9,
+    image=2e-5,     # |d outimage| / (sum_i |T_ai| |indata_i|): float32 accumulation differences
+)
+
+
+def oracle_tables(cfg, psfs, target):
+    from oracle import oracle as orc
+
+    g = orc.Geom(cfg.npixpsf, cfg.oversamp, cfg.dtheta_as / 3600.0, cfg.flat_penalty)
+    r_in, r_out = orc.pad_and_rfft2(psfs, g), orc.pad_and_rfft2(target, g)
+    tri = orc.overlap_self(r_in, g)
+    io = orc.overlap_cross(r_in, r_out, g)[:, 0]
+    C = orc.overlap_out_C(r_out, g)[0]
+    tabs = np.concatenate([tri, io])
+    return g, np.pad(tabs, ((0, 0), (6, 6), (6, 6))), float(C)
+
+
+def oracle_stamp(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab):
+    """Full oracle result for one stamp: A, Bt, T, maps, coaddition."""
+    from oracle import oracle as orc
+
+    A, Bt = orc.stamp_system(g, stamp.x, stamp.y, stamp.expo, tables_pad, pair_tab, pair_pen, io_tab, stamp.out_x0,
+                             stamp.out_y0, cfg.n2f)
+    mB = np.ascontiguousarray(Bt.T)
+    T, UC, Sigma, kappa, info = orc.chol_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
+    s = (cfg.n2f, cfg.n2f)
+    UC, Sigma, kappa = UC.reshape(s).copy(), Sigma.reshape(s).copy(), kappa.reshape(s).copy()
+    if cfg.fade > 0:  # coadd.py:1118-1122
+        for a in (kappa, Sigma, UC):
+            orc.trapezoid(a, cfg.fade)
+    T3 = T[None].copy()
+    outimage, Tsum_stamp, Tsum_inpix, Neff = orc.perform_coaddition(T3, stamp.indata, stamp.expo, stamp.n_expo, cfg.n2f,
+                                                                     cfg.n2, cfg.fade)
+    return dict(A=A, Bt=Bt, T=T3[0], UC=UC, Sigma=Sigma, kappa=kappa, outimage=outimage[0], Tsum_stamp=Tsum_stamp[0],
+                Tsum_inpix=Tsum_inpix[0], Neff=Neff[0], info=info)
+
+
+def check_batch(cfg, n_stamps=2, first_id=0, verbose=False, device="cuda:0"):
+    """Run n_stamps synthetic stamps of cfg through the HIP path and assert parity with the oracle."""
+    import torch
+
+    from . import synth
+    from .stamps import PSFGroupTables, StampBatch
+
+    stamps = [synth.make_stamp(cfg, first_id + i) for i in range(n_stamps)]
+    n_expo = max(s.n_expo for s in stamps)
+    psfs, target = synth.make_psfs(cfg, n_expo)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft, device=device)
+    batch = StampBatch(cfg, stamps, tabs, device=device)
+    res = batch.run()
+    torch.cuda.synchronize()
+    report = {}
+    g, tabs_ref, C_ref = oracle_tables(cfg, psfs, target)
+    t_gpu = tabs.tables.cpu().numpy()
+    report["tables"] = float(np.abs(t_gpu - tabs_ref).max() / np.abs(tabs_ref).max())
+    report["C"] = abs(tabs.C - C_ref) / C_ref
+    assert report["tables"] < TOL["tables"] and report["C"] < 1e-12, report
+    pair_tab, pair_pen, io_tab = tabs.pair_maps(cfg.flat_penalty)
+    for b, st in enumerate(stamps):
+        # the oracle interpolates the GPU's own tables so that A/B compare the interpolation alone
+        ref = oracle_stamp(cfg, g, t_gpu, tabs.C, st, pair_tab, pair_pen, io_tab)
+        n, m = st.n, cfg.m
+        A = batch.A[b, :n, :n].cpu().numpy()
+        Bt = batch.Bt[b, :n, :m].cpu().numpy()
+        eA = np.abs(A - ref["A"]).max() / np.abs(ref["A"]).max()
+        eB = np.abs(Bt - ref["Bt"]).max() / np.abs(ref["Bt"]).max()
+        assert np.array_equal(A, A.T), "A must be exactly symmetric"
+        pad = batch.A[b, n:, :].cpu().numpy()
+        assert np.array_equal(pad, np.eye(batch.ldn)[n:]), "identity padding"
+        T = res.T(b).cpu().numpy()
+        eT = np.abs(T - ref["T"]).max() / np.abs(ref["T"]).max()
+        # forward error of a backward-stable solve ~ cond * eps: allow for it on top of the float32 rounding
+        lam = np.linalg.eigvalsh(ref["A"])
+        cond = (lam[-1] + cfg.kappaC[0] * tabs.C) / (max(lam[0], 0.0) + cfg.kappaC[0] * tabs.C)
+        tolT = TOL["T"] + 50 * cond * 2.2e-16
+        ok = eA < TOL["A"] and eB < TOL["B"] and eT < tolT
+        maps = {}
+        for name in ("UC", "Sigma", "kappa"):
+            a, r = getattr(res, name)[b].cpu().numpy(), ref[name]
+            maps[name] = float(np.abs(a - r).max())
+            ok &= np.allclose(a, r, rtol=TOL["map_rtol"] + 50 * cond * 2.2e-16, atol=TOL["map_atol"])
+        scale = np.abs(ref["T"]) @ np.abs(st.indata.T).astype(np.float64)  # [m, n_inframe]
+        eI = np.abs(res.outimage[b].cpu().numpy().reshape(cfg.n_inframe, m) - ref["outimage"].reshape(cfg.n_inframe, m))
+        eI = float((eI / np.maximum(scale.T, 1e-30)).max())
+        sT = np.abs(ref["T"]).sum(axis=1)
+        eTs = float((np.abs(res.Tsum_inpix[b].cpu().numpy().ravel() - ref["Tsum_inpix"].ravel()) / sT).max())
+        eSt = float(np.abs(res.Tsum_stamp[b, : st.n_expo].cpu().numpy() - ref["Tsum_stamp"]).max() / (sT.sum() / cfg.n2**2))
+        rN = res.Neff[b].cpu().numpy()
+        eN = float(np.abs(rN - ref["Neff"]).max() / np.abs(ref["Neff"]).max())
+        ok &= eI < TOL["image"] and eTs < TOL["image"] and eSt < TOL["image"] and eN < 1e-3
+        report[f"stamp{b}"] = dict(n=int(n), cond=float(cond), A=float(eA), B=float(eB), T=float(eT), tolT=float(tolT), image=eI,
+                                   Tsum_inpix=eTs, Tsum_stamp=eSt, Neff=eN, info=int(res.info[b]), **maps)
+        if verbose:
+            print(f"[smoke] {cfg.name} stamp {b}:", report[f"stamp{b}"])
+        assert ok, report[f"stamp{b}"]
+    return report
+
+
+def run(verbose=False):
+    from . import synth
+
+    rep = check_batch(synth.CONFIGS["tiny"], n_stamps=2, verbose=verbose)
+    if verbose:
+        print("[smoke] tables rel err", rep["tables"], "C rel err", rep["C"], "-> OK")
+    return rep

@@ -1,0 +1,209 @@
+"""Device-resident stamp path: PSF overlap tables -> A, B -> Cholesky solve -> maps -> coaddition.
+
+Host-side mirror of the reference's stamp driver for a BATCH of independent postage stamps
+(OutStamp._build_system_matrices + _perform_coaddition, reference src/pyimcom/coadd.py:1002-1122,
+1294-1363; PSFGrp / PSFOvl, psfutil.py:520-1761).  torch is used only to own device memory and the
+stream; every number is produced by libimcom_hip kernels through the C-ABI (include/imcom_hip.h).
+"""
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from ._lib import PAIR_FLIP, TableGeom, check, default_context, lib
+
+NB = 128
+
+
+def _roundup(v, a):
+    return (v + a - 1) // a * a
+
+
+def _dp(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class PSFGroupTables:
+    """Overlap tables of ONE input PSF group against itself and the target PSF(s).
+
+    Mirrors PSFOvl(grp) (input self-overlap, triangle storage psfutil.py:1139-1175, 1270-1278),
+    PSFOvl(grp, outgrp) (input-output, 1259-1265) and the output self-overlap value C (1283-1290).
+    Table stack order: the E(E+1)/2 self tables in triangle order, then the E input-output tables.
+    """
+
+    def __init__(self, psf_in, psf_out, nfft, ctx=None, device="cuda:0"):
+        self.ctx = ctx or default_context()
+        E, ns, _ = psf_in.shape
+        self.n_psf, self.nsamp, self.nfft = E, ns, nfft
+        dev = torch.device(device)
+        pin = torch.as_tensor(np.ascontiguousarray(psf_in, dtype=np.float64), device=dev)
+        pout = torch.as_tensor(np.ascontiguousarray(psf_out[:1], dtype=np.float64), device=dev)
+        ng = ns + 12
+        self.ntri = E * (E + 1) // 2
+        self.tables = torch.empty((self.ntri + E, ng, ng), dtype=torch.float64, device=dev)
+        self._set_stream()
+        pairs = np.array([(i, j) for i in range(E) for j in range(i, E)], dtype=np.int32)
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pin), E, ns, nfft, _hp(pairs), len(pairs),
+                                    _dp(self.tables[: self.ntri])))
+        pairs = np.array([(i, 0) for i in range(E)], dtype=np.int32)
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pout), 1, ns, nfft, _hp(pairs), E,
+                                    _dp(self.tables[self.ntri :])))
+        cc = torch.empty((1, ng, ng), dtype=torch.float64, device=dev)
+        pairs = np.array([(0, 0)], dtype=np.int32)
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pout), 1, _dp(pout), 1, ns, nfft, _hp(pairs), 1, _dp(cc)))
+        nc = ns // 2
+        self.C = float(cc[0, 6 + nc, 6 + nc].item())  # psfutil.py:1290
+
+    def _set_stream(self):
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def tri(self, i, j):
+        """PSFOvl._idx_square2triangle (psfutil.py:1175)."""
+        assert i <= j
+        return (2 * self.n_psf - i + 1) * i // 2 + j - i
+
+    def pair_maps(self, flat_penalty):
+        """pair_tab / pair_pen / io_tab for stamps whose pixels all belong to this group, local PSF
+        index = exposure index (psfutil.py:1645-1708: table (j,i) for j <= i, the flipped (i,j) one
+        otherwise; penalty -fp/n_psf, +fp on the same exposure)."""
+        E = self.n_psf
+        tab = np.zeros((E, E), np.int32)
+        pen = np.zeros((E, E), np.float64)
+        for a in range(E):
+            for b in range(E):
+                tab[a, b] = self.tri(a, b) if a <= b else (self.tri(b, a) | PAIR_FLIP)
+                if flat_penalty != 0.0:
+                    v = 0.0
+                    v -= flat_penalty / E
+                    if a == b:
+                        v += flat_penalty
+                    pen[a, b] = v
+        io = np.arange(E, dtype=np.int32) + self.ntri
+        return tab, pen, io
+
+
+@dataclass
+class StampBatchResult:
+    Tt: torch.Tensor          # [batch, ldn, ldm] float32, input-pixel-major T (tapered when fade > 0)
+    UC: torch.Tensor          # [batch, n2f, n2f] float32
+    Sigma: torch.Tensor
+    kappa: torch.Tensor
+    outimage: torch.Tensor    # [batch, n_inframe, n2f, n2f] float32
+    Tsum_stamp: torch.Tensor  # [batch, n_expo] float64
+    Tsum_inpix: torch.Tensor  # [batch, n2f, n2f] float64
+    Neff: torch.Tensor
+    info: np.ndarray
+    n: np.ndarray
+
+    def T(self, s):
+        """T of stamp s in the reference layout [m, N] (lakernel.py:96)."""
+        m = self.UC.shape[-1] * self.UC.shape[-2]
+        return self.Tt[s, : int(self.n[s]), :m].T.contiguous()
+
+
+class StampBatch:
+    """A batch of stamps that share one PSF group, resident on one GPU.
+
+    Upload once (constructor), then ``build()`` (A and B), ``solve()``, ``coadd()`` or ``run()`` for all
+    three; buffers are reused across calls so a timed loop allocates nothing.
+    """
+
+    def __init__(self, cfg, stamps, tables: PSFGroupTables, ctx=None, device="cuda:0", ldn=None):
+        self.cfg, self.tables = cfg, tables
+        self.ctx = ctx or tables.ctx
+        dev = self.dev = torch.device(device)
+        self.batch = B = len(stamps)
+        self.n = np.array([s.n for s in stamps], dtype=np.int32)
+        self.ldn = ldn or _roundup(max(int(self.n.max()), 1), NB)
+        self.m, self.n2f = cfg.m, cfg.n2f
+        self.ldm = _roundup(self.m, NB)
+        self.n_expo = max(s.n_expo for s in stamps)
+        assert self.n_expo <= tables.n_psf
+        f64, i32, f32 = torch.float64, torch.int32, torch.float32
+        x = np.zeros((B, self.ldn)); y = np.zeros((B, self.ldn))
+        psf = np.zeros((B, self.ldn), np.int32)
+        indata = np.zeros((B, cfg.n_inframe, self.ldn), np.float32)
+        for b, s in enumerate(stamps):
+            x[b, : s.n], y[b, : s.n], psf[b, : s.n] = s.x, s.y, s.expo
+            indata[b, :, : s.n] = s.indata
+        self.x, self.y = torch.as_tensor(x, device=dev), torch.as_tensor(y, device=dev)
+        self.psf = torch.as_tensor(psf, device=dev)
+        self.indata = torch.as_tensor(indata, device=dev)
+        self.out_x0 = torch.as_tensor(np.array([s.out_x0 for s in stamps]), device=dev)
+        self.out_y0 = torch.as_tensor(np.array([s.out_y0 for s in stamps]), device=dev)
+        tab, pen, io = tables.pair_maps(cfg.flat_penalty)
+        P = self.npsf = tables.n_psf
+        self.pair_tab = torch.as_tensor(np.broadcast_to(tab, (B, P, P)).copy(), device=dev)
+        self.pair_pen = torch.as_tensor(np.broadcast_to(pen, (B, P, P)).copy(), device=dev)
+        self.io_tab = torch.as_tensor(np.broadcast_to(io, (B, P)).copy(), device=dev)
+        self.geom = TableGeom(tables.nsamp, float(tables.nsamp // 2), float(cfg.dscale), float(cfg.flat_penalty))
+        self.Cs = np.full((B,), tables.C, dtype=np.float64)
+        self.kappaC = np.ascontiguousarray(cfg.kappaC, dtype=np.float64)
+        # device buffers
+        self.A = torch.empty((B, self.ldn, self.ldn), dtype=f64, device=dev)
+        self.Bt = torch.empty((B, self.ldn, self.ldm), dtype=f64, device=dev)
+        self.Tt = torch.empty((B, self.ldn, self.ldm), dtype=f32, device=dev)
+        self.UC = torch.empty((B, self.m), dtype=f32, device=dev)
+        self.Sigma = torch.empty((B, self.m), dtype=f32, device=dev)
+        self.kappa = torch.empty((B, self.m), dtype=f32, device=dev)
+        self.outimage = torch.empty((B, cfg.n_inframe, self.m), dtype=f32, device=dev)
+        self.Tsum_stamp = torch.empty((B, self.n_expo), dtype=f64, device=dev)
+        self.Tsum_inpix = torch.empty((B, self.m), dtype=f64, device=dev)
+        self.Neff = torch.empty((B, self.m), dtype=f64, device=dev)
+        self.info = np.zeros((B,), np.int32)
+
+    def _stream(self):
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def build(self):
+        """A (psfutil.py:1401-1495, 1597-1732 + coadd.py:1027-1068) and B (1497-1595 + coadd.py:1075-1082)."""
+        self._stream()
+        h = self.ctx.handle
+        check(lib.imcom_build_A(h, self.batch, _hp(self.n), self.ldn, _dp(self.x), _dp(self.y), _dp(self.psf),
+                                _dp(self.tables.tables), self.tables.tables.shape[0], C.byref(self.geom),
+                                _dp(self.pair_tab), _dp(self.pair_pen), self.npsf, _dp(self.A)))
+        check(lib.imcom_build_B(h, self.batch, _hp(self.n), self.ldn, _dp(self.x), _dp(self.y), _dp(self.psf),
+                                _dp(self.tables.tables), self.tables.tables.shape[0], C.byref(self.geom),
+                                _dp(self.io_tab), self.npsf, _dp(self.out_x0), _dp(self.out_y0), self.n2f, self.ldm,
+                                _dp(self.Bt)))
+
+    def solve(self):
+        """lakernel.CholKernel (lakernel.py:281-394) + the map taper of coadd.py:1118-1122."""
+        self._stream()
+        cfg = self.cfg
+        if cfg.kernel != "Cholesky":
+            raise NotImplementedError("resident path: Cholesky kernel only (use lakernel.HipEigenKernel)")
+        check(lib.imcom_solve_chol_resident(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm,
+                                            _dp(self.A), _dp(self.Bt), _hp(self.Cs), _hp(self.kappaC), len(self.kappaC),
+                                            float(cfg.uctarget), float(cfg.sigmamax), _dp(self.Tt), _dp(self.UC),
+                                            _dp(self.Sigma), _dp(self.kappa), _hp(self.info)))
+        if cfg.fade > 0:
+            for t in (self.kappa, self.Sigma, self.UC):
+                check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))
+
+    def coadd(self):
+        """OutStamp._perform_coaddition (coadd.py:1294-1363)."""
+        self._stream()
+        cfg = self.cfg
+        check(lib.imcom_coadd_epilogue(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, self.n2f,
+                                       cfg.fade, cfg.n2, _dp(self.Tt), _dp(self.indata), cfg.n_inframe, _dp(self.psf),
+                                       self.n_expo, _dp(self.outimage), _dp(self.Tsum_stamp), _dp(self.Tsum_inpix),
+                                       _dp(self.Neff)))
+
+    def run(self):
+        self.build()
+        self.solve()
+        self.coadd()
+        return self.result()
+
+    def result(self):
+        s2 = (self.batch, self.n2f, self.n2f)
+        return StampBatchResult(self.Tt, self.UC.view(s2), self.Sigma.view(s2), self.kappa.view(s2),
+                                self.outimage.view(self.batch, self.cfg.n_inframe, self.n2f, self.n2f), self.Tsum_stamp,
+                                self.Tsum_inpix.view(s2), self.Neff.view(s2), self.info.copy(), self.n.copy())

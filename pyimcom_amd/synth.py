@@ -1,0 +1,235 @@
+"""Synthetic postage-stamp workloads: the inputs of the stamp seam without
+FITS/WCS machinery.  Host-side NumPy set-up code: it produces what pyimcom's Block/InStamp layers would
+hand to the stamp driver (pixel positions in output-pixel units, pixel values, sampled PSFs); none of it
+is on the timed path.
+
+Geometry follows the reference: OutStamp (j_st, i_st) = (1, 1) covers output pixels 0..n2-1 plus
+`fade` transition pixels each side (coadd.py:869-882); the nine neighbouring InStamps are the n2 x n2
+cells around it (coadd.py:207, 348-349, 853); selection = whole centre cell, edge strips within rho,
+corner quarter discs of radius rho = INPAD/dtheta output pixels (coadd.py:716-749, 923-931).
+"""
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+NATIVE_ARCSEC = 0.11  # Settings.pixscale_native (config.py)
+
+
+@dataclass
+class WorkloadConfig:
+    name: str
+    n2: int
+    fade: int
+    dtheta_as: float      # output pixel scale, arcsec
+    n_expo: int           # exposures (E); a (lo, hi) tuple draws a uniform integer per stamp
+    inpad_as: float       # INPAD, arcsec
+    kernel: str           # "Cholesky" | "Eigen"
+    kappaC: tuple
+    psf: str = "airy"     # "gauss" | "airy"
+    npixpsf: int = 48
+    oversamp: int = 8
+    uctarget: float = 1e-6
+    sigmamax: float = 0.5
+    flat_penalty: float = 1e-7
+    n_inframe: int = 2
+    extrasmooth: float = 0.934  # target Gaussian sigma in native pixels
+    mask_frac: float = 1e-3
+    psf_sigma: float = 0.9      # Gaussian input PSF width, native pixels (cfg-1: 0.9 + 0.05 e)
+
+    @property
+    def n2f(self):
+        return self.n2 + 2 * self.fade
+
+    @property
+    def m(self):
+        return self.n2f**2
+
+    @property
+    def nsamp(self):
+        return self.npixpsf * self.oversamp - 1
+
+    @property
+    def nc(self):
+        return self.nsamp // 2
+
+    @property
+    def nfft(self):
+        return self.npixpsf * self.oversamp * 2
+
+    @property
+    def dscale(self):
+        arcsec = np.pi / 180.0 / 60.0 / 60.0  # psfutil.py:610 with config.py:85-98
+        return ((NATIVE_ARCSEC * arcsec) / arcsec) / self.oversamp / ((self.dtheta_as / 3600.0) * 3600)
+
+    @property
+    def rho(self):
+        return self.inpad_as / self.dtheta_as  # coadd.py:923
+
+
+# BASELINE.json configs
+CONFIGS = {
+    "cfg1": WorkloadConfig("cfg1", 32, 0, 0.0390625, 4, 0.6, "Cholesky", (6e-4,), psf="gauss"),
+    "cfg2": WorkloadConfig("cfg2", 48, 0, 1.25 / 48, 6, 0.45, "Cholesky", (6e-4,)),
+    "cfg2f": WorkloadConfig("cfg2f", 48, 3, 1.25 / 48, 6, 0.45, "Cholesky", (6e-4,)),
+    "cfg3": WorkloadConfig("cfg3", 48, 0, 1.25 / 48, 8, 0.45, "Eigen", (1e-5, 1e-4, 1e-3)),
+    "cfg4": WorkloadConfig("cfg4", 48, 0, 1.25 / 48, (6, 10), 0.45, "Cholesky", (6e-4,)),
+    "cfg5": WorkloadConfig("cfg5", 48, 0, 1.25 / 48, 16, 0.45, "Cholesky", (6e-4,)),
+    # small cases for parity tests (oracle finishes in seconds)
+    "tiny": WorkloadConfig("tiny", 8, 1, 0.11 / 2.5, 3, 0.12, "Cholesky", (6e-4,), psf="gauss", npixpsf=8, oversamp=4,
+                           psf_sigma=0.45, extrasmooth=0.6),
+    "small": WorkloadConfig("small", 12, 2, 0.11 / 3.0, 4, 0.2, "Cholesky", (6e-4,), psf="gauss", npixpsf=12, oversamp=6,
+                            psf_sigma=0.5, extrasmooth=0.7),
+    "smallm": WorkloadConfig("smallm", 12, 0, 0.11 / 3.0, 4, 0.2, "Cholesky", (1e-5, 1e-4, 1e-3), psf="gauss", npixpsf=12,
+                             oversamp=6, psf_sigma=0.5, extrasmooth=0.7),
+}
+
+
+def _gauss_psf(cfg, sigma_tab, e1=0.0, e2=0.0):
+    ns = cfg.nsamp
+    c = (ns - 1) / 2.0
+    y, x = np.mgrid[0:ns, 0:ns].astype(np.float64)
+    x -= c
+    y -= c
+    u = x * (1 + e1) + y * e2
+    v = y * (1 - e1) + x * e2
+    p = np.exp(-0.5 * (u * u + v * v) / sigma_tab**2)
+    return p / p.sum()
+
+
+def _airy_psf(cfg, e1=0.0, e2=0.0):
+    """Obscured Airy (obsc 0.31, lambda/D = 1.25 native px, QFilterNative[H158]) convolved with the native
+    pixel top-hat and a Gaussian of 0.3 px -- the construction of OutPSF.psf_simple_airy
+    (psfutil.py:149-223) on sheared coordinates (per-exposure ellipticity)."""
+    from scipy.special import jv
+
+    ns, ov = cfg.nsamp, cfg.oversamp
+    ldp, obsc, tophat, sigma = 1.250 * ov, 0.31, 1.0 * ov, 0.3 * ov
+    kp = 1 + int(np.ceil(tophat + 6 * sigma))
+    npad = ns + 2 * kp
+    y, x = np.mgrid[(1 - npad) / 2 : (npad - 1) / 2 : npad * 1j, (1 - npad) / 2 : (npad - 1) / 2 : npad * 1j]
+    u = x * (1 + e1) + y * e2
+    v = y * (1 - e1) + x * e2
+    r = np.sqrt(u * u + v * v) / ldp
+    I_ = (np.square(jv(0, np.pi * r) + jv(2, np.pi * r) - obsc**2 * (jv(0, np.pi * r * obsc) + jv(2, np.pi * r * obsc)))
+          / (4.0 * ldp**2 * (1 - obsc**2)) * np.pi)
+    It = np.fft.rfft2(I_)
+    uxa = np.linspace(0, 1 - 1 / npad, npad)
+    uxa[-(npad // 2):] -= 1
+    ux = np.tile(uxa[None, : npad // 2 + 1], (npad, 1))
+    uy = np.tile(uxa[:, None], (1, npad // 2 + 1))
+    It *= np.exp(-2.0 * np.pi**2 * (np.square(ux * sigma) + np.square(uy * sigma))) * np.sinc(ux * tophat) * np.sinc(uy * tophat)
+    I_ = np.fft.irfft2(It, s=(npad, npad))[kp:-kp, kp:-kp]
+    return I_ / I_.sum()
+
+
+def make_psfs(cfg, n_expo, seed=20260723):
+    """Sampled input PSFs [E, nsamp, nsamp] (PSFGrp.psf_arr, psfutil.py:838) and the target PSF [1, nsamp, nsamp]."""
+    rng = np.random.default_rng(seed)
+    psfs = np.zeros((n_expo, cfg.nsamp, cfg.nsamp))
+    for e in range(n_expo):
+        if cfg.psf == "gauss":
+            psfs[e] = _gauss_psf(cfg, (cfg.psf_sigma + 0.05 * e) * cfg.oversamp)
+        else:
+            ang = rng.uniform(0, np.pi)
+            psfs[e] = _airy_psf(cfg, 0.02 * np.cos(2 * ang), 0.02 * np.sin(2 * ang))
+    target = _gauss_psf(cfg, cfg.extrasmooth * cfg.oversamp)[None]
+    return psfs, target
+
+
+@dataclass
+class Stamp:
+    """One postage stamp at the stamp seam (what OutStamp._process_input_stamps produces)."""
+    x: np.ndarray         # [N] f64 input pixel x, output-pixel units (coadd.py:972)
+    y: np.ndarray         # [N] f64
+    expo: np.ndarray      # [N] int32 exposure index of each pixel
+    seg: np.ndarray       # [N] int32 InStamp segment 0..8 (order of coadd.py:853)
+    indata: np.ndarray    # [n_inframe, N] f32 (coadd.py:975)
+    out_x0: float         # x of output pixel column 0 (left - fade)
+    out_y0: float
+    n_expo: int
+    inpix_cumsum: np.ndarray = field(default=None)  # [10] (coadd.py:937)
+
+    @property
+    def n(self):
+        return self.x.size
+
+
+def make_stamp(cfg, stamp_id, n_expo=None):
+    """Input pixels of one stamp: per exposure a rotated, dithered regular lattice of native pixels,
+    0.1 % masked, selected and ordered as the reference does (9 InStamp segments, exposure-major inside)."""
+    rng = np.random.default_rng(20260723 + stamp_id)
+    if n_expo is None:
+        n_expo = cfg.n_expo if isinstance(cfg.n_expo, int) else int(rng.integers(cfg.n_expo[0], cfg.n_expo[1] + 1))
+    n2, rho, p = cfg.n2, cfg.rho, NATIVE_ARCSEC / cfg.dtheta_as
+    assert rho <= n2, "INPAD larger than a stamp (coadd.py:1915)"
+    left, bottom = 0, 0
+    right, top = n2 - 1, n2 - 1
+    per_expo = []
+    half = int(np.ceil((1.5 * n2 + 2) * np.sqrt(2) / p)) + 2
+    for e in range(n_expo):
+        th = np.deg2rad(20.0 * e / n_expo + rng.uniform(-2.0, 2.0))
+        dx, dy = rng.uniform(0, p, 2)
+        jj, ii = np.mgrid[-half : half + 1, -half : half + 1]
+        gx, gy = ii.ravel() * p, jj.ravel() * p
+        x = (n2 - 1) / 2.0 + dx + np.cos(th) * gx - np.sin(th) * gy
+        y = (n2 - 1) / 2.0 + dy + np.sin(th) * gx + np.cos(th) * gy
+        keep = rng.uniform(size=x.size) >= cfg.mask_frac
+        per_expo.append((x[keep], y[keep]))
+    xs, ys, es, ss = [], [], [], []
+    cum = [0]
+    for idx, (dj, di) in enumerate((dj, di) for dj in (-1, 0, 1) for di in (-1, 0, 1)):
+        # InStamp cell (coadd.py:207, 348-349): x in [(1+di-1)*n2 - 0.5, (1+di)*n2 - 0.5)
+        x_lo, y_lo = (di * n2) - 0.5, (dj * n2) - 0.5
+        x_piv = [left - 0.5, None, right + 0.5][di + 1]
+        y_piv = [bottom - 0.5, None, top + 0.5][dj + 1]
+        count = 0
+        for e, (x, y) in enumerate(per_expo):
+            incell = (x >= x_lo) & (x < x_lo + n2) & (y >= y_lo) & (y < y_lo + n2)
+            xc, yc = x[incell], y[incell]
+            if x_piv is not None or y_piv is not None:
+                d2 = np.zeros(xc.shape)
+                if x_piv is not None:
+                    d2 += np.square(xc - x_piv)
+                if y_piv is not None:
+                    d2 += np.square(yc - y_piv)
+                sel = d2 < rho**2
+                xc, yc = xc[sel], yc[sel]
+            xs.append(xc); ys.append(yc)
+            es.append(np.full(xc.size, e, np.int32)); ss.append(np.full(xc.size, idx, np.int32))
+            count += xc.size
+        cum.append(cum[-1] + count)
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    expo, seg = np.concatenate(es), np.concatenate(ss)
+    # pixel values: a unit-flux point source near the stamp centre seen through a Gaussian of the
+    # exposure's width (frame 0) and white noise (frame 1)
+    sx, sy = (n2 - 1) / 2.0 + rng.uniform(-2, 2), (n2 - 1) / 2.0 + rng.uniform(-2, 2)
+    sig = (0.9 + 0.02 * expo) * p
+    star = np.exp(-0.5 * ((x - sx) ** 2 + (y - sy) ** 2) / sig**2) / (2 * np.pi * (sig / p) ** 2)
+    indata = np.zeros((cfg.n_inframe, x.size), np.float32)
+    indata[0] = star + rng.normal(0, 1e-3, x.size)
+    for f in range(1, cfg.n_inframe):
+        indata[f] = rng.normal(0, 1.0, x.size)
+    return Stamp(x, y, expo, seg, indata, float(left - cfg.fade), float(bottom - cfg.fade), n_expo,
+                 np.array(cum, dtype=np.uint32))
+
+
+def algorithmic_flops(cfg, n, nv=None):
+    """Per-stamp algorithmic work, fp64 flops, by stage."""
+    m = cfg.m
+    nv = nv or len(cfg.kappaC)
+    out = {
+        "build_A": 330.0 * n * (n + 1) / 2,
+        "build_B": 220.0 * n * m + 110.0 * n * cfg.n2f,
+        "epilogue": 2.0 * n * m * cfg.n_inframe + 3.0 * n * m,
+    }
+    if cfg.kernel == "Cholesky":
+        out["chol_factor"] = nv * n**3 / 3.0
+        out["chol_solve"] = nv * 2.0 * n * n * m
+        out["finalize"] = 4.0 * n * m * nv
+    else:
+        out["eigh"] = 9.0 * n**3
+        out["eigen_gemm"] = 4.0 * n * n * m
+        out["lakernel1"] = 6.0 * 14 * n * m
+    out["total"] = sum(out.values())
+    return out

@@ -1,0 +1,49 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/imcom_hip.h declares; no compute calls here (no GPU in the build container)."""
+
+import os
+import re
+
+from tests.conftest import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "imcom_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(imcom_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    import __graft_entry__ as g
+
+    g.build()
+    from pyimcom_amd import _lib
+
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in include/imcom_hip.h but not exported"
+    assert set(names) == set(_lib.EXPORTED), set(names) ^ set(_lib.EXPORTED)
+    assert _lib.lib.imcom_version() == 100
+
+
+def test_no_gpu_fails_loudly():
+    """Without a usable gfx950 device the context cannot be created and there is no fallback."""
+    import pytest
+
+    from pyimcom_amd import _lib
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.ImcomError):
+        _lib.Context(0)
+
+
+def test_product_does_not_import_oracle():
+    """Nothing under pyimcom_amd/ may import or call the oracle, except the smoke checker module."""
+    pkg = os.path.join(ROOT, "pyimcom_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f != "smoke.py":
+                src = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in src and "import oracle" not in src, f

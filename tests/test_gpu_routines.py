@@ -1,0 +1,214 @@
+"""GPU parity, native-routine seam and LA-kernel seam: libimcom_hip (through the C-ABI) vs the oracle
+and vs the golden vectors generated from the reference.  Run with -m gpu on an MI355X."""
+
+import numpy as np
+import pytest
+
+from tests.golden.make_golden import cosine_system, gaussian_system, make_outst
+
+pytestmark = pytest.mark.gpu
+
+# Floating-point tolerances (fp64 internals, same interpolation as the reference):
+TOL_INTERP = 1e-12  # |GPU - oracle| / max|table|: FMA contraction and nothing else
+TOL_T = 1e-6        # max|dT| <= TOL_T * max|T| after the float32 cast
+RTOL_MAP, ATOL_MAP = 1e-5, 1e-9  # UC, Sigma
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from pyimcom_amd import routines
+
+    return routines
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+
+    return oracle
+
+
+def test_getw(hip, golden):
+    g = golden("getw")
+    for fh, w_ref in zip(g["fh"], g["w"]):
+        w = np.zeros(10)
+        hip.iD5512C_getw(w, float(fh))
+        assert np.abs(w - w_ref).max() < 5e-16
+    w = np.zeros(10)
+    hip.iD5512C_getw(w, 0.5)  # reference tests/pyimcom/test_psf.py:55-61
+    assert abs(w[5] - 1) < 1e-8 and np.abs(np.delete(w, 5)).max() < 1e-8
+
+
+def test_interp_golden(hip, golden):
+    g = golden("interp")
+    f = np.full_like(g["f_scatter"], -7.0)
+    hip.iD5512C(g["infunc"], g["x"], g["y"], f)
+    assert np.array_equal(f == -7.0, g["f_scatter"] == -7.0)  # off-grid points untouched
+    assert np.abs(f - g["f_scatter"]).max() < TOL_INTERP
+    f = np.full_like(g["f_sym"], -7.0)
+    hip.iD5512C_sym(g["infunc"], g["xs"], g["ys"], f)
+    assert np.abs(f - g["f_sym"]).max() < TOL_INTERP
+    f = np.full_like(g["f_grid"], -7.0)
+    hip.gridD5512C(np.ascontiguousarray(g["infunc"][0]), g["xpos"], g["ypos"], f)
+    assert np.abs(f - g["f_grid"]).max() < TOL_INTERP
+    f = np.zeros_like(g["f_scatter_b"])
+    hip.iD5512C(g["infunc_b"], g["xb"], g["yb"], f)
+    assert np.abs(f - g["f_scatter_b"]).max() < TOL_INTERP * np.abs(g["infunc_b"]).max() * 10
+
+
+def test_interp_large_vs_oracle(hip, orc):
+    rng = np.random.default_rng(11)
+    tab = rng.standard_normal((2, 395, 395))
+    n = 200_000
+    x = rng.uniform(-3.0, 400.0, n)  # includes off-grid points on every side
+    y = rng.uniform(-3.0, 400.0, n)
+    a, b = np.full((2, n), 3.25), np.full((2, n), 3.25)
+    hip.iD5512C(tab, x, y, a)
+    orc.iD5512C(tab, x, y, b)
+    assert np.array_equal(a == 3.25, b == 3.25) and np.abs(a - b).max() < 5e-12
+    # symmetric form: 300 x 300 positions, symmetric by construction
+    sq = 300
+    xs = rng.uniform(4.0, 389.0, (sq, sq)); xs = np.triu(xs) + np.triu(xs, 1).T
+    ys = rng.uniform(4.0, 389.0, (sq, sq)); ys = np.triu(ys) + np.triu(ys, 1).T
+    a, b = np.zeros((2, sq * sq)), np.zeros((2, sq * sq))
+    hip.iD5512C_sym(tab, xs.ravel().copy(), ys.ravel().copy(), a)
+    orc.iD5512C_sym(tab, xs.ravel().copy(), ys.ravel().copy(), b)
+    assert np.abs(a - b).max() < 5e-12
+    assert np.array_equal(a.reshape(2, sq, sq), a.reshape(2, sq, sq).transpose(0, 2, 1))
+    # grid form at the cfg-2 geometry: 48 x 48 outputs at 1.894 table px pitch, plus an off-grid pixel
+    npi, n2f = 37, 48
+    x0 = rng.uniform(120.0, 280.0, npi); y0 = rng.uniform(120.0, 280.0, npi)
+    x0[3] = 380.0; y0[5] = -20.0
+    pitch = 1.894
+    xp = np.ascontiguousarray(x0[:, None] - pitch * np.arange(n2f)[None, :])
+    yp = np.ascontiguousarray(y0[:, None] - pitch * np.arange(n2f)[None, :])
+    a, b = np.zeros((npi, n2f * n2f)), np.zeros((npi, n2f * n2f))
+    hip.gridD5512C(tab[0], xp, yp, a)
+    orc.gridD5512C(np.ascontiguousarray(tab[0]), xp, yp, b)
+    assert np.abs(a - b).max() < 5e-12
+    # irregular (non-monotonic, widely spread) positions force the direct-evaluation fallback
+    xp = np.ascontiguousarray(rng.uniform(0.0, 395.0, (5, 40))); yp = np.ascontiguousarray(rng.uniform(0.0, 395.0, (5, 33)))
+    a, b = np.zeros((5, 40 * 33)), np.zeros((5, 40 * 33))
+    hip.gridD5512C(tab[1], xp, yp, a)
+    orc.gridD5512C(np.ascontiguousarray(tab[1]), xp, yp, b)
+    assert np.abs(a - b).max() < 5e-12
+
+
+def test_lakernel1(hip, orc, golden):
+    g = golden("lakernel1_small")
+    lam, mP = np.ascontiguousarray(g["lam"]), np.ascontiguousarray(g["mPhalf"])
+    m, n = mP.shape
+    k, S, U, T = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros((m, n))
+    hip.lakernel1(lam, None, mP, 0.7, 1e-8, 1e-16, 1e16, 53, k, S, U, T, 0.5)
+    # the reference's own C-vs-numba tolerances (tests/pyimcom/test_routine.py:133-145)
+    assert np.abs(k - g["kappa"]).max() < 1e-12 and np.abs(S - g["Sigma"]).max() < 1e-7
+    assert np.abs(U - g["UC"]).max() < 1e-13 and np.abs(T - g["T"]).max() < 1e-8
+    # the full-size case of the reference test, with its known-answer windows
+    A, mB, C = gaussian_system(33, 25)
+    lam, Q = np.linalg.eigh(A)
+    mP = np.ascontiguousarray(mB @ Q)
+    m, n = mP.shape
+    k, S, U, T = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros((m, n))
+    hip.lakernel1(lam, Q, mP, C, 1e-8, 1e-16, 1e16, 53, k, S, U, T, 0.5)
+    k2, S2, U2, T2 = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros((m, n))
+    orc.lakernel1(lam, Q, mP, C, 1e-8, 1e-16, 1e16, 53, k2, S2, U2, T2, 0.5)
+    assert np.abs(k - k2).max() < 1e-12 and np.abs(S - S2).max() < 1e-7 and np.abs(U - U2).max() < 1e-13
+    assert np.abs(T - T2).max() < 1e-8
+    assert 2.5e-7 < k.min() and k.max() < 3.5e-7 and 0.34 < S.min() and S.max() < 0.38
+    assert 9e-9 < U.min() and U.max() < 1.1e-8 and 0.077 < np.abs(T).max() < 0.079
+
+
+def test_build_reduced_T(hip, golden):
+    g = golden("build_reduced_T")
+    m, nv = g["brt_a_kappa"].size, g["kappa_nodes"].size
+    for tag in "abc":
+        ok, oS, oU, ow = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros(m * nv)
+        hip.build_reduced_T_wrap(g["Nflat"], g["Dflat"], g["Eflat"], g["kappa_nodes"], float(g[f"brt_{tag}_ucmin"]),
+                                 float(g[f"brt_{tag}_smax"]), ok, oS, oU, ow)
+        assert np.allclose(ok, g[f"brt_{tag}_kappa"], rtol=1e-12, atol=0)
+        assert np.allclose(oS, g[f"brt_{tag}_Sigma"], rtol=1e-9, atol=1e-14)
+        assert np.allclose(oU, g[f"brt_{tag}_UC"], rtol=0, atol=1e-12)
+        assert np.allclose(ow, g[f"brt_{tag}_w"], rtol=1e-8, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ LA seam
+def _run(K, A, mB, C, n2f, kC, uct, smax):
+    outst = make_outst(A.copy(), mB.copy(), C, n2f, kC, uct, smax)
+    k = K(outst)
+    k()
+    assert np.array_equal(outst.sysmata, A)  # caller-owned, unmodified
+    return outst
+
+
+CHOL_CASES = [("cos_chol1", "cos", [1e-2], 1e-4, 0.5, 4), ("cos_cholm", "cos", [1e-4, 1e-3, 1e-2], 1e-4, 1.0, 4),
+              ("gau_chol1", "gau", [6e-4], 1e-6, 0.5, 9), ("gau_cholm", "gau", [1e-5, 1e-4, 1e-3], 1e-6, 0.5, 9)]
+
+
+@pytest.mark.parametrize("name,sysn,kC,uct,smax,n2f", CHOL_CASES)
+def test_chol_kernel_golden(golden, name, sysn, kC, uct, smax, n2f):
+    from pyimcom_amd.lakernel import HipCholKernel
+
+    g = golden("lakernel")
+    o = _run(HipCholKernel, g[f"{sysn}_A"], g[f"{sysn}_mBhalf"], np.atleast_1d(g[f"{sysn}_C"]), n2f, np.array(kC), uct, smax)
+    assert o.T.dtype == np.float32 and o.T.shape == g[f"{name}_T"].shape and o.UC.shape == g[f"{name}_UC"].shape
+    assert np.abs(o.T - g[f"{name}_T"]).max() <= TOL_T * np.abs(g[f"{name}_T"]).max()
+    assert np.allclose(o.UC, g[f"{name}_UC"], rtol=RTOL_MAP, atol=ATOL_MAP)
+    assert np.allclose(o.Sigma, g[f"{name}_Sigma"], rtol=RTOL_MAP, atol=ATOL_MAP)
+    assert np.allclose(o.kappa, g[f"{name}_kappa"], rtol=1e-6, atol=0)
+
+
+def test_chol_kernel_known_answers():
+    """Range assertions of the reference's tests/pyimcom/test_la.py:92-99 on the HIP Cholesky kernel
+    (single kappa gives the same maps as the eigen kernel of that test)."""
+    from pyimcom_amd.lakernel import HipCholKernel
+
+    A, mB, C = cosine_system()
+    o = _run(HipCholKernel, A, mB, np.array([C]), 4, [1e-2], 1e-4, 0.5)
+    assert np.all(o.UC >= 0)
+    for j in range(16):
+        assert (o.UC.ravel()[j] < 1e-4) if j % 5 == 0 else (0.05 < o.UC.ravel()[j] < 0.2)
+        assert 0.6 < o.Sigma.ravel()[j] < 1.0 and 0.002 < o.kappa.ravel()[j] < 0.004
+
+
+def test_chol_empty_stamp(golden):
+    from pyimcom_amd.lakernel import HipCholKernel
+
+    g = golden("lakernel")
+    o = _run(HipCholKernel, np.zeros((0, 0)), np.zeros((1, 16, 0)), np.array([1.0]), 4, np.array([1e-3]), 1e-4, 0.5)
+    assert o.T.shape == (1, 16, 0) and o.T.dtype == np.float32
+    assert np.array_equal(o.UC, g["empty_UC"]) and np.array_equal(o.Sigma, g["empty_Sigma"])
+    assert np.array_equal(o.kappa, g["empty_kappa"])
+
+
+@pytest.mark.parametrize("nv", [1, 3])
+def test_chol_ragged_batch_vs_oracle(orc, nv):
+    """Direct C-ABI call: three stamps of different N (one spanning several 128-blocks, one empty) in one batch."""
+    import ctypes as C
+
+    from pyimcom_amd._lib import MEM_HOST, check, default_context, lib
+
+    rng = np.random.default_rng(7 + nv)
+    ns = np.array([300, 0, 131], dtype=np.int32)
+    ldn, m = 300, 150
+    A = np.zeros((3, ldn, ldn)); B = np.zeros((3, m, ldn)); Cs = np.array([0.9, 1.0, 1.3])
+    for s, n in enumerate(ns):
+        if n == 0:
+            continue
+        pts = rng.uniform(0, 12, (n, 2)); outp = rng.uniform(2, 10, (m, 2))
+        A[s, :n, :n] = Cs[s] * np.exp(-((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1) / 3.0)
+        B[s, :, :n] = Cs[s] * np.exp(-((outp[:, None, :] - pts[None, :, :]) ** 2).sum(-1) / 3.5)
+    kC = np.array([6e-4]) if nv == 1 else np.array([1e-5, 1e-4, 1e-3])
+    T = np.zeros((3, m, ldn), np.float32); UC = np.zeros((3, m), np.float32)
+    Sg = np.zeros((3, m), np.float32); kp = np.zeros((3, m), np.float32); info = np.zeros(3, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib.imcom_solve_chol(default_context().handle, 3, p(ns), ldn, m, p(A), p(B), p(Cs), p(kC), nv, 1e-6, 0.5,
+                               p(T), p(UC), p(Sg), p(kp), p(info), MEM_HOST))
+    for s, n in enumerate(ns):
+        if n == 0:
+            assert np.all(UC[s] == 1) and np.all(Sg[s] == 0) and np.all(kp[s] == 1) and np.all(T[s] == 0)
+            continue
+        To, Uo, So, ko, _ = orc.chol_kernel(A[s, :n, :n].copy(), np.ascontiguousarray(B[s, :, :n]), Cs[s], kC, 1e-6, 0.5)
+        assert np.abs(T[s, :, :n] - To).max() <= TOL_T * np.abs(To).max()
+        assert np.all(T[s, :, n:] == 0)
+        assert np.allclose(UC[s], Uo, rtol=RTOL_MAP, atol=ATOL_MAP) and np.allclose(Sg[s], So, rtol=RTOL_MAP, atol=ATOL_MAP)
+        assert np.allclose(kp[s], ko, rtol=1e-5, atol=0)
