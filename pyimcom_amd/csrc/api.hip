@@ -565,7 +565,7 @@ int imcom_build_A(imcom_ctx *ctx, int batch, const int *n_host, int ldn, const d
     int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
     IMCOM_TRY(upload(ctx, n_dev, n_host, batch));
     ProfScope ps(ctx, "build_A");
-    return launch_build_A(ctx, batch, n_dev, ldn, x, y, psf, tables, geom->nsamp + 12, geom->nc, geom->dscale, pair_tab,
+    return launch_build_A(ctx, batch, n_dev, ldn, x, y, psf, tables, ntab, geom->nsamp + 12, geom->nc, geom->dscale, pair_tab,
                           pair_pen, npsf_max, A);
 }
 

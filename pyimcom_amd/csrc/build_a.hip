@@ -1,0 +1,185 @@
+// build_a.hip -- the A builder: PSF-overlap system matrix of a batch of stamps by D5512 table
+// interpolation (reference src/pyimcom/psfutil.py:1401-1495 _call_ii_cross, 1597-1732 _call_ii_self, and
+// the sub-block assembly of coadd.py:1027-1068).
+//
+// The reference interpolates the element (i, j) with i before j in the stamp's pixel order and mirrors
+// it; so does this kernel: 16x16 sample tiles over the upper triangle of tiles, one sample per thread,
+// both the tile and its mirror written row-wise through an LDS transpose.
+// pair code: bits 0..27 table index; bit 29 SWAP (the reference evaluated the block from the other
+// stamp's side and transposed it, psfutil.py:1990-1996); bit 30 FLIP (np.flip'ed table, 1658-1665).
+//
+// This is gather-bound work (100 table reads per sample, 2.4 M samples per cfg-2 stamp), no MFMA.
+#include "common.h"
+#include "d5512.h"
+#include "launchers.h"
+
+namespace imcom {
+
+constexpr int PAIR_SWAP = 1 << 29, PAIR_FLIP = 1 << 30, PAIR_MASK = (1 << 28) - 1;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void tile_index(long t, int ntile, int &ti, int &tj)
+{
+    // linear index over the upper triangle of tiles: t = ti*ntile - ti(ti-1)/2 + (tj - ti)
+    const double b = 2.0 * ntile + 1.0;
+    ti = (int)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    while ((long)ti * ntile - (long)ti * (ti - 1) / 2 > t) ti--;
+    while ((long)(ti + 1) * ntile - (long)(ti + 1) * ti / 2 <= t) ti++;
+    tj = ti + (int)(t - ((long)ti * ntile - (long)ti * (ti - 1) / 2));
+}
+
+// Staging.  For every stencil row the 256 samples of a tile need 256 segments of 10 contiguous doubles
+// at arbitrary (8-byte aligned) table positions.  Six consecutive lanes fetch the six 16-byte aligned
+// chunks that cover one segment at either parity -- an instruction touches ~11 segments instead of 64
+// scattered ones -- and the chunks go global -> LDS directly (LDS-DMA, global_load_lds_dwordx4: the LDS
+// image is lane-linear, [sample][6 chunks], exactly the order the lanes are assigned in).  Row r+1 is in
+// flight while row r is consumed from the other LDS buffer.
+constexpr int SEG_W = 12;  // doubles staged per segment
+
+#define IMCOM_GLDS16(gptr, ldsptr)                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),           \
+                                     (__attribute__((address_space(3))) void *)(ldsptr), 16, 0, 0)
+
+__global__ __launch_bounds__(256) void build_A_kernel(const int *__restrict__ n, int ldn,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ y,
+                                                      const int *__restrict__ psf,
+                                                      const double *__restrict__ tables, long tab_elems,
+                                                      int ng, double nc, double dscale,
+                                                      const int *__restrict__ pair_tab,
+                                                      const double *__restrict__ pair_pen, int npsf_max,
+                                                      double *__restrict__ A, int ntile)
+{
+    __shared__ __attribute__((aligned(16))) double seg[2][256 * SEG_W];
+    __shared__ int seg0[256];   // first element (ascending address order) of stencil row 0; < 0: no loads
+    __shared__ int rstep[256];  // element step between stencil rows (+ng, or -ng for a flipped table)
+    __shared__ double tile[16][17];
+    const int s = blockIdx.y, tid = threadIdx.x;
+    int ti, tj;
+    tile_index(blockIdx.x, ntile, ti, tj);
+    const int ns = n[s];
+    const int nfull = (ns + NB - 1) / NB * NB;  // rows/cols the factorisation will ever read
+    if (ti * 16 >= nfull || tj * 16 >= nfull) return;
+    const int li = tid >> 4, lj = tid & 15;
+    const int i = ti * 16 + li, j = tj * 16 + lj;
+    double *As = A + (long)s * ldn * ldn;
+    const long base = (long)s * ldn;
+    double wx[10], wy[10];
+    double val = 0.0, pen = 0.0;
+    bool active = false;
+    long my_seg0 = -1;
+    int my_step = 0;
+    if (i < ns && j < ns && j >= i) {
+        const int pi = psf[base + i], pj = psf[base + j];
+        const long pidx = ((long)s * npsf_max + pi) * npsf_max + pj;
+        const int code = pair_tab[pidx];
+        pen = pair_pen[pidx];
+        if (code >= 0) {
+            const bool swap = code & PAIR_SWAP, rev = code & PAIR_FLIP;
+            const int tab = code & PAIR_MASK;
+            double dx = swap ? x[base + j] - x[base + i] : x[base + i] - x[base + j];
+            double dy = swap ? y[base + j] - y[base + i] : y[base + i] - y[base + j];
+            dx /= dscale; dx += nc; dx += 6.0;
+            dy /= dscale; dy += nc; dy += 6.0;
+            const int xi = to_cell(dx), yi = to_cell(dy);
+            if (!(xi < 4 || xi >= ng - 5 || yi < 4 || yi >= ng - 5)) {
+                d5512_getw(wx, dx - xi - 0.5);
+                d5512_getw(wy, dy - yi - 0.5);
+                const long t0 = (long)tab * ng * ng, off = (long)(yi - 4) * ng + (xi - 4);
+                // flipped table: tap (r, c) is element last - (off + r*ng + c): row r is the ascending
+                // segment that starts at last - off - r*ng - 9, read back to front
+                my_seg0 = rev ? t0 + ((long)ng * ng - 1 - off - 9) : t0 + off;
+                my_step = rev ? -ng : ng;
+                if (rev) {  // reversed taps: flip the x weights once; the sum below then runs k = 9..0,
+                            // which is the reference's order over the flipped table's columns
+#pragma unroll
+                    for (int c = 0; c < 5; c++) { const double t = wx[c]; wx[c] = wx[9 - c]; wx[9 - c] = t; }
+                }
+                active = true;
+            }
+        }
+    }
+    const bool rev = my_step < 0;
+    seg0[tid] = (int)my_seg0;  // launch_build_A checks that the table stack fits 31 bits
+    rstep[tid] = my_step;
+    __syncthreads();
+    // the six (sample, chunk) pairs this thread fetches for every stencil row: work item w = tid + 256 q
+    int fs0[6];
+    int fstep[6], fc[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const int w = tid + 256 * q, sm = w / 6;
+        fs0[q] = seg0[sm];
+        fstep[q] = rstep[sm];
+        fc[q] = 2 * (w - sm * 6);
+    }
+    const int wave_base = (tid & ~63) * 2;  // this wave's first double in a 256-item slab
+    auto stage = [&](int r, double *buf) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            double *dst = buf + 512 * q + wave_base;  // wave-uniform; lane l lands at dst + 2 l
+            if (fs0[q] >= 0) {
+                const long a = ((fs0[q] + (long)r * fstep[q]) & ~1L) + fc[q];
+                if (a + 1 < tab_elems) IMCOM_GLDS16(tables + a, dst);
+                else dst[2 * (tid & 63)] = (a < tab_elems) ? tables[a] : 0.0;  // chunk straddling the end
+            }
+        }
+    };
+    stage(0, seg[0]);
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {
+        if (r + 1 < 10) stage(r + 1, seg[(r + 1) & 1]);
+        if (active) {
+            const long e = my_seg0 + (long)r * my_step;
+            const f64x2 *row = (const f64x2 *)(seg[r & 1] + tid * SEG_W);
+            f64x2 c[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) c[q] = row[q];
+            const bool odd = e & 1;
+            double strip = 0.0;
+            if (rev) {
+#pragma unroll
+                for (int k = 9; k >= 0; k--) {
+                    const int w1 = k + 1;
+                    strip += wx[k] * (odd ? c[w1 >> 1][w1 & 1] : c[k >> 1][k & 1]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 10; k++) {
+                    const int w1 = k + 1;
+                    strip += wx[k] * (odd ? c[w1 >> 1][w1 & 1] : c[k >> 1][k & 1]);
+                }
+            }
+            val += strip * wy[r];
+        }
+        __syncthreads();
+    }
+    val += pen;
+    if (i >= ns || j >= ns) val = (i == j) ? 1.0 : 0.0;  // identity padding
+    tile[li][lj] = val;
+    __syncthreads();
+    if (ti == tj) {
+        const double v = (lj >= li) ? tile[li][lj] : tile[lj][li];
+        if (i < ldn && j < ldn) As[(long)i * ldn + j] = v;
+    } else {
+        if (i < ldn && j < ldn) As[(long)i * ldn + j] = val;
+        // mirrored tile, written row-wise: element (tj*16 + li, ti*16 + lj) = tile[lj][li]
+        const int mi = tj * 16 + li, mj = ti * 16 + lj;
+        if (mi < ldn && mj < ldn) As[(long)mi * ldn + mj] = tile[lj][li];
+    }
+}
+
+int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
+                   const int *psf, const double *tables, int ntab, int ng, double nc, double dscale,
+                   const int *pair_tab, const double *pair_pen, int npsf_max, double *A)
+{
+    IMCOM_REQUIRE((long)ntab * ng * ng < (1L << 31), "table stack too large (%d tables of %d^2)", ntab, ng);
+    const int nt = (ldn + 15) / 16;
+    const long ntri = (long)nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(build_A_kernel, dim3((unsigned)ntri, batch), dim3(256), 0, ctx->stream, n_dev, ldn, x, y, psf,
+                       tables, (long)ntab * ng * ng, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A, nt);
+    return check_launch("build_A_kernel");
+}
+
+}  // namespace imcom

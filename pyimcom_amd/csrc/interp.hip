@@ -10,74 +10,9 @@
 // stamp touches is kept in LDS and the y-pass reads it back, 5x fewer table reads than the direct
 // form, in the reference's own summation order (inner sum over x taps, outer over y taps).
 #include "common.h"
+#include "d5512.h"
 
 namespace imcom {
-
-// routine.py:29-122: taps k and 9-k are even(fh^2) +/- odd(fh^2)*fh, Horner in fh^2.
-__constant__ double D5512_EVEN[5][5] = {
-    {+1.651881673372979740e-05, -3.145538007199505447e-04, +1.793518183780194427e-03,
-     -2.904014557029917318e-03, +6.187591260980151433e-04},
-    {-1.146756217210629335e-04, +2.883845374976550142e-03, -1.857047531896089884e-02,
-     +3.147734488597204311e-02, -6.753293626461192439e-03},
-    {+3.256838096371517067e-04, -9.702063770653997568e-03, +8.678848026470635524e-02,
-     -1.659182651092198924e-01, +3.620560878249733799e-02},
-    {-4.541830837949564726e-04, +1.494862093737218955e-02, -1.668775957435094937e-01,
-     +5.879306056792649171e-01, -1.367845996704077915e-01},
-    {+2.266560930061513573e-04, -7.815848920941316502e-03, +9.686607348538181506e-02,
-     -4.505856722239036105e-01, +6.067135256905490381e-01},
-};
-__constant__ double D5512_ODD[5][5] = {
-    {-3.486978652054735998e-06, +6.753750285320532433e-05, -3.871378836550175566e-04,
-     +6.279918076641771273e-04, -1.338434614116611838e-04},
-    {+3.121412120355294799e-05, -8.040343683015897672e-04, +5.209574765466357636e-03,
-     -8.847326408846412429e-03, +1.898674086370833597e-03},
-    {-1.243658986204533102e-04, +3.804930695189636097e-03, -3.434861846914529643e-02,
-     +6.581033749134083954e-02, -1.436476114189205733e-02},
-    {+2.894406669584551734e-04, -9.794291009695265532e-03, +1.104231510875857830e-01,
-     -3.906954914039130755e-01, +9.092432925988773451e-02},
-    {-4.336085507644610966e-04, +1.537862263741893339e-02, -1.925091434770601628e-01,
-     +8.993141455798455697e-01, -1.213035309579723942e+00},
-};
-
-__device__ __forceinline__ void d5512_getw(double (&w)[10], double fh)
-{
-    const double fh2 = fh * fh;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        double e = D5512_EVEN[k][0], o = D5512_ODD[k][0];
-#pragma unroll
-        for (int c = 1; c < 5; c++) {
-            e = e * fh2 + D5512_EVEN[k][c];
-            o = o * fh2 + D5512_ODD[k][c];
-        }
-        o *= fh;
-        w[k] = e + o;
-        w[9 - k] = e - o;
-    }
-}
-
-// truncation toward zero like np.int32(x); anything absurd is treated as off-grid
-__device__ __forceinline__ int to_cell(double x)
-{
-    return (x > -1.0e9 && x < 1.0e9) ? (int)x : -1000000;
-}
-
-// one 10x10 stencil: f points at tap (0,0); step = +1 (plain table) or -1 (table flipped in both axes,
-// base at its last element): inner sum over x taps, outer over y taps (routine.py:176-180)
-__device__ __forceinline__ double stencil(const double *__restrict__ f, long row_stride, int step,
-                                          const double (&wx)[10], const double (&wy)[10])
-{
-    double out = 0.0;
-#pragma unroll
-    for (int i = 0; i < 10; i++) {
-        const double *row = f + i * row_stride;
-        double strip = 0.0;
-#pragma unroll
-        for (int j = 0; j < 10; j++) strip += wx[j] * row[j * step];
-        out += strip * wy[i];
-    }
-    return out;
-}
 
 // ------------------------------------------------------------------------------------------------
 __global__ void d5512_getw_kernel(const double *__restrict__ fh, long n, double *__restrict__ w)
@@ -273,64 +208,6 @@ __global__ __launch_bounds__(256) void build_B_kernel(const int *__restrict__ n,
 }
 
 // ------------------------------------------------------------------------------------------------
-// A builder (psfutil.py:1401-1495, 1597-1732 + coadd.py:1027-1068).  The reference interpolates the
-// element (i, j) with i before j in the stamp's pixel order and mirrors it; so does this kernel:
-// 16x16 thread tiles over the upper triangle, each thread one element, written to [i][j] and [j][i].
-// pair code: bits 0..27 table index; bit 29 SWAP (the reference evaluated the block from the other
-// stamp's side and transposed it, psfutil.py:1990-1996); bit 30 FLIP (np.flip'ed table, 1658-1665).
-constexpr int PAIR_SWAP = 1 << 29, PAIR_FLIP = 1 << 30, PAIR_MASK = (1 << 28) - 1;
-
-__global__ __launch_bounds__(256) void build_A_kernel(const int *__restrict__ n, int ldn,
-                                                      const double *__restrict__ x,
-                                                      const double *__restrict__ y,
-                                                      const int *__restrict__ psf,
-                                                      const double *__restrict__ tables, int ng, double nc,
-                                                      double dscale, const int *__restrict__ pair_tab,
-                                                      const double *__restrict__ pair_pen, int npsf_max,
-                                                      double *__restrict__ A)
-{
-    const int s = blockIdx.z;
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (tj < ti) return;
-    const int ns = n[s];
-    const int i = ti * 16 + (threadIdx.x >> 4), j = tj * 16 + (threadIdx.x & 15);
-    if (i >= ldn || j >= ldn || j < i) return;
-    double *As = A + (long)s * ldn * ldn;
-    if (i >= ns || j >= ns) {  // identity padding
-        const double v = (i == j) ? 1.0 : 0.0;
-        As[(long)i * ldn + j] = v;
-        As[(long)j * ldn + i] = v;
-        return;
-    }
-    const long base = (long)s * ldn;
-    const int pi = psf[base + i], pj = psf[base + j];
-    const long pidx = ((long)s * npsf_max + pi) * npsf_max + pj;
-    const int code = pair_tab[pidx];
-    double val = 0.0;
-    if (code >= 0) {
-        const bool swap = code & PAIR_SWAP, flip = code & PAIR_FLIP;
-        const int tab = code & PAIR_MASK;
-        double dx = swap ? x[base + j] - x[base + i] : x[base + i] - x[base + j];
-        double dy = swap ? y[base + j] - y[base + i] : y[base + i] - y[base + j];
-        dx /= dscale; dx += nc; dx += 6.0;
-        dy /= dscale; dy += nc; dy += 6.0;
-        const int xi = to_cell(dx), yi = to_cell(dy);
-        if (!(xi < 4 || xi >= ng - 5 || yi < 4 || yi >= ng - 5)) {
-            double wx[10], wy[10];
-            d5512_getw(wx, dx - xi - 0.5);
-            d5512_getw(wy, dy - yi - 0.5);
-            const double *f = tables + (long)tab * ng * ng;
-            const long off = (long)(yi - 4) * ng + (xi - 4);
-            val = flip ? stencil(f + ((long)ng * ng - 1 - off), -(long)ng, -1, wx, wy)
-                       : stencil(f + off, ng, 1, wx, wy);
-        }
-    }
-    val += pair_pen[pidx];
-    As[(long)i * ldn + j] = val;
-    As[(long)j * ldn + i] = val;
-}
-
-// ------------------------------------------------------------------------------------------------
 int launch_getw(imcom_ctx *ctx, const double *fh, long n, double *w)
 {
     if (n <= 0) return IMCOM_OK;
@@ -392,14 +269,5 @@ int launch_build_B(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const d
     return check_launch("build_B_kernel");
 }
 
-int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
-                   const int *psf, const double *tables, int ng, double nc, double dscale, const int *pair_tab,
-                   const double *pair_pen, int npsf_max, double *A)
-{
-    const int nt = (ldn + 15) / 16;
-    hipLaunchKernelGGL(build_A_kernel, dim3(nt, nt, batch), dim3(256), 0, ctx->stream, n_dev, ldn, x, y, psf,
-                       tables, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A);
-    return check_launch("build_A_kernel");
-}
 
 }  // namespace imcom

@@ -33,10 +33,18 @@ __global__ __launch_bounds__(128) void chol_diag_kernel(double *__restrict__ L, 
     for (int j = 0; j < NB; j++) {
         double v = 0.0;
         if (tid >= j) {
-            v = S[tid * DLD + j];
             const double *ri = S + tid * DLD, *rj = S + j * DLD;
-#pragma unroll 4
-            for (int c = 0; c < j; c++) v -= ri[c] * rj[c];
+            // four independent partial sums keep 8 LDS reads in flight per step of the chain
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int c = 0;
+            for (; c + 4 <= j; c += 4) {
+                s0 += ri[c] * rj[c];
+                s1 += ri[c + 1] * rj[c + 1];
+                s2 += ri[c + 2] * rj[c + 2];
+                s3 += ri[c + 3] * rj[c + 3];
+            }
+            for (; c < j; c++) s0 += ri[c] * rj[c];
+            v = S[tid * DLD + j] - ((s0 + s1) + (s2 + s3));
         }
         if (tid == j) piv = v;
         __syncthreads();
@@ -63,8 +71,16 @@ __global__ __launch_bounds__(128) void chol_diag_kernel(double *__restrict__ L, 
             const double *li = S + i * DLD;
             double sum = 0.0;
             if (c < i) {
-                sum = li[c] * xc;
-                for (int l = c + 1; l < i; l++) sum += li[l] * xrow[l];
+                double s0 = li[c] * xc, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int l = c + 1;
+                for (; l + 4 <= i; l += 4) {
+                    s0 += li[l] * xrow[l];
+                    s1 += li[l + 1] * xrow[l + 1];
+                    s2 += li[l + 2] * xrow[l + 2];
+                    s3 += li[l + 3] * xrow[l + 3];
+                }
+                for (; l < i; l++) s0 += li[l] * xrow[l];
+                sum = (s0 + s1) + (s2 + s3);
                 xrow[i] = -sum / dg[i];
             }
         }

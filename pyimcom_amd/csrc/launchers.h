@@ -51,8 +51,8 @@ int launch_interp(imcom_ctx *ctx, const double *infunc, int nlayer, int ngy, int
 int launch_grid(imcom_ctx *ctx, const double *infunc, int ngy, int ngx, const double *xpos, const double *ypos,
                 long npi, int nxo, int nyo, double *fhatout);
 int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
-                   const int *psf, const double *tables, int ng, double nc, double dscale, const int *pair_tab,
-                   const double *pair_pen, int npsf_max, double *A);
+                   const int *psf, const double *tables, int ntab, int ng, double nc, double dscale,
+                   const int *pair_tab, const double *pair_pen, int npsf_max, double *A);
 int launch_build_B(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
                    const int *psf, const double *tables, int ng, double nc, double dscale, const int *io_tab,
                    int npsf_max, const double *out_x0, const double *out_y0, int n2f, int ldm, double *Bt);
