@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg2")
-    ap.add_argument("--batch", type=int, default=128, help="stamps per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="stamps per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()

@@ -230,12 +230,14 @@ int launch_interp(imcom_ctx *ctx, const double *infunc, int nlayer, int ngy, int
     return check_launch("interp_d5512_sym_kernel");
 }
 
-static int grid_lds(int nxo, int nyo, int *max_rows, size_t *bytes)
+// rows_hint > 0: the caller knows how many table rows one pixel's output grid can touch (regular grids);
+// reserving just that keeps several workgroups resident per CU.  Otherwise a 96 KB budget is used.
+static int grid_lds(int nxo, int nyo, int rows_hint, int *max_rows, size_t *bytes)
 {
-    // budget 96 KB so that at least one more workgroup fits beside it
     const size_t fixed = (size_t)(10 * (nxo + nyo)) * 8 + (size_t)(nxo + nyo + 4) * 4;
     const size_t budget = 96 * 1024;
     long rows = fixed < budget ? (long)((budget - fixed) / ((size_t)nxo * 8)) : 0;
+    if (rows_hint > 0 && rows_hint < rows) rows = rows_hint;
     if (rows > 4096) rows = 4096;
     if (rows < 10) rows = 0;  // too wide for the LDS form: direct evaluation
     *max_rows = (int)rows;
@@ -248,7 +250,7 @@ int launch_grid(imcom_ctx *ctx, const double *infunc, int ngy, int ngx, const do
 {
     if (npi <= 0) return IMCOM_OK;
     int max_rows; size_t bytes;
-    grid_lds(nxo, nyo, &max_rows, &bytes);
+    grid_lds(nxo, nyo, 0, &max_rows, &bytes);
     IMCOM_REQUIRE(bytes <= 160 * 1024, "gridD5512C: output grid %d x %d too large for the LDS form", nxo, nyo);
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)grid_d5512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(grid_d5512_kernel, dim3((unsigned)npi), dim3(256), bytes, ctx->stream, infunc, ngy, ngx,
@@ -261,7 +263,8 @@ int launch_build_B(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const d
                    int npsf_max, const double *out_x0, const double *out_y0, int n2f, int ldm, double *Bt)
 {
     int max_rows; size_t bytes;
-    grid_lds(n2f, n2f, &max_rows, &bytes);
+    // output pixels are 1/dscale table samples apart: (n2f-1)/dscale + 10 taps (+2 for rounding at both ends)
+    grid_lds(n2f, n2f, (int)((n2f - 1) / dscale) + 13, &max_rows, &bytes);
     IMCOM_REQUIRE(bytes <= 160 * 1024, "build_B: n2f=%d too large", n2f);
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)build_B_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     hipLaunchKernelGGL(build_B_kernel, dim3(ldn, batch), dim3(256), bytes, ctx->stream, n_dev, ldn, x, y, psf,
