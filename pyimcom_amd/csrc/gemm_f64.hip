@@ -8,81 +8,17 @@
 // tiles (128 x 16 doubles) are staged global -> registers -> LDS with the next tile's global loads in
 // flight behind the current tile's 64 MFMAs per wave.  LDS images are padded so the per-lane
 // ds_read_b64 fragment reads are bank-conflict-free:
-//   row-major image  [128][16+2]  : lane (i = l&15, k = l>>4) reads word i*18 + k  -> 32 distinct banks
+//   row-major image  [128][16+1]  : lane (i = l&15, k = l>>4) reads word i*17 + k  -> distinct banks for
+//                                   ds_read_b64 (32-lane halves) and ds_read2_b64 (16-lane groups) alike
 //   k-major image    [16][128+16] : lane reads word k*144 + i                      -> 32 distinct banks
 // fp64 MFMA runs at the fp64 vector rate on gfx950, so the point of MFMA here is operand reuse
 // (one 8-byte LDS read per lane feeds 2048 flops), not a higher peak.
 #include "common.h"
+#include "mma_dma.h"
 
 namespace imcom {
 
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-
-constexpr int BK = 16;
-constexpr int LDS_RM = BK + 2;         // row-major image stride (doubles)
-constexpr int LDS_KM = NB + 16;        // k-major image stride (doubles)
-constexpr int TILE_WORDS = NB * LDS_RM;  // == BK * LDS_KM == 2304 doubles
-static_assert(NB * LDS_RM == BK * LDS_KM, "operand images must have one size");
-
-// acc[mi][ni] += sum_k Aop[m][k] * Bop[k][n] over K (multiple of 16), for the 128x128 tile whose
-// operands start at Ag / Bg.  KMAJOR operand: element (r,k) at p[k*ld + r]; else at p[r*ld + k].
-template <bool AKM, bool BKM>
-__device__ __forceinline__ void mma_tile(f64x4 (&acc)[4][4], const double *__restrict__ Ag, long lda,
-                                         const double *__restrict__ Bg, long ldb, int K, double *sA,
-                                         double *sB)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 15, lk = lane >> 4;
-    f64x2 ra[4], rb[4];
-    const int nt = K / BK;
-
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = tid + 256 * q;
-            if (AKM) ra[q] = *(const f64x2 *)(Ag + (long)(t * BK + (c >> 6)) * lda + (c & 63) * 2);
-            else     ra[q] = *(const f64x2 *)(Ag + (long)(c >> 3) * lda + t * BK + (c & 7) * 2);
-            if (BKM) rb[q] = *(const f64x2 *)(Bg + (long)(t * BK + (c >> 6)) * ldb + (c & 63) * 2);
-            else     rb[q] = *(const f64x2 *)(Bg + (long)(c >> 3) * ldb + t * BK + (c & 7) * 2);
-        }
-    };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = tid + 256 * q;
-            if (AKM) *(f64x2 *)(sA + (c >> 6) * LDS_KM + (c & 63) * 2) = ra[q];
-            else     *(f64x2 *)(sA + (c >> 3) * LDS_RM + (c & 7) * 2) = ra[q];
-            if (BKM) *(f64x2 *)(sB + (c >> 6) * LDS_KM + (c & 63) * 2) = rb[q];
-            else     *(f64x2 *)(sB + (c >> 3) * LDS_RM + (c & 7) * 2) = rb[q];
-        }
-    };
-
-    if (nt > 0) gload(0);
-    for (int t = 0; t < nt; t++) {
-        __syncthreads();  // every wave finished reading the previous images
-        sstore();
-        __syncthreads();
-        if (t + 1 < nt) gload(t + 1);  // in flight behind the MFMAs below
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                a[i] = AKM ? sA[(kk * 4 + lk) * LDS_KM + wm * 64 + i * 16 + li]
-                           : sA[(wm * 64 + i * 16 + li) * LDS_RM + kk * 4 + lk];
-                b[i] = BKM ? sB[(kk * 4 + lk) * LDS_KM + wn * 64 + i * 16 + li]
-                           : sB[(wn * 64 + i * 16 + li) * LDS_RM + kk * 4 + lk];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    }
-}
+constexpr int BK = DBK;  // K granularity of the tile engine (mma_dma.h)
 
 __device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][4])
 {
@@ -118,15 +54,14 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
                                                              const int *__restrict__ nblk,
                                                              const double *__restrict__ dshift)
 {
-    __shared__ double smem[2 * TILE_WORDS];
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     const int s = blockIdx.y, i = k + blockIdx.x;
     if (i >= nblk[s]) return;
     const long sA = (long)ldn * ldn;
     double *Ls = L + s * sA;
     f64x4 acc[4][4];
     zero_acc(acc);
-    mma_tile<false, false>(acc, Ls + (long)i * NB * ldn, ldn, Ls + (long)k * NB * ldn, ldn, k * NB, smem,
-                           smem + TILE_WORDS);
+    mma_tile_dma<false, false>(acc, Ls + (long)i * NB * ldn, ldn, Ls + (long)k * NB * ldn, ldn, k * NB, smem);
     const double *As = A + s * sA + (long)i * NB * ldn + k * NB;
     double *Lo = Ls + (long)i * NB * ldn + k * NB;
     // dshift = diagonal of A with the kappa increments already applied (diag_shift_kernel)
@@ -142,16 +77,33 @@ __global__ __launch_bounds__(256, 2) void chol_trsm_kernel(double *__restrict__ 
                                                            const double *__restrict__ Dinv, int ldn,
                                                            int k, const int *__restrict__ nblk)
 {
-    __shared__ double smem[2 * TILE_WORDS];
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     const int s = blockIdx.y, i = k + 1 + blockIdx.x;
     if (i >= nblk[s]) return;
     double *P = L + (long)s * ldn * ldn + (long)i * NB * ldn + k * NB;
     const double *Di = Dinv + ((long)s * (ldn / NB) + k) * NB * NB;
     f64x4 acc[4][4];
     zero_acc(acc);
-    mma_tile<false, false>(acc, P, ldn, Di, NB, NB, smem, smem + TILE_WORDS);
+    mma_tile_dma<false, false>(acc, P, ldn, Di, NB, NB, smem);
     __syncthreads();  // all of P[i] has been read by every wave before it is overwritten
     IMCOM_FOR_ACC(row, col, v, { P[(long)row * ldn + col] = v; })
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own L2.  All column
+// tiles of one stamp share that stamp's L panel, so they are placed on one XCD: XCD x takes stamps
+// x, x+8, ...  Bijective when the batch is a multiple of 8 (else the plain mapping is used); placement
+// only affects speed.
+__device__ __forceinline__ void solve_tile_of_block(int &c, int &s)
+{
+    const int ntile = gridDim.x, batch = gridDim.y;
+    c = blockIdx.x;
+    s = blockIdx.y;
+    if ((batch & 7) == 0) {
+        const int b = blockIdx.y * ntile + blockIdx.x;
+        const int xcd = b & 7, slot = b >> 3;
+        s = (slot / ntile) * 8 + xcd;
+        c = slot % ntile;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,14 +116,15 @@ __global__ __launch_bounds__(256, 2) void solve_fwd_kernel(const double *__restr
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk)
 {
-    __shared__ double smem[2 * TILE_WORDS];
-    const int s = blockIdx.y, c = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
+    int s, c;
+    solve_tile_of_block(c, s);
     if (k >= nblk[s]) return;
     const double *Ls = L + (long)s * ldn * ldn + (long)k * NB * ldn;
     double *Ys = Y + (long)s * ldn * ldm + c * NB;
     f64x4 acc[4][4];
     zero_acc(acc);
-    mma_tile<false, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem, smem + TILE_WORDS);
+    mma_tile_dma<false, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem);
     const double *Bs = Bt + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
     double *Yo = Ys + (long)k * NB * ldm;
     IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] = Bs[(long)row * ldm + col] - v; })
@@ -181,16 +134,16 @@ __global__ __launch_bounds__(256, 2) void solve_bwd_kernel(const double *__restr
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk)
 {
-    __shared__ double smem[2 * TILE_WORDS];
-    const int s = blockIdx.y, c = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
+    int s, c;
+    solve_tile_of_block(c, s);
     const int nb = nblk[s];
     if (k >= nb - 1) return;  // last block row: nothing to subtract
     const double *Lc = L + (long)s * ldn * ldn + (long)(k + 1) * NB * ldn + k * NB;  // L[k+1:, k]
     double *Ys = Y + (long)s * ldn * ldm + c * NB;
     f64x4 acc[4][4];
     zero_acc(acc);
-    mma_tile<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, (nb - 1 - k) * NB, smem,
-                         smem + TILE_WORDS);
+    mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, (nb - 1 - k) * NB, smem);
     double *Yo = Ys + (long)k * NB * ldm;
     IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] -= v; })
 }
@@ -201,14 +154,15 @@ __global__ __launch_bounds__(256, 2) void solve_dinv_kernel(const double *__rest
                                                             double *__restrict__ Y, int ldn, int ldm,
                                                             int k, const int *__restrict__ nblk)
 {
-    __shared__ double smem[2 * TILE_WORDS];
-    const int s = blockIdx.y, c = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
+    int s, c;
+    solve_tile_of_block(c, s);
     if (k >= nblk[s]) return;
     const double *Di = Dinv + ((long)s * (ldn / NB) + k) * NB * NB;
     double *Yk = Y + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
     f64x4 acc[4][4];
     zero_acc(acc);
-    mma_tile<TRANS, true>(acc, Di, NB, Yk, ldm, NB, smem, smem + TILE_WORDS);
+    mma_tile_dma<TRANS, true>(acc, Di, NB, Yk, ldm, NB, smem);
     __syncthreads();
     IMCOM_FOR_ACC(row, col, v, { Yk[(long)row * ldm + col] = v; })
 }
@@ -223,13 +177,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const double *__restrict__
                                                       long ldc, long strideC, int K, double alpha,
                                                       double beta)
 {
-    __shared__ double smem[2 * TILE_WORDS];
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     const int s = blockIdx.z, tm = blockIdx.y, tn = blockIdx.x;
     const double *Ag = A + s * strideA + (AKM ? (long)tm * NB : (long)tm * NB * lda);
     const double *Bg = B + s * strideB + (BKM ? (long)tn * NB : (long)tn * NB * ldb);
     f64x4 acc[4][4];
     zero_acc(acc);
-    mma_tile<AKM, BKM>(acc, Ag, lda, Bg, ldb, K, smem, smem + TILE_WORDS);
+    mma_tile_dma<AKM, BKM>(acc, Ag, lda, Bg, ldb, K, smem);
     double *Co = C + s * strideC + (long)tm * NB * ldc + (long)tn * NB;
     IMCOM_FOR_ACC(row, col, v, {
         double *p = Co + (long)row * ldc + col;
