@@ -133,7 +133,7 @@ __device__ __forceinline__ void grid_pixel(const double *__restrict__ f, int ngy
             const int iy = t / nxo, ix = t - iy * nxo;
             const int yc = yis[iy];
             const double *w = wys + 10 * iy;
-            const int r0 = (yc < 0 ? rlo : yc - 4 - rlo);  // invalid rows carry zero weights
+            const int r0 = (yc < 0 ? 0 : yc - 4 - rlo);  // invalid rows carry zero weights: any staged rows do
             double o = 0.0;
 #pragma unroll
             for (int i = 0; i < 10; i++) o += tmp[(r0 + i) * nxo + ix] * w[i];

@@ -212,3 +212,80 @@ def test_chol_ragged_batch_vs_oracle(orc, nv):
         assert np.all(T[s, :, n:] == 0)
         assert np.allclose(UC[s], Uo, rtol=RTOL_MAP, atol=ATOL_MAP) and np.allclose(Sg[s], So, rtol=RTOL_MAP, atol=ATOL_MAP)
         assert np.allclose(kp[s], ko, rtol=1e-5, atol=0)
+
+
+# ------------------------------------------------------------------------------------------------ eigen path
+def test_eigh_vs_numpy():
+    from pyimcom_amd.linalg import eigh
+
+    rng = np.random.default_rng(3)
+    for n in (5, 64, 150, 300):
+        M = rng.standard_normal((n, n))
+        A = M + M.T
+        lam, Q = eigh(A)
+        w = np.linalg.eigvalsh(A)
+        assert np.abs(lam - w).max() < 1e-12 * np.abs(w).max()
+        assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-12
+        assert np.abs(A @ Q - Q * lam).max() < 1e-11 * np.abs(w).max()
+    # the numerically semi-definite Gaussian overlap matrix of the LA tests (eigenvalues down to ~1e-17)
+    A, _, _ = gaussian_system(13, 9, sigma=2.0, off=4.0, step=0.5)
+    lam, Q = eigh(A)
+    w = np.linalg.eigvalsh(A)
+    assert np.abs(lam - w).max() < 2e-14 * w[-1]
+    assert np.abs(A @ Q - Q * lam).max() < 1e-13 * w[-1] * 10
+    # batch with equal sizes
+    As = np.stack([A, 2 * A + np.eye(A.shape[0])])
+    lams, Qs = eigh(As)
+    assert np.abs(lams[1] - (2 * w + 1)).max() < 1e-12 * (2 * w[-1] + 1)
+
+
+EIG_CASES = [("cos_eig1", "cos", [1e-2], 1e-4, 0.5, 4), ("cos_eigm", "cos", [1e-4, 1e-3, 1e-2], 1e-4, 1.0, 4),
+             ("gau_eig1", "gau", [6e-4], 1e-6, 0.5, 9), ("gau_eigm", "gau", [1e-5, 1e-4, 1e-3], 1e-6, 0.5, 9)]
+
+
+@pytest.mark.parametrize("name,sysn,kC,uct,smax,n2f", EIG_CASES)
+def test_eigen_kernel_golden(golden, name, sysn, kC, uct, smax, n2f):
+    from pyimcom_amd.lakernel import HipEigenKernel
+
+    g = golden("lakernel")
+    o = _run(HipEigenKernel, g[f"{sysn}_A"], g[f"{sysn}_mBhalf"], np.atleast_1d(g[f"{sysn}_C"]), n2f, np.array(kC), uct, smax)
+    assert o.T.dtype == np.float32 and o.T.shape == g[f"{name}_T"].shape
+    assert np.abs(o.T - g[f"{name}_T"]).max() <= TOL_T * np.abs(g[f"{name}_T"]).max()
+    assert np.allclose(o.UC, g[f"{name}_UC"], rtol=RTOL_MAP, atol=ATOL_MAP)
+    assert np.allclose(o.Sigma, g[f"{name}_Sigma"], rtol=RTOL_MAP, atol=ATOL_MAP)
+    assert np.allclose(o.kappa, g[f"{name}_kappa"], rtol=1e-6, atol=0)
+
+
+def test_eigen_kernel_known_answers():
+    """tests/pyimcom/test_la.py:46-160 (test_eigen, test_eigen2) on the HIP eigen kernel, incl. the kappa*C^2 quirk."""
+    from pyimcom_amd.lakernel import HipEigenKernel
+
+    A, mB, C = cosine_system()
+    o = _run(HipEigenKernel, A, mB, np.array([C]), 4, [1e-2], 1e-4, 0.5)
+    assert np.all(o.UC >= 0)
+    for j in range(16):
+        assert (o.UC.ravel()[j] < 1e-4) if j % 5 == 0 else (0.05 < o.UC.ravel()[j] < 0.2)
+        assert 0.6 < o.Sigma.ravel()[j] < 1.0 and 0.002 < o.kappa.ravel()[j] < 0.004
+    o = _run(HipEigenKernel, A, mB, np.array([C]), 4, [1e-4, 1e-3, 1e-2], 1e-4, 1.0)
+    assert np.all(o.UC >= 0)
+    for j in range(16):
+        if j % 5 == 0:
+            assert o.UC.ravel()[j] < 1e-4 and 5e-4 < o.kappa.ravel()[j] < 1.5e-3
+        else:
+            assert 0.05 < o.UC.ravel()[j] < 0.2 and 5e-6 < o.kappa.ravel()[j] < 1.5e-5
+        assert 0.6 < o.Sigma.ravel()[j] < 1.0
+
+
+def test_eigh_indefinite_pairs():
+    """+x / -x eigenvalue pairs (degenerate for a plain one-sided Jacobi, which sees A^2) must be resolved."""
+    from pyimcom_amd.linalg import eigh
+
+    rng = np.random.default_rng(8)
+    n = 96
+    Qr, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    w = np.concatenate([-np.linspace(0.1, 2.0, n // 2), np.linspace(0.1, 2.0, n // 2)])
+    A = (Qr * w) @ Qr.T
+    A = 0.5 * (A + A.T)
+    lam, Q = eigh(A)
+    assert np.abs(lam - np.sort(w)).max() < 1e-13
+    assert np.abs(A @ Q - Q * lam).max() < 1e-12
