@@ -128,6 +128,10 @@ static int upload(imcom_ctx *ctx, T *dst, const T *src_host, size_t count)
 //   A  [batch][Np][Np]   identity-padded, never modified
 //   Bt [batch][Np][mp]   input-pixel-major -B/2, zero padded
 // Produces Tt (float32 [batch][Np][mp]) and the per-pixel maps.
+size_t jacobi_ws_bytes(int batch, int ld);
+int jacobi_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA,
+                       double *lam, long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out);
+
 static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
 {
     WsPlan p;
@@ -136,7 +140,7 @@ static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
     p.add((size_t)batch * nb * NB * NB * 8);     // Dinv
     p.add((size_t)nv * batch * Np * mp * 8);     // Y / X per node
     p.add((size_t)batch * Np * 8);               // dshift
-    p.add((size_t)batch * 4 * 4);                // n, nblk, fail, ninc
+    p.add((size_t)batch * 4 * (3 + nv));         // n, nblk, ninc, fail[nv]
     p.add((size_t)batch * MAX_INC_HOST * 8);     // inc
     p.add((size_t)batch * 8 * 2);                // kap, C
     p.add((size_t)nv * 8);                       // kappaC
@@ -145,7 +149,27 @@ static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
         p.add((size_t)batch * m * nv * nv * 8);  // Npq
         p.add((size_t)batch * m * nv * 8);       // W
     }
+    // repair path (lakernel.py:262-279): eigenvalues of ONE stamp's A at a time
+    p.add(jacobi_ws_bytes(1, Np) + (size_t)Np * Np * 8 + (size_t)Np * 8 + 1024);
     return p.total + 4096;
+}
+
+// smallest eigenvalue of A[s] (leading n x n of the padded matrix), computed on the device
+static int lambda_min(imcom_ctx *ctx, const double *A_s, int n, int Np, double *w0)
+{
+    const size_t mark = ctx->ws_used;
+    double *lam = (double *)ws_take(ctx, (size_t)Np * 8);
+    double *Q = (double *)ws_take(ctx, (size_t)Np * Np * 8);
+    if (!lam || !Q) { set_error("internal: workspace (repair)"); return IMCOM_ERR_NOMEM; }
+    IMCOM_HIP_CHECK(hipMemsetAsync(Q, 0, (size_t)Np * Np * 8, ctx->stream));
+    int rc = jacobi_eigh_device(ctx, 1, &n, Np, A_s, Np, (long)Np * Np, lam, Np, Q, Np, (long)Np * Np, nullptr);
+    if (rc == IMCOM_OK) {
+        hipError_t e = hipMemcpyAsync(w0, lam, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { set_error("repair: %s", hipGetErrorString(e)); rc = IMCOM_ERR_HIP; }
+    }
+    ctx->ws_used = mark;
+    return rc;
 }
 
 static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m, int mp, const double *A,
@@ -158,7 +182,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     const long node_stride = (long)batch * Np * mp;
     double *Y = (double *)ws_take(ctx, (size_t)nv * node_stride * 8);
     double *dshift = (double *)ws_take(ctx, (size_t)batch * Np * 8);
-    int *ints = (int *)ws_take(ctx, (size_t)batch * 4 * 4);
+    int *ints = (int *)ws_take(ctx, (size_t)batch * 4 * (3 + nv));
     double *inc = (double *)ws_take(ctx, (size_t)batch * MAX_INC_HOST * 8);
     double *dbl = (double *)ws_take(ctx, (size_t)batch * 8 * 2);
     double *kappaC_dev = (double *)ws_take(ctx, (size_t)nv * 8);
@@ -172,11 +196,12 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         set_error("internal: workspace plan too small");
         return IMCOM_ERR_NOMEM;
     }
-    int *n_dev = ints, *nblk_dev = ints + batch, *fail_dev = ints + 2 * batch, *ninc_dev = ints + 3 * batch;
+    int *n_dev = ints, *nblk_dev = ints + batch, *ninc_dev = ints + 2 * batch, *fail_dev = ints + 3 * batch;  // fail[nv][batch]
     double *kap_dev = dbl, *C_dev = dbl + batch;
 
-    std::vector<int> nblk(batch), ninc(batch, 0);
-    std::vector<double> inc_h((size_t)batch * MAX_INC_HOST, 0.0), kap_h(batch);
+    std::vector<int> nblk(batch), ninc(batch, 0), fail((size_t)nv * batch);
+    std::vector<double> inc_h((size_t)batch * MAX_INC_HOST, 0.0), kap_h(batch), rep(batch, 0.0);
+    std::vector<char> repaired((size_t)nv * batch, 0), have_w0(batch, 0);
     int nbmax = 0;
     for (int s = 0; s < batch; s++) {
         IMCOM_REQUIRE(n_host[s] >= 0 && n_host[s] <= Np, "n[%d]=%d outside [0,%d]", s, n_host[s], Np);
@@ -188,57 +213,78 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     IMCOM_TRY(upload(ctx, nblk_dev, nblk.data(), batch));
     IMCOM_TRY(upload(ctx, C_dev, C_host, batch));
     IMCOM_TRY(upload(ctx, kappaC_dev, kappaC_host, nv));
-    IMCOM_HIP_CHECK(hipMemsetAsync(fail_dev, 0, (size_t)batch * 4, ctx->stream));
 
-    for (int p = 0; p < nv; p++) {
-        // diagonal increments applied so far, in the reference's order (lakernel.py:298 / 356)
-        for (int s = 0; s < batch; s++) {
-            const double kp = kappaC_host[p] * C_host[s];
-            double *ih = &inc_h[(size_t)s * MAX_INC_HOST];
-            if (nv == 1) { ih[0] = kp; ninc[s] = (kp != 0.0) ? 1 : 0; }
-            else {
-                const double prev = (p > 0) ? kappaC_host[p - 1] * C_host[s] : 0.0;
-                IMCOM_REQUIRE(ninc[s] < MAX_INC_HOST, "too many diagonal increments");
-                ih[ninc[s]++] = kp - prev;
+    for (int attempt = 0;; attempt++) {
+        IMCOM_HIP_CHECK(hipMemsetAsync(fail_dev, 0, (size_t)nv * batch * 4, ctx->stream));
+        for (int p = 0; p < nv; p++) {
+            // the diagonal of AA at node p as the reference builds it: a sequence of in-place adds
+            // (lakernel.py:298 single kappa; 356 node differences; 268/277 repair add and restore)
+            for (int s = 0; s < batch; s++) {
+                double *ih = &inc_h[(size_t)s * MAX_INC_HOST];
+                int c = 0;
+                if (nv == 1) { if (kappaC_host[0] * C_host[s] != 0.0) ih[c++] = kappaC_host[0] * C_host[s]; }
+                else
+                    for (int q = 0; q <= p; q++) {
+                        ih[c++] = kappaC_host[q] * C_host[s] - (q > 0 ? kappaC_host[q - 1] * C_host[s] : 0.0);
+                        if (q < p && repaired[(size_t)q * batch + s]) { ih[c++] = rep[s]; ih[c++] = -rep[s]; }
+                    }
+                if (repaired[(size_t)p * batch + s]) ih[c++] = rep[s];
+                IMCOM_REQUIRE(c <= MAX_INC_HOST, "too many diagonal increments");
+                ninc[s] = c;
+                kap_h[s] = kappaC_host[p] * C_host[s];
             }
-            kap_h[s] = kp;
+            IMCOM_TRY(upload(ctx, inc, inc_h.data(), inc_h.size()));
+            IMCOM_TRY(upload(ctx, ninc_dev, ninc.data(), batch));
+            IMCOM_TRY(upload(ctx, kap_dev, kap_h.data(), batch));
+            IMCOM_TRY(launch_diag_shift(ctx, A, Np, inc, ninc_dev, dshift, batch));
+            int *failp = fail_dev + (size_t)p * batch;
+            for (int k = 0; k < nbmax; k++) {
+                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_update(ctx, A, L, Np, k, nbmax, batch, nblk_dev, dshift)); }
+                { ProfScope ps(ctx, "chol_diag"); IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, batch, nblk_dev, failp)); }
+                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, batch, nblk_dev)); }
+            }
+            double *Yp = Y + p * node_stride;
+            for (int k = 0; k < nbmax; k++) {
+                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, batch, nblk_dev)); }
+                { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, false)); }
+            }
+            for (int k = nbmax - 1; k >= 0; k--) {
+                if (k < nbmax - 1) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, batch, nblk_dev)); }
+                { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, true)); }
+            }
         }
-        IMCOM_TRY(upload(ctx, inc, inc_h.data(), inc_h.size()));
-        IMCOM_TRY(upload(ctx, ninc_dev, ninc.data(), batch));
-        IMCOM_TRY(upload(ctx, kap_dev, kap_h.data(), batch));
-        IMCOM_TRY(launch_diag_shift(ctx, A, Np, inc, ninc_dev, dshift, batch));
-
-        for (int k = 0; k < nbmax; k++) {
-            { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_update(ctx, A, L, Np, k, nbmax, batch, nblk_dev, dshift)); }
-            { ProfScope ps(ctx, "chol_diag"); IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, batch, nblk_dev, fail_dev)); }
-            { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, batch, nblk_dev)); }
+        {
+            ProfScope ps(ctx, "finalize");
+            if (nv == 1)
+                IMCOM_TRY(launch_finalize_single(ctx, Y, Bt, Np, mp, m, n_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch));
+            else
+                IMCOM_TRY(launch_multi(ctx, Y, node_stride, Bt, Np, mp, m, n_dev, nv, kappaC_dev, C_dev, ucmin, smax, Dp, Npq, W, Tt, UC, Sigma, kappa, batch));
         }
-        double *Yp = Y + p * node_stride;
-        for (int k = 0; k < nbmax; k++) {
-            { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, batch, nblk_dev)); }
-            { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, false)); }
-        }
-        for (int k = nbmax - 1; k >= 0; k--) {
-            if (k < nbmax - 1) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, batch, nblk_dev)); }
-            { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, true)); }
-        }
+        IMCOM_HIP_CHECK(hipMemcpyAsync(fail.data(), fail_dev, fail.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        bool any = false;
+        for (int p = 0; p < nv; p++)
+            for (int s = 0; s < batch; s++) {
+                if (fail[(size_t)p * batch + s] == 0) continue;
+                if (repaired[(size_t)p * batch + s]) {
+                    set_error("stamp %d node %d: Cholesky failed again after the lakernel.py:262-279 repair (pivot %d)", s, p,
+                              fail[(size_t)p * batch + s]);
+                    return IMCOM_ERR_NUMERIC;
+                }
+                if (!have_w0[s]) {  // w, v = eigh(A); shift by |w[0]| + 1e-16
+                    double w0 = 0.0;
+                    ProfScope ps(ctx, "eigen_repair");
+                    IMCOM_TRY(lambda_min(ctx, A + (size_t)s * Np * Np, n_host[s], Np, &w0));
+                    rep[s] = fabs(w0) + 1e-16;
+                    have_w0[s] = 1;
+                }
+                repaired[(size_t)p * batch + s] = 1;
+                if (info_host[s] == 0) info_host[s] = p + 1;
+                any = true;
+            }
+        if (!any) break;
+        IMCOM_REQUIRE(attempt <= nv + 1, "repair loop did not terminate");
     }
-    {
-        ProfScope ps(ctx, "finalize");
-        if (nv == 1)
-            IMCOM_TRY(launch_finalize_single(ctx, Y, Bt, Np, mp, m, n_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch));
-        else
-            IMCOM_TRY(launch_multi(ctx, Y, node_stride, Bt, Np, mp, m, n_dev, nv, kappaC_dev, C_dev, ucmin, smax, Dp, Npq, W, Tt, UC, Sigma, kappa, batch));
-    }
-    std::vector<int> fail(batch);
-    IMCOM_HIP_CHECK(hipMemcpyAsync(fail.data(), fail_dev, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
-    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int s = 0; s < batch; s++)
-        if (fail[s] != 0) {
-            set_error("stamp %d: A + kappa I is not positive definite (pivot %d); the lakernel.py:262-279 repair "
-                      "needs imcom_eigh, which this build does not provide yet", s, fail[s]);
-            return IMCOM_ERR_NUMERIC;
-        }
     return IMCOM_OK;
 }
 

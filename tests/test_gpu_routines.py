@@ -79,6 +79,7 @@ def test_interp_large_vs_oracle(hip, orc):
     npi, n2f = 37, 48
     x0 = rng.uniform(120.0, 280.0, npi); y0 = rng.uniform(120.0, 280.0, npi)
     x0[3] = 380.0; y0[5] = -20.0
+    y0[7] = 40.0; x0[9] = 50.0; y0[11] = 420.0  # grids that leave the table part-way (rows / columns of zero weight)
     pitch = 1.894
     xp = np.ascontiguousarray(x0[:, None] - pitch * np.arange(n2f)[None, :])
     yp = np.ascontiguousarray(y0[:, None] - pitch * np.arange(n2f)[None, :])
@@ -289,3 +290,40 @@ def test_eigh_indefinite_pairs():
     lam, Q = eigh(A)
     assert np.abs(lam - np.sort(w)).max() < 1e-13
     assert np.abs(A @ Q - Q * lam).max() < 1e-12
+
+
+def test_chol_repair_golden(golden):
+    """Non-positive-definite A + kappa I: the eigh-shift repair of lakernel.py:262-279 (golden 'repair_*',
+    system of tests/pyimcom/test_la.py:8-24), with lambda_min computed on the GPU."""
+    from pyimcom_amd.lakernel import HipCholKernel
+
+    g = golden("lakernel")
+    A6, mB6, C6 = cosine_system()
+    o = _run(HipCholKernel, g["repair_A"], mB6, np.array([C6]), 4, np.array([1e-4 / C6]), 1e-4, 0.5)
+    assert np.abs(o.T - g["repair_chol1_T"]).max() <= 1e-5 * np.abs(g["repair_chol1_T"]).max()  # cond ~ 5e3 after the shift
+    assert np.allclose(o.UC, g["repair_chol1_UC"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(o.Sigma, g["repair_chol1_Sigma"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(o.kappa, g["repair_chol1_kappa"], rtol=1e-6, atol=0)
+
+
+def test_chol_repair_multi_kappa_vs_oracle(orc):
+    """Multi-kappa: only the first node needs the repair; later nodes continue from the restored diagonal."""
+    import ctypes as C
+
+    from pyimcom_amd._lib import MEM_HOST, check, default_context, lib
+
+    A, mB, Cc = gaussian_system(11, 7, sigma=1.2, off=3.0, step=0.7)
+    n, m = A.shape[0], mB.shape[0]
+    A = A - (np.linalg.eigvalsh(A)[0] + 2e-4 * Cc) * np.eye(n)  # lambda_min = -2e-4 C: node 1e-5 fails, 1e-3 does not
+    kC = np.array([1e-5, 1e-3, 1e-2])
+    To, Uo, So, ko, info_o = orc.chol_kernel(A.copy(), mB, Cc, kC, 1e-6, 0.5)
+    assert info_o == 1
+    T = np.zeros((1, m, n), np.float32); UC = np.zeros((1, m), np.float32)
+    Sg = np.zeros((1, m), np.float32); kp = np.zeros((1, m), np.float32); info = np.zeros(1, np.int32)
+    ns = np.array([n], np.int32); Cs = np.array([Cc])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib.imcom_solve_chol(default_context().handle, 1, p(ns), n, m, p(A), p(np.ascontiguousarray(mB)), p(Cs), p(kC), 3, 1e-6,
+                               0.5, p(T), p(UC), p(Sg), p(kp), p(info), MEM_HOST))
+    assert info[0] == 1
+    assert np.abs(T[0] - To).max() <= 1e-4 * np.abs(To).max()  # the repaired node is singular to ~1e-16: cond ~ 1e12 there
+    assert np.allclose(UC[0], Uo, rtol=1e-3, atol=1e-6) and np.allclose(Sg[0], So, rtol=1e-3, atol=1e-6)
