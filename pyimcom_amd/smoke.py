@@ -35,7 +35,8 @@ def oracle_stamp(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab):
     A, Bt = orc.stamp_system(g, stamp.x, stamp.y, stamp.expo, tables_pad, pair_tab, pair_pen, io_tab, stamp.out_x0,
                              stamp.out_y0, cfg.n2f)
     mB = np.ascontiguousarray(Bt.T)
-    T, UC, Sigma, kappa, info = orc.chol_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
+    la = orc.eigen_kernel if cfg.kernel == "Eigen" else orc.chol_kernel
+    T, UC, Sigma, kappa, info = la(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
     s = (cfg.n2f, cfg.n2f)
     UC, Sigma, kappa = UC.reshape(s).copy(), Sigma.reshape(s).copy(), kappa.reshape(s).copy()
     if cfg.fade > 0:  # coadd.py:1118-1122

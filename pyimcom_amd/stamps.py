@@ -177,9 +177,21 @@ class StampBatch:
         """lakernel.CholKernel (lakernel.py:281-394) + the map taper of coadd.py:1118-1122."""
         self._stream()
         cfg = self.cfg
-        if cfg.kernel != "Cholesky":
-            raise NotImplementedError("resident path: Cholesky kernel only (use lakernel.HipEigenKernel)")
-        check(lib.imcom_solve_chol_resident(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm,
+        if cfg.kernel == "Eigen":
+            # lakernel.EigenKernel (lakernel.py:141-223) on device pointers.  imcom_solve_eigen speaks the
+            # reference layout (-B/2 as [m][N], T as [m][N]); torch only re-strides the buffers.
+            mB = self.Bt[:, :, : self.m].transpose(1, 2).contiguous()
+            T = torch.empty((self.batch, self.m, self.ldn), dtype=torch.float32, device=self.dev)
+            check(lib.imcom_solve_eigen(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, _dp(self.A), _dp(mB),
+                                        _hp(self.Cs), _hp(self.kappaC), len(self.kappaC), float(cfg.uctarget),
+                                        float(cfg.sigmamax), 13, _dp(T), _dp(self.UC), _dp(self.Sigma), _dp(self.kappa),
+                                        _hp(self.info), 1))
+            self.Tt.zero_()
+            self.Tt[:, :, : self.m] = T.transpose(1, 2)
+        elif cfg.kernel != "Cholesky":
+            raise NotImplementedError(f"resident path: no {cfg.kernel} kernel")
+        else:
+            check(lib.imcom_solve_chol_resident(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm,
                                             _dp(self.A), _dp(self.Bt), _hp(self.Cs), _hp(self.kappaC), len(self.kappaC),
                                             float(cfg.uctarget), float(cfg.sigmamax), _dp(self.Tt), _dp(self.UC),
                                             _dp(self.Sigma), _dp(self.kappa), _hp(self.info)))
