@@ -167,7 +167,7 @@ def main():
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, stamps[:8], psfs, target, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(cfg, stamps[:64], psfs, target, args.cpu_budget)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

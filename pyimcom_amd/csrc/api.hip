@@ -249,7 +249,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                 { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, false)); }
             }
             for (int k = nbmax - 1; k >= 0; k--) {
-                if (k < nbmax - 1) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, batch, nblk_dev)); }
+                if (k < nbmax - 1) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, batch, nblk_dev, n_dev)); }
                 { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, true)); }
             }
         }

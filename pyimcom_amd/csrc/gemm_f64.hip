@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void solve_fwd_kernel(const double *__restr
 
 __global__ __launch_bounds__(256, 2) void solve_bwd_kernel(const double *__restrict__ L,
                                                            double *__restrict__ Y, int ldn, int ldm,
-                                                           int k, const int *__restrict__ nblk)
+                                                           int k, const int *__restrict__ nblk,
+                                                           const int *__restrict__ n)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -143,7 +144,9 @@ __global__ __launch_bounds__(256, 2) void solve_bwd_kernel(const double *__restr
     double *Ys = Y + (long)s * ldn * ldm + c * NB;
     f64x4 acc[4][4];
     zero_acc(acc);
-    mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, (nb - 1 - k) * NB, smem);
+    // rows of L below n[s] are identity padding (zero in this block column): stop the k loop at n rounded to 8
+    const int kend = ((n[s] + DBK - 1) / DBK) * DBK - (k + 1) * NB;
+    mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, kend, smem);
     double *Yo = Ys + (long)k * NB * ldm;
     IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] -= v; })
 }
@@ -220,10 +223,10 @@ int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *
 }
 
 int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int batch,
-                     const int *nblk)
+                     const int *nblk, const int *n)
 {
     dim3 grid(ldm / NB, batch);
-    hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(256), 0, ctx->stream, L, Y, ldn, ldm, k, nblk);
+    hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(256), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n);
     return check_launch("solve_bwd_kernel");
 }
 
