@@ -10,92 +10,6 @@
 namespace imcom {
 
 // ------------------------------------------------------------------------------------------------
-// Diagonal block: P[k] (NB x NB, lower part used) -> L[k,k] in place and Linv[k] = L[k,k]^-1.
-// One 128-thread workgroup per stamp; the block lives in LDS (129-word rows: conflict-free column and
-// row walks).  Column-by-column left-looking Cholesky, then one thread per column of the inverse
-// (forward substitution), Linv^T kept in the strict upper triangle of the same LDS image.
-// A non-positive pivot (LAPACK dpotrf's failure, scipy raises LinAlgError: lakernel.py:262-264)
-// records fail[s] = global column + 1 and leaves the block unfinished.
-constexpr int DLD = NB + 1;
-
-__global__ __launch_bounds__(128) void chol_diag_kernel(double *__restrict__ L, double *__restrict__ Dinv,
-                                                        int ldn, int k, const int *__restrict__ nblk,
-                                                        int *__restrict__ fail)
-{
-    extern __shared__ double S[];
-    double *dg = S + NB * DLD;
-    __shared__ double piv;
-    const int s = blockIdx.x, tid = threadIdx.x;
-    if (k >= nblk[s] || fail[s] != 0) return;
-    double *Lkk = L + (long)s * ldn * ldn + (long)k * NB * ldn + k * NB;
-    for (int r = 0; r < NB; r++) S[r * DLD + tid] = Lkk[(long)r * ldn + tid];
-    __syncthreads();
-    for (int j = 0; j < NB; j++) {
-        double v = 0.0;
-        if (tid >= j) {
-            const double *ri = S + tid * DLD, *rj = S + j * DLD;
-            // four independent partial sums keep 8 LDS reads in flight per step of the chain
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int c = 0;
-            for (; c + 4 <= j; c += 4) {
-                s0 += ri[c] * rj[c];
-                s1 += ri[c + 1] * rj[c + 1];
-                s2 += ri[c + 2] * rj[c + 2];
-                s3 += ri[c + 3] * rj[c + 3];
-            }
-            for (; c < j; c++) s0 += ri[c] * rj[c];
-            v = S[tid * DLD + j] - ((s0 + s1) + (s2 + s3));
-        }
-        if (tid == j) piv = v;
-        __syncthreads();
-        const double d = piv;
-        if (!(d > 0.0)) {  // also catches NaN
-            if (tid == 0) fail[s] = k * NB + j + 1;
-            return;
-        }
-        const double ljj = sqrt(d);
-        if (tid == j) { S[j * DLD + j] = ljj; dg[j] = ljj; }
-        else if (tid > j) S[tid * DLD + j] = v / ljj;
-        __syncthreads();
-    }
-    // write L[k,k] (strict upper part zeroed)
-    for (int r = 0; r < NB; r++) Lkk[(long)r * ldn + tid] = (tid <= r) ? S[r * DLD + tid] : 0.0;
-    __syncthreads();
-    // inverse: thread c owns column c; x_l (l > c) is stored at S[c][l] (upper triangle)
-    {
-        const int c = tid;
-        const double xc = 1.0 / dg[c];
-        double *xrow = S + c * DLD;
-        for (int i = 1; i < NB; i++) {
-            // wave-uniform trip count so that S[i][l] is a broadcast read; lanes with c >= i idle
-            const double *li = S + i * DLD;
-            double sum = 0.0;
-            if (c < i) {
-                double s0 = li[c] * xc, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                int l = c + 1;
-                for (; l + 4 <= i; l += 4) {
-                    s0 += li[l] * xrow[l];
-                    s1 += li[l + 1] * xrow[l + 1];
-                    s2 += li[l + 2] * xrow[l + 2];
-                    s3 += li[l + 3] * xrow[l + 3];
-                }
-                for (; l < i; l++) s0 += li[l] * xrow[l];
-                sum = (s0 + s1) + (s2 + s3);
-                xrow[i] = -sum / dg[i];
-            }
-        }
-        __syncthreads();
-        double *Di = Dinv + ((long)s * (ldn / NB) + k) * NB * NB;
-        // Linv[r][c] = (r > c) ? S[c][r] : (r == c ? 1/l_cc : 0); write rows coalesced over c = tid
-        for (int r = 0; r < NB; r++) {
-            double v = 0.0;
-            if (r > c) v = S[c * DLD + r];
-            else if (r == c) v = xc;
-            Di[r * NB + c] = v;
-        }
-    }
-}
-
 // diagonal of A + increments, applied the way the reference does: a sequence of in-place adds
 // (lakernel.py:298, 356, 268/277), so the rounding matches; used by chol_update via `shift`.
 __global__ void diag_shift_kernel(const double *__restrict__ A, int ldn, const double *__restrict__ inc,
@@ -563,18 +477,6 @@ __global__ __launch_bounds__(256) void tsum_stamp_kernel(const double *__restric
 
 // ------------------------------------------------------------------------------------------------
 // launchers
-int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail)
-{
-    static bool attr_set = false;
-    const size_t bytes = (size_t)(NB * DLD + NB) * sizeof(double);
-    if (!attr_set) {
-        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(batch), dim3(128), bytes, ctx->stream, L, Dinv, ldn, k, nblk, fail);
-    return check_launch("chol_diag_kernel");
-}
-
 int launch_diag_shift(imcom_ctx *ctx, const double *A, int ldn, const double *inc, const int *ninc, double *dshift, int batch)
 {
     hipLaunchKernelGGL(diag_shift_kernel, dim3((ldn + 255) / 256, batch), dim3(256), 0, ctx->stream, A, ldn, inc, ninc, dshift, batch);
