@@ -199,6 +199,18 @@ int imcom_coadd_epilogue(imcom_ctx *ctx, int batch, const int *n_host, int ldn, 
 /* OutStamp.trapezoid (coadd.py:1222-1292) on [batch][n2f][n2f] float32 maps (kappa, Sigma, UC). */
 int imcom_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fade);
 
+/* Block._output_stamp_wrapper map updates (coadd.py:1975-1993), on the device: for every stamp s of the batch,
+ * dst[layer][(jst-1)*n2 + r][(ist-1)*n2 + c] += src[s][layer][r][c], r,c < n2f = n2 + 2*fade.  dst is one of the
+ * block's float32 maps [nlayer][nside_pf][nside_pf] (out_map with nlayer = n_inframe; UC/Sigma/kappa/Tsum/Neff
+ * with nlayer = 1); src is float32 or float64 (src_is_f64).  jst/ist are HOST arrays of 1-based OutStamp
+ * indices.  Overlapping neighbours are added in four index-parity passes, so the result is deterministic. */
+int imcom_block_accumulate(imcom_ctx *ctx, int batch, const int *jst_host, const int *ist_host, int n2, int fade,
+                           int nlayer, const void *src, int src_is_f64, float *dst, int nside_pf);
+/* Block.build_output_file boundary recovery (coadd.py:2163-2181): OutStamp.trapezoid(maps, fade,
+ * recover_mode=True, pad_widths=(b,t,l,r)) on float32 maps [nmaps][ny][nx]. */
+int imcom_trapezoid_recover_f32(imcom_ctx *ctx, float *maps, long nmaps, int ny, int nx, int fade, int pad_b,
+                                int pad_t, int pad_l, int pad_r);
+
 /* PSFGrp.accel_pad_and_rfft2 + PSFOvl._build_psfovl (psfutil.py:943-986, 1244-1294): correlation
  * tables out[p][q] = irfft2(rft(psf1[p]) * conj(rft(psf2[q]))), rolled by nc and cropped to
  * nsamp x nsamp.  psf1[n1][nsamp][nsamp], psf2[n2][nsamp][nsamp]; pairs[npairs][2] HOST lists the

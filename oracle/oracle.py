@@ -413,6 +413,30 @@ def trapezoid(arr, fade_kernel):
     arr[..., :, ir : ir - fk2 : -1] *= s
 
 
+def trapezoid_recover(arr, fade_kernel, pad_widths=(0, 0, 0, 0)):
+    """OutStamp.trapezoid(..., recover_mode=True, pad_widths) (coadd.py:1262-1292), in place."""
+    fk2 = fade_kernel * 2
+    if not fk2 > 0:
+        return
+    ny, nx = arr.shape[-2:]
+    pb, pt, pl, pr = pad_widths
+    it, ir = ny - pt - 1, nx - pr - 1
+    s = np.arange(1, fk2 + 1, dtype=np.float64) / (fk2 + 1)
+    s -= np.sin(2 * np.pi * s) / (2 * np.pi)
+    sT = s[None, :].T
+    arr[..., pb : pb + fk2, :] /= sT
+    arr[..., it : it - fk2 : -1, :] /= sT
+    arr[..., :, pl : pl + fk2] /= s
+    arr[..., :, ir : ir - fk2 : -1] /= s
+
+
+def block_accumulate(dst, src, j_st, i_st, n2, fade_kernel):
+    """One map update of Block._output_stamp_wrapper (coadd.py:1975-1993): dst[..., bottom:top, left:right] += src."""
+    bottom, left = (j_st - 1) * n2, (i_st - 1) * n2
+    top, right = j_st * n2 + fade_kernel * 2, i_st * n2 + fade_kernel * 2
+    dst[..., bottom:top, left:right] += src
+
+
 def perform_coaddition(T, indata, expo, n_expo, n2f, n2, fade_kernel):
     """OutStamp._perform_coaddition (coadd.py:1294-1354) for one stamp.
 

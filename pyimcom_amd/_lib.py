@@ -76,6 +76,8 @@ SIGNATURES = {
     "imcom_coadd_epilogue": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "imcom_trapezoid_f32": [_vp, _vp, _l, _i, _i],
     "imcom_psf_overlap": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
+    "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
+    "imcom_trapezoid_recover_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i],
 }
 for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)

@@ -1,0 +1,68 @@
+"""Device-side block maps: the accumulators of Block.coadd_output_stamps /
+_output_stamp_wrapper (reference src/pyimcom/coadd.py:2031-2047, 1975-1993) kept on the GPU, and the
+boundary recovery of Block.build_output_file (coadd.py:2163-2181)."""
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import check, default_context, lib
+
+
+def _dp(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class BlockMaps:
+    """out_map [n_inframe, NsidePf, NsidePf] and the UC / Sigma / kappa / Tsum / Neff maps [NsidePf, NsidePf]
+    (float32, n_out = 1), T_weightmap [n_expo, n1P, n1P]."""
+
+    def __init__(self, n1P, n2, fade, n_inframe, n_expo, ctx=None, device="cuda:0"):
+        self.n1P, self.n2, self.fade, self.n_inframe, self.n_expo = n1P, n2, fade, n_inframe, n_expo
+        self.nside = n1P * n2 + 2 * fade  # NsidePf (coadd.py:2029)
+        self.ctx = ctx or default_context()
+        dev = torch.device(device)
+        f32 = torch.float32
+        self.out_map = torch.zeros((n_inframe, self.nside, self.nside), dtype=f32, device=dev)
+        self.maps = {k: torch.zeros((1, self.nside, self.nside), dtype=f32, device=dev) for k in ("UC", "Sigma", "kappa", "Tsum", "Neff")}
+        self.T_weightmap = torch.zeros((n_expo, n1P, n1P), dtype=f32, device=dev)
+
+    def add(self, res, jst, ist):
+        """Add a finished StampBatchResult; jst/ist = 1-based OutStamp indices of its stamps (coadd.py:1963)."""
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        jst = np.ascontiguousarray(jst, dtype=np.int32)
+        ist = np.ascontiguousarray(ist, dtype=np.int32)
+        b = len(jst)
+        h = self.ctx.handle
+
+        def acc(src, nlayer, dst):
+            src = src.contiguous()
+            check(lib.imcom_block_accumulate(h, b, _hp(jst), _hp(ist), self.n2, self.fade, nlayer, _dp(src),
+                                             1 if src.dtype == torch.float64 else 0, _dp(dst), self.nside))
+
+        acc(res.outimage, self.n_inframe, self.out_map)
+        acc(res.UC, 1, self.maps["UC"])
+        acc(res.Sigma, 1, self.maps["Sigma"])
+        acc(res.kappa, 1, self.maps["kappa"])
+        acc(res.Tsum_inpix, 1, self.maps["Tsum"])
+        acc(res.Neff, 1, self.maps["Neff"])
+        # T_weightmap[:, j_st-1, i_st-1] = Tsum_stamp (coadd.py:1981): plain indexed copy
+        jj = torch.as_tensor(jst.astype(np.int64) - 1, device=self.T_weightmap.device)
+        ii = torch.as_tensor(ist.astype(np.int64) - 1, device=self.T_weightmap.device)
+        self.T_weightmap[:, jj, ii] = res.Tsum_stamp[:, : self.n_expo].T.to(torch.float32)
+
+    def finalize(self, pad_sides="", postage_pad=0):
+        """coadd.py:2163-2181: recover the faded block boundary (the padding sides listed in `pad_sides` are
+        recovered at the array edge, the others `postage_pad` stamps further in)."""
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        h = self.ctx.handle
+        check(lib.imcom_trapezoid_recover_f32(h, _dp(self.out_map), self.n_inframe, self.nside, self.nside, self.fade, 0, 0, 0, 0))
+        w = postage_pad * self.n2
+        pads = [w * (s not in pad_sides) for s in "BTLR"]
+        for m in self.maps.values():
+            check(lib.imcom_trapezoid_recover_f32(h, _dp(m), 1, self.nside, self.nside, self.fade, *pads))

@@ -1,0 +1,102 @@
+// block.hip -- block-level accumulation of finished stamps on the device.
+//
+// Replaces the map updates of Block._output_stamp_wrapper (reference src/pyimcom/coadd.py:1975-1993:
+// out_map / UC / Sigma / kappa / Tsum / Neff maps += the stamp's n2f x n2f tile at
+// rows (j_st-1)*n2 .., cols (i_st-1)*n2 .., neighbouring stamps overlapping by 2*fade pixels) and the
+// boundary recovery of Block.build_output_file (coadd.py:2163-2181: OutStamp.trapezoid(..., recover_mode=True,
+// pad_widths)).  All maps are float32 as in the reference (coadd.py:2031-2047); float64 per-stamp inputs
+// (Tsum_inpix, Neff) are added in double and rounded once, as numpy's `f32 += f64` does.
+#include "common.h"
+#include "launchers.h"
+
+namespace imcom {
+
+template <typename SRC>
+__global__ void block_accumulate_kernel(int npass, const int *__restrict__ list, const int *__restrict__ jst,
+                                        const int *__restrict__ ist, int n2, int n2f, int nlayer,
+                                        const SRC *__restrict__ src, float *__restrict__ dst, int nside)
+{
+    // grid: (pixels of one tile, stamps of this parity pass, layers)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n2f * n2f || (int)blockIdx.y >= npass) return;
+    const int s = list[blockIdx.y], layer = blockIdx.z;
+    const int r = t / n2f, c = t - r * n2f;
+    const int row = (jst[s] - 1) * n2 + r, col = (ist[s] - 1) * n2 + c;
+    float *d = dst + ((long)layer * nside + row) * nside + col;
+    const SRC v = src[((long)s * nlayer + layer) * n2f * n2f + t];
+    *d = (float)((double)*d + (double)v);
+}
+
+// coadd.py:1284-1292 with pad widths (1262-1267): divide the 2f boundary rows/cols by the taper, B, T, L, R
+__global__ void trapezoid_recover_kernel(float *__restrict__ maps, long nmaps, int ny, int nx, int fade, int pb, int pt,
+                                         int pl, int pr)
+{
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (t >= nmaps * ny * nx) return;
+    const int x = (int)(t % nx), y = (int)((t / nx) % ny);
+    const int fk2 = 2 * fade;
+    const double two_pi = 6.283185307179586;
+    auto taper = [&](int k) { double s = (double)(k + 1) / (fk2 + 1); return s - sin(two_pi * s) / two_pi; };
+    float v = maps[t];
+    const int it = ny - pt - 1, ir = nx - pr - 1;
+    if (y >= pb && y < pb + fk2) v = (float)((double)v / taper(y - pb));
+    if (y <= it && y > it - fk2) v = (float)((double)v / taper(it - y));
+    if (x >= pl && x < pl + fk2) v = (float)((double)v / taper(x - pl));
+    if (x <= ir && x > ir - fk2) v = (float)((double)v / taper(ir - x));
+    maps[t] = v;
+}
+
+}  // namespace imcom
+
+using namespace imcom;
+
+extern "C" int imcom_block_accumulate(imcom_ctx *ctx, int batch, const int *jst_host, const int *ist_host, int n2, int fade,
+                                      int nlayer, const void *src, int src_is_f64, float *dst, int nside_pf)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
+    IMCOM_REQUIRE(batch >= 1 && jst_host && ist_host && src && dst && n2 >= 1 && fade >= 0 && nlayer >= 1, "bad arguments");
+    const int n2f = n2 + 2 * fade;
+    IMCOM_REQUIRE(2 * fade <= n2, "fade=%d: neighbouring stamps must overlap by less than a stamp", fade);
+    for (int s = 0; s < batch; s++)
+        IMCOM_REQUIRE(jst_host[s] >= 1 && ist_host[s] >= 1 && jst_host[s] * n2 + 2 * fade <= nside_pf && ist_host[s] * n2 + 2 * fade <= nside_pf,
+                      "stamp %d (%d,%d) outside the block", s, jst_host[s], ist_host[s]);
+    IMCOM_TRY(ws_reserve(ctx, (size_t)batch * 12 + 1024));
+    int *jd = (int *)ws_take(ctx, (size_t)batch * 4), *id = (int *)ws_take(ctx, (size_t)batch * 4), *ld = (int *)ws_take(ctx, (size_t)batch * 4);
+    // stamps of equal index parity never overlap: four ordered passes make the overlap sums deterministic
+    std::vector<int> order;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int p = 0; p < 4; p++)
+        for (int s = 0; s < batch; s++)
+            if ((((jst_host[s] & 1) << 1) | (ist_host[s] & 1)) == p) { order.push_back(s); cnt[p]++; }
+    IMCOM_HIP_CHECK(hipMemcpyAsync(jd, jst_host, (size_t)batch * 4, hipMemcpyHostToDevice, ctx->stream));
+    IMCOM_HIP_CHECK(hipMemcpyAsync(id, ist_host, (size_t)batch * 4, hipMemcpyHostToDevice, ctx->stream));
+    IMCOM_HIP_CHECK(hipMemcpyAsync(ld, order.data(), (size_t)batch * 4, hipMemcpyHostToDevice, ctx->stream));
+    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // `order` is a local
+    int off = 0;
+    for (int p = 0; p < 4; p++) {
+        if (cnt[p] == 0) continue;
+        dim3 grid((n2f * n2f + 255) / 256, cnt[p], nlayer);
+        if (src_is_f64)
+            hipLaunchKernelGGL(block_accumulate_kernel<double>, grid, dim3(256), 0, ctx->stream, cnt[p], ld + off, jd, id, n2, n2f, nlayer,
+                               (const double *)src, dst, nside_pf);
+        else
+            hipLaunchKernelGGL(block_accumulate_kernel<float>, grid, dim3(256), 0, ctx->stream, cnt[p], ld + off, jd, id, n2, n2f, nlayer,
+                               (const float *)src, dst, nside_pf);
+        off += cnt[p];
+    }
+    return check_launch("block_accumulate_kernel");
+}
+
+extern "C" int imcom_trapezoid_recover_f32(imcom_ctx *ctx, float *maps, long nmaps, int ny, int nx, int fade, int pad_b, int pad_t,
+                                           int pad_l, int pad_r)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
+    IMCOM_REQUIRE(maps && nmaps >= 0 && ny >= 1 && nx >= 1 && fade >= 0 && pad_b >= 0 && pad_t >= 0 && pad_l >= 0 && pad_r >= 0, "bad arguments");
+    if (fade == 0 || nmaps == 0) return IMCOM_OK;
+    const long tot = nmaps * ny * nx;
+    hipLaunchKernelGGL(trapezoid_recover_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, maps, nmaps, ny, nx, fade,
+                       pad_b, pad_t, pad_l, pad_r);
+    return check_launch("trapezoid_recover_kernel");
+}

@@ -1,0 +1,62 @@
+"""Device-side block accumulation against the oracle's restatement of coadd.py:1975-1993, 2163-2181."""
+
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_block_maps_vs_oracle():
+    import torch
+
+    from oracle import oracle as orc
+    from pyimcom_amd import synth
+    from pyimcom_amd.block import BlockMaps
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    cfg = dataclasses.replace(synth.CONFIGS["tiny"], fade=2)
+    n1P = 4
+    ids = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    stamps = [synth.make_stamp(cfg, 100 + k) for k in range(len(ids))]
+    psfs, target = synth.make_psfs(cfg, 3)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    res = StampBatch(cfg, stamps, tabs).run()
+    bm = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3)
+    half = len(ids) // 2  # two calls: overlaps both inside a call and across calls
+    for sl in (slice(0, half), slice(half, None)):
+        sub = dataclasses.replace(res, outimage=res.outimage[sl], UC=res.UC[sl], Sigma=res.Sigma[sl], kappa=res.kappa[sl],
+                                  Tsum_inpix=res.Tsum_inpix[sl], Neff=res.Neff[sl], Tsum_stamp=res.Tsum_stamp[sl])
+        bm.add(sub, [j for j, _ in ids[sl]], [i for _, i in ids[sl]])
+    torch.cuda.synchronize()
+    ns = bm.nside
+    ref = {k: np.zeros((1, ns, ns), np.float32) for k in ("UC", "Sigma", "kappa", "Tsum", "Neff")}
+    ref_out = np.zeros((1, cfg.n_inframe, ns, ns), np.float32)
+    src = dict(UC=res.UC, Sigma=res.Sigma, kappa=res.kappa, Tsum=res.Tsum_inpix, Neff=res.Neff)
+    for k, (j, i) in enumerate(ids):
+        orc.block_accumulate(ref_out, res.outimage[k].cpu().numpy()[None], j, i, cfg.n2, cfg.fade)
+        for name in ref:
+            orc.block_accumulate(ref[name], src[name][k].cpu().numpy()[None], j, i, cfg.n2, cfg.fade)
+    # float32 sums of up to four overlapping stamps: the order may differ from the reference's visiting order,
+    # so allow a few float32 ulps of the largest term (signed images can cancel)
+    def close(a, b):
+        return np.abs(a - b).max() <= 4e-7 * np.abs(b).max()
+
+    assert close(bm.out_map.cpu().numpy(), ref_out[0])
+    for name in ref:
+        assert close(bm.maps[name].cpu().numpy(), ref[name]), name
+    tw = bm.T_weightmap.cpu().numpy()
+    assert np.allclose(tw[:, 1, 2], res.Tsum_stamp[1 * n1P + 2].cpu().numpy().astype(np.float32))
+    bm.finalize(pad_sides="BL", postage_pad=1)
+    torch.cuda.synchronize()
+    orc.trapezoid_recover(ref_out, cfg.fade)
+    w = cfg.n2
+    for name in ref:
+        orc.trapezoid_recover(ref[name], cfg.fade, (0, w, 0, w))
+        assert close(bm.maps[name].cpu().numpy(), ref[name]), name
+    assert close(bm.out_map.cpu().numpy(), ref_out[0])
+    # the taper is a partition of unity: s_k + s_(2f+1-k) = 1, which is what makes the overlap-add exact
+    s = np.arange(1, 2 * cfg.fade + 1) / (2 * cfg.fade + 1.0)
+    s = s - np.sin(2 * np.pi * s) / (2 * np.pi)
+    assert np.allclose(s + s[::-1], 1.0)
