@@ -128,10 +128,6 @@ static int upload(imcom_ctx *ctx, T *dst, const T *src_host, size_t count)
 //   A  [batch][Np][Np]   identity-padded, never modified
 //   Bt [batch][Np][mp]   input-pixel-major -B/2, zero padded
 // Produces Tt (float32 [batch][Np][mp]) and the per-pixel maps.
-size_t jacobi_ws_bytes(int batch, int ld);
-int jacobi_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA,
-                       double *lam, long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out);
-
 static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
 {
     WsPlan p;
@@ -150,7 +146,7 @@ static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
         p.add((size_t)batch * m * nv * 8);       // W
     }
     // repair path (lakernel.py:262-279): eigenvalues of ONE stamp's A at a time
-    p.add(jacobi_ws_bytes(1, Np) + (size_t)Np * Np * 8 + (size_t)Np * 8 + 1024);
+    p.add(eigh_ws_bytes(1, Np, false) + (size_t)Np * Np * 8 + (size_t)Np * 8 + 1024);
     return p.total + 4096;
 }
 
@@ -159,10 +155,10 @@ static int lambda_min(imcom_ctx *ctx, const double *A_s, int n, int Np, double *
 {
     const size_t mark = ctx->ws_used;
     double *lam = (double *)ws_take(ctx, (size_t)Np * 8);
-    double *Q = (double *)ws_take(ctx, (size_t)Np * Np * 8);
-    if (!lam || !Q) { set_error("internal: workspace (repair)"); return IMCOM_ERR_NOMEM; }
-    IMCOM_HIP_CHECK(hipMemsetAsync(Q, 0, (size_t)Np * Np * 8, ctx->stream));
-    int rc = jacobi_eigh_device(ctx, 1, &n, Np, A_s, Np, (long)Np * Np, lam, Np, Q, Np, (long)Np * Np, nullptr);
+    double *Q = eigh_uses_jacobi() ? (double *)ws_take(ctx, (size_t)Np * Np * 8) : nullptr;  // eigenvalues only otherwise
+    if (!lam || (eigh_uses_jacobi() && !Q)) { set_error("internal: workspace (repair)"); return IMCOM_ERR_NOMEM; }
+    if (Q) IMCOM_HIP_CHECK(hipMemsetAsync(Q, 0, (size_t)Np * Np * 8, ctx->stream));
+    int rc = eigh_device(ctx, 1, &n, Np, A_s, Np, (long)Np * Np, lam, Np, Q, Np, (long)Np * Np, nullptr);
     if (rc == IMCOM_OK) {
         hipError_t e = hipMemcpyAsync(w0, lam, 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

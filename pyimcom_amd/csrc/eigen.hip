@@ -1,7 +1,7 @@
 // eigen.hip -- the eigendecomposition LA path (reference src/pyimcom/lakernel.py:141-223 EigenKernel)
 // and the public batched eigensolver entry point.
 //
-//   lam, Q = eigh(A)                     jacobi.hip (one-sided block Jacobi)
+//   lam, Q = eigh(A)                     tridiag.hip (Householder tridiagonalisation + implicit QR)
 //   P = (-B/2) Q                         fp64 MFMA GEMM
 //   single kappa (154-172): Sigma_a = sum_i (P_ai/(lam_i+kappa))^2, UC_a = 1 - sum_i (lam_i+2 kappa) P_ai^2/(lam_i+kappa)^2 / C
 //   multi kappa  (174-223): routine.lakernel1 per output pixel, then kappa *= C (line 222)
@@ -10,10 +10,6 @@
 #include "launchers.h"
 
 namespace imcom {
-
-size_t jacobi_ws_bytes(int batch, int ld);
-int jacobi_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA,
-                       double *lam, long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out);
 
 // Bp[s][a][j] = B[s][a*ldb + j] for a < m, j < n[s]; zero elsewhere   ([mp][np] row-major)
 __global__ void pad_B_kernel(const double *__restrict__ B, long ldb, int m, const int *__restrict__ n, double *__restrict__ Bp,
@@ -106,7 +102,7 @@ extern "C" int imcom_eigh(imcom_ctx *ctx, int batch, const int *n, int ldn, cons
     const bool host = memspace == IMCOM_MEM_HOST;
     const int ld = (int)align_up((size_t)std::max(nmax, 1), NB);
     const size_t szA = (size_t)batch * ldn * ldn, szL = (size_t)batch * ldn;
-    size_t total = jacobi_ws_bytes(batch, ld) + 8192;
+    size_t total = eigh_ws_bytes(batch, ld, true) + 8192;
     if (host) total += (2 * szA + szL) * 8 + 1024;
     IMCOM_TRY(ws_reserve(ctx, total));
     const double *A_d = A;
@@ -121,7 +117,7 @@ extern "C" int imcom_eigh(imcom_ctx *ctx, int batch, const int *n, int ldn, cons
     }
     IMCOM_HIP_CHECK(hipMemsetAsync(Q_d, 0, szA * 8, ctx->stream));
     IMCOM_HIP_CHECK(hipMemsetAsync(lam_d, 0, szL * 8, ctx->stream));
-    IMCOM_TRY(jacobi_eigh_device(ctx, batch, n, ld, A_d, ldn, (long)ldn * ldn, lam_d, ldn, Q_d, ldn, (long)ldn * ldn, nullptr));
+    IMCOM_TRY(eigh_device(ctx, batch, n, ld, A_d, ldn, (long)ldn * ldn, lam_d, ldn, Q_d, ldn, (long)ldn * ldn, nullptr));
     if (host) {
         IMCOM_HIP_CHECK(hipMemcpyAsync(lam, lam_d, szL * 8, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipMemcpyAsync(Q, Q_d, szA * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -148,7 +144,7 @@ extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ld
     const int np = (int)align_up((size_t)std::max(nmax, 1), NB), mp = (int)align_up((size_t)m, NB);
     const size_t szA = (size_t)batch * ldn * ldn, szB = (size_t)batch * m * ldn, szM = (size_t)batch * m;
     const size_t big = (size_t)batch * mp * np * 8;
-    size_t total = jacobi_ws_bytes(batch, np) + 4 * big + (size_t)batch * np * np * 8 + (size_t)batch * np * 8 + 3 * szM * 8 + 65536;
+    size_t total = eigh_ws_bytes(batch, np, true) + 4 * big + (size_t)batch * np * np * 8 + (size_t)batch * np * 8 + 3 * szM * 8 + 65536;
     if (host) total += szA * 8 + szB * 8 + szB * 4 + szM * 12;
     IMCOM_TRY(ws_reserve(ctx, total));
     const double *A_d = A, *B_d = mBhalf;
@@ -182,7 +178,7 @@ extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ld
     IMCOM_HIP_CHECK(hipMemsetAsync(lam, 0, (size_t)batch * np * 8, ctx->stream));
     if (nmax > 0) {
         int sweeps = 0;
-        IMCOM_TRY(jacobi_eigh_device(ctx, batch, n, np, A_d, ldn, (long)ldn * ldn, lam, np, Q, np, (long)np * np, &sweeps));
+        IMCOM_TRY(eigh_device(ctx, batch, n, np, A_d, ldn, (long)ldn * ldn, lam, np, Q, np, (long)np * np, &sweeps));
     }
     hipLaunchKernelGGL(pad_B_kernel, dim3((np + 255) / 256, mp, batch), dim3(256), 0, ctx->stream, B_d, (long)ldn, m, n_dev, Bp, mp, np);
     IMCOM_TRY(check_launch("pad_B_kernel"));

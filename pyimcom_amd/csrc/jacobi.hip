@@ -328,6 +328,16 @@ __global__ __launch_bounds__(256) void jacobi_scatter_kernel(const double *__res
     }
 }
 
+// Shared tail of both eigensolvers: ascending order + eigenvectors scattered into the columns of Q (Q may be
+// null: eigenvalues only).  Vt rows are eigenvectors, lam_raw[s*ld + a] their eigenvalues.
+int launch_eig_sort_scatter(imcom_ctx *ctx, const double *Vt, int ld, const double *lam_raw, const int *n_dev, int *rank,
+                            double *lam, long ldlam, double *Q, long ldq, long strideQ, int batch)
+{
+    hipLaunchKernelGGL(jacobi_rank_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, ctx->stream, lam_raw, ld, n_dev, rank, lam, ldlam);
+    if (Q) hipLaunchKernelGGL(jacobi_scatter_kernel, dim3(ld / 32, ld / 32, batch), dim3(256), 0, ctx->stream, Vt, ld, rank, n_dev, Q, ldq, strideQ);
+    return check_launch("eig sort/scatter");
+}
+
 // -------------------------------------------------------------------------------------------------
 size_t jacobi_ws_bytes(int batch, int ld)
 {
@@ -418,9 +428,7 @@ int jacobi_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, con
                        (double *)nullptr, ld, (const double *)nullptr);
     IMCOM_TRY(launch_gemm(ctx, false, true, ld, ld, ld, batch, Vt, ld, (long)ld * ld, Gt, ld, (long)ld * ld, G2, ld, (long)ld * ld, 1.0, 0.0));
     hipLaunchKernelGGL(jacobi_lambda_kernel, dim3((ld + 3) / 4, batch), dim3(256), 0, ctx->stream, G2, Vt, ld, n_dev, lam_raw);
-    hipLaunchKernelGGL(jacobi_rank_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, ctx->stream, lam_raw, ld, n_dev, rank, lam, ldlam);
-    hipLaunchKernelGGL(jacobi_scatter_kernel, dim3(ld / 32, ld / 32, batch), dim3(256), 0, ctx->stream, Vt, ld, rank, n_dev, Q, ldq, strideQ);
-    return check_launch("jacobi finish");
+    return launch_eig_sort_scatter(ctx, Vt, ld, lam_raw, n_dev, rank, lam, ldlam, Q, ldq, strideQ, batch);
 }
 
 }  // namespace imcom

@@ -19,6 +19,12 @@ int launch_gemm(imcom_ctx *ctx, bool akm, bool bkm, int M, int N, int K, int bat
                 long strideA, const double *B, long ldb, long strideB, double *C, long ldc, long strideC,
                 double alpha, double beta);
 
+// tridiag.hip (dispatch between the tridiagonal QR eigensolver and the Jacobi cross-check, jacobi.hip)
+bool eigh_uses_jacobi();
+size_t eigh_ws_bytes(int batch, int ld, bool vectors);
+int eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA, double *lam,
+                long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out);
+
 // la_kernels.hip
 int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail);
 int launch_diag_shift(imcom_ctx *ctx, const double *A, int ldn, const double *inc, const int *ninc, double *dshift,

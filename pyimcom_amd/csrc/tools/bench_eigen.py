@@ -18,4 +18,4 @@ for rep in range(2):
     b.ctx.profile_reset()
     torch.cuda.synchronize(); t = time.perf_counter()
     b.run(); torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print(f"{name} batch {nb} N~{b.n.mean():.0f}: {dt*1e3:.1f} ms/step = {dt/nb*1e3:.1f} ms/stamp", {f: round(b.ctx.profile_get(f)[0], 1) for f in ("eigen_jacobi", "eigen_gemm", "lakernel1", "build_A", "build_B")})
+    print(f"{name} batch {nb} N~{b.n.mean():.0f}: {dt*1e3:.1f} ms/step = {dt/nb*1e3:.1f} ms/stamp", {f: round(b.ctx.profile_get(f)[0], 1) for f in ("eigen_jacobi", "eigen_trd", "eigen_orgtr", "eigen_qr", "eigen_gemm", "lakernel1", "build_A", "build_B")})

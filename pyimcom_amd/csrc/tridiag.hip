@@ -1,0 +1,691 @@
+// tridiag.hip -- batched symmetric eigensolver: blocked Householder tridiagonalisation, implicit-shift QR on
+// the tridiagonal with logged Givens rotations, and a register-window wavefront kernel that applies the
+// logged rotations to the accumulated reflectors.  Replaces numpy.linalg.eigh at reference
+// src/pyimcom/lakernel.py:162, 201 (EigenKernel) and 266 (Cholesky repair).
+//
+//   A = Qh T Qh^T      Qh = H_0 H_1 ... H_{n-3},  H_j = I - tau_j v_j v_j^T          (trd_* kernels + GEMM)
+//   T = G Lambda G^T   G = product of the logged rotations                          (tql_chunk_kernel)
+//   eigenvectors       rows of X = (Qh G)^T, built as X = Qh^T then rotated in place  (orgtr GEMMs + rot_apply_kernel)
+//
+// Layouts (per stamp, all [ld][ld] with ld a multiple of 128, zero padded beyond n):
+//   At    working copy of A; after panel p the trailing block [pe:, pe:] holds the two-sided update
+//   Vall  Vall[j][r] = component r of reflector j (v_j[j+1] = 1, zero above) -- a panel of 128 reflectors is a
+//         k-major GEMM operand as it lies
+//   X     X[k][i] = component i of eigenvector k
+// The panel algorithm is the classic one (w_j = tau (A v - V W^T v - W V^T v), w += -1/2 tau (w.v) v, trailing
+// update A -= V W^T + W V^T); what is specific here is the batching: every kernel runs one column step for the
+// whole batch of stamps, the matrix-vector product is the only pass over the trailing matrix (HBM bound,
+// 8 n^2 bytes per column), and ragged n is handled by per-stamp guards.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "launchers.h"
+
+namespace imcom {
+
+constexpr int TP = NB;          // reflectors per panel
+constexpr int QRS = 16;         // QR sweeps per chunk = depth of the rotation wavefront
+constexpr int ROTPAD = 4 * QRS; // identity margin of the rotation log on both sides
+
+int launch_eig_sort_scatter(imcom_ctx *ctx, const double *Vt, int ld, const double *lam_raw, const int *n_dev, int *rank,
+                            double *lam, long ldlam, double *Q, long ldq, long strideQ, int batch);
+
+__device__ inline double block_sum_256(double v, double *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// At = A on the leading n x n (zero elsewhere), X = I
+__global__ void trd_init_kernel(const double *__restrict__ A, long lda, long strideA, const int *__restrict__ n,
+                                double *__restrict__ At, double *__restrict__ X, int ld)
+{
+    const int s = blockIdx.z, i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ld) return;
+    const int ns = n[s];
+    const long o = (long)s * ld * ld + (long)i * ld + j;
+    At[o] = (i < ns && j < ns) ? A[s * strideA + (long)i * lda + j] : 0.0;
+    if (X) X[o] = (i == j) ? 1.0 : 0.0;
+}
+
+// Column step, part 1.  (a) finish the previous reflector's w:  W[k-1] = w' + alpha v, alpha = -1/2 tau (w'.v);
+// (b) current column of the implicitly updated matrix: u = A[:, j] - V W[j,:]^T - W V[j,:]^T on rows >= j,
+// d_j = u_j, partial sums of u_r^2 (r >= j+2) for the Householder norm.
+__global__ __launch_bounds__(256) void trd_column_kernel(const double *__restrict__ At, double *__restrict__ Vall,
+                                                         double *__restrict__ Wp, const double *__restrict__ wprime,
+                                                         double *__restrict__ ubuf, double *__restrict__ dvec,
+                                                         const double *__restrict__ hd, const double *__restrict__ pdot,
+                                                         double *__restrict__ pnorm, const int *__restrict__ n, int ld, int j,
+                                                         int ps, int npart, int column_part)
+{
+    __shared__ double bw[TP], bv[TP], red[4];
+    const int s = blockIdx.y, ns = n[s];
+    if (j >= ns) return;
+    const int k = j - ps;
+    const long so = (long)s * ld * ld;
+    const double *V = Vall + so + (long)ps * ld;
+    double *W = Wp + (long)s * TP * ld;
+    const double *wp = wprime + (long)s * ld;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    double alpha = 0.0;
+    if (k > 0) {
+        double dsum = 0.0;
+        for (int q = 0; q < npart; q++) dsum += pdot[s * npart + q];
+        alpha = -0.5 * hd[s * 4] * dsum;
+    }
+    if ((int)threadIdx.x < k) {
+        const int c = threadIdx.x;
+        const double vj = V[(long)c * ld + j];
+        bv[c] = vj;
+        bw[c] = (c == k - 1) ? wp[j] + alpha * vj : W[(long)c * ld + j];
+    }
+    __syncthreads();
+    const bool act = r >= j && r < ns;
+    double u = 0.0;
+    if (act) {
+        double wlast = 0.0, vlast = 0.0;
+        if (k > 0) {
+            vlast = V[(long)(k - 1) * ld + r];
+            wlast = wp[r] + alpha * vlast;
+            W[(long)(k - 1) * ld + r] = wlast;
+        }
+        if (column_part) {
+            u = At[so + (long)j * ld + r];  // row j read as column j (the trailing matrix is symmetric)
+            for (int c = 0; c < k - 1; c++) u -= V[(long)c * ld + r] * bw[c] + W[(long)c * ld + r] * bv[c];
+            if (k > 0) u -= vlast * bw[k - 1] + wlast * bv[k - 1];
+            ubuf[(long)s * ld + r] = u;
+            if (r == j) dvec[(long)s * ld + j] = u;
+        }
+    }
+    if (column_part) {
+        const double sq = block_sum_256((act && r >= j + 2) ? u * u : 0.0, red);
+        if (threadIdx.x == 0) pnorm[s * npart + blockIdx.x] = sq;
+    }
+}
+
+struct HouseScalars {
+    double beta, tau, scale;
+};
+
+__device__ inline HouseScalars house_scalars(const double *pnorm, int npart, double a0)
+{
+    double xn2 = 0.0;
+    for (int q = 0; q < npart; q++) xn2 += pnorm[q];
+    HouseScalars h;
+    if (xn2 == 0.0) { h.beta = a0; h.tau = 0.0; h.scale = 0.0; }
+    else {
+        h.beta = -copysign(sqrt(a0 * a0 + xn2), a0);
+        h.tau = (h.beta - a0) / h.beta;
+        h.scale = 1.0 / (a0 - h.beta);
+    }
+    return h;
+}
+
+// Column step, part 2.  v = e_{j+1} + scale * u_{>= j+2}.  Row-tile blocks: p = A[j+1:, j+1:] v (the one pass over
+// the trailing matrix).  Dot blocks: (V^T v)_c and (W^T v)_c for the panel's earlier reflectors.
+__global__ __launch_bounds__(256) void trd_symv_kernel(const double *__restrict__ At, const double *__restrict__ Vall,
+                                                       const double *__restrict__ Wp, const double *__restrict__ ubuf,
+                                                       const double *__restrict__ pnorm, double *__restrict__ pvec,
+                                                       double *__restrict__ hd, double *__restrict__ evec,
+                                                       double *__restrict__ tauvec, double *__restrict__ wv,
+                                                       const int *__restrict__ n, int ld, int j, int ps, int npart, int nrowtiles)
+{
+    const int s = blockIdx.y, ns = n[s];
+    if (j + 1 >= ns) return;
+    const double *u = ubuf + (long)s * ld;
+    const HouseScalars h = house_scalars(pnorm + s * npart, npart, u[j + 1]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hd[s * 4] = h.tau;
+        hd[s * 4 + 1] = h.scale;
+        evec[(long)s * ld + j] = h.beta;
+        tauvec[(long)s * ld + j] = h.tau;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long so = (long)s * ld * ld;
+    if ((int)blockIdx.x < nrowtiles) {
+        const int rbase = ((j + 1) & ~31) + blockIdx.x * 32 + wave * 8;
+        if (rbase >= ns) return;
+        const double *A = At + so + (long)rbase * ld;
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = (j + 2) & ~127; c < ns; c += 128) {
+            const int cc = c + 2 * lane;
+            double2 uu = *(const double2 *)(u + cc);
+            if (cc < j + 2 || cc >= ns) uu.x = 0.0;
+            if (cc + 1 < j + 2 || cc + 1 >= ns) uu.y = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const double2 a = *(const double2 *)(A + (long)i * ld + cc);
+                acc[i] += a.x * uu.x + a.y * uu.y;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int r = rbase + i;
+                if (r >= j + 1 && r < ns) pvec[(long)s * ld + r] = A[(long)i * ld + (j + 1)] + h.scale * acc[i];
+            }
+        }
+    } else {
+        const int wid = (blockIdx.x - nrowtiles) * 4 + wave, c = wid >> 1, which = wid & 1;
+        if (c >= j - ps) return;
+        const double *vec = (which ? Wp + (long)s * TP * ld : Vall + so + (long)ps * ld) + (long)c * ld;
+        double acc = 0.0;
+        for (int r = j + 2 + lane; r < ns; r += 64) acc += vec[r] * u[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) wv[((long)s * 2 + which) * TP + c] = vec[j + 1] + h.scale * acc;
+    }
+}
+
+// Column step, part 3.  w' = tau (p - V (W^T v) - W (V^T v)) on rows >= j+1, v stored as reflector j, partial w'.v
+__global__ __launch_bounds__(256) void trd_w_kernel(double *__restrict__ Vall, const double *__restrict__ Wp,
+                                                    const double *__restrict__ ubuf, const double *__restrict__ pvec,
+                                                    const double *__restrict__ hd, const double *__restrict__ wv,
+                                                    double *__restrict__ wprime, double *__restrict__ pdot,
+                                                    const int *__restrict__ n, int ld, int j, int ps, int npart)
+{
+    __shared__ double swv[TP], svv[TP], red[4];
+    const int s = blockIdx.y, ns = n[s];
+    if (j + 1 >= ns) return;
+    const int k = j - ps;
+    const double tau = hd[s * 4], scale = hd[s * 4 + 1];
+    if ((int)threadIdx.x < k) {
+        svv[threadIdx.x] = wv[((long)s * 2 + 0) * TP + threadIdx.x];
+        swv[threadIdx.x] = wv[((long)s * 2 + 1) * TP + threadIdx.x];
+    }
+    __syncthreads();
+    const long so = (long)s * ld * ld;
+    double *V = Vall + so + (long)ps * ld;
+    const double *W = Wp + (long)s * TP * ld;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    double prod = 0.0;
+    if (r >= j + 1 && r < ns) {
+        const double v = (r == j + 1) ? 1.0 : ubuf[(long)s * ld + r] * scale;
+        double acc = pvec[(long)s * ld + r];
+        for (int c = 0; c < k; c++) acc -= V[(long)c * ld + r] * swv[c] + W[(long)c * ld + r] * svv[c];
+        const double w = tau * acc;
+        wprime[(long)s * ld + r] = w;
+        V[(long)k * ld + r] = v;
+        prod = w * v;
+    }
+    const double t = block_sum_256(prod, red);
+    if (threadIdx.x == 0) pdot[s * npart + blockIdx.x] = t;
+}
+
+// Triangular factor of a panel's block reflector H_ps ... H_pe-1 = I - V T V^T (forward, column-wise):
+// T[c][c] = tau_c, T[0:c, c] = -tau_c T[0:c, 0:c] (V^T v_c).  S = V^T V comes from a GEMM.  One block per stamp.
+__global__ __launch_bounds__(128) void trd_larft_kernel(const double *__restrict__ S, const double *__restrict__ tauvec, int ld,
+                                                        int ps, double *__restrict__ T)
+{
+    extern __shared__ double Ts[];  // [TP][TP]
+    const int s = blockIdx.x, r = threadIdx.x;
+    const double *Ss = S + (long)s * TP * TP;
+    for (int q = 0; q < TP; q++) Ts[r * TP + q] = 0.0;
+    __syncthreads();
+    for (int c = 0; c < TP; c++) {
+        const int j = ps + c;
+        const double tau = j < ld ? tauvec[(long)s * ld + j] : 0.0;
+        double t = 0.0;
+        if (r < c) {
+            for (int q = r; q < c; q++) t += Ts[r * TP + q] * Ss[(long)q * TP + c];
+            t *= -tau;
+        } else if (r == c) t = tau;
+        __syncthreads();
+        if (r <= c) Ts[r * TP + c] = t;
+        __syncthreads();
+    }
+    for (int q = 0; q < TP; q++) T[(long)s * TP * TP + (long)r * TP + q] = Ts[r * TP + q];
+}
+
+// One Givens step of the implicit QR bulge chase at position k of the block [lo, hi].  Carried state: (x, z) the
+// pair to be rotated, a1 = current d[k], b1 = current e[k].  Returns the rotation [c s; -s c].
+struct QrCarry {
+    double x, z, a1, b1;
+};
+
+__device__ inline double2 qr_step(double *d, double *e, int lo, int hi, int k, QrCarry &q)
+{
+    const double a2 = d[k + 1];
+    const double en = (k < hi - 1) ? e[k + 1] : 0.0;
+    const double h = q.x * q.x + q.z * q.z;
+    double c = 1.0, sn = 0.0, r = 0.0;
+    if (h > 0.0) {
+        const double ir = rsqrt(h);
+        c = q.x * ir;
+        sn = q.z * ir;
+        r = h * ir;
+    }
+    if (k > lo) e[k - 1] = r;
+    const double cc = c * c, ss = sn * sn, csn = c * sn;
+    d[k] = cc * q.a1 + 2.0 * csn * q.b1 + ss * a2;
+    const double ek = csn * (a2 - q.a1) + (cc - ss) * q.b1;
+    q.a1 = ss * q.a1 - 2.0 * csn * q.b1 + cc * a2;  // the new d[k+1]
+    e[k] = ek;
+    if (k == hi - 1) d[hi] = q.a1;
+    q.x = ek;
+    q.z = sn * en;
+    q.b1 = c * en;
+    return make_double2(c, sn);
+}
+
+// number of eigenvalues of the m x m tridiagonal (d, e) below x (Sturm sequence)
+__device__ inline int sturm_count(const double *d, const double *e, int m, double x)
+{
+    double q = d[0] - x;
+    int cnt = q < 0.0;
+    for (int i = 1; i < m; i++) {
+        if (q == 0.0) q = 1e-300;
+        q = d[i] - x - e[i - 1] * e[i - 1] / q;
+        cnt += q < 0.0;
+    }
+    return cnt;
+}
+
+// One chunk of QRS implicit-shift QR sweeps on the tridiagonal (d, e) of every stamp; one wave per stamp working
+// out of LDS.  Two modes, chosen by the size of the bottom unreduced block [lo, hi]:
+//   small block (<= QR_SMALL rows): Wilkinson-shift sweeps one after the other, continuing across deflations;
+//   large block: the QRS sweeps of the chunk use the eigenvalues of the trailing QRS x QRS block as shifts (found by
+//     bisection, one per lane) and run PIPELINED, lane sw chasing its bulge QR_LAG positions behind lane sw-1.
+// Rotation k of sweep sw -- [c s; -s c] on rows/columns (k, k+1) -- is logged at cs[(s*QRS + sw)*ldr + ROTPAD + k];
+// everything else in the log is the identity.
+// state[s]: 0 = bottom of the active part (hi), 1 = done, 2/3 = [LO, HI] rows touched by this chunk,
+// 4 = sweeps so far, 5 = tolerance initialised, 6 = HI of the previous chunk.
+constexpr int QR_SMALL = 3 * QRS;
+constexpr int QR_LAG = 3;
+
+__global__ __launch_bounds__(64) void tql_chunk_kernel(double *__restrict__ dvec, double *__restrict__ evec,
+                                                       double2 *__restrict__ cs, int *__restrict__ state,
+                                                       double *__restrict__ tolv, const int *__restrict__ n, int ld, int ldr,
+                                                       int want_rot, int max_sweeps)
+{
+    extern __shared__ double sm[];
+    const int s = blockIdx.x, ns = n[s], lane = threadIdx.x;
+    int *st = state + s * 8;
+    double *d = sm, *e = sm + ld;
+    if (st[1]) {
+        if (lane == 0) { st[2] = 0; st[3] = -1; }
+        return;
+    }
+    double tmax = 0.0;
+    for (int i = lane; i < ns; i += 64) {
+        d[i] = dvec[(long)s * ld + i];
+        e[i] = (i < ns - 1) ? evec[(long)s * ld + i] : 0.0;
+        tmax = fmax(tmax, fmax(fabs(d[i]), fabs(e[i])));
+    }
+    const bool first = st[5] == 0;
+    double tol;
+    if (first) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, off, 64));
+        tol = 2.220446049250313e-16 * tmax;
+    } else tol = tolv[s];
+    const int fill_hi = first ? ns - 1 : st[6];
+    if (want_rot) {
+        for (int sw = 0; sw < QRS; sw++) {
+            double2 *row = cs + ((long)s * QRS + sw) * ldr + ROTPAD;
+            for (int i = lane; i <= fill_hi; i += 64) row[i] = make_double2(1.0, 0.0);
+        }
+    }
+    __syncthreads();
+    // every lane follows the same control flow (uniform values, LDS broadcast reads); lane 0 stores
+    int hi = first ? ns - 1 : st[0];
+    int LO = ns, HI = -1, sw = 0, total = first ? 0 : st[4];
+    while (hi > 0 && sw < QRS) {
+        if (fabs(e[hi - 1]) <= tol) {
+            __syncthreads();
+            if (lane == 0) e[hi - 1] = 0.0;
+            hi--;
+            continue;
+        }
+        int lo = hi - 1;
+        while (lo > 0 && fabs(e[lo - 1]) > tol) lo--;
+        __syncthreads();
+        if (hi - lo + 1 <= QR_SMALL) {
+            if (lane == 0) {
+                const double dd = 0.5 * (d[hi - 1] - d[hi]), b = e[hi - 1];
+                const double mu = d[hi] - b * b / (dd + copysign(sqrt(dd * dd + b * b), dd));
+                QrCarry q{d[lo] - mu, e[lo], d[lo], e[lo]};
+                double2 *row = cs + ((long)s * QRS + sw) * ldr + ROTPAD;
+                for (int k = lo; k < hi; k++) {
+                    const double2 g = qr_step(d, e, lo, hi, k, q);
+                    if (want_rot) row[k] = g;
+                }
+            }
+            sw++;
+            total++;
+        } else {
+            if (sw > 0) break;  // a large block starts its own chunk (all QRS slots)
+            // shifts: eigenvalue `lane` of the trailing QRS x QRS block, by bisection
+            double mu = 0.0;
+            if (lane < QRS) {
+                const double *db = d + hi - QRS + 1, *eb = e + hi - QRS + 1;
+                double gl = 1e300, gu = -1e300;
+                for (int i = 0; i < QRS; i++) {
+                    const double rad = (i > 0 ? fabs(eb[i - 1]) : 0.0) + (i < QRS - 1 ? fabs(eb[i]) : 0.0);
+                    gl = fmin(gl, db[i] - rad);
+                    gu = fmax(gu, db[i] + rad);
+                }
+                for (int it = 0; it < 56; it++) {
+                    const double mid = 0.5 * (gl + gu);
+                    if (sturm_count(db, eb, QRS, mid) > lane) gu = mid; else gl = mid;
+                }
+                mu = 0.5 * (gl + gu);
+            }
+            __syncthreads();
+            QrCarry q{0.0, 0.0, 0.0, 0.0};
+            double2 *row = cs + ((long)s * QRS + lane) * ldr + ROTPAD;
+            const int nst = (hi - lo) + QR_LAG * (QRS - 1);
+            for (int t = 0; t < nst; t++) {
+                const int k = lo + t - QR_LAG * lane;
+                if (lane < QRS && k >= lo && k < hi) {
+                    if (k == lo) q = QrCarry{d[lo] - mu, e[lo], d[lo], e[lo]};
+                    const double2 g = qr_step(d, e, lo, hi, k, q);
+                    if (want_rot) row[k] = g;
+                }
+            }
+            sw = QRS;
+            total += QRS;
+        }
+        __syncthreads();
+        LO = min(LO, lo);
+        HI = max(HI, hi);
+    }
+    // trailing deflations so that `done` is seen as early as possible
+    while (hi > 0 && fabs(e[hi - 1]) <= tol) hi--;
+    __syncthreads();
+    if (lane == 0) {
+        st[0] = hi;
+        st[2] = LO;
+        st[3] = HI;
+        st[4] = total;
+        st[5] = 1;
+        st[6] = HI >= 0 ? HI : 0;
+        tolv[s] = tol;
+        if (hi <= 0) st[1] = 1;
+        else if (total >= max_sweeps) st[1] = 2;
+    }
+    for (int i = lane; i < ns; i += 64) {
+        dvec[(long)s * ld + i] = d[i];
+        if (i < ns - 1) evec[(long)s * ld + i] = e[i];
+    }
+}
+
+// Apply one chunk of logged rotations to the rows [LO, HI] of X.  One thread per column of X (coalesced over the
+// component index), one wave per block; the thread keeps a sliding window of 2*S rows in registers and runs the S
+// sweeps as a wavefront: at step t sweep sw applies its rotation at position t - 2 sw, so every row is loaded and
+// stored once per chunk while 4 S multiply-adds are done on it.  Window slots are addressed statically (t mod 2S
+// is a compile-time constant in the unrolled body).  Rows are prefetched ROT_PF steps ahead into a register ring;
+// the rotation coefficients of a group of 2S steps are staged through LDS (double buffered) and read as broadcasts.
+constexpr int ROT_PF = 8;
+
+template <int S>
+__global__ __launch_bounds__(64) void rot_apply_kernel(double *__restrict__ X, const double2 *__restrict__ cs,
+                                                       const int *__restrict__ state, const int *__restrict__ n, int ld, int ldr)
+{
+    constexpr int W = 2 * S;
+    static_assert(W % ROT_PF == 0, "window must be a multiple of the prefetch ring");
+    __shared__ double2 gl[2][W][S];
+    const int s = blockIdx.y, lane = threadIdx.x;
+    const int LO = state[s * 8 + 2], HI = state[s * 8 + 3];
+    if (HI <= LO) return;
+    const int ns = n[s];
+    if ((int)blockIdx.x * 64 >= ns) return;
+    // surplus lanes shadow the last column: same loads, same arithmetic, identical (benign) stores
+    const int i = min((int)blockIdx.x * 64 + lane, ns - 1);
+    double *x0 = X + (long)s * ld * ld + (long)LO * ld + i;
+    // The unrolled body stays branch-free: the surplus steps of the last group store into a scratch row (X carries
+    // one per stamp after the last matrix), the steps before row 0 is final store early values over row 0.
+    const int sinkrow = ((int)gridDim.y - s) * ld + s - LO;
+    const double2 *c0 = cs + (long)s * S * ldr + ROTPAD + LO;
+    const int R = HI - LO, nsteps = R + 2 * S - 1;
+    auto stage = [&](int buf, int t0) {  // lane-consecutive positions within one sweep's row: coalesced
+#pragma unroll
+        for (int q = 0; q < W * S / 64; q++) {
+            const int idx = q * 64 + lane, sw = idx / W, u = idx % W;
+            gl[buf][u][sw] = c0[(long)sw * ldr + (t0 + u - 2 * sw)];
+        }
+    };
+    // rows beyond R are only ever touched by identity rotations and never stored: load row R in their place
+    double w[W], ring[ROT_PF];
+#pragma unroll
+    for (int q = 0; q < W; q++) w[q] = 0.0;
+    w[0] = x0[0];
+#pragma unroll
+    for (int q = 0; q < ROT_PF; q++) ring[q] = x0[(long)min(q + 1, R) * ld];
+    stage(0, 0);
+    int buf = 0;
+    for (int t0 = 0; t0 < nsteps; t0 += W, buf ^= 1) {
+        stage(buf ^ 1, min(t0 + W, nsteps));  // past the end: identity margin of the log
+#pragma unroll
+        for (int u = 0; u < W; u++) {
+            const int t = t0 + u;
+            w[(u + 1) % W] = ring[u % ROT_PF];  // row t+1
+            ring[u % ROT_PF] = x0[(long)min(t + 1 + ROT_PF, R) * ld];
+#pragma unroll
+            for (int sw = 0; sw < S; sw++) {
+                const double2 g = gl[buf][u][sw];
+                const int a = ((u - 2 * sw) % W + W) % W, b = (a + 1) % W;
+                const double xa = w[a], xb = w[b];
+                w[a] = g.x * xa + g.y * xb;
+                w[b] = g.x * xb - g.y * xa;
+                // keep the unrolled rotations in groups of 8: hoisting the LDS reads of later ones spills registers
+                if (sw % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            const int rs = t - 2 * S + 2;
+            const int row = rs > R ? sinkrow : max(rs, 0);
+            x0[(long)row * ld] = w[(u + 2) % W];
+        }
+    }
+}
+
+__global__ void tql_state_init_kernel(int *state, int batch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch * 8) state[i] = 0;
+}
+
+// rotation log = identity everywhere (the margins are never written again)
+__global__ void rot_identity_kernel(double2 *cs, long count)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < count) cs[i] = make_double2(1.0, 0.0);
+}
+
+// -------------------------------------------------------------------------------------------------
+size_t tridiag_ws_bytes(int batch, int ld, bool vectors)
+{
+    const int ldr = ld + 2 * ROTPAD, npart = (ld + 255) / 256;
+    size_t t = 0;
+    auto add = [&](size_t b) { t = align_up(t, 256) + b; };
+    add((size_t)batch * ld * ld * 8);                      // At
+    add((size_t)batch * ld * ld * 8);                      // Vall
+    if (vectors) add((size_t)batch * ld * ld * 8 + (size_t)batch * ld * 8);  // X + one scratch row per stamp
+    add((size_t)batch * TP * ld * 8);                      // Wp
+    if (vectors) { add((size_t)batch * ld * TP * 8); add((size_t)batch * ld * TP * 8); }  // W1, W2
+    if (vectors) { add((size_t)batch * TP * TP * 8); add((size_t)batch * TP * TP * 8); }  // S, T
+    for (int q = 0; q < 6; q++) add((size_t)batch * ld * 8);  // u, p, w', d, e, tau
+    add((size_t)batch * 2 * TP * 8);                       // V^T v, W^T v
+    add((size_t)batch * 4 * 8);                            // hd
+    add((size_t)batch * npart * 8 * 2);                    // pnorm, pdot
+    if (vectors) add((size_t)batch * QRS * ldr * 16);      // rotation log
+    add((size_t)batch * 8 * 4 + (size_t)batch * 8 + (size_t)batch * 4);  // state, tol, n
+    add((size_t)batch * ld * 4);                           // rank
+    return t + 8192;
+}
+
+// Same contract as jacobi_eigh_device: A [batch] matrices (lda, strideA) on the device, n_host ragged, ld the
+// padded size (multiple of 128).  lam[s*ldlam + k] ascending; Q[s*strideQ + i*ldq + k] eigenvectors in columns
+// (Q == nullptr: eigenvalues only).
+int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA,
+                        double *lam, long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out)
+{
+    IMCOM_REQUIRE(ld % NB == 0 && ld >= NB, "tridiag: ld=%d must be a multiple of %d", ld, NB);
+    const bool vectors = Q != nullptr;
+    const int ldr = ld + 2 * ROTPAD, npart = (ld + 255) / 256;
+    const size_t mat = (size_t)batch * ld * ld * 8, vecb = (size_t)batch * ld * 8;
+    double *At = (double *)ws_take(ctx, mat), *Vall = (double *)ws_take(ctx, mat);
+    double *X = vectors ? (double *)ws_take(ctx, mat + (size_t)batch * ld * 8) : nullptr;
+    double *Wp = (double *)ws_take(ctx, (size_t)batch * TP * ld * 8);
+    double *W1 = nullptr, *W2 = nullptr, *Sm = nullptr, *Tm = nullptr;
+    if (vectors) {
+        W1 = (double *)ws_take(ctx, (size_t)batch * ld * TP * 8);
+        W2 = (double *)ws_take(ctx, (size_t)batch * ld * TP * 8);
+        Sm = (double *)ws_take(ctx, (size_t)batch * TP * TP * 8);
+        Tm = (double *)ws_take(ctx, (size_t)batch * TP * TP * 8);
+    }
+    double *ubuf = (double *)ws_take(ctx, vecb), *pvec = (double *)ws_take(ctx, vecb), *wprime = (double *)ws_take(ctx, vecb);
+    double *dvec = (double *)ws_take(ctx, vecb), *evec = (double *)ws_take(ctx, vecb), *tauvec = (double *)ws_take(ctx, vecb);
+    double *wv = (double *)ws_take(ctx, (size_t)batch * 2 * TP * 8);
+    double *hd = (double *)ws_take(ctx, (size_t)batch * 4 * 8);
+    double *pnorm = (double *)ws_take(ctx, (size_t)batch * npart * 8), *pdot = (double *)ws_take(ctx, (size_t)batch * npart * 8);
+    double2 *cs = vectors ? (double2 *)ws_take(ctx, (size_t)batch * QRS * ldr * 16) : nullptr;
+    int *state = (int *)ws_take(ctx, (size_t)batch * 8 * 4);
+    double *tolv = (double *)ws_take(ctx, (size_t)batch * 8);
+    int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
+    int *rank = (int *)ws_take(ctx, (size_t)batch * ld * 4);
+    if (!At || !Vall || (vectors && (!X || !W1 || !W2 || !Sm || !Tm || !cs)) || !Wp || !ubuf || !pvec || !wprime || !dvec || !evec ||
+        !tauvec || !wv || !hd || !pnorm || !pdot || !state || !tolv || !n_dev || !rank) {
+        set_error("internal: tridiag workspace");
+        return IMCOM_ERR_NOMEM;
+    }
+    int nmax = 0;
+    for (int s = 0; s < batch; s++) nmax = std::max(nmax, n_host[s]);
+    hipStream_t st = ctx->stream;
+    IMCOM_HIP_CHECK(hipMemcpyAsync(n_dev, n_host, (size_t)batch * 4, hipMemcpyHostToDevice, st));
+    IMCOM_HIP_CHECK(hipStreamSynchronize(st));  // n_host may be a caller local
+    IMCOM_HIP_CHECK(hipMemsetAsync(Vall, 0, mat, st));
+    for (double *v : {ubuf, pvec, wprime, dvec, evec, tauvec}) IMCOM_HIP_CHECK(hipMemsetAsync(v, 0, vecb, st));
+    IMCOM_HIP_CHECK(hipMemsetAsync(hd, 0, (size_t)batch * 32, st));
+    hipLaunchKernelGGL(trd_init_kernel, dim3((ld + 255) / 256, ld, batch), dim3(256), 0, st, A, lda, strideA, n_dev, At, X, ld);
+    IMCOM_TRY(check_launch("trd_init_kernel"));
+
+    // ---- tridiagonalisation
+    {
+        ProfScope ps_(ctx, "eigen_trd", nmax);
+        for (int ps = 0; ps < nmax; ps += TP) {
+            const int pe = std::min(ps + TP, nmax);
+            IMCOM_HIP_CHECK(hipMemsetAsync(Wp, 0, (size_t)batch * TP * ld * 8, st));
+            for (int j = ps; j < pe; j++) {
+                hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
+                                   n_dev, ld, j, ps, npart, 1);
+                if (j + 1 >= nmax) break;
+                const int nrowtiles = (nmax - ((j + 1) & ~31) + 31) / 32, ndot = (2 * (j - ps) + 3) / 4;
+                hipLaunchKernelGGL(trd_symv_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, Vall, Wp, ubuf, pnorm, pvec, hd,
+                                   evec, tauvec, wv, n_dev, ld, j, ps, npart, nrowtiles);
+                hipLaunchKernelGGL(trd_w_kernel, dim3(npart, batch), dim3(256), 0, st, Vall, Wp, ubuf, pvec, hd, wv, wprime, pdot, n_dev, ld,
+                                   j, ps, npart);
+            }
+            IMCOM_TRY(check_launch("trd column step"));
+            if (ps + TP < nmax) {  // trailing two-sided update A[pe:, pe:] -= V W^T + W V^T
+                const int pe2 = ps + TP, rem = ld - pe2;
+                hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
+                                   n_dev, ld, pe2, ps, npart, 0);
+                const double *Vp = Vall + (long)ps * ld + pe2, *Wq = Wp + pe2;
+                double *C = At + (long)pe2 * ld + pe2;
+                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TP, batch, Vp, ld, (long)ld * ld, Wq, ld, (long)TP * ld, C, ld, (long)ld * ld, -1.0, 1.0));
+                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TP, batch, Wq, ld, (long)TP * ld, Vp, ld, (long)ld * ld, C, ld, (long)ld * ld, -1.0, 1.0));
+            }
+        }
+    }
+
+    // ---- X = Qh^T: X <- X (I - V T^T V^T) panel by panel, last panel first
+    if (vectors) {
+        ProfScope ps_(ctx, "eigen_orgtr");
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TP * TP * 8));
+        const int npanels = (std::max(nmax - 2, 0) + TP - 1) / TP;
+        for (int p = npanels - 1; p >= 0; p--) {
+            const int ps = p * TP, rem = ld - ps;
+            const double *Vp = Vall + (long)ps * ld + ps;  // rows (reflectors) ps.., components ps..
+            double *Xb = X + (long)ps * ld + ps;
+            IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, rem, batch, Vp, ld, (long)ld * ld, Vp, ld, (long)ld * ld, Sm, TP, (long)TP * TP, 1.0, 0.0));
+            hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), TP * TP * 8, st, Sm, tauvec, ld, ps, Tm);
+            IMCOM_TRY(check_launch("trd_larft_kernel"));
+            IMCOM_TRY(launch_gemm(ctx, false, false, rem, TP, rem, batch, Xb, ld, (long)ld * ld, Vp, ld, (long)ld * ld, W1, TP, (long)ld * TP, 1.0, 0.0));
+            IMCOM_TRY(launch_gemm(ctx, false, false, rem, TP, TP, batch, W1, TP, (long)ld * TP, Tm, TP, (long)TP * TP, W2, TP, (long)ld * TP, 1.0, 0.0));
+            IMCOM_TRY(launch_gemm(ctx, false, true, rem, rem, TP, batch, W2, TP, (long)ld * TP, Vp, ld, (long)ld * ld, Xb, ld, (long)ld * ld, -1.0, 1.0));
+        }
+    }
+
+    // ---- implicit QR on the tridiagonal, rotations applied chunk by chunk
+    hipLaunchKernelGGL(tql_state_init_kernel, dim3((batch * 8 + 255) / 256), dim3(256), 0, st, state, batch);
+    if (vectors) {
+        const long count = (long)batch * QRS * ldr;
+        hipLaunchKernelGGL(rot_identity_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, cs, count);
+    }
+    IMCOM_TRY(check_launch("tql init"));
+    const size_t qr_lds = (size_t)2 * ld * 8;
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)tql_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qr_lds));
+    const int max_sweeps = 30 * std::max(nmax, 1);
+    const int max_chunks = max_sweeps / QRS + 2;
+    std::vector<int> sth((size_t)batch * 8);
+    int chunks = 0;
+    bool done = nmax <= 1;
+    while (!done && chunks < max_chunks) {
+        const int group = 16;
+        {
+            ProfScope ps_(ctx, "eigen_qr", group);
+            for (int g = 0; g < group; g++) {
+                hipLaunchKernelGGL(tql_chunk_kernel, dim3(batch), dim3(64), qr_lds, st, dvec, evec, cs, state, tolv, n_dev, ld, ldr,
+                                   vectors ? 1 : 0, max_sweeps);
+                if (vectors)
+                    hipLaunchKernelGGL(rot_apply_kernel<QRS>, dim3((nmax + 63) / 64, batch), dim3(64), 0, st, X, cs, state, n_dev, ld, ldr);
+            }
+            IMCOM_TRY(check_launch("tql chunk"));
+        }
+        chunks += group;
+        IMCOM_HIP_CHECK(hipMemcpyAsync(sth.data(), state, sth.size() * 4, hipMemcpyDeviceToHost, st));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(st));
+        done = true;
+        for (int s = 0; s < batch; s++) {
+            if (n_host[s] > 1 && sth[(size_t)s * 8 + 1] == 0) done = false;
+            if (sth[(size_t)s * 8 + 1] == 2) { set_error("tridiagonal QR did not converge for stamp %d", s); return IMCOM_ERR_NUMERIC; }
+        }
+    }
+    if (!done) { set_error("tridiagonal QR did not converge"); return IMCOM_ERR_NUMERIC; }
+    if (sweeps_out) {
+        int mx = 0;
+        for (int s = 0; s < batch; s++) mx = std::max(mx, sth[(size_t)s * 8 + 4]);
+        *sweeps_out = mx;
+    }
+    return launch_eig_sort_scatter(ctx, X, ld, dvec, n_dev, rank, lam, ldlam, Q, ldq, strideQ, batch);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Eigensolver used by the library.  The tridiagonal QR path is the product; IMCOM_EIGH=jacobi selects the
+// one-sided block Jacobi solver (jacobi.hip), kept as an independent cross-check.
+size_t jacobi_ws_bytes(int batch, int ld);
+int jacobi_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA,
+                       double *lam, long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out);
+
+bool eigh_uses_jacobi()
+{
+    const char *e = getenv("IMCOM_EIGH");
+    return e && strcmp(e, "jacobi") == 0;
+}
+
+size_t eigh_ws_bytes(int batch, int ld, bool vectors)
+{
+    return eigh_uses_jacobi() ? jacobi_ws_bytes(batch, ld) : tridiag_ws_bytes(batch, ld, vectors);
+}
+
+int eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA, double *lam,
+                long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out)
+{
+    if (eigh_uses_jacobi()) {
+        IMCOM_REQUIRE(Q != nullptr, "jacobi eigensolver needs the eigenvector output");
+        return jacobi_eigh_device(ctx, batch, n_host, ld, A, lda, strideA, lam, ldlam, Q, ldq, strideQ, sweeps_out);
+    }
+    return tridiag_eigh_device(ctx, batch, n_host, ld, A, lda, strideA, lam, ldlam, Q, ldq, strideQ, sweeps_out);
+}
+
+}  // namespace imcom
