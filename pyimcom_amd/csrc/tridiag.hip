@@ -126,15 +126,20 @@ __device__ inline HouseScalars house_scalars(const double *pnorm, int npart, dou
     return h;
 }
 
-// Column step, part 2.  v = e_{j+1} + scale * u_{>= j+2}.  Row-tile blocks: p = A[j+1:, j+1:] v (the one pass over
-// the trailing matrix).  Dot blocks: (V^T v)_c and (W^T v)_c for the panel's earlier reflectors.
+// Column step, part 2.  v = e_{j+1} + scale * u_{>= j+2}.  Strip blocks: the one pass over the trailing matrix,
+// reading only the lower triangle (plus diagonal blocks): a strip of 32 rows r accumulates its row sums over the
+// columns c < rb+32 and, from the same loads, the transposed contributions sum_r A[r][c] u_r to the rows c < rb,
+// which go to part[strip][c] and are added up by trd_w_kernel.  p = A[:, j+1] + scale * (row sums + partials).
+// Dot blocks: (V^T v)_c and (W^T v)_c for the panel's earlier reflectors.
 __global__ __launch_bounds__(256) void trd_symv_kernel(const double *__restrict__ At, const double *__restrict__ Vall,
                                                        const double *__restrict__ Wp, const double *__restrict__ ubuf,
                                                        const double *__restrict__ pnorm, double *__restrict__ pvec,
-                                                       double *__restrict__ hd, double *__restrict__ evec,
-                                                       double *__restrict__ tauvec, double *__restrict__ wv,
-                                                       const int *__restrict__ n, int ld, int j, int ps, int npart, int nrowtiles)
+                                                       double *__restrict__ part, double *__restrict__ hd,
+                                                       double *__restrict__ evec, double *__restrict__ tauvec,
+                                                       double *__restrict__ wv, const int *__restrict__ n, int ld, int j, int ps,
+                                                       int npart, int nrowtiles)
 {
+    __shared__ double y2s[2][4][128];
     const int s = blockIdx.y, ns = n[s];
     if (j + 1 >= ns) return;
     const double *u = ubuf + (long)s * ld;
@@ -148,19 +153,37 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const double *__restrict_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long so = (long)s * ld * ld;
     if ((int)blockIdx.x < nrowtiles) {
-        const int rbase = ((j + 1) & ~31) + blockIdx.x * 32 + wave * 8;
-        if (rbase >= ns) return;
-        const double *A = At + so + (long)rbase * ld;
+        const int strip = ((j + 1) >> 5) + blockIdx.x, rb = strip * 32;
+        if (rb >= ns) return;
+        const int r0 = rb + wave * 8;  // this wave's 8 rows; all four waves walk the same column chunks
+        double ur[8];                  // u-tilde of those rows (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < 8; i++) ur[i] = (r0 + i >= j + 2 && r0 + i < ns) ? u[r0 + i] : 0.0;
+        const double *A = At + so + (long)r0 * ld;
+        double *part_s = part + ((long)s * (ld / 32) + strip) * ld;
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int c = (j + 2) & ~127; c < ns; c += 128) {
+        const int cend = rb + 32;
+        int buf = 0;
+        for (int c = (j + 1) & ~127; c < cend; c += 128, buf ^= 1) {
             const int cc = c + 2 * lane;
             double2 uu = *(const double2 *)(u + cc);
-            if (cc < j + 2 || cc >= ns) uu.x = 0.0;
-            if (cc + 1 < j + 2 || cc + 1 >= ns) uu.y = 0.0;
+            if (cc < j + 2 || cc >= cend) uu.x = 0.0;
+            if (cc + 1 < j + 2 || cc + 1 >= cend) uu.y = 0.0;
+            double y2x = 0.0, y2y = 0.0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const double2 a = *(const double2 *)(A + (long)i * ld + cc);
                 acc[i] += a.x * uu.x + a.y * uu.y;
+                y2x += a.x * ur[i];
+                y2y += a.y * ur[i];
+            }
+            if (c < rb) {  // columns strictly left of the diagonal block receive the transposed contributions
+                *(double2 *)&y2s[buf][wave][2 * lane] = make_double2(y2x, y2y);
+                __syncthreads();
+                if (threadIdx.x < 128) {
+                    const int t = threadIdx.x;
+                    if (c + t < rb) part_s[c + t] = (y2s[buf][0][t] + y2s[buf][1][t]) + (y2s[buf][2][t] + y2s[buf][3][t]);
+                }
             }
         }
 #pragma unroll
@@ -171,7 +194,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const double *__restrict_
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const int r = rbase + i;
+                const int r = r0 + i;
                 if (r >= j + 1 && r < ns) pvec[(long)s * ld + r] = A[(long)i * ld + (j + 1)] + h.scale * acc[i];
             }
         }
@@ -187,12 +210,13 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const double *__restrict_
     }
 }
 
-// Column step, part 3.  w' = tau (p - V (W^T v) - W (V^T v)) on rows >= j+1, v stored as reflector j, partial w'.v
+// Column step, part 3.  p completed with the strips' partials; w' = tau (p - V (W^T v) - W (V^T v)) on rows >= j+1, v stored as reflector j, partial w'.v
 __global__ __launch_bounds__(256) void trd_w_kernel(double *__restrict__ Vall, const double *__restrict__ Wp,
                                                     const double *__restrict__ ubuf, const double *__restrict__ pvec,
                                                     const double *__restrict__ hd, const double *__restrict__ wv,
-                                                    double *__restrict__ wprime, double *__restrict__ pdot,
-                                                    const int *__restrict__ n, int ld, int j, int ps, int npart)
+                                                    const double *__restrict__ part, double *__restrict__ wprime,
+                                                    double *__restrict__ pdot, const int *__restrict__ n, int ld, int j, int ps,
+                                                    int npart)
 {
     __shared__ double swv[TP], svv[TP], red[4];
     const int s = blockIdx.y, ns = n[s];
@@ -211,7 +235,9 @@ __global__ __launch_bounds__(256) void trd_w_kernel(double *__restrict__ Vall, c
     double prod = 0.0;
     if (r >= j + 1 && r < ns) {
         const double v = (r == j + 1) ? 1.0 : ubuf[(long)s * ld + r] * scale;
-        double acc = pvec[(long)s * ld + r];
+        double tr = 0.0;  // transposed half of the symmetric product, one partial per strip below this row's strip
+        for (int strip = (r >> 5) + 1; strip <= (ns - 1) >> 5; strip++) tr += part[((long)s * (ld / 32) + strip) * ld + r];
+        double acc = pvec[(long)s * ld + r] + scale * tr;
         for (int c = 0; c < k; c++) acc -= V[(long)c * ld + r] * swv[c] + W[(long)c * ld + r] * svv[c];
         const double w = tau * acc;
         wprime[(long)s * ld + r] = w;
@@ -511,6 +537,7 @@ size_t tridiag_ws_bytes(int batch, int ld, bool vectors)
     add((size_t)batch * ld * ld * 8);                      // Vall
     if (vectors) add((size_t)batch * ld * ld * 8 + (size_t)batch * ld * 8);  // X + one scratch row per stamp
     add((size_t)batch * TP * ld * 8);                      // Wp
+    add((size_t)batch * (ld / 32) * ld * 8);               // per-strip partials of the symmetric product
     if (vectors) { add((size_t)batch * ld * TP * 8); add((size_t)batch * ld * TP * 8); }  // W1, W2
     if (vectors) { add((size_t)batch * TP * TP * 8); add((size_t)batch * TP * TP * 8); }  // S, T
     for (int q = 0; q < 6; q++) add((size_t)batch * ld * 8);  // u, p, w', d, e, tau
@@ -536,6 +563,7 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
     double *At = (double *)ws_take(ctx, mat), *Vall = (double *)ws_take(ctx, mat);
     double *X = vectors ? (double *)ws_take(ctx, mat + (size_t)batch * ld * 8) : nullptr;
     double *Wp = (double *)ws_take(ctx, (size_t)batch * TP * ld * 8);
+    double *part = (double *)ws_take(ctx, (size_t)batch * (ld / 32) * ld * 8);
     double *W1 = nullptr, *W2 = nullptr, *Sm = nullptr, *Tm = nullptr;
     if (vectors) {
         W1 = (double *)ws_take(ctx, (size_t)batch * ld * TP * 8);
@@ -553,7 +581,7 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
     double *tolv = (double *)ws_take(ctx, (size_t)batch * 8);
     int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
     int *rank = (int *)ws_take(ctx, (size_t)batch * ld * 4);
-    if (!At || !Vall || (vectors && (!X || !W1 || !W2 || !Sm || !Tm || !cs)) || !Wp || !ubuf || !pvec || !wprime || !dvec || !evec ||
+    if (!At || !Vall || (vectors && (!X || !W1 || !W2 || !Sm || !Tm || !cs)) || !Wp || !part || !ubuf || !pvec || !wprime || !dvec || !evec ||
         !tauvec || !wv || !hd || !pnorm || !pdot || !state || !tolv || !n_dev || !rank) {
         set_error("internal: tridiag workspace");
         return IMCOM_ERR_NOMEM;
@@ -579,10 +607,10 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
                 hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
                                    n_dev, ld, j, ps, npart, 1);
                 if (j + 1 >= nmax) break;
-                const int nrowtiles = (nmax - ((j + 1) & ~31) + 31) / 32, ndot = (2 * (j - ps) + 3) / 4;
-                hipLaunchKernelGGL(trd_symv_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, Vall, Wp, ubuf, pnorm, pvec, hd,
+                const int nrowtiles = ((nmax - 1) >> 5) - ((j + 1) >> 5) + 1, ndot = (2 * (j - ps) + 3) / 4;
+                hipLaunchKernelGGL(trd_symv_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, Vall, Wp, ubuf, pnorm, pvec, part, hd,
                                    evec, tauvec, wv, n_dev, ld, j, ps, npart, nrowtiles);
-                hipLaunchKernelGGL(trd_w_kernel, dim3(npart, batch), dim3(256), 0, st, Vall, Wp, ubuf, pvec, hd, wv, wprime, pdot, n_dev, ld,
+                hipLaunchKernelGGL(trd_w_kernel, dim3(npart, batch), dim3(256), 0, st, Vall, Wp, ubuf, pvec, hd, wv, part, wprime, pdot, n_dev, ld,
                                    j, ps, npart);
             }
             IMCOM_TRY(check_launch("trd column step"));
