@@ -126,6 +126,32 @@ int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, c
                       const double *mBhalf, const double *C, const double *kappaC, int nv,
                       double ucmin, double smax, int nbis, float *T, float *UC, float *Sigma,
                       float *kappa, int *info, int memspace);
+
+/* ---- secondary LA kernels: lakernel.IterKernel 533-744, lakernel.EmpirKernel 747-805 ----------------------
+ * Geometry (all in output-pixel units, as the reference computes them at lakernel.py:617-622 / 757-761):
+ *   out_yx  [batch][2][m]  outst.yx_val: y then x of every output pixel (row-major over the n2f x n2f stamp)
+ *   in_y,in_x [batch][ldn] outst.iny_val / inx_val
+ *   rho_acc = (cfg.instamp_pad / arcsec) / (cfg.dtheta * 3600): acceptance radius
+ * n, C, kappaC are HOST arrays as for imcom_solve_chol; the other pointers follow `memspace`.
+ *
+ * imcom_solve_iter: per output pixel, conjugate gradients (lakernel.py:397-442: x0 = 0, stop at |r| < rtol |b| or
+ * after maxiter steps) on the sub-system of the input pixels with hypot(dy, dx) < rho_acc; T is float32 and zero
+ * outside the disc.  nv == 1: lines 588-654; nv > 1: 656-744 (node solutions combined by build_reduced_T_wrap).
+ * exact_UC selects E = T A T^T (reference default for nv > 1) against the approximation D - kappa N (default for
+ * nv == 1).  At most 4096 input pixels per acceptance disc (IMCOM_ERR_ARG beyond). */
+int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A,
+                     const double *mBhalf, const double *C, const double *kappaC, int nv, double ucmin,
+                     double smax, const double *out_yx, const double *in_y, const double *in_x,
+                     double rho_acc, double rtol, int maxiter, int exact_UC, float *T, float *UC,
+                     float *Sigma, float *kappa, int memspace);
+/* imcom_solve_empir: T_ai = max(rho_acc - dist_ai, 0) / sum_i max(rho_acc - dist_ai, 0) (a pixel with no input
+ * pixel in range gets NaN, as in the reference); kappa = kappaC0 * C, Sigma = sum T^2, UC = 1 + (T A T^T - 2 D)/C.
+ * no_qlt_ctrl != 0 (cfg.no_qlt_ctrl, coadd.py:856-858): only T is produced, A / mBhalf / C may be NULL and the
+ * maps are zero (lakernel.py:774-777). */
+int imcom_solve_empir(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A,
+                      const double *mBhalf, const double *C, double kappaC0, const double *out_yx,
+                      const double *in_y, const double *in_x, double rho_acc, int no_qlt_ctrl, float *T,
+                      float *UC, float *Sigma, float *kappa, int memspace);
 /* Batched symmetric eigendecomposition used by the eigen path and by the Cholesky repair
  * (replaces numpy.linalg.eigh at lakernel.py:162,201,266): lam ascending [batch][ldn],
  * Q[batch][ldn][ldn] with eigenvectors in columns.  A is not modified. */

@@ -197,6 +197,117 @@ def eigen_kernel(A, mBhalf, C_, kappaC, ucmin, smax, nbis=13):
     return T, UC, Sigma, kappa, 0
 
 
+def conjugate_gradient(A, b, rtol=1.5e-3, maxiter=30):
+    """lakernel.conjugate_gradient (lakernel.py:397-442): plain CG from x = 0, stop when |r| < rtol |b|."""
+    atol = np.linalg.norm(b) * rtol
+    x = np.zeros_like(b)
+    r = b.copy()
+    rho_prev = 0.0
+    p = r.copy()
+    for iteration in range(maxiter):
+        rho_cur = np.dot(r, r)
+        if rho_cur**0.5 < atol:
+            break
+        if iteration > 0:
+            p *= rho_cur / rho_prev
+            p += r
+        q = A @ p
+        alpha = rho_cur / np.dot(p, q)
+        x += alpha * p
+        r -= alpha * q
+        rho_prev = rho_cur
+    return x
+
+
+def _relevant(out_y, out_x, in_y, in_x, rho_acc):
+    """Acceptance mask of lakernel.py:617-622: input pixel within rho_acc of the output pixel."""
+    return np.hypot(out_y[:, None] - in_y[None, :], out_x[:, None] - in_x[None, :]) < rho_acc
+
+
+def _iterative_wrapper(AA, mBhalf, relevant, rtol, maxiter):
+    """lakernel.IterKernel._iterative_wrapper (545-586): one restricted CG solve per output pixel, float32 T."""
+    m, n = mBhalf.shape
+    Ti = np.zeros((m, n), dtype=np.float32)
+    for a in range(m):
+        sel = np.nonzero(relevant[a])[0]
+        Ti[a, sel] = conjugate_gradient(AA[np.ix_(sel, sel)], mBhalf[a, sel], rtol, maxiter)
+    return Ti
+
+
+def iter_kernel(A, mBhalf, C_, kappaC, ucmin, smax, out_y, out_x, in_y, in_x, rho_acc, rtol=1.5e-3, maxiter=30,
+                exact_UC=None):
+    """lakernel.IterKernel for ONE target PSF (single kappa 588-654, multi kappa 656-744).  exact_UC None takes the
+    reference defaults (False for one node, True for several)."""
+    kappaC = np.atleast_1d(np.asarray(kappaC, dtype=np.float64))
+    nv = kappaC.size
+    m, n = mBhalf.shape
+    T = np.zeros((m, n), dtype=np.float32)
+    UC, Sigma, kappa = (np.zeros((m,), dtype=np.float32) for _ in range(3))
+    relevant = _relevant(out_y, out_x, in_y, in_x, rho_acc)
+    di = np.diag_indices(n)
+    if nv == 1:
+        exact = False if exact_UC is None else exact_UC
+        AA = np.copy(A)
+        my_kappa = kappaC[0] * C_
+        if my_kappa:
+            AA[di] += my_kappa
+        Ti = _iterative_wrapper(AA, mBhalf, relevant, rtol, maxiter)
+        D = np.einsum("ai,ai->a", mBhalf, Ti)
+        N = np.einsum("ai,ai->a", Ti, Ti)
+        kappa[:] = my_kappa
+        Sigma[:] = N
+        if exact:
+            E = np.einsum("ij,ai,aj->a", A, Ti, Ti)
+            UC[:] = 1.0 + (E - 2 * D) / C_
+        else:
+            UC[:] = 1.0 - (my_kappa * N + D) / C_
+        T[:, :] = Ti
+        return T, UC, Sigma, kappa, 0
+    exact = True if exact_UC is None else exact_UC
+    Tpi = np.zeros((nv, m, n))
+    AA = np.copy(A)
+    kappa_arr = kappaC * C_
+    for j in range(nv):
+        AA[di] += kappa_arr[j] - (kappa_arr[j - 1] if j > 0 else 0)
+        Tpi[j] = _iterative_wrapper(AA, mBhalf, relevant, rtol, maxiter)
+    Dp = np.einsum("ai,pai->ap", mBhalf, Tpi)
+    Npq = np.einsum("pai,qai->apq", Tpi, Tpi)
+    Epq = np.zeros((m, nv, nv))
+    for p in range(nv):
+        for q in range(p + 1):
+            if exact:
+                Epq[:, q, p] = Epq[:, p, q] = np.einsum("ij,ai,aj->a", A, Tpi[p], Tpi[q])
+            else:
+                Epq[:, q, p] = Epq[:, p, q] = Dp[:, q] - kappa_arr[p] * Npq[:, p, q]
+    ok, oS, oU, ow = np.zeros(m), np.zeros(m), np.zeros(m), np.zeros(m * nv)
+    build_reduced_T_wrap(Npq.flatten(), Dp.flatten() / C_, Epq.flatten() / C_, kappaC, ucmin, smax, ok, oS, oU, ow)
+    kappa[:] = ok * C_
+    Sigma[:] = oS
+    UC[:] = oU
+    T[:, :] = np.einsum("pai,ap->ai", Tpi, ow.reshape((m, nv)))
+    return T, UC, Sigma, kappa, 0
+
+
+def empir_kernel(A, mBhalf, C_, kappaC, out_y, out_x, in_y, in_x, rho_acc, no_qlt_ctrl=False):
+    """lakernel.EmpirKernel for ONE target PSF (747-805): T_ai = max(rho - dist, 0) / row sum, no linear solve."""
+    kappaC = np.atleast_1d(np.asarray(kappaC, dtype=np.float64))
+    m, n = mBhalf.shape
+    Ti = np.maximum(rho_acc - np.hypot(out_y[:, None] - in_y[None, :], out_x[:, None] - in_x[None, :]), 0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        Ti /= np.sum(Ti, axis=-1)[:, None]
+    T = Ti.astype(np.float32)
+    UC, Sigma, kappa = (np.zeros((m,), dtype=np.float32) for _ in range(3))
+    if no_qlt_ctrl:
+        return T, UC, Sigma, kappa, 0
+    D = np.einsum("ai,ai->a", mBhalf, Ti)
+    N = np.einsum("ai,ai->a", Ti, Ti)
+    E = np.einsum("ij,ai,aj->a", A, Ti, Ti)
+    kappa[:] = kappaC[0] * C_
+    Sigma[:] = N
+    UC[:] = 1.0 + (E - 2 * D) / C_
+    return T, UC, Sigma, kappa, 0
+
+
 def la_kernel(kind, A, mhalfb, outovlc, n2f, kappaC, ucmin, smax):
     """_LAKernel.__call__ (lakernel.py:84-138) over n_out target PSFs, incl. the n == 0 case (110-119)."""
     n_out, m, n = mhalfb.shape

@@ -97,10 +97,72 @@ class HipEigenKernel(_HipLAKernel):
                                     _ptr(UC), _ptr(Sigma), _ptr(kappa), _ptr(info), MEM_HOST))
 
 
-LAKERNEL = {"Cholesky": HipCholKernel, "Eigen": HipEigenKernel}
+class _HipGeomKernel(_HipLAKernel):
+    """Kernels that use the pixel geometry (lakernel.py:617-622, 757-761): outst.yx_val, iny_val, inx_val and
+    rho_acc = (cfg.instamp_pad / arcsec) / (cfg.dtheta * 3600)."""
+
+    ARCSEC = np.pi / 180.0 / 3600.0  # pyimcom.config.Settings.arcsec (config.py:85-98)
+
+    def _geometry(self):
+        cfg = self.outst.blk.cfg
+        yx = np.ascontiguousarray(np.asarray(self.outst.yx_val, dtype=np.float64).reshape(2, self.m))
+        iny = np.ascontiguousarray(self.outst.iny_val, dtype=np.float64)
+        inx = np.ascontiguousarray(self.outst.inx_val, dtype=np.float64)
+        rho_acc = (cfg.instamp_pad / self.ARCSEC) / (cfg.dtheta * 3600.0)
+        return yx, iny, inx, float(rho_acc)
 
 
-def register(outstamp_cls, names=("Cholesky", "Eigen")):
+class HipIterKernel(_HipGeomKernel):
+    """Iterative path: lakernel.IterKernel (lakernel.py:533-744), restricted CG per output pixel.
+
+    ``exact_UC`` None keeps the reference defaults (False for one kappa node, True for several)."""
+
+    exact_UC = None
+
+    def _solve(self, A, B, C_, T, UC, Sigma, kappa, info):
+        cfg = self.outst.blk.cfg
+        yx, iny, inx, rho = self._geometry()
+        exact = (self.nv > 1) if self.exact_UC is None else bool(self.exact_UC)
+        n_arr = np.array([self.n], dtype=np.int32)
+        check(lib.imcom_solve_iter(self.ctx.handle, 1, _ptr(n_arr), self.n, self.m, _ptr(A), _ptr(B), _ptr(C_),
+                                   _ptr(self.kappaC_arr), self.nv, self.ucmin, self.smax, _ptr(yx), _ptr(iny), _ptr(inx),
+                                   rho, float(cfg.iter_rtol), int(cfg.iter_max), int(exact), _ptr(T), _ptr(UC),
+                                   _ptr(Sigma), _ptr(kappa), MEM_HOST))
+
+
+class HipEmpirKernel(_HipGeomKernel):
+    """Empirical path: lakernel.EmpirKernel (lakernel.py:747-805); honours ``outst.no_qlt_ctrl``."""
+
+    def __call__(self):
+        if not getattr(self.outst, "no_qlt_ctrl", False) or self.n == 0:
+            return super().__call__()
+        # no quality control (coadd.py:1019-1024): the system matrices were never built; only T is produced
+        shape = (self.n_out, self.n2f, self.n2f)
+        yx, iny, inx, rho = self._geometry()
+        T = np.zeros((self.n_out, self.m, self.n), dtype=np.float32)
+        maps = np.zeros((3, self.m), dtype=np.float32)
+        n_arr = np.array([self.n], dtype=np.int32)
+        check(lib.imcom_solve_empir(self.ctx.handle, 1, _ptr(n_arr), self.n, self.m, None, None, None, 0.0, _ptr(yx),
+                                    _ptr(iny), _ptr(inx), rho, 1, _ptr(T[0]), _ptr(maps[0]), _ptr(maps[1]), _ptr(maps[2]),
+                                    MEM_HOST))
+        T[1:] = T[0]  # the same weights for every target PSF (lakernel.py:775)
+        self.outst.T = T
+        self.outst.UC = np.zeros(shape, dtype=np.float32)
+        self.outst.Sigma = np.zeros(shape, dtype=np.float32)
+        self.outst.kappa = np.zeros(shape, dtype=np.float32)
+
+    def _solve(self, A, B, C_, T, UC, Sigma, kappa, info):
+        yx, iny, inx, rho = self._geometry()
+        n_arr = np.array([self.n], dtype=np.int32)
+        check(lib.imcom_solve_empir(self.ctx.handle, 1, _ptr(n_arr), self.n, self.m, _ptr(A), _ptr(B), _ptr(C_),
+                                    float(self.kappaC_arr[0]), _ptr(yx), _ptr(iny), _ptr(inx), rho, 0, _ptr(T), _ptr(UC),
+                                    _ptr(Sigma), _ptr(kappa), MEM_HOST))
+
+
+LAKERNEL = {"Cholesky": HipCholKernel, "Eigen": HipEigenKernel, "Iterative": HipIterKernel, "Empirical": HipEmpirKernel}
+
+
+def register(outstamp_cls, names=("Cholesky", "Eigen", "Iterative", "Empirical")):
     """Swap the HIP kernels into ``OutStamp.LAKERNEL`` (coadd.py:839-844) under the given keys."""
     for name in names:
         outstamp_cls.LAKERNEL[name] = LAKERNEL[name]

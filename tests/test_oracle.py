@@ -175,3 +175,26 @@ def test_trapezoid_and_coaddition():
     assert np.allclose(Tin.ravel(), Tt.sum(axis=1), rtol=1e-5, atol=1e-5)
     assert np.allclose(Ts[0], [Tt[:, expo == e].sum() / n2**2 for e in range(E)], rtol=1e-5, atol=1e-5)
     assert (Neff[0, 2:4, 2:4] >= 1 - 1e-9).all() and (Neff[0, 2:4, 2:4] <= E + 1e-9).all()
+
+
+def test_iter_and_empir_kernels_golden(golden):
+    """lakernel.IterKernel 533-744 / EmpirKernel 747-805: the numpy restatement reproduces the reference's outputs
+    bit for bit (same BLAS underneath), including the NaN pixels of the approximate multi-kappa U/C."""
+    g = golden("lakernel_iter")
+    A, mB, C = g["A"], g["mBhalf"], g["C"]
+    oy, ox = g["yx"][0].ravel(), g["yx"][1].ravel()
+    geo = (oy, ox, g["iny"], g["inx"], float(g["rho_acc"]))
+    for name, kC, exact in (("iter1", [6e-4], None), ("iterm", [1e-5, 1e-4, 1e-3], None), ("iter1_exact", [6e-4], True),
+                            ("iterm_approx", [1e-5, 1e-4, 1e-3], False)):
+        for j in range(2):
+            T, UC, S, k, _ = orc.iter_kernel(A, mB[j], C[j], kC, 1e-6, 0.5, *geo, rtol=float(g["rtol"]), maxiter=int(g["itmax"]),
+                                             exact_UC=exact)
+            assert np.array_equal(T, g[f"{name}_T"][j], equal_nan=True), (name, j)
+            for got, key in ((UC, "UC"), (S, "Sigma"), (k, "kappa")):
+                assert np.array_equal(got, g[f"{name}_{key}"][j].ravel(), equal_nan=True), (name, j, key)
+    for name, nq in (("empir", False), ("empir_noqc", True)):
+        for j in range(2):
+            T, UC, S, k, _ = orc.empir_kernel(A, mB[j], C[j], [6e-4], *geo, no_qlt_ctrl=nq)
+            assert np.array_equal(T, g[f"{name}_T"][j])
+            for got, key in ((UC, "UC"), (S, "Sigma"), (k, "kappa")):
+                assert np.array_equal(got, g[f"{name}_{key}"][j].ravel()), (name, j, key)
