@@ -174,6 +174,23 @@ typedef struct {
     double flat_penalty; /* PSFOvl.flat_penalty */
 } imcom_table_geom;
 
+/* ---- input-pixel selection: OutStamp._process_input_stamps coadd.py:886-977 + InStamp.make_selection 716-749 ----
+ * The block's InStamps lie back to back in a pool:
+ *   pool_x, pool_y [npool] f64 (InStamp.x_val / y_val), pool_data [n_inframe][npool] f32 (InStamp.data),
+ *   pool_expo [npool] i32 (exposure index of each pixel, from InStamp.pix_cumsum),
+ *   inst_off [n_inst+1]: InStamp i owns pool[inst_off[i] : inst_off[i+1]].
+ * Per output stamp s and neighbour idx = 0..8 (row-major over dj, di = -1..1, coadd.py:878):
+ *   inst_id [batch][9] InStamp index or -1; pivot_x / pivot_y [batch][9] (NaN = None, lines 918-919);
+ *   radius = rpix_search (line 912; NaN = select everything).
+ * A pixel is kept when (x - px)^2 + (y - py)^2 < radius^2 (terms of missing pivot coordinates dropped), in pool
+ * order.  Outputs x, y [batch][ldn], indata [batch][n_inframe][ldn], expo [batch][ldn] (zero padded) and
+ * cumsum [batch][10] = inpix_cumsum; n[s] = cumsum[s][9].  IMCOM_ERR_ARG if a stamp selects more than ldn. */
+int imcom_select_pixels(imcom_ctx *ctx, int batch, const double *pool_x, const double *pool_y,
+                        const float *pool_data, long npool, int n_inframe, const int *pool_expo,
+                        const long *inst_off, int n_inst, const int *inst_id, const double *pivot_x,
+                        const double *pivot_y, double radius, int ldn, double *x, double *y, float *indata,
+                        int *expo, int *cumsum, int memspace);
+
 /* A[s][i][j] for i,j < n[s] (exactly symmetric: the element with i before j is interpolated and
  * mirrored, as the reference's sub-block assembly does, coadd.py:1038-1068), with the
  * padding rows/cols n[s] <= i < ldn set to the identity so the factorisation kernels can run on

@@ -583,6 +583,29 @@ def select_pixels(x, y, pivot, radius):
     return sel if sel.shape[0] < x.shape[0] else None
 
 
+def process_input_stamps(instamps, pivots, radius):
+    """OutStamp._process_input_stamps (coadd.py:886-977): concatenate the selections of the nine neighbours.
+
+    instamps: nine entries (x_val, y_val, data [n_inframe, k], pix_cumsum) or None; pivots: nine (x_pivot, y_pivot)
+    with None entries.  Returns inx_val, iny_val, indata, exposure index per pixel, inpix_cumsum [10]."""
+    xs, ys, ds, es, counts = [], [], [], [], []
+    for inst, pivot in zip(instamps, pivots):
+        if inst is None:
+            counts.append(0)
+            continue
+        x, y, data, cum = inst
+        expo = np.repeat(np.arange(len(cum) - 1), np.diff(cum))
+        sel = select_pixels(x, y, tuple(pivot), radius)
+        if sel is None:
+            sel = np.arange(x.shape[0])
+        xs.append(x[sel]); ys.append(y[sel]); ds.append(data[:, sel]); es.append(expo[sel])
+        counts.append(sel.shape[0])
+    n_inframe = next(i[2].shape[0] for i in instamps if i is not None)
+    cat = lambda parts, empty: np.hstack(parts) if parts else empty  # noqa: E731
+    return (cat(xs, np.zeros(0)), cat(ys, np.zeros(0)), cat(ds, np.zeros((n_inframe, 0), np.float32)),
+            cat(es, np.zeros(0, int)), np.cumsum([0] + counts))
+
+
 # ------------------------------------------------------------------------------------------------ stamp level
 def stamp_system(g, x, y, psf, tables_pad, pair_tab, pair_pen, io_tab, out_x0, out_y0, n2f):
     """A and Bt of ONE stamp from the device-seam description (include/imcom_hip.h: imcom_build_A/_B):

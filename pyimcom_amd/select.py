@@ -1,0 +1,65 @@
+"""Input-pixel selection on the device (reference ``OutStamp._process_input_stamps`` coadd.py:886-977 with
+``InStamp.make_selection`` 716-749): the block's InStamps are uploaded once as a pool, every output stamp then
+gathers its nine neighbours' pixels inside the acceptance region straight into the StampBatch layouts."""
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import MEM_DEVICE, check, default_context, lib
+
+
+class InStampPool:
+    """The InStamps of a block back to back on the GPU.
+
+    ``instamps``: sequence of (x_val f64 [k], y_val f64 [k], data f32 [n_inframe, k], pix_cumsum int [n_expo+1]) --
+    the attributes of the reference's ``InStamp`` (coadd.py:682-714)."""
+
+    def __init__(self, instamps, n_inframe, device="cuda:0"):
+        import torch
+
+        self.n_inst = len(instamps)
+        self.n_inframe = int(n_inframe)
+        counts = [len(t[0]) for t in instamps]
+        self.inst_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        npool = int(self.inst_off[-1])
+        x, y = np.zeros(npool), np.zeros(npool)
+        data = np.zeros((self.n_inframe, npool), np.float32)
+        expo = np.zeros(npool, np.int32)
+        for i, (xv, yv, dv, cum) in enumerate(instamps):
+            o0, o1 = self.inst_off[i], self.inst_off[i + 1]
+            x[o0:o1], y[o0:o1], data[:, o0:o1] = xv, yv, dv
+            expo[o0:o1] = np.repeat(np.arange(len(cum) - 1), np.diff(cum))
+        dev = torch.device(device)
+        self.device = dev
+        self.npool = npool
+        self.x, self.y = torch.as_tensor(x, device=dev), torch.as_tensor(y, device=dev)
+        self.data, self.expo = torch.as_tensor(data, device=dev), torch.as_tensor(expo, device=dev)
+        self.inst_off_dev = torch.as_tensor(self.inst_off, device=dev)
+
+
+def select_pixels(pool, inst_id, pivot_x, pivot_y, radius, ldn, ctx=None):
+    """Selections of a batch of output stamps.  ``inst_id`` int [B,9] (-1 = absent), ``pivot_x/pivot_y`` float [B,9]
+    (NaN = None), ``radius`` = rpix_search.  Returns device tensors x, y [B,ldn], indata [B,n_inframe,ldn],
+    expo [B,ldn] and the host array cumsum [B,10] (inpix_cumsum of each stamp)."""
+    import torch
+
+    ctx = ctx if ctx is not None else default_context(pool.device.index or 0)
+    inst_id = np.ascontiguousarray(inst_id, dtype=np.int32)
+    B = inst_id.shape[0]
+    assert inst_id.shape == (B, 9)
+    dev = pool.device
+    iid = torch.as_tensor(inst_id, device=dev)
+    pvx = torch.as_tensor(np.ascontiguousarray(pivot_x, dtype=np.float64), device=dev)
+    pvy = torch.as_tensor(np.ascontiguousarray(pivot_y, dtype=np.float64), device=dev)
+    x = torch.empty((B, ldn), dtype=torch.float64, device=dev)
+    y = torch.empty_like(x)
+    indata = torch.empty((B, pool.n_inframe, ldn), dtype=torch.float32, device=dev)
+    expo = torch.empty((B, ldn), dtype=torch.int32, device=dev)
+    cumsum = torch.empty((B, 10), dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    check(lib.imcom_select_pixels(ctx.handle, B, p(pool.x), p(pool.y), p(pool.data), pool.npool, pool.n_inframe, p(pool.expo),
+                                  p(pool.inst_off_dev), pool.n_inst, p(iid), p(pvx), p(pvy), float(radius), int(ldn), p(x), p(y),
+                                  p(indata), p(expo), p(cumsum), MEM_DEVICE))
+    return x, y, indata, expo, cumsum.cpu().numpy()

@@ -1,0 +1,84 @@
+"""GPU parity of the input-pixel selection (reference coadd.py:886-977, 716-749): bit-exact against the oracle on a
+synthetic block of InStamps, including block-edge stamps (missing neighbours), empty InStamps and pixels that
+sit exactly on the acceptance circle."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _block(rng, nside, n2, n_expo, n_inframe):
+    """InStamps of an nside x nside block: per exposure a jittered lattice binned into stamp cells (coadd.py:207)."""
+    inst = [[None] * nside for _ in range(nside)]
+    cells = {}
+    for e in range(n_expo):
+        p = 2.2 + 0.1 * e
+        g = np.arange(-2, nside * n2 / p + 2)
+        xx, yy = np.meshgrid(g * p + rng.uniform(0, p), g * p + rng.uniform(0, p))
+        th = np.deg2rad(7.0 * e)
+        x = (np.cos(th) * xx - np.sin(th) * yy).ravel()
+        y = (np.sin(th) * xx + np.cos(th) * yy).ravel()
+        keep = rng.uniform(size=x.size) > 0.02
+        x, y = x[keep], y[keep]
+        ci, cj = np.floor((x + 0.5) / n2).astype(int), np.floor((y + 0.5) / n2).astype(int)
+        for j in range(nside):
+            for i in range(nside):
+                m = (ci == i) & (cj == j)
+                cells.setdefault((j, i), []).append((x[m], y[m], rng.standard_normal((n_inframe, m.sum())).astype(np.float32)))
+    for (j, i), parts in cells.items():
+        if (j, i) == (1, 2):  # an InStamp without pixels
+            parts = [(np.zeros(0), np.zeros(0), np.zeros((n_inframe, 0), np.float32))] * n_expo
+        cum = np.concatenate([[0], np.cumsum([len(p_[0]) for p_ in parts])])
+        inst[j][i] = (np.hstack([p_[0] for p_ in parts]), np.hstack([p_[1] for p_ in parts]), np.hstack([p_[2] for p_ in parts]), cum)
+    return inst
+
+
+def test_select_pixels_bit_exact():
+    from oracle import oracle as orc
+    from pyimcom_amd.select import InStampPool, select_pixels
+
+    rng = np.random.default_rng(3)
+    nside, n2, n_expo, n_inframe, radius = 4, 8, 3, 2, 3.7
+    inst = _block(rng, nside, n2, n_expo, n_inframe)
+    # one pixel ON the circle (to rounding) around the lower-left pivot of stamp (1,1): the '<' decision must be
+    # the oracle's, i.e. the squares and the sum must round as numpy's do
+    x0, y0, d0, c0 = inst[0][0]
+    x0[0], y0[0] = (n2 - 0.5) - 3.0 * radius / 5.0, (n2 - 0.5) - 4.0 * radius / 5.0
+    flat = [inst[j][i] for j in range(nside) for i in range(nside)]
+    pool = InStampPool(flat, n_inframe)
+    stamps = [(j, i) for j in range(nside) for i in range(nside)]
+    inst_id = np.full((len(stamps), 9), -1, np.int32)
+    pvx, pvy = np.full((len(stamps), 9), np.nan), np.full((len(stamps), 9), np.nan)
+    refs = []
+    for s, (j, i) in enumerate(stamps):
+        left, right, bottom, top = i * n2, (i + 1) * n2 - 1, j * n2, (j + 1) * n2 - 1
+        nb, piv = [], []
+        for idx, (dj, di) in enumerate((dj, di) for dj in (-1, 0, 1) for di in (-1, 0, 1)):
+            jj, ii = j + dj, i + di
+            xp = [left - 0.5, None, right + 0.5][di + 1]
+            yp = [bottom - 0.5, None, top + 0.5][dj + 1]
+            piv.append((xp, yp))
+            if 0 <= jj < nside and 0 <= ii < nside:
+                inst_id[s, idx] = jj * nside + ii
+                nb.append(inst[jj][ii])
+            else:
+                nb.append(None)
+            if xp is not None:
+                pvx[s, idx] = xp
+            if yp is not None:
+                pvy[s, idx] = yp
+        refs.append(orc.process_input_stamps(nb, piv, radius))
+    ldn = max(r[0].size for r in refs) + 5
+    x, y, indata, expo, cumsum = select_pixels(pool, inst_id, pvx, pvy, radius, ldn)
+    x, y, indata, expo = x.cpu().numpy(), y.cpu().numpy(), indata.cpu().numpy(), expo.cpu().numpy()
+    for s, (rx, ry, rd, re, rc) in enumerate(refs):
+        n = rx.size
+        assert np.array_equal(cumsum[s], rc), (s, cumsum[s], rc)
+        assert np.array_equal(x[s, :n], rx) and np.array_equal(y[s, :n], ry)
+        assert np.array_equal(indata[s, :, :n], rd) and np.array_equal(expo[s, :n], re)
+        assert not x[s, n:].any() and not indata[s, :, n:].any()
+    assert refs[5][0].size > 0  # stamp (1,1), whose corner circle passes (to rounding) through the doctored pixel
+
+    with pytest.raises(Exception, match="more than ldn"):
+        select_pixels(pool, inst_id, pvx, pvy, radius, 8)
