@@ -254,6 +254,19 @@ int imcom_block_accumulate(imcom_ctx *ctx, int batch, const int *jst_host, const
 int imcom_trapezoid_recover_f32(imcom_ctx *ctx, float *maps, long nmaps, int ny, int nx, int fade, int pad_b,
                                 int pad_t, int pad_l, int pad_r);
 
+/* ---- PSF images -> sample grid, target PSFs --------------------------------------------------------------
+ * imcom_sample_psf: PSFGrp._sample_psf psfutil.py:709-795 followed by the circular cut-out / normalisation of
+ * PSFGrp.__init__ 650-656.  psf [n_psf][ny][nx]; yxco [n_psf][2][nsamp*nsamp] = y then x offsets of the sampling
+ * positions from the image centre in oversampled native pixels (the host computes them through the WCS,
+ * psfutil.py:751-771), or NULL for the unrotated grid PSFGrp.yxo (the target-PSF path, evaluated with gridD5512C
+ * as the reference does at 786-793).  psf_arr [n_psf][nsamp][nsamp] out; samples off the image stay zero. */
+int imcom_sample_psf(imcom_ctx *ctx, int n_psf, const double *psf, int ny, int nx, const double *yxco,
+                     int nsamp, int psf_circ, int psf_norm, double *psf_arr, int memspace);
+/* OutPSF.psf_gaussian psfutil.py:117-146 and OutPSF.psf_simple_airy 148-223 (n x n, row-major) */
+int imcom_psf_gaussian(imcom_ctx *ctx, int n, double sigmax, double sigmay, double *out, int memspace);
+int imcom_psf_simple_airy(imcom_ctx *ctx, int n, double ldp, double obsc, double tophat_conv, double sigma,
+                          double *out, int memspace);
+
 /* PSFGrp.accel_pad_and_rfft2 + PSFOvl._build_psfovl (psfutil.py:943-986, 1244-1294): correlation
  * tables out[p][q] = irfft2(rft(psf1[p]) * conj(rft(psf2[q]))), rolled by nc and cropped to
  * nsamp x nsamp.  psf1[n1][nsamp][nsamp], psf2[n2][nsamp][nsamp]; pairs[npairs][2] HOST lists the

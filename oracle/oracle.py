@@ -606,6 +606,48 @@ def process_input_stamps(instamps, pivots, radius):
             cat(es, np.zeros(0, int)), np.cumsum([0] + counts))
 
 
+QFILTER_NATIVE = [1.155, 1.456, 1.250, 1.021, 0.834, 0.689, 0.491, 1.009, 0.000, 1.159, 1.685]  # config.py:85-98
+OBSC = 0.31
+
+
+def sample_psf(psf, nsamp, yxco=None):
+    """PSFGrp._sample_psf (psfutil.py:709-795) for ONE image psf [ny, nx]: interpolate at the nsamp x nsamp sampling
+    positions (yxco [2, nsamp, nsamp] = y, x offsets from the image centre; None = the unrotated grid, which the
+    reference evaluates with the separable gridD5512C instead of iD5512C)."""
+    ny, nx = psf.shape
+    xctr, yctr = (nx - 1) / 2.0, (ny - 1) / 2.0
+    out_arr = np.zeros((1, nsamp * nsamp))
+    lin = np.linspace((1 - nsamp) / 2, (nsamp - 1) / 2, nsamp)
+    if yxco is not None:
+        iD5512C(np.pad(psf, 6).reshape((1, ny + 12, nx + 12)), np.ascontiguousarray(yxco[1].ravel() + xctr + 6),
+                np.ascontiguousarray(yxco[0].ravel() + yctr + 6), out_arr)
+    else:
+        gridD5512C(np.pad(psf, 6), (lin + xctr + 6)[None, :], (lin + yctr + 6)[None, :], out_arr)
+    return out_arr.reshape((nsamp, nsamp))
+
+
+def finish_psf_group(psf_arr, psf_circ, psf_norm):
+    """PSFGrp.__init__ (psfutil.py:650-656): circular cut-out and normalisation of the sampled PSFs (in place)."""
+    nsamp = psf_arr.shape[-1]
+    lin = np.linspace((1 - nsamp) / 2, (nsamp - 1) / 2, nsamp)
+    if psf_circ:
+        psf_arr *= np.hypot(lin[:, None], lin[None, :]) < nsamp // 2 + 0.5
+    if psf_norm:
+        v = np.moveaxis(psf_arr, 0, -1)
+        v /= psf_arr.sum(axis=(-2, -1))
+    return psf_arr
+
+
+def get_outpsf(outpsf, extrasmooth, use_filter, nsamp, oversamp):
+    """PSFGrp._get_outpsf (psfutil.py:854-896): the (nsamp+1)^2 target PSF image before sampling."""
+    if outpsf == "GAUSSIAN":
+        return psf_gaussian(nsamp + 1, extrasmooth * oversamp, extrasmooth * oversamp)
+    if outpsf in ("AIRYOBSC", "AIRYUNOBSC"):
+        return psf_simple_airy(nsamp + 1, QFILTER_NATIVE[use_filter] * oversamp, obsc=OBSC if outpsf == "AIRYOBSC" else 0.0,
+                               tophat_conv=0.0, sigma=extrasmooth * oversamp)
+    raise RuntimeError("Error: unsupported target output PSF type")
+
+
 # ------------------------------------------------------------------------------------------------ stamp level
 def stamp_system(g, x, y, psf, tables_pad, pair_tab, pair_pen, io_tab, out_x0, out_y0, n2f):
     """A and Bt of ONE stamp from the device-seam description (include/imcom_hip.h: imcom_build_A/_B):

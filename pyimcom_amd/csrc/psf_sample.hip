@@ -1,0 +1,258 @@
+// psf_sample.hip -- PSF images onto the output-aligned sample grid, and the analytic target PSFs.
+//
+// Reference (src/pyimcom/psfutil.py):
+//   PSFGrp._sample_psf 709-795           pad by 6, interpolate (iD5512C at given positions / gridD5512C on the unrotated grid)
+//   PSFGrp.__init__ 650-656              circular cut-out (ro < nc + 0.5) and normalisation to unit sum
+//   OutPSF.psf_gaussian 117-146          Gaussian spot
+//   OutPSF.psf_simple_airy 148-223       (obscured) Airy spot, optionally convolved with a top-hat and a Gaussian
+// The convolution of the Airy spot is a multiplication by a real, even, separable filter in Fourier space, i.e.
+// circulant matrices applied from both sides: out = C I C^T with C[i][j] = k[(i - j) mod npad],
+// k[d] = (1/npad) sum_u h(u) cos(2 pi u d / npad) -- two products on the fp64 MFMA GEMM, exact twiddles.
+#include "common.h"
+#include "launchers.h"
+
+namespace imcom {
+
+// padded[p][r][c] = psf[p][r-6][c-6] (zero border), ng = n + 12
+__global__ void pad6_kernel(const double *__restrict__ psf, int ny, int nx, double *__restrict__ out)
+{
+    const int p = blockIdx.z, r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gy = ny + 12, gx = nx + 12;
+    if (c >= gx) return;
+    const int rr = r - 6, cc = c - 6;
+    out[((long)p * gy + r) * gx + c] = (rr >= 0 && rr < ny && cc >= 0 && cc < nx) ? psf[((long)p * ny + rr) * nx + cc] : 0.0;
+}
+
+// interpolation positions: xpos = yxco[1] + xctr + 6, ypos = yxco[0] + yctr + 6   (psfutil.py:777-779)
+__global__ void sample_pos_kernel(const double *__restrict__ yxco, long npts, double xctr, double yctr, double *__restrict__ xpos,
+                                  double *__restrict__ ypos)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    ypos[i] = yxco[i] + yctr + 6.0;
+    xpos[i] = yxco[npts + i] + xctr + 6.0;
+}
+
+// unrotated grid: lin[i] = i - (nsamp-1)/2 (PSFGrp.yxo), positions lin + ctr + 6   (psfutil.py:788-790)
+__global__ void grid_pos_kernel(int nsamp, double xctr, double yctr, double *__restrict__ xpos, double *__restrict__ ypos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsamp) return;
+    const double lin = (double)i - 0.5 * (double)(nsamp - 1);
+    xpos[i] = lin + xctr + 6.0;
+    ypos[i] = lin + yctr + 6.0;
+}
+
+// circular cut-out and per-PSF sum; one block per PSF, then scale
+__global__ __launch_bounds__(256) void psf_circ_sum_kernel(double *__restrict__ arr, int nsamp, int circ, double *__restrict__ sums)
+{
+    __shared__ double red[4];
+    const int p = blockIdx.x;
+    const double c0 = 0.5 * (double)(nsamp - 1), rmax = (double)(nsamp / 2) + 0.5;
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < (long)nsamp * nsamp; i += 256) {
+        const int r = (int)(i / nsamp), c = (int)(i % nsamp);
+        double v = arr[(long)p * nsamp * nsamp + i];
+        if (circ && !(hypot((double)r - c0, (double)c - c0) < rmax)) {
+            v = 0.0;
+            arr[(long)p * nsamp * nsamp + i] = 0.0;
+        }
+        acc += v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[p] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void psf_scale_kernel(double *__restrict__ arr, long per, const double *__restrict__ sums)
+{
+    const int p = blockIdx.y;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < per) arr[p * per + i] /= sums[p];
+}
+
+__global__ void gaussian_kernel(int n, double sigmax, double sigmay, double *__restrict__ out)
+{
+    const int r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    // np.mgrid[(1-n)/2/s : (n-1)/2/s : n*1j]: start + i * step with step = (stop - start) / (n - 1)
+    const double y0 = 0.5 * (1 - n) / sigmay, y1 = 0.5 * (n - 1) / sigmay, x0 = 0.5 * (1 - n) / sigmax, x1 = 0.5 * (n - 1) / sigmax;
+    const double y = n > 1 ? y0 + r * ((y1 - y0) / (n - 1)) : y0, x = n > 1 ? x0 + c * ((x1 - x0) / (n - 1)) : x0;
+    out[(long)r * n + c] = exp(-0.5 * (x * x + y * y)) / (2.0 * M_PI * sigmax * sigmay);
+}
+
+// Airy intensity on the npad x npad grid (psfutil.py:189-203), written into the padded GEMM operand [P][P]
+__global__ void airy_kernel(int npad, int P, double ldp, double obsc, double *__restrict__ I)
+{
+    const int r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P) return;
+    double v = 0.0;
+    if (r < npad && c < npad) {
+        const double y = (double)r - 0.5 * (double)(npad - 1), x = (double)c - 0.5 * (double)(npad - 1);
+        const double pr = M_PI * (sqrt(x * x + y * y) / ldp);
+        double a = j0(pr) + jn(2, pr);
+        if (obsc != 0.0) a -= obsc * obsc * (j0(pr * obsc) + jn(2, pr * obsc));
+        v = a * a / (4.0 * ldp * ldp * (1.0 - obsc * obsc)) * M_PI;
+    }
+    I[(long)r * P + c] = v;
+}
+
+// circulant of the separable filter h(u) = exp(-2 pi^2 u^2 sigma^2) sinc(u tophat), u_k = k/npad (minus 1 in the upper half)
+__global__ __launch_bounds__(256) void airy_filter_kernel(int npad, double sigma, double tophat, double *__restrict__ kvec)
+{
+    __shared__ double red[4];
+    const int d = blockIdx.x;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < npad; k += 256) {
+        double u = (double)k / (double)npad;
+        if (k >= npad - npad / 2) u -= 1.0;
+        const double us = u * sigma, ut = u * tophat;
+        const double snc = ut == 0.0 ? 1.0 : sinpi(ut) / (M_PI * ut);
+        const double h = exp(-2.0 * M_PI * M_PI * (us * us)) * snc;
+        const long kd = ((long)k * d) % npad;
+        acc += h * cospi(2.0 * (double)kd / (double)npad);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) kvec[d] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)npad;
+}
+
+__global__ void circulant_kernel(const double *__restrict__ kvec, int npad, int P, double *__restrict__ Cm)
+{
+    const int r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P) return;
+    double v = 0.0;
+    if (r < npad && c < npad) v = kvec[(r - c + npad) % npad];
+    Cm[(long)r * P + c] = v;
+}
+
+__global__ void crop_kernel(const double *__restrict__ Z, int P, int kp, int n, double *__restrict__ out)
+{
+    const int r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    out[(long)r * n + c] = Z[(long)(r + kp) * P + (c + kp)];
+}
+
+}  // namespace imcom
+
+using namespace imcom;
+
+static int ctx_ok3(imcom_ctx *ctx)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
+    return IMCOM_OK;
+}
+
+extern "C" int imcom_sample_psf(imcom_ctx *ctx, int n_psf, const double *psf, int ny, int nx, const double *yxco, int nsamp,
+                                int psf_circ, int psf_norm, double *psf_arr, int memspace)
+{
+    IMCOM_TRY(ctx_ok3(ctx));
+    IMCOM_REQUIRE(n_psf >= 1 && psf && psf_arr && ny >= 1 && nx >= 1 && nsamp >= 1, "bad arguments");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const long npts = (long)nsamp * nsamp, gy = ny + 12, gx = nx + 12;
+    const size_t szin = (size_t)n_psf * ny * nx * 8, szout = (size_t)n_psf * npts * 8, szco = yxco ? (size_t)n_psf * 2 * npts * 8 : 0;
+    size_t total = 65536 + (size_t)n_psf * gy * gx * 8 + 2 * (size_t)npts * 8 + (size_t)n_psf * 8;
+    if (host) total += szin + szout + szco + 1024;
+    IMCOM_TRY(ws_reserve(ctx, total));
+    const double *psf_d = psf, *co_d = yxco;
+    double *out_d = psf_arr;
+    if (host) {
+        double *t = (double *)ws_take(ctx, szin);
+        out_d = (double *)ws_take(ctx, szout);
+        if (!t || !out_d) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+        IMCOM_HIP_CHECK(hipMemcpyAsync(t, psf, szin, hipMemcpyHostToDevice, ctx->stream));
+        psf_d = t;
+        if (yxco) {
+            double *c = (double *)ws_take(ctx, szco);
+            if (!c) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+            IMCOM_HIP_CHECK(hipMemcpyAsync(c, yxco, szco, hipMemcpyHostToDevice, ctx->stream));
+            co_d = c;
+        }
+    }
+    double *pad = (double *)ws_take(ctx, (size_t)n_psf * gy * gx * 8);
+    double *xpos = (double *)ws_take(ctx, (size_t)npts * 8), *ypos = (double *)ws_take(ctx, (size_t)npts * 8);
+    double *sums = (double *)ws_take(ctx, (size_t)n_psf * 8);
+    if (!pad || !xpos || !ypos || !sums) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    const double xctr = (nx - 1) / 2.0, yctr = (ny - 1) / 2.0;
+    hipLaunchKernelGGL(pad6_kernel, dim3((unsigned)((gx + 255) / 256), (unsigned)gy, n_psf), dim3(256), 0, ctx->stream, psf_d, ny, nx, pad);
+    IMCOM_TRY(check_launch("pad6_kernel"));
+    IMCOM_HIP_CHECK(hipMemsetAsync(out_d, 0, szout, ctx->stream));  // off-grid samples stay zero (psfutil.py:775, 785)
+    if (!co_d) {
+        hipLaunchKernelGGL(grid_pos_kernel, dim3((nsamp + 255) / 256), dim3(256), 0, ctx->stream, nsamp, xctr, yctr, xpos, ypos);
+        IMCOM_TRY(check_launch("grid_pos_kernel"));
+    }
+    for (int p = 0; p < n_psf; p++) {
+        const double *img = pad + (size_t)p * gy * gx;
+        if (co_d) {
+            hipLaunchKernelGGL(sample_pos_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, co_d + (size_t)p * 2 * npts, npts,
+                               xctr, yctr, xpos, ypos);
+            IMCOM_TRY(check_launch("sample_pos_kernel"));
+            IMCOM_TRY(launch_interp(ctx, img, 1, (int)gy, (int)gx, xpos, ypos, npts, out_d + (size_t)p * npts, 0));
+        } else {
+            IMCOM_TRY(launch_grid(ctx, img, (int)gy, (int)gx, xpos, ypos, 1, nsamp, nsamp, out_d + (size_t)p * npts));
+        }
+    }
+    if (psf_circ || psf_norm) {
+        hipLaunchKernelGGL(psf_circ_sum_kernel, dim3(n_psf), dim3(256), 0, ctx->stream, out_d, nsamp, psf_circ ? 1 : 0, sums);
+        if (psf_norm)
+            hipLaunchKernelGGL(psf_scale_kernel, dim3((unsigned)((npts + 255) / 256), n_psf), dim3(256), 0, ctx->stream, out_d, npts, sums);
+        IMCOM_TRY(check_launch("psf circ/norm"));
+    }
+    if (host) {
+        IMCOM_HIP_CHECK(hipMemcpyAsync(psf_arr, out_d, szout, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return IMCOM_OK;
+}
+
+extern "C" int imcom_psf_gaussian(imcom_ctx *ctx, int n, double sigmax, double sigmay, double *out, int memspace)
+{
+    IMCOM_TRY(ctx_ok3(ctx));
+    IMCOM_REQUIRE(n >= 1 && out && sigmax > 0.0 && sigmay > 0.0, "bad arguments");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const size_t sz = (size_t)n * n * 8;
+    IMCOM_TRY(ws_reserve(ctx, sz + 4096));
+    double *o = host ? (double *)ws_take(ctx, sz) : out;
+    if (!o) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    hipLaunchKernelGGL(gaussian_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, n, sigmax, sigmay, o);
+    IMCOM_TRY(check_launch("gaussian_kernel"));
+    if (host) {
+        IMCOM_HIP_CHECK(hipMemcpyAsync(out, o, sz, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return IMCOM_OK;
+}
+
+extern "C" int imcom_psf_simple_airy(imcom_ctx *ctx, int n, double ldp, double obsc, double tophat_conv, double sigma, double *out,
+                                     int memspace)
+{
+    IMCOM_TRY(ctx_ok3(ctx));
+    IMCOM_REQUIRE(n >= 1 && out && ldp > 0.0 && obsc >= 0.0 && obsc < 1.0 && tophat_conv >= 0.0 && sigma >= 0.0, "bad arguments");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const int kp = 1 + (int)ceil(tophat_conv + 6.0 * sigma), npad = n + 2 * kp;  // psfutil.py:185-186
+    const int P = (int)align_up((size_t)npad, NB);
+    const size_t szP = (size_t)P * P * 8, sz = (size_t)n * n * 8;
+    IMCOM_TRY(ws_reserve(ctx, 4 * szP + (size_t)npad * 8 + sz + 8192));
+    double *I = (double *)ws_take(ctx, szP), *Cm = (double *)ws_take(ctx, szP), *Y = (double *)ws_take(ctx, szP), *Z = (double *)ws_take(ctx, szP);
+    double *kvec = (double *)ws_take(ctx, (size_t)npad * 8);
+    double *o = host ? (double *)ws_take(ctx, sz) : out;
+    if (!I || !Cm || !Y || !Z || !kvec || !o) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    hipLaunchKernelGGL(airy_kernel, dim3((P + 255) / 256, P), dim3(256), 0, ctx->stream, npad, P, ldp, obsc, I);
+    hipLaunchKernelGGL(airy_filter_kernel, dim3(npad), dim3(256), 0, ctx->stream, npad, sigma, tophat_conv, kvec);
+    hipLaunchKernelGGL(circulant_kernel, dim3((P + 255) / 256, P), dim3(256), 0, ctx->stream, kvec, npad, P, Cm);
+    IMCOM_TRY(check_launch("airy setup"));
+    IMCOM_TRY(launch_gemm(ctx, false, false, P, P, P, 1, I, P, 0, Cm, P, 0, Y, P, 0, 1.0, 0.0));  // Y = I C^T
+    IMCOM_TRY(launch_gemm(ctx, false, true, P, P, P, 1, Cm, P, 0, Y, P, 0, Z, P, 0, 1.0, 0.0));   // Z = C Y
+    hipLaunchKernelGGL(crop_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, Z, P, kp, n, o);
+    IMCOM_TRY(check_launch("crop_kernel"));
+    if (host) {
+        IMCOM_HIP_CHECK(hipMemcpyAsync(out, o, sz, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return IMCOM_OK;
+}

@@ -1,0 +1,83 @@
+"""PSF sampling and target PSFs on the device: the host mirror of the reference's ``OutPSF`` static methods and of
+``PSFGrp._get_outpsf / _sample_psf`` (src/pyimcom/psfutil.py:117-223, 709-795, 854-929).
+
+Arrays may be numpy (host in, host out) or torch CUDA tensors (device in, device out)."""
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import MEM_DEVICE, MEM_HOST, check, default_context, lib
+
+QFILTER_NATIVE = [1.155, 1.456, 1.250, 1.021, 0.834, 0.689, 0.491, 1.009, 0.000, 1.159, 1.685]  # config.py:85-98
+OBSC = 0.31
+
+
+def _is_torch(a):
+    return a is not None and type(a).__module__.startswith("torch")
+
+
+def _out(shape, like, device):
+    if like == "torch":
+        import torch
+
+        return torch.empty(shape, dtype=torch.float64, device=device)
+    return np.empty(shape, dtype=np.float64)
+
+
+def _p(a):
+    if a is None:
+        return None
+    return C.c_void_p(a.data_ptr()) if _is_torch(a) else a.ctypes.data_as(C.c_void_p)
+
+
+def psf_gaussian(n, sigmax, sigmay, device=None, ctx=None):
+    """``OutPSF.psf_gaussian`` (psfutil.py:117-146); ``device`` given -> torch tensor on that device."""
+    ctx = ctx or default_context()
+    out = _out((n, n), "torch" if device else "numpy", device)
+    check(lib.imcom_psf_gaussian(ctx.handle, int(n), float(sigmax), float(sigmay), _p(out), MEM_DEVICE if device else MEM_HOST))
+    return out
+
+
+def psf_simple_airy(n, ldp, obsc=0.0, tophat_conv=0.0, sigma=0.0, device=None, ctx=None):
+    """``OutPSF.psf_simple_airy`` (psfutil.py:148-223)."""
+    ctx = ctx or default_context()
+    out = _out((n, n), "torch" if device else "numpy", device)
+    check(lib.imcom_psf_simple_airy(ctx.handle, int(n), float(ldp), float(obsc), float(tophat_conv), float(sigma), _p(out),
+                                    MEM_DEVICE if device else MEM_HOST))
+    return out
+
+
+def get_outpsf(outpsf, extrasmooth, use_filter, nsamp, oversamp, device=None, ctx=None):
+    """``PSFGrp._get_outpsf`` (psfutil.py:854-896): the (nsamp+1)^2 target PSF image."""
+    if outpsf == "GAUSSIAN":
+        return psf_gaussian(nsamp + 1, extrasmooth * oversamp, extrasmooth * oversamp, device, ctx)
+    if outpsf in ("AIRYOBSC", "AIRYUNOBSC"):
+        return psf_simple_airy(nsamp + 1, QFILTER_NATIVE[use_filter] * oversamp, OBSC if outpsf == "AIRYOBSC" else 0.0, 0.0,
+                               extrasmooth * oversamp, device, ctx)
+    raise RuntimeError("Error: unsupported target output PSF type")
+
+
+def sample_psf(psf, nsamp, yxco=None, psf_circ=False, psf_norm=False, ctx=None):
+    """``PSFGrp._sample_psf`` + the cut-out / normalisation of ``PSFGrp.__init__`` (psfutil.py:709-795, 650-656).
+
+    psf [n_psf, ny, nx]; yxco [n_psf, 2, nsamp, nsamp] (y, x offsets from the image centre) or None for the
+    unrotated grid.  Returns psf_arr [n_psf, nsamp, nsamp]."""
+    ctx = ctx or default_context()
+    tor = _is_torch(psf)
+    if tor:
+        import torch
+
+        psf = psf.contiguous()
+        yxco = None if yxco is None else yxco.contiguous()
+        ctx.set_stream(torch.cuda.current_stream(psf.device).cuda_stream)
+    else:
+        psf = np.ascontiguousarray(psf, dtype=np.float64)
+        yxco = None if yxco is None else np.ascontiguousarray(yxco, dtype=np.float64)
+    n_psf, ny, nx = psf.shape
+    if yxco is not None:
+        assert tuple(yxco.shape) == (n_psf, 2, nsamp, nsamp)
+    out = _out((n_psf, nsamp, nsamp), "torch" if tor else "numpy", psf.device if tor else None)
+    check(lib.imcom_sample_psf(ctx.handle, n_psf, _p(psf), ny, nx, _p(yxco), int(nsamp), int(bool(psf_circ)), int(bool(psf_norm)),
+                               _p(out), MEM_DEVICE if tor else MEM_HOST))
+    return out

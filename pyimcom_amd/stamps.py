@@ -42,8 +42,9 @@ class PSFGroupTables:
         E, ns, _ = psf_in.shape
         self.n_psf, self.nsamp, self.nfft = E, ns, nfft
         dev = torch.device(device)
-        pin = torch.as_tensor(np.ascontiguousarray(psf_in, dtype=np.float64), device=dev)
-        pout = torch.as_tensor(np.ascontiguousarray(psf_out[:1], dtype=np.float64), device=dev)
+        as_dev = lambda a: (a.to(dev).contiguous() if torch.is_tensor(a)  # noqa: E731
+                            else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev))
+        pin, pout = as_dev(psf_in), as_dev(psf_out[:1])
         ng = ns + 12
         self.ntri = E * (E + 1) // 2
         self.tables = torch.empty((self.ntri + E, ng, ng), dtype=torch.float64, device=dev)
@@ -59,6 +60,23 @@ class PSFGroupTables:
         check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pout), 1, _dp(pout), 1, ns, nfft, _hp(pairs), 1, _dp(cc)))
         nc = ns // 2
         self.C = float(cc[0, 6 + nc, 6 + nc].item())  # psfutil.py:1290
+
+    @classmethod
+    def from_images(cls, psf_images, yxco, target, nsamp, nfft, oversamp, psf_circ=False, psf_norm=False, ctx=None,
+                    device="cuda:0"):
+        """The whole PSF side of a 2x2 stamp group on the device (PSFGrp.__init__ for the input group and for the
+        output group, psfutil.py:615-671, then PSFOvl): ``psf_images`` [E, ny, nx] as returned by
+        ``InImage.get_psf_pos``, ``yxco`` [E, 2, nsamp, nsamp] their sampling positions (psfutil.py:751-771, the
+        WCS part stays on the host), ``target`` = (outpsf, extrasmooth, use_filter) of the configuration."""
+        from . import psfs
+
+        dev = torch.device(device)
+        img = torch.as_tensor(np.ascontiguousarray(psf_images, dtype=np.float64), device=dev)
+        co = torch.as_tensor(np.ascontiguousarray(yxco, dtype=np.float64), device=dev)
+        psf_in = psfs.sample_psf(img, nsamp, co, psf_circ, psf_norm, ctx)
+        timg = psfs.get_outpsf(target[0], target[1], target[2], nsamp, oversamp, device=dev, ctx=ctx)
+        psf_out = psfs.sample_psf(timg[None], nsamp, None, psf_circ, psf_norm, ctx)
+        return cls(psf_in, psf_out, nfft, ctx=ctx, device=device)
 
     def _set_stream(self):
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,73 @@
+"""GPU parity of PSF sampling and the analytic target PSFs against the reference's own outputs
+(tests/golden/make_golden_psf.py; psfutil.py:117-223, 709-795, 615-671)."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_target_psf_images(golden):
+    from pyimcom_amd import psfs
+
+    g = golden("psfovl")
+    a = psfs.psf_gaussian(16, 2.5, 2.5)
+    assert np.allclose(a, g["gauss_16_25"], rtol=1e-14, atol=0)
+    b = psfs.psf_simple_airy(24, 5.0, obsc=0.31, tophat_conv=4.0, sigma=1.2)
+    assert np.abs(b - g["airy_24"]).max() <= 2e-13 * np.abs(g["airy_24"]).max()
+
+
+def test_sample_psf_golden(golden):
+    import torch
+
+    from pyimcom_amd import psfs
+
+    g = golden("psf_sample")
+    ns = int(g["nsamp"])
+    a = psfs.sample_psf(g["in_psf"][None], ns, g["in_yxco"][None])[0]
+    assert np.abs(a - g["in_psf_arr"]).max() <= 1e-13 * np.abs(g["in_psf_arr"]).max()
+    b = psfs.sample_psf(g["grid_psf"], ns)
+    assert np.abs(b - g["grid_psf_arr"]).max() <= 1e-13 * np.abs(g["grid_psf_arr"]).max()
+    # device in / device out gives the same numbers
+    bt = psfs.sample_psf(torch.as_tensor(g["grid_psf"], device="cuda:0"), ns)
+    assert np.array_equal(bt.cpu().numpy(), b)
+
+
+@pytest.mark.parametrize("name,kind", [("gauss", "GAUSSIAN"), ("airyobsc", "AIRYOBSC"), ("airyunobsc", "AIRYUNOBSC")])
+def test_output_psf_group_golden(golden, name, kind):
+    """PSFGrp(in_or_out=False): _get_outpsf -> _sample_psf(None, .) -> circular cut-out -> normalisation."""
+    from pyimcom_amd import psfs
+
+    g = golden("psf_sample")
+    ns, ov = int(g["nsamp"]), int(g["oversamp"])
+    sig, uf, circ, norm = g[f"out_{name}_pars"]
+    img = psfs.get_outpsf(kind, float(sig), int(uf), ns, ov)
+    arr = psfs.sample_psf(img[None], ns, None, bool(circ), bool(norm))[0]
+    ref = g[f"out_{name}"]
+    assert np.abs(arr - ref).max() <= 3e-13 * np.abs(ref).max()
+    assert np.array_equal(arr == 0, ref == 0)  # the cut-out mask
+
+
+def test_group_tables_from_images(golden):
+    """Raw PSF images + sampling positions -> sampled PSFs -> overlap tables, all on the device, equals the
+    oracle's chain (sample_psf, finish_psf_group, pad_and_rfft2, overlap_*)."""
+    from oracle import oracle as orc
+    from pyimcom_amd.stamps import PSFGroupTables
+
+    g = golden("psf_sample")
+    ns, ov = int(g["nsamp"]), int(g["oversamp"])
+    nfft = 2 * (ns + 1)
+    rng = np.random.default_rng(2)
+    imgs = np.stack([g["in_psf"], g["in_psf"][::-1, ::-1] * 0.9 + 0.01 * rng.standard_normal(g["in_psf"].shape)])
+    yxco = np.stack([g["in_yxco"], 1.02 * g["in_yxco"][:, ::-1]])
+    tabs = PSFGroupTables.from_images(imgs, yxco, ("GAUSSIAN", 1.2, 2), ns, nfft, ov, psf_circ=True, psf_norm=True)
+    pin = np.stack([orc.sample_psf(imgs[e], ns, yxco[e]) for e in range(2)])
+    orc.finish_psf_group(pin, True, True)
+    pout = orc.sample_psf(orc.get_outpsf("GAUSSIAN", 1.2, 2, ns, ov), ns)[None].copy()
+    orc.finish_psf_group(pout, True, True)
+    geo = orc.Geom(int(g["npixpsf"]), ov, float(g["dtheta_as"]) / 3600.0, 0.0)
+    r_in, r_out = orc.pad_and_rfft2(pin, geo), orc.pad_and_rfft2(pout, geo)
+    ref = np.concatenate([orc.overlap_self(r_in, geo), orc.overlap_cross(r_in, r_out, geo)[:, 0]])
+    got = tabs.tables.cpu().numpy()[:, 6:-6, 6:-6]
+    assert np.abs(got - ref).max() <= 5e-13 * np.abs(ref).max()
+    assert abs(tabs.C - orc.overlap_out_C(r_out, geo)[0]) <= 1e-12 * tabs.C

@@ -198,3 +198,18 @@ def test_iter_and_empir_kernels_golden(golden):
             assert np.array_equal(T, g[f"{name}_T"][j])
             for got, key in ((UC, "UC"), (S, "Sigma"), (k, "kappa")):
                 assert np.array_equal(got, g[f"{name}_{key}"][j].ravel()), (name, j, key)
+
+
+def test_psf_sampling_golden(golden):
+    """PSFGrp._sample_psf 709-795 (both interpolator paths), _get_outpsf 854-896 and the cut-out / normalisation
+    of PSFGrp.__init__ 650-656: bit-exact against the reference's arrays."""
+    g = golden("psf_sample")
+    ns, ov = int(g["nsamp"]), int(g["oversamp"])
+    assert np.array_equal(orc.sample_psf(g["in_psf"], ns, g["in_yxco"]), g["in_psf_arr"])
+    for k in range(2):
+        assert np.array_equal(orc.sample_psf(g["grid_psf"][k], ns), g["grid_psf_arr"][k])
+    for name, kind in (("gauss", "GAUSSIAN"), ("airyobsc", "AIRYOBSC"), ("airyunobsc", "AIRYUNOBSC")):
+        sig, uf, circ, norm = g[f"out_{name}_pars"]
+        arr = orc.sample_psf(orc.get_outpsf(kind, sig, int(uf), ns, ov), ns)[None].copy()
+        orc.finish_psf_group(arr, bool(circ), bool(norm))
+        assert np.array_equal(arr[0], g[f"out_{name}"]), name
