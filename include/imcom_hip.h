@@ -270,9 +270,12 @@ int imcom_psf_simple_airy(imcom_ctx *ctx, int n, double ldp, double obsc, double
 /* PSFGrp.accel_pad_and_rfft2 + PSFOvl._build_psfovl (psfutil.py:943-986, 1244-1294): correlation
  * tables out[p][q] = irfft2(rft(psf1[p]) * conj(rft(psf2[q]))), rolled by nc and cropped to
  * nsamp x nsamp.  psf1[n1][nsamp][nsamp], psf2[n2][nsamp][nsamp]; pairs[npairs][2] HOST lists the
- * (p,q) wanted, tables[npairs][nsamp+12][nsamp+12] (zero border included). */
+ * (p,q) wanted, tables[npairs][nsamp+12][nsamp+12] (zero border included).
+ * amp_penalty HOST: NULL, or {cfg.amp_penalty[0], cfg.amp_penalty[1] * oversamp}: both groups' spectra are
+ * reweighted by 1 + a0 exp(-2 pi^2 |u|^2 a1^2) as PSFGrp.__init__ does (psfutil.py:661-671). */
 int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, const double *psf2, int n2,
-                      int nsamp, int nfft, const int *pairs_host, int npairs, double *tables);
+                      int nsamp, int nfft, const int *pairs_host, int npairs, const double *amp_penalty,
+                      double *tables);
 
 #ifdef __cplusplus
 }

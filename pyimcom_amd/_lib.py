@@ -81,7 +81,7 @@ SIGNATURES = {
     "imcom_sample_psf": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i],
     "imcom_psf_gaussian": [_vp, _i, _d, _d, _vp, _i],
     "imcom_psf_simple_airy": [_vp, _i, _d, _d, _d, _d, _vp, _i],
-    "imcom_psf_overlap": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
+    "imcom_psf_overlap": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
     "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
     "imcom_trapezoid_recover_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i],
 }

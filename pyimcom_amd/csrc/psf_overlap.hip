@@ -68,8 +68,10 @@ __global__ void pad_psf_kernel(const double *__restrict__ psf, int ns, double *_
 }
 
 // Z[pair] = R1[p] * conj(R2[q]);   R layout [psf][2][Mp*Np]
+// amp0 != 0: both spectra carry the Fourier-mode reweighting of PSFGrp.__init__ (psfutil.py:661-671),
+// w(u) = 1 + amp0 exp(-2 pi^2 |u|^2 amps^2) with u = k / nfft wrapped to (-1/2, 1/2]; the product carries w^2.
 __global__ void cmul_conj_kernel(const double *__restrict__ R1, const double *__restrict__ R2, const int *__restrict__ pairs,
-                                 long plane, double *__restrict__ Z)
+                                 long plane, int Hp, int nfft, double amp0, double amps, double *__restrict__ Z)
 {
     const int t = blockIdx.y;
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -77,8 +79,17 @@ __global__ void cmul_conj_kernel(const double *__restrict__ R1, const double *__
     const int p = pairs[2 * t], q = pairs[2 * t + 1];
     const double ar = R1[(2L * p) * plane + i], ai = R1[(2L * p + 1) * plane + i];
     const double br = R2[(2L * q) * plane + i], bi = R2[(2L * q + 1) * plane + i];
-    Z[(2L * t) * plane + i] = ar * br + ai * bi;
-    Z[(2L * t + 1) * plane + i] = ai * br - ar * bi;
+    double w2 = 1.0;
+    if (amp0 != 0.0) {
+        const int ky = (int)(i / Hp), kx = (int)(i % Hp);
+        double uy = (double)ky / (double)nfft, ux = (double)kx / (double)nfft;
+        if (uy > 0.5) uy -= 1.0;
+        if (ux > 0.5) ux -= 1.0;
+        const double w = 1.0 + amp0 * exp(-2.0 * M_PI * M_PI * (ux * ux + uy * uy) * (amps * amps));
+        w2 = w * w;
+    }
+    Z[(2L * t) * plane + i] = (ar * br + ai * bi) * w2;
+    Z[(2L * t + 1) * plane + i] = (ai * br - ar * bi) * w2;
 }
 
 // tables[t][6 + r][6 + c] = win[t][r][c] for r,c < ns; border zero
@@ -100,7 +111,7 @@ static int up(int v, int a) { return (v + a - 1) / a * a; }
 using namespace imcom;
 
 extern "C" int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, const double *psf2, int n2, int nsamp,
-                                 int nfft, const int *pairs_host, int npairs, double *tables)
+                                 int nfft, const int *pairs_host, int npairs, const double *amp_penalty, double *tables)
 {
     if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
     IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
@@ -176,7 +187,8 @@ extern "C" int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, con
     IMCOM_TRY(launch_gemm(ctx, false, true, Fp, Hp, Sp, npsf, FYc, Sp, 0, Y1i, Hp, sY1, Ri, Hp, sR, 1.0, 0.0));
     IMCOM_TRY(launch_gemm(ctx, false, true, Fp, Hp, Sp, npsf, FYs, Sp, 0, Y1r, Hp, sY1, Ri, Hp, sR, 1.0, 1.0));
     // spectra product
-    hipLaunchKernelGGL(cmul_conj_kernel, dim3((unsigned)((plane + 255) / 256), npairs), dim3(256), 0, st, R, R, pairs_dev, plane, Z);
+    hipLaunchKernelGGL(cmul_conj_kernel, dim3((unsigned)((plane + 255) / 256), npairs), dim3(256), 0, st, R, R, pairs_dev, plane, Hp,
+                       nfft, amp_penalty ? amp_penalty[0] : 0.0, amp_penalty ? amp_penalty[1] : 0.0, Z);
     IMCOM_TRY(check_launch("cmul_conj_kernel"));
     // inverse along y on the kept rows: U = (IYc + i IYs) Z    [Sp x Fp] . [Fp x Hp]
     const long sZ = 2L * plane, sU = 2L * Sp * Hp;

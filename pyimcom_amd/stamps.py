@@ -37,8 +37,11 @@ class PSFGroupTables:
     Table stack order: the E(E+1)/2 self tables in triangle order, then the E input-output tables.
     """
 
-    def __init__(self, psf_in, psf_out, nfft, ctx=None, device="cuda:0"):
+    def __init__(self, psf_in, psf_out, nfft, ctx=None, device="cuda:0", amp_penalty=None):
+        """amp_penalty: None or (cfg.amp_penalty[0], cfg.amp_penalty[1] * oversamp) (psfutil.py:661-671)."""
         self.ctx = ctx or default_context()
+        amp = None if amp_penalty is None or 0.0 in tuple(amp_penalty) else np.array(amp_penalty, dtype=np.float64)
+        ampp = None if amp is None else _hp(amp)
         E, ns, _ = psf_in.shape
         self.n_psf, self.nsamp, self.nfft = E, ns, nfft
         dev = torch.device(device)
@@ -50,20 +53,20 @@ class PSFGroupTables:
         self.tables = torch.empty((self.ntri + E, ng, ng), dtype=torch.float64, device=dev)
         self._set_stream()
         pairs = np.array([(i, j) for i in range(E) for j in range(i, E)], dtype=np.int32)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pin), E, ns, nfft, _hp(pairs), len(pairs),
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pin), E, ns, nfft, _hp(pairs), len(pairs), ampp,
                                     _dp(self.tables[: self.ntri])))
         pairs = np.array([(i, 0) for i in range(E)], dtype=np.int32)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pout), 1, ns, nfft, _hp(pairs), E,
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pout), 1, ns, nfft, _hp(pairs), E, ampp,
                                     _dp(self.tables[self.ntri :])))
         cc = torch.empty((1, ng, ng), dtype=torch.float64, device=dev)
         pairs = np.array([(0, 0)], dtype=np.int32)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pout), 1, _dp(pout), 1, ns, nfft, _hp(pairs), 1, _dp(cc)))
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pout), 1, _dp(pout), 1, ns, nfft, _hp(pairs), 1, ampp, _dp(cc)))
         nc = ns // 2
         self.C = float(cc[0, 6 + nc, 6 + nc].item())  # psfutil.py:1290
 
     @classmethod
     def from_images(cls, psf_images, yxco, target, nsamp, nfft, oversamp, psf_circ=False, psf_norm=False, ctx=None,
-                    device="cuda:0"):
+                    device="cuda:0", amp_penalty=None):
         """The whole PSF side of a 2x2 stamp group on the device (PSFGrp.__init__ for the input group and for the
         output group, psfutil.py:615-671, then PSFOvl): ``psf_images`` [E, ny, nx] as returned by
         ``InImage.get_psf_pos``, ``yxco`` [E, 2, nsamp, nsamp] their sampling positions (psfutil.py:751-771, the
@@ -76,7 +79,7 @@ class PSFGroupTables:
         psf_in = psfs.sample_psf(img, nsamp, co, psf_circ, psf_norm, ctx)
         timg = psfs.get_outpsf(target[0], target[1], target[2], nsamp, oversamp, device=dev, ctx=ctx)
         psf_out = psfs.sample_psf(timg[None], nsamp, None, psf_circ, psf_norm, ctx)
-        return cls(psf_in, psf_out, nfft, ctx=ctx, device=device)
+        return cls(psf_in, psf_out, nfft, ctx=ctx, device=device, amp_penalty=amp_penalty)
 
     def _set_stream(self):
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)

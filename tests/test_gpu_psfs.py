@@ -71,3 +71,21 @@ def test_group_tables_from_images(golden):
     got = tabs.tables.cpu().numpy()[:, 6:-6, 6:-6]
     assert np.abs(got - ref).max() <= 5e-13 * np.abs(ref).max()
     assert abs(tabs.C - orc.overlap_out_C(r_out, geo)[0]) <= 1e-12 * tabs.C
+
+
+def test_amp_penalty_tables_golden(golden):
+    """cfg.amp_penalty (psfutil.py:661-671): the reweighted spectra through to the overlap table and C."""
+    from pyimcom_amd import psfs
+    from pyimcom_amd.stamps import PSFGroupTables
+
+    g = golden("psf_sample")
+    ns, ov = int(g["nsamp"]), int(g["oversamp"])
+    a0, a1 = g["amp_penalty"]
+    mk = lambda kind, sig: psfs.sample_psf(psfs.get_outpsf(kind, sig, 2, ns, ov)[None], ns, None, True, True)  # noqa: E731
+    tabs = PSFGroupTables(mk("GAUSSIAN", 1.2), mk("AIRYOBSC", 0.9), 2 * (ns + 1), amp_penalty=(a0, a1 * ov))
+    got = tabs.tables[tabs.ntri].cpu().numpy()[6:-6, 6:-6]
+    ref = g["amp_ovl_io"][0, 0]
+    assert np.abs(got - ref).max() <= 5e-13 * np.abs(ref).max()
+    assert abs(tabs.C - g["amp_outovlc"][0]) <= 1e-12 * tabs.C
+    plain = PSFGroupTables(mk("GAUSSIAN", 1.2), mk("AIRYOBSC", 0.9), 2 * (ns + 1))
+    assert abs(plain.C - tabs.C) > 0.05 * tabs.C  # the weighting really changes the numbers

@@ -27,7 +27,7 @@ def test_psf_overlap_golden(golden):
         pairs = np.array(pairs, dtype=np.int32)
         out = torch.empty((len(pairs), ns + 12, ns + 12), dtype=torch.float64, device=dev)
         check(lib.imcom_psf_overlap(ctx.handle, dp(a), a.shape[0], dp(b), b.shape[0], ns, nfft,
-                                    pairs.ctypes.data_as(C.c_void_p), len(pairs), dp(out)))
+                                    pairs.ctypes.data_as(C.c_void_p), len(pairs), None, dp(out)))
         o = out.cpu().numpy()
         assert np.all(o[:, :6] == 0) and np.all(o[:, -6:] == 0) and np.all(o[:, :, :6] == 0) and np.all(o[:, :, -6:] == 0)
         return o[:, 6:-6, 6:-6]
