@@ -24,7 +24,8 @@
 
 namespace imcom {
 
-constexpr int TP = NB;          // reflectors per panel
+constexpr int TP = NB;          // reflectors per block reflector when Qh is formed
+constexpr int TPL = 64;         // reflectors per tridiagonalisation panel (the V / W corrections read 2 k values per row)
 constexpr int QRS = 16;         // QR sweeps per chunk = depth of the rotation wavefront
 constexpr int ROTPAD = 4 * QRS; // identity margin of the rotation log on both sides
 
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void trd_column_kernel(const double *__restric
     const int k = j - ps;
     const long so = (long)s * ld * ld;
     const double *V = Vall + so + (long)ps * ld;
-    double *W = Wp + (long)s * TP * ld;
+    double *W = Wp + (long)s * TPL * ld;
     const double *wp = wprime + (long)s * ld;
     const int r = blockIdx.x * 256 + threadIdx.x;
     double alpha = 0.0;
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const double *__restrict_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long so = (long)s * ld * ld;
     if ((int)blockIdx.x < nrowtiles) {
-        const int strip = ((j + 1) >> 5) + blockIdx.x, rb = strip * 32;
+        // longest strips (bottom of the matrix) first: they bound the launch's critical path
+        const int strip = ((j + 1) >> 5) + (nrowtiles - 1 - (int)blockIdx.x), rb = strip * 32;
         if (rb >= ns) return;
         const int r0 = rb + wave * 8;  // this wave's 8 rows; all four waves walk the same column chunks
         double ur[8];                  // u-tilde of those rows (wave-uniform)
@@ -164,18 +166,31 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const double *__restrict_
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int cend = rb + 32;
         int buf = 0;
-        for (int c = (j + 1) & ~127; c < cend; c += 128, buf ^= 1) {
+        // chunks of 128 columns, the next chunk's loads in flight while this one is reduced (a strip at the bottom of
+        // the matrix walks ~N/128 chunks one after the other: without the prefetch each costs a full memory latency)
+        double2 an[8], un;
+        auto fetch = [&](int c) {
             const int cc = c + 2 * lane;
-            double2 uu = *(const double2 *)(u + cc);
-            if (cc < j + 2 || cc >= cend) uu.x = 0.0;
-            if (cc + 1 < j + 2 || cc + 1 >= cend) uu.y = 0.0;
+            un = *(const double2 *)(u + cc);
+            if (cc < j + 2 || cc >= cend) un.x = 0.0;
+            if (cc + 1 < j + 2 || cc + 1 >= cend) un.y = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) an[i] = *(const double2 *)(A + (long)i * ld + cc);
+        };
+        const int cfirst = (j + 1) & ~127;
+        fetch(cfirst);
+        for (int c = cfirst; c < cend; c += 128, buf ^= 1) {
+            double2 a[8];
+            const double2 uu = un;
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = an[i];
+            if (c + 128 < cend) fetch(c + 128);
             double y2x = 0.0, y2y = 0.0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const double2 a = *(const double2 *)(A + (long)i * ld + cc);
-                acc[i] += a.x * uu.x + a.y * uu.y;
-                y2x += a.x * ur[i];
-                y2y += a.y * ur[i];
+                acc[i] += a[i].x * uu.x + a[i].y * uu.y;
+                y2x += a[i].x * ur[i];
+                y2y += a[i].y * ur[i];
             }
             if (c < rb) {  // columns strictly left of the diagonal block receive the transposed contributions
                 *(double2 *)&y2s[buf][wave][2 * lane] = make_double2(y2x, y2y);
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const double *__restrict_
     } else {
         const int wid = (blockIdx.x - nrowtiles) * 4 + wave, c = wid >> 1, which = wid & 1;
         if (c >= j - ps) return;
-        const double *vec = (which ? Wp + (long)s * TP * ld : Vall + so + (long)ps * ld) + (long)c * ld;
+        const double *vec = (which ? Wp + (long)s * TPL * ld : Vall + so + (long)ps * ld) + (long)c * ld;
         double acc = 0.0;
         for (int r = j + 2 + lane; r < ns; r += 64) acc += vec[r] * u[r];
 #pragma unroll
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(256) void trd_w_kernel(double *__restrict__ Vall, c
     __syncthreads();
     const long so = (long)s * ld * ld;
     double *V = Vall + so + (long)ps * ld;
-    const double *W = Wp + (long)s * TP * ld;
+    const double *W = Wp + (long)s * TPL * ld;
     const int r = blockIdx.x * 256 + threadIdx.x;
     double prod = 0.0;
     if (r >= j + 1 && r < ns) {
@@ -536,7 +551,7 @@ size_t tridiag_ws_bytes(int batch, int ld, bool vectors)
     add((size_t)batch * ld * ld * 8);                      // At
     add((size_t)batch * ld * ld * 8);                      // Vall
     if (vectors) add((size_t)batch * ld * ld * 8 + (size_t)batch * ld * 8);  // X + one scratch row per stamp
-    add((size_t)batch * TP * ld * 8);                      // Wp
+    add((size_t)batch * TPL * ld * 8);                     // Wp
     add((size_t)batch * (ld / 32) * ld * 8);               // per-strip partials of the symmetric product
     if (vectors) { add((size_t)batch * ld * TP * 8); add((size_t)batch * ld * TP * 8); }  // W1, W2
     if (vectors) { add((size_t)batch * TP * TP * 8); add((size_t)batch * TP * TP * 8); }  // S, T
@@ -562,7 +577,7 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
     const size_t mat = (size_t)batch * ld * ld * 8, vecb = (size_t)batch * ld * 8;
     double *At = (double *)ws_take(ctx, mat), *Vall = (double *)ws_take(ctx, mat);
     double *X = vectors ? (double *)ws_take(ctx, mat + (size_t)batch * ld * 8) : nullptr;
-    double *Wp = (double *)ws_take(ctx, (size_t)batch * TP * ld * 8);
+    double *Wp = (double *)ws_take(ctx, (size_t)batch * TPL * ld * 8);
     double *part = (double *)ws_take(ctx, (size_t)batch * (ld / 32) * ld * 8);
     double *W1 = nullptr, *W2 = nullptr, *Sm = nullptr, *Tm = nullptr;
     if (vectors) {
@@ -600,9 +615,9 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
     // ---- tridiagonalisation
     {
         ProfScope ps_(ctx, "eigen_trd", nmax);
-        for (int ps = 0; ps < nmax; ps += TP) {
-            const int pe = std::min(ps + TP, nmax);
-            IMCOM_HIP_CHECK(hipMemsetAsync(Wp, 0, (size_t)batch * TP * ld * 8, st));
+        for (int ps = 0; ps < nmax; ps += TPL) {
+            const int pe = std::min(ps + TPL, nmax);
+            IMCOM_HIP_CHECK(hipMemsetAsync(Wp, 0, (size_t)batch * TPL * ld * 8, st));
             for (int j = ps; j < pe; j++) {
                 hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
                                    n_dev, ld, j, ps, npart, 1);
@@ -614,14 +629,17 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
                                    j, ps, npart);
             }
             IMCOM_TRY(check_launch("trd column step"));
-            if (ps + TP < nmax) {  // trailing two-sided update A[pe:, pe:] -= V W^T + W V^T
-                const int pe2 = ps + TP, rem = ld - pe2;
+            if (ps + TPL < nmax) {  // trailing two-sided update A[pe:, pe:] -= V W^T + W V^T
+                const int pe2 = ps + TPL;
                 hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
                                    n_dev, ld, pe2, ps, npart, 0);
-                const double *Vp = Vall + (long)ps * ld + pe2, *Wq = Wp + pe2;
-                double *C = At + (long)pe2 * ld + pe2;
-                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TP, batch, Vp, ld, (long)ld * ld, Wq, ld, (long)TP * ld, C, ld, (long)ld * ld, -1.0, 1.0));
-                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TP, batch, Wq, ld, (long)TP * ld, Vp, ld, (long)ld * ld, C, ld, (long)ld * ld, -1.0, 1.0));
+                // The GEMM tiles are 128-aligned: start at the tile boundary at or below pe.  The extra rows/columns
+                // it touches are already reduced and only ever read again under a zero multiplier.
+                const int pa = pe2 / NB * NB, rem = ld - pa;
+                const double *Vp = Vall + (long)ps * ld + pa, *Wq = Wp + pa;
+                double *C = At + (long)pa * ld + pa;
+                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TPL, batch, Vp, ld, (long)ld * ld, Wq, ld, (long)TPL * ld, C, ld, (long)ld * ld, -1.0, 1.0));
+                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TPL, batch, Wq, ld, (long)TPL * ld, Vp, ld, (long)ld * ld, C, ld, (long)ld * ld, -1.0, 1.0));
             }
         }
     }
