@@ -335,6 +335,7 @@ int imcom_ctx_create(int device, imcom_ctx **out)
     ctx->device = device;
     ctx->cu_count = prop.multiProcessorCount;
     IMCOM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    IMCOM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return IMCOM_OK;
@@ -349,6 +350,8 @@ int imcom_ctx_destroy(imcom_ctx *ctx)
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->pin) hipHostFree(ctx->pin);
+    for (auto e : ctx->sync_events) hipEventDestroy(e);
+    if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return IMCOM_OK;

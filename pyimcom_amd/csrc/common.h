@@ -60,6 +60,8 @@ struct imcom_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // second queue for work that overlaps the main stream (eigensolver rotations)
+    std::vector<hipEvent_t> sync_events;  // plain (no timing) events for cross-stream ordering
     // bump-allocated device workspace; reset at the start of every API call that uses it
     char *ws = nullptr;
     size_t ws_bytes = 0;

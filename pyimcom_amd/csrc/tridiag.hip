@@ -28,6 +28,7 @@ constexpr int TP = NB;          // reflectors per block reflector when Qh is for
 constexpr int TPL = 64;         // reflectors per tridiagonalisation panel (the V / W corrections read 2 k values per row)
 constexpr int QRS = 16;         // QR sweeps per chunk = depth of the rotation wavefront
 constexpr int ROTPAD = 4 * QRS; // identity margin of the rotation log on both sides
+constexpr int QR_RING = 4;      // rotation logs in flight between the QR chain and the rotation kernels
 
 int launch_eig_sort_scatter(imcom_ctx *ctx, const double *Vt, int ld, const double *lam_raw, const int *n_dev, int *rank,
                             double *lam, long ldlam, double *Q, long ldq, long strideQ, int batch);
@@ -339,24 +340,26 @@ __device__ inline int sturm_count(const double *d, const double *e, int m, doubl
 //     bisection, one per lane) and run PIPELINED, lane sw chasing its bulge QR_LAG positions behind lane sw-1.
 // Rotation k of sweep sw -- [c s; -s c] on rows/columns (k, k+1) -- is logged at cs[(s*QRS + sw)*ldr + ROTPAD + k];
 // everything else in the log is the identity.
-// state[s]: 0 = bottom of the active part (hi), 1 = done, 2/3 = [LO, HI] rows touched by this chunk,
-// 4 = sweeps so far, 5 = tolerance initialised, 6 = HI of the previous chunk.
+// state[s]: 0 = bottom of the active part (hi), 1 = done, 4 = sweeps so far, 5 = tolerance initialised.
+// The log `cs` is one slot of a ring; info[s] = {LO, HI, dirty}: the rows this chunk touches, and the highest
+// position of the slot that may hold a rotation from an earlier chunk (reset to the identity on entry).
 constexpr int QR_SMALL = 3 * QRS;
 constexpr int QR_LAG = 3;
 
 __global__ __launch_bounds__(64) void tql_chunk_kernel(double *__restrict__ dvec, double *__restrict__ evec,
                                                        double2 *__restrict__ cs, int *__restrict__ state,
-                                                       double *__restrict__ tolv, const int *__restrict__ n, int ld, int ldr,
-                                                       int want_rot, int max_sweeps)
+                                                       int *__restrict__ info, double *__restrict__ tolv,
+                                                       const int *__restrict__ n, int ld, int ldr, int want_rot, int max_sweeps)
 {
     extern __shared__ double sm[];
     const int s = blockIdx.x, ns = n[s], lane = threadIdx.x;
-    int *st = state + s * 8;
+    int *st = state + s * 8, *inf = info + s * 3;
     double *d = sm, *e = sm + ld;
-    if (st[1]) {
-        if (lane == 0) { st[2] = 0; st[3] = -1; }
+    if (st[1]) {  // finished earlier: nothing to apply from this slot
+        if (lane == 0) { inf[0] = 0; inf[1] = -1; }
         return;
     }
+    const int fill_hi = inf[2];
     double tmax = 0.0;
     for (int i = lane; i < ns; i += 64) {
         d[i] = dvec[(long)s * ld + i];
@@ -370,7 +373,6 @@ __global__ __launch_bounds__(64) void tql_chunk_kernel(double *__restrict__ dvec
         for (int off = 32; off > 0; off >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, off, 64));
         tol = 2.220446049250313e-16 * tmax;
     } else tol = tolv[s];
-    const int fill_hi = first ? ns - 1 : st[6];
     if (want_rot) {
         for (int sw = 0; sw < QRS; sw++) {
             double2 *row = cs + ((long)s * QRS + sw) * ldr + ROTPAD;
@@ -446,11 +448,11 @@ __global__ __launch_bounds__(64) void tql_chunk_kernel(double *__restrict__ dvec
     __syncthreads();
     if (lane == 0) {
         st[0] = hi;
-        st[2] = LO;
-        st[3] = HI;
         st[4] = total;
         st[5] = 1;
-        st[6] = HI >= 0 ? HI : 0;
+        inf[0] = LO;
+        inf[1] = HI;
+        inf[2] = HI;
         tolv[s] = tol;
         if (hi <= 0) st[1] = 1;
         else if (total >= max_sweeps) st[1] = 2;
@@ -471,13 +473,13 @@ constexpr int ROT_PF = 8;
 
 template <int S>
 __global__ __launch_bounds__(64) void rot_apply_kernel(double *__restrict__ X, const double2 *__restrict__ cs,
-                                                       const int *__restrict__ state, const int *__restrict__ n, int ld, int ldr)
+                                                       const int *__restrict__ info, const int *__restrict__ n, int ld, int ldr)
 {
     constexpr int W = 2 * S;
     static_assert(W % ROT_PF == 0, "window must be a multiple of the prefetch ring");
     __shared__ double2 gl[2][W][S];
     const int s = blockIdx.y, lane = threadIdx.x;
-    const int LO = state[s * 8 + 2], HI = state[s * 8 + 3];
+    const int LO = info[s * 3], HI = info[s * 3 + 1];
     if (HI <= LO) return;
     const int ns = n[s];
     if ((int)blockIdx.x * 64 >= ns) return;
@@ -559,7 +561,8 @@ size_t tridiag_ws_bytes(int batch, int ld, bool vectors)
     add((size_t)batch * 2 * TP * 8);                       // V^T v, W^T v
     add((size_t)batch * 4 * 8);                            // hd
     add((size_t)batch * npart * 8 * 2);                    // pnorm, pdot
-    if (vectors) add((size_t)batch * QRS * ldr * 16);      // rotation log
+    if (vectors) add((size_t)batch * QRS * ldr * 16 * QR_RING);  // rotation logs
+    add((size_t)QR_RING * batch * 3 * 4);                  // per-slot {LO, HI, dirty}
     add((size_t)batch * 8 * 4 + (size_t)batch * 8 + (size_t)batch * 4);  // state, tol, n
     add((size_t)batch * ld * 4);                           // rank
     return t + 8192;
@@ -591,13 +594,14 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
     double *wv = (double *)ws_take(ctx, (size_t)batch * 2 * TP * 8);
     double *hd = (double *)ws_take(ctx, (size_t)batch * 4 * 8);
     double *pnorm = (double *)ws_take(ctx, (size_t)batch * npart * 8), *pdot = (double *)ws_take(ctx, (size_t)batch * npart * 8);
-    double2 *cs = vectors ? (double2 *)ws_take(ctx, (size_t)batch * QRS * ldr * 16) : nullptr;
+    double2 *cs = vectors ? (double2 *)ws_take(ctx, (size_t)batch * QRS * ldr * 16 * QR_RING) : nullptr;
+    int *info = (int *)ws_take(ctx, (size_t)QR_RING * batch * 3 * 4);
     int *state = (int *)ws_take(ctx, (size_t)batch * 8 * 4);
     double *tolv = (double *)ws_take(ctx, (size_t)batch * 8);
     int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
     int *rank = (int *)ws_take(ctx, (size_t)batch * ld * 4);
     if (!At || !Vall || (vectors && (!X || !W1 || !W2 || !Sm || !Tm || !cs)) || !Wp || !part || !ubuf || !pvec || !wprime || !dvec || !evec ||
-        !tauvec || !wv || !hd || !pnorm || !pdot || !state || !tolv || !n_dev || !rank) {
+        !tauvec || !wv || !hd || !pnorm || !pdot || !info || !state || !tolv || !n_dev || !rank) {
         set_error("internal: tridiag workspace");
         return IMCOM_ERR_NOMEM;
     }
@@ -662,42 +666,70 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
         }
     }
 
-    // ---- implicit QR on the tridiagonal, rotations applied chunk by chunk
+    // ---- implicit QR on the tridiagonal (a serial chain of one-wave kernels on the main stream), rotations applied
+    // chunk by chunk on the second stream: the two chains overlap through a ring of QR_RING rotation logs.
     hipLaunchKernelGGL(tql_state_init_kernel, dim3((batch * 8 + 255) / 256), dim3(256), 0, st, state, batch);
     if (vectors) {
-        const long count = (long)batch * QRS * ldr;
+        const long count = (long)batch * QRS * ldr * QR_RING;
         hipLaunchKernelGGL(rot_identity_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, cs, count);
+        IMCOM_HIP_CHECK(hipMemsetAsync(info, 0xff, (size_t)QR_RING * batch * 3 * 4, st));  // {LO, HI, dirty} = -1
     }
     IMCOM_TRY(check_launch("tql init"));
     const size_t qr_lds = (size_t)2 * ld * 8;
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)tql_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qr_lds));
+    while ((int)ctx->sync_events.size() < 2 * QR_RING + 1) {
+        hipEvent_t e;
+        IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_events.push_back(e);
+    }
+    hipEvent_t *ev_qr = ctx->sync_events.data(), *ev_ap = ev_qr + QR_RING, ev_x = ctx->sync_events[2 * QR_RING];
+    hipStream_t sb = ctx->aux_stream;
+    if (vectors) {  // X (Qh^T) is ready when everything queued so far has run
+        IMCOM_HIP_CHECK(hipEventRecord(ev_x, st));
+        IMCOM_HIP_CHECK(hipStreamWaitEvent(sb, ev_x, 0));
+    }
     const int max_sweeps = 30 * std::max(nmax, 1);
     const int max_chunks = max_sweeps / QRS + 2;
     std::vector<int> sth((size_t)batch * 8);
     int chunks = 0;
     bool done = nmax <= 1;
-    while (!done && chunks < max_chunks) {
-        const int group = 16;
-        {
-            ProfScope ps_(ctx, "eigen_qr", group);
-            for (int g = 0; g < group; g++) {
-                hipLaunchKernelGGL(tql_chunk_kernel, dim3(batch), dim3(64), qr_lds, st, dvec, evec, cs, state, tolv, n_dev, ld, ldr,
+    {
+        ProfScope ps_(ctx, "eigen_qr");
+        while (!done && chunks < max_chunks) {
+            const int group = 16;
+            for (int g = 0; g < group; g++, chunks++) {
+                const int slot = chunks % QR_RING;
+                double2 *log = vectors ? cs + (size_t)slot * batch * QRS * ldr : nullptr;
+                int *inf = info + (size_t)slot * batch * 3;
+                if (vectors && chunks >= QR_RING) IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_ap[slot], 0));  // slot free again
+                hipLaunchKernelGGL(tql_chunk_kernel, dim3(batch), dim3(64), qr_lds, st, dvec, evec, log, state, inf, tolv, n_dev, ld, ldr,
                                    vectors ? 1 : 0, max_sweeps);
-                if (vectors)
-                    hipLaunchKernelGGL(rot_apply_kernel<QRS>, dim3((nmax + 63) / 64, batch), dim3(64), 0, st, X, cs, state, n_dev, ld, ldr);
+                if (vectors) {
+                    IMCOM_HIP_CHECK(hipEventRecord(ev_qr[slot], st));
+                    IMCOM_HIP_CHECK(hipStreamWaitEvent(sb, ev_qr[slot], 0));
+                    hipLaunchKernelGGL(rot_apply_kernel<QRS>, dim3((nmax + 63) / 64, batch), dim3(64), 0, sb, X, log, inf, n_dev, ld, ldr);
+                    IMCOM_HIP_CHECK(hipEventRecord(ev_ap[slot], sb));
+                }
             }
             IMCOM_TRY(check_launch("tql chunk"));
+            IMCOM_HIP_CHECK(hipMemcpyAsync(sth.data(), state, sth.size() * 4, hipMemcpyDeviceToHost, st));
+            IMCOM_HIP_CHECK(hipStreamSynchronize(st));
+            done = true;
+            for (int s = 0; s < batch; s++) {
+                if (n_host[s] > 1 && sth[(size_t)s * 8 + 1] == 0) done = false;
+                if (sth[(size_t)s * 8 + 1] == 2) {
+                    hipStreamSynchronize(sb);  // nothing of this call may still be running when the workspace is reused
+                    set_error("tridiagonal QR did not converge for stamp %d", s);
+                    return IMCOM_ERR_NUMERIC;
+                }
+            }
         }
-        chunks += group;
-        IMCOM_HIP_CHECK(hipMemcpyAsync(sth.data(), state, sth.size() * 4, hipMemcpyDeviceToHost, st));
-        IMCOM_HIP_CHECK(hipStreamSynchronize(st));
-        done = true;
-        for (int s = 0; s < batch; s++) {
-            if (n_host[s] > 1 && sth[(size_t)s * 8 + 1] == 0) done = false;
-            if (sth[(size_t)s * 8 + 1] == 2) { set_error("tridiagonal QR did not converge for stamp %d", s); return IMCOM_ERR_NUMERIC; }
+        if (vectors && chunks > 0) {  // join: the main stream continues once the last rotations have been applied
+            IMCOM_HIP_CHECK(hipEventRecord(ev_x, sb));
+            IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_x, 0));
         }
     }
-    if (!done) { set_error("tridiagonal QR did not converge"); return IMCOM_ERR_NUMERIC; }
+    if (!done) { hipStreamSynchronize(sb); set_error("tridiagonal QR did not converge"); return IMCOM_ERR_NUMERIC; }
     if (sweeps_out) {
         int mx = 0;
         for (int s = 0; s < batch; s++) mx = std::max(mx, sth[(size_t)s * 8 + 4]);
