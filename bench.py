@@ -60,6 +60,24 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
     }
 
 
+def pmc_traffic(batch, cfg_name):
+    """HBM bytes per launch of the solve kernels from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this very command, corrected as MI355X_MICROARCH.md prescribes for gfx950; see
+    pyimcom_amd/csrc/tools/pmc_traffic.py).  Counters cannot be read from inside the process, so the figure is only
+    reported when the committed measurement was taken on the same workload and batch; otherwise null."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    doc = json.load(open(files[-1]))
+    if doc.get("batch") != batch or doc.get("workload") != cfg_name:
+        return None
+    ks = [doc["kernels"][k] for k in ("solve_fwd_kernel", "solve_bwd_kernel") if k in doc["kernels"]]
+    n = sum(k["launches"] for k in ks)
+    return sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +177,7 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.batch, cfg.name),
                 "flops_per_launch": solve_flops_step * args.steps / max(launches, 1),
                 "avg_launch_ms": ms / max(launches, 1),
                 "launches": launches,
