@@ -40,7 +40,7 @@ constexpr int SEG_W = 12;  // doubles staged per segment
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),           \
                                      (__attribute__((address_space(3))) void *)(ldsptr), 16, 0, 0)
 
-__global__ __launch_bounds__(256) void build_A_kernel(const int *__restrict__ n, int ldn,
+__global__ __launch_bounds__(256, 3) void build_A_kernel(const int *__restrict__ n, int ldn,
                                                       const double *__restrict__ x,
                                                       const double *__restrict__ y,
                                                       const int *__restrict__ psf,
@@ -65,6 +65,8 @@ __global__ __launch_bounds__(256) void build_A_kernel(const int *__restrict__ n,
     double *As = A + (long)s * ldn * ldn;
     const long base = (long)s * ldn;
     double wx[10], wy[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) wx[k] = wy[k] = 0.0;  // samples without a stencil (off the table, lower triangle) add nothing
     double val = 0.0, pen = 0.0;
     bool active = false;
     long my_seg0 = -1;
@@ -99,61 +101,94 @@ __global__ __launch_bounds__(256) void build_A_kernel(const int *__restrict__ n,
             }
         }
     }
-    const bool rev = my_step < 0;
     seg0[tid] = (int)my_seg0;  // launch_build_A checks that the table stack fits 31 bits
     rstep[tid] = my_step;
-    __syncthreads();
-    // the six (sample, chunk) pairs this thread fetches for every stencil row: work item w = tid + 256 q
-    int fs0[6];
-    int fstep[6], fc[6];
+    // A stencil row is staged as the six 16-byte chunks that cover its 10 taps at either parity.  The element step
+    // between stencil rows (+-ng) is odd, so the parity alternates from row to row: even rows all share the
+    // parity of row 0, odd rows the other one.  The chunks of a sample occupy six consecutive 16-byte LDS slots;
+    // samples 8..15 of every 16 store them rotated by one slot, which makes the 16-byte reads of a group of 16
+    // lanes hit 16 distinct bank groups (stride 96 B alone would pair lane t with t+8).
+    // Per-lane weight tables over the twelve staged doubles, in LDS slot order, for even and for odd rows:
+    const int f = (tid >> 3) & 1, p0 = (int)(my_seg0 & 1);
+    double we[12], wo[12];
+#pragma unroll
+    for (int m = 0; m < 12; m++) {
+        const int el0 = m, el1 = (m + 10) % 12;  // staged element held by slot position m without / with the rotation
+        auto wat = [&](int e) { return (e >= 0 && e < 10) ? wx[e] : 0.0; };
+        const double w_par0 = f ? wat(el1) : wat(el0), w_par1 = f ? wat(el1 - 1) : wat(el0 - 1);
+        we[m] = active ? (p0 ? w_par1 : w_par0) : 0.0;
+        wo[m] = active ? (p0 ? w_par0 : w_par1) : 0.0;
+    }
+    // does any stencil of this tile end within a chunk of the end of the table stack?  (block-uniform; almost never)
+    const long my_last = my_seg0 < 0 ? 0 : (my_step > 0 ? my_seg0 + 9L * my_step : my_seg0) + 12;
+    const int near_end = __syncthreads_or(my_last >= tab_elems);
+    // the six (sample, slot) pairs this thread fetches for every stencil row: work item w = tid + 256 q
+    int ae[6], ao[6], st2[6];  // first element of the chunk for the next even / odd row, and 2 * step
 #pragma unroll
     for (int q = 0; q < 6; q++) {
-        const int w = tid + 256 * q, sm = w / 6;
-        fs0[q] = seg0[sm];
-        fstep[q] = rstep[sm];
-        fc[q] = 2 * (w - sm * 6);
+        const int w = tid + 256 * q, sm = w / 6, slot = w - sm * 6;
+        const int ch = (slot - ((sm >> 3) & 1) + 6) % 6;
+        const int e0 = seg0[sm], stp = rstep[sm];
+        const bool on = e0 >= 0;  // samples without a stencil fetch element 0: harmless, and the fast path stays branch-free
+        ae[q] = on ? (e0 & ~1) + 2 * ch : 0;
+        ao[q] = on ? ((e0 + stp) & ~1) + 2 * ch : 0;
+        st2[q] = on ? 2 * stp : 0;
     }
     const int wave_base = (tid & ~63) * 2;  // this wave's first double in a 256-item slab
-    auto stage = [&](int r, double *buf) {
+    auto stage = [&](int (&at)[6], double *buf) {  // branch-free: every lane issues its six chunk loads
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-            double *dst = buf + 512 * q + wave_base;  // wave-uniform; lane l lands at dst + 2 l
-            if (fs0[q] >= 0) {
-                const long a = ((fs0[q] + (long)r * fstep[q]) & ~1L) + fc[q];
-                if (a + 1 < tab_elems) IMCOM_GLDS16(tables + a, dst);
-                else dst[2 * (tid & 63)] = (a < tab_elems) ? tables[a] : 0.0;  // chunk straddling the end
-            }
+            IMCOM_GLDS16(tables + at[q], buf + 512 * q + wave_base);  // wave-uniform LDS base; lane l lands at +2 l
+            at[q] += st2[q];
         }
     };
-    stage(0, seg[0]);
-    __syncthreads();
-#pragma unroll 1
-    for (int r = 0; r < 10; r++) {
-        if (r + 1 < 10) stage(r + 1, seg[(r + 1) & 1]);
-        if (active) {
-            const long e = my_seg0 + (long)r * my_step;
-            const f64x2 *row = (const f64x2 *)(seg[r & 1] + tid * SEG_W);
-            f64x2 c[6];
+    auto stage_checked = [&](int (&at)[6], double *buf) {  // tiles whose stencils reach the end of the table stack
 #pragma unroll
-            for (int q = 0; q < 6; q++) c[q] = row[q];
-            const bool odd = e & 1;
-            double strip = 0.0;
-            if (rev) {
-#pragma unroll
-                for (int k = 9; k >= 0; k--) {
-                    const int w1 = k + 1;
-                    strip += wx[k] * (odd ? c[w1 >> 1][w1 & 1] : c[k >> 1][k & 1]);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 10; k++) {
-                    const int w1 = k + 1;
-                    strip += wx[k] * (odd ? c[w1 >> 1][w1 & 1] : c[k >> 1][k & 1]);
-                }
-            }
-            val += strip * wy[r];
+        for (int q = 0; q < 6; q++) {
+            double *dst = buf + 512 * q + wave_base;
+            const long a_ = at[q];
+            if (a_ + 1 < tab_elems) IMCOM_GLDS16(tables + a_, dst);
+            else { dst[2 * (tid & 63)] = (a_ < tab_elems) ? tables[a_] : 0.0; dst[2 * (tid & 63) + 1] = 0.0; }
+            at[q] += st2[q];
         }
+    };
+    auto consume = [&](const double *buf, const double (&wt)[12], double wyr) {
+        const f64x2 *row = (const f64x2 *)(buf + tid * SEG_W);
+        f64x2 c[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) c[q] = row[q];
+        double strip = 0.0;
+#pragma unroll
+        for (int m = 0; m < 12; m++) strip += wt[m] * c[m >> 1][m & 1];
+        val += strip * wyr;
+    };
+    if (!near_end) {
+        stage(ae, seg[0]);
         __syncthreads();
+#pragma unroll
+        for (int rp = 0; rp < 5; rp++) {
+            stage(ao, seg[1]);                 // row 2 rp + 1 in flight
+            consume(seg[0], we, wy[2 * rp]);
+            __syncthreads();
+            if (rp < 4) stage(ae, seg[0]);     // row 2 rp + 2 in flight
+            consume(seg[1], wo, wy[2 * rp + 1]);
+            __syncthreads();
+        }
+    } else {
+        stage_checked(ae, seg[0]);
+        __syncthreads();
+#pragma unroll 1
+        for (int rp = 0; rp < 5; rp++) {
+            stage_checked(ao, seg[1]);
+            double wa = 0.0, wb = 0.0;
+#pragma unroll
+            for (int q = 0; q < 5; q++) { wa = rp == q ? wy[2 * q] : wa; wb = rp == q ? wy[2 * q + 1] : wb; }
+            consume(seg[0], we, wa);
+            __syncthreads();
+            if (rp < 4) stage_checked(ae, seg[0]);
+            consume(seg[1], wo, wb);
+            __syncthreads();
+        }
     }
     val += pen;
     if (i >= ns || j >= ns) val = (i == j) ? 1.0 : 0.0;  // identity padding
