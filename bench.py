@@ -184,7 +184,7 @@ def main():
             },
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = cpu_baseline(cfg, stamps[:64], psfs, target, args.cpu_budget)
         print(json.dumps(out))
     if dist is not None:
