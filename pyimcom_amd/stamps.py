@@ -209,6 +209,28 @@ class StampBatch:
                                         _hp(self.info), 1))
             self.Tt.zero_()
             self.Tt[:, :, : self.m] = T.transpose(1, 2)
+        elif cfg.kernel in ("Iterative", "Empirical"):
+            # lakernel.IterKernel / EmpirKernel (lakernel.py:533-805) on device pointers; the output pixel centres
+            # are the integer grid starting at (out_y0, out_x0), the acceptance radius is INPAD in output pixels
+            mB = self.Bt[:, :, : self.m].transpose(1, 2).contiguous()
+            T = torch.empty((self.batch, self.m, self.ldn), dtype=torch.float32, device=self.dev)
+            g = torch.arange(self.n2f, dtype=torch.float64, device=self.dev)
+            oy = (self.out_y0[:, None, None] + g[None, :, None]).expand(self.batch, self.n2f, self.n2f)
+            ox = (self.out_x0[:, None, None] + g[None, None, :]).expand(self.batch, self.n2f, self.n2f)
+            yx = torch.stack([oy.reshape(self.batch, self.m), ox.reshape(self.batch, self.m)], dim=1).contiguous()
+            if cfg.kernel == "Iterative":
+                nv = len(self.kappaC)
+                check(lib.imcom_solve_iter(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, _dp(self.A), _dp(mB),
+                                           _hp(self.Cs), _hp(self.kappaC), nv, float(cfg.uctarget), float(cfg.sigmamax), _dp(yx),
+                                           _dp(self.y), _dp(self.x), float(cfg.rho), float(getattr(cfg, "iter_rtol", 1.5e-3)),
+                                           int(getattr(cfg, "iter_max", 30)), int(nv > 1), _dp(T), _dp(self.UC), _dp(self.Sigma),
+                                           _dp(self.kappa), 1))
+            else:
+                check(lib.imcom_solve_empir(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, _dp(self.A), _dp(mB),
+                                            _hp(self.Cs), float(self.kappaC[0]), _dp(yx), _dp(self.y), _dp(self.x), float(cfg.rho),
+                                            0, _dp(T), _dp(self.UC), _dp(self.Sigma), _dp(self.kappa), 1))
+            self.Tt.zero_()
+            self.Tt[:, :, : self.m] = T.transpose(1, 2)
         elif cfg.kernel != "Cholesky":
             raise NotImplementedError(f"resident path: no {cfg.kernel} kernel")
         else:

@@ -64,3 +64,15 @@ def test_smoke_entry():
     import __graft_entry__ as g
 
     g.smoke()
+
+
+@pytest.mark.parametrize("kernel", ["Iterative", "Empirical"])
+def test_resident_path_secondary_kernels(kernel):
+    """The device-resident stamp path with the Iterative / Empirical LA kernels (lakernel.py:533-805) vs the oracle."""
+    import dataclasses
+
+    from pyimcom_amd import smoke, synth
+
+    cfg = dataclasses.replace(synth.CONFIGS["tiny"], kernel=kernel)
+    rep = smoke.check_batch(cfg, n_stamps=3)
+    assert rep["stamp0"]["T"] < (2e-4 if kernel == "Iterative" else 1e-6)
