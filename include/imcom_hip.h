@@ -253,6 +253,11 @@ int imcom_block_accumulate(imcom_ctx *ctx, int batch, const int *jst_host, const
  * recover_mode=True, pad_widths=(b,t,l,r)) on float32 maps [nmaps][ny][nx]. */
 int imcom_trapezoid_recover_f32(imcom_ctx *ctx, float *maps, long nmaps, int ny, int nx, int fade, int pad_b,
                                 int pad_t, int pad_l, int pad_r);
+/* Block.compress_map coadd.py:2087-2138 (device pointers): out[i] = clip(floor(coef * log10(clip(map[i], 1e-32, inf))
+ * + 0.5), a_min, a_max) in float32 arithmetic, as int16 (is_unsigned = 0) or uint16 (1).  The reference's
+ * coefficients (coadd.py:2249-2303): U/C -5000 uint16, Sigma -10000 int16, kappa -5000 uint16, Tsum 200000 int16,
+ * Neff 50000 uint16. */
+int imcom_compress_map_f32(imcom_ctx *ctx, const float *map, long count, int coef, int is_unsigned, void *out);
 
 /* ---- PSF images -> sample grid, target PSFs --------------------------------------------------------------
  * imcom_sample_psf: PSFGrp._sample_psf psfutil.py:709-795 followed by the circular cut-out / normalisation of

@@ -548,6 +548,12 @@ def block_accumulate(dst, src, j_st, i_st, n2, fade_kernel):
     dst[..., bottom:top, left:right] += src
 
 
+def compress_map(map_, coef, dtype):
+    """Block.compress_map (coadd.py:2087-2138) without the FITS wrapping."""
+    a_min, a_max = (0, 65535) if dtype == np.uint16 else (-32768, 32767)
+    return np.clip(np.floor(coef * np.log10(np.clip(map_, 1e-32, None)) + 0.5), a_min, a_max).astype(dtype)
+
+
 def perform_coaddition(T, indata, expo, n_expo, n2f, n2, fade_kernel):
     """OutStamp._perform_coaddition (coadd.py:1294-1354) for one stamp.
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "imcom_psf_simple_airy": [_vp, _i, _d, _d, _d, _d, _vp, _i],
     "imcom_psf_overlap": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
     "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
+    "imcom_compress_map_f32": [_vp, _vp, _l, _i, _i, _vp],
     "imcom_trapezoid_recover_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i],
 }
 for _name, _args in SIGNATURES.items():

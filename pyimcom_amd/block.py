@@ -56,6 +56,19 @@ class BlockMaps:
         ii = torch.as_tensor(ist.astype(np.int64) - 1, device=self.T_weightmap.device)
         self.T_weightmap[:, jj, ii] = res.Tsum_stamp[:, : self.n_expo].T.to(torch.float32)
 
+    COMPRESS = {"UC": (-5000, True), "Sigma": (-10000, False), "kappa": (-5000, True), "Tsum": (200000, False),
+                "Neff": (50000, True)}  # coefficient, unsigned (coadd.py:2249-2303)
+
+    def compress(self, name, fk=0):
+        """Block.compress_map (coadd.py:2087-2138) of one quality map, cropped by fk on every side as
+        build_output_file does: (u)int16 tensor of coef * log10(map)."""
+        coef, uns = self.COMPRESS[name]
+        m = self.maps[name][:, fk : self.nside - fk, fk : self.nside - fk].contiguous()
+        out = torch.empty(m.shape, dtype=torch.uint16 if uns else torch.int16, device=m.device)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        check(lib.imcom_compress_map_f32(self.ctx.handle, _dp(m), m.numel(), coef, 1 if uns else 0, _dp(out)))
+        return out
+
     def finalize(self, pad_sides="", postage_pad=0):
         """coadd.py:2163-2181: recover the faded block boundary (the padding sides listed in `pad_sides` are
         recovered at the array edge, the others `postage_pad` stamps further in)."""

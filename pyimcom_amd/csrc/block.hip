@@ -100,3 +100,34 @@ extern "C" int imcom_trapezoid_recover_f32(imcom_ctx *ctx, float *maps, long nma
                        pad_b, pad_t, pad_l, pad_r);
     return check_launch("trapezoid_recover_kernel");
 }
+
+// Block.compress_map (reference src/pyimcom/coadd.py:2087-2138): float32 map -> (u)int16 of coef * log10(map),
+//   clip(floor(coef * log10(clip(map, 1e-32, None)) + 0.5), a_min, a_max)
+// evaluated in float32 as numpy evaluates it for a float32 map (the python scalars are weakly typed); log10 is
+// rounded correctly to float32 (computed in double).  NaN inputs map to a_min.
+namespace imcom {
+__global__ void compress_map_kernel(const float *__restrict__ map, long count, float coef, float a_min, float a_max,
+                                    short *__restrict__ out)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float x = fmaxf(map[i], 1e-32f);
+    const float l = (float)log10((double)x);
+    float v = floorf(__fadd_rn(__fmul_rn(coef, l), 0.5f));
+    v = fminf(fmaxf(v, a_min), a_max);
+    if (!(v == v)) v = a_min;
+    const int iv = (int)v;
+    out[i] = (short)(unsigned short)(iv & 0xffff);  // two's complement bits serve both int16 and uint16
+}
+}  // namespace imcom
+
+extern "C" int imcom_compress_map_f32(imcom_ctx *ctx, const float *map, long count, int coef, int is_unsigned, void *out)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
+    IMCOM_REQUIRE(map && out && count >= 0, "bad arguments");
+    if (count == 0) return IMCOM_OK;
+    hipLaunchKernelGGL(compress_map_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, map, count, (float)coef,
+                       is_unsigned ? 0.0f : -32768.0f, is_unsigned ? 65535.0f : 32767.0f, (short *)out);
+    return check_launch("compress_map_kernel");
+}
