@@ -174,6 +174,20 @@ typedef struct {
     double flat_penalty; /* PSFOvl.flat_penalty */
 } imcom_table_geom;
 
+/* ---- pixel partition: the binning loop of InImage.partition_pixels coadd.py:329-358 (device pointers only) ----
+ * The host visits the relevant sparse-grid cells in order and evaluates the WCS (coadd.py:335-336); what it hands
+ * over, in visiting order: out_x, out_y [npix] f64 (position in output-block pixels), in_x, in_y [npix] u16 (index in
+ * the input image), mask [npix] u8 (0 = masked; NULL = none), use_instamps [nst][nst] u8 (blk.use_instamps, nst =
+ * n1P + 2).  A pixel is kept when pix_lower < x, y < pix_upper, unmasked, and its stamp (j_st, i_st) =
+ * floor((pos - pix_lower) / n2) is in use; kept pixels are appended to their stamp in visiting order:
+ * y_idx, x_idx u16 and y_val, x_val f64 [nst][nst][npixmax], pix_count u32 [nst][nst].
+ * IMCOM_ERR_ARG if a stamp would receive more than npixmax pixels (the reference's arrays overflow there). */
+int imcom_partition_pixels(imcom_ctx *ctx, long npix, const double *out_x, const double *out_y,
+                           const unsigned short *in_x, const unsigned short *in_y, const unsigned char *mask,
+                           const unsigned char *use_instamps, int nst, int n2, double pix_lower,
+                           double pix_upper, int npixmax, unsigned short *y_idx, unsigned short *x_idx,
+                           double *y_val, double *x_val, unsigned int *pix_count);
+
 /* ---- input-pixel selection: OutStamp._process_input_stamps coadd.py:886-977 + InStamp.make_selection 716-749 ----
  * The block's InStamps lie back to back in a pool:
  *   pool_x, pool_y [npool] f64 (InStamp.x_val / y_val), pool_data [n_inframe][npool] f32 (InStamp.data),

@@ -589,6 +589,32 @@ def select_pixels(x, y, pivot, radius):
     return sel if sel.shape[0] < x.shape[0] else None
 
 
+def partition_pixels(out_x, out_y, in_x, in_y, mask, use_instamps, n2, n1P, npixmax):
+    """The binning loop of InImage.partition_pixels (coadd.py:329-358), pixels given in visiting order."""
+    nst = n1P + 2
+    pix_lower, pix_upper = -n2 - 0.5, n1P * n2 + n2 - 0.5
+    y_idx = np.zeros((nst, nst, npixmax), dtype=np.uint16)
+    x_idx = np.zeros((nst, nst, npixmax), dtype=np.uint16)
+    y_val = np.zeros((nst, nst, npixmax))
+    x_val = np.zeros((nst, nst, npixmax))
+    pix_count = np.zeros((nst, nst), dtype=np.uint32)
+    for p in range(len(out_x)):
+        my_x, my_y = out_x[p], out_y[p]
+        if not (pix_lower < my_x < pix_upper and pix_lower < my_y < pix_upper):
+            continue
+        if mask is not None and not mask[p]:
+            continue
+        i_st = int((my_x - pix_lower) // n2)
+        j_st = int((my_y - pix_lower) // n2)
+        if not use_instamps[j_st, i_st]:
+            continue
+        k = pix_count[j_st, i_st]
+        y_idx[j_st, i_st, k], x_idx[j_st, i_st, k] = in_y[p], in_x[p]
+        y_val[j_st, i_st, k], x_val[j_st, i_st, k] = my_y, my_x
+        pix_count[j_st, i_st] += 1
+    return y_idx, x_idx, y_val, x_val, pix_count
+
+
 def process_input_stamps(instamps, pivots, radius):
     """OutStamp._process_input_stamps (coadd.py:886-977): concatenate the selections of the nine neighbours.
 

@@ -63,3 +63,48 @@ def select_pixels(pool, inst_id, pivot_x, pivot_y, radius, ldn, ctx=None):
                                   p(pool.inst_off_dev), pool.n_inst, p(iid), p(pvx), p(pvy), float(radius), int(ldn), p(x), p(y),
                                   p(indata), p(expo), p(cumsum), MEM_DEVICE))
     return x, y, indata, expo, cumsum.cpu().numpy()
+
+
+def visiting_order(relevant_matrix, sp_arr):
+    """Input-image indices (y, x) of the pixels InImage.partition_pixels visits, in its order (coadd.py:329-336):
+    relevant sparse-grid cells row-major, pixels row-major inside a cell."""
+    ys, xs = [], []
+    sp_res = relevant_matrix.shape[0]
+    for j_sp in range(sp_res):
+        for i_sp in range(sp_res):
+            if not relevant_matrix[j_sp, i_sp]:
+                continue
+            yy, xx = np.meshgrid(np.arange(sp_arr[j_sp], sp_arr[j_sp + 1]), np.arange(sp_arr[i_sp], sp_arr[i_sp + 1]), indexing="ij")
+            ys.append(yy.ravel())
+            xs.append(xx.ravel())
+    cat = lambda p: np.concatenate(p).astype(np.uint16) if p else np.zeros(0, np.uint16)  # noqa: E731
+    return cat(ys), cat(xs)
+
+
+def partition_pixels(out_x, out_y, in_x, in_y, mask, use_instamps, n2, n1P, npixmax, device="cuda:0", ctx=None):
+    """The binning of ``InImage.partition_pixels`` (coadd.py:329-358) on the device.  Inputs in visiting order (numpy or
+    CUDA tensors); returns y_idx, x_idx (uint16), y_val, x_val (float64) [nst, nst, npixmax] and pix_count (uint32)
+    [nst, nst] as CUDA tensors, nst = n1P + 2."""
+    import torch
+
+    dev = torch.device(device)
+    ctx = ctx if ctx is not None else default_context(dev.index or 0)
+    t = lambda a, dt: (a if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a), device=dev)).to(dt).contiguous()  # noqa: E731
+    ox, oy = t(out_x, torch.float64), t(out_y, torch.float64)
+    ix, iy = t(in_x, torch.uint16), t(in_y, torch.uint16)
+    mk = None if mask is None else t(mask, torch.uint8)
+    nst = n1P + 2
+    use = t(np.asarray(use_instamps).astype(np.uint8) if not torch.is_tensor(use_instamps) else use_instamps, torch.uint8)
+    assert tuple(use.shape) == (nst, nst)
+    npix = ox.numel()
+    y_idx = torch.zeros((nst, nst, npixmax), dtype=torch.uint16, device=dev)
+    x_idx = torch.zeros_like(y_idx)
+    y_val = torch.zeros((nst, nst, npixmax), dtype=torch.float64, device=dev)
+    x_val = torch.zeros_like(y_val)
+    count = torch.zeros((nst, nst), dtype=torch.uint32, device=dev)
+    pix_lower, pix_upper = -n2 - 0.5, n1P * n2 + n2 - 0.5  # coadd.py:208-209 (NsideP = n1P * n2)
+    p = lambda a: None if a is None else C.c_void_p(a.data_ptr())  # noqa: E731
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    check(lib.imcom_partition_pixels(ctx.handle, npix, p(ox), p(oy), p(ix), p(iy), p(mk), p(use), nst, int(n2), pix_lower, pix_upper,
+                                     int(npixmax), p(y_idx), p(x_idx), p(y_val), p(x_val), p(count)))
+    return y_idx, x_idx, y_val, x_val, count

@@ -82,3 +82,32 @@ def test_select_pixels_bit_exact():
 
     with pytest.raises(Exception, match="more than ldn"):
         select_pixels(pool, inst_id, pvx, pvy, radius, 8)
+
+
+def test_partition_pixels_bit_exact():
+    """InImage.partition_pixels binning (coadd.py:329-358): stable partition by stamp, bit-exact vs the oracle loop,
+    incl. pixels exactly on stamp boundaries, masked pixels, unused stamps and pixels outside the block."""
+    from oracle import oracle as orc
+    from pyimcom_amd.select import partition_pixels, visiting_order
+
+    rng = np.random.default_rng(8)
+    n1P, n2, npixmax = 4, 6, 260
+    nst = n1P + 2
+    # a 60 x 60 input image on a sparse grid of 5 x 5 cells, affine map to output pixels (pitch 0.41, rotated)
+    sp_arr = np.linspace(0, 60, 6, dtype=np.uint16)
+    rel = rng.uniform(size=(5, 5)) > 0.2
+    in_y, in_x = visiting_order(rel, sp_arr)
+    th = 0.3
+    ox = -9.0 + 0.41 * (np.cos(th) * in_x - np.sin(th) * in_y) + 6.0
+    oy = -9.0 + 0.41 * (np.sin(th) * in_x + np.cos(th) * in_y)
+    ox[:5] = [-6.5, -0.5, 5.5, 11.5, 29.5]   # exactly on stamp boundaries / the lower limit (strict inequality)
+    oy[:5] = [3.0, -0.5, 5.5, 3.0, 3.0]
+    mask = rng.uniform(size=in_x.size) > 0.1
+    use = rng.uniform(size=(nst, nst)) > 0.15
+    ref = orc.partition_pixels(ox, oy, in_x, in_y, mask, use, n2, n1P, npixmax)
+    got = partition_pixels(ox, oy, in_x, in_y, mask, use, n2, n1P, npixmax)
+    assert ref[4].sum() > 500 and ref[4].max() <= npixmax
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.cpu().numpy(), r)
+    with pytest.raises(Exception, match="more than npixmax"):
+        partition_pixels(ox, oy, in_x, in_y, mask, use, n2, n1P, 5)
