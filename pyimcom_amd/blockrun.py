@@ -1,0 +1,61 @@
+"""One output block end to end on the GPU: the stamp loop of ``Block.coadd_output_stamps`` (reference
+src/pyimcom/coadd.py:2003-2084) with every step device resident --
+
+    InStamp pool -> selection (coadd.py:886-977) -> A, B -> LA kernel -> coaddition -> block maps (1939-2001) -> edge recovery
+
+Scope of this driver: one PSF group for the whole block (uniform PSFs), which is what the synthetic workloads use.
+Stamps whose pixels belong to several 2x2 PSF groups are supported by the C-ABI (per-stamp pair maps of
+``imcom_build_A`` / ``imcom_build_B``) but are not orchestrated here.
+"""
+
+import numpy as np
+
+from .block import BlockMaps
+from .select import select_pixels
+from .stamps import NB, StampBatch
+
+
+def stamp_neighbours(j_st, i_st, n2, nst):
+    """The nine InStamps of OutStamp (j_st, i_st) (coadd.py:853) with the pivots of coadd.py:918-919 (NaN = None)."""
+    left, bottom = (i_st - 1) * n2, (j_st - 1) * n2
+    right, top = left + n2 - 1, bottom + n2 - 1
+    ids, pvx, pvy = np.full(9, -1, np.int32), np.full(9, np.nan), np.full(9, np.nan)
+    for idx, (dj, di) in enumerate((dj, di) for dj in (-1, 0, 1) for di in (-1, 0, 1)):
+        jj, ii = j_st + dj, i_st + di
+        if 0 <= jj < nst and 0 <= ii < nst:
+            ids[idx] = jj * nst + ii
+        xp = [left - 0.5, None, right + 0.5][di + 1]
+        yp = [bottom - 0.5, None, top + 0.5][dj + 1]
+        if xp is not None:
+            pvx[idx] = xp
+        if yp is not None:
+            pvy[idx] = yp
+    return ids, pvx, pvy
+
+
+def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_pad=0, ldn=None):
+    """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
+    order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables.  Returns the BlockMaps."""
+    nst = n1P + 2
+    assert pool.n_inst == nst * nst
+    maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device))
+    todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    counts = np.diff(pool.inst_off)
+    for c0 in range(0, len(todo), batch):
+        chunk = todo[c0 : c0 + batch]
+        nb = [stamp_neighbours(j, i, cfg.n2, nst) for j, i in chunk]
+        ids = np.stack([t[0] for t in nb])
+        # capacity: every pixel of the nine neighbours at most
+        cap = max(int(counts[t[0][t[0] >= 0]].sum()) for t in nb)
+        ld = ldn or max(NB, (cap + NB - 1) // NB * NB)
+        x, y, indata, expo, cumsum = select_pixels(pool, ids, np.stack([t[1] for t in nb]), np.stack([t[2] for t in nb]), cfg.rho, ld,
+                                                   ctx=tables.ctx)
+        n = cumsum[:, 9]
+        keep = (n.max() + NB - 1) // NB * NB if n.max() > 0 else NB  # trim the padding to what the batch needs
+        sb = StampBatch.from_device(cfg, tables, n, x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep],
+                                    [(i - 1) * cfg.n2 - cfg.fade for _, i in chunk], [(j - 1) * cfg.n2 - cfg.fade for j, _ in chunk],
+                                    n_expo, ctx=tables.ctx)
+        res = sb.run()
+        maps.add(res, [j for j, _ in chunk], [i for _, i in chunk])
+    maps.finalize(pad_sides, postage_pad)
+    return maps

@@ -136,28 +136,47 @@ class StampBatch:
     """
 
     def __init__(self, cfg, stamps, tables: PSFGroupTables, ctx=None, device="cuda:0", ldn=None):
-        self.cfg, self.tables = cfg, tables
-        self.ctx = ctx or tables.ctx
-        dev = self.dev = torch.device(device)
-        self.batch = B = len(stamps)
-        self.n = np.array([s.n for s in stamps], dtype=np.int32)
-        self.ldn = ldn or _roundup(max(int(self.n.max()), 1), NB)
-        self.m, self.n2f = cfg.m, cfg.n2f
-        self.ldm = _roundup(self.m, NB)
-        self.n_expo = max(s.n_expo for s in stamps)
-        assert self.n_expo <= tables.n_psf
-        f64, i32, f32 = torch.float64, torch.int32, torch.float32
-        x = np.zeros((B, self.ldn)); y = np.zeros((B, self.ldn))
-        psf = np.zeros((B, self.ldn), np.int32)
-        indata = np.zeros((B, cfg.n_inframe, self.ldn), np.float32)
+        dev = torch.device(device)
+        B = len(stamps)
+        n = np.array([s.n for s in stamps], dtype=np.int32)
+        ldn = ldn or _roundup(max(int(n.max()), 1), NB)
+        x = np.zeros((B, ldn)); y = np.zeros((B, ldn))
+        psf = np.zeros((B, ldn), np.int32)
+        indata = np.zeros((B, cfg.n_inframe, ldn), np.float32)
         for b, s in enumerate(stamps):
             x[b, : s.n], y[b, : s.n], psf[b, : s.n] = s.x, s.y, s.expo
             indata[b, :, : s.n] = s.indata
-        self.x, self.y = torch.as_tensor(x, device=dev), torch.as_tensor(y, device=dev)
-        self.psf = torch.as_tensor(psf, device=dev)
-        self.indata = torch.as_tensor(indata, device=dev)
-        self.out_x0 = torch.as_tensor(np.array([s.out_x0 for s in stamps]), device=dev)
-        self.out_y0 = torch.as_tensor(np.array([s.out_y0 for s in stamps]), device=dev)
+        self._setup(cfg, tables, ctx, dev, n, ldn, max(s.n_expo for s in stamps), torch.as_tensor(x, device=dev),
+                    torch.as_tensor(y, device=dev), torch.as_tensor(psf, device=dev), torch.as_tensor(indata, device=dev),
+                    np.array([s.out_x0 for s in stamps], dtype=np.float64), np.array([s.out_y0 for s in stamps], dtype=np.float64))
+
+    @classmethod
+    def from_device(cls, cfg, tables, n, x, y, expo, indata, out_x0, out_y0, n_expo, ctx=None):
+        """Batch whose pixel lists are already on the GPU (e.g. from pyimcom_amd.select.select_pixels): x, y f64 and
+        expo i32 [B, ldn], indata f32 [B, n_inframe, ldn] with ldn a multiple of 128 and zero padding; n, out_x0,
+        out_y0 host arrays [B]."""
+        self = cls.__new__(cls)
+        ldn = x.shape[1]
+        assert ldn % NB == 0 and tuple(indata.shape) == (x.shape[0], cfg.n_inframe, ldn)
+        self._setup(cfg, tables, ctx, x.device, np.ascontiguousarray(n, dtype=np.int32), ldn, int(n_expo), x.contiguous(), y.contiguous(),
+                    expo.contiguous(), indata.contiguous(), np.ascontiguousarray(out_x0, dtype=np.float64),
+                    np.ascontiguousarray(out_y0, dtype=np.float64))
+        return self
+
+    def _setup(self, cfg, tables, ctx, dev, n, ldn, n_expo, x, y, psf, indata, out_x0, out_y0):
+        self.cfg, self.tables = cfg, tables
+        self.ctx = ctx or tables.ctx
+        self.dev = dev
+        self.batch = B = len(n)
+        self.n, self.ldn = n, ldn
+        self.m, self.n2f = cfg.m, cfg.n2f
+        self.ldm = _roundup(self.m, NB)
+        self.n_expo = n_expo
+        assert self.n_expo <= tables.n_psf
+        f64, f32 = torch.float64, torch.float32
+        self.x, self.y, self.psf, self.indata = x, y, psf, indata
+        self.out_x0 = torch.as_tensor(out_x0, device=dev)
+        self.out_y0 = torch.as_tensor(out_y0, device=dev)
         tab, pen, io = tables.pair_maps(cfg.flat_penalty)
         P = self.npsf = tables.n_psf
         self.pair_tab = torch.as_tensor(np.broadcast_to(tab, (B, P, P)).copy(), device=dev)
