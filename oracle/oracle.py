@@ -507,6 +507,50 @@ def subblock_io(ovl_io, g, x_in, y_in, cnt, out_x, out_y, selection=None):
     return res
 
 
+def stamp_system_groups(instamps, selections, groups, rft_in, rft_out, g, out_x, out_y):
+    """OutStamp._build_system_matrices (coadd.py:1027-1082) with the sub-blocks SysMatA / SysMatB hand out
+    (psfutil.py:1904-2010, 2128-2199): nine InStamps (x_val, y_val, data, pix_cumsum) or None, their selections
+    (index arrays or None = all), the key of the 2x2 PSF group each belongs to, rft_in[key] = that group's PSF
+    transforms.  Sub-blocks between InStamps of one group come from the group's self overlap (_call_ii_self), between
+    groups from PSFOvl(group of the first InStamp, group of the second) (_call_ii_cross).  Returns A [N, N] and
+    -B/2 [m, N] for the first target PSF."""
+    present = [k for k in range(9) if instamps[k] is not None]
+    sels = {k: (np.arange(instamps[k][0].size) if selections[k] is None else np.asarray(selections[k])) for k in present}
+    counts = [sels[k].size if k in sels else 0 for k in range(9)]
+    cum = np.cumsum([0] + counts)
+    A = np.zeros((cum[-1], cum[-1]))
+    tri, cross = {}, {}
+    cnt = {k: np.diff(instamps[k][3]) for k in present}
+    for ia, a in enumerate(present):
+        xa, ya = instamps[a][0], instamps[a][1]
+        ga = groups[a]
+        if ga not in tri:
+            tri[ga] = overlap_self(rft_in[ga], g)
+        sub = subblock_ii_self(tri[ga], rft_in[ga].shape[0], g, xa, ya, cnt[a])
+        A[cum[a] : cum[a + 1], cum[a] : cum[a + 1]] = sub[np.ix_(sels[a], sels[a])]
+        for b in present[ia + 1 :]:
+            xb, yb = instamps[b][0], instamps[b][1]
+            gb = groups[b]
+            if ga == gb:
+                sub = subblock_ii_self(tri[ga], rft_in[ga].shape[0], g, xa, ya, cnt[a], xb, yb, cnt[b])
+            else:
+                if (ga, gb) not in cross:
+                    cross[(ga, gb)] = overlap_cross(rft_in[ga], rft_in[gb], g)
+                sub = subblock_ii_cross(cross[(ga, gb)], g, xa, ya, cnt[a], xb, yb, cnt[b])
+            sub = sub[np.ix_(sels[a], sels[b])]
+            A[cum[a] : cum[a + 1], cum[b] : cum[b + 1]] = sub
+            A[cum[b] : cum[b + 1], cum[a] : cum[a + 1]] = sub.T
+    mB = np.zeros((out_x.size * out_y.size, cum[-1]))
+    io = {}
+    for a in present:
+        ga = groups[a]
+        if ga not in io:
+            io[ga] = overlap_cross(rft_in[ga], rft_out, g)
+        sel = None if selections[a] is None else sels[a]
+        mB[:, cum[a] : cum[a + 1]] = subblock_io(io[ga], g, instamps[a][0], instamps[a][1], cnt[a], out_x, out_y, sel)[0]
+    return A, mB
+
+
 # ------------------------------------------------------------------------------------------------ ST-1..4
 def trapezoid(arr, fade_kernel):
     """OutStamp.trapezoid, default arguments (coadd.py:1222-1282), in place on (..., ny, nx)."""

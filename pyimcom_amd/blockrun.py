@@ -3,16 +3,17 @@ src/pyimcom/coadd.py:2003-2084) with every step device resident --
 
     InStamp pool -> selection (coadd.py:886-977) -> A, B -> LA kernel -> coaddition -> block maps (1939-2001) -> edge recovery
 
-Scope of this driver: one PSF group for the whole block (uniform PSFs), which is what the synthetic workloads use.
-Stamps whose pixels belong to several 2x2 PSF groups are supported by the C-ABI (per-stamp pair maps of
-``imcom_build_A`` / ``imcom_build_B``) but are not orchestrated here.
+``tables`` is either one ``PSFGroupTables`` (uniform PSFs over the block, what the synthetic workloads use) or a
+``BlockTables`` (one PSF group per 2x2 InStamps as in the reference, psfutil.py:1803-1824): then every stamp gets
+its own pair maps -- self tables inside a group, cross tables between the up to four groups its nine InStamps
+belong to -- and the tables are computed on demand into the arena.
 """
 
 import numpy as np
 
 from .block import BlockMaps
 from .select import select_pixels
-from .stamps import NB, StampBatch
+from .stamps import NB, BlockTables, StampBatch
 
 
 def stamp_neighbours(j_st, i_st, n2, nst):
@@ -52,9 +53,24 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_
                                                    ctx=tables.ctx)
         n = cumsum[:, 9]
         keep = (n.max() + NB - 1) // NB * NB if n.max() > 0 else NB  # trim the padding to what the batch needs
+        psf_slot = maps_ = None
+        if isinstance(tables, BlockTables):
+            import torch
+
+            E = tables.E
+            grp = [[(int(k) // nst >> 1, int(k) % nst >> 1) if k >= 0 else None for k in t[0]] for t in nb]
+            local = [list(dict.fromkeys(g for g in gs if g is not None)) for gs in grp]  # distinct groups of each stamp
+            tables.require([k for gs in local for k in BlockTables.keys_for(gs)])
+            per = [tables.stamp_maps(gs, cfg.flat_penalty) for gs in local]
+            maps_ = tuple(np.stack([p[q] for p in per]) for q in range(3))
+            # stamp-local PSF index of every pixel: (position of its InStamp's group in the stamp's list) * E + exposure
+            lg = np.array([[gs.index(g) if g is not None else 0 for g in row] for row, gs in zip(grp, local)], dtype=np.int64)
+            cs = torch.as_tensor(cumsum[:, 1:10].astype(np.int64), device=x.device)
+            seg = torch.searchsorted(cs, torch.arange(keep, device=x.device).expand(len(chunk), keep).contiguous(), right=True).clamp_(max=8)
+            psf_slot = (torch.as_tensor(lg, device=x.device).gather(1, seg) * E + expo[:, :keep].long()).to(torch.int32)
         sb = StampBatch.from_device(cfg, tables, n, x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep],
                                     [(i - 1) * cfg.n2 - cfg.fade for _, i in chunk], [(j - 1) * cfg.n2 - cfg.fade for j, _ in chunk],
-                                    n_expo, ctx=tables.ctx)
+                                    n_expo, ctx=tables.ctx, psf_slot=psf_slot, maps=maps_)
         res = sb.run()
         maps.add(res, [j for j, _ in chunk], [i for _, i in chunk])
     maps.finalize(pad_sides, postage_pad)

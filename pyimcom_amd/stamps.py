@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
-from ._lib import PAIR_FLIP, TableGeom, check, default_context, lib
+from ._lib import PAIR_SWAP,  PAIR_FLIP, TableGeom, check, default_context, lib
 
 NB = 128
 
@@ -109,6 +109,101 @@ class PSFGroupTables:
         return tab, pen, io
 
 
+class BlockTables:
+    """Overlap tables of a block whose PSFs vary from one 2x2 group of InStamps to the next (the reference's
+    PSFGrp per InStamp pair of even indices, SysMatA.ji_st2psf psfutil.py:1803-1824).
+
+    ``group_psfs``: {(gj, gi): array [E, nsamp, nsamp]} sampled input PSFs of every group (all E exposures in every
+    group, local index = exposure index); group (gj, gi) serves the InStamps (2gj..2gj+1, 2gi..2gi+1).  Tables live
+    in one device arena and are computed on demand: a group's self overlap (triangle order) and input-output
+    overlap, and the cross overlap of two groups (all E x E pairs, stored for the ordered key g_lo < g_hi).  When
+    the arena is full it is simply restarted -- stamps are visited group by group, so recomputation is rare."""
+
+    def __init__(self, group_psfs, psf_out, nfft, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0"):
+        self.ctx = ctx or default_context()
+        dev = self.dev = torch.device(device)
+        self.psf = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64), device=dev) for k, v in group_psfs.items()}
+        first = next(iter(self.psf.values()))
+        self.E, self.nsamp, self.nfft = first.shape[0], first.shape[1], nfft
+        self.n_psf = self.E
+        self.pout = torch.as_tensor(np.ascontiguousarray(psf_out[:1], dtype=np.float64), device=dev)
+        amp = None if amp_penalty is None or 0.0 in tuple(amp_penalty) else np.array(amp_penalty, dtype=np.float64)
+        self._amp = amp
+        ng = self.nsamp + 12
+        self.tables = torch.empty((capacity, ng, ng), dtype=torch.float64, device=dev)  # the arena
+        self.index, self.used = {}, 0
+        cc = torch.empty((1, ng, ng), dtype=torch.float64, device=dev)
+        self._overlap(self.pout, self.pout, [(0, 0)], cc)
+        nc = self.nsamp // 2
+        self.C = float(cc[0, 6 + nc, 6 + nc].item())
+
+    def _overlap(self, p1, p2, pairs, out):
+        pairs = np.array(pairs, dtype=np.int32)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(p1), p1.shape[0], _dp(p2), p2.shape[0], self.nsamp, self.nfft, _hp(pairs),
+                                    len(pairs), None if self._amp is None else _hp(self._amp), _dp(out)))
+
+    def _count(self, key):
+        E = self.E
+        return {"self": E * (E + 1) // 2, "io": E, "cross": E * E}[key[0]]
+
+    def require(self, keys):
+        """Make sure the table sets `keys` are in the arena; returns {key: first table index}."""
+        keys = list(dict.fromkeys(keys))
+        need = sum(self._count(k) for k in keys if k not in self.index)
+        if self.used + need > self.tables.shape[0]:
+            self.index, self.used = {}, 0
+            need = sum(self._count(k) for k in keys)
+            if need > self.tables.shape[0]:
+                raise ValueError(f"table arena of {self.tables.shape[0]} tables cannot hold the {need} of one batch")
+        E = self.E
+        for k in keys:
+            if k in self.index:
+                continue
+            cnt, off = self._count(k), self.used
+            out = self.tables[off : off + cnt]
+            if k[0] == "self":
+                self._overlap(self.psf[k[1]], self.psf[k[1]], [(i, j) for i in range(E) for j in range(i, E)], out)
+            elif k[0] == "io":
+                self._overlap(self.psf[k[1]], self.pout, [(i, 0) for i in range(E)], out)
+            else:
+                self._overlap(self.psf[k[1]], self.psf[k[2]], [(i, j) for i in range(E) for j in range(E)], out)
+            self.index[k] = off
+            self.used += cnt
+        return {k: self.index[k] for k in keys}
+
+    @staticmethod
+    def keys_for(groups):
+        """Table sets a stamp touching `groups` (distinct group keys) needs."""
+        gs = sorted(set(groups))
+        return ([("self", g) for g in gs] + [("io", g) for g in gs] + [("cross", a, b) for i, a in enumerate(gs) for b in gs[i + 1 :]])
+
+    def stamp_maps(self, groups, flat_penalty, slots=4):
+        """pair_tab / pair_pen / io_tab of one stamp whose pixels belong to `groups` (list of <= `slots` distinct group
+        keys; the stamp-local PSF index of a pixel is position_in_list * E + exposure).  Call require() first."""
+        E, P = self.E, slots * self.E
+        tab = np.full((P, P), -1, np.int32)
+        pen = np.zeros((P, P))
+        io = np.zeros(P, np.int32)
+        tri = lambda i, j: (2 * E - i + 1) * i // 2 + j - i  # noqa: E731  (psfutil.py:1175)
+        for la, ga in enumerate(groups):
+            io[la * E : (la + 1) * E] = self.index[("io", ga)] + np.arange(E)
+            for lb, gb in enumerate(groups):
+                for ea in range(E):
+                    for eb in range(E):
+                        a, b = la * E + ea, lb * E + eb
+                        if ga == gb:
+                            base = self.index[("self", ga)]
+                            tab[a, b] = base + tri(ea, eb) if ea <= eb else (base + tri(eb, ea)) | PAIR_FLIP
+                        elif ga < gb:
+                            tab[a, b] = self.index[("cross", ga, gb)] + ea * E + eb
+                        else:  # evaluated from the other group's side (psfutil.py:1990-1996)
+                            tab[a, b] = (self.index[("cross", gb, ga)] + eb * E + ea) | PAIR_SWAP
+                        if flat_penalty != 0.0:  # psfutil.py:1482-1486, 1705-1708 (sqrt(E E) = E for equal group sizes)
+                            pen[a, b] = -flat_penalty / E + (flat_penalty if ea == eb else 0.0)
+        return tab, pen, io
+
+
 @dataclass
 class StampBatchResult:
     Tt: torch.Tensor          # [batch, ldn, ldm] float32, input-pixel-major T (tapered when fade > 0)
@@ -151,19 +246,21 @@ class StampBatch:
                     np.array([s.out_x0 for s in stamps], dtype=np.float64), np.array([s.out_y0 for s in stamps], dtype=np.float64))
 
     @classmethod
-    def from_device(cls, cfg, tables, n, x, y, expo, indata, out_x0, out_y0, n_expo, ctx=None):
+    def from_device(cls, cfg, tables, n, x, y, expo, indata, out_x0, out_y0, n_expo, ctx=None, psf_slot=None, maps=None):
         """Batch whose pixel lists are already on the GPU (e.g. from pyimcom_amd.select.select_pixels): x, y f64 and
         expo i32 [B, ldn], indata f32 [B, n_inframe, ldn] with ldn a multiple of 128 and zero padding; n, out_x0,
-        out_y0 host arrays [B]."""
+        out_y0 host arrays [B].  Stamps whose pixels belong to several PSF groups pass ``psf_slot`` (i32 [B, ldn],
+        stamp-local PSF index of each pixel) and ``maps`` = (pair_tab [B,P,P] i32, pair_pen [B,P,P] f64, io_tab [B,P] i32)
+        as documented at imcom_build_A / imcom_build_B; ``tables`` then only needs .tables, .nsamp, .C, .ctx."""
         self = cls.__new__(cls)
         ldn = x.shape[1]
         assert ldn % NB == 0 and tuple(indata.shape) == (x.shape[0], cfg.n_inframe, ldn)
         self._setup(cfg, tables, ctx, x.device, np.ascontiguousarray(n, dtype=np.int32), ldn, int(n_expo), x.contiguous(), y.contiguous(),
                     expo.contiguous(), indata.contiguous(), np.ascontiguousarray(out_x0, dtype=np.float64),
-                    np.ascontiguousarray(out_y0, dtype=np.float64))
+                    np.ascontiguousarray(out_y0, dtype=np.float64), psf_slot=psf_slot, maps=maps)
         return self
 
-    def _setup(self, cfg, tables, ctx, dev, n, ldn, n_expo, x, y, psf, indata, out_x0, out_y0):
+    def _setup(self, cfg, tables, ctx, dev, n, ldn, n_expo, x, y, expo, indata, out_x0, out_y0, psf_slot=None, maps=None):
         self.cfg, self.tables = cfg, tables
         self.ctx = ctx or tables.ctx
         self.dev = dev
@@ -172,16 +269,27 @@ class StampBatch:
         self.m, self.n2f = cfg.m, cfg.n2f
         self.ldm = _roundup(self.m, NB)
         self.n_expo = n_expo
-        assert self.n_expo <= tables.n_psf
         f64, f32 = torch.float64, torch.float32
-        self.x, self.y, self.psf, self.indata = x, y, psf, indata
+        # expo: exposure (input image) of each pixel, what the coaddition sums over; psf: stamp-local PSF index, what
+        # selects the overlap tables.  One PSF group: the two coincide.
+        self.x, self.y, self.expo, self.indata = x, y, expo, indata
+        self.psf = expo if psf_slot is None else psf_slot.contiguous()
         self.out_x0 = torch.as_tensor(out_x0, device=dev)
         self.out_y0 = torch.as_tensor(out_y0, device=dev)
-        tab, pen, io = tables.pair_maps(cfg.flat_penalty)
-        P = self.npsf = tables.n_psf
-        self.pair_tab = torch.as_tensor(np.broadcast_to(tab, (B, P, P)).copy(), device=dev)
-        self.pair_pen = torch.as_tensor(np.broadcast_to(pen, (B, P, P)).copy(), device=dev)
-        self.io_tab = torch.as_tensor(np.broadcast_to(io, (B, P)).copy(), device=dev)
+        if maps is None:
+            assert self.n_expo <= tables.n_psf
+            tab, pen, io = tables.pair_maps(cfg.flat_penalty)
+            P = self.npsf = tables.n_psf
+            self.pair_tab = torch.as_tensor(np.broadcast_to(tab, (B, P, P)).copy(), device=dev)
+            self.pair_pen = torch.as_tensor(np.broadcast_to(pen, (B, P, P)).copy(), device=dev)
+            self.io_tab = torch.as_tensor(np.broadcast_to(io, (B, P)).copy(), device=dev)
+        else:
+            tab, pen, io = maps
+            P = self.npsf = tab.shape[-1]
+            assert tab.shape == (B, P, P) and pen.shape == (B, P, P) and io.shape == (B, P)
+            self.pair_tab = torch.as_tensor(np.ascontiguousarray(tab, dtype=np.int32), device=dev)
+            self.pair_pen = torch.as_tensor(np.ascontiguousarray(pen, dtype=np.float64), device=dev)
+            self.io_tab = torch.as_tensor(np.ascontiguousarray(io, dtype=np.int32), device=dev)
         self.geom = TableGeom(tables.nsamp, float(tables.nsamp // 2), float(cfg.dscale), float(cfg.flat_penalty))
         self.Cs = np.full((B,), tables.C, dtype=np.float64)
         self.kappaC = np.ascontiguousarray(cfg.kappaC, dtype=np.float64)
@@ -266,7 +374,7 @@ class StampBatch:
         self._stream()
         cfg = self.cfg
         check(lib.imcom_coadd_epilogue(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, self.n2f,
-                                       cfg.fade, cfg.n2, _dp(self.Tt), _dp(self.indata), cfg.n_inframe, _dp(self.psf),
+                                       cfg.fade, cfg.n2, _dp(self.Tt), _dp(self.indata), cfg.n_inframe, _dp(self.expo),
                                        self.n_expo, _dp(self.outimage), _dp(self.Tsum_stamp), _dp(self.Tsum_inpix),
                                        _dp(self.Neff)))
 

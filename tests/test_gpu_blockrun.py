@@ -87,3 +87,80 @@ def test_block_end_to_end_vs_oracle():
     for name in ref:
         a, b = maps.maps[name].cpu().numpy(), ref[name]
         assert np.allclose(a, b, rtol=2e-5, atol=1e-6 * np.abs(b).max()), (name, np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_block_with_psf_groups_vs_oracle():
+    """PSFs that differ between the 2x2 groups of InStamps: per-stamp pair maps, cross-group tables, table arena.
+    The oracle assembles A and B the reference's way -- sub-block by sub-block from PSFOvl(group, group') through
+    _call_ii_self / _call_ii_cross / _call_io_cross (functions pinned by the reference's goldens), an independent
+    route from the device's per-pixel pair codes."""
+    import torch
+
+    from oracle import oracle as orc
+    from pyimcom_amd import smoke, synth
+    from pyimcom_amd.blockrun import coadd_block, stamp_neighbours
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import BlockTables
+
+    cfg = synth.CONFIGS["tiny"]
+    n1P, n_expo = 2, 3
+    nst = n1P + 2
+    rng = np.random.default_rng(33)
+    inst = _instamps(cfg, n1P, n_expo, rng)
+    base, target = synth.make_psfs(cfg, n_expo)
+    ns = base.shape[-1]
+    lin = np.arange(ns) - ns // 2
+    group_psfs = {}
+    for gj in range(nst // 2):
+        for gi in range(nst // 2):  # a different smooth modulation per group (kept positive, renormalised)
+            mod = 1.0 + 0.08 * (gj + 1) * np.cos(0.21 * lin)[None, :, None] * 0 + 0.06 * (gi + 1) * np.sin(0.17 * lin)[None, None, :]
+            mod = mod + 0.05 * (gj + 1) * np.cos(0.13 * lin)[None, :, None]
+            p = base * mod
+            group_psfs[(gj, gi)] = p / p.sum(axis=(1, 2), keepdims=True)
+    tabs = BlockTables(group_psfs, target, cfg.nfft, capacity=96)  # small arena: forces a restart along the way
+    pool = InStampPool(inst, cfg.n_inframe)
+    maps = coadd_block(cfg, pool, tabs, n1P, n_expo, batch=2)
+    torch.cuda.synchronize()
+
+    geo = orc.Geom(cfg.npixpsf, cfg.oversamp, cfg.dtheta_as / 3600.0, cfg.flat_penalty)
+    rft_in = {k: orc.pad_and_rfft2(v, geo) for k, v in group_psfs.items()}
+    rft_out = orc.pad_and_rfft2(target, geo)
+    C = float(orc.overlap_out_C(rft_out, geo)[0])
+    nsd = maps.nside
+    ref = {k: np.zeros((1, nsd, nsd), np.float32) for k in ("UC", "Sigma", "kappa", "Tsum", "Neff")}
+    ref_out = np.zeros((1, cfg.n_inframe, nsd, nsd), np.float32)
+    g1 = np.arange(cfg.n2f, dtype=np.float64)
+    for j in range(1, n1P + 1):
+        for i in range(1, n1P + 1):
+            ids, pvx, pvy = stamp_neighbours(j, i, cfg.n2, nst)
+            piv = [(None if np.isnan(a) else a, None if np.isnan(b) else b) for a, b in zip(pvx, pvy)]
+            nine = [inst[k] if k >= 0 else None for k in ids]
+            sels = [None if t is None else orc.select_pixels(t[0], t[1], pv, cfg.rho) for t, pv in zip(nine, piv)]
+            groups = [None if k < 0 else (int(k) // nst >> 1, int(k) % nst >> 1) for k in ids]
+            x, y, indata, expo, cum = orc.process_input_stamps(nine, piv, cfg.rho)
+            ox, oy = (i - 1) * cfg.n2 - cfg.fade + g1, (j - 1) * cfg.n2 - cfg.fade + g1
+            A, mB = orc.stamp_system_groups(nine, sels, groups, rft_in, rft_out, geo, ox, oy)
+            T, UC, Sg, kp, _ = orc.chol_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
+            s2 = (cfg.n2f, cfg.n2f)
+            UC, Sg, kp = UC.reshape(s2).copy(), Sg.reshape(s2).copy(), kp.reshape(s2).copy()
+            for a in (kp, Sg, UC):
+                orc.trapezoid(a, cfg.fade)
+            T3 = T[None].copy()
+            outimage, _, Tin, Neff = orc.perform_coaddition(T3, indata, expo, n_expo, cfg.n2f, cfg.n2, cfg.fade)
+            orc.block_accumulate(ref_out, outimage, j, i, cfg.n2, cfg.fade)
+            for name, v in (("UC", UC), ("Sigma", Sg), ("kappa", kp), ("Tsum", Tin[0]), ("Neff", Neff[0])):
+                orc.block_accumulate(ref[name], np.asarray(v, dtype=np.float32)[None], j, i, cfg.n2, cfg.fade)
+    orc.trapezoid_recover(ref_out, cfg.fade)
+    for name in ref:
+        orc.trapezoid_recover(ref[name], cfg.fade)
+    assert abs(tabs.C - C) <= 1e-12 * C
+    got = maps.out_map.cpu().numpy()
+    assert np.abs(got - ref_out[0]).max() <= 5e-5 * np.abs(ref_out[0]).max()
+    for name in ref:
+        a, b = maps.maps[name].cpu().numpy(), ref[name]
+        assert np.allclose(a, b, rtol=5e-5, atol=2e-6 * np.abs(b).max()), (name, np.abs(a - b).max(), np.abs(b).max())
+    # the groups matter: the same block with one PSF group for all stamps is far outside these tolerances
+    from pyimcom_amd.stamps import PSFGroupTables
+
+    uni = coadd_block(cfg, pool, PSFGroupTables(group_psfs[(0, 0)], target, cfg.nfft), n1P, n_expo, batch=4)
+    assert np.abs(uni.out_map.cpu().numpy() - ref_out[0]).max() > 1e-3 * np.abs(ref_out[0]).max()
