@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="stamps per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="rehearsal of the multi-rank path on a box with ONE GPU: every rank uses cuda:0 and the ranks "
+                         "rendezvous over gloo (not a measurement)")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,13 +100,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.rehearse_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.rehearse_shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     from pyimcom_amd import synth
     from pyimcom_amd._lib import Context
@@ -139,7 +147,7 @@ def main():
                                             "finalize", "epilogue")}
     ctx.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_shared_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
