@@ -201,3 +201,46 @@ def test_iter_empir_batch_vs_oracle(nv):
             assert np.allclose(T2[s, fin, :n], Tr[fin], rtol=2e-7, atol=0)
             assert np.array_equal(np.isnan(T2[s, :, :n]).any(axis=1), ~fin)
             assert np.allclose(Sg2[s][fin], Sr[fin], rtol=1e-6) and np.allclose(UC2[s][fin], UCr[fin], rtol=1e-5, atol=2e-7)
+
+
+def test_iter_kernel_reference_known_answers():
+    """The reference's own tests/pyimcom/test_la.py:163-230 (test_iter2): cosine system, two kappa nodes, geometry
+    with four output pixels sitting on input pixels; its range assertions, on the HIP kernel."""
+    from pyimcom_amd.lakernel import HipIterKernel
+
+    N = 6
+    A = np.zeros((N, N))
+    d = 2 * np.pi * (np.arange(N)[:, None] - np.arange(N)[None, :]) / N
+    for k in range(1, N // 2 + 1):
+        A += np.cos(k * d) / k / N
+    mBhalf = np.zeros((1, 16, N))
+    for i in range(N):
+        for j in range(16):
+            _d = 2 * np.pi * (i - 0.4 * j) / N
+            for k in range(1, N // 2 + 1):
+                mBhalf[0, j, i] += np.cos(k * _d) / k / N
+    cfg = _Obj()
+    cfg.n2f, cfg.n_out = 4, 1
+    cfg.kappaC_arr = np.array([1e-3, 1e-2])
+    cfg.uctarget, cfg.sigmamax = 1e-4, 1.0
+    cfg.instamp_pad = 2.0 * (np.pi / 180.0 / 3600.0)
+    cfg.dtheta = 0.11 / 3600.0
+    cfg.iter_rtol, cfg.iter_max = 1e-2, 8
+    blk = _Obj()
+    blk.cfg = cfg
+    o = _Obj()
+    o.blk = blk
+    o.inpix_cumsum = np.array([N])
+    o.sysmata, o.mhalfb, o.outovlc = A, mBhalf, np.array([A[0, 0]])
+    o.yx_val = [np.linspace(0, 6, 16), np.zeros(16)]
+    o.iny_val, o.inx_val = np.zeros(N), np.linspace(0, N - 1, N)
+    HipIterKernel(o)()
+    assert np.all(o.UC >= 0)
+    for j in range(16):
+        if j % 5 == 0:
+            assert o.UC.ravel()[j] < 1.0e-4
+            assert 2e-3 < o.kappa.ravel()[j] < 4e-3
+        else:
+            assert 0.05 < o.UC.ravel()[j] < 0.2
+            assert 2e-4 < o.kappa.ravel()[j] < 4e-4
+        assert 0.6 < o.Sigma.ravel()[j] < 1.0

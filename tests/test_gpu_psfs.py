@@ -89,3 +89,18 @@ def test_amp_penalty_tables_golden(golden):
     assert abs(tabs.C - g["amp_outovlc"][0]) <= 1e-12 * tabs.C
     plain = PSFGroupTables(mk("GAUSSIAN", 1.2), mk("AIRYOBSC", 0.9), 2 * (ns + 1))
     assert abs(plain.C - tabs.C) > 0.05 * tabs.C  # the weighting really changes the numbers
+
+
+def test_airy_known_answers_of_the_reference():
+    """tests/pyimcom/test_psf.py:20-60 (centre value, sum, FWHM-free part) and 71-82 (output PSF peak ratios)."""
+    from pyimcom_amd import psfs
+
+    im = psfs.psf_simple_airy(100, 4.0)
+    assert abs(im[50, 50] - 0.045421877940855226) < 0.001 and abs(im.sum() - 0.9853733474017817) < 0.001
+    im = psfs.psf_simple_airy(100, 4.0, obsc=0.5)
+    assert abs(im[50, 50] - 0.03339794632862726) < 0.001 and abs(im.sum() - 0.970256598273068) < 0.001
+    ns, ov = 25 * 4 - 1, 4
+    mg = psfs.get_outpsf("GAUSSIAN", 0.3, 2, ns, ov).max()
+    mau = psfs.get_outpsf("AIRYUNOBSC", 0.3, 2, ns, ov).max()
+    mao = psfs.get_outpsf("AIRYOBSC", 0.3, 2, ns, ov).max()
+    assert 0.2 < mau / mg < 0.3 and 0.8 < mao / mau < 0.9
