@@ -327,3 +327,28 @@ def test_chol_repair_multi_kappa_vs_oracle(orc):
     assert info[0] == 1
     assert np.abs(T[0] - To).max() <= 1e-4 * np.abs(To).max()  # the repaired node is singular to ~1e-16: cond ~ 1e12 there
     assert np.allclose(UC[0], Uo, rtol=1e-3, atol=1e-6) and np.allclose(Sg[0], So, rtol=1e-3, atol=1e-6)
+
+
+def test_croutines_shim_is_importable_as_top_level_module(golden):
+    """The injection seam of the reference (lakernel.py:41-47, psfutil.py:37-49; tests/pyimcom/test_missing.py): with
+    furry_parakeet absent, a top-level module named `pyimcom_croutines` on sys.path is picked up unchanged."""
+    import importlib
+    import os
+    import sys
+
+    import pyimcom_amd
+
+    shim_dir = os.path.join(os.path.dirname(pyimcom_amd.__file__), "shim")
+    sys.path.insert(0, shim_dir)
+    try:
+        sys.modules.pop("pyimcom_croutines", None)
+        mod = importlib.import_module("pyimcom_croutines")
+        for name in ("iD5512C", "iD5512C_sym", "gridD5512C", "lakernel1", "build_reduced_T_wrap"):
+            assert callable(getattr(mod, name))
+        g = golden("interp")
+        out = np.full_like(g["f_scatter"], -7.0)  # the golden keeps -7 where the point is off the grid (output untouched)
+        mod.iD5512C(g["infunc"], g["x"], g["y"], out)
+        assert np.abs(out - g["f_scatter"]).max() < TOL_INTERP
+    finally:
+        sys.path.remove(shim_dir)
+        sys.modules.pop("pyimcom_croutines", None)
