@@ -450,8 +450,12 @@ def subblock_ii_self(ovl_tri, n_psf, g, x1, y1, cnt1, x2=None, y2=None, cnt2=Non
     return res
 
 
-def subblock_ii_cross(ovl, g, x1, y1, cnt1, x2, y2, cnt2):
-    """PSFOvl._call_ii_cross (psfutil.py:1401-1495); ovl [n1, n2, nsamp, nsamp]."""
+def subblock_ii_cross(ovl, g, x1, y1, cnt1, x2, y2, cnt2, ids1=None, ids2=None):
+    """PSFOvl._call_ii_cross (psfutil.py:1401-1495); ovl [n1, n2, nsamp, nsamp].  cnt1 / cnt2: pixels per PSF of
+    each group; ids1 / ids2: the block exposure index of each of those PSFs (idx_grp2blk; default: identical
+    numbering), which is what the same-exposure term of the flat penalty compares (lines 1483-1486)."""
+    ids1 = np.arange(len(cnt1)) if ids1 is None else np.asarray(ids1)
+    ids2 = np.arange(len(cnt2)) if ids2 is None else np.asarray(ids2)
     cs1 = np.concatenate([[0], np.cumsum(cnt1)]).astype(int)
     cs2 = np.concatenate([[0], np.cumsum(cnt2)]).astype(int)
     res = np.zeros((cs1[-1], cs2[-1]))
@@ -475,7 +479,7 @@ def subblock_ii_cross(ovl, g, x1, y1, cnt1, x2, y2, cnt2):
             res[sl] = out.reshape((int(cnt1[j]), int(cnt2[i])))
             if g.flat_penalty != 0.0:
                 res[sl] -= g.flat_penalty / n_in
-                if j == i:
+                if ids1[j] == ids2[i]:
                     res[sl] += g.flat_penalty
     return res
 
@@ -507,20 +511,24 @@ def subblock_io(ovl_io, g, x_in, y_in, cnt, out_x, out_y, selection=None):
     return res
 
 
-def stamp_system_groups(instamps, selections, groups, rft_in, rft_out, g, out_x, out_y):
+def stamp_system_groups(instamps, selections, groups, rft_in, rft_out, g, out_x, out_y, group_expo=None):
     """OutStamp._build_system_matrices (coadd.py:1027-1082) with the sub-blocks SysMatA / SysMatB hand out
     (psfutil.py:1904-2010, 2128-2199): nine InStamps (x_val, y_val, data, pix_cumsum) or None, their selections
     (index arrays or None = all), the key of the 2x2 PSF group each belongs to, rft_in[key] = that group's PSF
     transforms.  Sub-blocks between InStamps of one group come from the group's self overlap (_call_ii_self), between
-    groups from PSFOvl(group of the first InStamp, group of the second) (_call_ii_cross).  Returns A [N, N] and
-    -B/2 [m, N] for the first target PSF."""
+    groups from PSFOvl(group of the first InStamp, group of the second) (_call_ii_cross).  group_expo[key] lists the
+    block exposures the group holds PSFs for (idx_grp2blk, psfutil.py:820-832; default all): InStamps of the group
+    have no pixels from other exposures.  Returns A [N, N] and -B/2 [m, N] for the first target PSF."""
     present = [k for k in range(9) if instamps[k] is not None]
     sels = {k: (np.arange(instamps[k][0].size) if selections[k] is None else np.asarray(selections[k])) for k in present}
     counts = [sels[k].size if k in sels else 0 for k in range(9)]
     cum = np.cumsum([0] + counts)
     A = np.zeros((cum[-1], cum[-1]))
     tri, cross = {}, {}
-    cnt = {k: np.diff(instamps[k][3]) for k in present}
+    ge = (lambda k: np.arange(rft_in[k].shape[0])) if group_expo is None else (lambda k: np.asarray(group_expo[k]))
+    cnt = {k: np.diff(instamps[k][3])[ge(groups[k])] for k in present}  # per PSF of the InStamp's group
+    for k in present:
+        assert cnt[k].sum() == instamps[k][0].size, "an InStamp has pixels from an exposure its PSF group lacks"
     for ia, a in enumerate(present):
         xa, ya = instamps[a][0], instamps[a][1]
         ga = groups[a]
@@ -536,7 +544,7 @@ def stamp_system_groups(instamps, selections, groups, rft_in, rft_out, g, out_x,
             else:
                 if (ga, gb) not in cross:
                     cross[(ga, gb)] = overlap_cross(rft_in[ga], rft_in[gb], g)
-                sub = subblock_ii_cross(cross[(ga, gb)], g, xa, ya, cnt[a], xb, yb, cnt[b])
+                sub = subblock_ii_cross(cross[(ga, gb)], g, xa, ya, cnt[a], xb, yb, cnt[b], ge(ga), ge(gb))
             sub = sub[np.ix_(sels[a], sels[b])]
             A[cum[a] : cum[a + 1], cum[b] : cum[b + 1]] = sub
             A[cum[b] : cum[b + 1], cum[a] : cum[a + 1]] = sub.T

@@ -57,17 +57,22 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_
         if isinstance(tables, BlockTables):
             import torch
 
-            E = tables.E
             grp = [[(int(k) // nst >> 1, int(k) % nst >> 1) if k >= 0 else None for k in t[0]] for t in nb]
             local = [list(dict.fromkeys(g for g in gs if g is not None)) for gs in grp]  # distinct groups of each stamp
             tables.require([k for gs in local for k in BlockTables.keys_for(gs)])
             per = [tables.stamp_maps(gs, cfg.flat_penalty) for gs in local]
             maps_ = tuple(np.stack([p[q] for p in per]) for q in range(3))
-            # stamp-local PSF index of every pixel: (position of its InStamp's group in the stamp's list) * E + exposure
+            # stamp-local PSF index of every pixel: lut[position of its InStamp's group in the stamp's list, exposure]
+            lut = torch.as_tensor(np.stack([p[3] for p in per]).astype(np.int64), device=x.device)  # [B, 4, n_blk_expo]
             lg = np.array([[gs.index(g) if g is not None else 0 for g in row] for row, gs in zip(grp, local)], dtype=np.int64)
             cs = torch.as_tensor(cumsum[:, 1:10].astype(np.int64), device=x.device)
             seg = torch.searchsorted(cs, torch.arange(keep, device=x.device).expand(len(chunk), keep).contiguous(), right=True).clamp_(max=8)
-            psf_slot = (torch.as_tensor(lg, device=x.device).gather(1, seg) * E + expo[:, :keep].long()).to(torch.int32)
+            lgp = torch.as_tensor(lg, device=x.device).gather(1, seg)  # group position of every pixel
+            flat = lut.reshape(len(chunk), -1).gather(1, lgp * lut.shape[2] + expo[:, :keep].long())
+            valid = torch.arange(keep, device=x.device)[None, :] < torch.as_tensor(n.astype(np.int64), device=x.device)[:, None]
+            if bool(((flat < 0) & valid).any()):
+                raise ValueError("a pixel belongs to an exposure its PSF group holds no PSF for (BlockTables.group_expo)")
+            psf_slot = flat.clamp_(min=0).to(torch.int32)
         sb = StampBatch.from_device(cfg, tables, n, x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep],
                                     [(i - 1) * cfg.n2 - cfg.fade for _, i in chunk], [(j - 1) * cfg.n2 - cfg.fade for j, _ in chunk],
                                     n_expo, ctx=tables.ctx, psf_slot=psf_slot, maps=maps_)

@@ -113,19 +113,25 @@ class BlockTables:
     """Overlap tables of a block whose PSFs vary from one 2x2 group of InStamps to the next (the reference's
     PSFGrp per InStamp pair of even indices, SysMatA.ji_st2psf psfutil.py:1803-1824).
 
-    ``group_psfs``: {(gj, gi): array [E, nsamp, nsamp]} sampled input PSFs of every group (all E exposures in every
-    group, local index = exposure index); group (gj, gi) serves the InStamps (2gj..2gj+1, 2gi..2gi+1).  Tables live
-    in one device arena and are computed on demand: a group's self overlap (triangle order) and input-output
-    overlap, and the cross overlap of two groups (all E x E pairs, stored for the ordered key g_lo < g_hi).  When
-    the arena is full it is simply restarted -- stamps are visited group by group, so recomputation is rare."""
+    ``group_psfs``: {(gj, gi): array [n_g, nsamp, nsamp]} sampled input PSFs of every group; group (gj, gi) serves
+    the InStamps (2gj..2gj+1, 2gi..2gi+1).  ``group_expo``: {(gj, gi): block exposure index of each of those PSFs}
+    (PSFGrp.idx_grp2blk, psfutil.py:820-832: the reference keeps only exposures with pixels in the group; default
+    0..n_g-1).  Tables live in one device arena and are computed on demand: a group's self overlap (triangle order)
+    and input-output overlap, and the cross overlap of two groups (all n_g1 x n_g2 pairs, stored for the ordered key
+    g_lo < g_hi).  When the arena is full it is simply restarted -- stamps are visited group by group, so
+    recomputation is rare."""
 
-    def __init__(self, group_psfs, psf_out, nfft, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0"):
+    def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0"):
         self.ctx = ctx or default_context()
         dev = self.dev = torch.device(device)
         self.psf = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64), device=dev) for k, v in group_psfs.items()}
+        self.expo = {k: (list(range(v.shape[0])) if group_expo is None else [int(e) for e in group_expo[k]]) for k, v in self.psf.items()}
+        assert all(len(self.expo[k]) == v.shape[0] for k, v in self.psf.items())
         first = next(iter(self.psf.values()))
-        self.E, self.nsamp, self.nfft = first.shape[0], first.shape[1], nfft
-        self.n_psf = self.E
+        self.nsamp, self.nfft = first.shape[1], nfft
+        self.n_max = max(v.shape[0] for v in self.psf.values())
+        self.n_psf = self.n_max
+        self.n_blk_expo = 1 + max(max(v) for v in self.expo.values())
         self.pout = torch.as_tensor(np.ascontiguousarray(psf_out[:1], dtype=np.float64), device=dev)
         amp = None if amp_penalty is None or 0.0 in tuple(amp_penalty) else np.array(amp_penalty, dtype=np.float64)
         self._amp = amp
@@ -143,9 +149,15 @@ class BlockTables:
         check(lib.imcom_psf_overlap(self.ctx.handle, _dp(p1), p1.shape[0], _dp(p2), p2.shape[0], self.nsamp, self.nfft, _hp(pairs),
                                     len(pairs), None if self._amp is None else _hp(self._amp), _dp(out)))
 
+    def _n(self, g):
+        return self.psf[g].shape[0]
+
     def _count(self, key):
-        E = self.E
-        return {"self": E * (E + 1) // 2, "io": E, "cross": E * E}[key[0]]
+        if key[0] == "self":
+            return self._n(key[1]) * (self._n(key[1]) + 1) // 2
+        if key[0] == "io":
+            return self._n(key[1])
+        return self._n(key[1]) * self._n(key[2])
 
     def require(self, keys):
         """Make sure the table sets `keys` are in the arena; returns {key: first table index}."""
@@ -156,18 +168,18 @@ class BlockTables:
             need = sum(self._count(k) for k in keys)
             if need > self.tables.shape[0]:
                 raise ValueError(f"table arena of {self.tables.shape[0]} tables cannot hold the {need} of one batch")
-        E = self.E
         for k in keys:
             if k in self.index:
                 continue
             cnt, off = self._count(k), self.used
             out = self.tables[off : off + cnt]
             if k[0] == "self":
-                self._overlap(self.psf[k[1]], self.psf[k[1]], [(i, j) for i in range(E) for j in range(i, E)], out)
+                n = self._n(k[1])
+                self._overlap(self.psf[k[1]], self.psf[k[1]], [(i, j) for i in range(n) for j in range(i, n)], out)
             elif k[0] == "io":
-                self._overlap(self.psf[k[1]], self.pout, [(i, 0) for i in range(E)], out)
+                self._overlap(self.psf[k[1]], self.pout, [(i, 0) for i in range(self._n(k[1]))], out)
             else:
-                self._overlap(self.psf[k[1]], self.psf[k[2]], [(i, j) for i in range(E) for j in range(E)], out)
+                self._overlap(self.psf[k[1]], self.psf[k[2]], [(i, j) for i in range(self._n(k[1])) for j in range(self._n(k[2]))], out)
             self.index[k] = off
             self.used += cnt
         return {k: self.index[k] for k in keys}
@@ -179,29 +191,38 @@ class BlockTables:
         return ([("self", g) for g in gs] + [("io", g) for g in gs] + [("cross", a, b) for i, a in enumerate(gs) for b in gs[i + 1 :]])
 
     def stamp_maps(self, groups, flat_penalty, slots=4):
-        """pair_tab / pair_pen / io_tab of one stamp whose pixels belong to `groups` (list of <= `slots` distinct group
-        keys; the stamp-local PSF index of a pixel is position_in_list * E + exposure).  Call require() first."""
-        E, P = self.E, slots * self.E
+        """Maps of one stamp whose pixels belong to `groups` (list of <= `slots` distinct group keys): pair_tab
+        [P, P], pair_pen [P, P], io_tab [P] with P = slots * n_max, and lut [slots, n_blk_expo] = stamp-local PSF
+        index of a pixel of (position of its group in the list, block exposure), -1 where the group lacks the
+        exposure.  Call require() first."""
+        P = slots * self.n_max
         tab = np.full((P, P), -1, np.int32)
         pen = np.zeros((P, P))
         io = np.zeros(P, np.int32)
-        tri = lambda i, j: (2 * E - i + 1) * i // 2 + j - i  # noqa: E731  (psfutil.py:1175)
+        lut = np.full((slots, self.n_blk_expo), -1, np.int32)
+        base = np.concatenate([[0], np.cumsum([self._n(g) for g in groups])]).astype(int)
         for la, ga in enumerate(groups):
-            io[la * E : (la + 1) * E] = self.index[("io", ga)] + np.arange(E)
+            for k, e in enumerate(self.expo[ga]):
+                lut[la, e] = base[la] + k
+            na = self._n(ga)
+            io[base[la] : base[la] + na] = self.index[("io", ga)] + np.arange(na)
             for lb, gb in enumerate(groups):
-                for ea in range(E):
-                    for eb in range(E):
-                        a, b = la * E + ea, lb * E + eb
+                nb = self._n(gb)
+                tri = lambda i, j: (2 * na - i + 1) * i // 2 + j - i  # noqa: E731  (psfutil.py:1175), same group only
+                for ka in range(na):
+                    for kb in range(nb):
+                        a, b = base[la] + ka, base[lb] + kb
                         if ga == gb:
-                            base = self.index[("self", ga)]
-                            tab[a, b] = base + tri(ea, eb) if ea <= eb else (base + tri(eb, ea)) | PAIR_FLIP
+                            off = self.index[("self", ga)]
+                            tab[a, b] = off + tri(ka, kb) if ka <= kb else (off + tri(kb, ka)) | PAIR_FLIP
                         elif ga < gb:
-                            tab[a, b] = self.index[("cross", ga, gb)] + ea * E + eb
+                            tab[a, b] = self.index[("cross", ga, gb)] + ka * nb + kb
                         else:  # evaluated from the other group's side (psfutil.py:1990-1996)
-                            tab[a, b] = (self.index[("cross", gb, ga)] + eb * E + ea) | PAIR_SWAP
-                        if flat_penalty != 0.0:  # psfutil.py:1482-1486, 1705-1708 (sqrt(E E) = E for equal group sizes)
-                            pen[a, b] = -flat_penalty / E + (flat_penalty if ea == eb else 0.0)
-        return tab, pen, io
+                            tab[a, b] = (self.index[("cross", gb, ga)] + kb * na + ka) | PAIR_SWAP
+                        if flat_penalty != 0.0:  # psfutil.py:1433, 1482-1486, 1705-1708
+                            same = self.expo[ga][ka] == self.expo[gb][kb]
+                            pen[a, b] = -flat_penalty / (na * nb) ** 0.5 + (flat_penalty if same else 0.0)
+        return tab, pen, io, lut
 
 
 @dataclass

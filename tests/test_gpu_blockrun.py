@@ -117,7 +117,17 @@ def test_block_with_psf_groups_vs_oracle():
             mod = mod + 0.05 * (gj + 1) * np.cos(0.13 * lin)[None, :, None]
             p = base * mod
             group_psfs[(gj, gi)] = p / p.sum(axis=(1, 2), keepdims=True)
-    tabs = BlockTables(group_psfs, target, cfg.nfft, capacity=96)  # small arena: forces a restart along the way
+    # group (0, 1) holds PSFs for exposures 0 and 2 only (the reference drops exposures without pixels in the group,
+    # psfutil.py:812-832): its four InStamps lose their exposure-1 pixels
+    group_expo = {k: [0, 1, 2] for k in group_psfs}
+    group_expo[(0, 1)] = [0, 2]
+    group_psfs[(0, 1)] = group_psfs[(0, 1)][[0, 2]]
+    for jj in (0, 1):
+        for ii in (2, 3):
+            xs, ys, dat, cum = inst[jj * nst + ii]
+            keep = np.r_[0 : cum[1], cum[2] : cum[3]]
+            inst[jj * nst + ii] = (xs[keep], ys[keep], dat[:, keep], np.array([0, cum[1], cum[1], cum[1] + cum[3] - cum[2]]))
+    tabs = BlockTables(group_psfs, target, cfg.nfft, group_expo=group_expo, capacity=96)  # small arena: forces a restart
     pool = InStampPool(inst, cfg.n_inframe)
     maps = coadd_block(cfg, pool, tabs, n1P, n_expo, batch=2)
     torch.cuda.synchronize()
@@ -139,7 +149,7 @@ def test_block_with_psf_groups_vs_oracle():
             groups = [None if k < 0 else (int(k) // nst >> 1, int(k) % nst >> 1) for k in ids]
             x, y, indata, expo, cum = orc.process_input_stamps(nine, piv, cfg.rho)
             ox, oy = (i - 1) * cfg.n2 - cfg.fade + g1, (j - 1) * cfg.n2 - cfg.fade + g1
-            A, mB = orc.stamp_system_groups(nine, sels, groups, rft_in, rft_out, geo, ox, oy)
+            A, mB = orc.stamp_system_groups(nine, sels, groups, rft_in, rft_out, geo, ox, oy, group_expo)
             T, UC, Sg, kp, _ = orc.chol_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
             s2 = (cfg.n2f, cfg.n2f)
             UC, Sg, kp = UC.reshape(s2).copy(), Sg.reshape(s2).copy(), kp.reshape(s2).copy()
@@ -162,5 +172,5 @@ def test_block_with_psf_groups_vs_oracle():
     # the groups matter: the same block with one PSF group for all stamps is far outside these tolerances
     from pyimcom_amd.stamps import PSFGroupTables
 
-    uni = coadd_block(cfg, pool, PSFGroupTables(group_psfs[(0, 0)], target, cfg.nfft), n1P, n_expo, batch=4)
+    uni = coadd_block(cfg, pool, PSFGroupTables(group_psfs[(0, 0)], target, cfg.nfft), n1P, n_expo, batch=4)  # 3 PSFs for all
     assert np.abs(uni.out_map.cpu().numpy() - ref_out[0]).max() > 1e-3 * np.abs(ref_out[0]).max()
