@@ -343,23 +343,26 @@ __device__ inline int sturm_count(const double *d, const double *e, int m, doubl
 // state[s]: 0 = bottom of the active part (hi), 1 = done, 4 = sweeps so far, 5 = tolerance initialised.
 // The log `cs` is one slot of a ring; info[s] = {LO, HI, dirty}: the rows this chunk touches, and the highest
 // position of the slot that may hold a rotation from an earlier chunk (reset to the identity on entry).
-constexpr int QR_SMALL = 3 * QRS;
+constexpr int QRG = 2;             // rotation logs (groups of QRS sweeps) filled by one launch: QRG * QRS bulges in flight
+constexpr int QRW = QRG * QRS;     // sweeps per launch
+constexpr int QR_SMALL = 3 * QRW;
 constexpr int QR_LAG = 3;
 
 __global__ __launch_bounds__(64) void tql_chunk_kernel(double *__restrict__ dvec, double *__restrict__ evec,
-                                                       double2 *__restrict__ cs, int *__restrict__ state,
-                                                       int *__restrict__ info, double *__restrict__ tolv,
+                                                       double2 *__restrict__ cs, long slot_stride, int *__restrict__ state,
+                                                       int *__restrict__ info, long info_stride, double *__restrict__ tolv,
                                                        const int *__restrict__ n, int ld, int ldr, int want_rot, int max_sweeps)
 {
     extern __shared__ double sm[];
     const int s = blockIdx.x, ns = n[s], lane = threadIdx.x;
-    int *st = state + s * 8, *inf = info + s * 3;
+    int *st = state + s * 8;
     double *d = sm, *e = sm + ld;
-    if (st[1]) {  // finished earlier: nothing to apply from this slot
-        if (lane == 0) { inf[0] = 0; inf[1] = -1; }
+    auto inf = [&](int g) { return info + g * info_stride + s * 3; };
+    auto logrow = [&](int sw) { return cs + (sw / QRS) * slot_stride + ((long)s * QRS + sw % QRS) * ldr + ROTPAD; };
+    if (st[1]) {  // finished earlier: nothing to apply from these slots
+        if (lane < QRG) { inf(lane)[0] = 0; inf(lane)[1] = -1; }
         return;
     }
-    const int fill_hi = inf[2];
     double tmax = 0.0;
     for (int i = lane; i < ns; i += 64) {
         d[i] = dvec[(long)s * ld + i];
@@ -374,16 +377,20 @@ __global__ __launch_bounds__(64) void tql_chunk_kernel(double *__restrict__ dvec
         tol = 2.220446049250313e-16 * tmax;
     } else tol = tolv[s];
     if (want_rot) {
-        for (int sw = 0; sw < QRS; sw++) {
-            double2 *row = cs + ((long)s * QRS + sw) * ldr + ROTPAD;
+        for (int sw = 0; sw < QRW; sw++) {
+            const int fill_hi = inf(sw / QRS)[2];
+            double2 *row = logrow(sw);
             for (int i = lane; i <= fill_hi; i += 64) row[i] = make_double2(1.0, 0.0);
         }
     }
     __syncthreads();
     // every lane follows the same control flow (uniform values, LDS broadcast reads); lane 0 stores
     int hi = first ? ns - 1 : st[0];
-    int LO = ns, HI = -1, sw = 0, total = first ? 0 : st[4];
-    while (hi > 0 && sw < QRS) {
+    int LO[QRG], HI[QRG];
+#pragma unroll
+    for (int g = 0; g < QRG; g++) { LO[g] = ns; HI[g] = -1; }
+    int sw = 0, total = first ? 0 : st[4];
+    while (hi > 0 && sw < QRW) {
         if (fabs(e[hi - 1]) <= tol) {
             __syncthreads();
             if (lane == 0) e[hi - 1] = 0.0;
@@ -398,50 +405,53 @@ __global__ __launch_bounds__(64) void tql_chunk_kernel(double *__restrict__ dvec
                 const double dd = 0.5 * (d[hi - 1] - d[hi]), b = e[hi - 1];
                 const double mu = d[hi] - b * b / (dd + copysign(sqrt(dd * dd + b * b), dd));
                 QrCarry q{d[lo] - mu, e[lo], d[lo], e[lo]};
-                double2 *row = cs + ((long)s * QRS + sw) * ldr + ROTPAD;
+                double2 *row = logrow(sw);
                 for (int k = lo; k < hi; k++) {
                     const double2 g = qr_step(d, e, lo, hi, k, q);
                     if (want_rot) row[k] = g;
                 }
             }
+#pragma unroll
+            for (int g = 0; g < QRG; g++)
+                if (sw / QRS == g) { LO[g] = min(LO[g], lo); HI[g] = max(HI[g], hi); }
             sw++;
             total++;
         } else {
-            if (sw > 0) break;  // a large block starts its own chunk (all QRS slots)
-            // shifts: eigenvalue `lane` of the trailing QRS x QRS block, by bisection
+            if (sw > 0) break;  // a large block starts its own launch (all QRW sweeps)
+            // shifts: eigenvalue `lane` of the trailing QRW x QRW block, by bisection
             double mu = 0.0;
-            if (lane < QRS) {
-                const double *db = d + hi - QRS + 1, *eb = e + hi - QRS + 1;
+            if (lane < QRW) {
+                const double *db = d + hi - QRW + 1, *eb = e + hi - QRW + 1;
                 double gl = 1e300, gu = -1e300;
-                for (int i = 0; i < QRS; i++) {
-                    const double rad = (i > 0 ? fabs(eb[i - 1]) : 0.0) + (i < QRS - 1 ? fabs(eb[i]) : 0.0);
+                for (int i = 0; i < QRW; i++) {
+                    const double rad = (i > 0 ? fabs(eb[i - 1]) : 0.0) + (i < QRW - 1 ? fabs(eb[i]) : 0.0);
                     gl = fmin(gl, db[i] - rad);
                     gu = fmax(gu, db[i] + rad);
                 }
                 for (int it = 0; it < 56; it++) {
                     const double mid = 0.5 * (gl + gu);
-                    if (sturm_count(db, eb, QRS, mid) > lane) gu = mid; else gl = mid;
+                    if (sturm_count(db, eb, QRW, mid) > lane) gu = mid; else gl = mid;
                 }
                 mu = 0.5 * (gl + gu);
             }
             __syncthreads();
             QrCarry q{0.0, 0.0, 0.0, 0.0};
-            double2 *row = cs + ((long)s * QRS + lane) * ldr + ROTPAD;
-            const int nst = (hi - lo) + QR_LAG * (QRS - 1);
+            double2 *row = logrow(lane < QRW ? lane : 0);
+            const int nst = (hi - lo) + QR_LAG * (QRW - 1);
             for (int t = 0; t < nst; t++) {
                 const int k = lo + t - QR_LAG * lane;
-                if (lane < QRS && k >= lo && k < hi) {
+                if (lane < QRW && k >= lo && k < hi) {
                     if (k == lo) q = QrCarry{d[lo] - mu, e[lo], d[lo], e[lo]};
                     const double2 g = qr_step(d, e, lo, hi, k, q);
                     if (want_rot) row[k] = g;
                 }
             }
-            sw = QRS;
-            total += QRS;
+#pragma unroll
+            for (int g = 0; g < QRG; g++) { LO[g] = lo; HI[g] = hi; }
+            sw = QRW;
+            total += QRW;
         }
         __syncthreads();
-        LO = min(LO, lo);
-        HI = max(HI, hi);
     }
     // trailing deflations so that `done` is seen as early as possible
     while (hi > 0 && fabs(e[hi - 1]) <= tol) hi--;
@@ -450,9 +460,8 @@ __global__ __launch_bounds__(64) void tql_chunk_kernel(double *__restrict__ dvec
         st[0] = hi;
         st[4] = total;
         st[5] = 1;
-        inf[0] = LO;
-        inf[1] = HI;
-        inf[2] = HI;
+#pragma unroll
+        for (int g = 0; g < QRG; g++) { inf(g)[0] = LO[g]; inf(g)[1] = HI[g]; inf(g)[2] = HI[g]; }
         tolv[s] = tol;
         if (hi <= 0) st[1] = 1;
         else if (total >= max_sweeps) st[1] = 2;
@@ -476,6 +485,7 @@ __global__ __launch_bounds__(64) void rot_apply_kernel(double *__restrict__ X, c
                                                        const int *__restrict__ info, const int *__restrict__ n, int ld, int ldr)
 {
     constexpr int W = 2 * S;
+    static_assert(QR_RING % QRG == 0, "ring must hold whole launches");
     static_assert(W % ROT_PF == 0, "window must be a multiple of the prefetch ring");
     __shared__ double2 gl[2][W][S];
     const int s = blockIdx.y, lane = threadIdx.x;
@@ -507,6 +517,13 @@ __global__ __launch_bounds__(64) void rot_apply_kernel(double *__restrict__ X, c
     for (int q = 0; q < ROT_PF; q++) ring[q] = x0[(long)min(q + 1, R) * ld];
     stage(0, 0);
     int buf = 0;
+    // The S coefficients of a step are consumed in two halves; the half after the current one is read from LDS while
+    // the current one is being applied (software pipeline through the fully unrolled body, across the loop edge
+    // too: the first half of the next group of steps lives in the other LDS buffer, staged a group ahead).
+    constexpr int H = S / 2;
+    double2 gc[H], gn[H];
+#pragma unroll
+    for (int q = 0; q < H; q++) gc[q] = gl[0][0][q];
     for (int t0 = 0; t0 < nsteps; t0 += W, buf ^= 1) {
         stage(buf ^ 1, min(t0 + W, nsteps));  // past the end: identity margin of the log
 #pragma unroll
@@ -515,14 +532,23 @@ __global__ __launch_bounds__(64) void rot_apply_kernel(double *__restrict__ X, c
             w[(u + 1) % W] = ring[u % ROT_PF];  // row t+1
             ring[u % ROT_PF] = x0[(long)min(t + 1 + ROT_PF, R) * ld];
 #pragma unroll
-            for (int sw = 0; sw < S; sw++) {
-                const double2 g = gl[buf][u][sw];
-                const int a = ((u - 2 * sw) % W + W) % W, b = (a + 1) % W;
-                const double xa = w[a], xb = w[b];
-                w[a] = g.x * xa + g.y * xb;
-                w[b] = g.x * xb - g.y * xa;
-                // keep the unrolled rotations in groups of 8: hoisting the LDS reads of later ones spills registers
-                if (sw % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+            for (int h = 0; h < 2; h++) {
+                // next half: second half of this step, or the first half of the next step (next group: other buffer)
+#pragma unroll
+                for (int q = 0; q < H; q++)
+                    gn[q] = h == 0 ? gl[buf][u][H + q] : (u + 1 < W ? gl[buf][u + 1][q] : gl[buf ^ 1][0][q]);
+#pragma unroll
+                for (int q = 0; q < H; q++) {
+                    const int sw = h * H + q;
+                    const double2 g = gc[q];
+                    const int a = ((u - 2 * sw) % W + W) % W, b = (a + 1) % W;
+                    const double xa = w[a], xb = w[b];
+                    w[a] = g.x * xa + g.y * xb;
+                    w[b] = g.x * xb - g.y * xa;
+                }
+#pragma unroll
+                for (int q = 0; q < H; q++) gc[q] = gn[q];
+                __builtin_amdgcn_sched_barrier(0);  // keep the halves apart: hoisting more LDS reads spills registers
             }
             const int rs = t - 2 * S + 2;
             const int row = rs > R ? sinkrow : max(rs, 0);
@@ -689,7 +715,7 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
         IMCOM_HIP_CHECK(hipStreamWaitEvent(sb, ev_x, 0));
     }
     const int max_sweeps = 30 * std::max(nmax, 1);
-    const int max_chunks = max_sweeps / QRS + 2;
+    const int max_chunks = max_sweeps / QRW + 2;
     std::vector<int> sth((size_t)batch * 8);
     int chunks = 0;
     bool done = nmax <= 1;
@@ -698,17 +724,22 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
         while (!done && chunks < max_chunks) {
             const int group = 16;
             for (int g = 0; g < group; g++, chunks++) {
-                const int slot = chunks % QR_RING;
-                double2 *log = vectors ? cs + (size_t)slot * batch * QRS * ldr : nullptr;
-                int *inf = info + (size_t)slot * batch * 3;
-                if (vectors && chunks >= QR_RING) IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_ap[slot], 0));  // slot free again
-                hipLaunchKernelGGL(tql_chunk_kernel, dim3(batch), dim3(64), qr_lds, st, dvec, evec, log, state, inf, tolv, n_dev, ld, ldr,
-                                   vectors ? 1 : 0, max_sweeps);
+                const int slot0 = (chunks * QRG) % QR_RING;  // QRG consecutive slots per launch
+                const long slot_stride = (long)batch * QRS * ldr, info_stride = (long)batch * 3;
+                double2 *log = vectors ? cs + (size_t)slot0 * slot_stride : nullptr;
+                int *inf = info + (size_t)slot0 * info_stride;
+                if (vectors && chunks * QRG >= QR_RING)
+                    for (int q = 0; q < QRG; q++) IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_ap[slot0 + q], 0));  // slots free again
+                hipLaunchKernelGGL(tql_chunk_kernel, dim3(batch), dim3(64), qr_lds, st, dvec, evec, log, slot_stride, state, inf, info_stride,
+                                   tolv, n_dev, ld, ldr, vectors ? 1 : 0, max_sweeps);
                 if (vectors) {
-                    IMCOM_HIP_CHECK(hipEventRecord(ev_qr[slot], st));
-                    IMCOM_HIP_CHECK(hipStreamWaitEvent(sb, ev_qr[slot], 0));
-                    hipLaunchKernelGGL(rot_apply_kernel<QRS>, dim3((nmax + 63) / 64, batch), dim3(64), 0, sb, X, log, inf, n_dev, ld, ldr);
-                    IMCOM_HIP_CHECK(hipEventRecord(ev_ap[slot], sb));
+                    IMCOM_HIP_CHECK(hipEventRecord(ev_qr[slot0], st));
+                    IMCOM_HIP_CHECK(hipStreamWaitEvent(sb, ev_qr[slot0], 0));
+                    for (int q = 0; q < QRG; q++) {
+                        hipLaunchKernelGGL(rot_apply_kernel<QRS>, dim3((nmax + 63) / 64, batch), dim3(64), 0, sb, X, log + q * slot_stride,
+                                           inf + q * info_stride, n_dev, ld, ldr);
+                        IMCOM_HIP_CHECK(hipEventRecord(ev_ap[slot0 + q], sb));
+                    }
                 }
             }
             IMCOM_TRY(check_launch("tql chunk"));
