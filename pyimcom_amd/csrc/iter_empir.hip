@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void empir_maps_kernel(const double *__restric
     e = block_sum4(e, red);
     if (threadIdx.x == 0) {
         const long pa = (long)s * m + a;
+        if (ns == 0) { UC[pa] = 1.0f; Sigma[pa] = 0.0f; kappa[pa] = 1.0f; return; }  // lakernel.py:110-119
         kappa[pa] = (float)kap[s];
         Sigma[pa] = (float)nn;
         UC[pa] = (float)(1.0 + (e - 2.0 * d) / Cs[s]);
@@ -264,6 +265,16 @@ __global__ __launch_bounds__(256) void iter_reduce_kernel(const float *__restric
         }
     }
     if (threadIdx.x != 0) return;
+    if (ns == 0) {  // a stamp without input pixels inside a batch: lakernel.py:110-119
+        UC[pa] = 1.0f; Sigma[pa] = 0.0f; kappa[pa] = 1.0f;
+        if (nv > 1) {  // neutral node data: the reduced-space search of this pixel is overwritten by the combine kernel
+            for (int p = 0; p < nv; p++) {
+                Df[pa * nv + p] = 0.0;
+                for (int q = 0; q < nv; q++) { Nf[(pa * nv + p) * nv + q] = 0.0; Ef[(pa * nv + p) * nv + q] = 0.0; }
+            }
+        }
+        return;
+    }
     if (nv == 1) {
         const double k = kappaC[0] * C;
         kappa[pa] = (float)k;
@@ -306,6 +317,7 @@ __global__ __launch_bounds__(256) void iter_combine_kernel(const float *__restri
         T[pa * ldt + i] = (float)acc;
     }
     if (threadIdx.x == 0) {
+        if (ns == 0) { UC[pa] = 1.0f; Sigma[pa] = 0.0f; kappa[pa] = 1.0f; return; }
         kappa[pa] = (float)(ok[pa] * Cs[s]);
         Sigma[pa] = (float)oS[pa];
         UC[pa] = (float)oU[pa];
