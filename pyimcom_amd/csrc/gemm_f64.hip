@@ -3,16 +3,10 @@
 // Replaces scipy.linalg.cholesky + cho_solve as used by lakernel.CholKernel
 // (reference src/pyimcom/lakernel.py:262-279, 295-304, 355-358) for a BATCH of postage stamps.
 //
-// Design (gfx950): one 256-thread workgroup (4 waves, 2x2) owns a 128x128 output tile; each wave
-// accumulates a 64x64 sub-tile as 4x4 v_mfma_f64_16x16x4_f64 tiles (128 accumulator VGPRs).  Operand
-// tiles (128 x 16 doubles) are staged global -> registers -> LDS with the next tile's global loads in
-// flight behind the current tile's 64 MFMAs per wave.  LDS images are padded so the per-lane
-// ds_read_b64 fragment reads are bank-conflict-free:
-//   row-major image  [128][16+1]  : lane (i = l&15, k = l>>4) reads word i*17 + k  -> distinct banks for
-//                                   ds_read_b64 (32-lane halves) and ds_read2_b64 (16-lane groups) alike
-//   k-major image    [16][128+16] : lane reads word k*144 + i                      -> 32 distinct banks
-// fp64 MFMA runs at the fp64 vector rate on gfx950, so the point of MFMA here is operand reuse
-// (one 8-byte LDS read per lane feeds 2048 flops), not a higher peak.
+// Design (gfx950): one 512-thread workgroup (8 waves, 2x4) owns a 128x128 output tile; each wave accumulates a
+// 64x32 sub-tile as 4x2 v_mfma_f64_16x16x4_f64 tiles (64 accumulator VGPRs, four waves per SIMD resident).
+// Operand slices of k = 8 stream global -> LDS by LDS-DMA through a ring of four stages (mma_dma.h).
+// fp64 MFMA runs at the fp64 vector rate on gfx950, so the point of MFMA here is operand reuse, not a higher peak.
 #include "common.h"
 #include "mma_dma.h"
 
@@ -20,24 +14,24 @@ namespace imcom {
 
 constexpr int BK = DBK;  // K granularity of the tile engine (mma_dma.h)
 
-__device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][4])
+__device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][MMA_NJ])
 {
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < MMA_NJ; j++) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 }
 
 // C/D map of v_mfma_f64_16x16x4_f64: register r of lane l holds (row (l>>4) + 4r, col l&15).
 #define IMCOM_FOR_ACC(ROW, COL, VAL, BODY)                                   \
     {                                                                        \
         const int lane__ = threadIdx.x & 63, wave__ = threadIdx.x >> 6;      \
-        const int wm__ = wave__ >> 1, wn__ = wave__ & 1;                     \
+        const int wm__ = wave__ >> 2, wn__ = wave__ & 3;                     \
         _Pragma("unroll") for (int i__ = 0; i__ < 4; i__++)                  \
-        _Pragma("unroll") for (int j__ = 0; j__ < 4; j__++)                  \
+        _Pragma("unroll") for (int j__ = 0; j__ < MMA_NJ; j__++)             \
         _Pragma("unroll") for (int r__ = 0; r__ < 4; r__++) {                \
             const int ROW = wm__ * 64 + i__ * 16 + (lane__ >> 4) + 4 * r__;  \
-            const int COL = wn__ * 64 + j__ * 16 + (lane__ & 15);            \
+            const int COL = wn__ * 32 + j__ * 16 + (lane__ & 15);            \
             const double VAL = acc[i__][j__][r__];                           \
             BODY                                                             \
         }                                                                    \
@@ -49,7 +43,7 @@ __device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][4])
 //   L[k,k], Linv[k] from P[k]                                         (chol_diag.hip)
 //   L[i,k] = P[i] Linv[k]^T                                           (chol_trsm_kernel, i > k)
 // A is never written; L lives in its own buffer (the repair path and the multi-kappa path need A).
-__global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__restrict__ A,
+__global__ __launch_bounds__(MMA_THREADS, 2) void chol_update_kernel(const double *__restrict__ A,
                                                              double *__restrict__ L, int ldn, int k,
                                                              const int *__restrict__ nblk,
                                                              const double *__restrict__ dshift)
@@ -59,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
     if (i >= nblk[s]) return;
     const long sA = (long)ldn * ldn;
     double *Ls = L + s * sA;
-    f64x4 acc[4][4];
+    f64x4 acc[4][MMA_NJ];
     zero_acc(acc);
     mma_tile_dma<false, false>(acc, Ls + (long)i * NB * ldn, ldn, Ls + (long)k * NB * ldn, ldn, k * NB, smem);
     const double *As = A + s * sA + (long)i * NB * ldn + k * NB;
@@ -73,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void chol_update_kernel(const double *__res
     })
 }
 
-__global__ __launch_bounds__(256, 2) void chol_trsm_kernel(double *__restrict__ L,
+__global__ __launch_bounds__(MMA_THREADS, 2) void chol_trsm_kernel(double *__restrict__ L,
                                                            const double *__restrict__ Dinv, int ldn,
                                                            int k, const int *__restrict__ nblk)
 {
@@ -82,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void chol_trsm_kernel(double *__restrict__ 
     if (i >= nblk[s]) return;
     double *P = L + (long)s * ldn * ldn + (long)i * NB * ldn + k * NB;
     const double *Di = Dinv + ((long)s * (ldn / NB) + k) * NB * NB;
-    f64x4 acc[4][4];
+    f64x4 acc[4][MMA_NJ];
     zero_acc(acc);
     mma_tile_dma<false, false>(acc, P, ldn, Di, NB, NB, smem);
     __syncthreads();  // all of P[i] has been read by every wave before it is overwritten
@@ -111,7 +105,7 @@ __device__ __forceinline__ void solve_tile_of_block(int &c, int &s)
 //   forward  block row k:  R = Bt_k - L[k,0:k] Y[0:k]   then  Y_k = Linv[k]   R
 //   backward block row k:  R = Y_k - L[k+1:,k]^T X[k+1:] then  X_k = Linv[k]^T R
 // The update kernels carry all the 2 N^2 m flops of the solve (the "solve_gemm" family).
-__global__ __launch_bounds__(256, 2) void solve_fwd_kernel(const double *__restrict__ L,
+__global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double *__restrict__ L,
                                                            const double *__restrict__ Bt,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk)
@@ -122,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void solve_fwd_kernel(const double *__restr
     if (k >= nblk[s]) return;
     const double *Ls = L + (long)s * ldn * ldn + (long)k * NB * ldn;
     double *Ys = Y + (long)s * ldn * ldm + c * NB;
-    f64x4 acc[4][4];
+    f64x4 acc[4][MMA_NJ];
     zero_acc(acc);
     mma_tile_dma<false, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem);
     const double *Bs = Bt + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
@@ -130,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void solve_fwd_kernel(const double *__restr
     IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] = Bs[(long)row * ldm + col] - v; })
 }
 
-__global__ __launch_bounds__(256, 2) void solve_bwd_kernel(const double *__restrict__ L,
+__global__ __launch_bounds__(MMA_THREADS, 2) void solve_bwd_kernel(const double *__restrict__ L,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk,
                                                            const int *__restrict__ n)
@@ -142,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void solve_bwd_kernel(const double *__restr
     if (k >= nb - 1) return;  // last block row: nothing to subtract
     const double *Lc = L + (long)s * ldn * ldn + (long)(k + 1) * NB * ldn + k * NB;  // L[k+1:, k]
     double *Ys = Y + (long)s * ldn * ldm + c * NB;
-    f64x4 acc[4][4];
+    f64x4 acc[4][MMA_NJ];
     zero_acc(acc);
     // rows of L below n[s] are identity padding (zero in this block column): stop the k loop at n rounded to 8
     const int kend = ((n[s] + DBK - 1) / DBK) * DBK - (k + 1) * NB;
@@ -153,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void solve_bwd_kernel(const double *__restr
 
 // Y_k <- Linv[k] Y_k (TRANS=false) or Linv[k]^T Y_k (TRANS=true), in place.
 template <bool TRANS>
-__global__ __launch_bounds__(256, 2) void solve_dinv_kernel(const double *__restrict__ Dinv,
+__global__ __launch_bounds__(MMA_THREADS, 2) void solve_dinv_kernel(const double *__restrict__ Dinv,
                                                             double *__restrict__ Y, int ldn, int ldm,
                                                             int k, const int *__restrict__ nblk)
 {
@@ -163,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void solve_dinv_kernel(const double *__rest
     if (k >= nblk[s]) return;
     const double *Di = Dinv + ((long)s * (ldn / NB) + k) * NB * NB;
     double *Yk = Y + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
-    f64x4 acc[4][4];
+    f64x4 acc[4][MMA_NJ];
     zero_acc(acc);
     mma_tile_dma<TRANS, true>(acc, Di, NB, Yk, ldm, NB, smem);
     __syncthreads();
@@ -174,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void solve_dinv_kernel(const double *__rest
 // Generic batched C = alpha * op(A) * op(B) + beta * C on 128-multiples (used by the eigen path:
 // P = B Q, T = (P/(lam+kappa)) Q^T).  Element (r,k) of a K-major operand is p[k*ld + r].
 template <bool AKM, bool BKM>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const double *__restrict__ A, long lda,
+__global__ __launch_bounds__(MMA_THREADS, 2) void gemm_kernel(const double *__restrict__ A, long lda,
                                                       long strideA, const double *__restrict__ B,
                                                       long ldb, long strideB, double *__restrict__ C,
                                                       long ldc, long strideC, int K, double alpha,
@@ -184,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const double *__restrict__
     const int s = blockIdx.z, tm = blockIdx.y, tn = blockIdx.x;
     const double *Ag = A + s * strideA + (AKM ? (long)tm * NB : (long)tm * NB * lda);
     const double *Bg = B + s * strideB + (BKM ? (long)tn * NB : (long)tn * NB * ldb);
-    f64x4 acc[4][4];
+    f64x4 acc[4][MMA_NJ];
     zero_acc(acc);
     mma_tile_dma<AKM, BKM>(acc, Ag, lda, Bg, ldb, K, smem);
     double *Co = C + s * strideC + (long)tm * NB * ldc + (long)tn * NB;
@@ -201,7 +195,7 @@ int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int 
                        const int *nblk, const double *dshift)
 {
     dim3 grid(nbmax - k, batch);
-    hipLaunchKernelGGL(chol_update_kernel, grid, dim3(256), 0, ctx->stream, A, L, ldn, k, nblk, dshift);
+    hipLaunchKernelGGL(chol_update_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, A, L, ldn, k, nblk, dshift);
     return check_launch("chol_update_kernel");
 }
 
@@ -210,7 +204,7 @@ int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int
 {
     if (nbmax - k - 1 <= 0) return IMCOM_OK;
     dim3 grid(nbmax - k - 1, batch);
-    hipLaunchKernelGGL(chol_trsm_kernel, grid, dim3(256), 0, ctx->stream, L, Dinv, ldn, k, nblk);
+    hipLaunchKernelGGL(chol_trsm_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Dinv, ldn, k, nblk);
     return check_launch("chol_trsm_kernel");
 }
 
@@ -218,7 +212,7 @@ int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *
                      int batch, const int *nblk)
 {
     dim3 grid(ldm / NB, batch);
-    hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(256), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk);
+    hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk);
     return check_launch("solve_fwd_kernel");
 }
 
@@ -226,7 +220,7 @@ int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ld
                      const int *nblk, const int *n)
 {
     dim3 grid(ldm / NB, batch);
-    hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(256), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n);
+    hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n);
     return check_launch("solve_bwd_kernel");
 }
 
@@ -235,9 +229,9 @@ int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, in
 {
     dim3 grid(ldm / NB, batch);
     if (trans)
-        hipLaunchKernelGGL(solve_dinv_kernel<true>, grid, dim3(256), 0, ctx->stream, Dinv, Y, ldn, ldm, k, nblk);
+        hipLaunchKernelGGL(solve_dinv_kernel<true>, grid, dim3(MMA_THREADS), 0, ctx->stream, Dinv, Y, ldn, ldm, k, nblk);
     else
-        hipLaunchKernelGGL(solve_dinv_kernel<false>, grid, dim3(256), 0, ctx->stream, Dinv, Y, ldn, ldm, k, nblk);
+        hipLaunchKernelGGL(solve_dinv_kernel<false>, grid, dim3(MMA_THREADS), 0, ctx->stream, Dinv, Y, ldn, ldm, k, nblk);
     return check_launch("solve_dinv_kernel");
 }
 
@@ -248,7 +242,7 @@ int launch_gemm(imcom_ctx *ctx, bool akm, bool bkm, int M, int N, int K, int bat
     IMCOM_REQUIRE(M % NB == 0 && N % NB == 0 && K % BK == 0, "launch_gemm: sizes must be padded (M=%d N=%d K=%d)", M, N, K);
     dim3 grid(N / NB, M / NB, batch);
 #define IMCOM_GEMM_CASE(a, b)                                                                              \
-    hipLaunchKernelGGL((gemm_kernel<a, b>), grid, dim3(256), 0, ctx->stream, A, lda, strideA, B, ldb, strideB, \
+    hipLaunchKernelGGL((gemm_kernel<a, b>), grid, dim3(MMA_THREADS), 0, ctx->stream, A, lda, strideA, B, ldb, strideB, \
                        C, ldc, strideC, K, alpha, beta)
     if (akm && bkm) IMCOM_GEMM_CASE(true, true);
     else if (akm) IMCOM_GEMM_CASE(true, false);

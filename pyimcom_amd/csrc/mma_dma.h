@@ -1,7 +1,8 @@
 // mma_dma.h -- fp64 MFMA tile engine, LDS-DMA edition.
 //
-// acc(128x128) += sum_k Aop[m][k] * Bop[k][n] for one 256-thread workgroup (4 waves, 2x2, 64x64 per wave as
-// 4x4 v_mfma_f64_16x16x4_f64 tiles).  Operand slices of BK = 8 are streamed global -> LDS by LDS-DMA
+// acc(128x128) += sum_k Aop[m][k] * Bop[k][n] for one 512-thread workgroup (8 waves, 2x4, 64x32 per wave as
+// 4x2 v_mfma_f64_16x16x4_f64 tiles: 64 accumulator registers, so two workgroups = four waves per SIMD are
+// resident -- with one workgroup per CU the engine ran at 38 TFLOP/s, with two 4-wave ones at 62).  Operand slices of BK = 8 are streamed global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of NS = 4 stages, so three
 // slices (~6000 MFMA cycles) are in flight behind the one being consumed -- the probe
 // (tools/gemm_probe.hip) showed HBM latency, not barriers or LDS, was what held the register-staged
@@ -27,55 +28,47 @@ constexpr int DKM_LD = 128 + 16;             // k-major image row stride (double
 constexpr int DIMG = DBK * DKM_LD;           // doubles per operand image slot (1152; row-major needs 1024)
 constexpr int DSTAGE = 2 * DIMG;             // doubles per stage
 constexpr int DMA_LDS_DOUBLES = DNS * DSTAGE;  // 9216 doubles = 73,728 B per workgroup
+constexpr int MMA_THREADS = 512;             // 8 waves: wave (wm = w >> 2, wn = w & 3) owns rows 64 wm.., columns 32 wn..
+constexpr int MMA_NJ = 2;                    // 16-column MFMA tiles per wave
 
 #define IMCOM_GLDS16(gptr, ldsptr)                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),     \
                                      (__attribute__((address_space(3))) void *)(ldsptr), 16, 0, 0)
 
 template <bool AKM, bool BKM>
-__device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][4], const double *__restrict__ Ag, long lda,
+__device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const double *__restrict__ Ag, long lda,
                                              const double *__restrict__ Bg, long ldb, int K, double *lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 15, lk = lane >> 4;
     const int nt = K / DBK;
     if (nt <= 0) return;
 
-    // per-lane global source of this wave's two DMA instructions per operand, for slice 0
-    //   k-major: instruction q loads k-row (2*wave + q): lane -> doubles [2*lane, 2*lane+1] of that row
-    //   row-major: instruction q loads rows 16*(2*wave+q) .. +15: lane -> row 16u + (lane>>2), chunk (lane&3)^swz
-    const double *ga[2], *gb[2];
-    long ainc, binc;
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int u = 2 * wave + q;
-        if (AKM) ga[q] = Ag + (long)u * lda + 2 * lane;
-        else { const int row = 16 * u + (lane >> 2); ga[q] = Ag + (long)row * lda + 2 * ((lane & 3) ^ ((row >> 2) & 3)); }
-        if (BKM) gb[q] = Bg + (long)u * ldb + 2 * lane;
-        else { const int row = 16 * u + (lane >> 2); gb[q] = Bg + (long)row * ldb + 2 * ((lane & 3) ^ ((row >> 2) & 3)); }
+    // per-lane global source of this wave's ONE DMA instruction per operand, for slice 0
+    //   k-major: the wave loads k-row `wave`: lane -> doubles [2*lane, 2*lane+1] of that row
+    //   row-major: the wave loads rows 16*wave .. +15: lane -> row 16 wave + (lane>>2), chunk (lane&3)^swz
+    const double *ga, *gb;
+    {
+        const int row = 16 * wave + (lane >> 2);
+        ga = AKM ? Ag + (long)wave * lda + 2 * lane : Ag + (long)row * lda + 2 * ((lane & 3) ^ ((row >> 2) & 3));
+        gb = BKM ? Bg + (long)wave * ldb + 2 * lane : Bg + (long)row * ldb + 2 * ((lane & 3) ^ ((row >> 2) & 3));
     }
-    ainc = AKM ? (long)DBK * lda : DBK;
-    binc = BKM ? (long)DBK * ldb : DBK;
+    const long ainc = AKM ? (long)DBK * lda : DBK, binc = BKM ? (long)DBK * ldb : DBK;
     // wave-uniform LDS destinations inside a stage
-    const int da0 = AKM ? (2 * wave) * DKM_LD : (2 * wave) * 128;          // + q * (DKM_LD or 128)
-    const int dastep = AKM ? DKM_LD : 128;
-    const int db0 = DIMG + (BKM ? (2 * wave) * DKM_LD : (2 * wave) * 128);
-    const int dbstep = BKM ? DKM_LD : 128;
+    const int da0 = AKM ? wave * DKM_LD : wave * 128;
+    const int db0 = DIMG + (BKM ? wave * DKM_LD : wave * 128);
 
     auto issue = [&](int slot) {
         double *st = lds + slot * DSTAGE;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            IMCOM_GLDS16(ga[q], st + da0 + q * dastep);
-            IMCOM_GLDS16(gb[q], st + db0 + q * dbstep);
-            ga[q] += ainc;
-            gb[q] += binc;
-        }
+        IMCOM_GLDS16(ga, st + da0);
+        IMCOM_GLDS16(gb, st + db0);
+        ga += ainc;
+        gb += binc;
     };
 
     // fragment read offsets (doubles) inside a stage for kk = 0; kk = 1 adds 4 k
-    int ra[4], rb[4], ra1[4], rb1[4];
+    int ra[4], rb[MMA_NJ], ra1[4], rb1[MMA_NJ];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (AKM) { ra[i] = lk * DKM_LD + wm * 64 + i * 16 + li; ra1[i] = ra[i] + 4 * DKM_LD; }
@@ -84,9 +77,12 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][4], const double *_
             ra[i] = row * 8 + (((lk >> 1) ^ sw) << 1) + (lk & 1);
             ra1[i] = row * 8 + (((2 + (lk >> 1)) ^ sw) << 1) + (lk & 1);
         }
-        if (BKM) { rb[i] = DIMG + lk * DKM_LD + wn * 64 + i * 16 + li; rb1[i] = rb[i] + 4 * DKM_LD; }
+    }
+#pragma unroll
+    for (int i = 0; i < MMA_NJ; i++) {
+        if (BKM) { rb[i] = DIMG + lk * DKM_LD + wn * 32 + i * 16 + li; rb1[i] = rb[i] + 4 * DKM_LD; }
         else {
-            const int row = wn * 64 + i * 16 + li, sw = (row >> 2) & 3;
+            const int row = wn * 32 + i * 16 + li, sw = (row >> 2) & 3;
             rb[i] = DIMG + row * 8 + (((lk >> 1) ^ sw) << 1) + (lk & 1);
             rb1[i] = DIMG + row * 8 + (((2 + (lk >> 1)) ^ sw) << 1) + (lk & 1);
         }
@@ -96,8 +92,8 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][4], const double *_
     issue(0);
     if (nt > 1) issue(1);
     if (nt > 2) issue(2);
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // two DMA instructions per wave and slice
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -106,24 +102,24 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][4], const double *_
         // slot (t+3)&3 == (t-1)&3 was last read in iteration t-1; every wave passed that iteration's barrier
         if (t + 3 < nt) issue((t + 3) & 3);
         const double *st = lds + (t & 3) * DSTAGE;
-        double a0[4], b0[4], a1[4], b1[4];
+        double a0[4], b0[MMA_NJ], a1[4], b1[MMA_NJ];
 #pragma unroll
-        for (int i = 0; i < 4; i++) { a0[i] = st[ra[i]]; b0[i] = st[rb[i]]; }
+        for (int i = 0; i < 4; i++) { a0[i] = st[ra[i]]; a1[i] = st[ra1[i]]; }
 #pragma unroll
-        for (int i = 0; i < 4; i++) { a1[i] = st[ra1[i]]; b1[i] = st[rb1[i]]; }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MMA_NJ; i++) { b0[i] = st[rb[i]]; b1[i] = st[rb1[i]]; }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
         if (t + 1 < nt) {
             // slice t+1 must have landed (this wave's part) before the barrier publishes it; slices t+2, t+3
             // stay in flight
-            if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
