@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
-#include "../mma_dma.h"
+#include "mma_dma_4wave.h"
 using imcom::f64x4;
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int NB = 128, BK = 16, LDS_RM = 17, LDS_KM = 144, TILE_WORDS = BK * LDS_KM;
