@@ -2,19 +2,18 @@
 //
 // acc(128x128) += sum_k Aop[m][k] * Bop[k][n] for one 512-thread workgroup (8 waves, 2x4, 64x32 per wave as
 // 4x2 v_mfma_f64_16x16x4_f64 tiles: 64 accumulator registers, so two workgroups = four waves per SIMD are
-// resident -- with one workgroup per CU the engine ran at 38 TFLOP/s, with two 4-wave ones at 62).  Operand slices of BK = 8 are streamed global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of NS = 4 stages, so three
-// slices (~6000 MFMA cycles) are in flight behind the one being consumed -- the probe
-// (tools/gemm_probe.hip) showed HBM latency, not barriers or LDS, was what held the register-staged
-// engine at 60 of 78.6 TFLOP/s.  One raw s_barrier per slice with a counted vmcnt (never 0 in steady state).
+// resident -- with one workgroup per CU the engine ran at 38 TFLOP/s, with two 4-wave ones at 62).  Operand slices of BK = 16 are streamed global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass) into two stages of BK = 16: the next slice
+// streams in behind the 32 MFMAs per wave (x 4 waves per SIMD, ~8000 cycles) of the current one.  One raw
+// s_barrier per slice.
 //
 // LDS images (all in one __shared__ array; an LDS-DMA wave-instruction writes 64 x 16 B contiguously):
-//   k-major operand  (element (r,k) at p[k*ld + r]):  [8][128 + 16]; one instruction = one 1 KB k-row; the
-//                    16-word row pad makes lane (i = l&15, k = l>>4) reads hit 32 distinct banks.
-//   row-major operand (element (r,k) at p[r*ld + k]): [128][8], no pad; one instruction = 16 rows x 64 B.
-//                    Bank conflicts are removed by XOR-swizzling the 16-byte chunk index with bits 2..3 of
-//                    the row -- applied to the per-lane GLOBAL address (the LDS side of a DMA is linear)
-//                    and again on the read.
+//   k-major operand  (element (r,k) at p[k*ld + r]):  [16][128 + 16]; one instruction = one 1 KB k-row; the
+//                    row pad makes lane (i = l&15, k = l>>4) reads hit 32 distinct banks.
+//   row-major operand (element (r,k) at p[r*ld + k]): [128][16], no pad; one instruction = 8 rows x 128 B.
+//                    Bank conflicts are removed by XOR-swizzling the 16-byte chunk index (0..7) with the low
+//                    three bits of the row -- applied to the per-lane GLOBAL address (the LDS side of a DMA is
+//                    linear) and again on the read.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,10 +21,10 @@ namespace imcom {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DBK = 8;                       // k-slice per stage
-constexpr int DNS = 4;                       // ring stages
+constexpr int DBK = 16;                      // k-slice per stage
+constexpr int DNS = 2;                       // stages (double buffer)
 constexpr int DKM_LD = 128 + 16;             // k-major image row stride (doubles)
-constexpr int DIMG = DBK * DKM_LD;           // doubles per operand image slot (1152; row-major needs 1024)
+constexpr int DIMG = DBK * DKM_LD;           // doubles per operand image slot (2304; row-major needs 2048)
 constexpr int DSTAGE = 2 * DIMG;             // doubles per stage
 constexpr int DMA_LDS_DOUBLES = DNS * DSTAGE;  // 9216 doubles = 73,728 B per workgroup
 constexpr int MMA_THREADS = 512;             // 8 waves: wave (wm = w >> 2, wn = w & 3) owns rows 64 wm.., columns 32 wn..
@@ -45,84 +44,77 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     const int nt = K / DBK;
     if (nt <= 0) return;
 
-    // per-lane global source of this wave's ONE DMA instruction per operand, for slice 0
-    //   k-major: the wave loads k-row `wave`: lane -> doubles [2*lane, 2*lane+1] of that row
-    //   row-major: the wave loads rows 16*wave .. +15: lane -> row 16 wave + (lane>>2), chunk (lane&3)^swz
-    const double *ga, *gb;
-    {
-        const int row = 16 * wave + (lane >> 2);
-        ga = AKM ? Ag + (long)wave * lda + 2 * lane : Ag + (long)row * lda + 2 * ((lane & 3) ^ ((row >> 2) & 3));
-        gb = BKM ? Bg + (long)wave * ldb + 2 * lane : Bg + (long)row * ldb + 2 * ((lane & 3) ^ ((row >> 2) & 3));
+    // per-lane global source of this wave's two DMA instructions per operand, for slice 0
+    //   k-major: instruction q loads k-row 2*wave + q: lane -> doubles [2*lane, 2*lane+1] of that row
+    //   row-major ([128][16], 8 chunks of 16 B per row): instruction q loads rows 16 wave + 8 q .. +7:
+    //             lane -> row + (lane>>3), chunk (lane&7) ^ (row&7)
+    const double *ga[2], *gb[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int row = 16 * wave + 8 * q + (lane >> 3), ch = (lane & 7) ^ (row & 7);
+        ga[q] = AKM ? Ag + (long)(2 * wave + q) * lda + 2 * lane : Ag + (long)row * lda + 2 * ch;
+        gb[q] = BKM ? Bg + (long)(2 * wave + q) * ldb + 2 * lane : Bg + (long)row * ldb + 2 * ch;
     }
     const long ainc = AKM ? (long)DBK * lda : DBK, binc = BKM ? (long)DBK * ldb : DBK;
     // wave-uniform LDS destinations inside a stage
-    const int da0 = AKM ? wave * DKM_LD : wave * 128;
-    const int db0 = DIMG + (BKM ? wave * DKM_LD : wave * 128);
+    const int da0 = AKM ? 2 * wave * DKM_LD : 16 * wave * 16, dastep = AKM ? DKM_LD : 8 * 16;
+    const int db0 = DIMG + (BKM ? 2 * wave * DKM_LD : 16 * wave * 16), dbstep = BKM ? DKM_LD : 8 * 16;
 
     auto issue = [&](int slot) {
         double *st = lds + slot * DSTAGE;
-        IMCOM_GLDS16(ga, st + da0);
-        IMCOM_GLDS16(gb, st + db0);
-        ga += ainc;
-        gb += binc;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            IMCOM_GLDS16(ga[q], st + da0 + q * dastep);
+            IMCOM_GLDS16(gb[q], st + db0 + q * dbstep);
+            ga[q] += ainc;
+            gb[q] += binc;
+        }
     };
 
-    // fragment read offsets (doubles) inside a stage for kk = 0; kk = 1 adds 4 k
-    int ra[4], rb[MMA_NJ], ra1[4], rb1[MMA_NJ];
+    // fragment read offsets (doubles) inside a stage for the four k-quads kk (k = lk + 4 kk)
+    int ra[4][4], rb[4][MMA_NJ];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (AKM) { ra[i] = lk * DKM_LD + wm * 64 + i * 16 + li; ra1[i] = ra[i] + 4 * DKM_LD; }
-        else {
-            const int row = wm * 64 + i * 16 + li, sw = (row >> 2) & 3;
-            ra[i] = row * 8 + (((lk >> 1) ^ sw) << 1) + (lk & 1);
-            ra1[i] = row * 8 + (((2 + (lk >> 1)) ^ sw) << 1) + (lk & 1);
+    for (int kk = 0; kk < 4; kk++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = wm * 64 + i * 16 + li;
+            ra[kk][i] = AKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ (row & 7)) << 1) + (lk & 1);
         }
-    }
 #pragma unroll
-    for (int i = 0; i < MMA_NJ; i++) {
-        if (BKM) { rb[i] = DIMG + lk * DKM_LD + wn * 32 + i * 16 + li; rb1[i] = rb[i] + 4 * DKM_LD; }
-        else {
-            const int row = wn * 32 + i * 16 + li, sw = (row >> 2) & 3;
-            rb[i] = DIMG + row * 8 + (((lk >> 1) ^ sw) << 1) + (lk & 1);
-            rb1[i] = DIMG + row * 8 + (((2 + (lk >> 1)) ^ sw) << 1) + (lk & 1);
+        for (int i = 0; i < MMA_NJ; i++) {
+            const int row = wn * 32 + i * 16 + li;
+            rb[kk][i] = DIMG + (BKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ (row & 7)) << 1) + (lk & 1));
         }
     }
 
-    // prologue: up to three slices in flight, slice 0 landed
+    // prologue: slice 0 landed, slice 1 in flight
     issue(0);
     if (nt > 1) issue(1);
-    if (nt > 2) issue(2);
-    if (nt > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // two DMA instructions per wave and slice
-    else if (nt > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // four DMA instructions per wave and slice
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
     for (int t = 0; t < nt; t++) {
-        // slot (t+3)&3 == (t-1)&3 was last read in iteration t-1; every wave passed that iteration's barrier
-        if (t + 3 < nt) issue((t + 3) & 3);
-        const double *st = lds + (t & 3) * DSTAGE;
-        double a0[4], b0[MMA_NJ], a1[4], b1[MMA_NJ];
+        const double *st = lds + (t & 1) * DSTAGE;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { a0[i] = st[ra[i]]; a1[i] = st[ra1[i]]; }
+        for (int kk = 0; kk < 4; kk++) {
+            double a[4], b[MMA_NJ];
 #pragma unroll
-        for (int i = 0; i < MMA_NJ; i++) { b0[i] = st[rb[i]]; b1[i] = st[rb1[i]]; }
+            for (int i = 0; i < 4; i++) a[i] = st[ra[kk][i]];
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+            for (int i = 0; i < MMA_NJ; i++) b[i] = st[rb[kk][i]];
 #pragma unroll
-            for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i], b0[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
         if (t + 1 < nt) {
-            // slice t+1 must have landed (this wave's part) before the barrier publishes it; slices t+2, t+3
-            // stay in flight
-            if (t + 3 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // slice t+1 (this wave's part) has landed; the barrier publishes it and tells everybody that slot t&1 is free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nt) issue(t & 1);  // slice t+2 streams in behind the 32 MFMAs per wave of slice t+1
         }
     }
     // the caller's epilogue may reuse LDS: make sure every wave is done reading the last stage
