@@ -407,58 +407,133 @@ __global__ void trapezoid_f32_kernel(float *__restrict__ maps, long nmaps, int n
 
 // coadd.py:1320-1354.  Workgroup = 64 output pixels x 4 row groups over the input pixels.
 //   acc layout in LDS: [n_expo + n_inframe][256]
+constexpr int EPI_MAXF = 4;  // input frames (layers) accumulated in registers
+
+// the four sequential float32 roundings of the fade taper (row pass lower / upper edge, column pass left / right
+// edge; numpy multiplies the float32 array by float64 factors one pass at a time, coadd.py:1222-1292)
+__device__ __forceinline__ void taper_factors(int iy, int ix, int n2f, int fade, double (&s)[4])
+{
+    const int fk2 = 2 * fade;
+    auto edge = [&](int k) { double t = (double)k / (fk2 + 1); return t - sin(6.283185307179586 * t) / 6.283185307179586; };
+    s[0] = iy < fk2 ? edge(iy + 1) : 1.0;
+    s[1] = iy >= n2f - fk2 ? edge(n2f - iy) : 1.0;
+    s[2] = ix < fk2 ? edge(ix + 1) : 1.0;
+    s[3] = ix >= n2f - fk2 ? edge(n2f - ix) : 1.0;
+}
+
+// One thread owns CPT consecutive output pixels (CPT = 4: one 16-byte load per input pixel row; CPT = 1 when many
+// exposures would not leave room in LDS), four row groups per block.
+// The per-exposure sums ride in registers while the exposure index of the rows stays the same (pixels are ordered
+// InStamp by InStamp, exposure-major inside) and are flushed to LDS when it changes.
+template <int CPT>
 __global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__ Tt, int ldn, int ldm, int m,
                                                              int n2f, int fade, const int *__restrict__ n,
-                                                             const float *__restrict__ indata, int n_inframe,
+                                                             const float *__restrict__ indata, int n_inframe, int f0, int nf,
                                                              const int *__restrict__ expo, int n_expo,
                                                              float *__restrict__ outimage,
                                                              double *__restrict__ Tsum_image_part,
                                                              double *__restrict__ Tsum_inpix,
                                                              double *__restrict__ Neff)
 {
-    extern __shared__ double accs[];  // [(n_expo + n_inframe)][256]
-    const int s = blockIdx.y, c = threadIdx.x & 63, a = blockIdx.x * 64 + c, rg = threadIdx.x >> 6;
+    // frames f0 .. f0+nf-1 of the n_inframe input layers; the call with f0 == 0 also tapers T in place and writes
+    // the weight sums (later calls find T already tapered)
+    extern __shared__ double accs[];  // [n_expo + nf][256][CPT]
+    const bool first = f0 == 0;
+    const int s = blockIdx.y, c = threadIdx.x & 63, a0 = (blockIdx.x * 64 + c) * CPT, rg = threadIdx.x >> 6;
     const int ns = n[s];
-    const int nacc = n_expo + n_inframe;
-    for (int t = 0; t < nacc; t++) accs[t * 256 + threadIdx.x] = 0.0;
+    const int nacc = n_expo + nf;
+    for (int t = 0; t < nacc; t++)
+#pragma unroll
+        for (int q = 0; q < CPT; q++) accs[(t * 256 + threadIdx.x) * CPT + q] = 0.0;
     const long base = (long)s * ldn * ldm;
-    const int iy = a / n2f, ix = a - iy * n2f;
-    if (a < m) {
+    double tf[CPT][4];
+#pragma unroll
+    for (int q = 0; q < CPT; q++) {
+        const int a = min(a0 + q, m - 1);
+        taper_factors(a / n2f, a % n2f, n2f, fade > 0 ? fade : 0, tf[q]);
+    }
+    const bool live = a0 < m;  // ldm is a multiple of 128: the 16-byte access stays inside the row
+    double racc[CPT], oacc[EPI_MAXF][CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; q++) racc[q] = 0.0;
+#pragma unroll
+    for (int f = 0; f < EPI_MAXF; f++)
+#pragma unroll
+        for (int q = 0; q < CPT; q++) oacc[f][q] = 0.0;
+    int cur = -1;
+    const int *ex = expo + (long)s * ldn;
+    if (live) {
         for (int i = rg; i < ns; i += 4) {
-            float tv = Tt[base + (long)i * ldm + a];
-            if (fade > 0) {
-                tv = taper_f32(tv, iy, ix, n2f, fade);
-                Tt[base + (long)i * ldm + a] = tv;
+            float t4[CPT];
+            if constexpr (CPT == 4) {
+                const float4 tv = *(const float4 *)(Tt + base + (long)i * ldm + a0);
+                t4[0] = tv.x; t4[1] = tv.y; t4[2] = tv.z; t4[3] = tv.w;
+            } else t4[0] = Tt[base + (long)i * ldm + a0];
+            if (fade > 0 && first) {
+#pragma unroll
+                for (int q = 0; q < CPT; q++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) t4[q] = (float)((double)t4[q] * tf[q][k]);
+                if constexpr (CPT == 4) *(float4 *)(Tt + base + (long)i * ldm + a0) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                else Tt[base + (long)i * ldm + a0] = t4[0];
             }
-            const int e = expo[(long)s * ldn + i];
-            accs[e * 256 + threadIdx.x] += (double)tv;
-            for (int f = 0; f < n_inframe; f++)
-                accs[(n_expo + f) * 256 + threadIdx.x] += (double)tv * (double)indata[((long)s * n_inframe + f) * ldn + i];
+            const int e = ex[i];
+            if (e != cur) {
+                if (cur >= 0)
+#pragma unroll
+                    for (int q = 0; q < CPT; q++) accs[(cur * 256 + threadIdx.x) * CPT + q] += racc[q];
+#pragma unroll
+                for (int q = 0; q < CPT; q++) racc[q] = 0.0;
+                cur = e;
+            }
+#pragma unroll
+            for (int q = 0; q < CPT; q++) racc[q] += (double)t4[q];
+#pragma unroll
+            for (int f = 0; f < EPI_MAXF; f++) {
+                if (f < nf) {
+                    const double x = (double)indata[((long)s * n_inframe + f0 + f) * ldn + i];
+#pragma unroll
+                    for (int q = 0; q < CPT; q++) oacc[f][q] += (double)t4[q] * x;
+                }
+            }
         }
+        if (cur >= 0)
+#pragma unroll
+            for (int q = 0; q < CPT; q++) accs[(cur * 256 + threadIdx.x) * CPT + q] += racc[q];
+#pragma unroll
+        for (int f = 0; f < EPI_MAXF; f++)
+            if (f < nf)
+#pragma unroll
+                for (int q = 0; q < CPT; q++) accs[((n_expo + f) * 256 + threadIdx.x) * CPT + q] = oacc[f][q];
     }
     __syncthreads();
-    if (rg == 0 && a < m) {
-        double tot = 0.0, sabs = 0.0, sq = 0.0;
-        for (int e = 0; e < n_expo; e++) {
-            const double v = accs[e * 256 + c] + accs[e * 256 + 64 + c] + accs[e * 256 + 128 + c] + accs[e * 256 + 192 + c];
-            accs[e * 256 + c] = v;
-            tot += v;
-            sabs += fabs(v);
-            Tsum_image_part[((long)s * m + a) * n_expo + e] = v;
-        }
-        for (int e = 0; e < n_expo; e++) { const double t = accs[e * 256 + c] / sabs; sq += t * t; }
-        double neff = 1.0 / sq;
-        if (fade > 0) { neff *= taper_1d(iy, n2f, fade); neff *= taper_1d(ix, n2f, fade); }
-        Tsum_inpix[(long)s * m + a] = tot;
-        Neff[(long)s * m + a] = neff;
-        for (int f = 0; f < n_inframe; f++) {
-            const int r = (n_expo + f) * 256;
-            outimage[((long)s * n_inframe + f) * m + a] = (float)(accs[r + c] + accs[r + 64 + c] + accs[r + 128 + c] + accs[r + 192 + c]);
+    if (rg == 0 && live) {
+        auto tot4 = [&](int t, int q) {
+            return accs[(t * 256 + c) * CPT + q] + accs[(t * 256 + 64 + c) * CPT + q] + accs[(t * 256 + 128 + c) * CPT + q] + accs[(t * 256 + 192 + c) * CPT + q];
+        };
+        for (int q = 0; q < CPT; q++) {
+            const int a = a0 + q;
+            if (a >= m) break;
+            if (first) {
+                double tot = 0.0, sabs = 0.0, sq = 0.0;
+                for (int e = 0; e < n_expo; e++) {
+                    const double v = tot4(e, q);
+                    accs[(e * 256 + c) * CPT + q] = v;  // only this thread reads it again
+                    tot += v;
+                    sabs += fabs(v);
+                    Tsum_image_part[((long)s * m + a) * n_expo + e] = v;
+                }
+                for (int e = 0; e < n_expo; e++) { const double t = accs[(e * 256 + c) * CPT + q] / sabs; sq += t * t; }
+                double neff = 1.0 / sq;
+                if (fade > 0) { neff *= taper_1d(a / n2f, n2f, fade); neff *= taper_1d(a % n2f, n2f, fade); }
+                Tsum_inpix[(long)s * m + a] = tot;
+                Neff[(long)s * m + a] = neff;
+            }
+            for (int f = 0; f < nf; f++) outimage[((long)s * n_inframe + f0 + f) * m + a] = (float)tot4(n_expo + f, q);
         }
     }
 }
 
-// Tsum_stamp[s][e] = sum_a Tsum_image[s][a][e] / n2^2   (coadd.py:1339)
 __global__ __launch_bounds__(256) void tsum_stamp_kernel(const double *__restrict__ Tsum_image, int m, int n_expo,
                                                          int n2, double *__restrict__ Tsum_stamp)
 {
@@ -552,10 +627,21 @@ int launch_epilogue(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, int m,
                     const float *indata, int n_inframe, const int *expo, int n_expo, float *outimage, double *Tsum_image,
                     double *Tsum_stamp, double *Tsum_inpix, double *Neff)
 {
-    const size_t bytes = (size_t)(n_expo + n_inframe) * 256 * sizeof(double);
-    IMCOM_REQUIRE(bytes <= 128 * 1024, "epilogue: n_expo + n_inframe = %d too large", n_expo + n_inframe);
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)coadd_epilogue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    hipLaunchKernelGGL(coadd_epilogue_kernel, dim3((m + 63) / 64, batch), dim3(256), bytes, ctx->stream, Tt, ldn, ldm, m, n2f, fade, n_dev, indata, n_inframe, expo, n_expo, outimage, Tsum_image, Tsum_inpix, Neff);
+    for (int f0 = 0; f0 < n_inframe; f0 += EPI_MAXF) {  // EPI_MAXF input layers per pass over T
+        const int nf = n_inframe - f0 < EPI_MAXF ? n_inframe - f0 : EPI_MAXF;
+        const int cpt = (size_t)(n_expo + nf) * 256 * 4 * sizeof(double) <= 64 * 1024 + 2048 ? 4 : 1;  // 2 blocks per CU with 4
+        const size_t bytes = (size_t)(n_expo + nf) * 256 * cpt * sizeof(double);
+        IMCOM_REQUIRE(bytes <= 128 * 1024, "epilogue: n_expo = %d too large", n_expo);
+        if (cpt == 4) {
+            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)coadd_epilogue_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            hipLaunchKernelGGL(coadd_epilogue_kernel<4>, dim3((m + 255) / 256, batch), dim3(256), bytes, ctx->stream, Tt, ldn, ldm, m, n2f, fade,
+                               n_dev, indata, n_inframe, f0, nf, expo, n_expo, outimage, Tsum_image, Tsum_inpix, Neff);
+        } else {
+            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)coadd_epilogue_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            hipLaunchKernelGGL(coadd_epilogue_kernel<1>, dim3((m + 63) / 64, batch), dim3(256), bytes, ctx->stream, Tt, ldn, ldm, m, n2f, fade,
+                               n_dev, indata, n_inframe, f0, nf, expo, n_expo, outimage, Tsum_image, Tsum_inpix, Neff);
+        }
+    }
     IMCOM_TRY(check_launch("coadd_epilogue_kernel"));
     hipLaunchKernelGGL(tsum_stamp_kernel, dim3(n_expo, batch), dim3(256), 0, ctx->stream, Tsum_image, m, n_expo, n2, Tsum_stamp);
     return check_launch("tsum_stamp_kernel");

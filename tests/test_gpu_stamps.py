@@ -76,3 +76,13 @@ def test_resident_path_secondary_kernels(kernel):
     cfg = dataclasses.replace(synth.CONFIGS["tiny"], kernel=kernel)
     rep = smoke.check_batch(cfg, n_stamps=3)
     assert rep["stamp0"]["T"] < (2e-4 if kernel == "Iterative" else 1e-6)
+
+
+def test_resident_path_many_input_layers():
+    """n_inframe = 6 (science + noise / injected layers, coadd.py:975): the epilogue walks T once per four layers."""
+    import dataclasses
+
+    from pyimcom_amd import smoke, synth
+
+    cfg = dataclasses.replace(synth.CONFIGS["small"], n_inframe=6)
+    smoke.check_batch(cfg, n_stamps=2)
