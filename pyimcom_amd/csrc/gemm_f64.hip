@@ -26,12 +26,12 @@ __device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][MMA_NJ])
 #define IMCOM_FOR_ACC(ROW, COL, VAL, BODY)                                   \
     {                                                                        \
         const int lane__ = threadIdx.x & 63, wave__ = threadIdx.x >> 6;      \
-        const int wm__ = wave__ >> 2, wn__ = wave__ & 3;                     \
+        const int wm__ = wave__ / MMA_WN, wn__ = wave__ % MMA_WN;            \
         _Pragma("unroll") for (int i__ = 0; i__ < 4; i__++)                  \
         _Pragma("unroll") for (int j__ = 0; j__ < MMA_NJ; j__++)             \
         _Pragma("unroll") for (int r__ = 0; r__ < 4; r__++) {                \
             const int ROW = wm__ * 64 + i__ * 16 + (lane__ >> 4) + 4 * r__;  \
-            const int COL = wn__ * 32 + j__ * 16 + (lane__ & 15);            \
+            const int COL = wn__ * (16 * MMA_NJ) + j__ * 16 + (lane__ & 15); \
             const double VAL = acc[i__][j__][r__];                           \
             BODY                                                             \
         }                                                                    \

@@ -27,8 +27,14 @@ constexpr int DKM_LD = 128 + 16;             // k-major image row stride (double
 constexpr int DIMG = DBK * DKM_LD;           // doubles per operand image slot (2304; row-major needs 2048)
 constexpr int DSTAGE = 2 * DIMG;             // doubles per stage
 constexpr int DMA_LDS_DOUBLES = DNS * DSTAGE;  // 9216 doubles = 73,728 B per workgroup
-constexpr int MMA_THREADS = 512;             // 8 waves: wave (wm = w >> 2, wn = w & 3) owns rows 64 wm.., columns 32 wn..
-constexpr int MMA_NJ = 2;                    // 16-column MFMA tiles per wave
+#ifndef IMCOM_MMA_WAVES
+#define IMCOM_MMA_WAVES 8
+#endif
+constexpr int MMA_WAVES = IMCOM_MMA_WAVES;   // 8: wave (wm = w >> 2, wn = w & 3) owns rows 64 wm.., columns 32 wn..; 4: 2 x 2 waves of 64 x 64
+constexpr int MMA_THREADS = 64 * MMA_WAVES;
+constexpr int MMA_WN = MMA_WAVES / 2;        // waves along the columns
+constexpr int MMA_NJ = 8 / MMA_WN;           // 16-column MFMA tiles per wave
+constexpr int MMA_IQ = 16 / MMA_WAVES;       // LDS-DMA instructions per operand, wave and stage
 
 #define IMCOM_GLDS16(gptr, ldsptr)                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),     \
@@ -39,7 +45,7 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
                                              const double *__restrict__ Bg, long ldb, int K, double *lds)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / MMA_WN, wn = wave % MMA_WN;
     const int li = lane & 15, lk = lane >> 4;
     const int nt = K / DBK;
     if (nt <= 0) return;
@@ -48,22 +54,22 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     //   k-major: instruction q loads k-row 2*wave + q: lane -> doubles [2*lane, 2*lane+1] of that row
     //   row-major ([128][16], 8 chunks of 16 B per row): instruction q loads rows 16 wave + 8 q .. +7:
     //             lane -> row + (lane>>3), chunk (lane&7) ^ (row&7)
-    const double *ga[2], *gb[2];
+    const double *ga[MMA_IQ], *gb[MMA_IQ];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int row = 16 * wave + 8 * q + (lane >> 3), ch = (lane & 7) ^ (row & 7);
-        ga[q] = AKM ? Ag + (long)(2 * wave + q) * lda + 2 * lane : Ag + (long)row * lda + 2 * ch;
-        gb[q] = BKM ? Bg + (long)(2 * wave + q) * ldb + 2 * lane : Bg + (long)row * ldb + 2 * ch;
+    for (int q = 0; q < MMA_IQ; q++) {
+        const int u = MMA_IQ * wave + q, row = 8 * u + (lane >> 3), ch = (lane & 7) ^ (row & 7);
+        ga[q] = AKM ? Ag + (long)u * lda + 2 * lane : Ag + (long)row * lda + 2 * ch;
+        gb[q] = BKM ? Bg + (long)u * ldb + 2 * lane : Bg + (long)row * ldb + 2 * ch;
     }
     const long ainc = AKM ? (long)DBK * lda : DBK, binc = BKM ? (long)DBK * ldb : DBK;
     // wave-uniform LDS destinations inside a stage
-    const int da0 = AKM ? 2 * wave * DKM_LD : 16 * wave * 16, dastep = AKM ? DKM_LD : 8 * 16;
-    const int db0 = DIMG + (BKM ? 2 * wave * DKM_LD : 16 * wave * 16), dbstep = BKM ? DKM_LD : 8 * 16;
+    const int da0 = AKM ? MMA_IQ * wave * DKM_LD : 8 * MMA_IQ * wave * 16, dastep = AKM ? DKM_LD : 8 * 16;
+    const int db0 = DIMG + (BKM ? MMA_IQ * wave * DKM_LD : 8 * MMA_IQ * wave * 16), dbstep = BKM ? DKM_LD : 8 * 16;
 
     auto issue = [&](int slot) {
         double *st = lds + slot * DSTAGE;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < MMA_IQ; q++) {
             IMCOM_GLDS16(ga[q], st + da0 + q * dastep);
             IMCOM_GLDS16(gb[q], st + db0 + q * dbstep);
             ga[q] += ainc;
@@ -82,7 +88,7 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
         }
 #pragma unroll
         for (int i = 0; i < MMA_NJ; i++) {
-            const int row = wn * 32 + i * 16 + li;
+            const int row = wn * (16 * MMA_NJ) + i * 16 + li;
             rb[kk][i] = DIMG + (BKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ (row & 7)) << 1) + (lk & 1));
         }
     }
@@ -90,7 +96,7 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     // prologue: slice 0 landed, slice 1 in flight
     issue(0);
     if (nt > 1) issue(1);
-    if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // four DMA instructions per wave and slice
+    if (nt > 1) { if (MMA_IQ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }  // 2 MMA_IQ DMA instructions per wave and slice
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
