@@ -241,7 +241,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             }
             double *Yp = Y + p * node_stride;
             for (int k = 0; k < nbmax; k++) {
-                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, batch, nblk_dev)); }
+                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, batch, nblk_dev, n_dev)); }
                 { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, false)); }
             }
             for (int k = nbmax - 1; k >= 0; k--) {

@@ -108,7 +108,7 @@ __device__ __forceinline__ void solve_tile_of_block(int &c, int &s)
 __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double *__restrict__ L,
                                                            const double *__restrict__ Bt,
                                                            double *__restrict__ Y, int ldn, int ldm,
-                                                           int k, const int *__restrict__ nblk)
+                                                           int k, const int *__restrict__ nblk, const int *__restrict__ n)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -118,7 +118,10 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double 
     double *Ys = Y + (long)s * ldn * ldm + c * NB;
     f64x4 acc[4][MMA_NJ];
     zero_acc(acc);
-    mma_tile_dma<false, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem);
+    // rows of the last block row beyond n[s] are identity padding: their Y is Bt (zero), nothing has to be multiplied
+    const int mrows = min(NB, n[s] - k * NB);
+    if (mrows == NB) mma_tile_dma<false, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem);
+    else mma_tile_dma<false, true, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem, mrows);
     const double *Bs = Bt + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
     double *Yo = Ys + (long)k * NB * ldm;
     IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] = Bs[(long)row * ldm + col] - v; })
@@ -209,10 +212,10 @@ int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int
 }
 
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
-                     int batch, const int *nblk)
+                     int batch, const int *nblk, const int *n)
 {
     dim3 grid(ldm / NB, batch);
-    hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk);
+    hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n);
     return check_launch("solve_fwd_kernel");
 }
 

@@ -10,7 +10,7 @@ int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int 
 int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int k, int nbmax, int batch,
                      const int *nblk);
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
-                     int batch, const int *nblk);
+                     int batch, const int *nblk, const int *n);
 int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int batch,
                      const int *nblk, const int *n);
 int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, int ldm, int k, int batch,

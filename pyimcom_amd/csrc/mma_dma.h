@@ -40,15 +40,20 @@ constexpr int MMA_IQ = 16 / MMA_WAVES;       // LDS-DMA instructions per operand
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),     \
                                      (__attribute__((address_space(3))) void *)(ldsptr), 16, 0, 0)
 
-template <bool AKM, bool BKM>
+// PARTIAL: only the first `mrows` rows of the tile carry data (the last 128-block of a stamp is padded): 16-row
+// groups beyond it are neither read from LDS nor multiplied, their accumulators stay zero.  A separate
+// instantiation, so that the full-tile loop stays free of the test.
+template <bool AKM, bool BKM, bool PARTIAL = false>
 __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const double *__restrict__ Ag, long lda,
-                                             const double *__restrict__ Bg, long ldb, int K, double *lds)
+                                             const double *__restrict__ Bg, long ldb, int K, double *lds, int mrows = 128)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / MMA_WN, wn = wave % MMA_WN;
     const int li = lane & 15, lk = lane >> 4;
     const int nt = K / DBK;
     if (nt <= 0) return;
+    // PARTIAL: number of this wave's 16-row groups that hold data (wave-uniform)
+    const int ni = !PARTIAL ? 4 : (mrows - wm * 64 <= 0 ? 0 : (mrows - wm * 64 >= 64 ? 4 : (mrows - wm * 64 + 15) / 16));
 
     // per-lane global source of this wave's two DMA instructions per operand, for slice 0
     //   k-major: instruction q loads k-row 2*wave + q: lane -> doubles [2*lane, 2*lane+1] of that row
@@ -105,15 +110,29 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
         const double *st = lds + (t & 1) * DSTAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-            double a[4], b[MMA_NJ];
+            if constexpr (!PARTIAL) {
+                double a[4], b[MMA_NJ];
 #pragma unroll
-            for (int i = 0; i < 4; i++) a[i] = st[ra[kk][i]];
+                for (int i = 0; i < 4; i++) a[i] = st[ra[kk][i]];
 #pragma unroll
-            for (int i = 0; i < MMA_NJ; i++) b[i] = st[rb[kk][i]];
+                for (int i = 0; i < MMA_NJ; i++) b[i] = st[rb[kk][i]];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else if (ni > 0) {
+                double b[MMA_NJ];
+#pragma unroll
+                for (int i = 0; i < MMA_NJ; i++) b[i] = st[rb[kk][i]];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (i < ni) {
+                        const double a = st[ra[kk][i]];
+#pragma unroll
+                        for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
         }
         if (t + 1 < nt) {
             // slice t+1 (this wave's part) has landed; the barrier publishes it and tells everybody that slot t&1 is free
