@@ -56,7 +56,13 @@ __global__ __launch_bounds__(256, 3) void build_A_kernel(const int *__restrict__
     __shared__ double tile[16][17];
     const int s = blockIdx.y, tid = threadIdx.x;
     int ti, tj;
-    tile_index(blockIdx.x, ntile, ti, tj);
+    // Workgroups are dealt round-robin over the 8 XCDs (dispatch order % 8), each with its own L2: give every XCD a
+    // contiguous eighth of the tile list, so that the tiles it works on at one time use the same few tables.
+    // (gridDim.x is the tile count padded to a multiple of 8.)
+    const long ntri = (long)ntile * (ntile + 1) / 2, per = (ntri + 7) / 8;
+    const long t = (((long)blockIdx.y * gridDim.x + blockIdx.x) & 7) * per + ((long)blockIdx.x >> 3);
+    if (t >= ntri) return;
+    tile_index(t, ntile, ti, tj);
     const int ns = n[s];
     const int nfull = (ns + NB - 1) / NB * NB;  // rows/cols the factorisation will ever read
     if (ti * 16 >= nfull || tj * 16 >= nfull) return;
@@ -212,7 +218,8 @@ int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const d
     IMCOM_REQUIRE((long)ntab * ng * ng < (1L << 31), "table stack too large (%d tables of %d^2)", ntab, ng);
     const int nt = (ldn + 15) / 16;
     const long ntri = (long)nt * (nt + 1) / 2;
-    hipLaunchKernelGGL(build_A_kernel, dim3((unsigned)ntri, batch), dim3(256), 0, ctx->stream, n_dev, ldn, x, y, psf,
+    const long ngrid = (ntri + 7) / 8 * 8;  // padded to a multiple of 8 for the XCD-aware tile order
+    hipLaunchKernelGGL(build_A_kernel, dim3((unsigned)ngrid, batch), dim3(256), 0, ctx->stream, n_dev, ldn, x, y, psf,
                        tables, (long)ntab * ng * ng, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A, nt);
     return check_launch("build_A_kernel");
 }
