@@ -128,11 +128,13 @@ __global__ __launch_bounds__(256, 3) void build_A_kernel(const int *__restrict__
     // does any stencil of this tile end within a chunk of the end of the table stack?  (block-uniform; almost never)
     const long my_last = my_seg0 < 0 ? 0 : (my_step > 0 ? my_seg0 + 9L * my_step : my_seg0) + 12;
     const int near_end = __syncthreads_or(my_last >= tab_elems);
-    // the six (sample, slot) pairs this thread fetches for every stencil row: work item w = tid + 256 q
+    // the six (sample, slot) pairs this thread fetches for every stencil row.  A wave stages the chunks of its
+    // own 64 samples (work item w = lane + 64 q of the wave's 384), so that producer and consumer of an LDS row are
+    // the same wave: no workgroup barrier in the row loop, only counted vmcnt waits, and the four waves drift freely.
     int ae[6], ao[6], st2[6];  // first element of the chunk for the next even / odd row, and 2 * step
 #pragma unroll
     for (int q = 0; q < 6; q++) {
-        const int w = tid + 256 * q, sm = w / 6, slot = w - sm * 6;
+        const int w = (tid & 63) + 64 * q, sm = (tid & ~63) + w / 6, slot = w % 6;
         const int ch = (slot - ((sm >> 3) & 1) + 6) % 6;
         const int e0 = seg0[sm], stp = rstep[sm];
         const bool on = e0 >= 0;  // samples without a stencil fetch element 0: harmless, and the fast path stays branch-free
@@ -140,18 +142,18 @@ __global__ __launch_bounds__(256, 3) void build_A_kernel(const int *__restrict__
         ao[q] = on ? ((e0 + stp) & ~1) + 2 * ch : 0;
         st2[q] = on ? 2 * stp : 0;
     }
-    const int wave_base = (tid & ~63) * 2;  // this wave's first double in a 256-item slab
+    const int wave_base = (tid & ~63) * SEG_W;  // this wave's 64 x 12 doubles of a row buffer
     auto stage = [&](int (&at)[6], double *buf) {  // branch-free: every lane issues its six chunk loads
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-            IMCOM_GLDS16(tables + at[q], buf + 512 * q + wave_base);  // wave-uniform LDS base; lane l lands at +2 l
+            IMCOM_GLDS16(tables + at[q], buf + 128 * q + wave_base);  // wave-uniform LDS base; lane l lands at +2 l
             at[q] += st2[q];
         }
     };
     auto stage_checked = [&](int (&at)[6], double *buf) {  // tiles whose stencils reach the end of the table stack
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-            double *dst = buf + 512 * q + wave_base;
+            double *dst = buf + 128 * q + wave_base;
             const long a_ = at[q];
             if (a_ + 1 < tab_elems) IMCOM_GLDS16(tables + a_, dst);
             else { dst[2 * (tid & 63)] = (a_ < tab_elems) ? tables[a_] : 0.0; dst[2 * (tid & 63) + 1] = 0.0; }
@@ -169,16 +171,23 @@ __global__ __launch_bounds__(256, 3) void build_A_kernel(const int *__restrict__
         val += strip * wyr;
     };
     if (!near_end) {
+        // One row (six DMA instructions of this wave) is in flight while the previous one is consumed: vmcnt(6)
+        // = the older row has landed.  lgkmcnt(0) before a buffer is refilled: its LDS reads have returned.
         stage(ae, seg[0]);
-        __syncthreads();
 #pragma unroll
         for (int rp = 0; rp < 5; rp++) {
             stage(ao, seg[1]);                 // row 2 rp + 1 in flight
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             consume(seg[0], we, wy[2 * rp]);
-            __syncthreads();
-            if (rp < 4) stage(ae, seg[0]);     // row 2 rp + 2 in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (rp < 4) {
+                stage(ae, seg[0]);             // row 2 rp + 2 in flight
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             consume(seg[1], wo, wy[2 * rp + 1]);
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     } else {
         stage_checked(ae, seg[0]);

@@ -37,6 +37,23 @@ __device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][MMA_NJ])
         }                                                                    \
     }
 
+// Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own L2.  All column
+// tiles of one stamp share that stamp's L panel, so they are placed on one XCD: XCD x takes stamps
+// x, x+8, ...  Bijective when the batch is a multiple of 8 (else the plain mapping is used); placement
+// only affects speed.
+__device__ __forceinline__ void solve_tile_of_block(int &c, int &s)
+{
+    const int ntile = gridDim.x, batch = gridDim.y;
+    c = blockIdx.x;
+    s = blockIdx.y;
+    if ((batch & 7) == 0) {
+        const int b = blockIdx.y * ntile + blockIdx.x;
+        const int xcd = b & 7, slot = b >> 3;
+        s = (slot / ntile) * 8 + xcd;
+        c = slot % ntile;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Left-looking blocked Cholesky of A + kappa*I, block column k:
 //   P[i] = A[i,k] + kappa*delta - sum_{j<k} L[i,j] L[k,j]^T          (chol_update_kernel, i >= k)
@@ -49,7 +66,9 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void chol_update_kernel(const doubl
                                                              const double *__restrict__ dshift)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
-    const int s = blockIdx.y, i = k + blockIdx.x;
+    int s, c;
+    solve_tile_of_block(c, s);  // the row tiles of a stamp share L[k,0:k]: one XCD
+    const int i = k + c;
     if (i >= nblk[s]) return;
     const long sA = (long)ldn * ldn;
     double *Ls = L + s * sA;
@@ -72,7 +91,9 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void chol_trsm_kernel(double *__res
                                                            int k, const int *__restrict__ nblk)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
-    const int s = blockIdx.y, i = k + 1 + blockIdx.x;
+    int s, c;
+    solve_tile_of_block(c, s);
+    const int i = k + 1 + c;
     if (i >= nblk[s]) return;
     double *P = L + (long)s * ldn * ldn + (long)i * NB * ldn + k * NB;
     const double *Di = Dinv + ((long)s * (ldn / NB) + k) * NB * NB;
@@ -81,23 +102,6 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void chol_trsm_kernel(double *__res
     mma_tile_dma<false, false>(acc, P, ldn, Di, NB, NB, smem);
     __syncthreads();  // all of P[i] has been read by every wave before it is overwritten
     IMCOM_FOR_ACC(row, col, v, { P[(long)row * ldn + col] = v; })
-}
-
-// Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own L2.  All column
-// tiles of one stamp share that stamp's L panel, so they are placed on one XCD: XCD x takes stamps
-// x, x+8, ...  Bijective when the batch is a multiple of 8 (else the plain mapping is used); placement
-// only affects speed.
-__device__ __forceinline__ void solve_tile_of_block(int &c, int &s)
-{
-    const int ntile = gridDim.x, batch = gridDim.y;
-    c = blockIdx.x;
-    s = blockIdx.y;
-    if ((batch & 7) == 0) {
-        const int b = blockIdx.y * ntile + blockIdx.x;
-        const int xcd = b & 7, slot = b >> 3;
-        s = (slot / ntile) * 8 + xcd;
-        c = slot % ntile;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
