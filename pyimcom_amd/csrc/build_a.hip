@@ -40,7 +40,14 @@ constexpr int SEG_W = 12;  // doubles staged per segment
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),           \
                                      (__attribute__((address_space(3))) void *)(ldsptr), 16, 0, 0)
 
-__global__ __launch_bounds__(256, 3) void build_A_kernel(const int *__restrict__ n, int ldn,
+// Row buffers per wave; A_RING - 1 rows are in flight.  Three buffers (two workgroups per CU instead of three)
+// measured slower, 40.9 against 33.7 ms per 256 cfg-2 stamps: the gather needs the waves more than the depth.
+#ifndef IMCOM_A_RING
+#define IMCOM_A_RING 2
+#endif
+constexpr int A_RING = IMCOM_A_RING;
+
+__global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const int *__restrict__ n, int ldn,
                                                       const double *__restrict__ x,
                                                       const double *__restrict__ y,
                                                       const int *__restrict__ psf,
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(256, 3) void build_A_kernel(const int *__restrict__
                                                       const double *__restrict__ pair_pen, int npsf_max,
                                                       double *__restrict__ A, int ntile)
 {
-    __shared__ __attribute__((aligned(16))) double seg[2][256 * SEG_W];
+    __shared__ __attribute__((aligned(16))) double seg[A_RING][256 * SEG_W];
     __shared__ int seg0[256];   // first element (ascending address order) of stencil row 0; < 0: no loads
     __shared__ int rstep[256];  // element step between stencil rows (+ng, or -ng for a flipped table)
     __shared__ double tile[16][17];
@@ -174,19 +181,20 @@ __global__ __launch_bounds__(256, 3) void build_A_kernel(const int *__restrict__
         // One row (six DMA instructions of this wave) is in flight while the previous one is consumed: vmcnt(6)
         // = the older row has landed.  lgkmcnt(0) before a buffer is refilled: its LDS reads have returned.
         stage(ae, seg[0]);
+        if (A_RING > 2) stage(ao, seg[1]);
 #pragma unroll
-        for (int rp = 0; rp < 5; rp++) {
-            stage(ao, seg[1]);                 // row 2 rp + 1 in flight
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            consume(seg[0], we, wy[2 * rp]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (rp < 4) {
-                stage(ae, seg[0]);             // row 2 rp + 2 in flight
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int r = 0; r < 10; r++) {
+            const int ahead = r + A_RING - 1;  // the row issued now; rows r+1 .. ahead are in flight while r is consumed
+            if (ahead < 10) {
+                if (ahead & 1) stage(ao, seg[ahead % A_RING]);
+                else stage(ae, seg[ahead % A_RING]);
             }
-            consume(seg[1], wo, wy[2 * rp + 1]);
+            const int inflight = (ahead < 10 ? ahead : 9) - r;
+            if (inflight == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (inflight == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (r & 1) consume(seg[r % A_RING], wo, wy[r]);
+            else consume(seg[r % A_RING], we, wy[r]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     } else {
