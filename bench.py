@@ -154,10 +154,13 @@ def main():
     if rank == 0:
         n_arr = batch.n.astype(np.float64)
         # Algorithmic flops of the launches being timed.  SURVEY 8d counts 2 N^2 m per stamp for the two triangular
-        # solves; the solve_fwd / solve_bwd launches carry the part of it below the 128-row diagonal blocks,
-        # 2 m (N^2 - sum_k rows_k^2) (the diagonal blocks are applied by the solve_dinv launches, timed apart).
+        # solves, and the solve_fwd / solve_bwd launches carry all of it: the updates below the 128-row diagonal
+        # blocks and the diagonal blocks themselves (priced as the triangular solves they are, m rows_k^2 each,
+        # although the kernel multiplies by the dense inverse).  With IMCOM_SOLVE_UNFUSED=1 the diagonal blocks are
+        # separate solve_dinv launches, timed apart, and only 2 m (N^2 - sum_k rows_k^2) is attributed here.
         rows_sq = np.array([(np.minimum(128, np.maximum(n - 128 * np.arange((n + 127) // 128), 0)) ** 2).sum() for n in batch.n], dtype=np.float64)
-        solve_flops_step = float((2.0 * cfg.m * (n_arr**2 - rows_sq)).sum())
+        fused = fams["solve_dinv"][1] == 0
+        solve_flops_step = float((2.0 * cfg.m * (n_arr**2 - (0.0 if fused else 1.0) * rows_sq)).sum())
         ms, launches = fams["solve_gemm"]
         achieved = solve_flops_step * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out = {
@@ -183,7 +186,7 @@ def main():
                 "parallelism": f"block-farming x{world} (no collective)",
             },
             "roofline": {
-                "kernel": "solve_fwd_kernel+solve_bwd_kernel (blocked TRSM updates below the diagonal blocks, fp64 MFMA 16x16x4)",
+                "kernel": "solve_fwd_kernel+solve_bwd_kernel (blocked triangular solves: block-row updates" + (" and diagonal blocks" if fused else " below the diagonal blocks") + ", fp64 MFMA 16x16x4)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS,

@@ -240,13 +240,16 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                 { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, batch, nblk_dev)); }
             }
             double *Yp = Y + p * node_stride;
+            // the diagonal blocks are applied inside the update launches; IMCOM_SOLVE_UNFUSED=1 keeps them apart (A/B runs)
+            static const bool unfused = getenv("IMCOM_SOLVE_UNFUSED") != nullptr;
+            const double *Dfused = unfused ? nullptr : Dinv;
             for (int k = 0; k < nbmax; k++) {
-                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, batch, nblk_dev, n_dev)); }
-                { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, false)); }
+                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, batch, nblk_dev, n_dev, Dfused)); }
+                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, false)); }
             }
             for (int k = nbmax - 1; k >= 0; k--) {
-                if (k < nbmax - 1) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, batch, nblk_dev, n_dev)); }
-                { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, true)); }
+                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, batch, nblk_dev, n_dev, Dfused)); }
+                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, true)); }
             }
         }
         {

@@ -37,6 +37,21 @@ __device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][MMA_NJ])
         }                                                                    \
     }
 
+// accumulator map of the engine's TRI mode: the wave's row groups are 2 i + wm
+#define IMCOM_FOR_ACC_TRI(ROW, COL, VAL, BODY)                               \
+    {                                                                        \
+        const int lane__ = threadIdx.x & 63, wave__ = threadIdx.x >> 6;      \
+        const int wm__ = wave__ / MMA_WN, wn__ = wave__ % MMA_WN;            \
+        _Pragma("unroll") for (int i__ = 0; i__ < 4; i__++)                  \
+        _Pragma("unroll") for (int j__ = 0; j__ < MMA_NJ; j__++)             \
+        _Pragma("unroll") for (int r__ = 0; r__ < 4; r__++) {                \
+            const int ROW = (2 * i__ + wm__) * 16 + (lane__ >> 4) + 4 * r__; \
+            const int COL = wn__ * (16 * MMA_NJ) + j__ * 16 + (lane__ & 15); \
+            const double VAL = acc[i__][j__][r__];                           \
+            BODY                                                             \
+        }                                                                    \
+    }
+
 // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8), each with its own L2.  All column
 // tiles of one stamp share that stamp's L panel, so they are placed on one XCD: XCD x takes stamps
 // x, x+8, ...  Bijective when the batch is a multiple of 8 (else the plain mapping is used); placement
@@ -109,10 +124,27 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void chol_trsm_kernel(double *__res
 //   forward  block row k:  R = Bt_k - L[k,0:k] Y[0:k]   then  Y_k = Linv[k]   R
 //   backward block row k:  R = Y_k - L[k+1:,k]^T X[k+1:] then  X_k = Linv[k]^T R
 // The update kernels carry all the 2 N^2 m flops of the solve (the "solve_gemm" family).
+// The diagonal block of a block row, applied by the workgroup that has just written the row's residual R (its own
+// 128 x 128 tile of Y_k): Y_k = Linv[k] R (or Linv[k]^T R).  R comes back through the same L1 / L2 it was written to
+// -- workgroup-scope visibility is all that is needed -- so the residual makes no extra trip to HBM and the row costs
+// one launch instead of two.
+template <bool TRANS>
+__device__ __forceinline__ void solve_dinv_tile(f64x4 (&acc)[4][MMA_NJ], const double *__restrict__ Di, double *Yk, int ldm,
+                                                double *smem)
+{
+    __syncthreads();  // R is written (the barrier waits for vmcnt(0)) and the LDS ring of the update is free
+    zero_acc(acc);
+    // Linv[k] is lower triangular (chol_diag.hip writes exact zeros above the diagonal), its transpose upper
+    mma_tile_dma<TRANS, true, false, TRANS ? 2 : 1>(acc, Di, NB, Yk, ldm, NB, smem);
+    __syncthreads();  // every wave has read all of R before it is overwritten
+    IMCOM_FOR_ACC_TRI(row, col, v, { Yk[(long)row * ldm + col] = v; })
+}
+
 __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double *__restrict__ L,
                                                            const double *__restrict__ Bt,
                                                            double *__restrict__ Y, int ldn, int ldm,
-                                                           int k, const int *__restrict__ nblk, const int *__restrict__ n)
+                                                           int k, const int *__restrict__ nblk, const int *__restrict__ n,
+                                                           const double *__restrict__ Dinv)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -129,27 +161,31 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double 
     const double *Bs = Bt + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
     double *Yo = Ys + (long)k * NB * ldm;
     IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] = Bs[(long)row * ldm + col] - v; })
+    if (Dinv) solve_dinv_tile<false>(acc, Dinv + ((long)s * (ldn / NB) + k) * NB * NB, Yo, ldm, smem);
 }
 
 __global__ __launch_bounds__(MMA_THREADS, 2) void solve_bwd_kernel(const double *__restrict__ L,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk,
-                                                           const int *__restrict__ n)
+                                                           const int *__restrict__ n, const double *__restrict__ Dinv)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
     solve_tile_of_block(c, s);
     const int nb = nblk[s];
-    if (k >= nb - 1) return;  // last block row: nothing to subtract
-    const double *Lc = L + (long)s * ldn * ldn + (long)(k + 1) * NB * ldn + k * NB;  // L[k+1:, k]
+    if (k >= nb || (k == nb - 1 && !Dinv)) return;  // last block row: nothing to subtract
     double *Ys = Y + (long)s * ldn * ldm + c * NB;
-    f64x4 acc[4][MMA_NJ];
-    zero_acc(acc);
-    // rows of L below n[s] are identity padding (zero in this block column): stop the k loop at n rounded to 8
-    const int kend = ((n[s] + DBK - 1) / DBK) * DBK - (k + 1) * NB;
-    mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, kend, smem);
     double *Yo = Ys + (long)k * NB * ldm;
-    IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] -= v; })
+    f64x4 acc[4][MMA_NJ];
+    if (k < nb - 1) {
+        const double *Lc = L + (long)s * ldn * ldn + (long)(k + 1) * NB * ldn + k * NB;  // L[k+1:, k]
+        zero_acc(acc);
+        // rows of L below n[s] are identity padding (zero in this block column): stop the k loop at n rounded to 8
+        const int kend = ((n[s] + DBK - 1) / DBK) * DBK - (k + 1) * NB;
+        mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, kend, smem);
+        IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] -= v; })
+    }
+    if (Dinv) solve_dinv_tile<true>(acc, Dinv + ((long)s * (ldn / NB) + k) * NB * NB, Yo, ldm, smem);
 }
 
 // Y_k <- Linv[k] Y_k (TRANS=false) or Linv[k]^T Y_k (TRANS=true), in place.
@@ -216,18 +252,18 @@ int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int
 }
 
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
-                     int batch, const int *nblk, const int *n)
+                     int batch, const int *nblk, const int *n, const double *Dinv)
 {
     dim3 grid(ldm / NB, batch);
-    hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n);
+    hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n, Dinv);
     return check_launch("solve_fwd_kernel");
 }
 
 int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int batch,
-                     const int *nblk, const int *n)
+                     const int *nblk, const int *n, const double *Dinv)
 {
     dim3 grid(ldm / NB, batch);
-    hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n);
+    hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv);
     return check_launch("solve_bwd_kernel");
 }
 

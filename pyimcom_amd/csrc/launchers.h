@@ -10,9 +10,9 @@ int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int 
 int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int k, int nbmax, int batch,
                      const int *nblk);
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
-                     int batch, const int *nblk, const int *n);
+                     int batch, const int *nblk, const int *n, const double *Dinv);  // Dinv != null: Linv[k] applied in the same launch
 int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int batch,
-                     const int *nblk, const int *n);
+                     const int *nblk, const int *n, const double *Dinv);
 int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, int ldm, int k, int batch,
                       const int *nblk, bool trans);
 int launch_gemm(imcom_ctx *ctx, bool akm, bool bkm, int M, int N, int K, int batch, const double *A, long lda,

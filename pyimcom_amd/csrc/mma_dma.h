@@ -43,7 +43,11 @@ constexpr int MMA_IQ = 16 / MMA_WAVES;       // LDS-DMA instructions per operand
 // PARTIAL: only the first `mrows` rows of the tile carry data (the last 128-block of a stamp is padded): 16-row
 // groups beyond it are neither read from LDS nor multiplied, their accumulators stay zero.  A separate
 // instantiation, so that the full-tile loop stays free of the test.
-template <bool AKM, bool BKM, bool PARTIAL = false>
+// TRI (K = 128 only): the A operand is a triangular 128 x 128 block -- 1: lower (element (r,k) is zero for k > r), 2: upper.
+// 16-row group g only meets k-slices t <= g (lower) or t >= g (upper); the other products are skipped.  So that both
+// halves of the workgroup carry the same share, the wave's four row groups are then interleaved, g = 2 i + wm
+// (IMCOM_FOR_ACC_TRI is the matching accumulator map): 20 instead of 32 MFMA rounds on the critical path.
+template <bool AKM, bool BKM, bool PARTIAL = false, int TRI = 0>
 __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const double *__restrict__ Ag, long lda,
                                              const double *__restrict__ Bg, long ldb, int K, double *lds, int mrows = 128)
 {
@@ -88,7 +92,7 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     for (int kk = 0; kk < 4; kk++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int row = wm * 64 + i * 16 + li;
+            const int row = TRI ? (2 * i + wm) * 16 + li : wm * 64 + i * 16 + li;
             ra[kk][i] = AKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ (row & 7)) << 1) + (lk & 1);
         }
 #pragma unroll
@@ -110,7 +114,20 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
         const double *st = lds + (t & 1) * DSTAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-            if constexpr (!PARTIAL) {
+            if constexpr (TRI != 0) {
+                double b[MMA_NJ];
+#pragma unroll
+                for (int i = 0; i < MMA_NJ; i++) b[i] = st[rb[kk][i]];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int g = 2 * i + wm;
+                    if (TRI == 1 ? t <= g : t >= g) {  // wave-uniform
+                        const double a = st[ra[kk][i]];
+#pragma unroll
+                        for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            } else if constexpr (!PARTIAL) {
                 double a[4], b[MMA_NJ];
 #pragma unroll
                 for (int i = 0; i < 4; i++) a[i] = st[ra[kk][i]];
