@@ -33,6 +33,7 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
     from pyimcom_amd import smoke
 
     g, tabs, C = smoke.oracle_tables(cfg, psfs, target)
+    C = float(C[0])  # one target PSF
     E = psfs.shape[0]
     tri = lambda i, j: (2 * E - i + 1) * i // 2 + j - i
     tab = np.zeros((E, E), np.int32)

@@ -19,21 +19,22 @@ def _hp(a):
 
 
 class BlockMaps:
-    """out_map [n_inframe, NsidePf, NsidePf] and the UC / Sigma / kappa / Tsum / Neff maps [NsidePf, NsidePf]
-    (float32, n_out = 1), T_weightmap [n_expo, n1P, n1P]."""
+    """The reference's block arrays (coadd.py:2031-2047), float32: out_map [n_out, n_inframe, NsidePf, NsidePf], the
+    UC / Sigma / kappa / Tsum / Neff maps [n_out, NsidePf, NsidePf], T_weightmap [n_out, n_expo, n1P, n1P]."""
 
-    def __init__(self, n1P, n2, fade, n_inframe, n_expo, ctx=None, device="cuda:0"):
-        self.n1P, self.n2, self.fade, self.n_inframe, self.n_expo = n1P, n2, fade, n_inframe, n_expo
+    def __init__(self, n1P, n2, fade, n_inframe, n_expo, ctx=None, device="cuda:0", n_out=1):
+        self.n1P, self.n2, self.fade, self.n_inframe, self.n_expo, self.n_out = n1P, n2, fade, n_inframe, n_expo, n_out
         self.nside = n1P * n2 + 2 * fade  # NsidePf (coadd.py:2029)
         self.ctx = ctx or default_context()
         dev = torch.device(device)
         f32 = torch.float32
-        self.out_map = torch.zeros((n_inframe, self.nside, self.nside), dtype=f32, device=dev)
-        self.maps = {k: torch.zeros((1, self.nside, self.nside), dtype=f32, device=dev) for k in ("UC", "Sigma", "kappa", "Tsum", "Neff")}
-        self.T_weightmap = torch.zeros((n_expo, n1P, n1P), dtype=f32, device=dev)
+        self.out_map = torch.zeros((n_out, n_inframe, self.nside, self.nside), dtype=f32, device=dev)
+        self.maps = {k: torch.zeros((n_out, self.nside, self.nside), dtype=f32, device=dev) for k in ("UC", "Sigma", "kappa", "Tsum", "Neff")}
+        self.T_weightmap = torch.zeros((n_out, n_expo, n1P, n1P), dtype=f32, device=dev)
 
     def add(self, res, jst, ist):
-        """Add a finished StampBatchResult; jst/ist = 1-based OutStamp indices of its stamps (coadd.py:1963)."""
+        """Add a finished batch: a StampBatchResult, or the list of n_out of them (StampBatch.results());
+        jst/ist = 1-based OutStamp indices of its stamps (coadd.py:1963)."""
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         jst = np.ascontiguousarray(jst, dtype=np.int32)
         ist = np.ascontiguousarray(ist, dtype=np.int32)
@@ -45,16 +46,19 @@ class BlockMaps:
             check(lib.imcom_block_accumulate(h, b, _hp(jst), _hp(ist), self.n2, self.fade, nlayer, _dp(src),
                                              1 if src.dtype == torch.float64 else 0, _dp(dst), self.nside))
 
-        acc(res.outimage, self.n_inframe, self.out_map)
-        acc(res.UC, 1, self.maps["UC"])
-        acc(res.Sigma, 1, self.maps["Sigma"])
-        acc(res.kappa, 1, self.maps["kappa"])
-        acc(res.Tsum_inpix, 1, self.maps["Tsum"])
-        acc(res.Neff, 1, self.maps["Neff"])
-        # T_weightmap[:, j_st-1, i_st-1] = Tsum_stamp (coadd.py:1981): plain indexed copy
+        results = list(res) if isinstance(res, (list, tuple)) else [res]
+        assert len(results) == self.n_out
         jj = torch.as_tensor(jst.astype(np.int64) - 1, device=self.T_weightmap.device)
         ii = torch.as_tensor(ist.astype(np.int64) - 1, device=self.T_weightmap.device)
-        self.T_weightmap[:, jj, ii] = res.Tsum_stamp[:, : self.n_expo].T.to(torch.float32)
+        for o, r in enumerate(results):
+            acc(r.outimage, self.n_inframe, self.out_map[o])
+            acc(r.UC, 1, self.maps["UC"][o])
+            acc(r.Sigma, 1, self.maps["Sigma"][o])
+            acc(r.kappa, 1, self.maps["kappa"][o])
+            acc(r.Tsum_inpix, 1, self.maps["Tsum"][o])
+            acc(r.Neff, 1, self.maps["Neff"][o])
+            # T_weightmap[:, j_st-1, i_st-1] = Tsum_stamp (coadd.py:1981): plain indexed copy
+            self.T_weightmap[o][:, jj, ii] = r.Tsum_stamp[:, : self.n_expo].T.to(torch.float32)
 
     COMPRESS = {"UC": (-5000, True), "Sigma": (-10000, False), "kappa": (-5000, True), "Tsum": (200000, False),
                 "Neff": (50000, True)}  # coefficient, unsigned (coadd.py:2249-2303)
@@ -74,8 +78,8 @@ class BlockMaps:
         recovered at the array edge, the others `postage_pad` stamps further in)."""
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         h = self.ctx.handle
-        check(lib.imcom_trapezoid_recover_f32(h, _dp(self.out_map), self.n_inframe, self.nside, self.nside, self.fade, 0, 0, 0, 0))
+        check(lib.imcom_trapezoid_recover_f32(h, _dp(self.out_map), self.n_out * self.n_inframe, self.nside, self.nside, self.fade, 0, 0, 0, 0))
         w = postage_pad * self.n2
         pads = [w * (s not in pad_sides) for s in "BTLR"]
         for m in self.maps.values():
-            check(lib.imcom_trapezoid_recover_f32(h, _dp(m), 1, self.nside, self.nside, self.fade, *pads))
+            check(lib.imcom_trapezoid_recover_f32(h, _dp(m), self.n_out, self.nside, self.nside, self.fade, *pads))

@@ -39,7 +39,8 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_
     order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables.  Returns the BlockMaps."""
     nst = n1P + 2
     assert pool.n_inst == nst * nst
-    maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device))
+    maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
+                     n_out=int(getattr(tables, "n_out", 1)))
     todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
     counts = np.diff(pool.inst_off)
     for c0 in range(0, len(todo), batch):
@@ -76,7 +77,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_
         sb = StampBatch.from_device(cfg, tables, n, x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep],
                                     [(i - 1) * cfg.n2 - cfg.fade for _, i in chunk], [(j - 1) * cfg.n2 - cfg.fade for j, _ in chunk],
                                     n_expo, ctx=tables.ctx, psf_slot=psf_slot, maps=maps_)
-        res = sb.run()
-        maps.add(res, [j for j, _ in chunk], [i for _, i in chunk])
+        sb.run()
+        maps.add(sb.results(), [j for j, _ in chunk], [i for _, i in chunk])
     maps.finalize(pad_sides, postage_pad)
     return maps

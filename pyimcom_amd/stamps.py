@@ -34,7 +34,9 @@ class PSFGroupTables:
 
     Mirrors PSFOvl(grp) (input self-overlap, triangle storage psfutil.py:1139-1175, 1270-1278),
     PSFOvl(grp, outgrp) (input-output, 1259-1265) and the output self-overlap value C (1283-1290).
-    Table stack order: the E(E+1)/2 self tables in triangle order, then the E input-output tables.
+    Table stack order: the E(E+1)/2 self tables in triangle order, then the E input-output tables of every target
+    PSF (target-major).  ``psf_out`` [n_out, nsamp, nsamp]: the reference solves every target on its own
+    (lakernel.py:121-128, kappa = kappaC * C of that target); ``Cs`` [n_out], ``C`` = Cs[0].
     """
 
     def __init__(self, psf_in, psf_out, nfft, ctx=None, device="cuda:0", amp_penalty=None):
@@ -47,22 +49,24 @@ class PSFGroupTables:
         dev = torch.device(device)
         as_dev = lambda a: (a.to(dev).contiguous() if torch.is_tensor(a)  # noqa: E731
                             else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev))
-        pin, pout = as_dev(psf_in), as_dev(psf_out[:1])
+        pin, pout = as_dev(psf_in), as_dev(psf_out)
+        O = self.n_out = pout.shape[0]
         ng = ns + 12
         self.ntri = E * (E + 1) // 2
-        self.tables = torch.empty((self.ntri + E, ng, ng), dtype=torch.float64, device=dev)
+        self.tables = torch.empty((self.ntri + O * E, ng, ng), dtype=torch.float64, device=dev)
         self._set_stream()
         pairs = np.array([(i, j) for i in range(E) for j in range(i, E)], dtype=np.int32)
         check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pin), E, ns, nfft, _hp(pairs), len(pairs), ampp,
                                     _dp(self.tables[: self.ntri])))
-        pairs = np.array([(i, 0) for i in range(E)], dtype=np.int32)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pout), 1, ns, nfft, _hp(pairs), E, ampp,
+        pairs = np.array([(i, o) for o in range(O) for i in range(E)], dtype=np.int32)
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pout), O, ns, nfft, _hp(pairs), len(pairs), ampp,
                                     _dp(self.tables[self.ntri :])))
-        cc = torch.empty((1, ng, ng), dtype=torch.float64, device=dev)
-        pairs = np.array([(0, 0)], dtype=np.int32)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pout), 1, _dp(pout), 1, ns, nfft, _hp(pairs), 1, ampp, _dp(cc)))
+        cc = torch.empty((O, ng, ng), dtype=torch.float64, device=dev)
+        pairs = np.array([(o, o) for o in range(O)], dtype=np.int32)
+        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pout), O, _dp(pout), O, ns, nfft, _hp(pairs), O, ampp, _dp(cc)))
         nc = ns // 2
-        self.C = float(cc[0, 6 + nc, 6 + nc].item())  # psfutil.py:1290
+        self.Cs = cc[:, 6 + nc, 6 + nc].cpu().numpy().astype(np.float64)  # psfutil.py:1290
+        self.C = float(self.Cs[0])
 
     @classmethod
     def from_images(cls, psf_images, yxco, target, nsamp, nfft, oversamp, psf_circ=False, psf_norm=False, ctx=None,
@@ -70,15 +74,17 @@ class PSFGroupTables:
         """The whole PSF side of a 2x2 stamp group on the device (PSFGrp.__init__ for the input group and for the
         output group, psfutil.py:615-671, then PSFOvl): ``psf_images`` [E, ny, nx] as returned by
         ``InImage.get_psf_pos``, ``yxco`` [E, 2, nsamp, nsamp] their sampling positions (psfutil.py:751-771, the
-        WCS part stays on the host), ``target`` = (outpsf, extrasmooth, use_filter) of the configuration."""
+        WCS part stays on the host), ``target`` = (outpsf, extrasmooth, use_filter) of the configuration, or a list of
+        such tuples (OUTPSF plus the cfg.outpsf_extra entries, psfutil.py:906-915)."""
         from . import psfs
 
         dev = torch.device(device)
         img = torch.as_tensor(np.ascontiguousarray(psf_images, dtype=np.float64), device=dev)
         co = torch.as_tensor(np.ascontiguousarray(yxco, dtype=np.float64), device=dev)
         psf_in = psfs.sample_psf(img, nsamp, co, psf_circ, psf_norm, ctx)
-        timg = psfs.get_outpsf(target[0], target[1], target[2], nsamp, oversamp, device=dev, ctx=ctx)
-        psf_out = psfs.sample_psf(timg[None], nsamp, None, psf_circ, psf_norm, ctx)
+        targets = [target] if isinstance(target[0], str) else list(target)
+        timg = torch.stack([psfs.get_outpsf(t[0], t[1], t[2], nsamp, oversamp, device=dev, ctx=ctx) for t in targets])
+        psf_out = psfs.sample_psf(timg, nsamp, None, psf_circ, psf_norm, ctx)
         return cls(psf_in, psf_out, nfft, ctx=ctx, device=device, amp_penalty=amp_penalty)
 
     def _set_stream(self):
@@ -108,6 +114,10 @@ class PSFGroupTables:
         io = np.arange(E, dtype=np.int32) + self.ntri
         return tab, pen, io
 
+    def io_map(self, o):
+        """io_tab of target PSF o (pair_maps returns the one of target 0)."""
+        return np.arange(self.n_psf, dtype=np.int32) + self.ntri + o * self.n_psf
+
 
 class BlockTables:
     """Overlap tables of a block whose PSFs vary from one 2x2 group of InStamps to the next (the reference's
@@ -132,16 +142,18 @@ class BlockTables:
         self.n_max = max(v.shape[0] for v in self.psf.values())
         self.n_psf = self.n_max
         self.n_blk_expo = 1 + max(max(v) for v in self.expo.values())
-        self.pout = torch.as_tensor(np.ascontiguousarray(psf_out[:1], dtype=np.float64), device=dev)
+        self.pout = torch.as_tensor(np.ascontiguousarray(psf_out, dtype=np.float64), device=dev)
+        O = self.n_out = self.pout.shape[0]
         amp = None if amp_penalty is None or 0.0 in tuple(amp_penalty) else np.array(amp_penalty, dtype=np.float64)
         self._amp = amp
         ng = self.nsamp + 12
         self.tables = torch.empty((capacity, ng, ng), dtype=torch.float64, device=dev)  # the arena
         self.index, self.used = {}, 0
-        cc = torch.empty((1, ng, ng), dtype=torch.float64, device=dev)
-        self._overlap(self.pout, self.pout, [(0, 0)], cc)
+        cc = torch.empty((O, ng, ng), dtype=torch.float64, device=dev)
+        self._overlap(self.pout, self.pout, [(o, o) for o in range(O)], cc)
         nc = self.nsamp // 2
-        self.C = float(cc[0, 6 + nc, 6 + nc].item())
+        self.Cs = cc[:, 6 + nc, 6 + nc].cpu().numpy().astype(np.float64)
+        self.C = float(self.Cs[0])
 
     def _overlap(self, p1, p2, pairs, out):
         pairs = np.array(pairs, dtype=np.int32)
@@ -156,7 +168,7 @@ class BlockTables:
         if key[0] == "self":
             return self._n(key[1]) * (self._n(key[1]) + 1) // 2
         if key[0] == "io":
-            return self._n(key[1])
+            return self.n_out * self._n(key[1])
         return self._n(key[1]) * self._n(key[2])
 
     def require(self, keys):
@@ -177,7 +189,7 @@ class BlockTables:
                 n = self._n(k[1])
                 self._overlap(self.psf[k[1]], self.psf[k[1]], [(i, j) for i in range(n) for j in range(i, n)], out)
             elif k[0] == "io":
-                self._overlap(self.psf[k[1]], self.pout, [(i, 0) for i in range(self._n(k[1]))], out)
+                self._overlap(self.psf[k[1]], self.pout, [(i, o) for o in range(self.n_out) for i in range(self._n(k[1]))], out)
             else:
                 self._overlap(self.psf[k[1]], self.psf[k[2]], [(i, j) for i in range(self._n(k[1])) for j in range(self._n(k[2]))], out)
             self.index[k] = off
@@ -192,20 +204,21 @@ class BlockTables:
 
     def stamp_maps(self, groups, flat_penalty, slots=4):
         """Maps of one stamp whose pixels belong to `groups` (list of <= `slots` distinct group keys): pair_tab
-        [P, P], pair_pen [P, P], io_tab [P] with P = slots * n_max, and lut [slots, n_blk_expo] = stamp-local PSF
+        [P, P], pair_pen [P, P], io_tab [P] ([n_out, P] with several target PSFs) with P = slots * n_max, and lut [slots, n_blk_expo] = stamp-local PSF
         index of a pixel of (position of its group in the list, block exposure), -1 where the group lacks the
         exposure.  Call require() first."""
         P = slots * self.n_max
         tab = np.full((P, P), -1, np.int32)
         pen = np.zeros((P, P))
-        io = np.zeros(P, np.int32)
+        io = np.zeros((self.n_out, P), np.int32)
         lut = np.full((slots, self.n_blk_expo), -1, np.int32)
         base = np.concatenate([[0], np.cumsum([self._n(g) for g in groups])]).astype(int)
         for la, ga in enumerate(groups):
             for k, e in enumerate(self.expo[ga]):
                 lut[la, e] = base[la] + k
             na = self._n(ga)
-            io[base[la] : base[la] + na] = self.index[("io", ga)] + np.arange(na)
+            for o in range(self.n_out):
+                io[o, base[la] : base[la] + na] = self.index[("io", ga)] + o * na + np.arange(na)
             for lb, gb in enumerate(groups):
                 nb = self._n(gb)
                 tri = lambda i, j: (2 * na - i + 1) * i // 2 + j - i  # noqa: E731  (psfutil.py:1175), same group only
@@ -222,11 +235,12 @@ class BlockTables:
                         if flat_penalty != 0.0:  # psfutil.py:1433, 1482-1486, 1705-1708
                             same = self.expo[ga][ka] == self.expo[gb][kb]
                             pen[a, b] = -flat_penalty / (na * nb) ** 0.5 + (flat_penalty if same else 0.0)
-        return tab, pen, io, lut
+        return tab, pen, (io[0] if self.n_out == 1 else io), lut
 
 
 @dataclass
 class StampBatchResult:
+    """Outputs of a batch for ONE target PSF (StampBatch.results() lists them for n_out > 1)."""
     Tt: torch.Tensor          # [batch, ldn, ldm] float32, input-pixel-major T (tapered when fade > 0)
     UC: torch.Tensor          # [batch, n2f, n2f] float32
     Sigma: torch.Tensor
@@ -248,7 +262,9 @@ class StampBatch:
     """A batch of stamps that share one PSF group, resident on one GPU.
 
     Upload once (constructor), then ``build()`` (A and B), ``solve()``, ``coadd()`` or ``run()`` for all
-    three; buffers are reused across calls so a timed loop allocates nothing.
+    three; buffers are reused across calls so a timed loop allocates nothing.  With n_out > 1 target PSFs
+    (``tables.n_out``) A is built once and B, the solve (kappa = kappaC * C of the target, lakernel.py:121-128) and
+    the coaddition run per target; every per-target buffer ``X_o`` has a leading target axis and ``X`` is target 0.
     """
 
     def __init__(self, cfg, stamps, tables: PSFGroupTables, ctx=None, device="cuda:0", ldn=None):
@@ -297,35 +313,45 @@ class StampBatch:
         self.psf = expo if psf_slot is None else psf_slot.contiguous()
         self.out_x0 = torch.as_tensor(out_x0, device=dev)
         self.out_y0 = torch.as_tensor(out_y0, device=dev)
+        O = self.n_out = int(getattr(tables, "n_out", 1))
         if maps is None:
             assert self.n_expo <= tables.n_psf
-            tab, pen, io = tables.pair_maps(cfg.flat_penalty)
+            tab, pen, _ = tables.pair_maps(cfg.flat_penalty)
             P = self.npsf = tables.n_psf
             self.pair_tab = torch.as_tensor(np.broadcast_to(tab, (B, P, P)).copy(), device=dev)
             self.pair_pen = torch.as_tensor(np.broadcast_to(pen, (B, P, P)).copy(), device=dev)
-            self.io_tab = torch.as_tensor(np.broadcast_to(io, (B, P)).copy(), device=dev)
+            io = np.stack([np.broadcast_to(tables.io_map(o), (B, P)) for o in range(O)])
         else:
             tab, pen, io = maps
             P = self.npsf = tab.shape[-1]
-            assert tab.shape == (B, P, P) and pen.shape == (B, P, P) and io.shape == (B, P)
+            io = np.asarray(io)
+            if io.ndim == 3 and io.shape[0] == B and O > 1:  # [B, n_out, P] as stacked from BlockTables.stamp_maps
+                io = io.transpose(1, 0, 2)
+            io = io.reshape(O, B, P)
+            assert tab.shape == (B, P, P) and pen.shape == (B, P, P)
             self.pair_tab = torch.as_tensor(np.ascontiguousarray(tab, dtype=np.int32), device=dev)
             self.pair_pen = torch.as_tensor(np.ascontiguousarray(pen, dtype=np.float64), device=dev)
-            self.io_tab = torch.as_tensor(np.ascontiguousarray(io, dtype=np.int32), device=dev)
+        self.io_tab_o = torch.as_tensor(np.ascontiguousarray(io, dtype=np.int32), device=dev)  # [n_out, B, P]
         self.geom = TableGeom(tables.nsamp, float(tables.nsamp // 2), float(cfg.dscale), float(cfg.flat_penalty))
-        self.Cs = np.full((B,), tables.C, dtype=np.float64)
+        Cs = np.asarray(getattr(tables, "Cs", [tables.C]), dtype=np.float64)
+        self.Cs_o = np.ascontiguousarray(np.broadcast_to(Cs[:, None], (O, B)))
         self.kappaC = np.ascontiguousarray(cfg.kappaC, dtype=np.float64)
         # device buffers
         self.A = torch.empty((B, self.ldn, self.ldn), dtype=f64, device=dev)
-        self.Bt = torch.empty((B, self.ldn, self.ldm), dtype=f64, device=dev)
-        self.Tt = torch.empty((B, self.ldn, self.ldm), dtype=f32, device=dev)
-        self.UC = torch.empty((B, self.m), dtype=f32, device=dev)
-        self.Sigma = torch.empty((B, self.m), dtype=f32, device=dev)
-        self.kappa = torch.empty((B, self.m), dtype=f32, device=dev)
-        self.outimage = torch.empty((B, cfg.n_inframe, self.m), dtype=f32, device=dev)
-        self.Tsum_stamp = torch.empty((B, self.n_expo), dtype=f64, device=dev)
-        self.Tsum_inpix = torch.empty((B, self.m), dtype=f64, device=dev)
-        self.Neff = torch.empty((B, self.m), dtype=f64, device=dev)
-        self.info = np.zeros((B,), np.int32)
+        self.Bt_o = torch.empty((O, B, self.ldn, self.ldm), dtype=f64, device=dev)
+        self.Tt_o = torch.empty((O, B, self.ldn, self.ldm), dtype=f32, device=dev)
+        self.UC_o = torch.empty((O, B, self.m), dtype=f32, device=dev)
+        self.Sigma_o = torch.empty((O, B, self.m), dtype=f32, device=dev)
+        self.kappa_o = torch.empty((O, B, self.m), dtype=f32, device=dev)
+        self.outimage_o = torch.empty((O, B, cfg.n_inframe, self.m), dtype=f32, device=dev)
+        self.Tsum_stamp_o = torch.empty((O, B, self.n_expo), dtype=f64, device=dev)
+        self.Tsum_inpix_o = torch.empty((O, B, self.m), dtype=f64, device=dev)
+        self.Neff_o = torch.empty((O, B, self.m), dtype=f64, device=dev)
+        self.info_o = np.zeros((O, B), np.int32)
+        # target 0 under the plain names
+        self.io_tab, self.Cs, self.info = self.io_tab_o[0], self.Cs_o[0], self.info_o[0]
+        for name in ("Bt", "Tt", "UC", "Sigma", "kappa", "outimage", "Tsum_stamp", "Tsum_inpix", "Neff"):
+            setattr(self, name, getattr(self, name + "_o")[0])
 
     def _stream(self):
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -337,30 +363,35 @@ class StampBatch:
         check(lib.imcom_build_A(h, self.batch, _hp(self.n), self.ldn, _dp(self.x), _dp(self.y), _dp(self.psf),
                                 _dp(self.tables.tables), self.tables.tables.shape[0], C.byref(self.geom),
                                 _dp(self.pair_tab), _dp(self.pair_pen), self.npsf, _dp(self.A)))
-        check(lib.imcom_build_B(h, self.batch, _hp(self.n), self.ldn, _dp(self.x), _dp(self.y), _dp(self.psf),
-                                _dp(self.tables.tables), self.tables.tables.shape[0], C.byref(self.geom),
-                                _dp(self.io_tab), self.npsf, _dp(self.out_x0), _dp(self.out_y0), self.n2f, self.ldm,
-                                _dp(self.Bt)))
+        for o in range(self.n_out):
+            check(lib.imcom_build_B(h, self.batch, _hp(self.n), self.ldn, _dp(self.x), _dp(self.y), _dp(self.psf),
+                                    _dp(self.tables.tables), self.tables.tables.shape[0], C.byref(self.geom),
+                                    _dp(self.io_tab_o[o]), self.npsf, _dp(self.out_x0), _dp(self.out_y0), self.n2f, self.ldm,
+                                    _dp(self.Bt_o[o])))
 
     def solve(self):
         """lakernel.CholKernel (lakernel.py:281-394) + the map taper of coadd.py:1118-1122."""
         self._stream()
+        for o in range(self.n_out):
+            self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o])
+
+    def _solve_target(self, Bt, Cs, Tt, UC, Sigma, kappa, info):
         cfg = self.cfg
         if cfg.kernel == "Eigen":
             # lakernel.EigenKernel (lakernel.py:141-223) on device pointers.  imcom_solve_eigen speaks the
             # reference layout (-B/2 as [m][N], T as [m][N]); torch only re-strides the buffers.
-            mB = self.Bt[:, :, : self.m].transpose(1, 2).contiguous()
+            mB = Bt[:, :, : self.m].transpose(1, 2).contiguous()
             T = torch.empty((self.batch, self.m, self.ldn), dtype=torch.float32, device=self.dev)
             check(lib.imcom_solve_eigen(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, _dp(self.A), _dp(mB),
-                                        _hp(self.Cs), _hp(self.kappaC), len(self.kappaC), float(cfg.uctarget),
-                                        float(cfg.sigmamax), 13, _dp(T), _dp(self.UC), _dp(self.Sigma), _dp(self.kappa),
-                                        _hp(self.info), 1))
-            self.Tt.zero_()
-            self.Tt[:, :, : self.m] = T.transpose(1, 2)
+                                        _hp(Cs), _hp(self.kappaC), len(self.kappaC), float(cfg.uctarget),
+                                        float(cfg.sigmamax), 13, _dp(T), _dp(UC), _dp(Sigma), _dp(kappa),
+                                        _hp(info), 1))
+            Tt.zero_()
+            Tt[:, :, : self.m] = T.transpose(1, 2)
         elif cfg.kernel in ("Iterative", "Empirical"):
             # lakernel.IterKernel / EmpirKernel (lakernel.py:533-805) on device pointers; the output pixel centres
             # are the integer grid starting at (out_y0, out_x0), the acceptance radius is INPAD in output pixels
-            mB = self.Bt[:, :, : self.m].transpose(1, 2).contiguous()
+            mB = Bt[:, :, : self.m].transpose(1, 2).contiguous()
             T = torch.empty((self.batch, self.m, self.ldn), dtype=torch.float32, device=self.dev)
             g = torch.arange(self.n2f, dtype=torch.float64, device=self.dev)
             oy = (self.out_y0[:, None, None] + g[None, :, None]).expand(self.batch, self.n2f, self.n2f)
@@ -369,35 +400,36 @@ class StampBatch:
             if cfg.kernel == "Iterative":
                 nv = len(self.kappaC)
                 check(lib.imcom_solve_iter(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, _dp(self.A), _dp(mB),
-                                           _hp(self.Cs), _hp(self.kappaC), nv, float(cfg.uctarget), float(cfg.sigmamax), _dp(yx),
+                                           _hp(Cs), _hp(self.kappaC), nv, float(cfg.uctarget), float(cfg.sigmamax), _dp(yx),
                                            _dp(self.y), _dp(self.x), float(cfg.rho), float(getattr(cfg, "iter_rtol", 1.5e-3)),
-                                           int(getattr(cfg, "iter_max", 30)), int(nv > 1), _dp(T), _dp(self.UC), _dp(self.Sigma),
-                                           _dp(self.kappa), 1))
+                                           int(getattr(cfg, "iter_max", 30)), int(nv > 1), _dp(T), _dp(UC), _dp(Sigma),
+                                           _dp(kappa), 1))
             else:
                 check(lib.imcom_solve_empir(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, _dp(self.A), _dp(mB),
-                                            _hp(self.Cs), float(self.kappaC[0]), _dp(yx), _dp(self.y), _dp(self.x), float(cfg.rho),
-                                            0, _dp(T), _dp(self.UC), _dp(self.Sigma), _dp(self.kappa), 1))
-            self.Tt.zero_()
-            self.Tt[:, :, : self.m] = T.transpose(1, 2)
+                                            _hp(Cs), float(self.kappaC[0]), _dp(yx), _dp(self.y), _dp(self.x), float(cfg.rho),
+                                            0, _dp(T), _dp(UC), _dp(Sigma), _dp(kappa), 1))
+            Tt.zero_()
+            Tt[:, :, : self.m] = T.transpose(1, 2)
         elif cfg.kernel != "Cholesky":
             raise NotImplementedError(f"resident path: no {cfg.kernel} kernel")
         else:
             check(lib.imcom_solve_chol_resident(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm,
-                                            _dp(self.A), _dp(self.Bt), _hp(self.Cs), _hp(self.kappaC), len(self.kappaC),
-                                            float(cfg.uctarget), float(cfg.sigmamax), _dp(self.Tt), _dp(self.UC),
-                                            _dp(self.Sigma), _dp(self.kappa), _hp(self.info)))
+                                            _dp(self.A), _dp(Bt), _hp(Cs), _hp(self.kappaC), len(self.kappaC),
+                                            float(cfg.uctarget), float(cfg.sigmamax), _dp(Tt), _dp(UC),
+                                            _dp(Sigma), _dp(kappa), _hp(info)))
         if cfg.fade > 0:
-            for t in (self.kappa, self.Sigma, self.UC):
+            for t in (kappa, Sigma, UC):
                 check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))
 
     def coadd(self):
         """OutStamp._perform_coaddition (coadd.py:1294-1363)."""
         self._stream()
         cfg = self.cfg
-        check(lib.imcom_coadd_epilogue(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, self.n2f,
-                                       cfg.fade, cfg.n2, _dp(self.Tt), _dp(self.indata), cfg.n_inframe, _dp(self.expo),
-                                       self.n_expo, _dp(self.outimage), _dp(self.Tsum_stamp), _dp(self.Tsum_inpix),
-                                       _dp(self.Neff)))
+        for o in range(self.n_out):
+            check(lib.imcom_coadd_epilogue(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, self.n2f,
+                                           cfg.fade, cfg.n2, _dp(self.Tt_o[o]), _dp(self.indata), cfg.n_inframe, _dp(self.expo),
+                                           self.n_expo, _dp(self.outimage_o[o]), _dp(self.Tsum_stamp_o[o]), _dp(self.Tsum_inpix_o[o]),
+                                           _dp(self.Neff_o[o])))
 
     def run(self):
         self.build()
@@ -405,8 +437,12 @@ class StampBatch:
         self.coadd()
         return self.result()
 
-    def result(self):
+    def result(self, o=0):
+        """Outputs for target PSF o (the reference's leading n_out axis, one StampBatchResult per target)."""
         s2 = (self.batch, self.n2f, self.n2f)
-        return StampBatchResult(self.Tt, self.UC.view(s2), self.Sigma.view(s2), self.kappa.view(s2),
-                                self.outimage.view(self.batch, self.cfg.n_inframe, self.n2f, self.n2f), self.Tsum_stamp,
-                                self.Tsum_inpix.view(s2), self.Neff.view(s2), self.info.copy(), self.n.copy())
+        return StampBatchResult(self.Tt_o[o], self.UC_o[o].view(s2), self.Sigma_o[o].view(s2), self.kappa_o[o].view(s2),
+                                self.outimage_o[o].view(self.batch, self.cfg.n_inframe, self.n2f, self.n2f), self.Tsum_stamp_o[o],
+                                self.Tsum_inpix_o[o].view(s2), self.Neff_o[o].view(s2), self.info_o[o].copy(), self.n.copy())
+
+    def results(self):
+        return [self.result(o) for o in range(self.n_out)]

@@ -36,6 +36,7 @@ class WorkloadConfig:
     extrasmooth: float = 0.934  # target Gaussian sigma in native pixels
     mask_frac: float = 1e-3
     psf_sigma: float = 0.9      # Gaussian input PSF width, native pixels (cfg-1: 0.9 + 0.05 e)
+    n_out: int = 1              # target PSFs (OUTPSF + cfg.outpsf_extra); target k is a Gaussian of width extrasmooth * (1 + k/4)
 
     @property
     def n2f(self):
@@ -124,7 +125,7 @@ def _airy_psf(cfg, e1=0.0, e2=0.0):
 
 
 def make_psfs(cfg, n_expo, seed=20260723):
-    """Sampled input PSFs [E, nsamp, nsamp] (PSFGrp.psf_arr, psfutil.py:838) and the target PSF [1, nsamp, nsamp]."""
+    """Sampled input PSFs [E, nsamp, nsamp] (PSFGrp.psf_arr, psfutil.py:838) and the target PSFs [n_out, nsamp, nsamp]."""
     rng = np.random.default_rng(seed)
     psfs = np.zeros((n_expo, cfg.nsamp, cfg.nsamp))
     for e in range(n_expo):
@@ -133,7 +134,7 @@ def make_psfs(cfg, n_expo, seed=20260723):
         else:
             ang = rng.uniform(0, np.pi)
             psfs[e] = _airy_psf(cfg, 0.02 * np.cos(2 * ang), 0.02 * np.sin(2 * ang))
-    target = _gauss_psf(cfg, cfg.extrasmooth * cfg.oversamp)[None]
+    target = np.stack([_gauss_psf(cfg, cfg.extrasmooth * (1.0 + 0.25 * k) * cfg.oversamp) for k in range(cfg.n_out)])
     return psfs, target
 
 

@@ -43,10 +43,10 @@ def test_block_maps_vs_oracle():
     def close(a, b):
         return np.abs(a - b).max() <= 4e-7 * np.abs(b).max()
 
-    assert close(bm.out_map.cpu().numpy(), ref_out[0])
+    assert close(bm.out_map[0].cpu().numpy(), ref_out[0])
     for name in ref:
         assert close(bm.maps[name].cpu().numpy(), ref[name]), name
-    tw = bm.T_weightmap.cpu().numpy()
+    tw = bm.T_weightmap[0].cpu().numpy()
     assert np.allclose(tw[:, 1, 2], res.Tsum_stamp[1 * n1P + 2].cpu().numpy().astype(np.float32))
     bm.finalize(pad_sides="BL", postage_pad=1)
     torch.cuda.synchronize()
@@ -55,7 +55,7 @@ def test_block_maps_vs_oracle():
     for name in ref:
         orc.trapezoid_recover(ref[name], cfg.fade, (0, w, 0, w))
         assert close(bm.maps[name].cpu().numpy(), ref[name]), name
-    assert close(bm.out_map.cpu().numpy(), ref_out[0])
+    assert close(bm.out_map[0].cpu().numpy(), ref_out[0])
     # the taper is a partition of unity: s_k + s_(2f+1-k) = 1, which is what makes the overlap-add exact
     s = np.arange(1, 2 * cfg.fade + 1) / (2 * cfg.fade + 1.0)
     s = s - np.sin(2 * np.pi * s) / (2 * np.pi)

@@ -86,3 +86,33 @@ def test_resident_path_many_input_layers():
 
     cfg = dataclasses.replace(synth.CONFIGS["small"], n_inframe=6)
     smoke.check_batch(cfg, n_stamps=2)
+
+
+def test_two_target_psfs_vs_oracle():
+    """n_out = 2 (OUTPSF plus one cfg.outpsf_extra entry): the reference solves every target on its own with
+    kappa = kappaC * C of that target (lakernel.py:121-128); A is shared.  Every output of both targets against the
+    oracle, and the two targets must really differ."""
+    import dataclasses
+
+    import torch
+
+    from pyimcom_amd import smoke, synth
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    cfg = dataclasses.replace(synth.CONFIGS["tiny"], name="tiny2", n_out=2, fade=1)
+    rep = smoke.check_batch(cfg, n_stamps=2, verbose=True)
+    assert "stamp1.target1" in rep
+    stamps = [synth.make_stamp(cfg, i) for i in range(2)]
+    psfs, target = synth.make_psfs(cfg, max(s.n_expo for s in stamps))
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    assert tabs.n_out == 2 and abs(tabs.Cs[0] - tabs.Cs[1]) > 0.05 * tabs.Cs[0]
+    sb = StampBatch(cfg, stamps, tabs)
+    sb.run()
+    torch.cuda.synchronize()
+    r0, r1 = sb.results()
+    assert (r0.outimage - r1.outimage).abs().max() > 1e-3 * r0.outimage.abs().max()
+    # target 0 of the pair == the single-target run, bit for bit
+    one = StampBatch(cfg, stamps, PSFGroupTables(psfs, target[:1], cfg.nfft)).run()
+    torch.cuda.synchronize()
+    for name in ("UC", "Sigma", "kappa", "outimage", "Tsum_inpix", "Neff"):
+        assert torch.equal(getattr(one, name), getattr(r0, name)), name
