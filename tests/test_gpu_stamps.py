@@ -116,3 +116,42 @@ def test_two_target_psfs_vs_oracle():
     torch.cuda.synchronize()
     for name in ("UC", "Sigma", "kappa", "outimage", "Tsum_inpix", "Neff"):
         assert torch.equal(getattr(one, name), getattr(r0, name)), name
+
+
+def test_empty_stamp_in_resident_batch():
+    """A stamp without input pixels inside a resident batch (block corners with every neighbour masked): the
+    reference's N == 0 case (lakernel.py:110-119: UC = 1, Sigma = 0, kappa = 1, T empty) next to a normal stamp,
+    which must come out exactly as it does alone."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    cfg = synth.CONFIGS["tiny"]
+    st = synth.make_stamp(cfg, 3)
+    psfs, target = synth.make_psfs(cfg, st.n_expo)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    alone = StampBatch(cfg, [st], tabs).run()
+    torch.cuda.synchronize()
+    ldn = alone.Tt.shape[1]
+    dev = alone.Tt.device
+    x = torch.zeros((2, ldn), dtype=torch.float64, device=dev)
+    y = torch.zeros_like(x)
+    expo = torch.zeros((2, ldn), dtype=torch.int32, device=dev)
+    indata = torch.zeros((2, cfg.n_inframe, ldn), dtype=torch.float32, device=dev)
+    x[1, : st.n], y[1, : st.n] = torch.as_tensor(st.x, device=dev), torch.as_tensor(st.y, device=dev)
+    expo[1, : st.n] = torch.as_tensor(st.expo, device=dev)
+    indata[1, :, : st.n] = torch.as_tensor(st.indata, device=dev)
+    sb = StampBatch.from_device(cfg, tabs, [0, st.n], x, y, expo, indata, [st.out_x0] * 2, [st.out_y0] * 2, st.n_expo)
+    res = sb.run()
+    torch.cuda.synchronize()
+    from oracle import oracle as orc
+
+    ones = np.ones((cfg.n2f, cfg.n2f), np.float32)
+    orc.trapezoid(ones, cfg.fade)  # the maps are tapered like any other stamp's (coadd.py:1118-1122)
+    assert np.array_equal(res.UC[0].cpu().numpy(), ones) and np.array_equal(res.kappa[0].cpu().numpy(), ones)
+    assert torch.all(res.Sigma[0] == 0)
+    assert torch.all(res.outimage[0] == 0) and torch.all(res.Tsum_inpix[0] == 0) and torch.all(res.Tsum_stamp[0] == 0)
+    assert torch.all(res.Tt[0] == 0)
+    for name in ("UC", "Sigma", "kappa", "outimage", "Tsum_inpix", "Neff", "Tsum_stamp"):
+        assert torch.equal(getattr(res, name)[1], getattr(alone, name)[0]), name
