@@ -425,6 +425,8 @@ __device__ __forceinline__ void taper_factors(int iy, int ix, int n2f, int fade,
 // exposures would not leave room in LDS), four row groups per block.
 // The per-exposure sums ride in registers while the exposure index of the rows stays the same (pixels are ordered
 // InStamp by InStamp, exposure-major inside) and are flushed to LDS when it changes.
+constexpr int EPI_U = 4;  // rows in flight per thread
+
 template <int CPT>
 __global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__ Tt, int ldn, int ldm, int m,
                                                              int n2f, int fade, const int *__restrict__ n,
@@ -463,37 +465,55 @@ __global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__
     int cur = -1;
     const int *ex = expo + (long)s * ldn;
     if (live) {
-        for (int i = rg; i < ns; i += 4) {
-            float t4[CPT];
-            if constexpr (CPT == 4) {
-                const float4 tv = *(const float4 *)(Tt + base + (long)i * ldm + a0);
-                t4[0] = tv.x; t4[1] = tv.y; t4[2] = tv.z; t4[3] = tv.w;
-            } else t4[0] = Tt[base + (long)i * ldm + a0];
-            if (fade > 0 && first) {
+        // the rows are independent loads: EPI_U of them (and their exposure / pixel values) are fetched before any is
+        // consumed, so that a wave has several 1 KB requests in flight; the sums run in the same order as before
+        for (int i0 = rg; i0 < ns; i0 += 4 * EPI_U) {
+            float tl[EPI_U][CPT], xl[EPI_U][EPI_MAXF];
+            int el[EPI_U];
 #pragma unroll
-                for (int q = 0; q < CPT; q++)
+            for (int u = 0; u < EPI_U; u++) {
+                const int i = min(i0 + 4 * u, ns - 1);
+                if constexpr (CPT == 4) {
+                    const float4 tv = *(const float4 *)(Tt + base + (long)i * ldm + a0);
+                    tl[u][0] = tv.x; tl[u][1] = tv.y; tl[u][2] = tv.z; tl[u][3] = tv.w;
+                } else tl[u][0] = Tt[base + (long)i * ldm + a0];
+                el[u] = ex[i];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) t4[q] = (float)((double)t4[q] * tf[q][k]);
-                if constexpr (CPT == 4) *(float4 *)(Tt + base + (long)i * ldm + a0) = make_float4(t4[0], t4[1], t4[2], t4[3]);
-                else Tt[base + (long)i * ldm + a0] = t4[0];
-            }
-            const int e = ex[i];
-            if (e != cur) {
-                if (cur >= 0)
-#pragma unroll
-                    for (int q = 0; q < CPT; q++) accs[(cur * 256 + threadIdx.x) * CPT + q] += racc[q];
-#pragma unroll
-                for (int q = 0; q < CPT; q++) racc[q] = 0.0;
-                cur = e;
+                for (int f = 0; f < EPI_MAXF; f++) xl[u][f] = f < nf ? indata[((long)s * n_inframe + f0 + f) * ldn + i] : 0.0f;
             }
 #pragma unroll
-            for (int q = 0; q < CPT; q++) racc[q] += (double)t4[q];
+            for (int u = 0; u < EPI_U; u++) {
+                const int i = i0 + 4 * u;
+                if (i >= ns) break;
+                float t4[CPT];
 #pragma unroll
-            for (int f = 0; f < EPI_MAXF; f++) {
-                if (f < nf) {
-                    const double x = (double)indata[((long)s * n_inframe + f0 + f) * ldn + i];
+                for (int q = 0; q < CPT; q++) t4[q] = tl[u][q];
+                if (fade > 0 && first) {
 #pragma unroll
-                    for (int q = 0; q < CPT; q++) oacc[f][q] += (double)t4[q] * x;
+                    for (int q = 0; q < CPT; q++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) t4[q] = (float)((double)t4[q] * tf[q][k]);
+                    if constexpr (CPT == 4) *(float4 *)(Tt + base + (long)i * ldm + a0) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                    else Tt[base + (long)i * ldm + a0] = t4[0];
+                }
+                const int e = el[u];
+                if (e != cur) {
+                    if (cur >= 0)
+#pragma unroll
+                        for (int q = 0; q < CPT; q++) accs[(cur * 256 + threadIdx.x) * CPT + q] += racc[q];
+#pragma unroll
+                    for (int q = 0; q < CPT; q++) racc[q] = 0.0;
+                    cur = e;
+                }
+#pragma unroll
+                for (int q = 0; q < CPT; q++) racc[q] += (double)t4[q];
+#pragma unroll
+                for (int f = 0; f < EPI_MAXF; f++) {
+                    if (f < nf) {
+                        const double x = (double)xl[u][f];
+#pragma unroll
+                        for (int q = 0; q < CPT; q++) oacc[f][q] += (double)t4[q] * x;
+                    }
                 }
             }
         }
