@@ -5,7 +5,7 @@
 //
 // Design (gfx950): one 512-thread workgroup (8 waves, 2x4) owns a 128x128 output tile; each wave accumulates a
 // 64x32 sub-tile as 4x2 v_mfma_f64_16x16x4_f64 tiles (64 accumulator VGPRs, four waves per SIMD resident).
-// Operand slices of k = 8 stream global -> LDS by LDS-DMA through a ring of four stages (mma_dma.h).
+// Operand slices of k = 16 stream global -> LDS by LDS-DMA through a double buffer (mma_dma.h).
 // fp64 MFMA runs at the fp64 vector rate on gfx950, so the point of MFMA here is operand reuse, not a higher peak.
 #include "common.h"
 #include "mma_dma.h"
