@@ -12,6 +12,9 @@
 // O(n^2 log n); for the <= 28 tables of a 2x2 stamp group this is ~50 GFlop, amortised over the
 // stamps that share the group.  (A butterfly FFT would do less work; this form is exact to fp64
 // rounding and reuses the one hot GEMM kernel -- noted in DESIGN.md as the next thing to replace.)
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 #include "launchers.h"
 
@@ -104,6 +107,267 @@ __global__ void crop_table_kernel(const double *__restrict__ win, int Wp, int ns
     tables[((long)t * ng + r) * ng + c] = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Butterfly path: mixed-radix Stockham FFTs in LDS (radices 4, 2, 3, 5), used whenever nfft factors into them and
+// the lines fit (nfft <= 1024); the dense-DFT GEMM form above stays as the general fallback and as an independent
+// cross-check (IMCOM_PSF_OVERLAP=gemm).  A workgroup transforms FFT_L lines at once, all in one LDS buffer: in
+// every stage each thread first reads all of its butterflies into registers, then -- after a barrier -- writes
+// them back in Stockham order, so no second buffer and no digit reversal are needed.
+//   forward:  rows two-for-one (two real PSF rows ride as one complex line), then columns on tiles of FFT_L
+//   inverse:  columns of R1 conj(R2) (the product is formed on load), kept rows only; then rows two-for-one from
+//             the Hermitian half back to two real window rows, rolled by nc and cropped on store.
+constexpr int FFT_L = 4;       // lines per workgroup
+constexpr int FFT_MAXIT = 8;   // butterflies per thread and stage (nfft * FFT_L / (radix * 256) <= 8)
+constexpr int FFT_MAXN = 1024;
+
+struct FftPlan { int n, nst, radix[12]; };
+
+typedef double2 cplx;
+__device__ __forceinline__ cplx cmulf(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+template <int R, bool INV> __device__ __forceinline__ void small_dft(cplx (&v)[R]);
+template <> __device__ __forceinline__ void small_dft<2, false>(cplx (&v)[2])
+{ const cplx a = v[0], b = v[1]; v[0] = make_double2(a.x + b.x, a.y + b.y); v[1] = make_double2(a.x - b.x, a.y - b.y); }
+template <> __device__ __forceinline__ void small_dft<2, true>(cplx (&v)[2]) { small_dft<2, false>(v); }
+template <bool INV> __device__ __forceinline__ void dft4(cplx (&v)[4])
+{
+    const cplx t0 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
+    const cplx t2 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y), d = make_double2(v[1].x - v[3].x, v[1].y - v[3].y);
+    const cplx t3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);  // d * (+i) or d * (-i)
+    v[0] = make_double2(t0.x + t2.x, t0.y + t2.y);
+    v[2] = make_double2(t0.x - t2.x, t0.y - t2.y);
+    v[1] = make_double2(t1.x + t3.x, t1.y + t3.y);
+    v[3] = make_double2(t1.x - t3.x, t1.y - t3.y);
+}
+template <> __device__ __forceinline__ void small_dft<4, false>(cplx (&v)[4]) { dft4<false>(v); }
+template <> __device__ __forceinline__ void small_dft<4, true>(cplx (&v)[4]) { dft4<true>(v); }
+template <bool INV> __device__ __forceinline__ void dft3(cplx (&v)[3])
+{
+    const double s3 = INV ? 0.8660254037844386 : -0.8660254037844386;  // sin(-+ 2 pi / 3)
+    const cplx t = make_double2(v[1].x + v[2].x, v[1].y + v[2].y), u = make_double2(v[1].x - v[2].x, v[1].y - v[2].y);
+    const cplx m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y), iu = make_double2(-s3 * u.y, s3 * u.x);  // i s3 u
+    v[0] = make_double2(v[0].x + t.x, v[0].y + t.y);
+    v[1] = make_double2(m.x + iu.x, m.y + iu.y);
+    v[2] = make_double2(m.x - iu.x, m.y - iu.y);
+}
+template <> __device__ __forceinline__ void small_dft<3, false>(cplx (&v)[3]) { dft3<false>(v); }
+template <> __device__ __forceinline__ void small_dft<3, true>(cplx (&v)[3]) { dft3<true>(v); }
+template <bool INV> __device__ __forceinline__ void dft5(cplx (&v)[5])
+{
+    // y_u = sum_t v_t w^(u t), w = exp(-+ 2 pi i / 5)
+    const double c1 = 0.30901699437494745, c2 = -0.8090169943749475;
+    const double s1 = INV ? 0.9510565162951535 : -0.9510565162951535, s2 = INV ? 0.5877852522924731 : -0.5877852522924731;
+    const cplx a = make_double2(v[1].x + v[4].x, v[1].y + v[4].y), b = make_double2(v[1].x - v[4].x, v[1].y - v[4].y);
+    const cplx c = make_double2(v[2].x + v[3].x, v[2].y + v[3].y), d = make_double2(v[2].x - v[3].x, v[2].y - v[3].y);
+    const cplx m1 = make_double2(v[0].x + c1 * a.x + c2 * c.x, v[0].y + c1 * a.y + c2 * c.y);
+    const cplx m2 = make_double2(v[0].x + c2 * a.x + c1 * c.x, v[0].y + c2 * a.y + c1 * c.y);
+    const cplx n1 = make_double2(-(s1 * b.y + s2 * d.y), s1 * b.x + s2 * d.x);  // i (s1 b + s2 d)
+    const cplx n2 = make_double2(-(s2 * b.y - s1 * d.y), s2 * b.x - s1 * d.x);  // i (s2 b - s1 d)
+    v[0] = make_double2(v[0].x + a.x + c.x, v[0].y + a.y + c.y);
+    v[1] = make_double2(m1.x + n1.x, m1.y + n1.y);
+    v[4] = make_double2(m1.x - n1.x, m1.y - n1.y);
+    v[2] = make_double2(m2.x + n2.x, m2.y + n2.y);
+    v[3] = make_double2(m2.x - n2.x, m2.y - n2.y);
+}
+template <> __device__ __forceinline__ void small_dft<5, false>(cplx (&v)[5]) { dft5<false>(v); }
+template <> __device__ __forceinline__ void small_dft<5, true>(cplx (&v)[5]) { dft5<true>(v); }
+
+// one Stockham stage of radix R on FFT_L lines of length n in `buf` ([line][n]); Ns = product of the earlier radices;
+// tw[k] = exp(-2 pi i k / n)
+template <int R, bool INV>
+__device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *__restrict__ tw)
+{
+    const int nb = n / R, total = nb * FFT_L, step = n / (Ns * R);
+    cplx v[FFT_MAXIT][R];
+#pragma unroll
+    for (int it = 0; it < FFT_MAXIT; it++) {
+        const int b = threadIdx.x + it * 256;
+        if (b < total) {
+            const int line = b / nb, j = b - line * nb, k = j % Ns;
+            const cplx *x = buf + line * n;
+#pragma unroll
+            for (int t = 0; t < R; t++) {
+                cplx a = x[j + t * nb];
+                if (t > 0) {
+                    cplx w = tw[t * k * step];
+                    if (INV) w.y = -w.y;
+                    a = cmulf(a, w);
+                }
+                v[it][t] = a;
+            }
+            small_dft<R, INV>(v[it]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < FFT_MAXIT; it++) {
+        const int b = threadIdx.x + it * 256;
+        if (b < total) {
+            const int line = b / nb, j = b - line * nb, k = j % Ns;
+            cplx *x = buf + line * n + (j - k) * R + k;
+#pragma unroll
+            for (int u = 0; u < R; u++) x[u * Ns] = v[it][u];
+        }
+    }
+    __syncthreads();
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft_lines(cplx *buf, const FftPlan &pl, const cplx *__restrict__ tw)
+{
+    int Ns = 1;
+    for (int st = 0; st < pl.nst; st++) {
+        const int r = pl.radix[st];
+        if (r == 4) fft_stage<4, INV>(buf, pl.n, Ns, tw);
+        else if (r == 2) fft_stage<2, INV>(buf, pl.n, Ns, tw);
+        else if (r == 3) fft_stage<3, INV>(buf, pl.n, Ns, tw);
+        else fft_stage<5, INV>(buf, pl.n, Ns, tw);
+        Ns *= r;
+    }
+}
+
+__global__ void fft_twiddle_kernel(int n, cplx *__restrict__ tw)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double c, s;
+    twiddle(k, n, &c, &s);
+    tw[k] = make_double2(c, -s);
+}
+
+// forward, along x: rows 2l, 2l+1 of PSF p as one complex line; Y1[p][row][kx], kx < nh
+__global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restrict__ psf, int ns, FftPlan pl,
+                                                           const cplx *__restrict__ tw, cplx *__restrict__ Y1)
+{
+    extern __shared__ cplx fbuf[];
+    const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y;
+    const double *img = psf + (long)p * ns * ns;
+    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
+        const int line = e / n, x = e - line * n, r0 = 2 * (blockIdx.x * FFT_L + line);
+        double re = 0.0, im = 0.0;
+        if (x < ns) {
+            if (r0 < ns) re = img[(long)r0 * ns + x];
+            if (r0 + 1 < ns) im = img[(long)(r0 + 1) * ns + x];
+        }
+        fbuf[e] = make_double2(re, im);
+    }
+    __syncthreads();
+    fft_lines<false>(fbuf, pl, tw);
+    for (int e = threadIdx.x; e < FFT_L * nh; e += 256) {
+        const int line = e / nh, k = e - line * nh, r0 = 2 * (blockIdx.x * FFT_L + line);
+        if (r0 >= ns) continue;
+        const cplx zk = fbuf[line * n + k], zm = fbuf[line * n + (n - k) % n];
+        Y1[((long)p * ns + r0) * nh + k] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        if (r0 + 1 < ns) Y1[((long)p * ns + r0 + 1) * nh + k] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+    }
+}
+
+// forward, along y: FFT_L columns of Y1[p] (rows >= ns are zero) -> R[p][ky][kx]
+__global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restrict__ Y1, int ns, FftPlan pl,
+                                                           const cplx *__restrict__ tw, cplx *__restrict__ R)
+{
+    extern __shared__ cplx fbuf[];
+    const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y, kx0 = blockIdx.x * FFT_L;
+    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
+        const int y = e / FFT_L, c = e - y * FFT_L;
+        cplx v = make_double2(0.0, 0.0);
+        if (y < ns && kx0 + c < nh) v = Y1[((long)p * ns + y) * nh + kx0 + c];
+        fbuf[c * n + y] = v;
+    }
+    __syncthreads();
+    fft_lines<false>(fbuf, pl, tw);
+    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
+        const int ky = e / FFT_L, c = e - ky * FFT_L;
+        if (kx0 + c < nh) R[((long)p * n + ky) * nh + kx0 + c] = fbuf[c * n + ky];
+    }
+}
+
+// inverse, along y: FFT_L columns of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][y'][kx] for the
+// kept rows y' < ns (source row (y' - nc) mod n: the roll of psfutil.py:1225-1232)
+__global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restrict__ R, const int *__restrict__ pairs, int ns,
+                                                           FftPlan pl, const cplx *__restrict__ tw, double amp0, double amps,
+                                                           cplx *__restrict__ V)
+{
+    extern __shared__ cplx fbuf[];
+    const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, kx0 = blockIdx.x * FFT_L, nc = ns / 2;
+    const cplx *R1 = R + (long)pairs[2 * t] * n * nh, *R2 = R + (long)pairs[2 * t + 1] * n * nh;
+    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
+        const int ky = e / FFT_L, c = e - ky * FFT_L, kx = kx0 + c;
+        cplx z = make_double2(0.0, 0.0);
+        if (kx < nh) {
+            const cplx a = R1[(long)ky * nh + kx], b = R2[(long)ky * nh + kx];
+            double w2 = 1.0;
+            if (amp0 != 0.0) {
+                double uy = (double)ky / (double)n, ux = (double)kx / (double)n;
+                if (uy > 0.5) uy -= 1.0;
+                if (ux > 0.5) ux -= 1.0;
+                const double w = 1.0 + amp0 * exp(-2.0 * M_PI * M_PI * (ux * ux + uy * uy) * (amps * amps));
+                w2 = w * w;
+            }
+            z = make_double2((a.x * b.x + a.y * b.y) * w2, (a.y * b.x - a.x * b.y) * w2);
+        }
+        fbuf[c * n + ky] = z;
+    }
+    __syncthreads();
+    fft_lines<true>(fbuf, pl, tw);
+    for (int e = threadIdx.x; e < FFT_L * ns; e += 256) {
+        const int yp = e / FFT_L, c = e - yp * FFT_L;
+        if (kx0 + c < nh) V[((long)t * ns + yp) * nh + kx0 + c] = fbuf[c * n + (yp - nc + n) % n];
+    }
+}
+
+// inverse, along x: window rows 2l, 2l+1 of pair t from their Hermitian halves as one complex line; the real and the
+// imaginary part of the result are the two rows.  numpy's c2r ignores the imaginary parts of the DC and Nyquist
+// bins; so does this.  Stored rolled by nc, cropped to ns, scaled by 1/n^2, inside the 6-sample zero border.
+__global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restrict__ V, int ns, FftPlan pl,
+                                                           const cplx *__restrict__ tw, double *__restrict__ tables)
+{
+    extern __shared__ cplx fbuf[];
+    const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, nc = ns / 2, ng = ns + 12;
+    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
+        const int line = e / n, k = e - line * n, r0 = 2 * (blockIdx.x * FFT_L + line);
+        const int kk = k < nh ? k : n - k;
+        const bool edge = kk == 0 || 2 * kk == n;
+        cplx a = make_double2(0.0, 0.0), b = a;
+        if (r0 < ns) a = V[((long)t * ns + r0) * nh + kk];
+        if (r0 + 1 < ns) b = V[((long)t * ns + r0 + 1) * nh + kk];
+        if (k >= nh) { a.y = -a.y; b.y = -b.y; }
+        if (edge) { a.y = 0.0; b.y = 0.0; }
+        fbuf[e] = make_double2(a.x - b.y, a.y + b.x);
+    }
+    __syncthreads();
+    fft_lines<true>(fbuf, pl, tw);
+    const double scale = 1.0 / ((double)n * (double)n);
+    for (int e = threadIdx.x; e < FFT_L * ns; e += 256) {
+        const int line = e / ns, xp = e - line * ns, r0 = 2 * (blockIdx.x * FFT_L + line);
+        if (r0 >= ns) continue;
+        const cplx z = fbuf[line * n + (xp - nc + n) % n];
+        tables[((long)t * ng + 6 + r0) * ng + 6 + xp] = z.x * scale;
+        if (r0 + 1 < ns) tables[((long)t * ng + 6 + r0 + 1) * ng + 6 + xp] = z.y * scale;
+    }
+}
+
+// nfft = product of radices 4, 2, 3, 5 with lines that fit the butterfly kernels?
+static bool fft_plan(int n, FftPlan *pl)
+{
+    if (n > FFT_MAXN) return false;
+    pl->n = n;
+    pl->nst = 0;
+    int r = n;
+    const int cand[4] = {4, 2, 3, 5};
+    for (int ci = 0; ci < 4; ci++)
+        while (r % cand[ci] == 0 && !(cand[ci] == 4 && r % 4 != 0)) {
+            if (pl->nst >= 12) return false;
+            pl->radix[pl->nst++] = cand[ci];
+            r /= cand[ci];
+        }
+    if (r != 1) return false;
+    for (int st = 0; st < pl->nst; st++)
+        if ((n / pl->radix[st]) * FFT_L > FFT_MAXIT * 256) return false;
+    return true;
+}
+
 static int up(int v, int a) { return (v + a - 1) / a * a; }
 
 }  // namespace imcom
@@ -122,6 +386,45 @@ extern "C" int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, con
     for (int t = 0; t < npairs; t++)
         IMCOM_REQUIRE(pairs_host[2 * t] >= 0 && pairs_host[2 * t] < n1 && pairs_host[2 * t + 1] >= 0 && pairs_host[2 * t + 1] < n2,
                       "pair %d out of range", t);
+    FftPlan pl;
+    static const bool force_gemm = getenv("IMCOM_PSF_OVERLAP") && !strcmp(getenv("IMCOM_PSF_OVERLAP"), "gemm");
+    if (!force_gemm && fft_plan(nfft, &pl)) {
+        const int nh_ = nfft / 2 + 1, ng_ = nsamp + 12;
+        const bool same_ = (psf1 == psf2 && n1 == n2);
+        const int npsf_ = same_ ? n1 : n1 + n2;
+        size_t total_ = 0;
+        auto plan_ = [&](size_t b) { total_ = align_up(total_, 256) + b; };
+        plan_((size_t)nfft * 16);
+        plan_((size_t)npsf_ * nsamp * nh_ * 16);
+        plan_((size_t)npsf_ * nfft * nh_ * 16);
+        plan_((size_t)npairs * nsamp * nh_ * 16);
+        plan_((size_t)npairs * 8);
+        IMCOM_TRY(ws_reserve(ctx, total_ + 8192));
+        cplx *tw = (cplx *)ws_take(ctx, (size_t)nfft * 16);
+        cplx *Y1 = (cplx *)ws_take(ctx, (size_t)npsf_ * nsamp * nh_ * 16);
+        cplx *R = (cplx *)ws_take(ctx, (size_t)npsf_ * nfft * nh_ * 16);
+        cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * nsamp * nh_ * 16);
+        int *pairs_dev = (int *)ws_take(ctx, (size_t)npairs * 8);
+        if (!tw || !Y1 || !R || !V || !pairs_dev) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
+        hipStream_t st = ctx->stream;
+        ProfScope ps(ctx, "psf_overlap");
+        std::vector<int> pr(2 * (size_t)npairs);
+        for (int t = 0; t < npairs; t++) { pr[2 * t] = pairs_host[2 * t]; pr[2 * t + 1] = pairs_host[2 * t + 1] + (same_ ? 0 : n1); }
+        IMCOM_HIP_CHECK(hipMemcpyAsync(pairs_dev, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, st));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(st));  // pr is a local
+        const size_t lds = (size_t)FFT_L * nfft * 16;
+        const int row_blocks = ((nsamp + 1) / 2 + FFT_L - 1) / FFT_L, col_blocks = (nh_ + FFT_L - 1) / FFT_L;
+        hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
+        hipLaunchKernelGGL(fft_fwd_rows_kernel, dim3(row_blocks, n1), dim3(256), lds, st, psf1, nsamp, pl, tw, Y1);
+        if (!same_)
+            hipLaunchKernelGGL(fft_fwd_rows_kernel, dim3(row_blocks, n2), dim3(256), lds, st, psf2, nsamp, pl, tw, Y1 + (long)n1 * nsamp * nh_);
+        hipLaunchKernelGGL(fft_fwd_cols_kernel, dim3(col_blocks, npsf_), dim3(256), lds, st, Y1, nsamp, pl, tw, R);
+        hipLaunchKernelGGL(fft_inv_cols_kernel, dim3(col_blocks, npairs), dim3(256), lds, st, R, pairs_dev, nsamp, pl, tw,
+                           amp_penalty ? amp_penalty[0] : 0.0, amp_penalty ? amp_penalty[1] : 0.0, V);
+        IMCOM_HIP_CHECK(hipMemsetAsync(tables, 0, (size_t)npairs * ng_ * ng_ * 8, st));
+        hipLaunchKernelGGL(fft_inv_rows_kernel, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
+        return check_launch("psf_overlap (butterfly path)");
+    }
     const int nh = nfft / 2 + 1, nc = nsamp / 2;
     const int Sp = up(nsamp, NB);  // padded nsamp (as an M/N extent and as a K extent)
     const int Hp = up(nh, NB);     // padded half-spectrum width

@@ -104,3 +104,42 @@ def test_airy_known_answers_of_the_reference():
     mau = psfs.get_outpsf("AIRYUNOBSC", 0.3, 2, ns, ov).max()
     mao = psfs.get_outpsf("AIRYOBSC", 0.3, 2, ns, ov).max()
     assert 0.2 < mau / mg < 0.3 and 0.8 < mao / mau < 0.9
+
+
+@pytest.mark.parametrize("npixpsf,oversamp", [(5, 6), (10, 4), (9, 2), (7, 4)])
+def test_psf_overlap_mixed_radix_vs_oracle(npixpsf, oversamp):
+    """Table geometries whose nfft exercises every radix of the butterfly path (60 = 4 3 5, 80 = 4 4 5, 36 = 4 3 3) and
+    one that has none of them (56 = 8 7: the dense-DFT fallback), all against the oracle's numpy FFTs, with the
+    amp_penalty weighting on."""
+    import ctypes as C
+
+    import torch
+
+    from oracle import oracle as orc
+    from pyimcom_amd._lib import check, default_context, lib
+
+    geo = orc.Geom(npixpsf, oversamp, 0.04 / 3600.0, 0.0)
+    ns, nfft = geo.nsamp, geo.nfft
+    rng = np.random.default_rng(ns)
+    yy, xx = np.mgrid[:ns, :ns] - ns // 2
+    p1 = np.stack([np.exp(-(xx**2 + yy**2) / (2.0 * (2.0 + 0.3 * k) ** 2)) + 0.01 * rng.standard_normal((ns, ns)) for k in range(3)])
+    p2 = np.stack([np.exp(-((xx - 0.7) ** 2 + (yy + 0.4) ** 2) / (2.0 * (2.5 + 0.2 * k) ** 2)) for k in range(2)])
+    amp = np.array([0.3, 0.45 * oversamp])
+    r1, r2 = orc.pad_and_rfft2(p1, geo), orc.pad_and_rfft2(p2, geo)
+    # Fourier-mode reweighting of PSFGrp.__init__ (psfutil.py:661-671): 1 + a0 exp(-2 pi^2 |u|^2 a1^2), u in cycles per sample
+    uy, ux = np.fft.fftfreq(nfft)[:, None], np.fft.rfftfreq(nfft)[None, :]
+    w = 1.0 + amp[0] * np.exp(-2.0 * np.pi**2 * (ux**2 + uy**2) * amp[1] ** 2)
+    dev = torch.device("cuda:0")
+    ctx = default_context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    t1, t2 = torch.as_tensor(p1, device=dev), torch.as_tensor(p2, device=dev)
+    dp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for use_amp in (False, True):
+        a1, a2 = (r1 * w, r2 * w) if use_amp else (r1, r2)
+        ref = orc.overlap_cross(a1, a2, geo)
+        pairs = np.array([(i, j) for i in range(3) for j in range(2)], dtype=np.int32)
+        out = torch.empty((len(pairs), ns + 12, ns + 12), dtype=torch.float64, device=dev)
+        check(lib.imcom_psf_overlap(ctx.handle, dp(t1), 3, dp(t2), 2, ns, nfft, pairs.ctypes.data_as(C.c_void_p), len(pairs),
+                                    amp.ctypes.data_as(C.c_void_p) if use_amp else None, dp(out)))
+        got = out.cpu().numpy()[:, 6:-6, 6:-6].reshape(3, 2, ns, ns)
+        assert np.abs(got - ref).max() < 2e-13 * np.abs(ref).max(), (nfft, use_amp, np.abs(got - ref).max() / np.abs(ref).max())

@@ -74,6 +74,11 @@ def test_resident_path_secondary_kernels(kernel):
     from pyimcom_amd import smoke, synth
 
     cfg = dataclasses.replace(synth.CONFIGS["tiny"], kernel=kernel)
+    if kernel == "Iterative":
+        # kappa/C = 0.1 (cond ~ 1e2): CG converges below rtol well inside iter_max.  At the tiny config's own 6e-4
+        # (cond 1.7e4) it runs into the 30-step limit and the iterate it stops on amplifies 1e-16 differences in A
+        # to per cent level -- nothing a parity test can pin (tests/test_gpu_iter_empir.py treats that regime).
+        cfg = dataclasses.replace(cfg, kappaC=(0.1,))
     rep = smoke.check_batch(cfg, n_stamps=3)
     assert rep["stamp0"]["T"] < (2e-4 if kernel == "Iterative" else 1e-6)
 
