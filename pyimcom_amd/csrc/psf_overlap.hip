@@ -5,13 +5,12 @@
 //     table[p,q] = roll(irfft2(rfft2(pad(psf1[p])) * conj(rfft2(pad(psf2[q])))), nc)[:nsamp, :nsamp]
 // written with the 6-pixel zero border the interpolators expect.
 //
-// Formulation: the zero-padded 2-D DFTs are evaluated as dense real matrix products with exact
-// twiddle matrices (integer argument reduction mod nfft, then cos/sin of a multiple of pi/nfft), on the
-// fp64 MFMA tile engine of gemm_f64.hip.  Only the nsamp x nsamp window of the inverse transform that
-// is kept is ever computed.  Cost is O(nfft * nsamp * nh) per transform stage instead of an FFT's
-// O(n^2 log n); for the <= 28 tables of a 2x2 stamp group this is ~50 GFlop, amortised over the
-// stamps that share the group.  (A butterfly FFT would do less work; this form is exact to fp64
-// rounding and reuses the one hot GEMM kernel -- noted in DESIGN.md as the next thing to replace.)
+// Two formulations.  (1) Butterfly path (default whenever nfft = product of 4, 2, 3, 5 and <= 1024): mixed-radix
+// Stockham FFTs in LDS, see below -- 16 us per cfg-2 table (nfft 768) including the forward transforms.
+// (2) Dense-DFT path (general fallback, IMCOM_PSF_OVERLAP=gemm): the zero-padded 2-D DFTs as dense real matrix
+// products with exact twiddle matrices (integer argument reduction mod nfft, then cos/sin of a multiple of
+// pi/nfft) on the fp64 MFMA tile engine of gemm_f64.hip; only the kept nsamp x nsamp window of the inverse is
+// computed; O(nfft * nsamp * nh) per stage, 51 us per cfg-2 table.  Both agree with numpy's FFTs to ~1e-15.
 #include <cstdlib>
 #include <cstring>
 
@@ -176,7 +175,7 @@ template <> __device__ __forceinline__ void small_dft<5, true>(cplx (&v)[5]) { d
 // one Stockham stage of radix R on FFT_L lines of length n in `buf` ([line][n]); Ns = product of the earlier radices;
 // tw[k] = exp(-2 pi i k / n)
 template <int R, bool INV>
-__device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *__restrict__ tw)
+__device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *tw)
 {
     const int nb = n / R, total = nb * FFT_L, step = n / (Ns * R);
     cplx v[FFT_MAXIT][R];
@@ -214,7 +213,7 @@ __device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *
 }
 
 template <bool INV>
-__device__ __forceinline__ void fft_lines(cplx *buf, const FftPlan &pl, const cplx *__restrict__ tw)
+__device__ __forceinline__ void fft_lines(cplx *buf, const FftPlan &pl, const cplx *tw)
 {
     int Ns = 1;
     for (int st = 0; st < pl.nst; st++) {
@@ -236,12 +235,14 @@ __global__ void fft_twiddle_kernel(int n, cplx *__restrict__ tw)
     tw[k] = make_double2(c, -s);
 }
 
-// forward, along x: rows 2l, 2l+1 of PSF p as one complex line; Y1[p][row][kx], kx < nh
+// forward, along x: rows 2l, 2l+1 of PSF p as one complex line; Y1[p][kx][row], kx < nh
 __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restrict__ psf, int ns, FftPlan pl,
                                                            const cplx *__restrict__ tw, cplx *__restrict__ Y1)
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y;
+    cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
+    for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     const double *img = psf + (long)p * ns * ns;
     for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
         const int line = e / n, x = e - line * n, r0 = 2 * (blockIdx.x * FFT_L + line);
@@ -253,37 +254,39 @@ __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restr
         fbuf[e] = make_double2(re, im);
     }
     __syncthreads();
-    fft_lines<false>(fbuf, pl, tw);
-    for (int e = threadIdx.x; e < FFT_L * nh; e += 256) {
-        const int line = e / nh, k = e - line * nh, r0 = 2 * (blockIdx.x * FFT_L + line);
+    fft_lines<false>(fbuf, pl, twl);
+    for (int e = threadIdx.x; e < FFT_L * nh; e += 256) {  // Y1 is stored [kx][row]: the 2 FFT_L rows of this block are contiguous
+        const int k = e / FFT_L, line = e - k * FFT_L, r0 = 2 * (blockIdx.x * FFT_L + line);
         if (r0 >= ns) continue;
         const cplx zk = fbuf[line * n + k], zm = fbuf[line * n + (n - k) % n];
-        Y1[((long)p * ns + r0) * nh + k] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-        if (r0 + 1 < ns) Y1[((long)p * ns + r0 + 1) * nh + k] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+        Y1[((long)p * nh + k) * ns + r0] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        if (r0 + 1 < ns) Y1[((long)p * nh + k) * ns + r0 + 1] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
     }
 }
 
-// forward, along y: FFT_L columns of Y1[p] (rows >= ns are zero) -> R[p][ky][kx]
+// forward, along y: FFT_L columns of Y1[p] (rows >= ns are zero) -> R[p][kx][ky]
 __global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restrict__ Y1, int ns, FftPlan pl,
                                                            const cplx *__restrict__ tw, cplx *__restrict__ R)
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y, kx0 = blockIdx.x * FFT_L;
+    cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
+    for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
-        const int y = e / FFT_L, c = e - y * FFT_L;
+        const int c = e / n, y = e - c * n;
         cplx v = make_double2(0.0, 0.0);
-        if (y < ns && kx0 + c < nh) v = Y1[((long)p * ns + y) * nh + kx0 + c];
-        fbuf[c * n + y] = v;
+        if (y < ns && kx0 + c < nh) v = Y1[((long)p * nh + kx0 + c) * ns + y];
+        fbuf[e] = v;
     }
     __syncthreads();
-    fft_lines<false>(fbuf, pl, tw);
-    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
-        const int ky = e / FFT_L, c = e - ky * FFT_L;
-        if (kx0 + c < nh) R[((long)p * n + ky) * nh + kx0 + c] = fbuf[c * n + ky];
+    fft_lines<false>(fbuf, pl, twl);
+    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {  // spectra are stored [kx][ky]: whole lines
+        const int c = e / n, ky = e - c * n;
+        if (kx0 + c < nh) R[((long)p * nh + kx0 + c) * n + ky] = fbuf[e];
     }
 }
 
-// inverse, along y: FFT_L columns of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][y'][kx] for the
+// inverse, along y: FFT_L columns of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][kx][y'] for the
 // kept rows y' < ns (source row (y' - nc) mod n: the roll of psfutil.py:1225-1232)
 __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restrict__ R, const int *__restrict__ pairs, int ns,
                                                            FftPlan pl, const cplx *__restrict__ tw, double amp0, double amps,
@@ -291,12 +294,14 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, kx0 = blockIdx.x * FFT_L, nc = ns / 2;
+    cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
+    for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     const cplx *R1 = R + (long)pairs[2 * t] * n * nh, *R2 = R + (long)pairs[2 * t + 1] * n * nh;
     for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
-        const int ky = e / FFT_L, c = e - ky * FFT_L, kx = kx0 + c;
+        const int c = e / n, ky = e - c * n, kx = kx0 + c;
         cplx z = make_double2(0.0, 0.0);
         if (kx < nh) {
-            const cplx a = R1[(long)ky * nh + kx], b = R2[(long)ky * nh + kx];
+            const cplx a = R1[(long)kx * n + ky], b = R2[(long)kx * n + ky];
             double w2 = 1.0;
             if (amp0 != 0.0) {
                 double uy = (double)ky / (double)n, ux = (double)kx / (double)n;
@@ -307,13 +312,13 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
             }
             z = make_double2((a.x * b.x + a.y * b.y) * w2, (a.y * b.x - a.x * b.y) * w2);
         }
-        fbuf[c * n + ky] = z;
+        fbuf[e] = z;
     }
     __syncthreads();
-    fft_lines<true>(fbuf, pl, tw);
-    for (int e = threadIdx.x; e < FFT_L * ns; e += 256) {
-        const int yp = e / FFT_L, c = e - yp * FFT_L;
-        if (kx0 + c < nh) V[((long)t * ns + yp) * nh + kx0 + c] = fbuf[c * n + (yp - nc + n) % n];
+    fft_lines<true>(fbuf, pl, twl);
+    for (int e = threadIdx.x; e < FFT_L * ns; e += 256) {  // V is stored [kx][y']
+        const int c = e / ns, yp = e - c * ns;
+        if (kx0 + c < nh) V[((long)t * nh + kx0 + c) * ns + yp] = fbuf[c * n + (yp - nc + n) % n];
     }
 }
 
@@ -325,19 +330,21 @@ __global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restric
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, nc = ns / 2, ng = ns + 12;
-    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
-        const int line = e / n, k = e - line * n, r0 = 2 * (blockIdx.x * FFT_L + line);
+    cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
+    for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
+    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {  // the 2 FFT_L rows of this block are contiguous in V[kx][y']
+        const int k = e / FFT_L, line = e - k * FFT_L, r0 = 2 * (blockIdx.x * FFT_L + line);
         const int kk = k < nh ? k : n - k;
         const bool edge = kk == 0 || 2 * kk == n;
         cplx a = make_double2(0.0, 0.0), b = a;
-        if (r0 < ns) a = V[((long)t * ns + r0) * nh + kk];
-        if (r0 + 1 < ns) b = V[((long)t * ns + r0 + 1) * nh + kk];
+        if (r0 < ns) a = V[((long)t * nh + kk) * ns + r0];
+        if (r0 + 1 < ns) b = V[((long)t * nh + kk) * ns + r0 + 1];
         if (k >= nh) { a.y = -a.y; b.y = -b.y; }
         if (edge) { a.y = 0.0; b.y = 0.0; }
-        fbuf[e] = make_double2(a.x - b.y, a.y + b.x);
+        fbuf[line * n + k] = make_double2(a.x - b.y, a.y + b.x);
     }
     __syncthreads();
-    fft_lines<true>(fbuf, pl, tw);
+    fft_lines<true>(fbuf, pl, twl);
     const double scale = 1.0 / ((double)n * (double)n);
     for (int e = threadIdx.x; e < FFT_L * ns; e += 256) {
         const int line = e / ns, xp = e - line * ns, r0 = 2 * (blockIdx.x * FFT_L + line);
@@ -412,7 +419,13 @@ extern "C" int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, con
         for (int t = 0; t < npairs; t++) { pr[2 * t] = pairs_host[2 * t]; pr[2 * t + 1] = pairs_host[2 * t + 1] + (same_ ? 0 : n1); }
         IMCOM_HIP_CHECK(hipMemcpyAsync(pairs_dev, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, st));
         IMCOM_HIP_CHECK(hipStreamSynchronize(st));  // pr is a local
-        const size_t lds = (size_t)FFT_L * nfft * 16;
+        const size_t lds = (size_t)(FFT_L + 1) * nfft * 16;  // lines + twiddle table
+        if (lds > 48 * 1024) {
+            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         const int row_blocks = ((nsamp + 1) / 2 + FFT_L - 1) / FFT_L, col_blocks = (nh_ + FFT_L - 1) / FFT_L;
         hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
         hipLaunchKernelGGL(fft_fwd_rows_kernel, dim3(row_blocks, n1), dim3(256), lds, st, psf1, nsamp, pl, tw, Y1);
