@@ -296,6 +296,19 @@ int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, const double *
                       int nsamp, int nfft, const int *pairs_host, int npairs, const double *amp_penalty,
                       double *tables);
 
+/* The two halves of imcom_psf_overlap, for callers that keep the forward spectra of a PSF group resident and cross
+ * them with several other groups (SysMatA builds PSFOvl(grp1, grp2) for every pair of neighbouring 2x2 groups from
+ * the same PSFGrp.psf_rft, psfutil.py:1904-2010, 943-986):
+ *   imcom_psf_spectra_size   doubles per PSF of a spectra buffer, or 0 when nfft has no butterfly plan (other prime
+ *                            factors than 2, 3, 5, or > 1024) -- then only imcom_psf_overlap (dense-DFT form) serves
+ *   imcom_psf_spectra        spectra[n][size] (DEVICE) = rfft2 of the zero-padded PSFs psf[n][nsamp][nsamp] (DEVICE)
+ *   imcom_psf_overlap_spectra  tables[npairs][nsamp+12][nsamp+12] (DEVICE) exactly as imcom_psf_overlap, from spectra;
+ *                            pairs (HOST) index spec1 / spec2 */
+long imcom_psf_spectra_size(int nsamp, int nfft);
+int imcom_psf_spectra(imcom_ctx *ctx, const double *psf, int n, int nsamp, int nfft, double *spectra);
+int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp, int nfft,
+                              const int *pairs, int npairs, const double *amp_penalty, double *tables);
+
 #ifdef __cplusplus
 }
 #endif

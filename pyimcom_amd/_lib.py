@@ -83,6 +83,8 @@ SIGNATURES = {
     "imcom_psf_gaussian": [_vp, _i, _d, _d, _vp, _i],
     "imcom_psf_simple_airy": [_vp, _i, _d, _d, _d, _d, _vp, _i],
     "imcom_psf_overlap": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
+    "imcom_psf_spectra": [_vp, _vp, _i, _i, _i, _vp],
+    "imcom_psf_overlap_spectra": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
     "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
     "imcom_compress_map_f32": [_vp, _vp, _l, _i, _i, _vp],
     "imcom_trapezoid_recover_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i],
@@ -93,10 +95,12 @@ for _name, _args in SIGNATURES.items():
     _f.restype = C.c_int
 lib.imcom_version.argtypes = []
 lib.imcom_version.restype = C.c_int
+lib.imcom_psf_spectra_size.argtypes = [_i, _i]
+lib.imcom_psf_spectra_size.restype = C.c_long
 lib.imcom_last_error.argtypes = []
 lib.imcom_last_error.restype = C.c_char_p
 
-EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_last_error"])
+EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_last_error", "imcom_psf_spectra_size"])
 
 
 def check(status):

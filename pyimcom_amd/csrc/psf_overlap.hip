@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restric
 
 // inverse, along y: FFT_L columns of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][kx][y'] for the
 // kept rows y' < ns (source row (y' - nc) mod n: the roll of psfutil.py:1225-1232)
-__global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restrict__ R, const int *__restrict__ pairs, int ns,
+__global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
+                                                           const int *__restrict__ pairs, int ns,
                                                            FftPlan pl, const cplx *__restrict__ tw, double amp0, double amps,
                                                            cplx *__restrict__ V)
 {
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
     const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, kx0 = blockIdx.x * FFT_L, nc = ns / 2;
     cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
-    const cplx *R1 = R + (long)pairs[2 * t] * n * nh, *R2 = R + (long)pairs[2 * t + 1] * n * nh;
+    const cplx *R1 = Ra + (long)pairs[2 * t] * n * nh, *R2 = Rb + (long)pairs[2 * t + 1] * n * nh;
     for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
         const int c = e / n, ky = e - c * n, kx = kx0 + c;
         cplx z = make_double2(0.0, 0.0);
@@ -375,6 +376,71 @@ static bool fft_plan(int n, FftPlan *pl)
     return true;
 }
 
+
+static bool fft_force_gemm()
+{
+    static const bool f = getenv("IMCOM_PSF_OVERLAP") && !strcmp(getenv("IMCOM_PSF_OVERLAP"), "gemm");
+    return f;
+}
+
+static size_t fft_lds_bytes(int nfft) { return (size_t)(FFT_L + 1) * nfft * 16; }  // lines + twiddle table
+
+static int fft_set_lds(int nfft)
+{
+    const size_t lds = fft_lds_bytes(nfft);
+    if (lds > 48 * 1024) {
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    return IMCOM_OK;
+}
+
+static size_t fft_forward_ws(int n, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)n * nsamp * (nfft / 2 + 1) * 16 + 1024; }
+static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * nsamp * (nfft / 2 + 1) * 16 + (size_t)npairs * 8 + 1024; }
+
+// spectra R[n][nh][nfft] (complex) of n sampled PSFs; the caller has reserved fft_forward_ws() of workspace
+static int fft_forward(imcom_ctx *ctx, const FftPlan &pl, const double *psf, int n, int nsamp, cplx *R)
+{
+    const int nfft = pl.n, nh = nfft / 2 + 1;
+    cplx *tw = (cplx *)ws_take(ctx, (size_t)nfft * 16);
+    cplx *Y1 = (cplx *)ws_take(ctx, (size_t)n * nsamp * nh * 16);
+    if (!tw || !Y1) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
+    IMCOM_TRY(fft_set_lds(nfft));
+    hipStream_t st = ctx->stream;
+    const size_t lds = fft_lds_bytes(nfft);
+    const int row_blocks = ((nsamp + 1) / 2 + FFT_L - 1) / FFT_L, col_blocks = (nh + FFT_L - 1) / FFT_L;
+    hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
+    hipLaunchKernelGGL(fft_fwd_rows_kernel, dim3(row_blocks, n), dim3(256), lds, st, psf, nsamp, pl, tw, Y1);
+    hipLaunchKernelGGL(fft_fwd_cols_kernel, dim3(col_blocks, n), dim3(256), lds, st, Y1, nsamp, pl, tw, R);
+    return check_launch("psf spectra (butterfly path)");
+}
+
+// tables[t] from spectra pairs (Ra[pairs[2t]], Rb[pairs[2t+1]]); the caller has reserved fft_inverse_ws()
+static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const cplx *Rb, const int *pairs_host, int npairs,
+                       int nsamp, const double *amp_penalty, double *tables)
+{
+    const int nfft = pl.n, nh = nfft / 2 + 1, ng = nsamp + 12;
+    cplx *tw = (cplx *)ws_take(ctx, (size_t)nfft * 16);
+    cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * nsamp * nh * 16);
+    int *pairs_dev = (int *)ws_take(ctx, (size_t)npairs * 8);
+    if (!tw || !V || !pairs_dev) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
+    IMCOM_TRY(fft_set_lds(nfft));
+    hipStream_t st = ctx->stream;
+    IMCOM_HIP_CHECK(hipMemcpyAsync(pairs_dev, pairs_host, (size_t)npairs * 8, hipMemcpyHostToDevice, st));
+    const size_t lds = fft_lds_bytes(nfft);
+    const int row_blocks = ((nsamp + 1) / 2 + FFT_L - 1) / FFT_L, col_blocks = (nh + FFT_L - 1) / FFT_L;
+    hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
+    hipLaunchKernelGGL(fft_inv_cols_kernel, dim3(col_blocks, npairs), dim3(256), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw,
+                       amp_penalty ? amp_penalty[0] : 0.0, amp_penalty ? amp_penalty[1] : 0.0, V);
+    IMCOM_HIP_CHECK(hipMemsetAsync(tables, 0, (size_t)npairs * ng * ng * 8, st));
+    hipLaunchKernelGGL(fft_inv_rows_kernel, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
+    IMCOM_TRY(check_launch("psf_overlap (butterfly path)"));
+    IMCOM_HIP_CHECK(hipStreamSynchronize(st));  // pairs_host belongs to the caller
+    return IMCOM_OK;
+}
+
 static int up(int v, int a) { return (v + a - 1) / a * a; }
 
 }  // namespace imcom
@@ -394,49 +460,17 @@ extern "C" int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, con
         IMCOM_REQUIRE(pairs_host[2 * t] >= 0 && pairs_host[2 * t] < n1 && pairs_host[2 * t + 1] >= 0 && pairs_host[2 * t + 1] < n2,
                       "pair %d out of range", t);
     FftPlan pl;
-    static const bool force_gemm = getenv("IMCOM_PSF_OVERLAP") && !strcmp(getenv("IMCOM_PSF_OVERLAP"), "gemm");
-    if (!force_gemm && fft_plan(nfft, &pl)) {
-        const int nh_ = nfft / 2 + 1, ng_ = nsamp + 12;
+    if (!fft_force_gemm() && fft_plan(nfft, &pl)) {
+        const int nh_ = nfft / 2 + 1;
         const bool same_ = (psf1 == psf2 && n1 == n2);
         const int npsf_ = same_ ? n1 : n1 + n2;
-        size_t total_ = 0;
-        auto plan_ = [&](size_t b) { total_ = align_up(total_, 256) + b; };
-        plan_((size_t)nfft * 16);
-        plan_((size_t)npsf_ * nsamp * nh_ * 16);
-        plan_((size_t)npsf_ * nfft * nh_ * 16);
-        plan_((size_t)npairs * nsamp * nh_ * 16);
-        plan_((size_t)npairs * 8);
-        IMCOM_TRY(ws_reserve(ctx, total_ + 8192));
-        cplx *tw = (cplx *)ws_take(ctx, (size_t)nfft * 16);
-        cplx *Y1 = (cplx *)ws_take(ctx, (size_t)npsf_ * nsamp * nh_ * 16);
+        IMCOM_TRY(ws_reserve(ctx, fft_forward_ws(npsf_, nsamp, nfft) + (size_t)npsf_ * nfft * nh_ * 16 + fft_inverse_ws(npairs, nsamp, nfft) + (size_t)nfft * 64 + 65536));
         cplx *R = (cplx *)ws_take(ctx, (size_t)npsf_ * nfft * nh_ * 16);
-        cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * nsamp * nh_ * 16);
-        int *pairs_dev = (int *)ws_take(ctx, (size_t)npairs * 8);
-        if (!tw || !Y1 || !R || !V || !pairs_dev) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
-        hipStream_t st = ctx->stream;
+        if (!R) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
         ProfScope ps(ctx, "psf_overlap");
-        std::vector<int> pr(2 * (size_t)npairs);
-        for (int t = 0; t < npairs; t++) { pr[2 * t] = pairs_host[2 * t]; pr[2 * t + 1] = pairs_host[2 * t + 1] + (same_ ? 0 : n1); }
-        IMCOM_HIP_CHECK(hipMemcpyAsync(pairs_dev, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, st));
-        IMCOM_HIP_CHECK(hipStreamSynchronize(st));  // pr is a local
-        const size_t lds = (size_t)(FFT_L + 1) * nfft * 16;  // lines + twiddle table
-        if (lds > 48 * 1024) {
-            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        const int row_blocks = ((nsamp + 1) / 2 + FFT_L - 1) / FFT_L, col_blocks = (nh_ + FFT_L - 1) / FFT_L;
-        hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
-        hipLaunchKernelGGL(fft_fwd_rows_kernel, dim3(row_blocks, n1), dim3(256), lds, st, psf1, nsamp, pl, tw, Y1);
-        if (!same_)
-            hipLaunchKernelGGL(fft_fwd_rows_kernel, dim3(row_blocks, n2), dim3(256), lds, st, psf2, nsamp, pl, tw, Y1 + (long)n1 * nsamp * nh_);
-        hipLaunchKernelGGL(fft_fwd_cols_kernel, dim3(col_blocks, npsf_), dim3(256), lds, st, Y1, nsamp, pl, tw, R);
-        hipLaunchKernelGGL(fft_inv_cols_kernel, dim3(col_blocks, npairs), dim3(256), lds, st, R, pairs_dev, nsamp, pl, tw,
-                           amp_penalty ? amp_penalty[0] : 0.0, amp_penalty ? amp_penalty[1] : 0.0, V);
-        IMCOM_HIP_CHECK(hipMemsetAsync(tables, 0, (size_t)npairs * ng_ * ng_ * 8, st));
-        hipLaunchKernelGGL(fft_inv_rows_kernel, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
-        return check_launch("psf_overlap (butterfly path)");
+        IMCOM_TRY(fft_forward(ctx, pl, psf1, n1, nsamp, R));
+        if (!same_) IMCOM_TRY(fft_forward(ctx, pl, psf2, n2, nsamp, R + (long)n1 * nfft * nh_));
+        return fft_inverse(ctx, pl, R, same_ ? R : R + (long)n1 * nfft * nh_, pairs_host, npairs, nsamp, amp_penalty, tables);
     }
     const int nh = nfft / 2 + 1, nc = nsamp / 2;
     const int Sp = up(nsamp, NB);  // padded nsamp (as an M/N extent and as a K extent)
@@ -519,4 +553,40 @@ extern "C" int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, con
     const int ng = nsamp + 12;
     hipLaunchKernelGGL(crop_table_kernel, dim3((ng + 255) / 256, ng, npairs), dim3(256), 0, st, W, Sp, nsamp, tables);
     return check_launch("crop_table_kernel");
+}
+
+extern "C" long imcom_psf_spectra_size(int nsamp, int nfft)
+{
+    FftPlan pl;
+    if (nsamp < 1 || nfft < 2 * nsamp || nfft % 2 || fft_force_gemm() || !fft_plan(nfft, &pl)) return 0;
+    return 2L * (nfft / 2 + 1) * nfft;
+}
+
+extern "C" int imcom_psf_spectra(imcom_ctx *ctx, const double *psf, int n, int nsamp, int nfft, double *spectra)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
+    IMCOM_REQUIRE(psf && spectra && n >= 1, "null pointer / empty set");
+    IMCOM_REQUIRE(imcom_psf_spectra_size(nsamp, nfft) > 0, "no butterfly plan for nfft=%d (use imcom_psf_overlap)", nfft);
+    FftPlan pl;
+    fft_plan(nfft, &pl);
+    IMCOM_TRY(ws_reserve(ctx, fft_forward_ws(n, nsamp, nfft) + 8192));
+    return fft_forward(ctx, pl, psf, n, nsamp, (cplx *)spectra);
+}
+
+extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp,
+                                         int nfft, const int *pairs_host, int npairs, const double *amp_penalty, double *tables)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
+    IMCOM_REQUIRE(spec1 && spec2 && pairs_host && tables && npairs >= 1, "null pointer / no pairs");
+    IMCOM_REQUIRE(imcom_psf_spectra_size(nsamp, nfft) > 0, "no butterfly plan for nfft=%d (use imcom_psf_overlap)", nfft);
+    for (int t = 0; t < npairs; t++)
+        IMCOM_REQUIRE(pairs_host[2 * t] >= 0 && pairs_host[2 * t] < n1 && pairs_host[2 * t + 1] >= 0 && pairs_host[2 * t + 1] < n2,
+                      "pair %d out of range", t);
+    FftPlan pl;
+    fft_plan(nfft, &pl);
+    IMCOM_TRY(ws_reserve(ctx, fft_inverse_ws(npairs, nsamp, nfft) + 8192));
+    ProfScope ps(ctx, "psf_overlap");
+    return fft_inverse(ctx, pl, (const cplx *)spec1, (const cplx *)spec2, pairs_host, npairs, nsamp, amp_penalty, tables);
 }

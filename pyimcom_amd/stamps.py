@@ -29,6 +29,42 @@ def _hp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+_GRIDS = {}
+
+
+def _index_grid(na, nb):
+    if (na, nb) not in _GRIDS:
+        _GRIDS[(na, nb)] = tuple(np.ascontiguousarray(a) for a in np.meshgrid(np.arange(na), np.arange(nb), indexing="ij"))
+    return _GRIDS[(na, nb)]
+
+
+def psf_spectra(ctx, psf, nfft):
+    """Forward spectra [n, size] (float64 view of complex [n, nfft/2+1, nfft]) of sampled PSFs [n, nsamp, nsamp] on the
+    device, or None when nfft has no butterfly plan (imcom_psf_spectra_size == 0)."""
+    n, ns, _ = psf.shape
+    size = int(lib.imcom_psf_spectra_size(ns, nfft))
+    if size == 0:
+        return None
+    spec = torch.empty((n, size), dtype=torch.float64, device=psf.device)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    check(lib.imcom_psf_spectra(ctx.handle, _dp(psf), n, ns, nfft, _dp(spec)))
+    return spec
+
+
+def overlap_tables(ctx, p1, s1, p2, s2, nsamp, nfft, pairs, amp, out):
+    """Tables of the (i, j) `pairs` between two PSF sets, from their spectra when both are given (else from the
+    sampled PSFs through imcom_psf_overlap)."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    ampp = None if amp is None else _hp(amp)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if s1 is not None and s2 is not None:
+        check(lib.imcom_psf_overlap_spectra(ctx.handle, _dp(s1), s1.shape[0], _dp(s2), s2.shape[0], nsamp, nfft, _hp(pairs),
+                                            len(pairs), ampp, _dp(out)))
+    else:
+        check(lib.imcom_psf_overlap(ctx.handle, _dp(p1), p1.shape[0], _dp(p2), p2.shape[0], nsamp, nfft, _hp(pairs), len(pairs),
+                                    ampp, _dp(out)))
+
+
 class PSFGroupTables:
     """Overlap tables of ONE input PSF group against itself and the target PSF(s).
 
@@ -43,7 +79,6 @@ class PSFGroupTables:
         """amp_penalty: None or (cfg.amp_penalty[0], cfg.amp_penalty[1] * oversamp) (psfutil.py:661-671)."""
         self.ctx = ctx or default_context()
         amp = None if amp_penalty is None or 0.0 in tuple(amp_penalty) else np.array(amp_penalty, dtype=np.float64)
-        ampp = None if amp is None else _hp(amp)
         E, ns, _ = psf_in.shape
         self.n_psf, self.nsamp, self.nfft = E, ns, nfft
         dev = torch.device(device)
@@ -53,17 +88,16 @@ class PSFGroupTables:
         O = self.n_out = pout.shape[0]
         ng = ns + 12
         self.ntri = E * (E + 1) // 2
-        self.tables = torch.empty((self.ntri + O * E, ng, ng), dtype=torch.float64, device=dev)
-        self._set_stream()
-        pairs = np.array([(i, j) for i in range(E) for j in range(i, E)], dtype=np.int32)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pin), E, ns, nfft, _hp(pairs), len(pairs), ampp,
-                                    _dp(self.tables[: self.ntri])))
-        pairs = np.array([(i, o) for o in range(O) for i in range(E)], dtype=np.int32)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pin), E, _dp(pout), O, ns, nfft, _hp(pairs), len(pairs), ampp,
-                                    _dp(self.tables[self.ntri :])))
-        cc = torch.empty((O, ng, ng), dtype=torch.float64, device=dev)
-        pairs = np.array([(o, o) for o in range(O)], dtype=np.int32)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(pout), O, _dp(pout), O, ns, nfft, _hp(pairs), O, ampp, _dp(cc)))
+        # one set of E + O PSFs: self pairs (triangle order), input-output pairs (target-major), output self pairs;
+        # their spectra are computed once and every table comes from them in one call
+        allp = torch.cat([pin, pout])
+        spec = psf_spectra(self.ctx, allp, nfft)
+        pairs = ([(i, j) for i in range(E) for j in range(i, E)] + [(i, E + o) for o in range(O) for i in range(E)]
+                 + [(E + o, E + o) for o in range(O)])
+        full = torch.empty((len(pairs), ng, ng), dtype=torch.float64, device=dev)
+        overlap_tables(self.ctx, allp, spec, allp, spec, ns, nfft, pairs, amp, full)
+        self.tables = full[: self.ntri + O * E]
+        cc = full[self.ntri + O * E :]
         nc = ns // 2
         self.Cs = cc[:, 6 + nc, 6 + nc].cpu().numpy().astype(np.float64)  # psfutil.py:1290
         self.C = float(self.Cs[0])
@@ -149,17 +183,50 @@ class BlockTables:
         ng = self.nsamp + 12
         self.tables = torch.empty((capacity, ng, ng), dtype=torch.float64, device=dev)  # the arena
         self.index, self.used = {}, 0
+        # forward spectra of the target PSFs and of every group in ONE arena, so that all the table sets a batch of
+        # stamps needs come out of a single call; a group's rows are filled on first use (28 MB per group at E = 6,
+        # nfft 768).  size == 0: nfft has no butterfly plan, every set goes through imcom_psf_overlap on its own.
+        size = int(lib.imcom_psf_spectra_size(self.nsamp, nfft))
+        self._spec_row, row = {None: 0}, O
+        for k, v in self.psf.items():
+            self._spec_row[k] = row
+            row += v.shape[0]
+        self._spec_done = set()
+        self._spec_all = torch.empty((row, size), dtype=torch.float64, device=dev) if size else None
+        if size:
+            self._fill_spectra(None)
         cc = torch.empty((O, ng, ng), dtype=torch.float64, device=dev)
-        self._overlap(self.pout, self.pout, [(o, o) for o in range(O)], cc)
+        self._compute([(None, None, [(o, o) for o in range(O)])], cc)
         nc = self.nsamp // 2
         self.Cs = cc[:, 6 + nc, 6 + nc].cpu().numpy().astype(np.float64)
         self.C = float(self.Cs[0])
 
-    def _overlap(self, p1, p2, pairs, out):
-        pairs = np.array(pairs, dtype=np.int32)
+    def _psf_of(self, g):
+        return self.pout if g is None else self.psf[g]
+
+    def _fill_spectra(self, g):
+        if g in self._spec_done:
+            return
+        p, r0 = self._psf_of(g), self._spec_row[g]
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        check(lib.imcom_psf_overlap(self.ctx.handle, _dp(p1), p1.shape[0], _dp(p2), p2.shape[0], self.nsamp, self.nfft, _hp(pairs),
-                                    len(pairs), None if self._amp is None else _hp(self._amp), _dp(out)))
+        check(lib.imcom_psf_spectra(self.ctx.handle, _dp(p), p.shape[0], self.nsamp, self.nfft, _dp(self._spec_all[r0 : r0 + p.shape[0]])))
+        self._spec_done.add(g)
+
+    def _compute(self, jobs, out):
+        """jobs: list of (g1, g2, local pairs) whose tables fill `out` back to back (g = None: the target PSFs)."""
+        if self._spec_all is None:
+            off = 0
+            for g1, g2, pairs in jobs:
+                overlap_tables(self.ctx, self._psf_of(g1), None, self._psf_of(g2), None, self.nsamp, self.nfft, pairs, self._amp,
+                               out[off : off + len(pairs)])
+                off += len(pairs)
+            return
+        allp = []
+        for g1, g2, pairs in jobs:
+            self._fill_spectra(g1)
+            self._fill_spectra(g2)
+            allp.append(np.asarray(pairs, dtype=np.int64) + np.array([self._spec_row[g1], self._spec_row[g2]]))
+        overlap_tables(self.ctx, None, self._spec_all, None, self._spec_all, self.nsamp, self.nfft, np.concatenate(allp), self._amp, out)
 
     def _n(self, g):
         return self.psf[g].shape[0]
@@ -180,20 +247,21 @@ class BlockTables:
             need = sum(self._count(k) for k in keys)
             if need > self.tables.shape[0]:
                 raise ValueError(f"table arena of {self.tables.shape[0]} tables cannot hold the {need} of one batch")
+        jobs, first = [], self.used
         for k in keys:
             if k in self.index:
                 continue
-            cnt, off = self._count(k), self.used
-            out = self.tables[off : off + cnt]
             if k[0] == "self":
                 n = self._n(k[1])
-                self._overlap(self.psf[k[1]], self.psf[k[1]], [(i, j) for i in range(n) for j in range(i, n)], out)
+                jobs.append((k[1], k[1], [(i, j) for i in range(n) for j in range(i, n)]))
             elif k[0] == "io":
-                self._overlap(self.psf[k[1]], self.pout, [(i, o) for o in range(self.n_out) for i in range(self._n(k[1]))], out)
+                jobs.append((k[1], None, [(i, o) for o in range(self.n_out) for i in range(self._n(k[1]))]))
             else:
-                self._overlap(self.psf[k[1]], self.psf[k[2]], [(i, j) for i in range(self._n(k[1])) for j in range(self._n(k[2]))], out)
-            self.index[k] = off
-            self.used += cnt
+                jobs.append((k[1], k[2], [(i, j) for i in range(self._n(k[1])) for j in range(self._n(k[2]))]))
+            self.index[k] = self.used
+            self.used += self._count(k)
+        if jobs:
+            self._compute(jobs, self.tables[first : self.used])
         return {k: self.index[k] for k in keys}
 
     @staticmethod
@@ -214,27 +282,26 @@ class BlockTables:
         lut = np.full((slots, self.n_blk_expo), -1, np.int32)
         base = np.concatenate([[0], np.cumsum([self._n(g) for g in groups])]).astype(int)
         for la, ga in enumerate(groups):
-            for k, e in enumerate(self.expo[ga]):
-                lut[la, e] = base[la] + k
             na = self._n(ga)
+            ea = np.asarray(self.expo[ga])
+            lut[la, ea] = base[la] + np.arange(na)
             for o in range(self.n_out):
                 io[o, base[la] : base[la] + na] = self.index[("io", ga)] + o * na + np.arange(na)
             for lb, gb in enumerate(groups):
                 nb = self._n(gb)
-                tri = lambda i, j: (2 * na - i + 1) * i // 2 + j - i  # noqa: E731  (psfutil.py:1175), same group only
-                for ka in range(na):
-                    for kb in range(nb):
-                        a, b = base[la] + ka, base[lb] + kb
-                        if ga == gb:
-                            off = self.index[("self", ga)]
-                            tab[a, b] = off + tri(ka, kb) if ka <= kb else (off + tri(kb, ka)) | PAIR_FLIP
-                        elif ga < gb:
-                            tab[a, b] = self.index[("cross", ga, gb)] + ka * nb + kb
-                        else:  # evaluated from the other group's side (psfutil.py:1990-1996)
-                            tab[a, b] = (self.index[("cross", gb, ga)] + kb * na + ka) | PAIR_SWAP
-                        if flat_penalty != 0.0:  # psfutil.py:1433, 1482-1486, 1705-1708
-                            same = self.expo[ga][ka] == self.expo[gb][kb]
-                            pen[a, b] = -flat_penalty / (na * nb) ** 0.5 + (flat_penalty if same else 0.0)
+                ka, kb = _index_grid(na, nb)
+                if ga == gb:  # triangle storage of the group's self overlap (psfutil.py:1175); (j, i) with j > i flipped
+                    lo, hi = np.minimum(ka, kb), np.maximum(ka, kb)
+                    blk = self.index[("self", ga)] + (2 * na - lo + 1) * lo // 2 + hi - lo
+                    blk = np.where(ka <= kb, blk, blk | PAIR_FLIP)
+                elif ga < gb:
+                    blk = self.index[("cross", ga, gb)] + ka * nb + kb
+                else:  # evaluated from the other group's side (psfutil.py:1990-1996)
+                    blk = (self.index[("cross", gb, ga)] + kb * na + ka) | PAIR_SWAP
+                tab[base[la] : base[la] + na, base[lb] : base[lb] + nb] = blk
+                if flat_penalty != 0.0:  # psfutil.py:1433, 1482-1486, 1705-1708
+                    same = ea[:, None] == np.asarray(self.expo[gb])[None, :]
+                    pen[base[la] : base[la] + na, base[lb] : base[lb] + nb] = -flat_penalty / (na * nb) ** 0.5 + np.where(same, flat_penalty, 0.0)
         return tab, pen, (io[0] if self.n_out == 1 else io), lut
 
 

@@ -9,34 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _instamps(cfg, n1P, n_expo, rng):
-    """InStamps of the (n1P+2)^2 cells (coadd.py:207, 329-358): per exposure a rotated lattice of native pixels binned
-    by cell, exposure-major inside a cell, random data."""
-    from pyimcom_amd.synth import NATIVE_ARCSEC
+    from pyimcom_amd.synth import make_instamps
 
-    nst, n2, p = n1P + 2, cfg.n2, NATIVE_ARCSEC / cfg.dtheta_as
-    lo, hi = -n2 - 0.5, (n1P + 1) * n2 - 0.5
-    cells = [[[] for _ in range(nst)] for _ in range(nst)]
-    for e in range(n_expo):
-        th = np.deg2rad(11.0 * e + 3.0)
-        g = np.arange(-nst * n2, 2 * nst * n2) * p
-        xx, yy = np.meshgrid(g + rng.uniform(0, p), g + rng.uniform(0, p))
-        x = (np.cos(th) * xx - np.sin(th) * yy).ravel()
-        y = (np.sin(th) * xx + np.cos(th) * yy).ravel()
-        ok = (x > lo) & (x < hi) & (y > lo) & (y < hi) & (rng.uniform(size=x.size) > 0.01)
-        x, y = x[ok], y[ok]
-        ci, cj = ((x - lo) // n2).astype(int), ((y - lo) // n2).astype(int)
-        for j in range(nst):
-            for i in range(nst):
-                m = (ci == i) & (cj == j)
-                cells[j][i].append((x[m], y[m]))
-    out = []
-    for j in range(nst):
-        for i in range(nst):
-            parts = cells[j][i]
-            cum = np.concatenate([[0], np.cumsum([len(q[0]) for q in parts])])
-            xs, ys = np.hstack([q[0] for q in parts]), np.hstack([q[1] for q in parts])
-            out.append((xs, ys, rng.standard_normal((cfg.n_inframe, xs.size)).astype(np.float32), cum))
-    return out
+    return make_instamps(cfg, n1P, n_expo, rng)
 
 
 @pytest.mark.parametrize("n_out", [1, 2])
