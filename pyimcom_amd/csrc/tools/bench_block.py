@@ -47,4 +47,4 @@ for gj in range(ng):
         mod = 1.0 + 0.02 * np.sin(0.05 * lin * (1 + gi % 3))[None, None, :] + 0.02 * np.cos(0.04 * lin * (1 + gj % 3))[None, :, None]
         q = psfs * mod
         groups[(gj, gi)] = q / q.sum(axis=(1, 2), keepdims=True)
-timed(f"{ng * ng} PSF groups (2x2)", lambda: BlockTables(groups, target, cfg.nfft, capacity=4096))
+timed(f"{ng * ng} PSF groups (2x2)", lambda: BlockTables(groups, target, cfg.nfft, capacity=12000))
