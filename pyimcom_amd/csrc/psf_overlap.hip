@@ -110,17 +110,18 @@ __global__ void crop_table_kernel(const double *__restrict__ win, int Wp, int ns
 // ---------------------------------------------------------------------------------------------------------
 // Butterfly path: mixed-radix Stockham FFTs in LDS (radices 4, 2, 3, 5), used whenever nfft factors into them and
 // the lines fit (nfft <= 1024); the dense-DFT GEMM form above stays as the general fallback and as an independent
-// cross-check (IMCOM_PSF_OVERLAP=gemm).  A workgroup transforms FFT_L lines at once, all in one LDS buffer: in
+// cross-check (IMCOM_PSF_OVERLAP=gemm).  A workgroup transforms L (8 or 4) lines at once, all in one LDS buffer: in
 // every stage each thread first reads all of its butterflies into registers, then -- after a barrier -- writes
 // them back in Stockham order, so no second buffer and no digit reversal are needed.
-//   forward:  rows two-for-one (two real PSF rows ride as one complex line), then columns on tiles of FFT_L
+//   forward:  rows two-for-one (two real PSF rows ride as one complex line), then columns on tiles of L
 //   inverse:  columns of R1 conj(R2) (the product is formed on load), kept rows only; then rows two-for-one from
 //             the Hermitian half back to two real window rows, rolled by nc and cropped on store.
-constexpr int FFT_L = 4;       // lines per workgroup
-constexpr int FFT_MAXIT = 8;   // butterflies per thread and stage (nfft * FFT_L / (radix * 256) <= 8)
+// lines per workgroup: template parameter L of the kernels, 8 where the plan allows (the per-workgroup costs -- twiddle
+// table, barriers -- are shared by more lines: 0.39 against 0.43 ms for 36 cfg-2 tables), else 4
+constexpr int FFT_MAXIT = 8;   // butterflies per thread and stage (nfft * L / (radix * 256) <= 8)
 constexpr int FFT_MAXN = 1024;
 
-struct FftPlan { int n, nst, radix[12]; };
+struct FftPlan { int n, nst, radix[12], lines; };
 
 typedef double2 cplx;
 __device__ __forceinline__ cplx cmulf(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -172,12 +173,12 @@ template <bool INV> __device__ __forceinline__ void dft5(cplx (&v)[5])
 template <> __device__ __forceinline__ void small_dft<5, false>(cplx (&v)[5]) { dft5<false>(v); }
 template <> __device__ __forceinline__ void small_dft<5, true>(cplx (&v)[5]) { dft5<true>(v); }
 
-// one Stockham stage of radix R on FFT_L lines of length n in `buf` ([line][n]); Ns = product of the earlier radices;
+// one Stockham stage of radix R on L lines of length n in `buf` ([line][n]); Ns = product of the earlier radices;
 // tw[k] = exp(-2 pi i k / n)
-template <int R, bool INV>
+template <int R, bool INV, int L>
 __device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *tw)
 {
-    const int nb = n / R, total = nb * FFT_L, step = n / (Ns * R);
+    const int nb = n / R, total = nb * L, step = n / (Ns * R);
     cplx v[FFT_MAXIT][R];
 #pragma unroll
     for (int it = 0; it < FFT_MAXIT; it++) {
@@ -212,16 +213,16 @@ __device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *
     __syncthreads();
 }
 
-template <bool INV>
+template <bool INV, int L>
 __device__ __forceinline__ void fft_lines(cplx *buf, const FftPlan &pl, const cplx *tw)
 {
     int Ns = 1;
     for (int st = 0; st < pl.nst; st++) {
         const int r = pl.radix[st];
-        if (r == 4) fft_stage<4, INV>(buf, pl.n, Ns, tw);
-        else if (r == 2) fft_stage<2, INV>(buf, pl.n, Ns, tw);
-        else if (r == 3) fft_stage<3, INV>(buf, pl.n, Ns, tw);
-        else fft_stage<5, INV>(buf, pl.n, Ns, tw);
+        if (r == 4) fft_stage<4, INV, L>(buf, pl.n, Ns, tw);
+        else if (r == 2) fft_stage<2, INV, L>(buf, pl.n, Ns, tw);
+        else if (r == 3) fft_stage<3, INV, L>(buf, pl.n, Ns, tw);
+        else fft_stage<5, INV, L>(buf, pl.n, Ns, tw);
         Ns *= r;
     }
 }
@@ -236,16 +237,17 @@ __global__ void fft_twiddle_kernel(int n, cplx *__restrict__ tw)
 }
 
 // forward, along x: rows 2l, 2l+1 of PSF p as one complex line; Y1[p][kx][row], kx < nh
+template <int L>
 __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restrict__ psf, int ns, FftPlan pl,
                                                            const cplx *__restrict__ tw, cplx *__restrict__ Y1)
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y;
-    cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
+    cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     const double *img = psf + (long)p * ns * ns;
-    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
-        const int line = e / n, x = e - line * n, r0 = 2 * (blockIdx.x * FFT_L + line);
+    for (int e = threadIdx.x; e < L * n; e += 256) {
+        const int line = e / n, x = e - line * n, r0 = 2 * (blockIdx.x * L + line);
         double re = 0.0, im = 0.0;
         if (x < ns) {
             if (r0 < ns) re = img[(long)r0 * ns + x];
@@ -254,9 +256,9 @@ __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restr
         fbuf[e] = make_double2(re, im);
     }
     __syncthreads();
-    fft_lines<false>(fbuf, pl, twl);
-    for (int e = threadIdx.x; e < FFT_L * nh; e += 256) {  // Y1 is stored [kx][row]: the 2 FFT_L rows of this block are contiguous
-        const int k = e / FFT_L, line = e - k * FFT_L, r0 = 2 * (blockIdx.x * FFT_L + line);
+    fft_lines<false, L>(fbuf, pl, twl);
+    for (int e = threadIdx.x; e < L * nh; e += 256) {  // Y1 is stored [kx][row]: the 2 L rows of this block are contiguous
+        const int k = e / L, line = e - k * L, r0 = 2 * (blockIdx.x * L + line);
         if (r0 >= ns) continue;
         const cplx zk = fbuf[line * n + k], zm = fbuf[line * n + (n - k) % n];
         Y1[((long)p * nh + k) * ns + r0] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
@@ -264,41 +266,43 @@ __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restr
     }
 }
 
-// forward, along y: FFT_L columns of Y1[p] (rows >= ns are zero) -> R[p][kx][ky]
+// forward, along y: L columns of Y1[p] (rows >= ns are zero) -> R[p][kx][ky]
+template <int L>
 __global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restrict__ Y1, int ns, FftPlan pl,
                                                            const cplx *__restrict__ tw, cplx *__restrict__ R)
 {
     extern __shared__ cplx fbuf[];
-    const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y, kx0 = blockIdx.x * FFT_L;
-    cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
+    const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y, kx0 = blockIdx.x * L;
+    cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
-    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
+    for (int e = threadIdx.x; e < L * n; e += 256) {
         const int c = e / n, y = e - c * n;
         cplx v = make_double2(0.0, 0.0);
         if (y < ns && kx0 + c < nh) v = Y1[((long)p * nh + kx0 + c) * ns + y];
         fbuf[e] = v;
     }
     __syncthreads();
-    fft_lines<false>(fbuf, pl, twl);
-    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {  // spectra are stored [kx][ky]: whole lines
+    fft_lines<false, L>(fbuf, pl, twl);
+    for (int e = threadIdx.x; e < L * n; e += 256) {  // spectra are stored [kx][ky]: whole lines
         const int c = e / n, ky = e - c * n;
         if (kx0 + c < nh) R[((long)p * nh + kx0 + c) * n + ky] = fbuf[e];
     }
 }
 
-// inverse, along y: FFT_L columns of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][kx][y'] for the
+// inverse, along y: L columns of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][kx][y'] for the
 // kept rows y' < ns (source row (y' - nc) mod n: the roll of psfutil.py:1225-1232)
+template <int L>
 __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
                                                            const int *__restrict__ pairs, int ns,
                                                            FftPlan pl, const cplx *__restrict__ tw, double amp0, double amps,
                                                            cplx *__restrict__ V)
 {
     extern __shared__ cplx fbuf[];
-    const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, kx0 = blockIdx.x * FFT_L, nc = ns / 2;
-    cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
+    const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, kx0 = blockIdx.x * L, nc = ns / 2;
+    cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     const cplx *R1 = Ra + (long)pairs[2 * t] * n * nh, *R2 = Rb + (long)pairs[2 * t + 1] * n * nh;
-    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {
+    for (int e = threadIdx.x; e < L * n; e += 256) {
         const int c = e / n, ky = e - c * n, kx = kx0 + c;
         cplx z = make_double2(0.0, 0.0);
         if (kx < nh) {
@@ -316,8 +320,8 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
         fbuf[e] = z;
     }
     __syncthreads();
-    fft_lines<true>(fbuf, pl, twl);
-    for (int e = threadIdx.x; e < FFT_L * ns; e += 256) {  // V is stored [kx][y']
+    fft_lines<true, L>(fbuf, pl, twl);
+    for (int e = threadIdx.x; e < L * ns; e += 256) {  // V is stored [kx][y']
         const int c = e / ns, yp = e - c * ns;
         if (kx0 + c < nh) V[((long)t * nh + kx0 + c) * ns + yp] = fbuf[c * n + (yp - nc + n) % n];
     }
@@ -326,15 +330,16 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
 // inverse, along x: window rows 2l, 2l+1 of pair t from their Hermitian halves as one complex line; the real and the
 // imaginary part of the result are the two rows.  numpy's c2r ignores the imaginary parts of the DC and Nyquist
 // bins; so does this.  Stored rolled by nc, cropped to ns, scaled by 1/n^2, inside the 6-sample zero border.
+template <int L>
 __global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restrict__ V, int ns, FftPlan pl,
                                                            const cplx *__restrict__ tw, double *__restrict__ tables)
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, nc = ns / 2, ng = ns + 12;
-    cplx *twl = fbuf + FFT_L * n;  // the twiddle table rides in LDS behind the lines
+    cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
-    for (int e = threadIdx.x; e < FFT_L * n; e += 256) {  // the 2 FFT_L rows of this block are contiguous in V[kx][y']
-        const int k = e / FFT_L, line = e - k * FFT_L, r0 = 2 * (blockIdx.x * FFT_L + line);
+    for (int e = threadIdx.x; e < L * n; e += 256) {  // the 2 L rows of this block are contiguous in V[kx][y']
+        const int k = e / L, line = e - k * L, r0 = 2 * (blockIdx.x * L + line);
         const int kk = k < nh ? k : n - k;
         const bool edge = kk == 0 || 2 * kk == n;
         cplx a = make_double2(0.0, 0.0), b = a;
@@ -345,10 +350,10 @@ __global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restric
         fbuf[line * n + k] = make_double2(a.x - b.y, a.y + b.x);
     }
     __syncthreads();
-    fft_lines<true>(fbuf, pl, twl);
+    fft_lines<true, L>(fbuf, pl, twl);
     const double scale = 1.0 / ((double)n * (double)n);
-    for (int e = threadIdx.x; e < FFT_L * ns; e += 256) {
-        const int line = e / ns, xp = e - line * ns, r0 = 2 * (blockIdx.x * FFT_L + line);
+    for (int e = threadIdx.x; e < L * ns; e += 256) {
+        const int line = e / ns, xp = e - line * ns, r0 = 2 * (blockIdx.x * L + line);
         if (r0 >= ns) continue;
         const cplx z = fbuf[line * n + (xp - nc + n) % n];
         tables[((long)t * ng + 6 + r0) * ng + 6 + xp] = z.x * scale;
@@ -371,9 +376,12 @@ static bool fft_plan(int n, FftPlan *pl)
             r /= cand[ci];
         }
     if (r != 1) return false;
-    for (int st = 0; st < pl->nst; st++)
-        if ((n / pl->radix[st]) * FFT_L > FFT_MAXIT * 256) return false;
-    return true;
+    for (int lines = 8; lines >= 4; lines /= 2) {
+        bool ok = (size_t)(lines + 1) * n * 16 <= 160 * 1024;
+        for (int st = 0; st < pl->nst; st++) ok = ok && (n / pl->radix[st]) * lines <= FFT_MAXIT * 256;
+        if (ok) { pl->lines = lines; return true; }
+    }
+    return false;
 }
 
 
@@ -383,18 +391,23 @@ static bool fft_force_gemm()
     return f;
 }
 
-static size_t fft_lds_bytes(int nfft) { return (size_t)(FFT_L + 1) * nfft * 16; }  // lines + twiddle table
+static size_t fft_lds_bytes(const FftPlan &pl) { return (size_t)(pl.lines + 1) * pl.n * 16; }  // lines + twiddle table
 
-static int fft_set_lds(int nfft)
+template <int L>
+static int fft_set_lds_l(size_t lds)
 {
-    const size_t lds = fft_lds_bytes(nfft);
-    if (lds > 48 * 1024) {
-        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_rows_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_cols_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_cols_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_rows_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     return IMCOM_OK;
+}
+
+static int fft_set_lds(const FftPlan &pl)
+{
+    const size_t lds = fft_lds_bytes(pl);
+    if (lds <= 48 * 1024) return IMCOM_OK;
+    return pl.lines == 8 ? fft_set_lds_l<8>(lds) : fft_set_lds_l<4>(lds);
 }
 
 static size_t fft_forward_ws(int n, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)n * nsamp * (nfft / 2 + 1) * 16 + 1024; }
@@ -407,13 +420,18 @@ static int fft_forward(imcom_ctx *ctx, const FftPlan &pl, const double *psf, int
     cplx *tw = (cplx *)ws_take(ctx, (size_t)nfft * 16);
     cplx *Y1 = (cplx *)ws_take(ctx, (size_t)n * nsamp * nh * 16);
     if (!tw || !Y1) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
-    IMCOM_TRY(fft_set_lds(nfft));
+    IMCOM_TRY(fft_set_lds(pl));
     hipStream_t st = ctx->stream;
-    const size_t lds = fft_lds_bytes(nfft);
-    const int row_blocks = ((nsamp + 1) / 2 + FFT_L - 1) / FFT_L, col_blocks = (nh + FFT_L - 1) / FFT_L;
+    const size_t lds = fft_lds_bytes(pl);
+    const int FL = pl.lines, row_blocks = ((nsamp + 1) / 2 + FL - 1) / FL, col_blocks = (nh + FL - 1) / FL;
     hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
-    hipLaunchKernelGGL(fft_fwd_rows_kernel, dim3(row_blocks, n), dim3(256), lds, st, psf, nsamp, pl, tw, Y1);
-    hipLaunchKernelGGL(fft_fwd_cols_kernel, dim3(col_blocks, n), dim3(256), lds, st, Y1, nsamp, pl, tw, R);
+    if (FL == 8) {
+        hipLaunchKernelGGL(fft_fwd_rows_kernel<8>, dim3(row_blocks, n), dim3(256), lds, st, psf, nsamp, pl, tw, Y1);
+        hipLaunchKernelGGL(fft_fwd_cols_kernel<8>, dim3(col_blocks, n), dim3(256), lds, st, Y1, nsamp, pl, tw, R);
+    } else {
+        hipLaunchKernelGGL(fft_fwd_rows_kernel<4>, dim3(row_blocks, n), dim3(256), lds, st, psf, nsamp, pl, tw, Y1);
+        hipLaunchKernelGGL(fft_fwd_cols_kernel<4>, dim3(col_blocks, n), dim3(256), lds, st, Y1, nsamp, pl, tw, R);
+    }
     return check_launch("psf spectra (butterfly path)");
 }
 
@@ -426,16 +444,21 @@ static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const 
     cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * nsamp * nh * 16);
     int *pairs_dev = (int *)ws_take(ctx, (size_t)npairs * 8);
     if (!tw || !V || !pairs_dev) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
-    IMCOM_TRY(fft_set_lds(nfft));
+    IMCOM_TRY(fft_set_lds(pl));
     hipStream_t st = ctx->stream;
     IMCOM_HIP_CHECK(hipMemcpyAsync(pairs_dev, pairs_host, (size_t)npairs * 8, hipMemcpyHostToDevice, st));
-    const size_t lds = fft_lds_bytes(nfft);
-    const int row_blocks = ((nsamp + 1) / 2 + FFT_L - 1) / FFT_L, col_blocks = (nh + FFT_L - 1) / FFT_L;
+    const size_t lds = fft_lds_bytes(pl);
+    const int FL = pl.lines, row_blocks = ((nsamp + 1) / 2 + FL - 1) / FL, col_blocks = (nh + FL - 1) / FL;
+    const double a0 = amp_penalty ? amp_penalty[0] : 0.0, a1 = amp_penalty ? amp_penalty[1] : 0.0;
     hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
-    hipLaunchKernelGGL(fft_inv_cols_kernel, dim3(col_blocks, npairs), dim3(256), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw,
-                       amp_penalty ? amp_penalty[0] : 0.0, amp_penalty ? amp_penalty[1] : 0.0, V);
     IMCOM_HIP_CHECK(hipMemsetAsync(tables, 0, (size_t)npairs * ng * ng * 8, st));
-    hipLaunchKernelGGL(fft_inv_rows_kernel, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
+    if (FL == 8) {
+        hipLaunchKernelGGL(fft_inv_cols_kernel<8>, dim3(col_blocks, npairs), dim3(256), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
+        hipLaunchKernelGGL(fft_inv_rows_kernel<8>, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
+    } else {
+        hipLaunchKernelGGL(fft_inv_cols_kernel<4>, dim3(col_blocks, npairs), dim3(256), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
+        hipLaunchKernelGGL(fft_inv_rows_kernel<4>, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
+    }
     IMCOM_TRY(check_launch("psf_overlap (butterfly path)"));
     IMCOM_HIP_CHECK(hipStreamSynchronize(st));  // pairs_host belongs to the caller
     return IMCOM_OK;
