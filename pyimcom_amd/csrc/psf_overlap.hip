@@ -178,38 +178,46 @@ template <> __device__ __forceinline__ void small_dft<5, true>(cplx (&v)[5]) { d
 template <int R, bool INV, int L>
 __device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *tw)
 {
-    const int nb = n / R, total = nb * L, step = n / (Ns * R);
-    cplx v[FFT_MAXIT][R];
+    // butterfly j of a line is handled by thread j mod 256, line after line: no index divisions (fft_plan guarantees
+    // n / R <= 256 * FFT_MAXIT / L); Ns is a power of two until the first radix-3 / 5 stage
+    constexpr int Q = FFT_MAXIT / L;
+    const int nb = n / R, step = n / (Ns * R);
+    const bool pow2 = (Ns & (Ns - 1)) == 0;
+    cplx v[L * Q][R];
 #pragma unroll
-    for (int it = 0; it < FFT_MAXIT; it++) {
-        const int b = threadIdx.x + it * 256;
-        if (b < total) {
-            const int line = b / nb, j = b - line * nb, k = j % Ns;
-            const cplx *x = buf + line * n;
+    for (int line = 0; line < L; line++)
 #pragma unroll
-            for (int t = 0; t < R; t++) {
-                cplx a = x[j + t * nb];
-                if (t > 0) {
-                    cplx w = tw[t * k * step];
-                    if (INV) w.y = -w.y;
-                    a = cmulf(a, w);
+        for (int q = 0; q < Q; q++) {
+            const int j = threadIdx.x + q * 256;
+            if (j < nb) {
+                const int k = pow2 ? (j & (Ns - 1)) : j % Ns;
+                const cplx *x = buf + line * n;
+#pragma unroll
+                for (int t = 0; t < R; t++) {
+                    cplx a = x[j + t * nb];
+                    if (t > 0) {
+                        cplx w = tw[t * k * step];
+                        if (INV) w.y = -w.y;
+                        a = cmulf(a, w);
+                    }
+                    v[line * Q + q][t] = a;
                 }
-                v[it][t] = a;
+                small_dft<R, INV>(v[line * Q + q]);
             }
-            small_dft<R, INV>(v[it]);
         }
-    }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < FFT_MAXIT; it++) {
-        const int b = threadIdx.x + it * 256;
-        if (b < total) {
-            const int line = b / nb, j = b - line * nb, k = j % Ns;
-            cplx *x = buf + line * n + (j - k) * R + k;
+    for (int line = 0; line < L; line++)
 #pragma unroll
-            for (int u = 0; u < R; u++) x[u * Ns] = v[it][u];
+        for (int q = 0; q < Q; q++) {
+            const int j = threadIdx.x + q * 256;
+            if (j < nb) {
+                const int k = pow2 ? (j & (Ns - 1)) : j % Ns;
+                cplx *x = buf + line * n + (j - k) * R + k;
+#pragma unroll
+                for (int u = 0; u < R; u++) x[u * Ns] = v[line * Q + q][u];
+            }
         }
-    }
     __syncthreads();
 }
 
@@ -246,8 +254,8 @@ __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restr
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     const double *img = psf + (long)p * ns * ns;
-    for (int e = threadIdx.x; e < L * n; e += 256) {
-        const int line = e / n, x = e - line * n, r0 = 2 * (blockIdx.x * L + line);
+    for (int line = 0; line < L; line++) for (int x = threadIdx.x; x < n; x += 256) {
+        const int e = line * n + x, r0 = 2 * (blockIdx.x * L + line);
         double re = 0.0, im = 0.0;
         if (x < ns) {
             if (r0 < ns) re = img[(long)r0 * ns + x];
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restr
     for (int e = threadIdx.x; e < L * nh; e += 256) {  // Y1 is stored [kx][row]: the 2 L rows of this block are contiguous
         const int k = e / L, line = e - k * L, r0 = 2 * (blockIdx.x * L + line);
         if (r0 >= ns) continue;
-        const cplx zk = fbuf[line * n + k], zm = fbuf[line * n + (n - k) % n];
+        const cplx zk = fbuf[line * n + k], zm = fbuf[line * n + (k ? n - k : 0)];
         Y1[((long)p * nh + k) * ns + r0] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
         if (r0 + 1 < ns) Y1[((long)p * nh + k) * ns + r0 + 1] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
     }
@@ -275,16 +283,16 @@ __global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restric
     const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y, kx0 = blockIdx.x * L;
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
-    for (int e = threadIdx.x; e < L * n; e += 256) {
-        const int c = e / n, y = e - c * n;
+    for (int c = 0; c < L; c++) for (int y = threadIdx.x; y < n; y += 256) {
+        const int e = c * n + y;
         cplx v = make_double2(0.0, 0.0);
         if (y < ns && kx0 + c < nh) v = Y1[((long)p * nh + kx0 + c) * ns + y];
         fbuf[e] = v;
     }
     __syncthreads();
     fft_lines<false, L>(fbuf, pl, twl);
-    for (int e = threadIdx.x; e < L * n; e += 256) {  // spectra are stored [kx][ky]: whole lines
-        const int c = e / n, ky = e - c * n;
+    for (int c = 0; c < L; c++) for (int ky = threadIdx.x; ky < n; ky += 256) {  // spectra are stored [kx][ky]: whole lines
+        const int e = c * n + ky;
         if (kx0 + c < nh) R[((long)p * nh + kx0 + c) * n + ky] = fbuf[e];
     }
 }
@@ -302,8 +310,8 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     const cplx *R1 = Ra + (long)pairs[2 * t] * n * nh, *R2 = Rb + (long)pairs[2 * t + 1] * n * nh;
-    for (int e = threadIdx.x; e < L * n; e += 256) {
-        const int c = e / n, ky = e - c * n, kx = kx0 + c;
+    for (int c = 0; c < L; c++) for (int ky = threadIdx.x; ky < n; ky += 256) {
+        const int e = c * n + ky, kx = kx0 + c;
         cplx z = make_double2(0.0, 0.0);
         if (kx < nh) {
             const cplx a = R1[(long)kx * n + ky], b = R2[(long)kx * n + ky];
@@ -321,9 +329,8 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
     }
     __syncthreads();
     fft_lines<true, L>(fbuf, pl, twl);
-    for (int e = threadIdx.x; e < L * ns; e += 256) {  // V is stored [kx][y']
-        const int c = e / ns, yp = e - c * ns;
-        if (kx0 + c < nh) V[((long)t * nh + kx0 + c) * ns + yp] = fbuf[c * n + (yp - nc + n) % n];
+    for (int c = 0; c < L; c++) for (int yp = threadIdx.x; yp < ns; yp += 256) {  // V is stored [kx][y']
+        if (kx0 + c < nh) V[((long)t * nh + kx0 + c) * ns + yp] = fbuf[c * n + yp - nc + (yp < nc ? n : 0)];
     }
 }
 
@@ -352,10 +359,10 @@ __global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restric
     __syncthreads();
     fft_lines<true, L>(fbuf, pl, twl);
     const double scale = 1.0 / ((double)n * (double)n);
-    for (int e = threadIdx.x; e < L * ns; e += 256) {
-        const int line = e / ns, xp = e - line * ns, r0 = 2 * (blockIdx.x * L + line);
+    for (int line = 0; line < L; line++) for (int xp = threadIdx.x; xp < ns; xp += 256) {
+        const int r0 = 2 * (blockIdx.x * L + line);
         if (r0 >= ns) continue;
-        const cplx z = fbuf[line * n + (xp - nc + n) % n];
+        const cplx z = fbuf[line * n + xp - nc + (xp < nc ? n : 0)];
         tables[((long)t * ng + 6 + r0) * ng + 6 + xp] = z.x * scale;
         if (r0 + 1 < ns) tables[((long)t * ng + 6 + r0 + 1) * ng + 6 + xp] = z.y * scale;
     }
@@ -378,7 +385,7 @@ static bool fft_plan(int n, FftPlan *pl)
     if (r != 1) return false;
     for (int lines = 8; lines >= 4; lines /= 2) {
         bool ok = (size_t)(lines + 1) * n * 16 <= 160 * 1024;
-        for (int st = 0; st < pl->nst; st++) ok = ok && (n / pl->radix[st]) * lines <= FFT_MAXIT * 256;
+        for (int st = 0; st < pl->nst; st++) ok = ok && n / pl->radix[st] <= 256 * (FFT_MAXIT / lines);
         if (ok) { pl->lines = lines; return true; }
     }
     return false;
