@@ -99,30 +99,6 @@ int pin_reserve(imcom_ctx *ctx, size_t bytes)
     return IMCOM_OK;
 }
 
-// Small host arrays go through a pinned ring so the async copy never reads caller memory after the
-// call returned; the stream is drained when the ring wraps.
-template <typename T>
-static int upload(imcom_ctx *ctx, T *dst, const T *src_host, size_t count)
-{
-    if (count == 0) return IMCOM_OK;
-    const size_t bytes = count * sizeof(T);
-    if (!ctx->pin) IMCOM_TRY(pin_reserve(ctx, (size_t)4 << 20));
-    if (bytes > ctx->pin_bytes / 4) {  // large: plain synchronous copy
-        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        IMCOM_HIP_CHECK(hipMemcpy(dst, src_host, bytes, hipMemcpyHostToDevice));
-        return IMCOM_OK;
-    }
-    size_t off = align_up(ctx->pin_used, 64);
-    if (off + bytes > ctx->pin_bytes) {
-        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        off = 0;
-    }
-    memcpy(ctx->pin + off, src_host, bytes);
-    ctx->pin_used = off + bytes;
-    IMCOM_HIP_CHECK(hipMemcpyAsync(dst, ctx->pin + off, bytes, hipMemcpyHostToDevice, ctx->stream));
-    return IMCOM_OK;
-}
-
 // -------------------------------------------------------------------------------------------------
 // Batched blocked Cholesky solve on padded, device-resident operands.
 //   A  [batch][Np][Np]   identity-padded, never modified

@@ -453,7 +453,7 @@ static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const 
     if (!tw || !V || !pairs_dev) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
     IMCOM_TRY(fft_set_lds(pl));
     hipStream_t st = ctx->stream;
-    IMCOM_HIP_CHECK(hipMemcpyAsync(pairs_dev, pairs_host, (size_t)npairs * 8, hipMemcpyHostToDevice, st));
+    IMCOM_TRY(upload(ctx, pairs_dev, pairs_host, 2 * (size_t)npairs));  // through the pinned ring: no stream drain
     const size_t lds = fft_lds_bytes(pl);
     const int FL = pl.lines, row_blocks = ((nsamp + 1) / 2 + FL - 1) / FL, col_blocks = (nh + FL - 1) / FL;
     const double a0 = amp_penalty ? amp_penalty[0] : 0.0, a1 = amp_penalty ? amp_penalty[1] : 0.0;
@@ -466,9 +466,7 @@ static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const 
         hipLaunchKernelGGL(fft_inv_cols_kernel<4>, dim3(col_blocks, npairs), dim3(256), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
         hipLaunchKernelGGL(fft_inv_rows_kernel<4>, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
     }
-    IMCOM_TRY(check_launch("psf_overlap (butterfly path)"));
-    IMCOM_HIP_CHECK(hipStreamSynchronize(st));  // pairs_host belongs to the caller
-    return IMCOM_OK;
+    return check_launch("psf_overlap (butterfly path)");
 }
 
 static int up(int v, int a) { return (v + a - 1) / a * a; }
