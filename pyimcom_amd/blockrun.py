@@ -34,7 +34,7 @@ def stamp_neighbours(j_st, i_st, n2, nst):
     return ids, pvx, pvy
 
 
-def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_pad=0, ldn=None):
+def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_pad=0, ldn=None, pipeline=True):
     """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
     order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables.  Returns the BlockMaps."""
     nst = n1P + 2
@@ -43,29 +43,33 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_
                      n_out=int(getattr(tables, "n_out", 1)))
     todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
     counts = np.diff(pool.inst_off)
-    for c0 in range(0, len(todo), batch):
-        chunk = todo[c0 : c0 + batch]
+    def prepare(chunk):
+        """Selection, table sets, pair maps and the StampBatch of one chunk of stamps (everything up to build())."""
         nb = [stamp_neighbours(j, i, cfg.n2, nst) for j, i in chunk]
         ids = np.stack([t[0] for t in nb])
         # capacity: every pixel of the nine neighbours at most
         cap = max(int(counts[t[0][t[0] >= 0]].sum()) for t in nb)
         ld = ldn or max(NB, (cap + NB - 1) // NB * NB)
-        x, y, indata, expo, cumsum = select_pixels(pool, ids, np.stack([t[1] for t in nb]), np.stack([t[2] for t in nb]), cfg.rho, ld,
-                                                   ctx=tables.ctx)
-        n = cumsum[:, 9]
-        keep = (n.max() + NB - 1) // NB * NB if n.max() > 0 else NB  # trim the padding to what the batch needs
+        # first everything that needs no answer from the GPU -- table sets (queued), pair maps (host) -- then the
+        # selection, whose pixel counts the host has to wait for
         psf_slot = maps_ = None
-        if isinstance(tables, BlockTables):
-            import torch
-
+        grouped = isinstance(tables, BlockTables)
+        if grouped:
             grp = [[(int(k) // nst >> 1, int(k) % nst >> 1) if k >= 0 else None for k in t[0]] for t in nb]
             local = [list(dict.fromkeys(g for g in gs if g is not None)) for gs in grp]  # distinct groups of each stamp
             tables.require([k for gs in local for k in BlockTables.keys_for(gs)])
             per = [tables.stamp_maps(gs, cfg.flat_penalty) for gs in local]
             maps_ = tuple(np.stack([p[q] for p in per]) for q in range(3))
+            lg = np.array([[gs.index(g) if g is not None else 0 for g in row] for row, gs in zip(grp, local)], dtype=np.int64)
+        x, y, indata, expo, cumsum = select_pixels(pool, ids, np.stack([t[1] for t in nb]), np.stack([t[2] for t in nb]), cfg.rho, ld,
+                                                   ctx=tables.ctx)
+        n = cumsum[:, 9]
+        keep = (n.max() + NB - 1) // NB * NB if n.max() > 0 else NB  # trim the padding to what the batch needs
+        if grouped:
+            import torch
+
             # stamp-local PSF index of every pixel: lut[position of its InStamp's group in the stamp's list, exposure]
             lut = torch.as_tensor(np.stack([p[3] for p in per]).astype(np.int64), device=x.device)  # [B, 4, n_blk_expo]
-            lg = np.array([[gs.index(g) if g is not None else 0 for g in row] for row, gs in zip(grp, local)], dtype=np.int64)
             cs = torch.as_tensor(cumsum[:, 1:10].astype(np.int64), device=x.device)
             seg = torch.searchsorted(cs, torch.arange(keep, device=x.device).expand(len(chunk), keep).contiguous(), right=True).clamp_(max=8)
             lgp = torch.as_tensor(lg, device=x.device).gather(1, seg)  # group position of every pixel
@@ -77,7 +81,22 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_
         sb = StampBatch.from_device(cfg, tables, n, x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep],
                                     [(i - 1) * cfg.n2 - cfg.fade for _, i in chunk], [(j - 1) * cfg.n2 - cfg.fade for j, _ in chunk],
                                     n_expo, ctx=tables.ctx, psf_slot=psf_slot, maps=maps_)
-        sb.run()
+        return sb
+
+    # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after
+    # the current one's A and B builds have been queued, i.e. while the GPU is busy with them; only then does the host
+    # block in the solve's status read-back
+    chunks = [todo[c0 : c0 + batch] for c0 in range(0, len(todo), batch)]
+    nxt = prepare(chunks[0]) if chunks else None
+    for k, chunk in enumerate(chunks):
+        sb = nxt
+        sb.build()
+        if pipeline:
+            nxt = prepare(chunks[k + 1]) if k + 1 < len(chunks) else None
+        sb.solve()
+        sb.coadd()
+        if not pipeline:
+            nxt = prepare(chunks[k + 1]) if k + 1 < len(chunks) else None
         maps.add(sb.results(), [j for j, _ in chunk], [i for _, i in chunk])
     maps.finalize(pad_sides, postage_pad)
     return maps

@@ -25,14 +25,14 @@ nst = n1P + 2
 print(f"block {n1P}x{n1P} stamps, {pool.npool} input pixels in {nst * nst} InStamps, batch {batch}")
 
 
-def timed(label, tables_factory, reps=2):
+def timed(label, tables_factory, reps=3, pipeline=True):
     tabs = tables_factory()
-    coadd_block(cfg, pool, tabs, n1P, E, batch=batch)  # warm-up: workspace and buffers
+    coadd_block(cfg, pool, tabs, n1P, E, batch=batch, pipeline=pipeline)  # warm-up: workspace and buffers
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         tabs = tables_factory()  # table construction is part of the block
-        maps = coadd_block(cfg, pool, tabs, n1P, E, batch=batch)
+        maps = coadd_block(cfg, pool, tabs, n1P, E, batch=batch, pipeline=pipeline)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(f"{label}: {dt * 1e3:8.1f} ms per block = {n1P * n1P / dt:7.1f} stamps/s  (out_map rms {float(maps.out_map.square().mean().sqrt()):.4g})")
@@ -47,4 +47,5 @@ for gj in range(ng):
         mod = 1.0 + 0.02 * np.sin(0.05 * lin * (1 + gi % 3))[None, None, :] + 0.02 * np.cos(0.04 * lin * (1 + gj % 3))[None, :, None]
         q = psfs * mod
         groups[(gj, gi)] = q / q.sum(axis=(1, 2), keepdims=True)
-timed(f"{ng * ng} PSF groups (2x2)", lambda: BlockTables(groups, target, cfg.nfft, capacity=12000))
+for pl in (True, False, True, False):
+    timed(f"{ng * ng} PSF groups (2x2), pipeline={pl}", lambda: BlockTables(groups, target, cfg.nfft, capacity=12000), pipeline=pl)
