@@ -254,7 +254,10 @@ __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restr
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     const double *img = psf + (long)p * ns * ns;
-    for (int line = 0; line < L; line++) for (int x = threadIdx.x; x < n; x += 256) {
+#pragma unroll
+    for (int line = 0; line < L; line++)
+#pragma unroll 3
+        for (int x = threadIdx.x; x < n; x += 256) {
         const int e = line * n + x, r0 = 2 * (blockIdx.x * L + line);
         double re = 0.0, im = 0.0;
         if (x < ns) {
@@ -283,7 +286,10 @@ __global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restric
     const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y, kx0 = blockIdx.x * L;
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
-    for (int c = 0; c < L; c++) for (int y = threadIdx.x; y < n; y += 256) {
+#pragma unroll
+    for (int c = 0; c < L; c++)
+#pragma unroll 3
+        for (int y = threadIdx.x; y < n; y += 256) {
         const int e = c * n + y;
         cplx v = make_double2(0.0, 0.0);
         if (y < ns && kx0 + c < nh) v = Y1[((long)p * nh + kx0 + c) * ns + y];
@@ -291,7 +297,10 @@ __global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restric
     }
     __syncthreads();
     fft_lines<false, L>(fbuf, pl, twl);
-    for (int c = 0; c < L; c++) for (int ky = threadIdx.x; ky < n; ky += 256) {  // spectra are stored [kx][ky]: whole lines
+#pragma unroll
+    for (int c = 0; c < L; c++)
+#pragma unroll 3
+        for (int ky = threadIdx.x; ky < n; ky += 256) {  // spectra are stored [kx][ky]: whole lines
         const int e = c * n + ky;
         if (kx0 + c < nh) R[((long)p * nh + kx0 + c) * n + ky] = fbuf[e];
     }
@@ -310,7 +319,10 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
     const cplx *R1 = Ra + (long)pairs[2 * t] * n * nh, *R2 = Rb + (long)pairs[2 * t + 1] * n * nh;
-    for (int c = 0; c < L; c++) for (int ky = threadIdx.x; ky < n; ky += 256) {
+#pragma unroll
+    for (int c = 0; c < L; c++)
+#pragma unroll 3
+        for (int ky = threadIdx.x; ky < n; ky += 256) {
         const int e = c * n + ky, kx = kx0 + c;
         cplx z = make_double2(0.0, 0.0);
         if (kx < nh) {
@@ -329,7 +341,10 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
     }
     __syncthreads();
     fft_lines<true, L>(fbuf, pl, twl);
-    for (int c = 0; c < L; c++) for (int yp = threadIdx.x; yp < ns; yp += 256) {  // V is stored [kx][y']
+#pragma unroll
+    for (int c = 0; c < L; c++)
+#pragma unroll 3
+        for (int yp = threadIdx.x; yp < ns; yp += 256) {  // V is stored [kx][y']
         if (kx0 + c < nh) V[((long)t * nh + kx0 + c) * ns + yp] = fbuf[c * n + yp - nc + (yp < nc ? n : 0)];
     }
 }
@@ -345,6 +360,7 @@ __global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restric
     const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, nc = ns / 2, ng = ns + 12;
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
     for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
+#pragma unroll 6
     for (int e = threadIdx.x; e < L * n; e += 256) {  // the 2 L rows of this block are contiguous in V[kx][y']
         const int k = e / L, line = e - k * L, r0 = 2 * (blockIdx.x * L + line);
         const int kk = k < nh ? k : n - k;
@@ -359,7 +375,10 @@ __global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restric
     __syncthreads();
     fft_lines<true, L>(fbuf, pl, twl);
     const double scale = 1.0 / ((double)n * (double)n);
-    for (int line = 0; line < L; line++) for (int xp = threadIdx.x; xp < ns; xp += 256) {
+#pragma unroll
+    for (int line = 0; line < L; line++)
+#pragma unroll 3
+        for (int xp = threadIdx.x; xp < ns; xp += 256) {
         const int r0 = 2 * (blockIdx.x * L + line);
         if (r0 >= ns) continue;
         const cplx z = fbuf[line * n + xp - nc + (xp < nc ? n : 0)];
