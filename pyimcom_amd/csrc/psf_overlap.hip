@@ -6,7 +6,7 @@
 // written with the 6-pixel zero border the interpolators expect.
 //
 // Two formulations.  (1) Butterfly path (default whenever nfft = product of 4, 2, 3, 5 and <= 1024): mixed-radix
-// Stockham FFTs in LDS, see below -- 16 us per cfg-2 table (nfft 768) including the forward transforms.
+// Stockham FFTs in LDS, see below -- 7 us per cfg-2 table (nfft 768).
 // (2) Dense-DFT path (general fallback, IMCOM_PSF_OVERLAP=gemm): the zero-padded 2-D DFTs as dense real matrix
 // products with exact twiddle matrices (integer argument reduction mod nfft, then cos/sin of a multiple of
 // pi/nfft) on the fp64 MFMA tile engine of gemm_f64.hip; only the kept nsamp x nsamp window of the inverse is
@@ -120,6 +120,7 @@ __global__ void crop_table_kernel(const double *__restrict__ win, int Wp, int ns
 // table, barriers -- are shared by more lines: 0.39 against 0.43 ms for 36 cfg-2 tables), else 4
 constexpr int FFT_MAXIT = 8;   // butterflies per thread and stage (nfft * L / (radix * 256) <= 8)
 constexpr int FFT_MAXN = 1024;
+constexpr int FFT_NT = 1024;    // threads per workgroup of the line kernels
 
 struct FftPlan { int n, nst, radix[12], lines; };
 
@@ -180,15 +181,17 @@ __device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *
 {
     // butterfly j of a line is handled by thread j mod 256, line after line: no index divisions (fft_plan guarantees
     // n / R <= 256 * FFT_MAXIT / L); Ns is a power of two until the first radix-3 / 5 stage
-    constexpr int Q = FFT_MAXIT / L;
-    const int nb = n / R, step = n / (Ns * R);
+    // the workgroup is FFT_NT / 256 groups of 256 threads, each taking its share of the lines (sixteen waves per CU hide
+    // the LDS latency better than four with four times the butterflies each: 0.31 -> 0.25 ms for 36 cfg-2 tables)
+    constexpr int Q = FFT_MAXIT / L, LH = L / (FFT_NT / 256);
+    const int nb = n / R, step = n / (Ns * R), tid = threadIdx.x & 255, l0 = (threadIdx.x >> 8) * LH;
     const bool pow2 = (Ns & (Ns - 1)) == 0;
-    cplx v[L * Q][R];
+    cplx v[LH * Q][R];
 #pragma unroll
-    for (int line = 0; line < L; line++)
+    for (int lh = 0; lh < LH; lh++)
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const int j = threadIdx.x + q * 256;
+            const int j = tid + q * 256, line = l0 + lh;
             if (j < nb) {
                 const int k = pow2 ? (j & (Ns - 1)) : j % Ns;
                 const cplx *x = buf + line * n;
@@ -200,22 +203,22 @@ __device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *
                         if (INV) w.y = -w.y;
                         a = cmulf(a, w);
                     }
-                    v[line * Q + q][t] = a;
+                    v[lh * Q + q][t] = a;
                 }
-                small_dft<R, INV>(v[line * Q + q]);
+                small_dft<R, INV>(v[lh * Q + q]);
             }
         }
     __syncthreads();
 #pragma unroll
-    for (int line = 0; line < L; line++)
+    for (int lh = 0; lh < LH; lh++)
 #pragma unroll
         for (int q = 0; q < Q; q++) {
-            const int j = threadIdx.x + q * 256;
+            const int j = tid + q * 256, line = l0 + lh;
             if (j < nb) {
                 const int k = pow2 ? (j & (Ns - 1)) : j % Ns;
                 cplx *x = buf + line * n + (j - k) * R + k;
 #pragma unroll
-                for (int u = 0; u < R; u++) x[u * Ns] = v[line * Q + q][u];
+                for (int u = 0; u < R; u++) x[u * Ns] = v[lh * Q + q][u];
             }
         }
     __syncthreads();
@@ -246,18 +249,18 @@ __global__ void fft_twiddle_kernel(int n, cplx *__restrict__ tw)
 
 // forward, along x: rows 2l, 2l+1 of PSF p as one complex line; Y1[p][kx][row], kx < nh
 template <int L>
-__global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restrict__ psf, int ns, FftPlan pl,
+__global__ __launch_bounds__(FFT_NT) void fft_fwd_rows_kernel(const double *__restrict__ psf, int ns, FftPlan pl,
                                                            const cplx *__restrict__ tw, cplx *__restrict__ Y1)
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y;
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
-    for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
+    for (int e = threadIdx.x; e < n; e += FFT_NT) twl[e] = tw[e];
     const double *img = psf + (long)p * ns * ns;
 #pragma unroll
     for (int line = 0; line < L; line++)
 #pragma unroll 3
-        for (int x = threadIdx.x; x < n; x += 256) {
+        for (int x = threadIdx.x; x < n; x += FFT_NT) {
         const int e = line * n + x, r0 = 2 * (blockIdx.x * L + line);
         double re = 0.0, im = 0.0;
         if (x < ns) {
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restr
     }
     __syncthreads();
     fft_lines<false, L>(fbuf, pl, twl);
-    for (int e = threadIdx.x; e < L * nh; e += 256) {  // Y1 is stored [kx][row]: the 2 L rows of this block are contiguous
+    for (int e = threadIdx.x; e < L * nh; e += FFT_NT) {  // Y1 is stored [kx][row]: the 2 L rows of this block are contiguous
         const int k = e / L, line = e - k * L, r0 = 2 * (blockIdx.x * L + line);
         if (r0 >= ns) continue;
         const cplx zk = fbuf[line * n + k], zm = fbuf[line * n + (k ? n - k : 0)];
@@ -279,17 +282,17 @@ __global__ __launch_bounds__(256) void fft_fwd_rows_kernel(const double *__restr
 
 // forward, along y: L columns of Y1[p] (rows >= ns are zero) -> R[p][kx][ky]
 template <int L>
-__global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restrict__ Y1, int ns, FftPlan pl,
+__global__ __launch_bounds__(FFT_NT) void fft_fwd_cols_kernel(const cplx *__restrict__ Y1, int ns, FftPlan pl,
                                                            const cplx *__restrict__ tw, cplx *__restrict__ R)
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y, kx0 = blockIdx.x * L;
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
-    for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
+    for (int e = threadIdx.x; e < n; e += FFT_NT) twl[e] = tw[e];
 #pragma unroll
     for (int c = 0; c < L; c++)
 #pragma unroll 3
-        for (int y = threadIdx.x; y < n; y += 256) {
+        for (int y = threadIdx.x; y < n; y += FFT_NT) {
         const int e = c * n + y;
         cplx v = make_double2(0.0, 0.0);
         if (y < ns && kx0 + c < nh) v = Y1[((long)p * nh + kx0 + c) * ns + y];
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restric
 #pragma unroll
     for (int c = 0; c < L; c++)
 #pragma unroll 3
-        for (int ky = threadIdx.x; ky < n; ky += 256) {  // spectra are stored [kx][ky]: whole lines
+        for (int ky = threadIdx.x; ky < n; ky += FFT_NT) {  // spectra are stored [kx][ky]: whole lines
         const int e = c * n + ky;
         if (kx0 + c < nh) R[((long)p * nh + kx0 + c) * n + ky] = fbuf[e];
     }
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void fft_fwd_cols_kernel(const cplx *__restric
 // inverse, along y: L columns of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][kx][y'] for the
 // kept rows y' < ns (source row (y' - nc) mod n: the roll of psfutil.py:1225-1232)
 template <int L>
-__global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
+__global__ __launch_bounds__(FFT_NT) void fft_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
                                                            const int *__restrict__ pairs, int ns,
                                                            FftPlan pl, const cplx *__restrict__ tw, double amp0, double amps,
                                                            cplx *__restrict__ V)
@@ -317,12 +320,12 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, kx0 = blockIdx.x * L, nc = ns / 2;
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
-    for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
+    for (int e = threadIdx.x; e < n; e += FFT_NT) twl[e] = tw[e];
     const cplx *R1 = Ra + (long)pairs[2 * t] * n * nh, *R2 = Rb + (long)pairs[2 * t + 1] * n * nh;
 #pragma unroll
     for (int c = 0; c < L; c++)
 #pragma unroll 3
-        for (int ky = threadIdx.x; ky < n; ky += 256) {
+        for (int ky = threadIdx.x; ky < n; ky += FFT_NT) {
         const int e = c * n + ky, kx = kx0 + c;
         cplx z = make_double2(0.0, 0.0);
         if (kx < nh) {
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
 #pragma unroll
     for (int c = 0; c < L; c++)
 #pragma unroll 3
-        for (int yp = threadIdx.x; yp < ns; yp += 256) {  // V is stored [kx][y']
+        for (int yp = threadIdx.x; yp < ns; yp += FFT_NT) {  // V is stored [kx][y']
         if (kx0 + c < nh) V[((long)t * nh + kx0 + c) * ns + yp] = fbuf[c * n + yp - nc + (yp < nc ? n : 0)];
     }
 }
@@ -353,15 +356,15 @@ __global__ __launch_bounds__(256) void fft_inv_cols_kernel(const cplx *__restric
 // imaginary part of the result are the two rows.  numpy's c2r ignores the imaginary parts of the DC and Nyquist
 // bins; so does this.  Stored rolled by nc, cropped to ns, scaled by 1/n^2, inside the 6-sample zero border.
 template <int L>
-__global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restrict__ V, int ns, FftPlan pl,
+__global__ __launch_bounds__(FFT_NT) void fft_inv_rows_kernel(const cplx *__restrict__ V, int ns, FftPlan pl,
                                                            const cplx *__restrict__ tw, double *__restrict__ tables)
 {
     extern __shared__ cplx fbuf[];
     const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, nc = ns / 2, ng = ns + 12;
     cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
-    for (int e = threadIdx.x; e < n; e += 256) twl[e] = tw[e];
+    for (int e = threadIdx.x; e < n; e += FFT_NT) twl[e] = tw[e];
 #pragma unroll 6
-    for (int e = threadIdx.x; e < L * n; e += 256) {  // the 2 L rows of this block are contiguous in V[kx][y']
+    for (int e = threadIdx.x; e < L * n; e += FFT_NT) {  // the 2 L rows of this block are contiguous in V[kx][y']
         const int k = e / L, line = e - k * L, r0 = 2 * (blockIdx.x * L + line);
         const int kk = k < nh ? k : n - k;
         const bool edge = kk == 0 || 2 * kk == n;
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256) void fft_inv_rows_kernel(const cplx *__restric
 #pragma unroll
     for (int line = 0; line < L; line++)
 #pragma unroll 3
-        for (int xp = threadIdx.x; xp < ns; xp += 256) {
+        for (int xp = threadIdx.x; xp < ns; xp += FFT_NT) {
         const int r0 = 2 * (blockIdx.x * L + line);
         if (r0 >= ns) continue;
         const cplx z = fbuf[line * n + xp - nc + (xp < nc ? n : 0)];
@@ -452,11 +455,11 @@ static int fft_forward(imcom_ctx *ctx, const FftPlan &pl, const double *psf, int
     const int FL = pl.lines, row_blocks = ((nsamp + 1) / 2 + FL - 1) / FL, col_blocks = (nh + FL - 1) / FL;
     hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
     if (FL == 8) {
-        hipLaunchKernelGGL(fft_fwd_rows_kernel<8>, dim3(row_blocks, n), dim3(256), lds, st, psf, nsamp, pl, tw, Y1);
-        hipLaunchKernelGGL(fft_fwd_cols_kernel<8>, dim3(col_blocks, n), dim3(256), lds, st, Y1, nsamp, pl, tw, R);
+        hipLaunchKernelGGL(fft_fwd_rows_kernel<8>, dim3(row_blocks, n), dim3(FFT_NT), lds, st, psf, nsamp, pl, tw, Y1);
+        hipLaunchKernelGGL(fft_fwd_cols_kernel<8>, dim3(col_blocks, n), dim3(FFT_NT), lds, st, Y1, nsamp, pl, tw, R);
     } else {
-        hipLaunchKernelGGL(fft_fwd_rows_kernel<4>, dim3(row_blocks, n), dim3(256), lds, st, psf, nsamp, pl, tw, Y1);
-        hipLaunchKernelGGL(fft_fwd_cols_kernel<4>, dim3(col_blocks, n), dim3(256), lds, st, Y1, nsamp, pl, tw, R);
+        hipLaunchKernelGGL(fft_fwd_rows_kernel<4>, dim3(row_blocks, n), dim3(FFT_NT), lds, st, psf, nsamp, pl, tw, Y1);
+        hipLaunchKernelGGL(fft_fwd_cols_kernel<4>, dim3(col_blocks, n), dim3(FFT_NT), lds, st, Y1, nsamp, pl, tw, R);
     }
     return check_launch("psf spectra (butterfly path)");
 }
@@ -479,11 +482,11 @@ static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const 
     hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
     IMCOM_HIP_CHECK(hipMemsetAsync(tables, 0, (size_t)npairs * ng * ng * 8, st));
     if (FL == 8) {
-        hipLaunchKernelGGL(fft_inv_cols_kernel<8>, dim3(col_blocks, npairs), dim3(256), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
-        hipLaunchKernelGGL(fft_inv_rows_kernel<8>, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
+        hipLaunchKernelGGL(fft_inv_cols_kernel<8>, dim3(col_blocks, npairs), dim3(FFT_NT), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
+        hipLaunchKernelGGL(fft_inv_rows_kernel<8>, dim3(row_blocks, npairs), dim3(FFT_NT), lds, st, V, nsamp, pl, tw, tables);
     } else {
-        hipLaunchKernelGGL(fft_inv_cols_kernel<4>, dim3(col_blocks, npairs), dim3(256), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
-        hipLaunchKernelGGL(fft_inv_rows_kernel<4>, dim3(row_blocks, npairs), dim3(256), lds, st, V, nsamp, pl, tw, tables);
+        hipLaunchKernelGGL(fft_inv_cols_kernel<4>, dim3(col_blocks, npairs), dim3(FFT_NT), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
+        hipLaunchKernelGGL(fft_inv_rows_kernel<4>, dim3(row_blocks, npairs), dim3(FFT_NT), lds, st, V, nsamp, pl, tw, tables);
     }
     return check_launch("psf_overlap (butterfly path)");
 }
