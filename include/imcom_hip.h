@@ -286,6 +286,16 @@ int imcom_psf_gaussian(imcom_ctx *ctx, int n, double sigmax, double sigmay, doub
 int imcom_psf_simple_airy(imcom_ctx *ctx, int n, double ldp, double obsc, double tophat_conv, double sigma,
                           double *out, int memspace);
 
+/* InImage.smooth_and_pad (reference src/pyimcom/coadd.py:433-474), the smearing of a raw PSF image that
+ * InImage.get_psf_pos applies before the image reaches PSFGrp (coadd.py:603-640): zero-pad by
+ * npad = imcom_smooth_pad_width() = ceil(tophatwidth + 6 gaussiansigma + 1) rounded up to a multiple of 4 on every
+ * side, then convolve (circularly on the padded grid, as the reference's FFT product does) with a top-hat of width
+ * tophatwidth and a Gaussian of sigma gaussiansigma, both in pixels of the array.
+ *   in  [n][ny][nx]                       out [n][ny + 2 npad][nx + 2 npad]      (host or device, memspace) */
+int imcom_smooth_pad_width(double tophatwidth, double gaussiansigma);
+int imcom_smooth_and_pad(imcom_ctx *ctx, int n, const double *in, int ny, int nx, double tophatwidth, double gaussiansigma,
+                         double *out, int memspace);
+
 /* PSFGrp.accel_pad_and_rfft2 + PSFOvl._build_psfovl (psfutil.py:943-986, 1244-1294): correlation
  * tables out[p][q] = irfft2(rft(psf1[p]) * conj(rft(psf2[q]))), rolled by nc and cropped to
  * nsamp x nsamp.  psf1[n1][nsamp][nsamp], psf2[n2][nsamp][nsamp]; pairs[npairs][2] HOST lists the

@@ -783,3 +783,22 @@ def stamp_system(g, x, y, psf, tables_pad, pair_tab, pair_pen, io_tab, out_x0, o
         gridD5512C(np.ascontiguousarray(from_pad[io_tab[p]]), np.ascontiguousarray(ddx + 6), np.ascontiguousarray(ddy + 6), out)
         Bt[sel] = out
     return A, Bt
+
+
+def smooth_and_pad(image, tophatwidth=0.0, gaussiansigma=0.0):
+    """InImage.smooth_and_pad (coadd.py:433-474): pad by npad = ceil(w + 6 s + 1) rounded up to a multiple of 4, multiply
+    the 2-D DFT by sinc(ux w) sinc(uy w) exp(-2 pi^2 s^2 |u|^2) with u in cycles per pixel wrapped to (-1/2, 1/2], keep
+    the real part of the inverse.  Pinned by tests/golden/smooth_pad.npz (the reference function itself, executed)."""
+    npad = int(np.ceil(tophatwidth + 6 * gaussiansigma + 1))
+    npad += (4 - npad) % 4
+    ny, nx = image.shape
+    big = np.zeros((ny + 2 * npad, nx + 2 * npad))
+    big[npad : npad + ny, npad : npad + nx] = image
+
+    def freq(n):
+        u = np.arange(n) / n
+        return np.where(u > 0.5, u - 1, u)
+
+    uy, ux = freq(big.shape[0])[:, None], freq(big.shape[1])[None, :]
+    h = np.sinc(ux * tophatwidth) * np.sinc(uy * tophatwidth) * np.exp(-2.0 * np.pi**2 * gaussiansigma**2 * (ux**2 + uy**2))
+    return np.real(np.fft.ifft2(np.fft.fft2(big) * h))

@@ -82,6 +82,7 @@ SIGNATURES = {
     "imcom_sample_psf": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i],
     "imcom_psf_gaussian": [_vp, _i, _d, _d, _vp, _i],
     "imcom_psf_simple_airy": [_vp, _i, _d, _d, _d, _d, _vp, _i],
+    "imcom_smooth_and_pad": [_vp, _i, _vp, _i, _i, _d, _d, _vp, _i],
     "imcom_psf_overlap": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
     "imcom_psf_spectra": [_vp, _vp, _i, _i, _i, _vp],
     "imcom_psf_overlap_spectra": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
@@ -97,10 +98,12 @@ lib.imcom_version.argtypes = []
 lib.imcom_version.restype = C.c_int
 lib.imcom_psf_spectra_size.argtypes = [_i, _i]
 lib.imcom_psf_spectra_size.restype = C.c_long
+lib.imcom_smooth_pad_width.argtypes = [_d, _d]
+lib.imcom_smooth_pad_width.restype = C.c_int
 lib.imcom_last_error.argtypes = []
 lib.imcom_last_error.restype = C.c_char_p
 
-EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_last_error", "imcom_psf_spectra_size"])
+EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_last_error", "imcom_psf_spectra_size", "imcom_smooth_pad_width"])
 
 
 def check(status):

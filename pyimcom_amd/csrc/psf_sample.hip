@@ -137,6 +137,22 @@ __global__ void crop_kernel(const double *__restrict__ Z, int P, int kp, int n, 
     out[(long)r * n + c] = Z[(long)(r + kp) * P + (c + kp)];
 }
 
+// smooth_and_pad operand: I[p][r][c] = in[p][r - npad][c - npad] inside, zero elsewhere (incl. the GEMM padding)
+__global__ void pad_rect_kernel(const double *__restrict__ in, int ny, int nx, int npad, int Py, int Px, double *__restrict__ I)
+{
+    const int p = blockIdx.z, r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Px) return;
+    const int rr = r - npad, cc = c - npad;
+    I[((long)p * Py + r) * Px + c] = (rr >= 0 && rr < ny && cc >= 0 && cc < nx) ? in[((long)p * ny + rr) * nx + cc] : 0.0;
+}
+
+__global__ void crop_rect_kernel(const double *__restrict__ Z, int Py, int Px, int nyy, int nxx, double *__restrict__ out)
+{
+    const int p = blockIdx.z, r = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nxx) return;
+    out[((long)p * nyy + r) * nxx + c] = Z[((long)p * Py + r) * Px + c];
+}
+
 }  // namespace imcom
 
 using namespace imcom;
@@ -253,6 +269,58 @@ extern "C" int imcom_psf_simple_airy(imcom_ctx *ctx, int n, double ldp, double o
     if (host) {
         IMCOM_HIP_CHECK(hipMemcpyAsync(out, o, sz, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return IMCOM_OK;
+}
+
+extern "C" int imcom_smooth_pad_width(double tophatwidth, double gaussiansigma)
+{
+    int npad = (int)ceil(tophatwidth + 6.0 * gaussiansigma + 1.0);  // coadd.py:453-454
+    npad += ((4 - npad % 4) % 4);
+    return npad;
+}
+
+// InImage.smooth_and_pad (coadd.py:433-474).  The reference multiplies the 2-D DFT of the padded image by the real, even,
+// separable filter sinc(ux w) sinc(uy w) exp(-2 pi^2 s^2 (ux^2 + uy^2)) and keeps the real part of the inverse: a
+// circular convolution along each axis with k[d] = (1/N) sum_u h(u) cos(2 pi u d / N), i.e. out = Cy I Cx^T with
+// symmetric circulants -- two products on the fp64 MFMA GEMM for any image size, exact twiddles.
+extern "C" int imcom_smooth_and_pad(imcom_ctx *ctx, int n, const double *in, int ny, int nx, double tophatwidth, double gaussiansigma,
+                                    double *out, int memspace)
+{
+    IMCOM_TRY(ctx_ok3(ctx));
+    IMCOM_REQUIRE(n >= 1 && in && out && ny >= 1 && nx >= 1 && tophatwidth >= 0.0 && gaussiansigma >= 0.0, "bad arguments");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const int npad = imcom_smooth_pad_width(tophatwidth, gaussiansigma), nyy = ny + 2 * npad, nxx = nx + 2 * npad;
+    const int Py = (int)align_up((size_t)nyy, NB), Px = (int)align_up((size_t)nxx, NB);
+    const size_t szI = (size_t)n * Py * Px * 8, szIn = (size_t)n * ny * nx * 8, szOut = (size_t)n * nyy * nxx * 8;
+    IMCOM_TRY(ws_reserve(ctx, 3 * szI + (size_t)Py * Py * 8 + (size_t)Px * Px * 8 + (size_t)(nyy + nxx) * 8 + (host ? szIn + szOut : 0) + 16384));
+    double *I = (double *)ws_take(ctx, szI), *Y = (double *)ws_take(ctx, szI), *Z = (double *)ws_take(ctx, szI);
+    double *Cy = (double *)ws_take(ctx, (size_t)Py * Py * 8), *Cx = (double *)ws_take(ctx, (size_t)Px * Px * 8);
+    double *ky = (double *)ws_take(ctx, (size_t)nyy * 8), *kx = (double *)ws_take(ctx, (size_t)nxx * 8);
+    const double *src = in;
+    double *dst = out;
+    if (host) {
+        double *in_d = (double *)ws_take(ctx, szIn);
+        dst = (double *)ws_take(ctx, szOut);
+        if (!in_d || !dst) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+        IMCOM_HIP_CHECK(hipMemcpyAsync(in_d, in, szIn, hipMemcpyHostToDevice, ctx->stream));
+        src = in_d;
+    }
+    if (!I || !Y || !Z || !Cy || !Cx || !ky || !kx) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(pad_rect_kernel, dim3((Px + 255) / 256, Py, n), dim3(256), 0, st, src, ny, nx, npad, Py, Px, I);
+    hipLaunchKernelGGL(airy_filter_kernel, dim3(nyy), dim3(256), 0, st, nyy, gaussiansigma, tophatwidth, ky);
+    hipLaunchKernelGGL(airy_filter_kernel, dim3(nxx), dim3(256), 0, st, nxx, gaussiansigma, tophatwidth, kx);
+    hipLaunchKernelGGL(circulant_kernel, dim3((Py + 255) / 256, Py), dim3(256), 0, st, ky, nyy, Py, Cy);
+    hipLaunchKernelGGL(circulant_kernel, dim3((Px + 255) / 256, Px), dim3(256), 0, st, kx, nxx, Px, Cx);
+    IMCOM_TRY(check_launch("smooth_and_pad setup"));
+    IMCOM_TRY(launch_gemm(ctx, false, false, Py, Px, Px, n, I, Px, (long)Py * Px, Cx, Px, 0, Y, Px, (long)Py * Px, 1.0, 0.0));  // Y = I Cx^T
+    IMCOM_TRY(launch_gemm(ctx, false, true, Py, Px, Py, n, Cy, Py, 0, Y, Px, (long)Py * Px, Z, Px, (long)Py * Px, 1.0, 0.0));   // Z = Cy Y
+    hipLaunchKernelGGL(crop_rect_kernel, dim3((nxx + 255) / 256, nyy, n), dim3(256), 0, st, Z, Py, Px, nyy, nxx, dst);
+    IMCOM_TRY(check_launch("crop_rect_kernel"));
+    if (host) {
+        IMCOM_HIP_CHECK(hipMemcpyAsync(out, dst, szOut, hipMemcpyDeviceToHost, st));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(st));
     }
     return IMCOM_OK;
 }

@@ -48,6 +48,29 @@ def psf_simple_airy(n, ldp, obsc=0.0, tophat_conv=0.0, sigma=0.0, device=None, c
     return out
 
 
+def smooth_and_pad(inArray, tophatwidth=0.0, gaussiansigma=0.0, ctx=None):
+    """``InImage.smooth_and_pad`` (coadd.py:433-474): smear a PSF image [ny, nx] (or a stack [n, ny, nx]) with a top-hat
+    and a Gaussian, padded by ``npad`` on every side.  numpy in -> numpy out; torch (device) in -> torch out."""
+    ctx = ctx or default_context()
+    single = inArray.ndim == 2
+    a = inArray[None] if single else inArray
+    n, ny, nx = a.shape
+    npad = int(lib.imcom_smooth_pad_width(float(tophatwidth), float(gaussiansigma)))
+    if _is_torch(a):
+        import torch
+
+        a = a.to(torch.float64).contiguous()
+        out = torch.empty((n, ny + 2 * npad, nx + 2 * npad), dtype=torch.float64, device=a.device)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        mem = MEM_DEVICE
+    else:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = np.empty((n, ny + 2 * npad, nx + 2 * npad))
+        mem = MEM_HOST
+    check(lib.imcom_smooth_and_pad(ctx.handle, n, _p(a), ny, nx, float(tophatwidth), float(gaussiansigma), _p(out), mem))
+    return out[0] if single else out
+
+
 def get_outpsf(outpsf, extrasmooth, use_filter, nsamp, oversamp, device=None, ctx=None):
     """``PSFGrp._get_outpsf`` (psfutil.py:854-896): the (nsamp+1)^2 target PSF image."""
     if outpsf == "GAUSSIAN":

@@ -144,3 +144,27 @@ def test_psf_overlap_mixed_radix_vs_oracle(npixpsf, oversamp):
                                     amp.ctypes.data_as(C.c_void_p) if use_amp else None, dp(out)))
         got = out.cpu().numpy()[:, 6:-6, 6:-6].reshape(3, 2, ns, ns)
         assert np.abs(got - ref).max() < 2e-13 * np.abs(ref).max(), (nfft, use_amp, np.abs(got - ref).max() / np.abs(ref).max())
+
+
+def test_smooth_and_pad_golden(golden):
+    """imcom_smooth_and_pad (circulant products on the GEMM engine) vs the reference function's own outputs; host and
+    device buffers, single image and stack."""
+    import torch
+
+    from pyimcom_amd import psfs
+
+    g = golden("smooth_pad")
+    for name in "abcde":
+        w, sg = (float(v) for v in g[f"{name}_pars"])
+        ref = g[f"{name}_out"]
+        got = psfs.smooth_and_pad(g[f"{name}_in"], w, sg)
+        assert isinstance(got, np.ndarray) and got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-14 * np.abs(ref).max(), (name, np.abs(got - ref).max())
+    # a stack on the device: three copies of one image come out identical to the single call
+    img = torch.as_tensor(g["b_in"], device="cuda:0")
+    w, sg = (float(v) for v in g["b_pars"])
+    st = psfs.smooth_and_pad(torch.stack([img, 2.0 * img, img]), w, sg)
+    assert st.shape == (3,) + g["b_out"].shape
+    one = psfs.smooth_and_pad(img, w, sg)
+    assert torch.equal(st[0], one) and torch.equal(st[2], one) and torch.allclose(st[1], 2.0 * one, rtol=1e-15, atol=0)
+    assert np.abs(one.cpu().numpy() - g["b_out"]).max() <= 2e-14 * np.abs(g["b_out"]).max()

@@ -213,3 +213,15 @@ def test_psf_sampling_golden(golden):
         arr = orc.sample_psf(orc.get_outpsf(kind, sig, int(uf), ns, ov), ns)[None].copy()
         orc.finish_psf_group(arr, bool(circ), bool(norm))
         assert np.array_equal(arr[0], g[f"out_{name}"]), name
+
+
+def test_smooth_and_pad_golden(golden):
+    """InImage.smooth_and_pad (coadd.py:433-474): the restatement against the reference function executed on five
+    images (square / rectangular / odd sizes; top-hat only, Gaussian only, both, neither)."""
+    g = golden("smooth_pad")
+    for name in "abcde":
+        w, sg = g[f"{name}_pars"]
+        got = orc.smooth_and_pad(g[f"{name}_in"], float(w), float(sg))
+        ref = g[f"{name}_out"]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 4e-16 * np.abs(ref).max(), name
