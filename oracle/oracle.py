@@ -606,18 +606,27 @@ def compress_map(map_, coef, dtype):
     return np.clip(np.floor(coef * np.log10(np.clip(map_, 1e-32, None)) + 0.5), a_min, a_max).astype(dtype)
 
 
-def perform_coaddition(T, indata, expo, n_expo, n2f, n2, fade_kernel):
+def perform_coaddition(T, indata, expo, n_expo, n2f, n2, fade_kernel, inpix_cumsum=None):
     """OutStamp._perform_coaddition (coadd.py:1294-1354) for one stamp.
 
-    T f32 [n_out, m, N] (tapered in place), indata f32 [n_inframe, N], expo[N] = exposure of each pixel
-    (the my_cumsum bookkeeping of 1329-1337 sums T over the pixels of each exposure)."""
+    T f32 [n_out, m, N] (tapered in place), indata f32 [n_inframe, N], expo[N] = exposure of each pixel.  The
+    reference walks the nine InStamps and adds, per InStamp and exposure, the float32 sum of that segment of T into a
+    float64 accumulator (1329-1337): the segments are the runs of equal exposure inside each InStamp, delimited by
+    inpix_cumsum [10] (without it: the maximal runs of equal exposure, the same thing unless two neighbouring
+    InStamps meet on one exposure)."""
     n_out, m, N = T.shape
     if fade_kernel > 0:
         T_view = np.moveaxis(T, 1, -1).reshape((n_out, N, n2f, n2f))
         trapezoid(T_view, fade_kernel)
     Tsum_image = np.zeros((n_out, m, n_expo))
-    for e in range(n_expo):
-        Tsum_image[:, :, e] += np.sum(T[:, :, expo == e], axis=2)
+    expo = np.asarray(expo)
+    cuts = np.flatnonzero(np.diff(expo)) + 1
+    if inpix_cumsum is not None:
+        cuts = np.union1d(cuts, np.asarray(inpix_cumsum, dtype=np.int64)[1:-1])
+    bounds = np.concatenate([[0], cuts[(cuts > 0) & (cuts < N)], [N]]).astype(np.int64)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b > a:
+            Tsum_image[:, :, int(expo[a])] += np.sum(T[:, :, a:b], axis=2)
     Tsum_stamp = np.sum(Tsum_image, axis=1) / n2**2
     Tsum_inpix = np.sum(Tsum_image, axis=2).reshape((n_out, n2f, n2f))
     Tsum_norm = Tsum_image / np.abs(Tsum_image).sum(axis=2)[:, :, None]

@@ -86,3 +86,30 @@ def test_compress_map_vs_oracle():
         assert got.dtype == ref.dtype and got.shape == ref.shape
         d = np.abs(got.astype(np.int64) - ref.astype(np.int64))
         assert d.max() <= 1 and (d > 0).mean() <= 1e-2, (name, d.max(), (d > 0).mean())
+
+
+def test_recover_and_compress_vs_reference_golden(golden):
+    """imcom_trapezoid_recover_f32 and imcom_compress_map_f32 on the inputs of tests/golden/coadd_stamp.npz against the
+    outputs of the reference's own OutStamp.trapezoid(recover_mode=True, pad_widths) and Block.compress_map code."""
+    import ctypes as C
+
+    import torch
+
+    from pyimcom_amd._lib import check, default_context, lib
+
+    g = golden("coadd_stamp")
+    ctx = default_context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    a = torch.as_tensor(g["recover_in"].copy(), device="cuda:0")
+    pb, pt, pl, pr = (int(v) for v in g["recover_pads"])
+    check(lib.imcom_trapezoid_recover_f32(ctx.handle, dp(a), a.shape[0], a.shape[1], a.shape[2], 2, pb, pt, pl, pr))
+    # the reference divides float32 by float64 factors in place (one rounding per side); so does the kernel
+    assert np.array_equal(a.cpu().numpy(), g["recover_out"])
+    m = torch.as_tensor(g["cmp_in"].copy(), device="cuda:0")
+    for coef, uns, tag in ((-5000, 1, "u5000"), (-10000, 0, "i10000"), (200000, 0, "i200000"), (50000, 1, "u50000")):
+        out = torch.empty(m.shape, dtype=torch.uint16 if uns else torch.int16, device=m.device)
+        check(lib.imcom_compress_map_f32(ctx.handle, dp(m), m.numel(), coef, uns, dp(out)))
+        ref = g[f"cmp_{tag}"]
+        d = np.abs(out.cpu().numpy().astype(np.int64) - ref.astype(np.int64))
+        assert d.max() <= 1 and (d > 0).sum() <= 1, (tag, d.max(), int((d > 0).sum()))  # numpy's float32 log10: see the test above

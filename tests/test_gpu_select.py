@@ -111,3 +111,61 @@ def test_partition_pixels_bit_exact():
         assert np.array_equal(g.cpu().numpy(), r)
     with pytest.raises(Exception, match="more than npixmax"):
         partition_pixels(ox, oy, in_x, in_y, mask, use, n2, n1P, 5)
+
+
+def test_selection_and_coaddition_vs_reference_golden(golden):
+    """Device selection (imcom_select_pixels) and coaddition epilogue (imcom_coadd_epilogue) on the inputs of
+    tests/golden/coadd_stamp.npz, against what the reference's own _process_input_stamps / _perform_coaddition code
+    returned for them.  Selection and the taper of T: bit for bit.  Sums: the reference adds every (InStamp, exposure)
+    segment of T in float32 before accumulating in float64 (coadd.py:1329-1337), the device accumulates in float64
+    throughout -- a few float32 ulps apart."""
+    import ctypes as C
+
+    import torch
+
+    from pyimcom_amd._lib import check, default_context, lib
+    from pyimcom_amd.select import InStampPool, select_pixels
+
+    g = golden("coadd_stamp")
+    order = [tuple(int(v) for v in ji) for ji in g["sel_order"]]
+    flat = [(g[f"in{j}{i}_x"], g[f"in{j}{i}_y"], g[f"in{j}{i}_data"], g[f"in{j}{i}_cum"].astype(np.int64)) for j, i in order]
+    n2, fade, n_expo, n_inframe = (int(v) for v in g["co_pars"])
+    pool = InStampPool(flat, n_inframe)
+    bottom, top, left, right = (int(v) for v in g["sel_box"])
+    pvx, pvy = np.full((1, 9), np.nan), np.full((1, 9), np.nan)
+    for k, (j, i) in enumerate(order):
+        xp, yp = [left - 0.5, None, right + 0.5][i - 2 + 1], [bottom - 0.5, None, top + 0.5][j - 2 + 1]
+        if xp is not None:
+            pvx[0, k] = xp
+        if yp is not None:
+            pvy[0, k] = yp
+    N = int(g["sel_cumsum"][-1])
+    ldn = 256
+    x, y, indata, expo, cumsum = select_pixels(pool, np.arange(9, dtype=np.int32)[None], pvx, pvy, float(g["sel_rpix"]), ldn)
+    assert np.array_equal(cumsum[0], g["sel_cumsum"].astype(cumsum.dtype))
+    assert np.array_equal(x[0, :N].cpu().numpy(), g["sel_x"]) and np.array_equal(y[0, :N].cpu().numpy(), g["sel_y"])
+    assert np.array_equal(indata[0, :, :N].cpu().numpy(), g["sel_data"])
+
+    n2f = n2 + 2 * fade
+    m, ldm = n2f * n2f, 128
+    ctx = default_context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = x.device
+    dp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    for o in range(g["co_T_in"].shape[0]):
+        Tt = torch.zeros((1, ldn, ldm), dtype=torch.float32, device=dev)
+        Tt[0, :N, :m] = torch.as_tensor(g["co_T_in"][o].T.copy(), device=dev)
+        outimage = torch.empty((1, n_inframe, m), dtype=torch.float32, device=dev)
+        Ts = torch.empty((1, n_expo), dtype=torch.float64, device=dev)
+        Tin = torch.empty((1, m), dtype=torch.float64, device=dev)
+        Neff = torch.empty((1, m), dtype=torch.float64, device=dev)
+        nn = np.array([N], np.int32)
+        check(lib.imcom_coadd_epilogue(ctx.handle, 1, nn.ctypes.data_as(C.c_void_p), ldn, m, ldm, n2f, fade, n2, dp(Tt), dp(indata), n_inframe,
+                                       dp(expo), n_expo, dp(outimage), dp(Ts), dp(Tin), dp(Neff)))
+        torch.cuda.synchronize()
+        assert np.array_equal(Tt[0, :N, :m].cpu().numpy().T, g["co_T_out"][o])  # tapered T, float32
+        ref_img = g["co_outimage"][o].reshape(n_inframe, m)
+        assert np.abs(outimage[0].cpu().numpy() - ref_img).max() <= 1e-6 * np.abs(ref_img).max()
+        assert np.allclose(Ts[0].cpu().numpy(), g["co_Tsum_stamp"][o], rtol=1e-6, atol=0)
+        assert np.allclose(Tin[0].cpu().numpy(), g["co_Tsum_inpix"][o].ravel(), rtol=0, atol=2e-7 * np.abs(g["co_Tsum_inpix"][o]).max())
+        assert np.allclose(Neff[0].cpu().numpy(), g["co_Neff"][o].ravel(), rtol=2e-6, atol=0)

@@ -225,3 +225,46 @@ def test_smooth_and_pad_golden(golden):
         ref = g[f"{name}_out"]
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() <= 4e-16 * np.abs(ref).max(), name
+
+
+def test_coadd_stamp_functions_golden(golden):
+    """The stamp-driver functions of coadd.py -- make_selection / _process_input_stamps (716-749, 886-977), trapezoid
+    in both modes (1222-1292), _perform_coaddition (1294-1363), compress_map (2087-2138) -- against outputs of the
+    reference's own code (tests/golden/make_golden_coadd.py executes the function definitions taken from coadd.py's
+    syntax tree).  Bit for bit, except the einsum / sum reductions of the coaddition (numpy's own reduction order is
+    what it is: a few float32 / float64 ulps)."""
+    g = golden("coadd_stamp")
+    a = g["trap_in"].copy()
+    orc.trapezoid(a, 2)
+    assert np.array_equal(a, g["trap_out"])
+    b = g["recover_in"].copy()
+    orc.trapezoid_recover(b, 2, tuple(int(v) for v in g["recover_pads"]))
+    assert b.dtype == np.float32 and np.array_equal(b, g["recover_out"])
+
+    bottom, top, left, right = (int(v) for v in g["sel_box"])
+    rpix = float(g["sel_rpix"])
+    nine, pivots = [], []
+    for k, (j, i) in enumerate(g["sel_order"]):
+        nine.append((g[f"in{j}{i}_x"], g[f"in{j}{i}_y"], g[f"in{j}{i}_data"], g[f"in{j}{i}_cum"]))
+        pivots.append(([left - 0.5, None, right + 0.5][i - 2 + 1], [bottom - 0.5, None, top + 0.5][j - 2 + 1]))  # coadd.py:927-928
+        sel = orc.select_pixels(nine[-1][0], nine[-1][1], pivots[-1], rpix)
+        ref = g[f"sel_idx{k}"]
+        assert (sel is None and ref[0] == -1 and ref.size == 1) or np.array_equal(sel, ref.astype(np.int64)), k
+    x, y, indata, expo, cum = orc.process_input_stamps(nine, pivots, rpix)
+    assert np.array_equal(cum, g["sel_cumsum"]) and np.array_equal(x, g["sel_x"]) and np.array_equal(y, g["sel_y"])
+    assert np.array_equal(indata, g["sel_data"])
+
+    n2, fade, n_expo, n_inframe = (int(v) for v in g["co_pars"])
+    T = g["co_T_in"].copy()
+    outimage, Tsum_stamp, Tsum_inpix, Neff = orc.perform_coaddition(T, indata, expo, n_expo, n2 + 2 * fade, n2, fade, cum)
+    assert np.array_equal(T, g["co_T_out"])  # the taper of T, float32 in place
+    assert np.allclose(Tsum_stamp, g["co_Tsum_stamp"], rtol=1e-13, atol=0)
+    assert np.allclose(Tsum_inpix, g["co_Tsum_inpix"], rtol=1e-12, atol=1e-15)
+    assert np.allclose(Neff, g["co_Neff"], rtol=1e-11, atol=0)
+    assert outimage.dtype == g["co_outimage"].dtype
+    assert np.abs(outimage - g["co_outimage"]).max() <= 4e-7 * np.abs(g["co_outimage"]).max()
+
+    with np.errstate(all="ignore"):
+        for coef, dt, tag in ((-5000, np.uint16, "u5000"), (-10000, np.int16, "i10000"), (200000, np.int16, "i200000"), (50000, np.uint16, "u50000")):
+            got = orc.compress_map(g["cmp_in"], coef, dt)
+            assert got.dtype == g[f"cmp_{tag}"].dtype and np.array_equal(got, g[f"cmp_{tag}"]), tag
