@@ -169,3 +169,15 @@ def test_selection_and_coaddition_vs_reference_golden(golden):
         assert np.allclose(Ts[0].cpu().numpy(), g["co_Tsum_stamp"][o], rtol=1e-6, atol=0)
         assert np.allclose(Tin[0].cpu().numpy(), g["co_Tsum_inpix"][o].ravel(), rtol=0, atol=2e-7 * np.abs(g["co_Tsum_inpix"][o]).max())
         assert np.allclose(Neff[0].cpu().numpy(), g["co_Neff"][o].ravel(), rtol=2e-6, atol=0)
+
+
+def test_partition_vs_reference_golden(golden):
+    """imcom_partition_pixels against the arrays the reference's own binning statement filled (partition.npz)."""
+    from pyimcom_amd.select import partition_pixels
+    from tests.test_host_logic import _partition_inputs
+
+    g = golden("partition")
+    in_y, in_x, ox, oy, mask = _partition_inputs(g)
+    got = partition_pixels(ox, oy, in_x, in_y, mask, g["use_instamps"], int(g["n2"]), int(g["n1P"]), int(g["npixmax"]))
+    for a, name in zip(got, ("y_idx", "x_idx", "y_val", "x_val", "pix_count")):
+        assert np.array_equal(a.cpu().numpy(), g[name]), name

@@ -53,3 +53,25 @@ def test_oracle_selection_and_block_helpers():
     orc.trapezoid_recover(b, 2)
     assert np.allclose(b, 1.0) and a[0, 0, 0] < 0.05
     assert orc.compress_map(np.array([1.0, 1e-40, 10.0], np.float32), -5000, np.uint16).tolist() == [0, 65535, 0]
+
+
+def _partition_inputs(g):
+    """Inputs of the partition in the reference's visiting order, from tests/golden/partition.npz."""
+    from pyimcom_amd.select import visiting_order
+
+    in_y, in_x = visiting_order(g["relevant"], g["sp_arr"])
+    out = np.stack([in_x, in_y], axis=1).astype(np.float64) @ g["M"].T + g["t0"]  # as the generator's affine map, row by row
+    mask = g["mask"][in_y, in_x]
+    return in_y, in_x, out[:, 0], out[:, 1], mask
+
+
+def test_partition_golden(golden):
+    """The oracle's partition loop and the host's visiting order against the reference's own binning statement
+    (coadd.py:329-358, executed by tests/golden/make_golden_partition.py): every array bit for bit."""
+    from oracle import oracle as orc
+
+    g = golden("partition")
+    in_y, in_x, ox, oy, mask = _partition_inputs(g)
+    got = orc.partition_pixels(ox, oy, in_x, in_y, mask, g["use_instamps"], int(g["n2"]), int(g["n1P"]), int(g["npixmax"]))
+    for a, name in zip(got, ("y_idx", "x_idx", "y_val", "x_val", "pix_count")):
+        assert a.dtype == g[name].dtype and np.array_equal(a, g[name]), name
