@@ -113,3 +113,38 @@ def test_recover_and_compress_vs_reference_golden(golden):
         ref = g[f"cmp_{tag}"]
         d = np.abs(out.cpu().numpy().astype(np.int64) - ref.astype(np.int64))
         assert d.max() <= 1 and (d > 0).sum() <= 1, (tag, d.max(), int((d > 0).sum()))  # numpy's float32 log10: see the test above
+
+
+def test_block_maps_vs_reference_golden(golden):
+    """BlockMaps.add / finalize against the maps the reference's own _output_stamp_wrapper and build_output_file code
+    produced for nine finished stamps with two target PSFs (block_maps.npz).  The adds of overlapping stamps may come in
+    another order than the reference's stamp loop: a few float32 ulps of the largest term."""
+    import torch
+
+    from pyimcom_amd.block import BlockMaps
+    from pyimcom_amd.stamps import StampBatchResult
+
+    g = golden("block_maps")
+    n1P, n2, fk, n_out, n_inframe, n_inimage = (int(v) for v in g["pars"])
+    bm = BlockMaps(n1P, n2, fk, n_inframe, n_inimage, n_out=n_out)
+    ids = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    dev = "cuda:0"
+    t = lambda key, o: torch.as_tensor(np.stack([g[f"st{j}{i}_{key}"][o] for j, i in ids]), device=dev)  # noqa: E731
+    res = [StampBatchResult(None, t("UC", o), t("Sigma", o), t("kappa", o), t("outimage", o), t("Tsum_stamp", o), t("Tsum_inpix", o),
+                            t("Neff", o), None, None) for o in range(n_out)]
+    bm.add(res, [j for j, _ in ids], [i for _, i in ids])
+    torch.cuda.synchronize()
+
+    def close(a, b):
+        return np.abs(a - b).max() <= 4e-7 * np.abs(b).max()
+
+    names = dict(UC="UC_map", Sigma="Sigma_map", kappa="kappa_map", Tsum="Tsum_map", Neff="Neff_map")
+    assert close(bm.out_map.cpu().numpy(), g["acc_out_map"])
+    assert np.array_equal(bm.T_weightmap.cpu().numpy(), g["acc_T_weightmap"])
+    for k, nm in names.items():
+        assert close(bm.maps[k].cpu().numpy(), g[f"acc_{nm}"]), k
+    bm.finalize(pad_sides=str(g["pad_sides"]), postage_pad=int(g["postage_pad"]))
+    torch.cuda.synchronize()
+    assert close(bm.out_map.cpu().numpy(), g["fin_out_map"])
+    for k, nm in names.items():
+        assert close(bm.maps[k].cpu().numpy(), g[f"fin_{nm}"]), k

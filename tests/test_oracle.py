@@ -268,3 +268,29 @@ def test_coadd_stamp_functions_golden(golden):
         for coef, dt, tag in ((-5000, np.uint16, "u5000"), (-10000, np.int16, "i10000"), (200000, np.int16, "i200000"), (50000, np.uint16, "u50000")):
             got = orc.compress_map(g["cmp_in"], coef, dt)
             assert got.dtype == g[f"cmp_{tag}"].dtype and np.array_equal(got, g[f"cmp_{tag}"]), tag
+
+
+def test_block_accumulation_golden(golden):
+    """Block._output_stamp_wrapper (coadd.py:1975-1993) and the boundary recovery of build_output_file (2163-2181)
+    against the reference's own code run on nine finished stamps (make_golden_block.py): bit for bit."""
+    g = golden("block_maps")
+    n1P, n2, fk, n_out, n_inframe, n_inimage = (int(v) for v in g["pars"])
+    ns = n1P * n2 + 2 * fk
+    maps = {k: np.zeros((n_out, ns, ns), np.float32) for k in ("UC", "Sigma", "kappa", "Tsum", "Neff")}
+    out_map = np.zeros((n_out, n_inframe, ns, ns), np.float32)
+    src = dict(UC="UC", Sigma="Sigma", kappa="kappa", Tsum="Tsum_inpix", Neff="Neff")
+    for j in range(1, n1P + 1):
+        for i in range(1, n1P + 1):
+            orc.block_accumulate(out_map, g[f"st{j}{i}_outimage"], j, i, n2, fk)
+            for k, key in src.items():
+                orc.block_accumulate(maps[k], g[f"st{j}{i}_{key}"], j, i, n2, fk)
+    assert np.array_equal(out_map, g["acc_out_map"])
+    for k in maps:
+        assert np.array_equal(maps[k], g[f"acc_{k}_map"]), k
+    orc.trapezoid_recover(out_map, fk)
+    w = int(g["postage_pad"]) * n2
+    pads = tuple(w * (s not in str(g["pad_sides"])) for s in "BTLR")
+    assert np.array_equal(out_map, g["fin_out_map"])
+    for k in maps:
+        orc.trapezoid_recover(maps[k], fk, pads)
+        assert np.array_equal(maps[k], g[f"fin_{k}_map"]), k
