@@ -159,3 +159,64 @@ def test_block_with_psf_groups_vs_oracle(n_out):
 
     uni = coadd_block(cfg, pool, PSFGroupTables(group_psfs[(0, 0)], target[:1], cfg.nfft), n1P, n_expo, batch=4)  # 3 PSFs for all
     assert np.abs(uni.out_map[0].cpu().numpy() - ref_out[0]).max() > 1e-3 * np.abs(ref_out[0]).max()
+
+
+def test_full_chain_vs_reference_golden(golden):
+    """The device chain from raw inputs -- PSF images sampled on the device, PSF groups per 2x2 InStamps (one lacking an
+    exposure), table sets, selection, A, B, Cholesky, taper, coaddition -- for the output stamp of
+    tests/golden/stamp_chain.npz, against what the reference's own code produced end to end (PSFGrp, PSFOvl, SysMatA /
+    SysMatB, OutStamp._build_system_matrices, CholKernel, _perform_coaddition)."""
+    import torch
+
+    from pyimcom_amd import psfs, synth
+    from pyimcom_amd.blockrun import prepare_batch
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import BlockTables
+    from tests.test_oracle import _chain_inputs
+
+    g = golden("stamp_chain")
+    geo, inst, _, group_expo, (n1P, n2, fade, n_inimage, n_inframe) = _chain_inputs(g)
+    ns, nst = geo.nsamp, n1P + 2
+    cfg = synth.WorkloadConfig("chain", n2, fade, float(g["dtheta_as"]), n_inimage, float(g["instamp_pad_as"]), "Cholesky",
+                               tuple(float(k) for k in g["kappaC"]), npixpsf=int(g["npixpsf"]), oversamp=int(g["oversamp"]),
+                               flat_penalty=float(g["flat_penalty"]), n_inframe=n_inframe, uctarget=1e-6, sigmamax=0.5)
+    assert abs(cfg.dscale - geo.dscale) <= 1e-15 * geo.dscale
+    dev = "cuda:0"
+    lin = np.arange(ns) - (ns - 1) / 2.0
+    gx, gy = np.meshgrid(lin, lin)
+    xy = np.stack([gx.ravel(), gy.ravel()], axis=1) * geo.dscale
+    group_psfs = {}
+    for (gj, gi), expos in group_expo.items():  # PSFGrp._build_inpsfgrp / _sample_psf on the device
+        p0 = np.array([2 * gi * n2 - 0.5, 2 * gj * n2 - 0.5])
+        imgs = np.stack([g[f"inpsf{e}"] for e in expos])
+        co = []
+        for e in expos:
+            M, t0 = g[f"inM{e}"], g[f"int0{e}"]
+            d = ((xy + p0) @ M.T + t0 - (p0[None, :] @ M.T + t0)) * geo.oversamp
+            co.append(np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)]))
+        group_psfs[(gj, gi)] = psfs.sample_psf(torch.as_tensor(imgs, device=dev), ns, torch.as_tensor(np.stack(co), device=dev), True, True)
+    timg = psfs.get_outpsf("GAUSSIAN", 1.1, 2, ns, geo.oversamp, device=dev)
+    target = psfs.sample_psf(timg[None], ns, None, True, True)
+    tabs = BlockTables({k: v.cpu().numpy() for k, v in group_psfs.items()}, target.cpu().numpy(), geo.nfft, group_expo=group_expo, capacity=256)
+    assert abs(tabs.C - float(g["C"][0])) <= 1e-12 * float(g["C"][0])
+    pool = InStampPool([inst[(j, i)] for j in range(nst) for i in range(nst)], n_inframe)
+    j_st, i_st = int(g["j_st"]), int(g["i_st"])
+    sb = prepare_batch(cfg, pool, tabs, [(j_st, i_st)], n1P, n_inimage)
+    res = sb.run()
+    torch.cuda.synchronize()
+    N, m = g["A"].shape[0], cfg.m
+    assert int(sb.n[0]) == N
+    A, Bt = sb.A[0, :N, :N].cpu().numpy(), sb.Bt[0, :N, :m].cpu().numpy()
+    assert np.abs(A - g["A"]).max() <= 1e-11 * np.abs(g["A"]).max()
+    assert np.abs(Bt.T - g["mBhalf"][0]).max() <= 1e-11 * np.abs(g["mBhalf"]).max()
+    lam = np.linalg.eigvalsh(g["A"])
+    kap = float(g["kappaC"][0]) * float(g["C"][0])
+    cond = (lam[-1] + kap) / (max(lam[0], 0.0) + kap)
+    T = res.T(0).cpu().numpy()
+    assert np.abs(T - g["T"][0]).max() <= (1e-6 + 50 * cond * 2.2e-16) * np.abs(g["T"]).max()
+    for name in ("UC", "Sigma", "kappa"):
+        assert np.allclose(getattr(res, name)[0].cpu().numpy(), g[name][0], rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9), name
+    ref_img = g["outimage"][0]
+    assert np.abs(res.outimage[0].cpu().numpy() - ref_img).max() <= 2e-5 * np.abs(ref_img).max()
+    assert np.allclose(res.Tsum_stamp[0, :n_inimage].cpu().numpy(), g["Tsum_stamp"][0], rtol=1e-5)
+    assert np.allclose(res.Neff[0].cpu().numpy(), g["Neff"][0], rtol=1e-4)

@@ -294,3 +294,75 @@ def test_block_accumulation_golden(golden):
     for k in maps:
         orc.trapezoid_recover(maps[k], fk, pads)
         assert np.array_equal(maps[k], g[f"fin_{k}_map"]), k
+
+
+def _chain_inputs(g):
+    """Geometry, per-group sampled PSFs and the nine InStamps of the output stamp in tests/golden/stamp_chain.npz."""
+    n1P, n2, fade, n_inimage, n_inframe = (int(v) for v in g["pars"])
+    geo = orc.Geom(int(g["npixpsf"]), int(g["oversamp"]), float(g["dtheta_as"]) / 3600.0, float(g["flat_penalty"]))
+    ns, nst = geo.nsamp, n1P + 2
+    lin = np.arange(ns) - (ns - 1) / 2.0
+    gx, gy = np.meshgrid(lin, lin)
+    xy = np.stack([gx.ravel(), gy.ravel()], axis=1) * geo.dscale  # psfutil.py:751-771
+    inst = {(j, i): (g[f"in{j}{i}_x"], g[f"in{j}{i}_y"], g[f"in{j}{i}_data"], g[f"in{j}{i}_cum"].astype(np.int64)) for j in range(nst) for i in range(nst)}
+    group_psfs, group_expo = {}, {}
+    for gj in range(nst // 2):
+        for gi in range(nst // 2):
+            used = np.zeros(n_inimage, bool)
+            for dj in range(2):
+                for di in range(2):
+                    used |= np.diff(inst[(2 * gj + dj, 2 * gi + di)][3]) > 0  # psfutil.py:812-818
+            p0 = np.array([2 * gi * n2 - 0.5, 2 * gj * n2 - 0.5])          # coadd.py:712
+            arr = []
+            for e in np.flatnonzero(used):
+                M, t0 = g[f"inM{e}"], g[f"int0{e}"]
+                d = ((xy + p0) @ M.T + t0 - (p0[None, :] @ M.T + t0)) * geo.oversamp
+                yxco = np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)])
+                arr.append(orc.sample_psf(g[f"inpsf{e}"], ns, yxco))
+            group_psfs[(gj, gi)] = orc.finish_psf_group(np.stack(arr), True, True)
+            group_expo[(gj, gi)] = [int(e) for e in np.flatnonzero(used)]
+    return geo, inst, group_psfs, group_expo, (n1P, n2, fade, n_inimage, n_inframe)
+
+
+def test_full_chain_golden(golden):
+    """ONE output stamp end to end against the reference's own chain (make_golden_chain.py: PSFGrp sampling -> PSFOvl ->
+    SysMatA / SysMatB -> OutStamp._build_system_matrices -> CholKernel -> taper -> _perform_coaddition, four PSF groups,
+    one lacking an exposure).  The oracle starts from the same raw inputs (PSF images, affine maps, InStamp pixels)."""
+    g = golden("stamp_chain")
+    geo, inst, group_psfs, group_expo, (n1P, n2, fade, n_inimage, n_inframe) = _chain_inputs(g)
+    assert group_expo[(0, 1)] == [0, 2]
+    ns, nst, n2f = geo.nsamp, n1P + 2, n2 + 2 * fade
+    j_st, i_st = int(g["j_st"]), int(g["i_st"])
+    tgt = orc.sample_psf(orc.get_outpsf("GAUSSIAN", 1.1, 2, ns, geo.oversamp), ns, None)[None]
+    rft_out = orc.pad_and_rfft2(orc.finish_psf_group(tgt, True, True), geo)
+    C = orc.overlap_out_C(rft_out, geo)
+    assert np.allclose(C, g["C"], rtol=1e-14, atol=0)
+    rft_in = {k: orc.pad_and_rfft2(v, geo) for k, v in group_psfs.items()}
+    rpix = float(g["instamp_pad_as"]) / float(g["dtheta_as"])
+    bottom, left = (j_st - 1) * n2, (i_st - 1) * n2
+    top, right = bottom + n2 - 1, left + n2 - 1
+    nine, piv, groups = [], [], []
+    for dj in (-1, 0, 1):
+        for di in (-1, 0, 1):
+            nine.append(inst[(j_st + dj, i_st + di)])
+            piv.append(([left - 0.5, None, right + 0.5][di + 1], [bottom - 0.5, None, top + 0.5][dj + 1]))
+            groups.append(((j_st + dj) >> 1, (i_st + di) >> 1))
+    sels = [orc.select_pixels(t[0], t[1], pv, rpix) for t, pv in zip(nine, piv)]
+    x, y, indata, expo, cum = orc.process_input_stamps(nine, piv, rpix)
+    assert np.array_equal(cum, g["inpix_cumsum"])
+    ox, oy = left - fade + np.arange(n2f, dtype=np.float64), bottom - fade + np.arange(n2f, dtype=np.float64)
+    A, mB = orc.stamp_system_groups(nine, sels, groups, rft_in, rft_out, geo, ox, oy, group_expo)
+    assert np.abs(A - g["A"]).max() <= 1e-14 * np.abs(g["A"]).max()
+    assert np.abs(mB - g["mBhalf"][0]).max() <= 1e-14 * np.abs(g["mBhalf"]).max()
+    T, UC, Sg, kp, _ = orc.chol_kernel(g["A"], g["mBhalf"][0], float(g["C"][0]), g["kappaC"], 1e-6, 0.5)
+    assert np.abs(T - g["T_raw"][0]).max() <= 1e-6 * np.abs(g["T_raw"]).max()
+    s2 = (n2f, n2f)
+    UC, Sg, kp = UC.reshape(s2).copy(), Sg.reshape(s2).copy(), kp.reshape(s2).copy()
+    for a in (kp, Sg, UC):
+        orc.trapezoid(a, fade)
+    assert np.allclose(UC, g["UC"][0], rtol=2e-5, atol=1e-12) and np.allclose(Sg, g["Sigma"][0], rtol=2e-5) and np.array_equal(kp, g["kappa"][0])
+    T3 = g["T_raw"].copy()
+    outimage, Tsum_stamp, Tsum_inpix, Neff = orc.perform_coaddition(T3, indata, expo, n_inimage, n2f, n2, fade, cum)
+    assert np.array_equal(T3, g["T"])
+    assert np.abs(outimage - g["outimage"]).max() <= 4e-7 * np.abs(g["outimage"]).max()
+    assert np.allclose(Tsum_stamp, g["Tsum_stamp"], rtol=1e-12) and np.allclose(Neff, g["Neff"], rtol=1e-10)
