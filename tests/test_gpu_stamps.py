@@ -160,3 +160,20 @@ def test_empty_stamp_in_resident_batch():
     assert torch.all(res.Tt[0] == 0)
     for name in ("UC", "Sigma", "kappa", "outimage", "Tsum_inpix", "Neff", "Tsum_stamp"):
         assert torch.equal(getattr(res, name)[1], getattr(alone, name)[0]), name
+
+
+def test_alternative_code_paths_in_subprocess():
+    """The switches kept for A/B runs and as cross-checks must not rot: the unfused diagonal-block launches
+    (IMCOM_SOLVE_UNFUSED), the dense-DFT table path (IMCOM_PSF_OVERLAP=gemm) and the Jacobi eigensolver (IMCOM_EIGH=jacobi)
+    are read once per process, so the parity check runs in a child process with all three set."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IMCOM_SOLVE_UNFUSED="1", IMCOM_PSF_OVERLAP="gemm", IMCOM_EIGH="jacobi", PYTHONPATH=root)
+    code = ("import dataclasses; from pyimcom_amd import smoke, synth; "
+            "smoke.check_batch(synth.CONFIGS['small'], 2); "
+            "smoke.check_batch(dataclasses.replace(synth.CONFIGS['tiny'], kernel='Eigen'), 2); print('alt paths ok')")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "alt paths ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
