@@ -65,8 +65,11 @@ def oracle_stamp(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab):
                 Tsum_inpix=Tsum_inpix[0], Neff=Neff[0], info=info)
 
 
-def check_batch(cfg, n_stamps=2, first_id=0, verbose=False, device="cuda:0"):
-    """Run n_stamps synthetic stamps of cfg through the HIP path and assert parity with the oracle."""
+def check_batch(cfg, n_stamps=2, first_id=0, verbose=False, device="cuda:0", tolT_scale=1.0):
+    """Run n_stamps synthetic stamps of cfg through the HIP path and assert parity with the oracle.  tolT_scale widens the
+    bound on T alone: with five or more kappa nodes the nv x nv reduced systems of build_reduced_T (routine.py:546-588)
+    are nearly singular and T = sum_p w_p T_p moves by ~1e-6 along their near-null directions from one summation order
+    to the next, while kappa, Sigma and U/C stay put."""
     import torch
 
     from . import synth
@@ -105,7 +108,7 @@ def check_batch(cfg, n_stamps=2, first_id=0, verbose=False, device="cuda:0"):
         # forward error of a backward-stable solve ~ cond * eps: allow for it on top of the float32 rounding
         lam = np.linalg.eigvalsh(ref["A"])
         cond = (lam[-1] + cfg.kappaC[0] * C_o) / (max(lam[0], 0.0) + cfg.kappaC[0] * C_o)
-        tolT = TOL["T"] + 50 * cond * 2.2e-16
+        tolT = (TOL["T"] + 50 * cond * 2.2e-16) * tolT_scale
         ok = eA < TOL["A"] and eB < TOL["B"] and eT < tolT
         maps = {}
         for name in ("UC", "Sigma", "kappa"):

@@ -177,3 +177,22 @@ def test_alternative_code_paths_in_subprocess():
             "smoke.check_batch(dataclasses.replace(synth.CONFIGS['tiny'], kernel='Eigen'), 2); print('alt paths ok')")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "alt paths ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name,kw,scale", [
+    ("one_frame", dict(n_inframe=1), 1.0), ("one_expo", dict(n_expo=1), 1.0), ("odd_n2_nofade", dict(n2=7, fade=0), 1.0),
+    ("fade3", dict(fade=3), 1.0), ("wide_pad", dict(inpad_as=0.3), 1.0), ("multi_kappa4", dict(kappaC=(1e-5, 1e-4, 1e-3, 1e-2)), 1.0),
+    ("multi_kappa5", dict(kappaC=(1e-6, 1e-5, 1e-4, 1e-3, 1e-2)), 10.0), ("airy", dict(psf="airy"), 1.0),
+    ("no_penalty", dict(flat_penalty=0.0), 1.0), ("eigen_multi", dict(kernel="Eigen", kappaC=(1e-5, 1e-2)), 1.0),
+    ("empirical", dict(kernel="Empirical"), 1.0), ("two_targets_eigen", dict(kernel="Eigen", n_out=2), 1.0),
+    ("many_expo", dict(n_expo=9), 1.0)])
+def test_unusual_configurations(name, kw, scale):
+    """Corners of the configuration space on the resident path against the oracle: one input layer, one exposure, odd
+    stamp size without fade, a wide fade, a large acceptance radius, four and five kappa nodes (the latter with the wider
+    bound on T that smoke.check_batch documents), Airy PSFs, no flat penalty, Eigen with two nodes / two targets, the
+    empirical kernel, nine exposures."""
+    import dataclasses
+
+    from pyimcom_amd import smoke, synth
+
+    smoke.check_batch(dataclasses.replace(synth.CONFIGS["tiny"], name=name, **kw), n_stamps=3, tolT_scale=scale)
