@@ -12,7 +12,7 @@
 What is duck-typed: the Block (configuration numbers, timer), the InStamp containers (pixel arrays), the InImages
 (get_psf_pos returns a fixed oversampled PSF image per exposure, outpix2world2inpix an affine map) and blk.outwcs
 (only printed).  A 2 x 2 block of n2 = 4 stamps, 3 exposures, one PSF group lacking exposure 1; OutStamp (1, 2) touches
-all four PSF groups.
+all four PSF groups.  With --mid also stamp_chain_mid.npz: the same with n2 = 12, npixpsf = 16 and INPAD 0.3 arcsec (N ~ 250 input pixels).
 """
 
 import ast
@@ -38,7 +38,7 @@ def _strip(fn):
     return fn
 
 
-def main():
+def main(tag="", npixpsf=8, n2=4, seed=909, inpad_as=0.12):
     _, lakernel, psfutil = mg._load_reference()
     PSFGrp, PSFOvl, SysMatA, SysMatB = psfutil.PSFGrp, psfutil.PSFOvl, psfutil.SysMatA, psfutil.SysMatB
     tree = ast.parse(open(REF).read(), filename=REF)
@@ -80,17 +80,17 @@ def main():
     ns["OutStamp"], ns["InStamp"] = OutStamp, InStamp
 
     # ---- geometry
-    npixpsf, oversamp, dtheta_as = 8, 4, 0.04
-    n1P, n2, fade, n_inimage, n_inframe = 2, 4, 1, 3, 2
+    oversamp, dtheta_as = 4, 0.04
+    n1P, fade, n_inimage, n_inframe = 2, 1, 3, 2
     PSFGrp.setup(npixpsf=npixpsf, oversamp=oversamp, dtheta=dtheta_as / 3600.0, psfsplit=False)
     PSFOvl.setup(flat_penalty=1e-7)
-    rng = np.random.default_rng(909)
+    rng = np.random.default_rng(seed)
     out = dict(npixpsf=npixpsf, oversamp=oversamp, dtheta_as=dtheta_as, pars=np.array([n1P, n2, fade, n_inimage, n_inframe]),
-               flat_penalty=1e-7, kappaC=np.array([2e-3]), instamp_pad_as=0.12)
+               flat_penalty=1e-7, kappaC=np.array([2e-3]), instamp_pad_as=inpad_as)
 
     cfg = mg.Empty()
     cfg.n1P, cfg.n2, cfg.fade_kernel, cfg.n2f, cfg.n_inframe = n1P, n2, fade, n2 + 2 * fade, n_inframe
-    cfg.dtheta, cfg.instamp_pad = dtheta_as / 3600.0, 0.12 * Stn.arcsec
+    cfg.dtheta, cfg.instamp_pad = dtheta_as / 3600.0, inpad_as * Stn.arcsec
     cfg.linear_algebra, cfg.no_qlt_ctrl, cfg.tempfile = "Cholesky", False, None
     cfg.kappaC_arr, cfg.uctarget, cfg.sigmamax = out["kappaC"], 1e-6, 0.5
     cfg.psf_circ, cfg.psf_norm, cfg.amp_penalty = True, True, [0.0, 0.0]
@@ -103,12 +103,12 @@ def main():
 
     # InImages: a fixed oversampled PSF image and an affine output-pixel -> input-pixel map per exposure
     blk.inimages = []
-    ny, nx = 44, 40
+    ny, nx = 11 * npixpsf // 2, 5 * npixpsf
     yy, xx = np.mgrid[:ny, :nx]
     for e in range(n_inimage):
         im = mg.Empty()
         im.idsca = (100 + e, 1)
-        psf = np.exp(-((xx - 19.2 - 0.3 * e) ** 2 / (26.0 + 3 * e) + (yy - 21.6 + 0.2 * e) ** 2 / (22.0 + 2 * e))) + 0.01 * rng.standard_normal((ny, nx))
+        psf = np.exp(-((xx - 0.48 * nx - 0.3 * e) ** 2 / (26.0 + 3 * e) + (yy - 0.49 * ny + 0.2 * e) ** 2 / (22.0 + 2 * e))) + 0.01 * rng.standard_normal((ny, nx))
         th = 0.15 + 0.4 * e
         M = (dtheta_as / 0.11) * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
         t0 = np.array([500.0 + 30 * e, 700.0 - 20 * e])
@@ -126,7 +126,7 @@ def main():
     cells = [[[] for _ in range(nst)] for _ in range(nst)]
     for e in range(n_inimage):
         th = 0.15 + 0.4 * e
-        g = np.arange(-10, 11) * pitch
+        g = np.arange(-14, 15) * pitch
         gx, gy = np.meshgrid(g + rng.uniform(0, pitch), g + rng.uniform(0, pitch))
         x = (np.cos(th) * gx - np.sin(th) * gy).ravel() + n2
         y = (np.sin(th) * gx + np.cos(th) * gy).ravel() + n2
@@ -170,10 +170,12 @@ def main():
         ost._perform_coaddition(save_t=True)
     out.update(j_st=j_st, i_st=i_st, A=A, mBhalf=mB, C=C, UC=UC, Sigma=Sigma, kappa=kappa, T_raw=T_raw, T=ost.T, outimage=ost.outimage,
                Tsum_stamp=ost.Tsum_stamp, Tsum_inpix=ost.Tsum_inpix, Neff=ost.Neff, inpix_cumsum=ost.inpix_cumsum)
-    np.savez_compressed(f"{HERE}/stamp_chain.npz", **out)
+    np.savez_compressed(f"{HERE}/stamp_chain{tag}.npz", **out)
     print("N =", A.shape[0], "cumsum", ost.inpix_cumsum, "C", C, "UC range", float(UC.min()), float(UC.max()))
     print("A sym err", float(np.abs(A - A.T).max()), "lam min", float(np.linalg.eigvalsh(A)[0]))
 
 
 if __name__ == "__main__":
-    main()
+    main()                                          # N = 29: every branch, seconds
+    if "--mid" in sys.argv:                         # N ~ 250, PSF tables wide enough for the whole stamp: minutes (interpreted loops)
+        main("_mid", npixpsf=16, n2=12, seed=911, inpad_as=0.3)

@@ -161,7 +161,8 @@ def test_block_with_psf_groups_vs_oracle(n_out):
     assert np.abs(uni.out_map[0].cpu().numpy() - ref_out[0]).max() > 1e-3 * np.abs(ref_out[0]).max()
 
 
-def test_full_chain_vs_reference_golden(golden):
+@pytest.mark.parametrize("name", ["stamp_chain", "stamp_chain_mid"])
+def test_full_chain_vs_reference_golden(golden, name):
     """The device chain from raw inputs -- PSF images sampled on the device, PSF groups per 2x2 InStamps (one lacking an
     exposure), table sets, selection, A, B, Cholesky, taper, coaddition -- for the output stamp of
     tests/golden/stamp_chain.npz, against what the reference's own code produced end to end (PSFGrp, PSFOvl, SysMatA /
@@ -174,7 +175,7 @@ def test_full_chain_vs_reference_golden(golden):
     from pyimcom_amd.stamps import BlockTables
     from tests.test_oracle import _chain_inputs
 
-    g = golden("stamp_chain")
+    g = golden(name)
     geo, inst, _, group_expo, (n1P, n2, fade, n_inimage, n_inframe) = _chain_inputs(g)
     ns, nst = geo.nsamp, n1P + 2
     cfg = synth.WorkloadConfig("chain", n2, fade, float(g["dtheta_as"]), n_inimage, float(g["instamp_pad_as"]), "Cholesky",

@@ -324,11 +324,13 @@ def _chain_inputs(g):
     return geo, inst, group_psfs, group_expo, (n1P, n2, fade, n_inimage, n_inframe)
 
 
-def test_full_chain_golden(golden):
+@pytest.mark.parametrize("name", ["stamp_chain", "stamp_chain_mid"])
+def test_full_chain_golden(golden, name):
     """ONE output stamp end to end against the reference's own chain (make_golden_chain.py: PSFGrp sampling -> PSFOvl ->
     SysMatA / SysMatB -> OutStamp._build_system_matrices -> CholKernel -> taper -> _perform_coaddition, four PSF groups,
-    one lacking an exposure).  The oracle starts from the same raw inputs (PSF images, affine maps, InStamp pixels)."""
-    g = golden("stamp_chain")
+    one lacking an exposure; N = 29 and N = 220 input pixels).  The oracle starts from the same raw inputs (PSF images,
+    affine maps, InStamp pixels)."""
+    g = golden(name)
     geo, inst, group_psfs, group_expo, (n1P, n2, fade, n_inimage, n_inframe) = _chain_inputs(g)
     assert group_expo[(0, 1)] == [0, 2]
     ns, nst, n2f = geo.nsamp, n1P + 2, n2 + 2 * fade
@@ -364,5 +366,6 @@ def test_full_chain_golden(golden):
     T3 = g["T_raw"].copy()
     outimage, Tsum_stamp, Tsum_inpix, Neff = orc.perform_coaddition(T3, indata, expo, n_inimage, n2f, n2, fade, cum)
     assert np.array_equal(T3, g["T"])
-    assert np.abs(outimage - g["outimage"]).max() <= 4e-7 * np.abs(g["outimage"]).max()
+    # float32 einsum over N terms: numpy picks its reduction (BLAS or not) by operand layout, a few float32 ulps of the sum
+    assert np.abs(outimage - g["outimage"]).max() <= 2e-6 * np.abs(g["outimage"]).max()
     assert np.allclose(Tsum_stamp, g["Tsum_stamp"], rtol=1e-12) and np.allclose(Neff, g["Neff"], rtol=1e-10)
