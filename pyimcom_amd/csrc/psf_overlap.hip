@@ -11,6 +11,7 @@
 // products with exact twiddle matrices (integer argument reduction mod nfft, then cos/sin of a multiple of
 // pi/nfft) on the fp64 MFMA tile engine of gemm_f64.hip; only the kept nsamp x nsamp window of the inverse is
 // computed; O(nfft * nsamp * nh) per stage, 51 us per cfg-2 table.  Both agree with numpy's FFTs to ~1e-15.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -636,7 +637,17 @@ extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, in
                       "pair %d out of range", t);
     FftPlan pl;
     fft_plan(nfft, &pl);
-    IMCOM_TRY(ws_reserve(ctx, fft_inverse_ws(npairs, nsamp, nfft) + 8192));
+    // in chunks of pairs, so that the intermediate (nsamp x nh complex per pair) stays within ~4 GB however many
+    // tables a caller asks for at once; the chunks run back to back on the stream and reuse the workspace in order
+    const size_t per_pair = (size_t)nsamp * (nfft / 2 + 1) * 16;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs, ((size_t)4 << 30) / per_pair));
+    IMCOM_TRY(ws_reserve(ctx, fft_inverse_ws(chunk, nsamp, nfft) + 8192));
     ProfScope ps(ctx, "psf_overlap");
-    return fft_inverse(ctx, pl, (const cplx *)spec1, (const cplx *)spec2, pairs_host, npairs, nsamp, amp_penalty, tables);
+    const size_t tab = (size_t)(nsamp + 12) * (nsamp + 12);
+    for (int p0 = 0; p0 < npairs; p0 += chunk) {
+        ctx->ws_used = 0;
+        IMCOM_TRY(fft_inverse(ctx, pl, (const cplx *)spec1, (const cplx *)spec2, pairs_host + 2 * (size_t)p0, std::min(chunk, npairs - p0), nsamp,
+                              amp_penalty, tables + (size_t)p0 * tab));
+    }
+    return IMCOM_OK;
 }

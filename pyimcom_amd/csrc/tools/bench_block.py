@@ -48,4 +48,4 @@ for gj in range(ng):
         q = psfs * mod
         groups[(gj, gi)] = q / q.sum(axis=(1, 2), keepdims=True)
 for pl in (True, False, True, False):
-    timed(f"{ng * ng} PSF groups (2x2), pipeline={pl}", lambda: BlockTables(groups, target, cfg.nfft, capacity=12000), pipeline=pl)
+    timed(f"{ng * ng} PSF groups (2x2), pipeline={pl}", lambda: BlockTables(groups, target, cfg.nfft, capacity=13500), pipeline=pl)
