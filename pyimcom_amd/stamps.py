@@ -163,7 +163,8 @@ class BlockTables:
     0..n_g-1).  Tables live in one device arena and are computed on demand: a group's self overlap (triangle order)
     and input-output overlap, and the cross overlap of two groups (all n_g1 x n_g2 pairs, stored for the ordered key
     g_lo < g_hi).  When the arena is full it is simply restarted -- stamps are visited group by group, so
-    recomputation is rare."""
+    recomputation is rare.  ``capacity`` (tables) is bounded by the 31-bit element offsets of the A builder:
+    capacity * (nsamp + 12)^2 < 2^31, i.e. 13 763 tables (17 GB) at nsamp = 383; one batch of stamps must fit."""
 
     def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0"):
         self.ctx = ctx or default_context()
@@ -181,6 +182,8 @@ class BlockTables:
         amp = None if amp_penalty is None or 0.0 in tuple(amp_penalty) else np.array(amp_penalty, dtype=np.float64)
         self._amp = amp
         ng = self.nsamp + 12
+        if capacity * ng * ng >= 2**31:
+            raise ValueError(f"capacity {capacity} x {ng}^2 table elements exceeds the 31-bit offsets of imcom_build_A (max {(2**31 - 1) // (ng * ng)})")
         self.tables = torch.empty((capacity, ng, ng), dtype=torch.float64, device=dev)  # the arena
         self.index, self.used = {}, 0
         # forward spectra of the target PSFs and of every group in ONE arena, so that all the table sets a batch of
