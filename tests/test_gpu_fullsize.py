@@ -74,3 +74,35 @@ def test_cfg5_properties():
     b.coadd()
     torch.cuda.synchronize()
     assert torch.allclose(b.outimage, 2.0 * first[2].reshape(b.outimage.shape), rtol=1e-6, atol=0)
+
+
+def test_cfg2_block_groups_equal_single_group():
+    """cfg-2 geometry through the block driver (selection, tables, A, B, Cholesky, coaddition, block maps) at full stamp
+    size (N ~ 2.2k), as a size-independent property: when every 2x2 PSF group holds the SAME PSFs, the per-group route
+    (BlockTables: self / cross / input-output sets, per-stamp pair maps, flipped and swapped tables) must reproduce the
+    one-group route.  The tables of a pair come from different FFT evaluations on the two routes (1e-16 apart), so the
+    maps agree to the conditioning of the solve, not bit for bit."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import coadd_block
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import BlockTables, PSFGroupTables
+
+    cfg = synth.CONFIGS["cfg2"]
+    n1P, E = 3, cfg.n_expo
+    inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng(12))
+    pool = InStampPool(inst, cfg.n_inframe)
+    psfs, target = synth.make_psfs(cfg, E)
+    one = coadd_block(cfg, pool, PSFGroupTables(psfs, target, cfg.nfft), n1P, E, batch=9)
+    ng = (n1P + 3) // 2
+    grp = coadd_block(cfg, pool, BlockTables({(gj, gi): psfs for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, capacity=1500),
+                      n1P, E, batch=5)
+    torch.cuda.synchronize()
+    a, b = one.out_map.cpu().numpy(), grp.out_map.cpu().numpy()
+    assert np.isfinite(a).all() and np.abs(a).max() > 0
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max()
+    for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+        x, y = one.maps[k].cpu().numpy(), grp.maps[k].cpu().numpy()
+        assert np.allclose(x, y, rtol=1e-4, atol=1e-7 * np.abs(x).max()), k
+    assert np.allclose(one.T_weightmap.cpu().numpy(), grp.T_weightmap.cpu().numpy(), rtol=1e-5, atol=1e-8)
