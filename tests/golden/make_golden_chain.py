@@ -70,7 +70,8 @@ def main(tag="", npixpsf=8, n2=4, seed=909, inpad_as=0.12):
         make_selection = got[("InStamp", "make_selection")]
 
     class OutStamp:
-        LAKERNEL = {"Cholesky": lakernel.CholKernel}
+        LAKERNEL = {"Cholesky": lakernel.CholKernel, "Eigen": lakernel.EigenKernel, "Iterative": lakernel.IterKernel,
+                    "Empirical": lakernel.EmpirKernel}
         __init__ = got[("OutStamp", "__init__")]
         _process_input_stamps = got[("OutStamp", "_process_input_stamps")]
         _build_system_matrices = got[("OutStamp", "_build_system_matrices")]
@@ -167,9 +168,24 @@ def main(tag="", npixpsf=8, n2=4, seed=909, inpad_as=0.12):
         A, mB, C = ost.sysmata.copy(), ost.mhalfb.copy(), np.array(ost.outovlc, dtype=np.float64)
         UC, Sigma, kappa = ost.UC.copy(), ost.Sigma.copy(), ost.kappa.copy()
         T_raw = ost.T.copy()
+        yx_val, iny_val, inx_val = ost.yx_val.copy(), ost.iny_val.copy(), ost.inx_val.copy()
+        # the other LA kernels on the same (realistic) A, -B/2, C: lakernel.py 141-223, 325-394, 533-744, 747-805
+        cfg.iter_rtol, cfg.iter_max = 1.5e-3, 30
+        alt = {}
+        for akey, kern, kC in (("eig1", "Eigen", [2e-3]), ("eig2", "Eigen", [1e-4, 1e-1]), ("chol3", "Cholesky", [1e-4, 1e-3, 1e-2]),
+                              ("iter1", "Iterative", [3e-2]), ("emp", "Empirical", [2e-3])):
+            cfg.linear_algebra, cfg.kappaC_arr = kern, np.array(kC)
+            K = OutStamp.LAKERNEL[kern](ost)
+            K()
+            alt[akey] = (np.array(kC), ost.T.copy(), ost.UC.copy(), ost.Sigma.copy(), ost.kappa.copy())
+        cfg.linear_algebra, cfg.kappaC_arr = "Cholesky", out["kappaC"]
+        ost.T, ost.UC, ost.Sigma, ost.kappa = T_raw.copy(), UC.copy(), Sigma.copy(), kappa.copy()
         ost._perform_coaddition(save_t=True)
     out.update(j_st=j_st, i_st=i_st, A=A, mBhalf=mB, C=C, UC=UC, Sigma=Sigma, kappa=kappa, T_raw=T_raw, T=ost.T, outimage=ost.outimage,
                Tsum_stamp=ost.Tsum_stamp, Tsum_inpix=ost.Tsum_inpix, Neff=ost.Neff, inpix_cumsum=ost.inpix_cumsum)
+    for k, (kC, T_, UC_, Sg_, kp_) in alt.items():
+        out[f"{k}_kappaC"], out[f"{k}_T"], out[f"{k}_UC"], out[f"{k}_Sigma"], out[f"{k}_kappa"] = kC, T_, UC_, Sg_, kp_
+    out["yx_val"], out["iny_val"], out["inx_val"] = yx_val, iny_val, inx_val
     np.savez_compressed(f"{HERE}/stamp_chain{tag}.npz", **out)
     print("N =", A.shape[0], "cumsum", ost.inpix_cumsum, "C", C, "UC range", float(UC.min()), float(UC.max()))
     print("A sym err", float(np.abs(A - A.T).max()), "lam min", float(np.linalg.eigvalsh(A)[0]))

@@ -246,3 +246,47 @@ def test_iter_kernel_reference_known_answers():
             assert 0.05 < o.UC.ravel()[j] < 0.2
             assert 2e-4 < o.kappa.ravel()[j] < 4e-4
         assert 0.6 < o.Sigma.ravel()[j] < 1.0
+
+
+@pytest.mark.parametrize("name", ["stamp_chain", "stamp_chain_mid"])
+def test_all_kernels_on_chain_system(golden, name):
+    """The four kernel classes of the drop-in seam on the reference chain's own A, -B/2, C (tests/golden/stamp_chain*.npz: a
+    real PSF-overlap system with four PSF groups), against what the reference's CholKernel / EigenKernel / IterKernel /
+    EmpirKernel returned for it."""
+    from pyimcom_amd.lakernel import HipCholKernel, HipEigenKernel, HipEmpirKernel, HipIterKernel
+
+    g = golden(name)
+    A, C = g["A"], g["C"]
+    lam = np.linalg.eigvalsh(A)
+    rho_as, dth = float(g["instamp_pad_as"]), float(g["dtheta_as"])
+    n2f = g["yx_val"].shape[-1]
+
+    def outst(kC):
+        cfg = _Obj()
+        cfg.n2f, cfg.n_out = n2f, 1
+        cfg.kappaC_arr = np.asarray(kC, dtype=np.float64)
+        cfg.uctarget, cfg.sigmamax = 1e-6, 0.5
+        cfg.dtheta, cfg.instamp_pad = dth / 3600.0, rho_as * (np.pi / 180.0 / 3600.0)
+        cfg.iter_rtol, cfg.iter_max = 1.5e-3, 30
+        o = _Obj()
+        o.blk = _Obj()
+        o.blk.cfg = cfg
+        o.inpix_cumsum = np.array([A.shape[0]])
+        o.sysmata, o.mhalfb, o.outovlc = A.copy(), g["mBhalf"].copy(), C.copy()
+        o.iny_val, o.inx_val, o.yx_val = g["iny_val"], g["inx_val"], g["yx_val"].astype(np.float64)
+        o.no_qlt_ctrl = False
+        return o
+
+    for tag, K in (("eig1", HipEigenKernel), ("eig2", HipEigenKernel), ("chol3", HipCholKernel), ("iter1", HipIterKernel), ("emp", HipEmpirKernel)):
+        kC = g[f"{tag}_kappaC"]
+        o = outst(kC)
+        K(o)()
+        kap = float(kC[0]) * float(C[0])
+        cond = (lam[-1] + kap) / (max(lam[0], 0.0) + kap)
+        tT = 3e-5 if tag == "iter1" else 1e-6 + 100 * cond * 2.2e-16
+        rt = 2e-3 if tag == "iter1" else 2e-5 + 100 * cond * 2.2e-16
+        assert o.T.dtype == np.float32 and o.T.shape == g[f"{tag}_T"].shape
+        assert np.abs(o.T - g[f"{tag}_T"]).max() <= tT * np.abs(g[f"{tag}_T"]).max(), tag
+        assert np.allclose(o.kappa, g[f"{tag}_kappa"], rtol=rt, atol=0), tag
+        assert np.allclose(o.Sigma, g[f"{tag}_Sigma"], rtol=rt, atol=1e-9), tag
+        assert np.allclose(o.UC, g[f"{tag}_UC"], rtol=rt, atol=2e-7), tag

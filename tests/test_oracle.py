@@ -369,3 +369,29 @@ def test_full_chain_golden(golden, name):
     # float32 einsum over N terms: numpy picks its reduction (BLAS or not) by operand layout, a few float32 ulps of the sum
     assert np.abs(outimage - g["outimage"]).max() <= 2e-6 * np.abs(g["outimage"]).max()
     assert np.allclose(Tsum_stamp, g["Tsum_stamp"], rtol=1e-12) and np.allclose(Neff, g["Neff"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["stamp_chain", "stamp_chain_mid"])
+def test_chain_other_kernels_golden(golden, name):
+    """The other LA kernels (Eigen one / two nodes, Cholesky three nodes, Iterative, Empirical) run by the reference on
+    the chain's own A, -B/2, C (a real PSF-overlap system, not a synthetic one): oracle against those outputs."""
+    g = golden(name)
+    A, mB, C = g["A"], g["mBhalf"][0], float(g["C"][0])
+    oy, ox = g["yx_val"][0].ravel().astype(np.float64), g["yx_val"][1].ravel().astype(np.float64)
+    rho = float(g["instamp_pad_as"]) / float(g["dtheta_as"])
+    runs = {"eig1": lambda kC: orc.eigen_kernel(A, mB, C, kC, 1e-6, 0.5), "eig2": lambda kC: orc.eigen_kernel(A, mB, C, kC, 1e-6, 0.5),
+            "chol3": lambda kC: orc.chol_kernel(A, mB, C, kC, 1e-6, 0.5),
+            "iter1": lambda kC: orc.iter_kernel(A, mB, C, kC, 1e-6, 0.5, oy, ox, g["iny_val"], g["inx_val"], rho),
+            "emp": lambda kC: orc.empir_kernel(A, mB, C, kC, oy, ox, g["iny_val"], g["inx_val"], rho)}
+    lam = np.linalg.eigvalsh(A)
+    for tag, f in runs.items():
+        kC = g[f"{tag}_kappaC"]
+        T, UC, Sg, kp, _ = f(kC)
+        kap = float(kC[0]) * C
+        cond = (lam[-1] + kap) / (max(lam[0], 0.0) + kap)
+        tT = 3e-5 if tag == "iter1" else 1e-6 + 100 * cond * 2.2e-16
+        assert np.abs(T - g[f"{tag}_T"][0]).max() <= tT * np.abs(g[f"{tag}_T"]).max(), tag
+        rt = 2e-3 if tag == "iter1" else 2e-5 + 100 * cond * 2.2e-16
+        assert np.allclose(kp, g[f"{tag}_kappa"][0].ravel(), rtol=rt, atol=0), tag
+        assert np.allclose(Sg, g[f"{tag}_Sigma"][0].ravel(), rtol=rt, atol=1e-9), tag
+        assert np.allclose(UC, g[f"{tag}_UC"][0].ravel(), rtol=rt, atol=2e-7), tag
