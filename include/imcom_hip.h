@@ -255,6 +255,10 @@ int imcom_coadd_epilogue(imcom_ctx *ctx, int batch, const int *n_host, int ldn, 
                          double *Tsum_inpix, double *Neff);
 /* OutStamp.trapezoid (coadd.py:1222-1292) on [batch][n2f][n2f] float32 maps (kappa, Sigma, UC). */
 int imcom_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fade);
+/* OutStamp._build_system_matrices, coadd.py:1104-1107: after the "Iterative" kernel (whose U/C and Sigma can come
+ * out negative) the reference sets UC = np.maximum(UC, 1e-32), Sigma = np.maximum(Sigma, 1e-32), before the map
+ * taper.  maps[i] = maps[i] < lo ? lo : maps[i] on `count` device float32 values; NaN stays NaN (np.maximum). */
+int imcom_clamp_min_f32(imcom_ctx *ctx, float *maps, long count, float lo);
 
 /* Block._output_stamp_wrapper map updates (coadd.py:1975-1993), on the device: for every stamp s of the batch,
  * dst[layer][(jst-1)*n2 + r][(ist-1)*n2 + c] += src[s][layer][r][c], r,c < n2f = n2 + 2*fade.  dst is one of the

@@ -17,6 +17,9 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction, so
  * the arithmetic matches the reference's interpreted float64 operations).
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <math.h>
 #include <stddef.h>
 #include <stdlib.h>
@@ -80,8 +83,11 @@ static double stencil(const double *f, long ngx, int yi, int xi, const double *w
 void orc_interp_d5512(const double *infunc, int nlayer, int ngy, int ngx, const double *xpos,
                       const double *ypos, long nout, double *fhatout)
 {
-    double wx[10], wy[10];
+    /* points are independent: threads split them (bench.py's cpu_baseline uses all host cores; orc_set_threads(1)
+     * gives the scalar figure).  No value depends on the thread count. */
+#pragma omp parallel for schedule(static) if (nout > 4096)
     for (long p = 0; p < nout; p++) {
+        double wx[10], wy[10];
         double x = xpos[p], y = ypos[p];
         int xi = (int)x, yi = (int)y; /* np.int32(x): truncation toward zero */
         if (xi < 4 || xi >= ngx - 5 || yi < 4 || yi >= ngy - 5) continue;
@@ -119,35 +125,49 @@ void orc_interp_d5512_sym(const double *infunc, int nlayer, int ngy, int ngx, co
 void orc_grid_d5512(const double *infunc, int ngy, int ngx, const double *xpos, const double *ypos,
                     long npi, int nxo, int nyo, double *fhatout)
 {
-    double *wx = (double *)malloc(sizeof(double) * 10 * (size_t)nxo);
-    double *wy = (double *)malloc(sizeof(double) * 10 * (size_t)nyo);
-    int *xi = (int *)malloc(sizeof(int) * (size_t)nxo);
-    int *yi = (int *)malloc(sizeof(int) * (size_t)nyo);
-    for (long p = 0; p < npi; p++) {
-        for (int ix = 0; ix < nxo; ix++) {
-            double x = xpos[p * nxo + ix];
-            xi[ix] = (int)x;
-            if (xi[ix] < 4 || xi[ix] >= ngx - 5) {
-                xi[ix] = 4;
-                memset(wx + 10 * ix, 0, 10 * sizeof(double));
-            } else
-                orc_d5512_getw(wx + 10 * ix, x - xi[ix] - 0.5);
+#pragma omp parallel if (npi > 64)
+    {
+        double *wx = (double *)malloc(sizeof(double) * 10 * (size_t)nxo);
+        double *wy = (double *)malloc(sizeof(double) * 10 * (size_t)nyo);
+        int *xi = (int *)malloc(sizeof(int) * (size_t)nxo);
+        int *yi = (int *)malloc(sizeof(int) * (size_t)nyo);
+#pragma omp for schedule(static)
+        for (long p = 0; p < npi; p++) {
+            for (int ix = 0; ix < nxo; ix++) {
+                double x = xpos[p * nxo + ix];
+                xi[ix] = (int)x;
+                if (xi[ix] < 4 || xi[ix] >= ngx - 5) {
+                    xi[ix] = 4;
+                    memset(wx + 10 * ix, 0, 10 * sizeof(double));
+                } else
+                    orc_d5512_getw(wx + 10 * ix, x - xi[ix] - 0.5);
+            }
+            for (int iy = 0; iy < nyo; iy++) {
+                double y = ypos[p * nyo + iy];
+                yi[iy] = (int)y;
+                if (yi[iy] < 4 || yi[iy] >= ngy - 5) {
+                    yi[iy] = 4;
+                    memset(wy + 10 * iy, 0, 10 * sizeof(double));
+                } else
+                    orc_d5512_getw(wy + 10 * iy, y - yi[iy] - 0.5);
+            }
+            double *o = fhatout + p * (long)nyo * nxo;
+            for (int iy = 0; iy < nyo; iy++)
+                for (int ix = 0; ix < nxo; ix++)
+                    *o++ = stencil(infunc, ngx, yi[iy], xi[ix], wx + 10 * ix, wy + 10 * iy);
         }
-        for (int iy = 0; iy < nyo; iy++) {
-            double y = ypos[p * nyo + iy];
-            yi[iy] = (int)y;
-            if (yi[iy] < 4 || yi[iy] >= ngy - 5) {
-                yi[iy] = 4;
-                memset(wy + 10 * iy, 0, 10 * sizeof(double));
-            } else
-                orc_d5512_getw(wy + 10 * iy, y - yi[iy] - 0.5);
-        }
-        double *o = fhatout + p * (long)nyo * nxo;
-        for (int iy = 0; iy < nyo; iy++)
-            for (int ix = 0; ix < nxo; ix++)
-                *o++ = stencil(infunc, ngx, yi[iy], xi[ix], wx + 10 * ix, wy + 10 * iy);
+        free(wx); free(wy); free(xi); free(yi);
     }
-    free(wx); free(wy); free(xi); free(yi);
+}
+
+/* thread count of the two interpolators above (0 = OpenMP default = all cores) */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+    (void)n;
+#endif
 }
 
 /* EI-2  routine.py:341-430  lakernel1: per output pixel geometric bisection on kappa */

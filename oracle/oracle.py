@@ -6,10 +6,12 @@ relative to the reference's src/pyimcom/) in NumPy/SciPy (LAPACK potrf/potrs, sy
 plain-C routines of oracle/imcom_oracle.c.
 
 Parity status: PINNED -- tests/test_oracle.py checks every function here against golden vectors
-produced by running the reference itself (tests/golden/make_golden.py).  The stamp-driver functions
-restated from coadd.py (select_pixels, assemble_*, trapezoid, perform_coaddition) could not be run in the
-build container (coadd.py needs asdf/astropy/fitsio at import); they are restated from the source text
-and pinned by hand-computed cases and by consistency with the pinned sub-block functions.
+produced by running the reference itself: routine.py / lakernel.py / psfutil.py imported by file path
+(tests/golden/make_golden.py, make_golden_iter.py, make_golden_psf.py), and the stamp-driver functions of
+coadd.py (make_selection, _process_input_stamps, trapezoid, _perform_coaddition, compress_map, smooth_and_pad,
+the partition loop, _output_stamp_wrapper, the boundary recovery, the Iterative clamp of
+_build_system_matrices) executed out of the module's syntax tree (make_golden_coadd.py, _smooth.py,
+_partition.py, _block.py, _clamp.py); make_golden_chain.py runs one stamp through the whole unmodified chain.
 """
 
 import ctypes as C
@@ -31,6 +33,11 @@ def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO
+
+
+def set_threads(n=0):
+    """Threads of the C interpolators (0 = all host cores); LAPACK/BLAS threads are numpy's own (threadpoolctl)."""
+    _c().orc_set_threads(int(n))
 
 
 def _c():
@@ -576,6 +583,12 @@ def trapezoid(arr, fade_kernel):
     arr[..., :, ir : ir - fk2 : -1] *= s
 
 
+def iterative_clamp(UC, Sigma):
+    """OutStamp._build_system_matrices after the "Iterative" kernel (coadd.py:1104-1107): UC and Sigma "could be
+    negative as the iterative kernel is not exact" and are raised to 1e-32.  Returns new arrays (np.maximum)."""
+    return np.maximum(UC, 1e-32), np.maximum(Sigma, 1e-32)
+
+
 def trapezoid_recover(arr, fade_kernel, pad_widths=(0, 0, 0, 0)):
     """OutStamp.trapezoid(..., recover_mode=True, pad_widths) (coadd.py:1262-1292), in place."""
     fk2 = fade_kernel * 2
@@ -811,3 +824,59 @@ def smooth_and_pad(image, tophatwidth=0.0, gaussiansigma=0.0):
     uy, ux = freq(big.shape[0])[:, None], freq(big.shape[1])[None, :]
     h = np.sinc(ux * tophatwidth) * np.sinc(uy * tophatwidth) * np.exp(-2.0 * np.pi**2 * gaussiansigma**2 * (ux**2 + uy**2))
     return np.real(np.fft.ifft2(np.fft.fft2(big) * h))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole-stamp oracle: tables -> A, B -> LA kernel -> map post-processing -> coaddition, for a synthetic workload
+# configuration `cfg` (pyimcom_amd.synth.WorkloadConfig: plain numbers, nothing of the product is executed)
+def stamp_tables(cfg, psfs, target):
+    """Geom, the padded table stack [E(E+1)/2 self tables + E input-output tables per target] and C per target
+    (psfutil.py:943-986, 1178-1294)."""
+    g = Geom(cfg.npixpsf, cfg.oversamp, cfg.dtheta_as / 3600.0, cfg.flat_penalty)
+    r_in, r_out = pad_and_rfft2(psfs, g), pad_and_rfft2(target, g)
+    tri = overlap_self(r_in, g)
+    cross = overlap_cross(r_in, r_out, g)  # [E, n_out, ...] -> target-major stack
+    io = np.concatenate([cross[:, o] for o in range(cross.shape[1])])
+    Cs = overlap_out_C(r_out, g)
+    tabs = np.concatenate([tri, io])
+    return g, np.pad(tabs, ((0, 0), (6, 6), (6, 6))), np.asarray(Cs, dtype=np.float64)
+
+
+def stamp_full(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab, timings=None):
+    """One stamp through the reference's stamp driver: _build_system_matrices (coadd.py:1002-1122: A, -B/2, LA kernel,
+    the Iterative clamp, the map taper) and _perform_coaddition (1294-1363).  ``timings``: optional dict that
+    receives the seconds spent per stage (build / solve / epilogue)."""
+    import time
+
+    t0 = time.perf_counter()
+    A, Bt = stamp_system(g, stamp.x, stamp.y, stamp.expo, tables_pad, pair_tab, pair_pen, io_tab, stamp.out_x0,
+                         stamp.out_y0, cfg.n2f)
+    mB = np.ascontiguousarray(Bt.T)
+    t1 = time.perf_counter()
+    if cfg.kernel in ("Iterative", "Empirical"):
+        g1 = np.arange(cfg.n2f, dtype=np.float64)
+        oy, ox = np.repeat(stamp.out_y0 + g1, cfg.n2f), np.tile(stamp.out_x0 + g1, cfg.n2f)
+        if cfg.kernel == "Iterative":
+            T, UC, Sigma, kappa, info = iter_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax, oy, ox,
+                                                    stamp.y, stamp.x, cfg.rho)
+            UC, Sigma = iterative_clamp(UC, Sigma)
+        else:
+            T, UC, Sigma, kappa, info = empir_kernel(A, mB, C, np.array(cfg.kappaC), oy, ox, stamp.y, stamp.x, cfg.rho)
+    else:
+        la = eigen_kernel if cfg.kernel == "Eigen" else chol_kernel
+        T, UC, Sigma, kappa, info = la(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
+    s = (cfg.n2f, cfg.n2f)
+    UC, Sigma, kappa = UC.reshape(s).copy(), Sigma.reshape(s).copy(), kappa.reshape(s).copy()
+    if cfg.fade > 0:  # coadd.py:1118-1122
+        for a in (kappa, Sigma, UC):
+            trapezoid(a, cfg.fade)
+    t2 = time.perf_counter()
+    T3 = T[None].copy()
+    outimage, Tsum_stamp, Tsum_inpix, Neff = perform_coaddition(T3, stamp.indata, stamp.expo, stamp.n_expo, cfg.n2f,
+                                                                 cfg.n2, cfg.fade)
+    t3 = time.perf_counter()
+    if timings is not None:
+        for k, v in (("build", t1 - t0), ("solve", t2 - t1), ("epilogue", t3 - t2)):
+            timings[k] = timings.get(k, 0.0) + v
+    return dict(A=A, Bt=Bt, T=T3[0], UC=UC, Sigma=Sigma, kappa=kappa, outimage=outimage[0], Tsum_stamp=Tsum_stamp[0],
+                Tsum_inpix=Tsum_inpix[0], Neff=Neff[0], info=info)

@@ -631,4 +631,11 @@ int imcom_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fa
     return launch_trapezoid_f32(ctx, maps, nmaps, n2f, fade);
 }
 
+int imcom_clamp_min_f32(imcom_ctx *ctx, float *maps, long count, float lo)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(count >= 0 && (count == 0 || maps), "bad arguments");
+    return launch_clamp_min_f32(ctx, maps, count, lo);
+}
+
 }  // extern "C"

@@ -405,6 +405,15 @@ __global__ void trapezoid_f32_kernel(float *__restrict__ maps, long nmaps, int n
     maps[t] = taper_f32(maps[t], a / n2f, a % n2f, n2f, fade);
 }
 
+// coadd.py:1104-1107: np.maximum(map, 1e-32) after the Iterative kernel (NaN propagates, as in numpy)
+__global__ void clamp_min_f32_kernel(float *__restrict__ maps, long count, float lo)
+{
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const float v = maps[t];
+    if (v < lo) maps[t] = lo;
+}
+
 // coadd.py:1320-1354.  Workgroup = 64 output pixels x 4 row groups over the input pixels.
 //   acc layout in LDS: [n_expo + n_inframe][256]
 constexpr int EPI_MAXF = 4;  // input frames (layers) accumulated in registers
@@ -641,6 +650,13 @@ int launch_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int f
     if (tot <= 0 || fade <= 0) return IMCOM_OK;
     hipLaunchKernelGGL(trapezoid_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, maps, nmaps, n2f, fade);
     return check_launch("trapezoid_f32_kernel");
+}
+
+int launch_clamp_min_f32(imcom_ctx *ctx, float *maps, long count, float lo)
+{
+    if (count <= 0) return IMCOM_OK;
+    hipLaunchKernelGGL(clamp_min_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, maps, count, lo);
+    return check_launch("clamp_min_f32_kernel");
 }
 
 int launch_epilogue(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, int m, int ldm, int n2f, int fade, int n2, float *Tt,

@@ -46,6 +46,7 @@ int launch_lakernel1(imcom_ctx *ctx, const double *lam, const double *mPhalf, lo
                      double targetleak, double kCmin, double kCmax, int nbis, double *kappa, double *Sigma,
                      double *UC, double *T, long ldt, double smax);
 int launch_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fade);
+int launch_clamp_min_f32(imcom_ctx *ctx, float *maps, long count, float lo);
 int launch_epilogue(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, int m, int ldm, int n2f, int fade, int n2,
                     float *Tt, const float *indata, int n_inframe, const int *expo, int n_expo, float *outimage,
                     double *Tsum_image, double *Tsum_stamp, double *Tsum_inpix, double *Neff);

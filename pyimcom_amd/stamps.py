@@ -487,6 +487,9 @@ class StampBatch:
                                             _dp(self.A), _dp(Bt), _hp(Cs), _hp(self.kappaC), len(self.kappaC),
                                             float(cfg.uctarget), float(cfg.sigmamax), _dp(Tt), _dp(UC),
                                             _dp(Sigma), _dp(kappa), _hp(info)))
+        if cfg.kernel == "Iterative":  # coadd.py:1104-1107: "these could be negative as the iterative kernel is not exact"
+            for t in (UC, Sigma):
+                check(lib.imcom_clamp_min_f32(self.ctx.handle, _dp(t), t.numel(), 1e-32))
         if cfg.fade > 0:
             for t in (kappa, Sigma, UC):
                 check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))

@@ -1,7 +1,6 @@
 """Checker for the device-resident stamp path: runs a batch on the GPU and compares every output with
-the CPU oracle on the same inputs.  This is the ONLY module of the package that touches oracle/ -- it is
-the smoke test / parity harness (used by __graft_entry__.smoke() and tests/), not part of the product
-path."""
+the CPU oracle on the same inputs.  Test infrastructure (used by __graft_entry__.smoke() and tests/): it lives
+outside the product package, and nothing under pyimcom_amd/ imports it or oracle/."""
 
 import numpy as np
 
@@ -25,55 +24,25 @@ TOL_ITER = dict(TOL, T=2e-4, map_rtol=5e-3, map_atol=1e-3, image=5e-3)
 def oracle_tables(cfg, psfs, target):
     from oracle import oracle as orc
 
-    g = orc.Geom(cfg.npixpsf, cfg.oversamp, cfg.dtheta_as / 3600.0, cfg.flat_penalty)
-    r_in, r_out = orc.pad_and_rfft2(psfs, g), orc.pad_and_rfft2(target, g)
-    tri = orc.overlap_self(r_in, g)
-    cross = orc.overlap_cross(r_in, r_out, g)  # [E, n_out, ...] -> target-major stack
-    io = np.concatenate([cross[:, o] for o in range(cross.shape[1])])
-    C = orc.overlap_out_C(r_out, g)
-    tabs = np.concatenate([tri, io])
-    return g, np.pad(tabs, ((0, 0), (6, 6), (6, 6))), np.asarray(C, dtype=np.float64)
+    return orc.stamp_tables(cfg, psfs, target)
 
 
 def oracle_stamp(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab):
-    """Full oracle result for one stamp: A, Bt, T, maps, coaddition."""
+    """Full oracle result for one stamp: A, Bt, T, maps (incl. the Iterative clamp of coadd.py:1104-1107), coaddition."""
     from oracle import oracle as orc
 
-    A, Bt = orc.stamp_system(g, stamp.x, stamp.y, stamp.expo, tables_pad, pair_tab, pair_pen, io_tab, stamp.out_x0,
-                             stamp.out_y0, cfg.n2f)
-    mB = np.ascontiguousarray(Bt.T)
-    if cfg.kernel in ("Iterative", "Empirical"):
-        g1 = np.arange(cfg.n2f, dtype=np.float64)
-        oy, ox = np.repeat(stamp.out_y0 + g1, cfg.n2f), np.tile(stamp.out_x0 + g1, cfg.n2f)
-        if cfg.kernel == "Iterative":
-            T, UC, Sigma, kappa, info = orc.iter_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax, oy, ox,
-                                                        stamp.y, stamp.x, cfg.rho)
-        else:
-            T, UC, Sigma, kappa, info = orc.empir_kernel(A, mB, C, np.array(cfg.kappaC), oy, ox, stamp.y, stamp.x, cfg.rho)
-    else:
-        la = orc.eigen_kernel if cfg.kernel == "Eigen" else orc.chol_kernel
-        T, UC, Sigma, kappa, info = la(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
-    s = (cfg.n2f, cfg.n2f)
-    UC, Sigma, kappa = UC.reshape(s).copy(), Sigma.reshape(s).copy(), kappa.reshape(s).copy()
-    if cfg.fade > 0:  # coadd.py:1118-1122
-        for a in (kappa, Sigma, UC):
-            orc.trapezoid(a, cfg.fade)
-    T3 = T[None].copy()
-    outimage, Tsum_stamp, Tsum_inpix, Neff = orc.perform_coaddition(T3, stamp.indata, stamp.expo, stamp.n_expo, cfg.n2f,
-                                                                     cfg.n2, cfg.fade)
-    return dict(A=A, Bt=Bt, T=T3[0], UC=UC, Sigma=Sigma, kappa=kappa, outimage=outimage[0], Tsum_stamp=Tsum_stamp[0],
-                Tsum_inpix=Tsum_inpix[0], Neff=Neff[0], info=info)
+    return orc.stamp_full(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab)
 
 
-def check_batch(cfg, n_stamps=2, first_id=0, verbose=False, device="cuda:0", tolT_scale=1.0):
+def check_batch(cfg, n_stamps=2, first_id=0, verbose=False, device="cuda:0", tolT_scale=1.0, collect=()):
     """Run n_stamps synthetic stamps of cfg through the HIP path and assert parity with the oracle.  tolT_scale widens the
     bound on T alone: with five or more kappa nodes the nv x nv reduced systems of build_reduced_T (routine.py:546-588)
     are nearly singular and T = sum_p w_p T_p moves by ~1e-6 along their near-null directions from one summation order
     to the next, while kappa, Sigma and U/C stay put."""
     import torch
 
-    from . import synth
-    from .stamps import PSFGroupTables, StampBatch
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
 
     stamps = [synth.make_stamp(cfg, first_id + i) for i in range(n_stamps)]
     n_expo = max(s.n_expo for s in stamps)
@@ -130,11 +99,14 @@ def check_batch(cfg, n_stamps=2, first_id=0, verbose=False, device="cuda:0", tol
         if verbose:
             print(f"[smoke] {cfg.name} {key}:", report[key])
         assert ok, report[key]
+        for name in collect:  # raw maps for the caller's own accounting (e.g. kappa decision flips)
+            report[key][name + "_gpu"] = getattr(res, name)[b].cpu().numpy().ravel()
+            report[key][name + "_ref"] = np.asarray(ref[name]).ravel()
     return report
 
 
 def run(verbose=False):
-    from . import synth
+    from pyimcom_amd import synth
 
     rep = check_batch(synth.CONFIGS["tiny"], n_stamps=2, verbose=verbose)
     if verbose:

@@ -21,7 +21,8 @@ def test_block_end_to_end_vs_oracle(n_out):
     import torch
 
     from oracle import oracle as orc
-    from pyimcom_amd import smoke, synth
+    from pyimcom_amd import synth
+    from tests import parity as smoke
     from pyimcom_amd.blockrun import coadd_block, stamp_neighbours
     from pyimcom_amd.select import InStampPool
     from pyimcom_amd.stamps import PSFGroupTables
@@ -81,7 +82,8 @@ def test_block_with_psf_groups_vs_oracle(n_out):
     import torch
 
     from oracle import oracle as orc
-    from pyimcom_amd import smoke, synth
+    from pyimcom_amd import synth
+    from tests import parity as smoke
     from pyimcom_amd.blockrun import coadd_block, stamp_neighbours
     from pyimcom_amd.select import InStampPool
     from pyimcom_amd.stamps import BlockTables

@@ -290,3 +290,34 @@ def test_all_kernels_on_chain_system(golden, name):
         assert np.allclose(o.kappa, g[f"{tag}_kappa"], rtol=rt, atol=0), tag
         assert np.allclose(o.Sigma, g[f"{tag}_Sigma"], rtol=rt, atol=1e-9), tag
         assert np.allclose(o.UC, g[f"{tag}_UC"], rtol=rt, atol=2e-7), tag
+
+
+def test_iterative_clamp_golden(golden):
+    """imcom_clamp_min_f32 against the reference's own statement (coadd.py:1104-1107, make_golden_clamp.py), bit for
+    bit incl. NaN / inf / subnormals, and through the resident path: an Iterative batch never returns UC or Sigma
+    below float32(1e-32) while the un-clamped kernel output does go negative on the same stamps."""
+    import dataclasses
+
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd._lib import check, default_context, lib
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    g = golden("iter_clamp")
+    ctx = default_context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for name in ("UC", "Sigma"):
+        t = torch.as_tensor(g[f"{name}_in"], device="cuda:0").contiguous()
+        check(lib.imcom_clamp_min_f32(ctx.handle, C.c_void_p(t.data_ptr()), t.numel(), 1e-32))
+        assert np.array_equal(t.cpu().numpy(), g[f"{name}_Iterative"], equal_nan=True)
+    cfg = dataclasses.replace(synth.CONFIGS["tiny"], kernel="Iterative", name="tiny_iter")
+    stamps = [synth.make_stamp(cfg, 7 + i) for i in range(3)]
+    psfs, target = synth.make_psfs(cfg, max(s.n_expo for s in stamps))
+    sb = StampBatch(cfg, stamps, PSFGroupTables(psfs, target, cfg.nfft))
+    r = sb.run()
+    torch.cuda.synchronize()
+    lo = np.float32(1e-32)
+    for m in (r.UC, r.Sigma):
+        a = m.cpu().numpy()
+        assert np.nanmin(a) >= lo

@@ -44,7 +44,8 @@ def test_psf_overlap_golden(golden):
 
 @pytest.mark.parametrize("name,nst", [("tiny", 3), ("small", 2), ("smallm", 2)])
 def test_resident_path_vs_oracle(name, nst):
-    from pyimcom_amd import smoke, synth
+    from pyimcom_amd import synth
+    from tests import parity as smoke
 
     rep = smoke.check_batch(synth.CONFIGS[name], n_stamps=nst, verbose=True)
     assert rep["tables"] < smoke.TOL["tables"]
@@ -54,7 +55,8 @@ def test_resident_ragged_exposures():
     """Variable exposure depth per stamp (cfg-4 style): ragged N inside one batch."""
     import dataclasses
 
-    from pyimcom_amd import smoke, synth
+    from pyimcom_amd import synth
+    from tests import parity as smoke
 
     cfg = dataclasses.replace(synth.CONFIGS["small"], name="smallr", n_expo=(2, 5), fade=0)
     smoke.check_batch(cfg, n_stamps=4, first_id=40, verbose=True)
@@ -71,7 +73,8 @@ def test_resident_path_secondary_kernels(kernel):
     """The device-resident stamp path with the Iterative / Empirical LA kernels (lakernel.py:533-805) vs the oracle."""
     import dataclasses
 
-    from pyimcom_amd import smoke, synth
+    from pyimcom_amd import synth
+    from tests import parity as smoke
 
     cfg = dataclasses.replace(synth.CONFIGS["tiny"], kernel=kernel)
     if kernel == "Iterative":
@@ -87,7 +90,8 @@ def test_resident_path_many_input_layers():
     """n_inframe = 6 (science + noise / injected layers, coadd.py:975): the epilogue walks T once per four layers."""
     import dataclasses
 
-    from pyimcom_amd import smoke, synth
+    from pyimcom_amd import synth
+    from tests import parity as smoke
 
     cfg = dataclasses.replace(synth.CONFIGS["small"], n_inframe=6)
     smoke.check_batch(cfg, n_stamps=2)
@@ -101,7 +105,8 @@ def test_two_target_psfs_vs_oracle():
 
     import torch
 
-    from pyimcom_amd import smoke, synth
+    from pyimcom_amd import synth
+    from tests import parity as smoke
     from pyimcom_amd.stamps import PSFGroupTables, StampBatch
 
     cfg = dataclasses.replace(synth.CONFIGS["tiny"], name="tiny2", n_out=2, fade=1)
@@ -172,7 +177,7 @@ def test_alternative_code_paths_in_subprocess():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, IMCOM_SOLVE_UNFUSED="1", IMCOM_PSF_OVERLAP="gemm", IMCOM_EIGH="jacobi", PYTHONPATH=root)
-    code = ("import dataclasses; from pyimcom_amd import smoke, synth; "
+    code = ("import dataclasses; from pyimcom_amd import synth; from tests import parity as smoke; "
             "smoke.check_batch(synth.CONFIGS['small'], 2); "
             "smoke.check_batch(dataclasses.replace(synth.CONFIGS['tiny'], kernel='Eigen'), 2); print('alt paths ok')")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
@@ -193,6 +198,7 @@ def test_unusual_configurations(name, kw, scale):
     empirical kernel, nine exposures."""
     import dataclasses
 
-    from pyimcom_amd import smoke, synth
+    from pyimcom_amd import synth
+    from tests import parity as smoke
 
     smoke.check_batch(dataclasses.replace(synth.CONFIGS["tiny"], name=name, **kw), n_stamps=3, tolT_scale=scale)

@@ -395,3 +395,14 @@ def test_chain_other_kernels_golden(golden, name):
         assert np.allclose(kp, g[f"{tag}_kappa"][0].ravel(), rtol=rt, atol=0), tag
         assert np.allclose(Sg, g[f"{tag}_Sigma"][0].ravel(), rtol=rt, atol=1e-9), tag
         assert np.allclose(UC, g[f"{tag}_UC"][0].ravel(), rtol=rt, atol=2e-7), tag
+
+
+def test_iterative_clamp_golden(golden):
+    """coadd.py:1104-1107 executed by the reference (make_golden_clamp.py): negatives, zeros, sub-1e-32 values and
+    subnormals rise to float32(1e-32), NaN and +inf stay, dtype float32; other kernels leave the maps alone."""
+    g = golden("iter_clamp")
+    UC, Sigma = orc.iterative_clamp(g["UC_in"], g["Sigma_in"])
+    assert UC.dtype == g["UC_Iterative"].dtype == np.float32
+    assert np.array_equal(UC, g["UC_Iterative"], equal_nan=True) and np.array_equal(Sigma, g["Sigma_Iterative"], equal_nan=True)
+    assert np.array_equal(g["UC_Cholesky"], g["UC_in"], equal_nan=True)
+    assert np.nanmin(UC) == np.float32(1e-32) and np.isnan(UC).sum() == np.isnan(g["UC_in"]).sum()

@@ -3,7 +3,8 @@ import dataclasses
 import sys
 
 sys.path.insert(0, ".")
-from pyimcom_amd import smoke, synth  # noqa: E402
+from pyimcom_amd import synth  # noqa: E402
+from tests import parity as smoke  # noqa: E402
 
 base = synth.CONFIGS["tiny"]
 variants = {
