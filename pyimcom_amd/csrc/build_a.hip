@@ -9,6 +9,8 @@
 // stamp's side and transposed it, psfutil.py:1990-1996); bit 30 FLIP (np.flip'ed table, 1658-1665).
 //
 // This is gather-bound work (100 table reads per sample, 2.4 M samples per cfg-2 stamp), no MFMA.
+#include <cstdlib>
+
 #include "common.h"
 #include "d5512.h"
 #include "launchers.h"
@@ -72,10 +74,16 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     tile_index(t, ntile, ti, tj);
     const int ns = n[s];
     const int nfull = (ns + NB - 1) / NB * NB;  // rows/cols the factorisation will ever read
-    if (ti * 16 >= nfull || tj * 16 >= nfull) return;
     const int li = tid >> 4, lj = tid & 15;
     const int i = ti * 16 + li, j = tj * 16 + lj;
     double *As = A + (long)s * ldn * ldn;
+    if (ti * 16 >= nfull || tj * 16 >= nfull) {
+        // beyond this stamp's pixels (a shorter stamp of a ragged batch): identity out to ldn, as imcom_build_A promises
+        if (i < ldn && j < ldn) As[(long)i * ldn + j] = (i == j) ? 1.0 : 0.0;
+        const int mi = tj * 16 + li, mj = ti * 16 + lj;
+        if (ti != tj && mi < ldn && mj < ldn) As[(long)mi * ldn + mj] = 0.0;
+        return;
+    }
     const long base = (long)s * ldn;
     double wx[10], wy[10];
 #pragma unroll
@@ -228,10 +236,18 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     }
 }
 
+int launch_build_A_win(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y, const int *psf,
+                       const double *tables, int ntab, int ng, double nc, double dscale, const int *pair_tab, const double *pair_pen,
+                       int npsf_max, double *A);  // build_a_win.hip
+
 int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
                    const int *psf, const double *tables, int ntab, int ng, double nc, double dscale,
                    const int *pair_tab, const double *pair_pen, int npsf_max, double *A)
 {
+    // IMCOM_BUILD_A=window selects the experimental LDS-window builder (build_a_win.hip: parity-tested, but slower than
+    // this file's per-sample DMA builder on rotated exposures -- DESIGN.md, "A builder, round 2")
+    static const bool window = getenv("IMCOM_BUILD_A") && !strcmp(getenv("IMCOM_BUILD_A"), "window");
+    if (window) return launch_build_A_win(ctx, batch, n_dev, ldn, x, y, psf, tables, ntab, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A);
     IMCOM_REQUIRE((long)ntab * ng * ng < (1L << 31), "table stack too large (%d tables of %d^2)", ntab, ng);
     const int nt = (ldn + 15) / 16;
     const long ntri = (long)nt * (nt + 1) / 2;

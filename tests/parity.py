@@ -69,9 +69,8 @@ def check_batch(cfg, n_stamps=2, first_id=0, verbose=False, device="cuda:0", tol
         eA = np.abs(A - ref["A"]).max() / np.abs(ref["A"]).max()
         eB = np.abs(Bt - ref["Bt"]).max() / np.abs(ref["Bt"]).max()
         assert np.array_equal(A, A.T), "A must be exactly symmetric"
-        nfull = (n + 127) // 128 * 128  # the factorisation reads whole 128-blocks: identity padding up to there
-        pad = batch.A[b, n:nfull, :nfull].cpu().numpy()
-        assert np.array_equal(pad, np.eye(nfull)[n:]), "identity padding"
+        pad = batch.A[b, n:, :].cpu().numpy()  # rows beyond the stamp's pixels: identity out to ldn (imcom_build_A's contract)
+        assert np.array_equal(pad, np.eye(batch.ldn)[n:]) and np.array_equal(batch.A[b, :n, n:].cpu().numpy(), np.zeros((n, batch.ldn - n))), "identity padding"
         T = res.T(b).cpu().numpy()
         eT = np.abs(T - ref["T"]).max() / np.abs(ref["T"]).max()
         # forward error of a backward-stable solve ~ cond * eps: allow for it on top of the float32 rounding

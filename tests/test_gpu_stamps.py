@@ -169,14 +169,15 @@ def test_empty_stamp_in_resident_batch():
 
 def test_alternative_code_paths_in_subprocess():
     """The switches kept for A/B runs and as cross-checks must not rot: the unfused diagonal-block launches
-    (IMCOM_SOLVE_UNFUSED), the dense-DFT table path (IMCOM_PSF_OVERLAP=gemm) and the Jacobi eigensolver (IMCOM_EIGH=jacobi)
-    are read once per process, so the parity check runs in a child process with all three set."""
+    (IMCOM_SOLVE_UNFUSED), the dense-DFT table path (IMCOM_PSF_OVERLAP=gemm), the Jacobi eigensolver (IMCOM_EIGH=jacobi) and the
+    experimental LDS-window A builder (IMCOM_BUILD_A=window)
+    are read once per process, so the parity check runs in a child process with all of them set."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, IMCOM_SOLVE_UNFUSED="1", IMCOM_PSF_OVERLAP="gemm", IMCOM_EIGH="jacobi", PYTHONPATH=root)
+    env = dict(os.environ, IMCOM_SOLVE_UNFUSED="1", IMCOM_PSF_OVERLAP="gemm", IMCOM_EIGH="jacobi", IMCOM_BUILD_A="window", PYTHONPATH=root)
     code = ("import dataclasses; from pyimcom_amd import synth; from tests import parity as smoke; "
             "smoke.check_batch(synth.CONFIGS['small'], 2); "
             "smoke.check_batch(dataclasses.replace(synth.CONFIGS['tiny'], kernel='Eigen'), 2); print('alt paths ok')")
