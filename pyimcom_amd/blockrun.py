@@ -79,14 +79,16 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
 
 
 
-def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_pad=0, ldn=None, pipeline=True):
+def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None):
     """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
-    order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables.  Returns the BlockMaps."""
+    order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables or BlockTables.  ``stamps``: the (j_st, i_st) to
+    coadd (default all n1P x n1P, row by row as coadd.py:2049-2052); ``pad_sides=None`` leaves the boundary recovery of
+    coadd.py:2163-2181 out.  Returns the BlockMaps."""
     nst = n1P + 2
     assert pool.n_inst == nst * nst
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
                      n_out=int(getattr(tables, "n_out", 1)))
-    todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)] if stamps is None else [(int(j), int(i)) for j, i in stamps]
     prepare = lambda chunk: prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn)  # noqa: E731
 
     # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after
@@ -104,5 +106,6 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_
         if not pipeline:
             nxt = prepare(chunks[k + 1]) if k + 1 < len(chunks) else None
         maps.add(sb.results(), [j for j, _ in chunk], [i for _, i in chunk])
-    maps.finalize(pad_sides, postage_pad)
+    if pad_sides is not None:
+        maps.finalize(pad_sides, postage_pad)
     return maps

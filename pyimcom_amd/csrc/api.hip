@@ -330,6 +330,7 @@ int imcom_ctx_destroy(imcom_ctx *ctx)
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->pin) hipHostFree(ctx->pin);
     for (auto e : ctx->sync_events) hipEventDestroy(e);
+    if (ctx->stream_event) hipEventDestroy(ctx->stream_event);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -339,7 +340,15 @@ int imcom_ctx_destroy(imcom_ctx *ctx)
 int imcom_ctx_set_stream(imcom_ctx *ctx, void *hip_stream)
 {
     IMCOM_TRY(check_ctx(ctx));
-    ctx->stream = (hipStream_t)hip_stream;  // NULL = the legacy default stream, which is what torch's default is
+    hipStream_t next = (hipStream_t)hip_stream;  // NULL = the legacy default stream, which is what torch's default is
+    if (next != ctx->stream) {
+        // work queued on the old stream may still be using the context's bump workspace, which the next call on the new
+        // stream hands out again from offset 0: order the new stream behind it
+        if (!ctx->stream_event) IMCOM_HIP_CHECK(hipEventCreateWithFlags(&ctx->stream_event, hipEventDisableTiming));
+        IMCOM_HIP_CHECK(hipEventRecord(ctx->stream_event, ctx->stream));
+        IMCOM_HIP_CHECK(hipStreamWaitEvent(next, ctx->stream_event, 0));
+        ctx->stream = next;
+    }
     return IMCOM_OK;
 }
 

@@ -62,6 +62,7 @@ struct imcom_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // second queue for work that overlaps the main stream (eigensolver rotations)
     std::vector<hipEvent_t> sync_events;  // plain (no timing) events for cross-stream ordering
+    hipEvent_t stream_event = nullptr;    // orders a newly bound stream behind the previous one (imcom_ctx_set_stream)
     // bump-allocated device workspace; reset at the start of every API call that uses it
     char *ws = nullptr;
     size_t ws_bytes = 0;

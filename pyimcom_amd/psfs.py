@@ -31,10 +31,20 @@ def _p(a):
     return C.c_void_p(a.data_ptr()) if _is_torch(a) else a.ctypes.data_as(C.c_void_p)
 
 
+def _bind(ctx, device):
+    """Device-mode calls enqueue on the context's stream and return without a sync: that stream must be torch's current
+    one, or torch could consume the output tensor before the kernel has written it."""
+    if device is not None:
+        import torch
+
+        ctx.set_stream(torch.cuda.current_stream(torch.device(device)).cuda_stream)
+
+
 def psf_gaussian(n, sigmax, sigmay, device=None, ctx=None):
     """``OutPSF.psf_gaussian`` (psfutil.py:117-146); ``device`` given -> torch tensor on that device."""
     ctx = ctx or default_context()
     out = _out((n, n), "torch" if device else "numpy", device)
+    _bind(ctx, device)
     check(lib.imcom_psf_gaussian(ctx.handle, int(n), float(sigmax), float(sigmay), _p(out), MEM_DEVICE if device else MEM_HOST))
     return out
 
@@ -43,6 +53,7 @@ def psf_simple_airy(n, ldp, obsc=0.0, tophat_conv=0.0, sigma=0.0, device=None, c
     """``OutPSF.psf_simple_airy`` (psfutil.py:148-223)."""
     ctx = ctx or default_context()
     out = _out((n, n), "torch" if device else "numpy", device)
+    _bind(ctx, device)
     check(lib.imcom_psf_simple_airy(ctx.handle, int(n), float(ldp), float(obsc), float(tophat_conv), float(sigma), _p(out),
                                     MEM_DEVICE if device else MEM_HOST))
     return out

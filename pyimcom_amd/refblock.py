@@ -1,0 +1,145 @@
+"""Block seam: ``Block.coadd_output_stamps`` of the reference on the GPU, taking the reference's own containers.
+
+    from pyimcom_amd.refblock import coadd_output_stamps
+    coadd_output_stamps(blk, PSFGrp)      # instead of the stamp loop of coadd.py:2003-2084
+
+``blk`` is a (duck-typed) ``pyimcom.coadd.Block`` after its constructor has parsed the configuration, loaded the input
+images and partitioned their pixels (coadd.py:1560-1937); what is read from it:
+
+    blk.cfg            n1P, n2, fade_kernel, n_inframe, dtheta [deg], instamp_pad [rad], linear_algebra, kappaC_arr,
+                       uctarget, sigmamax, psf_circ, psf_norm, amp_penalty, outpsf, sigmatarget, use_filter,
+                       outpsf_extra / sigmatarget_extra, postage_pad, iter_rtol / iter_max (Iterative), psfsplit, psf_interp
+    blk.instamps[j][i] x_val, y_val, data, pix_count, pix_cumsum; psf_compute_point_pix on the even-even ones (coadd.py:682-714)
+    blk.inimages[e]    get_psf_pos(world, use_shortrange=True), outpix2world2inpix(xy)   (coadd.py:531-640)
+    blk.outwcs         all_pix2world(xy, 0);   blk.n_inimage;   blk.pad_sides
+    PSFGrp             the reference's class after PSFGrp.setup(): nsamp, oversamp, dscale, nfft, npixpsf (psfutil.py:568-613);
+    flat_penalty       PSFOvl.flat_penalty (psfutil.py:1065-1089)
+
+What is written is what the reference's loop leaves behind (coadd.py:1939-2001, 2163-2181): ``blk.out_map`` f32
+[n_out, n_inframe, Ns, Ns], ``blk.UC_map / Sigma_map / kappa_map / Tsum_map / Neff_map`` f32 [n_out, Ns, Ns] and
+``blk.T_weightmap`` f32 [n_out, n_inimage, n1P, n1P], boundary recovery included.  The host keeps what only it can do -- the
+PSF file broker and the WCS evaluation of the PSF sampling positions -- everything else (PSF sampling, overlap tables per
+2x2 group of InStamps, pixel selection, A, B, the LA kernel, coaddition, block accumulation) runs in libimcom_hip.
+
+Configurations this build cannot serve raise ``ImcomError`` with status IMCOM_ERR_UNSUPPORTED instead of silently taking
+another path: PSFINTERP "G4460" (the 8x8 interpolator of furry_parakeet: no source and no numerical test in the reference,
+SURVEY 8c) and PSF splitting (``psfsplit``, psfutil.py:594-606 -- a different table pipeline).
+"""
+
+import numpy as np
+
+from ._lib import ImcomError
+from .synth import WorkloadConfig  # the plain configuration record of the stamp seam (nothing synthetic about it)
+
+IMCOM_ERR_UNSUPPORTED = -4
+ARCSEC = np.pi / 180.0 / 3600.0  # pyimcom.config.Settings.arcsec (config.py:85-98)
+
+
+def check_supported(cfg):
+    """Raise IMCOM_ERR_UNSUPPORTED for the reference configurations that have no device path."""
+    interp = str(getattr(cfg, "psf_interp", "D5512") or "D5512").upper()
+    if interp != "D5512":
+        raise ImcomError(IMCOM_ERR_UNSUPPORTED, f"PSFINTERP = {interp!r}: only the D5512 (10x10) interpolator is built "
+                         "(iG4460C has no in-tree source or numerical test to pin it against, coadd.py:1599-1601)")
+    if getattr(cfg, "psfsplit", None):
+        raise ImcomError(IMCOM_ERR_UNSUPPORTED, "PSFSPLIT is set: the split-PSF table pipeline (psfutil.py:594-606, 1178-1242) is not built")
+    kernel = getattr(cfg, "linear_algebra", "Cholesky")
+    if kernel not in ("Cholesky", "Eigen", "Iterative", "Empirical"):
+        raise ImcomError(IMCOM_ERR_UNSUPPORTED, f"LAKERNEL = {kernel!r}")
+    if kernel == "Empirical" and getattr(cfg, "no_qlt_ctrl", False):
+        raise ImcomError(IMCOM_ERR_UNSUPPORTED, "Empirical kernel without quality control on the block seam "
+                         "(use the kernel-class seam, pyimcom_amd.lakernel.HipEmpirKernel)")
+
+
+def stamp_config(cfg, psfgrp, n_inimage, flat_penalty, name="block"):
+    """The stamp-seam configuration record of a reference Config."""
+    targets = 1 + len(getattr(cfg, "outpsf_extra", []) or [])
+    return WorkloadConfig(name, int(cfg.n2), int(cfg.fade_kernel), float(cfg.dtheta) * 3600.0, int(n_inimage),
+                          float(cfg.instamp_pad) / ARCSEC, str(cfg.linear_algebra), tuple(float(k) for k in np.atleast_1d(cfg.kappaC_arr)),
+                          npixpsf=int(psfgrp.npixpsf), oversamp=int(psfgrp.oversamp), uctarget=float(cfg.uctarget),
+                          sigmamax=float(cfg.sigmamax), flat_penalty=float(flat_penalty), n_inframe=int(cfg.n_inframe), n_out=targets)
+
+
+def input_psf_groups(blk, psfgrp, device):
+    """PSFGrp._build_inpsfgrp for every 2x2 group of InStamps (psfutil.py:797-851): the exposures with pixels in the group,
+    their PSF images at the group's computation point (host: file broker, WCS), sampled on the device."""
+    import torch
+
+    from . import psfs
+
+    ns = int(psfgrp.nsamp)
+    nst = int(blk.cfg.n1P) + 2
+    lin = np.arange(ns) - (ns - 1) / 2.0
+    gx, gy = np.meshgrid(lin, lin)
+    xy = np.stack([gx.ravel(), gy.ravel()], axis=1) * float(psfgrp.dscale)  # psfutil.py:751-771
+    group_psfs, group_expo = {}, {}
+    for gj in range(nst // 2):
+        for gi in range(nst // 2):
+            used = np.zeros(int(blk.n_inimage), bool)
+            for dj in (0, 1):
+                for di in (0, 1):
+                    st = blk.instamps[2 * gj + dj][2 * gi + di]
+                    cnt = getattr(st, "pix_count", None)
+                    used |= (np.diff(st.pix_cumsum) if cnt is None else np.asarray(cnt)).astype(bool)
+            expos = [int(e) for e in np.flatnonzero(used)]
+            if not expos:
+                continue
+            p0 = np.array(blk.instamps[2 * gj][2 * gi].psf_compute_point_pix, dtype=np.float64)
+            world = blk.outwcs.all_pix2world(np.array([p0]), 0)[0]
+            imgs, yxco = [], []
+            for e in expos:
+                im = blk.inimages[e]
+                imgs.append(np.asarray(im.get_psf_pos(world, use_shortrange=True), dtype=np.float64))
+                d = (np.asarray(im.outpix2world2inpix(xy + p0)) - np.asarray(im.outpix2world2inpix(p0[None]))) * float(psfgrp.oversamp)
+                yxco.append(np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)]))
+            group_psfs[(gj, gi)] = psfs.sample_psf(torch.as_tensor(np.stack(imgs), device=device), ns,
+                                                   torch.as_tensor(np.stack(yxco), device=device), bool(blk.cfg.psf_circ),
+                                                   bool(blk.cfg.psf_norm)).cpu().numpy()
+            group_expo[(gj, gi)] = expos
+    return group_psfs, group_expo
+
+
+def target_psfs(cfg, psfgrp, device):
+    """The output PSF group (psfutil.py:898-929): OUTPSF plus the cfg.outpsf_extra entries."""
+    import torch
+
+    from . import psfs
+
+    ns = int(psfgrp.nsamp)
+    specs = [(cfg.outpsf, cfg.sigmatarget)] + list(zip(getattr(cfg, "outpsf_extra", []) or [], getattr(cfg, "sigmatarget_extra", []) or []))
+    imgs = torch.stack([psfs.get_outpsf(o, s, cfg.use_filter, ns, int(psfgrp.oversamp), device=device) for o, s in specs])
+    return psfs.sample_psf(imgs, ns, None, bool(cfg.psf_circ), bool(cfg.psf_norm))
+
+
+def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=128, device="cuda:0", stamps=None, finalize=True, table_capacity=None):
+    """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  ``stamps``: optional list of
+    (j_st, i_st) to coadd instead of all n1P x n1P (the reference's ``stoptile`` debugging aid stops early in the same
+    way); ``finalize=False`` skips the boundary recovery of coadd.py:2163-2181.  Returns the ``BlockMaps``."""
+    from .blockrun import coadd_block
+    from .select import InStampPool
+    from .stamps import BlockTables
+
+    cfg = blk.cfg
+    check_supported(cfg)
+    if flat_penalty is None:
+        flat_penalty = getattr(cfg, "flat_penalty", 0.0)
+    scfg = stamp_config(cfg, psfgrp, blk.n_inimage, flat_penalty)
+    for k in ("iter_rtol", "iter_max"):
+        if hasattr(cfg, k):
+            setattr(scfg, k, getattr(cfg, k))
+    pool = InStampPool([(st.x_val, st.y_val, st.data, st.pix_cumsum) for row in blk.instamps for st in row], scfg.n_inframe, device=device)
+    group_psfs, group_expo = input_psf_groups(blk, psfgrp, device)
+    target = target_psfs(cfg, psfgrp, device).cpu().numpy()
+    amp = getattr(cfg, "amp_penalty", None)
+    amp = None if amp is None or 0.0 in tuple(amp) else (float(amp[0]), float(amp[1]) * float(psfgrp.oversamp))  # psfutil.py:661-671
+    n_max = max(v.shape[0] for v in group_psfs.values())
+    if table_capacity is None:  # the sets one batch of stamps can touch, with room to keep neighbouring groups resident
+        per_group = n_max * (n_max + 1) // 2 + target.shape[0] * n_max + 4 * n_max * n_max
+        table_capacity = min(max(4 * per_group * max(1, batch // 4), 256), (2**31 - 1) // ((int(psfgrp.nsamp) + 12) ** 2))
+    tables = BlockTables(group_psfs, target, int(psfgrp.nfft), group_expo=group_expo, capacity=int(table_capacity), amp_penalty=amp, device=device)
+    maps = coadd_block(scfg, pool, tables, int(cfg.n1P), int(blk.n_inimage), batch=batch, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
+                       postage_pad=int(getattr(cfg, "postage_pad", 0)), stamps=stamps)
+    blk.out_map, blk.T_weightmap = maps.out_map.cpu().numpy(), maps.T_weightmap.cpu().numpy()
+    blk.UC_map, blk.Sigma_map, blk.kappa_map = (maps.maps[k].cpu().numpy() for k in ("UC", "Sigma", "kappa"))
+    blk.Tsum_map, blk.Neff_map = maps.maps["Tsum"].cpu().numpy(), maps.maps["Neff"].cpu().numpy()
+    return maps

@@ -22,43 +22,85 @@ def test_partition_properties():
     assert farm.estimate_cost(2200, 2304) > farm.estimate_cost(1900, 1024)
 
 
-def _worker(rank, world, port, out):
+class _FakeMaps:
+    """What coadd_block returns, as far as farm.write_block reads it."""
+
+    def __init__(self, spec):
+        import torch
+
+        v = float(spec["pool"].sum())  # stands for the coaddition: a function of the block's inputs alone
+        self.out_map = torch.full((1, 2, 4, 4), v)
+        self.T_weightmap = torch.full((1, spec["n_expo"], 2, 2), v)
+        self.maps = {k: torch.full((1, 4, 4), v + i) for i, k in enumerate(("UC", "Sigma", "kappa", "Tsum", "Neff"))}
+
+
+def _host_mosaic():
+    """A 4x4 mosaic with variable depth whose 'blocks' are plain arrays: the driver's logic without a GPU."""
+    rng = np.random.default_rng(5)
+    depth = rng.integers(6, 11, 16)
+    costs = [farm.estimate_cost(350.0 * e, 2304) for e in depth]
+    made = []
+
+    def make_block(b):
+        made.append(b)
+        return dict(cfg=None, pool=np.random.default_rng(b).standard_normal(100), tables=None, n1P=2, n_expo=int(depth[b]), meta=dict(block=b))
+
+    return list(range(16)), costs, make_block, made
+
+
+def _fake_coadd(cfg, pool, tables, n1P, n_expo, batch, pad_sides, postage_pad):
+    return _FakeMaps(dict(pool=pool, n_expo=n_expo))
+
+
+def _worker(rank, world, port, outdir, out):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pyimcom_amd import synth
-
-    cfg = synth.CONFIGS["cfg4"]
-    # 16 blocks of one stamp each (synthetic): cost from the stamp's pixel count
-    stamps = [synth.make_stamp(cfg, b) for b in range(16)]
-    costs = [farm.estimate_cost(s.n, cfg.m) for s in stamps]
-    mine = farm.my_units(costs, rank, world)
+    blocks, costs, make_block, made = _host_mosaic()
     dist.barrier()
-    # "coadd" = a per-block checksum of the inputs; nothing is exchanged while working
-    res = {b: float(stamps[b].x.sum() + stamps[b].y.sum()) for b in mine}
+    # blocks -> this rank's share -> "coadd" -> one file per block; nothing is exchanged while working
+    done = farm.run(blocks, costs, make_block, outdir, rank, world, coadd=_fake_coadd, log=lambda *a: None)
     dist.barrier()
     gathered = [None] * world
-    dist.all_gather_object(gathered, res)
+    dist.all_gather_object(gathered, (done, made))
     if rank == 0:
         out.put(gathered)
     dist.destroy_process_group()
 
 
-def test_gloo_world2_cover():
+def test_gloo_world2_farm_driver(tmp_path):
+    """world_size 2 over gloo: the two ranks run farm.run on the same block list and write disjoint sets of block files
+    that together cover the mosaic; every file holds what a single process writes for that block; a second run skips
+    what exists (the restart rule of multiblock_norep.pl:25-27) and recomputes only a deleted block."""
     import torch.multiprocessing as mp
 
+    outdir = str(tmp_path / "farm")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 500)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, outdir, q)) for r in range(2)]
     for p in procs:
         p.start()
     gathered = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    keys = sorted(k for g in gathered for k in g)
-    assert keys == list(range(16)) and len(gathered[0]) + len(gathered[1]) == 16
-    assert not set(gathered[0]) & set(gathered[1])
+    (done0, made0), (done1, made1) = gathered
+    assert sorted(done0 + done1) == list(range(16)) and not set(done0) & set(done1)
+    assert made0 == done0 and made1 == done1  # a rank builds only the blocks it owns
+    # single process, same driver
+    blocks, costs, make_block, made = _host_mosaic()
+    single = str(tmp_path / "single")
+    assert farm.run(blocks, costs, make_block, single, coadd=_fake_coadd, log=lambda *a: None) == sorted(blocks, key=lambda b: blocks.index(b))
+    for b in blocks:
+        a, c = np.load(farm.block_path(outdir, b)), np.load(farm.block_path(single, b))
+        assert sorted(a.files) == sorted(c.files) and all(np.array_equal(a[k], c[k]) for k in a.files)
+        assert int(a["meta_block"]) == b
+    # restart: nothing to do; after deleting one file only that block is redone
+    made.clear()
+    assert farm.run(blocks, costs, make_block, single, coadd=_fake_coadd, log=lambda *a: None) == [] and made == []
+    os.remove(farm.block_path(single, 7))
+    assert farm.run(blocks, costs, make_block, single, coadd=_fake_coadd, log=lambda *a: None) == [7] and made == [7]
+    assert not [f for f in os.listdir(single) if ".tmp" in f]

@@ -1,0 +1,51 @@
+"""Block farming on the device (BASELINE configs[3]): `python -m pyimcom_amd.farm` as two processes sharing
+cuda:0 (the one-GPU rehearsal of one process per GPU) against a single process, bit for bit; restart behaviour."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _farm(out, rank, world, extra=()):
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "pyimcom_amd.farm", "--out", out, "--config", "smallm", "--mosaic", "2", "--n1P", "2", "--batch", "3",
+           "--shared-gpu", *extra]
+    return subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def test_farm_two_processes_equal_one(tmp_path):
+    from pyimcom_amd import farm
+
+    two, one = str(tmp_path / "two"), str(tmp_path / "one")
+    procs = [_farm(two, r, 2) for r in range(2)]  # concurrently, on the same GPU
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    p1 = _farm(one, 0, 1)
+    o1 = p1.communicate(timeout=600)[0]
+    assert p1.returncode == 0, o1
+    blocks, costs, _ = farm.synthetic_mosaic("smallm", 2, 2)
+    parts = farm.partition(costs, 2)
+    assert sorted(parts[0] + parts[1]) == blocks and all(f"done: {sorted(parts[r])}" in outs[r] for r in range(2)), outs
+    for b in blocks:
+        a, c = np.load(farm.block_path(two, b)), np.load(farm.block_path(one, b))
+        assert sorted(a.files) == sorted(c.files)
+        for k in a.files:
+            assert np.array_equal(a[k], c[k]), (b, k)  # same kernels, same batches: identical bits
+        assert np.isfinite(a["out_map"]).all() and np.abs(a["out_map"]).max() > 0 and a["UC"].shape[-1] == 2 * 12
+    # restart: every block is skipped; a deleted block alone is redone and comes out identical
+    keep = np.load(farm.block_path(one, 2))["out_map"].copy()
+    p = _farm(one, 0, 1)
+    o = p.communicate(timeout=600)[0]
+    assert p.returncode == 0 and o.count("skipped") == 4 and "done: []" in o, o
+    os.remove(farm.block_path(one, 2))
+    p = _farm(one, 0, 1)
+    o = p.communicate(timeout=600)[0]
+    assert p.returncode == 0 and o.count("skipped") == 3 and "done: [2]" in o, o
+    assert np.array_equal(np.load(farm.block_path(one, 2))["out_map"], keep)
