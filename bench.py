@@ -25,14 +25,20 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (spec); 77.2 measu
 
 
 def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded
-    sample of the same workload: whole stamps (A/B build in single-thread C, LAPACK potrf/potrs with
-    the default BLAS threading, coaddition), as many as fit in ~budget_s."""
+    """The oracle (CPU restatement of the reference path, oracle/) timed on this box's host cores on a bounded sample of
+    the same workload: whole stamps -- A and B build (C interpolators, OpenMP over the samples), LAPACK potrf / potrs (numpy
+    / scipy BLAS threads), maps, coaddition -- first on all cores, then on ONE thread (threadpoolctl + orc.set_threads),
+    each for about half the budget, with the split build / solve / epilogue that SURVEY 8(d) asks for."""
     import numpy as np
 
-    from pyimcom_amd import smoke
+    from oracle import oracle as orc
 
-    g, tabs, C = smoke.oracle_tables(cfg, psfs, target)
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:  # pragma: no cover
+        threadpool_limits = None
+
+    g, tabs, C = orc.stamp_tables(cfg, psfs, target)
     C = float(C[0])  # one target PSF
     E = psfs.shape[0]
     tri = lambda i, j: (2 * E - i + 1) * i // 2 + j - i
@@ -43,40 +49,57 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
             tab[a, b] = tri(a, b) if a <= b else (tri(b, a) | (1 << 30))
             pen[a, b] = -cfg.flat_penalty / E + (cfg.flat_penalty if a == b else 0.0)
     io = np.arange(E) + E * (E + 1) // 2
-    t0 = time.perf_counter()
-    done = 0
-    for st in stamps:
-        smoke.oracle_stamp(cfg, g, tabs, C, st, tab, pen, io)
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {
+
+    def sample(budget, nthreads):
+        orc.set_threads(nthreads)
+        stages, done = {}, 0
+        t0 = time.perf_counter()
+        for st in stamps:
+            orc.stamp_full(cfg, g, tabs, C, st, tab, pen, io, timings=stages)
+            done += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        dt = time.perf_counter() - t0
+        return done, dt, {k: v / done * 1e3 for k, v in stages.items()}
+
+    cores = os.cpu_count()
+    done, dt, stages = sample(budget_s * 0.5, 0)
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            done1, dt1, stages1 = sample(budget_s * 0.5, 1)
+    else:
+        done1, dt1, stages1 = 0, 0.0, {}
+    orc.set_threads(0)
+    out = {
         "value": done / dt,
         "unit": "postage-stamps/s",
-        "cores": os.cpu_count(),
+        "cores": cores,
         "kind": "port",
-        "sample": f"{done} whole {cfg.name} stamps (N~{stamps[0].n}, m={cfg.m}) through oracle/: A,B build single-thread C, "
-                  f"scipy potrf/potrs with default BLAS threads ({os.cpu_count()} cores), coaddition; {dt:.1f} s",
+        "sample": f"{done} whole {cfg.name} stamps (N~{stamps[0].n}, m={cfg.m}) through oracle/ on {cores} cores ({dt:.1f} s): C interpolators "
+                  f"with OpenMP, scipy potrf/potrs; then {done1} stamps on 1 thread ({dt1:.1f} s)",
+        "stage_ms_per_stamp": stages,
     }
+    if done1:
+        out["one_thread"] = {"value": done1 / dt1, "unit": "postage-stamps/s", "cores": 1, "stage_ms_per_stamp": stages1}
+    return out
 
 
 def pmc_traffic(batch, cfg_name):
-    """HBM bytes per launch of the solve kernels from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of this very command, corrected as MI355X_MICROARCH.md prescribes for gfx950; see
-    pyimcom_amd/csrc/tools/pmc_traffic.py).  Counters cannot be read from inside the process, so the figure is only
-    reported when the committed measurement was taken on the same workload and batch; otherwise null."""
+    """HBM bytes per launch of the solve kernels from the newest committed rocprofv3 --pmc passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this very command, corrected as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.py).
+    Counters cannot be read from inside the process: the figure is reported with the file it came from, and only when
+    that measurement was taken on the same workload and batch; otherwise null."""
     import glob
 
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     doc = json.load(open(files[-1]))
     if doc.get("batch") != batch or doc.get("workload") != cfg_name:
-        return None
+        return None, None
     ks = [doc["kernels"][k] for k in ("solve_fwd_kernel", "solve_bwd_kernel") if k in doc["kernels"]]
     n = sum(k["launches"] for k in ks)
-    return sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None
+    return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
 
 
 def main():
@@ -163,6 +186,7 @@ def main():
         fused = fams["solve_dinv"][1] == 0
         solve_flops_step = float((2.0 * cfg.m * (n_arr**2 - (0.0 if fused else 1.0) * rows_sq)).sum())
         ms, launches = fams["solve_gemm"]
+        traffic, traffic_src = pmc_traffic(args.batch, cfg.name)
         achieved = solve_flops_step * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out = {
             "metric": "postage-stamps/sec (and ms/stamp) for N~2k A-solve",
@@ -193,7 +217,8 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic(args.batch, cfg.name),
+                "traffic": traffic,
+                "traffic_source": traffic_src,  # a committed rocprofv3 --pmc measurement of this command (not this run)
                 "flops_per_launch": solve_flops_step * args.steps / max(launches, 1),
                 "avg_launch_ms": ms / max(launches, 1),
                 "launches": launches,

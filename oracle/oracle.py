@@ -123,11 +123,13 @@ def cholesky_wrapper(AA, A):
         return L, True
 
 
-def chol_kernel(A, mBhalf, C_, kappaC, ucmin, smax):
+def chol_kernel(A, mBhalf, C_, kappaC, ucmin, smax, timings=None):
     """lakernel.CholKernel for ONE target PSF: A [n,n], mBhalf [m,n], C_ scalar.
 
     Single kappa: lakernel.py:281-323.  Multi kappa: 325-394.  Returns T f32 [m,n], UC, Sigma, kappa f32 [m],
-    info (0, or node+1 of the first repaired factorisation)."""
+    info (0, or node+1 of the first repaired factorisation).  ``timings`` (single kappa): dict that receives the
+    seconds of the factorisation and of the triangular solves."""
+    import time
     kappaC = np.atleast_1d(np.asarray(kappaC, dtype=np.float64))
     nv = kappaC.size
     m, n = mBhalf.shape
@@ -140,9 +142,14 @@ def chol_kernel(A, mBhalf, C_, kappaC, ucmin, smax):
         if my_kappa:
             AA[:: n + 1] += my_kappa
         AA = AA.reshape((n, n))
+        t0 = time.perf_counter()
         L, rep = cholesky_wrapper(AA, A)
+        t1 = time.perf_counter()
         info = 1 if rep else 0
         Ti = cho_solve((L, True), mBhalf.T, check_finite=False).T
+        if timings is not None:
+            timings["factor"] = timings.get("factor", 0.0) + t1 - t0
+            timings["tri_solve"] = timings.get("tri_solve", 0.0) + time.perf_counter() - t1
         D = np.einsum("ai,ai->a", mBhalf, Ti)
         N = np.einsum("ai,ai->a", Ti, Ti)
         kappa[:] = my_kappa
@@ -845,7 +852,8 @@ def stamp_tables(cfg, psfs, target):
 def stamp_full(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab, timings=None):
     """One stamp through the reference's stamp driver: _build_system_matrices (coadd.py:1002-1122: A, -B/2, LA kernel,
     the Iterative clamp, the map taper) and _perform_coaddition (1294-1363).  ``timings``: optional dict that
-    receives the seconds spent per stage (build / solve / epilogue)."""
+    receives the seconds spent per stage (build / solve / epilogue; the Cholesky kernel adds factor and tri_solve, the two parts
+    of solve)."""
     import time
 
     t0 = time.perf_counter()
@@ -863,8 +871,10 @@ def stamp_full(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab, timings
         else:
             T, UC, Sigma, kappa, info = empir_kernel(A, mB, C, np.array(cfg.kappaC), oy, ox, stamp.y, stamp.x, cfg.rho)
     else:
-        la = eigen_kernel if cfg.kernel == "Eigen" else chol_kernel
-        T, UC, Sigma, kappa, info = la(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
+        if cfg.kernel == "Eigen":
+            T, UC, Sigma, kappa, info = eigen_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
+        else:
+            T, UC, Sigma, kappa, info = chol_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax, timings=timings)
     s = (cfg.n2f, cfg.n2f)
     UC, Sigma, kappa = UC.reshape(s).copy(), Sigma.reshape(s).copy(), kappa.reshape(s).copy()
     if cfg.fade > 0:  # coadd.py:1118-1122

@@ -104,6 +104,9 @@ int pin_reserve(imcom_ctx *ctx, size_t bytes)
 //   A  [batch][Np][Np]   identity-padded, never modified
 //   Bt [batch][Np][mp]   input-pixel-major -B/2, zero padded
 // Produces Tt (float32 [batch][Np][mp]) and the per-pixel maps.
+constexpr int CHOL_MAXNV = 8;  // kappa nodes of the multi-kappa Cholesky kernel (launch_multi's MAXNV; 3 nv diagonal increments <= MAX_INC)
+static_assert(3 * CHOL_MAXNV <= MAX_INC_HOST, "diagonal increments of the repair sequence");
+
 static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
 {
     WsPlan p;
@@ -200,8 +203,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                         ih[c++] = kappaC_host[q] * C_host[s] - (q > 0 ? kappaC_host[q - 1] * C_host[s] : 0.0);
                         if (q < p && repaired[(size_t)q * batch + s]) { ih[c++] = rep[s]; ih[c++] = -rep[s]; }
                     }
-                if (repaired[(size_t)p * batch + s]) ih[c++] = rep[s];
-                IMCOM_REQUIRE(c <= MAX_INC_HOST, "too many diagonal increments");
+                if (repaired[(size_t)p * batch + s]) ih[c++] = rep[s];  // c <= 3 nv <= MAX_INC: nv <= CHOL_MAXNV is checked at entry
                 ninc[s] = c;
                 kap_h[s] = kappaC_host[p] * C_host[s];
             }
@@ -529,6 +531,7 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
     IMCOM_TRY(check_ctx(ctx));
     IMCOM_REQUIRE(batch >= 1 && n && C && kappaC && UC && Sigma && kappa && info, "null pointer / empty batch");
     IMCOM_REQUIRE(m >= 1 && nv >= 1 && ldn >= 0, "bad sizes");
+    IMCOM_REQUIRE(nv <= CHOL_MAXNV, "nv=%d kappa nodes: at most %d", nv, CHOL_MAXNV);
     int nmax = 0;
     for (int s = 0; s < batch; s++) {
         IMCOM_REQUIRE(n[s] >= 0 && n[s] <= ldn, "n[%d]=%d exceeds ldn=%d", s, n[s], ldn);
@@ -582,6 +585,7 @@ int imcom_solve_chol_resident(imcom_ctx *ctx, int batch, const int *n_host, int 
     IMCOM_TRY(check_ctx(ctx));
     IMCOM_REQUIRE(batch >= 1 && n_host && A && Bt && C_host && kappaC_host && Tt && UC && Sigma && kappa && info_host, "null pointer");
     IMCOM_REQUIRE(ldn >= NB && ldn % NB == 0 && ldm % NB == 0 && m >= 1 && m <= ldm && nv >= 1, "ldn=%d / ldm=%d must be multiples of %d", ldn, ldm, NB);
+    IMCOM_REQUIRE(nv <= CHOL_MAXNV, "nv=%d kappa nodes: at most %d", nv, CHOL_MAXNV);
     IMCOM_TRY(ws_reserve(ctx, chol_core_bytes(batch, ldn, m, ldm, nv)));
     return chol_core(ctx, batch, n_host, ldn, m, ldm, A, Bt, C_host, kappaC_host, nv, ucmin, smax, Tt, UC, Sigma, kappa, info_host);
 }

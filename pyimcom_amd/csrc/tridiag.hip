@@ -710,6 +710,13 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
     }
     hipEvent_t *ev_qr = ctx->sync_events.data(), *ev_ap = ev_qr + QR_RING, ev_x = ctx->sync_events[2 * QR_RING];
     hipStream_t sb = ctx->aux_stream;
+    // whatever path leaves this function (an IMCOM_TRY / IMCOM_HIP_CHECK early return included), nothing may still be
+    // running on the second stream: the next API call hands the same workspace out again
+    struct AuxDrain {
+        hipStream_t s;
+        bool armed = true;
+        ~AuxDrain() { if (armed) hipStreamSynchronize(s); }
+    } aux_drain{sb};
     if (vectors) {  // X (Qh^T) is ready when everything queued so far has run
         IMCOM_HIP_CHECK(hipEventRecord(ev_x, st));
         IMCOM_HIP_CHECK(hipStreamWaitEvent(sb, ev_x, 0));
@@ -759,6 +766,7 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
             IMCOM_HIP_CHECK(hipEventRecord(ev_x, sb));
             IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_x, 0));
         }
+        if (done) aux_drain.armed = false;  // joined through the event: the main stream orders everything that follows
     }
     if (!done) { hipStreamSynchronize(sb); set_error("tridiagonal QR did not converge"); return IMCOM_ERR_NUMERIC; }
     if (sweeps_out) {

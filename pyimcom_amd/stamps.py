@@ -162,11 +162,16 @@ class BlockTables:
     (PSFGrp.idx_grp2blk, psfutil.py:820-832: the reference keeps only exposures with pixels in the group; default
     0..n_g-1).  Tables live in one device arena and are computed on demand: a group's self overlap (triangle order)
     and input-output overlap, and the cross overlap of two groups (all n_g1 x n_g2 pairs, stored for the ordered key
-    g_lo < g_hi).  When the arena is full it is simply restarted -- stamps are visited group by group, so
-    recomputation is rare.  ``capacity`` (tables) is bounded by the 31-bit element offsets of the A builder:
-    capacity * (nsamp + 12)^2 < 2^31, i.e. 13 763 tables (17 GB) at nsamp = 383; one batch of stamps must fit."""
+    g_lo < g_hi).  ``capacity`` (tables) is bounded by the 31-bit element offsets of the A builder:
+    capacity * (nsamp + 12)^2 < 2^31, i.e. 13 763 tables (17 GB) at nsamp = 383; one batch of stamps must fit, else
+    ValueError.  When a later batch does not fit next to what is resident, ``on_full`` decides: "evict" (default) drops
+    every resident set and recomputes what the batch needs -- stamps are visited group by group, so that is rare; it is
+    counted in ``evictions`` and the kernels of earlier batches, queued on the same stream, have read their tables by the
+    time the new ones are written -- or "raise" (ValueError: size the arena for the block instead)."""
 
-    def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0"):
+    def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict"):
+        assert on_full in ("evict", "raise")
+        self.on_full, self.evictions = on_full, 0
         self.ctx = ctx or default_context()
         dev = self.dev = torch.device(device)
         self.psf = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64), device=dev) for k, v in group_psfs.items()}
@@ -246,10 +251,14 @@ class BlockTables:
         keys = list(dict.fromkeys(keys))
         need = sum(self._count(k) for k in keys if k not in self.index)
         if self.used + need > self.tables.shape[0]:
+            total = sum(self._count(k) for k in keys)
+            if total > self.tables.shape[0]:
+                raise ValueError(f"table arena of {self.tables.shape[0]} tables cannot hold the {total} of one batch")
+            if self.on_full == "raise":
+                raise ValueError(f"table arena full: {self.used} of {self.tables.shape[0]} tables resident, {need} more needed (on_full='raise')")
             self.index, self.used = {}, 0
-            need = sum(self._count(k) for k in keys)
-            if need > self.tables.shape[0]:
-                raise ValueError(f"table arena of {self.tables.shape[0]} tables cannot hold the {need} of one batch")
+            self.evictions += 1
+            need = total
         jobs, first = [], self.used
         for k in keys:
             if k in self.index:

@@ -117,6 +117,10 @@ def test_block_with_psf_groups_vs_oracle(n_out):
     pool = InStampPool(inst, cfg.n_inframe)
     maps = coadd_block(cfg, pool, tabs, n1P, n_expo, batch=2)
     torch.cuda.synchronize()
+    assert tabs.evictions >= 1  # the arena was restarted on the way, and says so
+    strict = BlockTables(group_psfs, target, cfg.nfft, group_expo=group_expo, capacity=96, on_full="raise")
+    with pytest.raises(ValueError, match="arena full"):
+        coadd_block(cfg, pool, strict, n1P, n_expo, batch=2)
 
     geo = orc.Geom(cfg.npixpsf, cfg.oversamp, cfg.dtheta_as / 3600.0, cfg.flat_penalty)
     rft_in = {k: orc.pad_and_rfft2(v, geo) for k, v in group_psfs.items()}
