@@ -113,14 +113,10 @@ def test_block_with_psf_groups_vs_oracle(n_out):
             xs, ys, dat, cum = inst[jj * nst + ii]
             keep = np.r_[0 : cum[1], cum[2] : cum[3]]
             inst[jj * nst + ii] = (xs[keep], ys[keep], dat[:, keep], np.array([0, cum[1], cum[1], cum[1] + cum[3] - cum[2]]))
-    tabs = BlockTables(group_psfs, target, cfg.nfft, group_expo=group_expo, capacity=96)  # small arena: forces a restart
+    tabs = BlockTables(group_psfs, target, cfg.nfft, group_expo=group_expo, capacity=96)
     pool = InStampPool(inst, cfg.n_inframe)
     maps = coadd_block(cfg, pool, tabs, n1P, n_expo, batch=2)
     torch.cuda.synchronize()
-    assert tabs.evictions >= 1  # the arena was restarted on the way, and says so
-    strict = BlockTables(group_psfs, target, cfg.nfft, group_expo=group_expo, capacity=96, on_full="raise")
-    with pytest.raises(ValueError, match="arena full"):
-        coadd_block(cfg, pool, strict, n1P, n_expo, batch=2)
 
     geo = orc.Geom(cfg.npixpsf, cfg.oversamp, cfg.dtheta_as / 3600.0, cfg.flat_penalty)
     rft_in = {k: orc.pad_and_rfft2(v, geo) for k, v in group_psfs.items()}
@@ -227,3 +223,32 @@ def test_full_chain_vs_reference_golden(golden, name):
     assert np.abs(res.outimage[0].cpu().numpy() - ref_img).max() <= 2e-5 * np.abs(ref_img).max()
     assert np.allclose(res.Tsum_stamp[0, :n_inimage].cpu().numpy(), g["Tsum_stamp"][0], rtol=1e-5)
     assert np.allclose(res.Neff[0].cpu().numpy(), g["Neff"][0], rtol=1e-4)
+
+
+def test_block_tables_eviction_policy():
+    """The table arena says what it does when full: 'evict' drops the resident sets, recomputes and counts it; 'raise' refuses;
+    a request that can never fit raises under both."""
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import BlockTables
+
+    cfg = synth.CONFIGS["tiny"]
+    psfs, target = synth.make_psfs(cfg, 3)
+    groups = {(0, 0): psfs, (0, 1): psfs * 1.0, (1, 0): psfs[:2]}
+    a, b = BlockTables.keys_for([(0, 0), (0, 1)]), BlockTables.keys_for([(1, 0)])
+    for policy in ("evict", "raise"):
+        t = BlockTables(groups, target, cfg.nfft, capacity=27, on_full=policy)  # the sets of `a` need 6 + 6 + 3 + 3 + 9 = 27 tables
+        first = t.require(a)
+        assert t.used == 27 and t.evictions == 0 and t.require(a) == first
+        if policy == "evict":
+            got = t.require(b)  # 3 + 2 tables: no room next to the 27 resident ones
+            assert t.evictions == 1 and t.used == 5 and sorted(got.values()) == [0, 3]
+            ref = BlockTables(groups, target, cfg.nfft, capacity=64)
+            idx = ref.require(b)
+            for k in b:  # recomputed tables are the same tables
+                n = t._count(k)
+                assert np.array_equal(t.tables[got[k] : got[k] + n].cpu().numpy(), ref.tables[idx[k] : idx[k] + n].cpu().numpy())
+        else:
+            with pytest.raises(ValueError, match="arena full"):
+                t.require(b)
+        with pytest.raises(ValueError, match="cannot hold"):
+            BlockTables(groups, target, cfg.nfft, capacity=20, on_full=policy).require(a)
