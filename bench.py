@@ -63,7 +63,10 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
         return done, dt, {k: v / done * 1e3 for k, v in stages.items()}
 
     cores = os.cpu_count()
-    done, dt, stages = sample(budget_s * 0.5, 0)
+    # the C interpolators are called once per exposure pair (~80k samples): more than ~32 OpenMP threads only add
+    # start-up and spinning next to the BLAS threads (measured: 256 threads 5.7 s per stamp, 1 thread 0.3 s)
+    omp = min(cores, 32)
+    done, dt, stages = sample(budget_s * 0.5, omp)
     if threadpool_limits is not None:
         with threadpool_limits(limits=1):
             done1, dt1, stages1 = sample(budget_s * 0.5, 1)
@@ -76,7 +79,7 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
         "cores": cores,
         "kind": "port",
         "sample": f"{done} whole {cfg.name} stamps (N~{stamps[0].n}, m={cfg.m}) through oracle/ on {cores} cores ({dt:.1f} s): C interpolators "
-                  f"with OpenMP, scipy potrf/potrs; then {done1} stamps on 1 thread ({dt1:.1f} s)",
+                  f"with {omp} OpenMP threads, scipy potrf/potrs with the BLAS default; then {done1} stamps on 1 thread ({dt1:.1f} s)",
         "stage_ms_per_stamp": stages,
     }
     if done1:
@@ -102,6 +105,62 @@ def pmc_traffic(batch, cfg_name):
     return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
 
 
+def block_leg(ctx, dev, n1P=16, batch=128, reps=2):
+    """The same path one level up, as a block of the reference runs it (coadd.py:2003-2084): cfg-2 geometry, a block of
+    n1P x n1P output stamps whose PSFs change from one 2 x 2 group of InStamps to the next (SysMatA.ji_st2psf,
+    psfutil.py:1803-1824), and everything the headline loop leaves out inside the timed region: PSF spectra and overlap
+    tables per group (self / cross / input-output sets), pixel selection from the InStamp pool, per-stamp pair maps,
+    A, B, Cholesky, coaddition, block-map accumulation and boundary recovery.  Only the upload of the InStamp pool and of
+    the sampled PSFs is outside."""
+    import numpy as np
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import coadd_block
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import BlockTables
+
+    cfg = synth.CONFIGS["cfg2"]
+    E = cfg.n_expo
+    inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng(5))
+    pool = InStampPool(inst, cfg.n_inframe, device=dev)
+    psfs, target = synth.make_psfs(cfg, E)
+    nst = n1P + 2
+    ng = (nst + 1) // 2
+    lin = np.arange(psfs.shape[-1]) - psfs.shape[-1] // 2
+    groups = {}
+    for gj in range(ng):
+        for gi in range(ng):  # a smooth modulation per group: every group has PSFs of its own
+            mod = 1.0 + 0.02 * np.sin(0.05 * lin * (1 + gi % 3))[None, None, :] + 0.02 * np.cos(0.04 * lin * (1 + gj % 3))[None, :, None]
+            q = psfs * mod
+            groups[(gj, gi)] = q / q.sum(axis=(1, 2), keepdims=True)
+    fams = ("psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize", "epilogue", "block_acc")
+
+    def one():
+        tabs = BlockTables(groups, target, cfg.nfft, capacity=13500, ctx=ctx, device=dev)  # table construction is part of the block
+        return coadd_block(cfg, pool, tabs, n1P, E, batch=batch)
+
+    one()
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        maps = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    stages = {f: ctx.profile_get(f)[0] / reps for f in fams}
+    ctx.profile_enable(False)
+    return {
+        "value": n1P * n1P / dt, "unit": "postage-stamps/s", "ms_per_block": dt * 1e3, "stamps_per_block": n1P * n1P, "psf_groups": ng * ng,
+        "batch": batch, "input_pixels": int(pool.npool),
+        "workload": f"cfg2 geometry, block of {n1P}x{n1P} output stamps, PSF group per 2x2 InStamps; tables + selection + pair maps + A, B, Cholesky, "
+                    "coaddition + block maps inside the timed region",
+        "stage_ms_per_block": stages, "host_and_gaps_ms_per_block": dt * 1e3 - sum(stages.values()),
+        "out_map_rms": float(maps.out_map.square().mean().sqrt()),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +169,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--batch", type=int, default=256, help="stamps per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-block", action="store_true", help="skip the block-level leg (tables + selection + stamps + block maps)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal of the multi-rank path on a box with ONE GPU: every rank uses cuda:0 and the ranks "
@@ -225,6 +285,10 @@ def main():
             },
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()},
         }
+        if not args.no_block and world == 1 and args.config == "cfg2":
+            del batch
+            torch.cuda.empty_cache()
+            out["block"] = block_leg(ctx, dev)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = cpu_baseline(cfg, stamps[:64], psfs, target, args.cpu_budget)
         print(json.dumps(out))

@@ -69,10 +69,11 @@ extern "C" int imcom_block_accumulate(imcom_ctx *ctx, int batch, const int *jst_
     for (int p = 0; p < 4; p++)
         for (int s = 0; s < batch; s++)
             if ((((jst_host[s] & 1) << 1) | (ist_host[s] & 1)) == p) { order.push_back(s); cnt[p]++; }
-    IMCOM_HIP_CHECK(hipMemcpyAsync(jd, jst_host, (size_t)batch * 4, hipMemcpyHostToDevice, ctx->stream));
-    IMCOM_HIP_CHECK(hipMemcpyAsync(id, ist_host, (size_t)batch * 4, hipMemcpyHostToDevice, ctx->stream));
-    IMCOM_HIP_CHECK(hipMemcpyAsync(ld, order.data(), (size_t)batch * 4, hipMemcpyHostToDevice, ctx->stream));
-    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // `order` is a local
+    // through the pinned ring: the copies read it, not the caller's arrays, so the call returns without draining the stream
+    IMCOM_TRY(upload(ctx, jd, jst_host, (size_t)batch));
+    IMCOM_TRY(upload(ctx, id, ist_host, (size_t)batch));
+    IMCOM_TRY(upload(ctx, ld, order.data(), (size_t)batch));
+    ProfScope ps(ctx, "block_acc");
     int off = 0;
     for (int p = 0; p < 4; p++) {
         if (cnt[p] == 0) continue;

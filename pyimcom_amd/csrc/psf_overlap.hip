@@ -622,6 +622,7 @@ extern "C" int imcom_psf_spectra(imcom_ctx *ctx, const double *psf, int n, int n
     FftPlan pl;
     fft_plan(nfft, &pl);
     IMCOM_TRY(ws_reserve(ctx, fft_forward_ws(n, nsamp, nfft) + 8192));
+    ProfScope ps(ctx, "psf_spectra");
     return fft_forward(ctx, pl, psf, n, nsamp, (cplx *)spectra);
 }
 

@@ -131,9 +131,10 @@ extern "C" int imcom_select_pixels(imcom_ctx *ctx, int batch, const double *pool
     int *status = (int *)take(4);
     if (!status) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     IMCOM_HIP_CHECK(hipMemsetAsync(status, 0, 4, ctx->stream));
+    { ProfScope ps(ctx, "select");
     hipLaunchKernelGGL(select_pixels_kernel, dim3(batch), dim3(256), 0, ctx->stream, (const double *)px_, (const double *)py_,
                        (const float *)pd_, npool, n_inframe, (const int *)pe_, (const long *)io_, (const int *)ii_, (const double *)vx_,
-                       (const double *)vy_, radius, ldn, x_d, y_d, d_d, e_d, c_d, status);
+                       (const double *)vy_, radius, ldn, x_d, y_d, d_d, e_d, c_d, status); }
     IMCOM_TRY(check_launch("select_pixels_kernel"));
     int st = 0;
     IMCOM_HIP_CHECK(hipMemcpyAsync(&st, status, 4, hipMemcpyDeviceToHost, ctx->stream));
