@@ -49,3 +49,23 @@ def test_farm_two_processes_equal_one(tmp_path):
     o = p.communicate(timeout=600)[0]
     assert p.returncode == 0 and o.count("skipped") == 3 and "done: [2]" in o, o
     assert np.array_equal(np.load(farm.block_path(one, 2))["out_map"], keep)
+
+
+def test_bench_multi_rank_rehearsal():
+    """bench.py's N > 1 path (torch.distributed.run, one rank per GPU, barrier + max-over-ranks timing, rank 0 prints
+    the one JSON line) rehearsed on this one-GPU box: two ranks share cuda:0 and rendezvous over gloo.  Not a
+    measurement -- it keeps the launch contract of the scaling run from rotting."""
+    import json
+
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8",
+           "--rehearse-shared-gpu"]
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "postage-stamps/s"
+    assert d["config"]["stamps_per_step_per_gpu"] == 8 and d["value"] > 0 and "cpu_baseline" not in d and "block" not in d
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # whole-job aggregate over both ranks
