@@ -181,3 +181,39 @@ def test_partition_vs_reference_golden(golden):
     got = partition_pixels(ox, oy, in_x, in_y, mask, g["use_instamps"], int(g["n2"]), int(g["n1P"]), int(g["npixmax"]))
     for a, name in zip(got, ("y_idx", "x_idx", "y_val", "x_val", "pix_count")):
         assert np.array_equal(a.cpu().numpy(), g[name]), name
+
+
+@pytest.mark.parametrize("n1P,npix", [(10, 300_001), (62, 1_000_003)])
+def test_partition_large_stable(n1P, npix):
+    """The binning at image scale: many workgroups of the radix sort, two passes (144 stamps) and three (4096), random
+    positions with a quarter of the pixels dropped (outside, masked, unused stamps); every stamp's pixels must be exactly the
+    stamp's pixels in visiting order (numpy's stable argsort is the reference)."""
+    import torch
+
+    from pyimcom_amd.select import partition_pixels
+
+    rng = np.random.default_rng(n1P)
+    n2, nst = 8, n1P + 2
+    lo, hi = -n2 - 0.5, n1P * n2 + n2 - 0.5
+    ox, oy = rng.uniform(lo - 3, hi + 3, npix), rng.uniform(lo - 3, hi + 3, npix)
+    in_x, in_y = rng.integers(0, 4088, npix).astype(np.uint16), rng.integers(0, 4088, npix).astype(np.uint16)
+    mask = rng.uniform(size=npix) > 0.1
+    use = rng.uniform(size=(nst, nst)) > 0.05
+    ist, jst = np.floor((ox - lo) / n2).astype(int), np.floor((oy - lo) / n2).astype(int)
+    ok = (lo < ox) & (ox < hi) & (lo < oy) & (oy < hi) & mask
+    ok &= use[np.clip(jst, 0, nst - 1), np.clip(ist, 0, nst - 1)]
+    key = np.where(ok, jst * nst + ist, nst * nst)
+    order = np.argsort(key, kind="stable")
+    counts = np.bincount(key, minlength=nst * nst + 1)[: nst * nst]
+    npixmax = int(counts.max())
+    y_idx, x_idx, y_val, x_val, count = partition_pixels(ox, oy, in_x, in_y, mask, use, n2, n1P, npixmax)
+    torch.cuda.synchronize()
+    assert np.array_equal(count.cpu().numpy().astype(np.int64).ravel(), counts)
+    got_x, got_ix = x_val.cpu().numpy().reshape(nst * nst, npixmax), x_idx.cpu().numpy().reshape(nst * nst, npixmax)
+    got_y = y_val.cpu().numpy().reshape(nst * nst, npixmax)
+    start = np.concatenate([[0], np.cumsum(counts)])
+    for k in rng.choice(nst * nst, 60, replace=False):
+        sel = order[start[k] : start[k + 1]]
+        assert np.array_equal(got_x[k, : counts[k]], ox[sel]) and np.array_equal(got_y[k, : counts[k]], oy[sel]) and np.array_equal(got_ix[k, : counts[k]], in_x[sel])
+    with pytest.raises(Exception):
+        partition_pixels(ox, oy, in_x, in_y, mask, use, n2, n1P, npixmax - 1)
