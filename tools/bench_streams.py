@@ -4,9 +4,9 @@ import numpy as np, torch
 from pyimcom_amd import synth
 from pyimcom_amd._lib import Context
 from pyimcom_amd.stamps import PSFGroupTables, StampBatch
-cfg = synth.CONFIGS["cfg2"]
+cfg = synth.CONFIGS[sys.argv[3] if len(sys.argv) > 3 else "cfg2"]
 nthr, per = int(sys.argv[1]), int(sys.argv[2])
-psfs, target = synth.make_psfs(cfg, 6)
+psfs, target = synth.make_psfs(cfg, cfg.n_expo)
 ctxs = [Context(0) for _ in range(nthr)]
 streams = [torch.cuda.Stream() for _ in range(nthr)]
 batches = []
