@@ -107,16 +107,38 @@ int pin_reserve(imcom_ctx *ctx, size_t bytes)
 constexpr int CHOL_MAXNV = 8;  // kappa nodes of the multi-kappa Cholesky kernel (launch_multi's MAXNV; 3 nv diagonal increments <= MAX_INC)
 static_assert(3 * CHOL_MAXNV <= MAX_INC_HOST, "diagonal increments of the repair sequence");
 
+// Split-K for small batches: with fewer than ~256 tiles per launch (the kernel-class seam hands over one stamp: 18) the K
+// loop of every tile is dealt to up to 8 workgroups, so that a launch has ~512 of them (gemm_f64.hip).
+static int splitk_parts(int batch, int tiles)
+{
+    const long wgs = (long)batch * tiles;
+    if (wgs >= 256) return 1;
+    return (int)std::min<long>(8, std::max<long>(1, 512 / std::max<long>(wgs, 1)));
+}
+
+static size_t splitk_bytes(int batch, int Np, int mp)
+{
+    const int tiles = std::max(Np, mp) / NB;
+    return splitk_parts(batch, std::min(Np, mp) / NB) > 1 ? (size_t)batch * tiles * 8 * NB * NB * 8 + 256 : 0;
+}
+
+// Multi-kappa on a small batch: the nv factorisations and solves of a stamp are independent, so they are run as ONE pass over
+// nv x batch "stamps" (node-major: exactly the layout of Y) instead of nv passes that each fill a fraction of the chip.
+static int nodes_per_pass(int batch, int mp, int nv)
+{
+    return (nv > 1 && (long)batch * nv * (mp / NB) <= 1024) ? nv : 1;
+}
+
 static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
 {
     WsPlan p;
-    const size_t nb = Np / NB;
-    p.add((size_t)batch * Np * Np * 8);          // L
-    p.add((size_t)batch * nb * NB * NB * 8);     // Dinv
+    const size_t nb = Np / NB, eb = (size_t)batch * nodes_per_pass(batch, mp, nv);
+    p.add(eb * Np * Np * 8);                     // L
+    p.add(eb * nb * NB * NB * 8);                // Dinv
     p.add((size_t)nv * batch * Np * mp * 8);     // Y / X per node
-    p.add((size_t)batch * Np * 8);               // dshift
-    p.add((size_t)batch * 4 * (3 + nv));         // n, nblk, ninc, fail[nv]
-    p.add((size_t)batch * MAX_INC_HOST * 8);     // inc
+    p.add(eb * Np * 8);                          // dshift
+    p.add(eb * 4 * 3 + (size_t)batch * 4 * nv);  // n, nblk, ninc, fail[nv]
+    p.add(eb * MAX_INC_HOST * 8);                // inc
     p.add((size_t)batch * 8 * 2);                // kap, C
     p.add((size_t)nv * 8);                       // kappaC
     if (nv > 1) {
@@ -126,6 +148,7 @@ static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
     }
     // repair path (lakernel.py:262-279): eigenvalues of ONE stamp's A at a time
     p.add(eigh_ws_bytes(1, Np, false) + (size_t)Np * Np * 8 + (size_t)Np * 8 + 1024);
+    p.add(splitk_bytes((int)eb, Np, mp));
     return p.total + 4096;
 }
 
@@ -152,13 +175,14 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                      double smax, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host)
 {
     const int nbmax_all = Np / NB;
-    double *L = (double *)ws_take(ctx, (size_t)batch * Np * Np * 8);
-    double *Dinv = (double *)ws_take(ctx, (size_t)batch * nbmax_all * NB * NB * 8);
+    const int pb = nodes_per_pass(batch, mp, nv), eb = batch * pb;  // nodes per pass, stamps x nodes of a pass
+    double *L = (double *)ws_take(ctx, (size_t)eb * Np * Np * 8);
+    double *Dinv = (double *)ws_take(ctx, (size_t)eb * nbmax_all * NB * NB * 8);
     const long node_stride = (long)batch * Np * mp;
     double *Y = (double *)ws_take(ctx, (size_t)nv * node_stride * 8);
-    double *dshift = (double *)ws_take(ctx, (size_t)batch * Np * 8);
-    int *ints = (int *)ws_take(ctx, (size_t)batch * 4 * (3 + nv));
-    double *inc = (double *)ws_take(ctx, (size_t)batch * MAX_INC_HOST * 8);
+    double *dshift = (double *)ws_take(ctx, (size_t)eb * Np * 8);
+    int *ints = (int *)ws_take(ctx, (size_t)eb * 4 * 3 + (size_t)batch * 4 * nv);
+    double *inc = (double *)ws_take(ctx, (size_t)eb * MAX_INC_HOST * 8);
     double *dbl = (double *)ws_take(ctx, (size_t)batch * 8 * 2);
     double *kappaC_dev = (double *)ws_take(ctx, (size_t)nv * 8);
     double *Dp = nullptr, *Npq = nullptr, *W = nullptr;
@@ -167,11 +191,14 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         Npq = (double *)ws_take(ctx, (size_t)batch * m * nv * nv * 8);
         W = (double *)ws_take(ctx, (size_t)batch * m * nv * 8);
     }
-    if (!L || !Dinv || !Y || !dshift || !ints || !inc || !dbl || !kappaC_dev || (nv > 1 && (!Dp || !Npq || !W))) {
+    const size_t pbytes = splitk_bytes(eb, Np, mp);
+    double *partial = pbytes ? (double *)ws_take(ctx, pbytes) : nullptr;
+    const int parts_solve = partial ? splitk_parts(eb, mp / NB) : 1;
+    if (!L || !Dinv || !Y || !dshift || !ints || !inc || !dbl || !kappaC_dev || (nv > 1 && (!Dp || !Npq || !W)) || (pbytes && !partial)) {
         set_error("internal: workspace plan too small");
         return IMCOM_ERR_NOMEM;
     }
-    int *n_dev = ints, *nblk_dev = ints + batch, *ninc_dev = ints + 2 * batch, *fail_dev = ints + 3 * batch;  // fail[nv][batch]
+    int *n_dev = ints, *nblk_dev = ints + eb, *ninc_dev = ints + 2 * eb, *fail_dev = ints + 3 * eb;  // n, nblk, ninc [eb]; fail[nv][batch]
     double *kap_dev = dbl, *C_dev = dbl + batch;
 
     std::vector<int> nblk(batch), ninc(batch, 0), fail((size_t)nv * batch);
@@ -184,50 +211,55 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         if (nblk[s] > nbmax) nbmax = nblk[s];
         info_host[s] = 0;
     }
-    IMCOM_TRY(upload(ctx, n_dev, n_host, batch));
-    IMCOM_TRY(upload(ctx, nblk_dev, nblk.data(), batch));
+    for (int q = 0; q < pb; q++) {  // the stamps of a pass: node-major copies
+        IMCOM_TRY(upload(ctx, n_dev + q * batch, n_host, batch));
+        IMCOM_TRY(upload(ctx, nblk_dev + q * batch, nblk.data(), batch));
+    }
     IMCOM_TRY(upload(ctx, C_dev, C_host, batch));
     IMCOM_TRY(upload(ctx, kappaC_dev, kappaC_host, nv));
 
     for (int attempt = 0;; attempt++) {
         IMCOM_HIP_CHECK(hipMemsetAsync(fail_dev, 0, (size_t)nv * batch * 4, ctx->stream));
-        for (int p = 0; p < nv; p++) {
-            // the diagonal of AA at node p as the reference builds it: a sequence of in-place adds
-            // (lakernel.py:298 single kappa; 356 node differences; 268/277 repair add and restore)
-            for (int s = 0; s < batch; s++) {
-                double *ih = &inc_h[(size_t)s * MAX_INC_HOST];
-                int c = 0;
-                if (nv == 1) { if (kappaC_host[0] * C_host[s] != 0.0) ih[c++] = kappaC_host[0] * C_host[s]; }
-                else
-                    for (int q = 0; q <= p; q++) {
-                        ih[c++] = kappaC_host[q] * C_host[s] - (q > 0 ? kappaC_host[q - 1] * C_host[s] : 0.0);
-                        if (q < p && repaired[(size_t)q * batch + s]) { ih[c++] = rep[s]; ih[c++] = -rep[s]; }
-                    }
-                if (repaired[(size_t)p * batch + s]) ih[c++] = rep[s];  // c <= 3 nv <= MAX_INC: nv <= CHOL_MAXNV is checked at entry
-                ninc[s] = c;
-                kap_h[s] = kappaC_host[p] * C_host[s];
+        for (int p0 = 0; p0 < nv; p0 += pb) {
+            for (int q = 0; q < pb; q++) {
+                const int p = p0 + q;
+                // the diagonal of AA at node p as the reference builds it: a sequence of in-place adds
+                // (lakernel.py:298 single kappa; 356 node differences; 268/277 repair add and restore)
+                for (int s = 0; s < batch; s++) {
+                    double *ih = &inc_h[(size_t)s * MAX_INC_HOST];
+                    int c = 0;
+                    if (nv == 1) { if (kappaC_host[0] * C_host[s] != 0.0) ih[c++] = kappaC_host[0] * C_host[s]; }
+                    else
+                        for (int qq = 0; qq <= p; qq++) {
+                            ih[c++] = kappaC_host[qq] * C_host[s] - (qq > 0 ? kappaC_host[qq - 1] * C_host[s] : 0.0);
+                            if (qq < p && repaired[(size_t)qq * batch + s]) { ih[c++] = rep[s]; ih[c++] = -rep[s]; }
+                        }
+                    if (repaired[(size_t)p * batch + s]) ih[c++] = rep[s];  // c <= 3 nv <= MAX_INC: nv <= CHOL_MAXNV is checked at entry
+                    ninc[s] = c;
+                    kap_h[s] = kappaC_host[p] * C_host[s];
+                }
+                IMCOM_TRY(upload(ctx, inc + (size_t)q * batch * MAX_INC_HOST, inc_h.data(), inc_h.size()));
+                IMCOM_TRY(upload(ctx, ninc_dev + q * batch, ninc.data(), batch));
+                if (q == 0) IMCOM_TRY(upload(ctx, kap_dev, kap_h.data(), batch));  // used by the single-kappa finalize only
+                IMCOM_TRY(launch_diag_shift(ctx, A, Np, inc + (size_t)q * batch * MAX_INC_HOST, ninc_dev + q * batch, dshift + (size_t)q * batch * Np, batch));
             }
-            IMCOM_TRY(upload(ctx, inc, inc_h.data(), inc_h.size()));
-            IMCOM_TRY(upload(ctx, ninc_dev, ninc.data(), batch));
-            IMCOM_TRY(upload(ctx, kap_dev, kap_h.data(), batch));
-            IMCOM_TRY(launch_diag_shift(ctx, A, Np, inc, ninc_dev, dshift, batch));
-            int *failp = fail_dev + (size_t)p * batch;
+            int *failp = fail_dev + (size_t)p0 * batch;
             for (int k = 0; k < nbmax; k++) {
-                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_update(ctx, A, L, Np, k, nbmax, batch, nblk_dev, dshift)); }
-                { ProfScope ps(ctx, "chol_diag"); IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, batch, nblk_dev, failp)); }
-                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, batch, nblk_dev)); }
+                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_update(ctx, A, L, Np, k, nbmax, eb, batch, nblk_dev, dshift, partial, partial ? splitk_parts(eb, nbmax - k) : 1)); }
+                { ProfScope ps(ctx, "chol_diag"); IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, eb, nblk_dev, failp)); }
+                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, eb, nblk_dev)); }
             }
-            double *Yp = Y + p * node_stride;
+            double *Yp = Y + p0 * node_stride;
             // the diagonal blocks are applied inside the update launches; IMCOM_SOLVE_UNFUSED=1 keeps them apart (A/B runs)
             static const bool unfused = getenv("IMCOM_SOLVE_UNFUSED") != nullptr;
             const double *Dfused = unfused ? nullptr : Dinv;
             for (int k = 0; k < nbmax; k++) {
-                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, batch, nblk_dev, n_dev, Dfused)); }
-                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, false)); }
+                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, eb, batch, nblk_dev, n_dev, Dfused, partial, parts_solve)); }
+                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nblk_dev, false)); }
             }
             for (int k = nbmax - 1; k >= 0; k--) {
-                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, batch, nblk_dev, n_dev, Dfused)); }
-                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, batch, nblk_dev, true)); }
+                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, nbmax, eb, nblk_dev, n_dev, Dfused, partial, parts_solve)); }
+                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nblk_dev, true)); }
             }
         }
         {

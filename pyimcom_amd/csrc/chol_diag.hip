@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
     extern __shared__ double S[];            // [128][SLD]
     double *Xd = S + NB * SLD;               // [8][16][XLD] inverses of the diagonal sub-blocks
     double *dg = Xd + 8 * 16 * XLD;          // [128] diagonal of L
+    double *rdg = dg + NB;                   // [128] its reciprocal: the dependent chains below multiply instead of dividing
     __shared__ int bad;
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (k >= nblk[s] || fail[s] != 0) return;
@@ -62,9 +63,9 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
                     if (lane == 0) { bad = 1; fail[s] = k * NB + o + j + 1; }
                     break;
                 }
-                const double ljj = sqrt(d);
-                if (lane == j) { S[(o + j) * SLD + o + j] = ljj; dg[o + j] = ljj; }
-                else if (lane < 16 && lane > j) S[(o + lane) * SLD + o + j] = v / ljj;
+                const double ljj = sqrt(d), rl = 1.0 / ljj;
+                if (lane == j) { S[(o + j) * SLD + o + j] = ljj; dg[o + j] = ljj; rdg[o + j] = rl; }
+                else if (lane < 16 && lane > j) S[(o + lane) * SLD + o + j] = v * rl;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
 #pragma unroll
                     for (int c = 0; c < 16; c++)
                         if (c < j) v -= x[c] * S[(o + j) * SLD + o + c];
-                    x[j] = v / dg[o + j];
+                    x[j] = v * rdg[o + j];
                 }
 #pragma unroll
                 for (int j = 0; j < 16; j++) S[r * SLD + o + j] = x[j];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
 #pragma unroll
             for (int l = 0; l < 16; l++)
                 if (l < i && l >= c) v -= S[(o + i) * SLD + o + l] * x[l];
-            x[i] = (i >= c) ? v / dg[o + i] : 0.0;
+            x[i] = (i >= c) ? v * rdg[o + i] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) Xd[(blk * 16 + i) * XLD + c] = x[i];
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
 int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail)
 {
     static bool attr_set = false;
-    const size_t bytes = (size_t)(NB * SLD + 8 * 16 * XLD + NB) * sizeof(double);
+    const size_t bytes = (size_t)(NB * SLD + 8 * 16 * XLD + 2 * NB) * sizeof(double);
     if (!attr_set) {
         IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)chol_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr_set = true;

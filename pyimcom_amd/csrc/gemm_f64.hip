@@ -75,10 +75,55 @@ __device__ __forceinline__ void solve_tile_of_block(int &c, int &s)
 //   L[k,k], Linv[k] from P[k]                                         (chol_diag.hip)
 //   L[i,k] = P[i] Linv[k]^T                                           (chol_trsm_kernel, i > k)
 // A is never written; L lives in its own buffer (the repair path and the multi-kappa path need A).
+// Split-K for small batches (the kernel-class seam hands over ONE stamp per call: 18 workgroups per launch on 256 CUs).
+// The K range of a tile is dealt to `nparts` workgroups that store their partial 128 x 128 products
+// (partial[(stamp * gridDim.x + tile) * nparts + part][128][128], plain row-major); the tile's own kernel then adds them
+// up in a fixed order instead of running the K loop, so the result does not depend on which part finished first.
+__device__ __forceinline__ void store_partial(const f64x4 (&acc)[4][MMA_NJ], double *P)
+{
+    IMCOM_FOR_ACC(row, col, v, { P[row * NB + col] = v; })
+}
+
+__device__ __forceinline__ void sum_partials(f64x4 (&acc)[4][MMA_NJ], const double *P, int nparts)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / MMA_WN, wn = wave % MMA_WN;
+    for (int p = 0; p < nparts; p++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < MMA_NJ; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    acc[i][j][r] += P[(long)p * NB * NB + (wm * 64 + i * 16 + (lane >> 4) + 4 * r) * NB + wn * (16 * MMA_NJ) + j * 16 + (lane & 15)];
+}
+
+// K blocks [k0, k1) of part `p` of `nparts` over `kb` blocks
+__device__ __forceinline__ void part_range(int kb, int p, int nparts, int &k0, int &k1)
+{
+    k0 = (int)((long)p * kb / nparts);
+    k1 = (int)((long)(p + 1) * kb / nparts);
+}
+
+__global__ __launch_bounds__(MMA_THREADS, 2) void chol_partial_kernel(const double *__restrict__ L, int ldn, int k,
+                                                              const int *__restrict__ nblk, int nparts, double *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
+    const int c = blockIdx.x, p = blockIdx.y, s = blockIdx.z, i = k + c;
+    if (i >= nblk[s]) return;
+    const double *Ls = L + (long)s * ldn * ldn;
+    int k0, k1;
+    part_range(k, p, nparts, k0, k1);
+    f64x4 acc[4][MMA_NJ];
+    zero_acc(acc);
+    mma_tile_dma<false, false>(acc, Ls + (long)i * NB * ldn + k0 * NB, ldn, Ls + (long)k * NB * ldn + k0 * NB, ldn, (k1 - k0) * NB, smem);
+    store_partial(acc, partial + (((long)s * gridDim.x + c) * nparts + p) * NB * NB);
+}
+
 __global__ __launch_bounds__(MMA_THREADS, 2) void chol_update_kernel(const double *__restrict__ A,
                                                              double *__restrict__ L, int ldn, int k,
                                                              const int *__restrict__ nblk,
-                                                             const double *__restrict__ dshift)
+                                                             const double *__restrict__ dshift,
+                                                             const double *__restrict__ partial, int nparts, int abatch)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -89,8 +134,9 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void chol_update_kernel(const doubl
     double *Ls = L + s * sA;
     f64x4 acc[4][MMA_NJ];
     zero_acc(acc);
-    mma_tile_dma<false, false>(acc, Ls + (long)i * NB * ldn, ldn, Ls + (long)k * NB * ldn, ldn, k * NB, smem);
-    const double *As = A + s * sA + (long)i * NB * ldn + k * NB;
+    if (partial) sum_partials(acc, partial + ((long)s * gridDim.x + c) * nparts * NB * NB, nparts);
+    else mma_tile_dma<false, false>(acc, Ls + (long)i * NB * ldn, ldn, Ls + (long)k * NB * ldn, ldn, k * NB, smem);
+    const double *As = A + (s % abatch) * sA + (long)i * NB * ldn + k * NB;  // node-batched passes: stamp s of the pass reads A of stamp s mod abatch
     double *Lo = Ls + (long)i * NB * ldn + k * NB;
     // dshift = diagonal of A with the kappa increments already applied (diag_shift_kernel)
     const double *dsh = dshift + (long)s * ldn + i * NB;
@@ -140,11 +186,41 @@ __device__ __forceinline__ void solve_dinv_tile(f64x4 (&acc)[4][MMA_NJ], const d
     IMCOM_FOR_ACC_TRI(row, col, v, { Yk[(long)row * ldm + col] = v; })
 }
 
+// partial products of one block row of the triangular solves (split-K, see chol_partial_kernel)
+template <bool BWD>
+__global__ __launch_bounds__(MMA_THREADS, 2) void solve_partial_kernel(const double *__restrict__ L, const double *__restrict__ Y,
+                                                               int ldn, int ldm, int k, const int *__restrict__ nblk,
+                                                               const int *__restrict__ n, int nparts, double *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
+    const int c = blockIdx.x, p = blockIdx.y, s = blockIdx.z, nb = nblk[s];
+    if (k >= nb) return;
+    const double *Ys = Y + (long)s * ldn * ldm + c * NB;
+    f64x4 acc[4][MMA_NJ];
+    zero_acc(acc);
+    int k0, k1;
+    if (!BWD) {
+        part_range(k, p, nparts, k0, k1);
+        const double *Ls = L + (long)s * ldn * ldn + (long)k * NB * ldn + k0 * NB;
+        const int mrows = min(NB, n[s] - k * NB);
+        if (mrows == NB) mma_tile_dma<false, true>(acc, Ls, ldn, Ys + (long)k0 * NB * ldm, ldm, (k1 - k0) * NB, smem);
+        else mma_tile_dma<false, true, true>(acc, Ls, ldn, Ys + (long)k0 * NB * ldm, ldm, (k1 - k0) * NB, smem, mrows);
+    } else {
+        part_range(nb - 1 - k, p, nparts, k0, k1);
+        const int kend = ((n[s] + DBK - 1) / DBK) * DBK - (k + 1) * NB;  // rows of L below n[s] are zero in this block column
+        const int K = min(k1 * NB, kend) - k0 * NB;
+        const double *Lc = L + (long)s * ldn * ldn + (long)(k + 1 + k0) * NB * ldn + k * NB;
+        if (K > 0) mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1 + k0) * NB * ldm, ldm, K, smem);
+    }
+    store_partial(acc, partial + (((long)s * gridDim.x + c) * nparts + p) * NB * NB);
+}
+
 __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double *__restrict__ L,
                                                            const double *__restrict__ Bt,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk, const int *__restrict__ n,
-                                                           const double *__restrict__ Dinv)
+                                                           const double *__restrict__ Dinv,
+                                                           const double *__restrict__ partial, int nparts, int bbatch)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -156,9 +232,10 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double 
     zero_acc(acc);
     // rows of the last block row beyond n[s] are identity padding: their Y is Bt (zero), nothing has to be multiplied
     const int mrows = min(NB, n[s] - k * NB);
-    if (mrows == NB) mma_tile_dma<false, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem);
+    if (partial) sum_partials(acc, partial + ((long)s * gridDim.x + c) * nparts * NB * NB, nparts);
+    else if (mrows == NB) mma_tile_dma<false, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem);
     else mma_tile_dma<false, true, true>(acc, Ls, ldn, Ys, ldm, k * NB, smem, mrows);
-    const double *Bs = Bt + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
+    const double *Bs = Bt + (long)(s % bbatch) * ldn * ldm + (long)k * NB * ldm + c * NB;  // node-batched passes share -B/2
     double *Yo = Ys + (long)k * NB * ldm;
     IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] = Bs[(long)row * ldm + col] - v; })
     if (Dinv) solve_dinv_tile<false>(acc, Dinv + ((long)s * (ldn / NB) + k) * NB * NB, Yo, ldm, smem);
@@ -167,7 +244,8 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double 
 __global__ __launch_bounds__(MMA_THREADS, 2) void solve_bwd_kernel(const double *__restrict__ L,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk,
-                                                           const int *__restrict__ n, const double *__restrict__ Dinv)
+                                                           const int *__restrict__ n, const double *__restrict__ Dinv,
+                                                           const double *__restrict__ partial, int nparts)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -182,7 +260,8 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_bwd_kernel(const double 
         zero_acc(acc);
         // rows of L below n[s] are identity padding (zero in this block column): stop the k loop at n rounded to 8
         const int kend = ((n[s] + DBK - 1) / DBK) * DBK - (k + 1) * NB;
-        mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, kend, smem);
+        if (partial) sum_partials(acc, partial + ((long)s * gridDim.x + c) * nparts * NB * NB, nparts);
+        else mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, kend, smem);
         IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] -= v; })
     }
     if (Dinv) solve_dinv_tile<true>(acc, Dinv + ((long)s * (ldn / NB) + k) * NB * NB, Yo, ldm, smem);
@@ -234,11 +313,16 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void gemm_kernel(const double *__re
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 
-int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int k, int nbmax, int batch,
-                       const int *nblk, const double *dshift)
+int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int k, int nbmax, int batch, int abatch,
+                       const int *nblk, const double *dshift, double *partial, int nparts)
 {
     dim3 grid(nbmax - k, batch);
-    hipLaunchKernelGGL(chol_update_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, A, L, ldn, k, nblk, dshift);
+    if (nparts > 1 && k >= nparts) {
+        hipLaunchKernelGGL(chol_partial_kernel, dim3(nbmax - k, nparts, batch), dim3(MMA_THREADS), 0, ctx->stream, L, ldn, k, nblk, nparts, partial);
+        IMCOM_TRY(check_launch("chol_partial_kernel"));
+        hipLaunchKernelGGL(chol_update_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, A, L, ldn, k, nblk, dshift, partial, nparts, abatch);
+    } else
+        hipLaunchKernelGGL(chol_update_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, A, L, ldn, k, nblk, dshift, nullptr, 0, abatch);
     return check_launch("chol_update_kernel");
 }
 
@@ -251,19 +335,30 @@ int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int
     return check_launch("chol_trsm_kernel");
 }
 
+// nparts > 1: the K loop of the block row is dealt to nparts workgroups per tile first (split-K for small batches); kb = K blocks of the row
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
-                     int batch, const int *nblk, const int *n, const double *Dinv)
+                     int batch, int bbatch, const int *nblk, const int *n, const double *Dinv, double *partial, int nparts)
 {
     dim3 grid(ldm / NB, batch);
-    hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n, Dinv);
+    if (nparts > 1 && k >= nparts) {
+        hipLaunchKernelGGL(solve_partial_kernel<false>, dim3(ldm / NB, nparts, batch), dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, nparts, partial);
+        IMCOM_TRY(check_launch("solve_partial_kernel"));
+        hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, bbatch);
+    } else
+        hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, bbatch);
     return check_launch("solve_fwd_kernel");
 }
 
-int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int batch,
-                     const int *nblk, const int *n, const double *Dinv)
+int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int nbmax, int batch,
+                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts)
 {
     dim3 grid(ldm / NB, batch);
-    hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv);
+    if (nparts > 1 && nbmax - 1 - k >= nparts) {
+        hipLaunchKernelGGL(solve_partial_kernel<true>, dim3(ldm / NB, nparts, batch), dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, nparts, partial);
+        IMCOM_TRY(check_launch("solve_partial_kernel"));
+        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts);
+    } else
+        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0);
     return check_launch("solve_bwd_kernel");
 }
 

@@ -5,14 +5,14 @@
 namespace imcom {
 
 // gemm_f64.hip
-int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int k, int nbmax, int batch,
-                       const int *nblk, const double *dshift);
+int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int k, int nbmax, int batch, int abatch,
+                       const int *nblk, const double *dshift, double *partial, int nparts);  // nparts > 1: split-K through `partial`
 int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int k, int nbmax, int batch,
                      const int *nblk);
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
-                     int batch, const int *nblk, const int *n, const double *Dinv);  // Dinv != null: Linv[k] applied in the same launch
-int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int batch,
-                     const int *nblk, const int *n, const double *Dinv);
+                     int batch, int bbatch, const int *nblk, const int *n, const double *Dinv, double *partial, int nparts);  // Dinv != null: Linv[k] applied in the same launch
+int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int nbmax, int batch,
+                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts);
 int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, int ldm, int k, int batch,
                       const int *nblk, bool trans);
 int launch_gemm(imcom_ctx *ctx, bool akm, bool bkm, int M, int N, int K, int batch, const double *A, long lda,
