@@ -36,7 +36,8 @@ __device__ __forceinline__ void tile_index(long t, int ntile, int &ti, int &tj)
 // scattered ones -- and the chunks go global -> LDS directly (LDS-DMA, global_load_lds_dwordx4: the LDS
 // image is lane-linear, [sample][6 chunks], exactly the order the lanes are assigned in).  Row r+1 is in
 // flight while row r is consumed from the other LDS buffer.
-constexpr int SEG_W = 12;  // doubles staged per segment
+constexpr int SEG_W = 10;  // doubles staged per stencil row of a sample
+constexpr int NCH = 5;     // 16-byte chunks per stencil row
 
 #define IMCOM_GLDS16(gptr, ldsptr)                                                                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),           \
@@ -124,100 +125,88 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     }
     seg0[tid] = (int)my_seg0;  // launch_build_A checks that the table stack fits 31 bits
     rstep[tid] = my_step;
-    // A stencil row is staged as the six 16-byte chunks that cover its 10 taps at either parity.  The element step
-    // between stencil rows (+-ng) is odd, so the parity alternates from row to row: even rows all share the
-    // parity of row 0, odd rows the other one.  The chunks of a sample occupy six consecutive 16-byte LDS slots;
-    // samples 8..15 of every 16 store them rotated by one slot, which makes the 16-byte reads of a group of 16
-    // lanes hit 16 distinct bank groups (stride 96 B alone would pair lane t with t+8).
-    // Per-lane weight tables over the twelve staged doubles, in LDS slot order, for even and for odd rows:
-    const int f = (tid >> 3) & 1, p0 = (int)(my_seg0 & 1);
-    double we[12], wo[12];
+    // A stencil row is staged as the FIVE 16-byte chunks that hold exactly its 10 taps: the LDS-DMA takes 8-byte aligned
+    // global addresses, so a chunk may start on any double (round 1 fetched six aligned chunks per row and carried two
+    // zero-weight doubles: 96 instead of 80 bytes through the L2 -> CU path that bounds this kernel, and two weight
+    // tables for the alternating parity of the rows).  The five chunks of a sample are five consecutive 16-byte LDS slots:
+    // stride 80 B = 20 banks, which takes the 16 lanes of a ds_read_b128 group through all 64 banks.
+    double wt[10];
 #pragma unroll
-    for (int m = 0; m < 12; m++) {
-        const int el0 = m, el1 = (m + 10) % 12;  // staged element held by slot position m without / with the rotation
-        auto wat = [&](int e) { return (e >= 0 && e < 10) ? wx[e] : 0.0; };
-        const double w_par0 = f ? wat(el1) : wat(el0), w_par1 = f ? wat(el1 - 1) : wat(el0 - 1);
-        we[m] = active ? (p0 ? w_par1 : w_par0) : 0.0;
-        wo[m] = active ? (p0 ? w_par0 : w_par1) : 0.0;
-    }
+    for (int m = 0; m < 10; m++) wt[m] = active ? wx[m] : 0.0;
     // does any stencil of this tile end within a chunk of the end of the table stack?  (block-uniform; almost never)
-    const long my_last = my_seg0 < 0 ? 0 : (my_step > 0 ? my_seg0 + 9L * my_step : my_seg0) + 12;
+    const long my_last = my_seg0 < 0 ? 0 : (my_step > 0 ? my_seg0 + 9L * my_step : my_seg0) + 10;
     const int near_end = __syncthreads_or(my_last >= tab_elems);
-    // the six (sample, slot) pairs this thread fetches for every stencil row.  A wave stages the chunks of its
-    // own 64 samples (work item w = lane + 64 q of the wave's 384), so that producer and consumer of an LDS row are
+    // the five (sample, chunk) pairs this thread fetches for every stencil row.  A wave stages the chunks of its
+    // own 64 samples (work item w = lane + 64 q of the wave's 320), so that producer and consumer of an LDS row are
     // the same wave: no workgroup barrier in the row loop, only counted vmcnt waits, and the four waves drift freely.
-    int ae[6], ao[6], st2[6];  // first element of the chunk for the next even / odd row, and 2 * step
+    int at[NCH], st1[NCH];  // first element of the chunk for the next row, and the step between rows
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-        const int w = (tid & 63) + 64 * q, sm = (tid & ~63) + w / 6, slot = w % 6;
-        const int ch = (slot - ((sm >> 3) & 1) + 6) % 6;
+    for (int q = 0; q < NCH; q++) {
+        const int w = (tid & 63) + 64 * q, sm = (tid & ~63) + w / NCH, ch = w % NCH;
         const int e0 = seg0[sm], stp = rstep[sm];
         const bool on = e0 >= 0;  // samples without a stencil fetch element 0: harmless, and the fast path stays branch-free
-        ae[q] = on ? (e0 & ~1) + 2 * ch : 0;
-        ao[q] = on ? ((e0 + stp) & ~1) + 2 * ch : 0;
-        st2[q] = on ? 2 * stp : 0;
+        at[q] = on ? e0 + 2 * ch : 0;
+        st1[q] = on ? stp : 0;
     }
-    const int wave_base = (tid & ~63) * SEG_W;  // this wave's 64 x 12 doubles of a row buffer
-    auto stage = [&](int (&at)[6], double *buf) {  // branch-free: every lane issues its six chunk loads
+    const int wave_base = (tid & ~63) * SEG_W;  // this wave's 64 x 10 doubles of a row buffer
+    auto stage = [&](double *buf) {  // branch-free: every lane issues its five chunk loads
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
+        for (int q = 0; q < NCH; q++) {
             IMCOM_GLDS16(tables + at[q], buf + 128 * q + wave_base);  // wave-uniform LDS base; lane l lands at +2 l
-            at[q] += st2[q];
+            at[q] += st1[q];
         }
     };
-    auto stage_checked = [&](int (&at)[6], double *buf) {  // tiles whose stencils reach the end of the table stack
+    auto stage_checked = [&](double *buf) {  // tiles whose stencils reach the end of the table stack
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
+        for (int q = 0; q < NCH; q++) {
             double *dst = buf + 128 * q + wave_base;
             const long a_ = at[q];
-            if (a_ + 1 < tab_elems) IMCOM_GLDS16(tables + a_, dst);
-            else { dst[2 * (tid & 63)] = (a_ < tab_elems) ? tables[a_] : 0.0; dst[2 * (tid & 63) + 1] = 0.0; }
-            at[q] += st2[q];
+            if (a_ >= 0 && a_ + 1 < tab_elems) IMCOM_GLDS16(tables + a_, dst);
+            else { dst[2 * (tid & 63)] = (a_ >= 0 && a_ < tab_elems) ? tables[a_] : 0.0; dst[2 * (tid & 63) + 1] = 0.0; }
+            at[q] += st1[q];
         }
     };
-    auto consume = [&](const double *buf, const double (&wt)[12], double wyr) {
+    auto consume = [&](const double *buf, double wyr) {
         const f64x2 *row = (const f64x2 *)(buf + tid * SEG_W);
-        f64x2 c[6];
+        f64x2 c[NCH];
 #pragma unroll
-        for (int q = 0; q < 6; q++) c[q] = row[q];
+        for (int q = 0; q < NCH; q++) c[q] = row[q];
         double strip = 0.0;
 #pragma unroll
-        for (int m = 0; m < 12; m++) strip += wt[m] * c[m >> 1][m & 1];
+        for (int m = 0; m < 10; m++) strip += wt[m] * c[m >> 1][m & 1];
         val += strip * wyr;
     };
     if (!near_end) {
-        // One row (six DMA instructions of this wave) is in flight while the previous one is consumed: vmcnt(6)
+        // One row (five DMA instructions of this wave) is in flight while the previous one is consumed: vmcnt(5)
         // = the older row has landed.  lgkmcnt(0) before a buffer is refilled: its LDS reads have returned.
-        stage(ae, seg[0]);
-        if (A_RING > 2) stage(ao, seg[1]);
+        stage(seg[0]);
+        if (A_RING > 2) stage(seg[1]);
 #pragma unroll
         for (int r = 0; r < 10; r++) {
             const int ahead = r + A_RING - 1;  // the row issued now; rows r+1 .. ahead are in flight while r is consumed
-            if (ahead < 10) {
-                if (ahead & 1) stage(ao, seg[ahead % A_RING]);
-                else stage(ae, seg[ahead % A_RING]);
-            }
+            if (ahead < 10) stage(seg[ahead % A_RING]);
             const int inflight = (ahead < 10 ? ahead : 9) - r;
-            if (inflight == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (inflight == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (inflight == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (inflight == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (r & 1) consume(seg[r % A_RING], wo, wy[r]);
-            else consume(seg[r % A_RING], we, wy[r]);
+            consume(seg[r % A_RING], wy[r]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     } else {
-        stage_checked(ae, seg[0]);
+        stage_checked(seg[0]);
         __syncthreads();
 #pragma unroll 1
         for (int rp = 0; rp < 5; rp++) {
-            stage_checked(ao, seg[1]);
+            stage_checked(seg[1]);
             double wa = 0.0, wb = 0.0;
 #pragma unroll
             for (int q = 0; q < 5; q++) { wa = rp == q ? wy[2 * q] : wa; wb = rp == q ? wy[2 * q + 1] : wb; }
-            consume(seg[0], we, wa);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            consume(seg[0], wa);
             __syncthreads();
-            if (rp < 4) stage_checked(ae, seg[0]);
-            consume(seg[1], wo, wb);
+            if (rp < 4) stage_checked(seg[0]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            consume(seg[1], wb);
             __syncthreads();
         }
     }
