@@ -14,6 +14,8 @@
 
 namespace imcom {
 
+typedef double f64x2u __attribute__((ext_vector_type(2), aligned(8)));  // two doubles at any double boundary
+
 // ------------------------------------------------------------------------------------------------
 __global__ void d5512_getw_kernel(const double *__restrict__ fh, long n, double *__restrict__ w)
 {
@@ -121,11 +123,16 @@ __device__ __forceinline__ void grid_pixel(const double *__restrict__ f, int ngy
         // x-pass over the touched table rows
         for (int t = tid; t < nrows * nxo; t += nth) {
             const int r = t / nxo, ix = t - r * nxo;
-            const double *row = f + (long)(rlo + r) * ngx + (xis[ix] - 4);
+            // the ten taps as five 16-byte loads at an 8-byte aligned address (global memory takes them): half the
+            // load instructions of ten 8-byte ones through the texture path that bounds this pass
+            const f64x2u *row = (const f64x2u *)(f + (long)(rlo + r) * ngx + (xis[ix] - 4));
             const double *w = wxs + 10 * ix;
+            f64x2u c[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) c[q] = row[q];
             double strip = 0.0;
 #pragma unroll
-            for (int j = 0; j < 10; j++) strip += w[j] * row[j];
+            for (int j = 0; j < 10; j++) strip += w[j] * c[j >> 1][j & 1];
             tmp[t] = strip;
         }
         __syncthreads();
