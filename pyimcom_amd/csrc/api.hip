@@ -149,6 +149,7 @@ static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
     // repair path (lakernel.py:262-279): eigenvalues of ONE stamp's A at a time
     p.add(eigh_ws_bytes(1, Np, false) + (size_t)Np * Np * 8 + (size_t)Np * 8 + 1024);
     p.add(splitk_bytes((int)eb, Np, mp));
+    if (nv == 1) p.add((size_t)batch * 2 * nb * mp * 8 * 2);  // per-block-row column sums of Y^2 and X^2
     return p.total + 4096;
 }
 
@@ -194,7 +195,12 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     const size_t pbytes = splitk_bytes(eb, Np, mp);
     double *partial = pbytes ? (double *)ws_take(ctx, pbytes) : nullptr;
     const int parts_solve = partial ? splitk_parts(eb, mp / NB) : 1;
-    if (!L || !Dinv || !Y || !dshift || !ints || !inc || !dbl || !kappaC_dev || (nv > 1 && (!Dp || !Npq || !W)) || (pbytes && !partial)) {
+    // single kappa with the diagonal blocks fused into the solve launches: the launches leave T (float32) and the column sums
+    // the maps need behind, and the pass of finalize_single_kernel over X and -B/2 (27 GB per 256 cfg-2 stamps) is not needed
+    static const bool unfused_solve = getenv("IMCOM_SOLVE_UNFUSED") != nullptr;
+    double *colsums = (nv == 1 && !unfused_solve) ? (double *)ws_take(ctx, (size_t)batch * 2 * nbmax_all * mp * 8 * 2) : nullptr;
+    double *Dpart = colsums, *Npart = colsums ? colsums + (size_t)batch * 2 * nbmax_all * mp : nullptr;
+    if (!L || !Dinv || !Y || !dshift || !ints || !inc || !dbl || !kappaC_dev || (nv > 1 && (!Dp || !Npq || !W)) || (pbytes && !partial) || (nv == 1 && !unfused_solve && !colsums)) {
         set_error("internal: workspace plan too small");
         return IMCOM_ERR_NOMEM;
     }
@@ -254,17 +260,19 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             static const bool unfused = getenv("IMCOM_SOLVE_UNFUSED") != nullptr;
             const double *Dfused = unfused ? nullptr : Dinv;
             for (int k = 0; k < nbmax; k++) {
-                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, eb, batch, nblk_dev, n_dev, Dfused, partial, parts_solve)); }
+                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, eb, batch, nblk_dev, n_dev, Dfused, partial, parts_solve, Dpart)); }
                 if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nblk_dev, false)); }
             }
             for (int k = nbmax - 1; k >= 0; k--) {
-                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, nbmax, eb, nblk_dev, n_dev, Dfused, partial, parts_solve)); }
+                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, nbmax, eb, nblk_dev, n_dev, Dfused, partial, parts_solve, Npart, Tt)); }
                 if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nblk_dev, true)); }
             }
         }
         {
             ProfScope ps(ctx, "finalize");
-            if (nv == 1)
+            if (nv == 1 && colsums)
+                IMCOM_TRY(launch_finalize_fused(ctx, Dpart, Npart, Np, mp, m, n_dev, nblk_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch));
+            else if (nv == 1)
                 IMCOM_TRY(launch_finalize_single(ctx, Y, Bt, Np, mp, m, n_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch));
             else
                 IMCOM_TRY(launch_multi(ctx, Y, node_stride, Bt, Np, mp, m, n_dev, nv, kappaC_dev, C_dev, ucmin, smax, Dp, Npq, W, Tt, UC, Sigma, kappa, batch));

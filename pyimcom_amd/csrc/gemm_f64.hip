@@ -215,12 +215,32 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_partial_kernel(const dou
     store_partial(acc, partial + (((long)s * gridDim.x + c) * nparts + p) * NB * NB);
 }
 
+// Column sums of squares of the tile a workgroup has just finished (its accumulators, any row map): out[wm * stride + column].
+// They let the single-kappa maps do without a pass over X and -B/2: D_a = sum_i B_ai T_ai = b^T (A + kappa)^-1 b = |L^-1 b|^2
+// = sum_i Y_ia^2 (forward solve), N_a = sum_i X_ia^2 (backward solve); the two wave rows keep separate partial sums.
+__device__ __forceinline__ void tile_col_sumsq(const f64x4 (&acc)[4][MMA_NJ], double *__restrict__ out, int stride)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / MMA_WN, wn = wave % MMA_WN;
+#pragma unroll
+    for (int j = 0; j < MMA_NJ; j++) {
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) q += acc[i][j][r] * acc[i][j][r];
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 16) out[(long)wm * stride + wn * (16 * MMA_NJ) + j * 16 + lane] = q;
+    }
+}
+
 __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double *__restrict__ L,
                                                            const double *__restrict__ Bt,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk, const int *__restrict__ n,
                                                            const double *__restrict__ Dinv,
-                                                           const double *__restrict__ partial, int nparts, int bbatch)
+                                                           const double *__restrict__ partial, int nparts, int bbatch,
+                                                           double *__restrict__ Dpart)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -238,14 +258,19 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double 
     const double *Bs = Bt + (long)(s % bbatch) * ldn * ldm + (long)k * NB * ldm + c * NB;  // node-batched passes share -B/2
     double *Yo = Ys + (long)k * NB * ldm;
     IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] = Bs[(long)row * ldm + col] - v; })
-    if (Dinv) solve_dinv_tile<false>(acc, Dinv + ((long)s * (ldn / NB) + k) * NB * NB, Yo, ldm, smem);
+    if (Dinv) {
+        solve_dinv_tile<false>(acc, Dinv + ((long)s * (ldn / NB) + k) * NB * NB, Yo, ldm, smem);
+        // partial D of this block row: Dpart[stamp][2 k + wm][ldm]
+        if (Dpart) tile_col_sumsq(acc, Dpart + ((long)s * 2 * (ldn / NB) + 2 * k) * ldm + c * NB, ldm);
+    }
 }
 
 __global__ __launch_bounds__(MMA_THREADS, 2) void solve_bwd_kernel(const double *__restrict__ L,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk,
                                                            const int *__restrict__ n, const double *__restrict__ Dinv,
-                                                           const double *__restrict__ partial, int nparts)
+                                                           const double *__restrict__ partial, int nparts,
+                                                           double *__restrict__ Npart, float *__restrict__ Tt)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -264,7 +289,14 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_bwd_kernel(const double 
         else mma_tile_dma<true, true>(acc, Lc, ldn, Ys + (long)(k + 1) * NB * ldm, ldm, kend, smem);
         IMCOM_FOR_ACC(row, col, v, { Yo[(long)row * ldm + col] -= v; })
     }
-    if (Dinv) solve_dinv_tile<true>(acc, Dinv + ((long)s * (ldn / NB) + k) * NB * NB, Yo, ldm, smem);
+    if (Dinv) {
+        solve_dinv_tile<true>(acc, Dinv + ((long)s * (ldn / NB) + k) * NB * NB, Yo, ldm, smem);
+        if (Npart) {  // X_k is final: its float32 copy (T, input-pixel-major) and its share of N_a = sum_i T_ai^2
+            tile_col_sumsq(acc, Npart + ((long)s * 2 * (ldn / NB) + 2 * k) * ldm + c * NB, ldm);
+            float *To = Tt + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
+            IMCOM_FOR_ACC_TRI(row, col, v, { To[(long)row * ldm + col] = (float)v; })
+        }
+    }
 }
 
 // Y_k <- Linv[k] Y_k (TRANS=false) or Linv[k]^T Y_k (TRANS=true), in place.
@@ -337,28 +369,28 @@ int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int
 
 // nparts > 1: the K loop of the block row is dealt to nparts workgroups per tile first (split-K for small batches); kb = K blocks of the row
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
-                     int batch, int bbatch, const int *nblk, const int *n, const double *Dinv, double *partial, int nparts)
+                     int batch, int bbatch, const int *nblk, const int *n, const double *Dinv, double *partial, int nparts, double *Dpart)
 {
     dim3 grid(ldm / NB, batch);
     if (nparts > 1 && k >= nparts) {
         hipLaunchKernelGGL(solve_partial_kernel<false>, dim3(ldm / NB, nparts, batch), dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, nparts, partial);
         IMCOM_TRY(check_launch("solve_partial_kernel"));
-        hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, bbatch);
+        hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, bbatch, Dpart);
     } else
-        hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, bbatch);
+        hipLaunchKernelGGL(solve_fwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Bt, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, bbatch, Dpart);
     return check_launch("solve_fwd_kernel");
 }
 
 int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int nbmax, int batch,
-                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts)
+                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts, double *Npart, float *Tt)
 {
     dim3 grid(ldm / NB, batch);
     if (nparts > 1 && nbmax - 1 - k >= nparts) {
         hipLaunchKernelGGL(solve_partial_kernel<true>, dim3(ldm / NB, nparts, batch), dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, nparts, partial);
         IMCOM_TRY(check_launch("solve_partial_kernel"));
-        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts);
+        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, Npart, Tt);
     } else
-        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0);
+        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, Npart, Tt);
     return check_launch("solve_bwd_kernel");
 }
 

@@ -129,6 +129,34 @@ __global__ __launch_bounds__(256) void finalize_single_kernel(const double *__re
     }
 }
 
+// The same maps when the triangular solves have already left T (float32) and the per-block-row column sums behind
+// (gemm_f64.hip, tile_col_sumsq): D_a = sum over the forward partials, N_a = sum over the backward ones, in a fixed order.
+// Rows of Tt beyond the stamp's last 128-block (shorter stamps of a ragged batch) are zeroed here.
+__global__ __launch_bounds__(256) void finalize_fused_kernel(const double *__restrict__ Dpart, const double *__restrict__ Npart,
+                                                             int ldn, int ldm, int m, const int *__restrict__ n,
+                                                             const int *__restrict__ nblk, const double *__restrict__ kap,
+                                                             const double *__restrict__ Cs, float *__restrict__ Tt,
+                                                             float *__restrict__ UC, float *__restrict__ Sigma,
+                                                             float *__restrict__ kappa)
+{
+    const int s = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= ldm) return;
+    const int ns = n[s], nb = nblk[s], np = 2 * (ldn / NB);
+    for (long i = (long)nb * NB; i < ldn; i++) Tt[((long)s * ldn + i) * ldm + a] = 0.0f;
+    if (a >= m) return;
+    double D = 0.0, N = 0.0;
+    for (int p = 0; p < 2 * nb; p++) {
+        D += Dpart[((long)s * np + p) * ldm + a];
+        N += Npart[((long)s * np + p) * ldm + a];
+    }
+    const long o = (long)s * m + a;
+    if (ns == 0) { UC[o] = 1.0f; Sigma[o] = 0.0f; kappa[o] = 1.0f; return; }  // lakernel.py:110-119
+    const double k = kap[s], C = Cs[s];
+    kappa[o] = (float)k;
+    Sigma[o] = (float)N;
+    UC[o] = (float)(1.0 - (k * N + D) / C);
+}
+
 // ------------------------------------------------------------------------------------------------
 // routine.py:433-484 on tiny nv x nv systems held in thread-private arrays
 constexpr int MAXNV = 8;
@@ -611,6 +639,14 @@ int launch_finalize_single(imcom_ctx *ctx, const double *X, const double *Bt, in
 {
     hipLaunchKernelGGL(finalize_single_kernel, dim3(ldm / 64, batch), dim3(256), 0, ctx->stream, X, Bt, ldn, ldm, m, n, kap, Cs, Tt, UC, Sigma, kappa);
     return check_launch("finalize_single_kernel");
+}
+
+int launch_finalize_fused(imcom_ctx *ctx, const double *Dpart, const double *Npart, int ldn, int ldm, int m, const int *n,
+                          const int *nblk, const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa, int batch)
+{
+    hipLaunchKernelGGL(finalize_fused_kernel, dim3((ldm + 255) / 256, batch), dim3(256), 0, ctx->stream, Dpart, Npart, ldn, ldm, m, n, nblk, kap, Cs,
+                       Tt, UC, Sigma, kappa);
+    return check_launch("finalize_fused_kernel");
 }
 
 int launch_multi(imcom_ctx *ctx, const double *Xs, long node_stride, const double *Bt, int ldn, int ldm, int m, const int *n,

@@ -10,9 +10,10 @@ int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int 
 int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int k, int nbmax, int batch,
                      const int *nblk);
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
-                     int batch, int bbatch, const int *nblk, const int *n, const double *Dinv, double *partial, int nparts);  // Dinv != null: Linv[k] applied in the same launch
+                     int batch, int bbatch, const int *nblk, const int *n, const double *Dinv, double *partial, int nparts,
+                     double *Dpart);  // Dinv != null: Linv[k] applied in the same launch; Dpart: column sums of Y^2 per block row
 int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int nbmax, int batch,
-                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts);
+                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts, double *Npart, float *Tt);
 int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, int ldm, int k, int batch,
                       const int *nblk, bool trans);
 int launch_gemm(imcom_ctx *ctx, bool akm, bool bkm, int M, int N, int K, int batch, const double *A, long lda,
@@ -34,6 +35,9 @@ int launch_pack_Bt(imcom_ctx *ctx, const double *B, long ldb, int m, const int *
                    int batch);
 int launch_unpack_T(imcom_ctx *ctx, const float *Tt, int ldp, int ldm, const int *n, int m, float *T, long ldt,
                     int batch);
+int launch_finalize_fused(imcom_ctx *ctx, const double *Dpart, const double *Npart, int ldn, int ldm, int m, const int *n,
+                          const int *nblk, const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa,
+                          int batch);
 int launch_finalize_single(imcom_ctx *ctx, const double *X, const double *Bt, int ldn, int ldm, int m, const int *n,
                            const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa,
                            int batch);
