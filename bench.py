@@ -2,7 +2,9 @@
 """Headline benchmark: postage-stamps/s of the IMCOM stamp path on MI355X (BASELINE.json metric).
 
 A "step" = one pass of the hot path (A build, B build, blocked Cholesky, T solve, U/C-Sigma-kappa maps,
-coaddition epilogue) over one batch of synthetic postage stamps that are already resident in HBM.
+coaddition epilogue) over one batch of synthetic postage stamps that are already resident in HBM.  (Since round 2 the
+single-kappa maps ride in the solve launches: the forward launches leave the column sums of Y^2, the backward ones T in
+float32 and the sums of X^2, so the "finalize" stage is a reduction of a few MB and the solve family carries that work.)
 Workload = BASELINE.json configs[1] ("cfg2": 48x48-output stamps, 6 exposures, analytic Roman-like
 PSF, fp64, Cholesky kappa/C = 6e-4).  One process per GPU, no data-path collective
 (blocks/stamps are independent): weak scaling, each rank runs its own batch.
