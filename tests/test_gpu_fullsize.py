@@ -175,3 +175,43 @@ def test_cfg2_block_groups_equal_single_group():
         x, y = one.maps[k].cpu().numpy(), grp.maps[k].cpu().numpy()
         assert np.allclose(x, y, rtol=1e-4, atol=1e-7 * np.abs(x).max()), k
     assert np.allclose(one.T_weightmap.cpu().numpy(), grp.T_weightmap.cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("kC", [(6e-4,), (1e-5, 1e-4, 1e-3)])
+def test_kernel_class_seam_full_size_vs_oracle(kC):
+    """ONE cfg-2 stamp (N ~ 2.2k, m = 2304) through the drop-in kernel class over host buffers -- the small-batch path of the
+    library: split-K partial products in the Cholesky updates and the solves (8 parts per tile), the kappa nodes of a multi-kappa call as one
+    node-major pass -- against the oracle's CholKernel on the same A, -B/2, C."""
+    import torch
+
+    from oracle import oracle as orc
+    from pyimcom_amd import synth
+    from pyimcom_amd.lakernel import HipCholKernel
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+    from tests.golden.make_golden import make_outst
+
+    cfg = synth.CONFIGS["cfg2"]
+    st = synth.make_stamp(cfg, 11)
+    psfs, target = synth.make_psfs(cfg, st.n_expo)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    sb = StampBatch(cfg, [st], tabs)
+    sb.build()
+    torch.cuda.synchronize()
+    n, m = st.n, cfg.m
+    A = sb.A[0, :n, :n].cpu().numpy().copy()
+    mB = np.ascontiguousarray(sb.Bt[0, :n, :m].cpu().numpy().T)[None]
+    C = np.array([tabs.C])
+    kCa = np.array(kC)
+    o = make_outst(A.copy(), mB.copy(), C, cfg.n2f, kCa, cfg.uctarget, cfg.sigmamax)
+    K = HipCholKernel(o)
+    K()
+    assert np.array_equal(o.sysmata, A) and int(K.info[0]) == 0
+    To, Uo, So, ko, _ = orc.chol_kernel(A, mB[0], float(C[0]), kCa, cfg.uctarget, cfg.sigmamax)
+    lam = np.linalg.eigvalsh(A)
+    cond = (lam[-1] + kCa[0] * C[0]) / (max(lam[0], 0.0) + kCa[0] * C[0])
+    scale = 1.0 if len(kC) == 1 else 4.0  # the nv x nv reduced systems of build_reduced_T amplify the solve's rounding (parity.check_batch)
+    assert np.abs(o.T[0] - To).max() <= (1e-6 + 50 * cond * 2.2e-16) * scale * np.abs(To).max()
+    s2 = (cfg.n2f, cfg.n2f)
+    assert np.allclose(o.UC[0], Uo.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)
+    assert np.allclose(o.Sigma[0], So.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)
+    assert np.allclose(o.kappa[0], ko.reshape(s2), rtol=1e-5, atol=0)
