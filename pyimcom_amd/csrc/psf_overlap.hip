@@ -5,8 +5,9 @@
 //     table[p,q] = roll(irfft2(rfft2(pad(psf1[p])) * conj(rfft2(pad(psf2[q])))), nc)[:nsamp, :nsamp]
 // written with the 6-pixel zero border the interpolators expect.
 //
-// Two formulations.  (1) Butterfly path (default whenever nfft = product of 4, 2, 3, 5 and <= 1024): mixed-radix
-// Stockham FFTs in LDS, see below -- 7 us per cfg-2 table (nfft 768).
+// Two formulations.  (1) Butterfly path (default whenever nfft <= 1024 is a product of 16, 8, 4, 2, 3, 5): line FFTs with
+// one wavefront per line, butterflies in registers, the line exchanged through the wave's LDS slice without workgroup
+// barriers (fft_lines.h), see below.
 // (2) Dense-DFT path (general fallback, IMCOM_PSF_OVERLAP=gemm): the zero-padded 2-D DFTs as dense real matrix
 // products with exact twiddle matrices (integer argument reduction mod nfft, then cos/sin of a multiple of
 // pi/nfft) on the fp64 MFMA tile engine of gemm_f64.hip; only the kept nsamp x nsamp window of the inverse is
@@ -16,6 +17,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "fft_lines.h"
 #include "launchers.h"
 
 namespace imcom {
@@ -109,311 +111,179 @@ __global__ void crop_table_kernel(const double *__restrict__ win, int Wp, int ns
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Butterfly path: mixed-radix Stockham FFTs in LDS (radices 4, 2, 3, 5), used whenever nfft factors into them and
-// the lines fit (nfft <= 1024); the dense-DFT GEMM form above stays as the general fallback and as an independent
-// cross-check (IMCOM_PSF_OVERLAP=gemm).  A workgroup transforms L (8 or 4) lines at once, all in one LDS buffer: in
-// every stage each thread first reads all of its butterflies into registers, then -- after a barrier -- writes
-// them back in Stockham order, so no second buffer and no digit reversal are needed.
-//   forward:  rows two-for-one (two real PSF rows ride as one complex line), then columns on tiles of L
-//   inverse:  columns of R1 conj(R2) (the product is formed on load), kept rows only; then rows two-for-one from
-//             the Hermitian half back to two real window rows, rolled by nc and cropped on store.
-// lines per workgroup: template parameter L of the kernels, 8 where the plan allows (the per-workgroup costs -- twiddle
-// table, barriers -- are shared by more lines: 0.39 against 0.43 ms for 36 cfg-2 tables), else 4
-constexpr int FFT_MAXIT = 8;   // butterflies per thread and stage (nfft * L / (radix * 256) <= 8)
-constexpr int FFT_MAXN = 1024;
-constexpr int FFT_NT = 1024;    // threads per workgroup of the line kernels
-
-struct FftPlan { int n, nst, radix[12], lines; };
-
-typedef double2 cplx;
-__device__ __forceinline__ cplx cmulf(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-
-template <int R, bool INV> __device__ __forceinline__ void small_dft(cplx (&v)[R]);
-template <> __device__ __forceinline__ void small_dft<2, false>(cplx (&v)[2])
-{ const cplx a = v[0], b = v[1]; v[0] = make_double2(a.x + b.x, a.y + b.y); v[1] = make_double2(a.x - b.x, a.y - b.y); }
-template <> __device__ __forceinline__ void small_dft<2, true>(cplx (&v)[2]) { small_dft<2, false>(v); }
-template <bool INV> __device__ __forceinline__ void dft4(cplx (&v)[4])
+// Butterfly path: line FFTs with one wavefront per line (fft_lines.h), used whenever nfft <= 1024 factors into 16, 8, 4,
+// 2, 3, 5; the dense-DFT GEMM form above stays as the general fallback and as an independent cross-check
+// (IMCOM_PSF_OVERLAP=gemm).
+//   forward:  rows two-for-one (two real PSF rows ride as one complex line), then the columns of the half spectrum
+//   inverse:  columns of R1 conj(R2) (the product is formed in the first stage's loads), kept rows only (stored by the
+//             last stage, rolled by nc); then rows two-for-one from the Hermitian half back to two real window rows,
+//             rolled by nc, cropped and scaled on store, inside the 6-sample zero border the same kernel writes.
+// Workgroups are ordered pair-fastest: the workgroups in flight work on the same few spectrum columns of different
+// pairs, so a spectrum column is fetched from HBM once per L2 instead of once per table that uses it.
+__global__ void fft_twiddle_kernel(FftPlan pl, cplx *__restrict__ tw)
 {
-    const cplx t0 = make_double2(v[0].x + v[2].x, v[0].y + v[2].y), t1 = make_double2(v[0].x - v[2].x, v[0].y - v[2].y);
-    const cplx t2 = make_double2(v[1].x + v[3].x, v[1].y + v[3].y), d = make_double2(v[1].x - v[3].x, v[1].y - v[3].y);
-    const cplx t3 = INV ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);  // d * (+i) or d * (-i)
-    v[0] = make_double2(t0.x + t2.x, t0.y + t2.y);
-    v[2] = make_double2(t0.x - t2.x, t0.y - t2.y);
-    v[1] = make_double2(t1.x + t3.x, t1.y + t3.y);
-    v[3] = make_double2(t1.x - t3.x, t1.y - t3.y);
-}
-template <> __device__ __forceinline__ void small_dft<4, false>(cplx (&v)[4]) { dft4<false>(v); }
-template <> __device__ __forceinline__ void small_dft<4, true>(cplx (&v)[4]) { dft4<true>(v); }
-template <bool INV> __device__ __forceinline__ void dft3(cplx (&v)[3])
-{
-    const double s3 = INV ? 0.8660254037844386 : -0.8660254037844386;  // sin(-+ 2 pi / 3)
-    const cplx t = make_double2(v[1].x + v[2].x, v[1].y + v[2].y), u = make_double2(v[1].x - v[2].x, v[1].y - v[2].y);
-    const cplx m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y), iu = make_double2(-s3 * u.y, s3 * u.x);  // i s3 u
-    v[0] = make_double2(v[0].x + t.x, v[0].y + t.y);
-    v[1] = make_double2(m.x + iu.x, m.y + iu.y);
-    v[2] = make_double2(m.x - iu.x, m.y - iu.y);
-}
-template <> __device__ __forceinline__ void small_dft<3, false>(cplx (&v)[3]) { dft3<false>(v); }
-template <> __device__ __forceinline__ void small_dft<3, true>(cplx (&v)[3]) { dft3<true>(v); }
-template <bool INV> __device__ __forceinline__ void dft5(cplx (&v)[5])
-{
-    // y_u = sum_t v_t w^(u t), w = exp(-+ 2 pi i / 5)
-    const double c1 = 0.30901699437494745, c2 = -0.8090169943749475;
-    const double s1 = INV ? 0.9510565162951535 : -0.9510565162951535, s2 = INV ? 0.5877852522924731 : -0.5877852522924731;
-    const cplx a = make_double2(v[1].x + v[4].x, v[1].y + v[4].y), b = make_double2(v[1].x - v[4].x, v[1].y - v[4].y);
-    const cplx c = make_double2(v[2].x + v[3].x, v[2].y + v[3].y), d = make_double2(v[2].x - v[3].x, v[2].y - v[3].y);
-    const cplx m1 = make_double2(v[0].x + c1 * a.x + c2 * c.x, v[0].y + c1 * a.y + c2 * c.y);
-    const cplx m2 = make_double2(v[0].x + c2 * a.x + c1 * c.x, v[0].y + c2 * a.y + c1 * c.y);
-    const cplx n1 = make_double2(-(s1 * b.y + s2 * d.y), s1 * b.x + s2 * d.x);  // i (s1 b + s2 d)
-    const cplx n2 = make_double2(-(s2 * b.y - s1 * d.y), s2 * b.x - s1 * d.x);  // i (s2 b - s1 d)
-    v[0] = make_double2(v[0].x + a.x + c.x, v[0].y + a.y + c.y);
-    v[1] = make_double2(m1.x + n1.x, m1.y + n1.y);
-    v[4] = make_double2(m1.x - n1.x, m1.y - n1.y);
-    v[2] = make_double2(m2.x + n2.x, m2.y + n2.y);
-    v[3] = make_double2(m2.x - n2.x, m2.y - n2.y);
-}
-template <> __device__ __forceinline__ void small_dft<5, false>(cplx (&v)[5]) { dft5<false>(v); }
-template <> __device__ __forceinline__ void small_dft<5, true>(cplx (&v)[5]) { dft5<true>(v); }
-
-// one Stockham stage of radix R on L lines of length n in `buf` ([line][n]); Ns = product of the earlier radices;
-// tw[k] = exp(-2 pi i k / n)
-template <int R, bool INV, int L>
-__device__ __forceinline__ void fft_stage(cplx *buf, int n, int Ns, const cplx *tw)
-{
-    // butterfly j of a line is handled by thread j mod 256, line after line: no index divisions (fft_plan guarantees
-    // n / R <= 256 * FFT_MAXIT / L); Ns is a power of two until the first radix-3 / 5 stage
-    // the workgroup is FFT_NT / 256 groups of 256 threads, each taking its share of the lines (sixteen waves per CU hide
-    // the LDS latency better than four with four times the butterflies each: 0.31 -> 0.25 ms for 36 cfg-2 tables)
-    constexpr int Q = FFT_MAXIT / L, LH = L / (FFT_NT / 256);
-    const int nb = n / R, step = n / (Ns * R), tid = threadIdx.x & 255, l0 = (threadIdx.x >> 8) * LH;
-    const bool pow2 = (Ns & (Ns - 1)) == 0;
-    cplx v[LH * Q][R];
-#pragma unroll
-    for (int lh = 0; lh < LH; lh++)
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int j = tid + q * 256, line = l0 + lh;
-            if (j < nb) {
-                const int k = pow2 ? (j & (Ns - 1)) : j % Ns;
-                const cplx *x = buf + line * n;
-#pragma unroll
-                for (int t = 0; t < R; t++) {
-                    cplx a = x[j + t * nb];
-                    if (t > 0) {
-                        cplx w = tw[t * k * step];
-                        if (INV) w.y = -w.y;
-                        a = cmulf(a, w);
-                    }
-                    v[lh * Q + q][t] = a;
-                }
-                small_dft<R, INV>(v[lh * Q + q]);
-            }
-        }
-    __syncthreads();
-#pragma unroll
-    for (int lh = 0; lh < LH; lh++)
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int j = tid + q * 256, line = l0 + lh;
-            if (j < nb) {
-                const int k = pow2 ? (j & (Ns - 1)) : j % Ns;
-                cplx *x = buf + line * n + (j - k) * R + k;
-#pragma unroll
-                for (int u = 0; u < R; u++) x[u * Ns] = v[lh * Q + q][u];
-            }
-        }
-    __syncthreads();
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= pl.twn) return;
+    int s = 1, Ns = pl.radix[0];
+    while (s + 1 < pl.nst && e >= pl.twoff[s + 1]) { Ns *= pl.radix[s]; s++; }
+    const int local = e - pl.twoff[s], t = local / Ns + 1, k = local - (t - 1) * Ns;
+    double c, sn;
+    twiddle((long)t * k * (pl.n / (Ns * pl.radix[s])), pl.n, &c, &sn);
+    tw[e] = make_double2(c, -sn);
 }
 
-template <bool INV, int L>
-__device__ __forceinline__ void fft_lines(cplx *buf, const FftPlan &pl, const cplx *tw)
-{
-    int Ns = 1;
-    for (int st = 0; st < pl.nst; st++) {
-        const int r = pl.radix[st];
-        if (r == 4) fft_stage<4, INV, L>(buf, pl.n, Ns, tw);
-        else if (r == 2) fft_stage<2, INV, L>(buf, pl.n, Ns, tw);
-        else if (r == 3) fft_stage<3, INV, L>(buf, pl.n, Ns, tw);
-        else fft_stage<5, INV, L>(buf, pl.n, Ns, tw);
-        Ns *= r;
-    }
-}
-
-__global__ void fft_twiddle_kernel(int n, cplx *__restrict__ tw)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    double c, s;
-    twiddle(k, n, &c, &s);
-    tw[k] = make_double2(c, -s);
-}
+#define IMCOM_WF_PROLOGUE                                                                        \
+    extern __shared__ cplx fbuf[];                                                               \
+    const int n = pl.n, nh = n / 2 + 1, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  \
+    cplx *twl = fbuf + pl.waves * pl.npad; /* the stage tables ride in LDS behind the lines */   \
+    for (int e = threadIdx.x; e < pl.twn; e += blockDim.x) twl[e] = tw[e];                       \
+    __syncthreads();                                                                             \
+    cplx *line = fbuf + wave * pl.npad
 
 // forward, along x: rows 2l, 2l+1 of PSF p as one complex line; Y1[p][kx][row], kx < nh
-template <int L>
-__global__ __launch_bounds__(FFT_NT) void fft_fwd_rows_kernel(const double *__restrict__ psf, int ns, FftPlan pl,
-                                                           const cplx *__restrict__ tw, cplx *__restrict__ Y1)
+__global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_fwd_rows_kernel(const double *__restrict__ psf, int ns, FftPlan pl,
+                                                            const cplx *__restrict__ tw, cplx *__restrict__ Y1)
 {
-    extern __shared__ cplx fbuf[];
-    const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y;
-    cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
-    for (int e = threadIdx.x; e < n; e += FFT_NT) twl[e] = tw[e];
-    const double *img = psf + (long)p * ns * ns;
-#pragma unroll
-    for (int line = 0; line < L; line++)
-#pragma unroll 3
-        for (int x = threadIdx.x; x < n; x += FFT_NT) {
-        const int e = line * n + x, r0 = 2 * (blockIdx.x * L + line);
-        double re = 0.0, im = 0.0;
-        if (x < ns) {
-            if (r0 < ns) re = img[(long)r0 * ns + x];
-            if (r0 + 1 < ns) im = img[(long)(r0 + 1) * ns + x];
-        }
-        fbuf[e] = make_double2(re, im);
-    }
-    __syncthreads();
-    fft_lines<false, L>(fbuf, pl, twl);
-    for (int e = threadIdx.x; e < L * nh; e += FFT_NT) {  // Y1 is stored [kx][row]: the 2 L rows of this block are contiguous
-        const int k = e / L, line = e - k * L, r0 = 2 * (blockIdx.x * L + line);
-        if (r0 >= ns) continue;
-        const cplx zk = fbuf[line * n + k], zm = fbuf[line * n + (k ? n - k : 0)];
-        Y1[((long)p * nh + k) * ns + r0] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
-        if (r0 + 1 < ns) Y1[((long)p * nh + k) * ns + r0 + 1] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+    IMCOM_WF_PROLOGUE;
+    const int p = blockIdx.x, r0 = 2 * (blockIdx.y * pl.waves + wave), lane = threadIdx.x & 63;
+    if (r0 >= ns) return;
+    const double *row0 = psf + ((long)p * ns + r0) * ns, *row1 = row0 + ns;
+    const bool two = r0 + 1 < ns;
+    auto load0 = [&](int x) { return x < ns ? make_double2(row0[x], two ? row1[x] : 0.0) : make_double2(0.0, 0.0); };
+    auto keep = [line](int i, cplx v) { line[wf_swz(i)] = v; };
+    wf_line<false>(line, twl, pl, load0, keep);
+    // z = FFT(a + i b) of two real rows: A_k = (z_k + conj z_{n-k}) / 2, B_k = (z_k - conj z_{n-k}) / (2 i)
+    for (int k = lane; k < nh; k += 64) {
+        const cplx zk = line[wf_swz(k)], zm = line[wf_swz(k ? n - k : 0)];
+        cplx *dst = Y1 + ((long)p * nh + k) * ns + r0;
+        dst[0] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        if (two) dst[1] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
     }
 }
 
-// forward, along y: L columns of Y1[p] (rows >= ns are zero) -> R[p][kx][ky]
-template <int L>
-__global__ __launch_bounds__(FFT_NT) void fft_fwd_cols_kernel(const cplx *__restrict__ Y1, int ns, FftPlan pl,
-                                                           const cplx *__restrict__ tw, cplx *__restrict__ R)
+// forward, along y: column kx of Y1[p] (rows >= ns are zero) -> R[p][kx][ky]
+__global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_fwd_cols_kernel(const cplx *__restrict__ Y1, int ns, FftPlan pl,
+                                                            const cplx *__restrict__ tw, cplx *__restrict__ R)
 {
-    extern __shared__ cplx fbuf[];
-    const int n = pl.n, nh = n / 2 + 1, p = blockIdx.y, kx0 = blockIdx.x * L;
-    cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
-    for (int e = threadIdx.x; e < n; e += FFT_NT) twl[e] = tw[e];
-#pragma unroll
-    for (int c = 0; c < L; c++)
-#pragma unroll 3
-        for (int y = threadIdx.x; y < n; y += FFT_NT) {
-        const int e = c * n + y;
-        cplx v = make_double2(0.0, 0.0);
-        if (y < ns && kx0 + c < nh) v = Y1[((long)p * nh + kx0 + c) * ns + y];
-        fbuf[e] = v;
-    }
-    __syncthreads();
-    fft_lines<false, L>(fbuf, pl, twl);
-#pragma unroll
-    for (int c = 0; c < L; c++)
-#pragma unroll 3
-        for (int ky = threadIdx.x; ky < n; ky += FFT_NT) {  // spectra are stored [kx][ky]: whole lines
-        const int e = c * n + ky;
-        if (kx0 + c < nh) R[((long)p * nh + kx0 + c) * n + ky] = fbuf[e];
-    }
+    IMCOM_WF_PROLOGUE;
+    const int p = blockIdx.x, kx = blockIdx.y * pl.waves + wave;
+    if (kx >= nh) return;
+    const cplx *src = Y1 + ((long)p * nh + kx) * ns;
+    cplx *dst = R + ((long)p * nh + kx) * n;
+    auto load0 = [&](int y) { return y < ns ? src[y] : make_double2(0.0, 0.0); };
+    auto storeN = [&](int ky, cplx v) { dst[ky] = v; };
+    wf_line<false>(line, twl, pl, load0, storeN);
 }
 
-// inverse, along y: L columns of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][kx][y'] for the
-// kept rows y' < ns (source row (y' - nc) mod n: the roll of psfutil.py:1225-1232)
-template <int L>
-__global__ __launch_bounds__(FFT_NT) void fft_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
-                                                           const int *__restrict__ pairs, int ns,
-                                                           FftPlan pl, const cplx *__restrict__ tw, double amp0, double amps,
-                                                           cplx *__restrict__ V)
+// inverse, along y: column kx of R1[p] conj(R2[q]) (x the squared Fourier-mode weight) -> V[t][y' / 2][kx][y' & 1] for the
+// kept rows y' < ns (source row (y' - nc) mod n: the roll of psfutil.py:1225-1232).  Rows 2l, 2l+1 sit next to each other
+// because the row transform takes them as one complex line: it then reads its line as one contiguous run.
+__global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
+                                                            const int *__restrict__ pairs, int ns, FftPlan pl,
+                                                            const cplx *__restrict__ tw, double amp0, double amps,
+                                                            cplx *__restrict__ V)
 {
-    extern __shared__ cplx fbuf[];
-    const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, kx0 = blockIdx.x * L, nc = ns / 2;
-    cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
-    for (int e = threadIdx.x; e < n; e += FFT_NT) twl[e] = tw[e];
-    const cplx *R1 = Ra + (long)pairs[2 * t] * n * nh, *R2 = Rb + (long)pairs[2 * t + 1] * n * nh;
-#pragma unroll
-    for (int c = 0; c < L; c++)
-#pragma unroll 3
-        for (int ky = threadIdx.x; ky < n; ky += FFT_NT) {
-        const int e = c * n + ky, kx = kx0 + c;
-        cplx z = make_double2(0.0, 0.0);
-        if (kx < nh) {
-            const cplx a = R1[(long)kx * n + ky], b = R2[(long)kx * n + ky];
-            double w2 = 1.0;
-            if (amp0 != 0.0) {
-                double uy = (double)ky / (double)n, ux = (double)kx / (double)n;
-                if (uy > 0.5) uy -= 1.0;
-                if (ux > 0.5) ux -= 1.0;
-                const double w = 1.0 + amp0 * exp(-2.0 * M_PI * M_PI * (ux * ux + uy * uy) * (amps * amps));
-                w2 = w * w;
-            }
-            z = make_double2((a.x * b.x + a.y * b.y) * w2, (a.y * b.x - a.x * b.y) * w2);
+    IMCOM_WF_PROLOGUE;
+    const int t = blockIdx.x, kx = blockIdx.y * pl.waves + wave, nc = ns / 2;
+    if (kx >= nh) return;
+    const cplx *R1 = Ra + ((long)pairs[2 * t] * nh + kx) * n, *R2 = Rb + ((long)pairs[2 * t + 1] * nh + kx) * n;
+    cplx *dst = V + ((long)t * ((ns + 1) / 2) * nh + kx) * 2;
+    double ux = (double)kx / (double)n;
+    if (ux > 0.5) ux -= 1.0;
+    auto load0 = [&](int ky) {
+        const cplx a = R1[ky], b = R2[ky];
+        double w2 = 1.0;
+        if (amp0 != 0.0) {
+            double uy = (double)ky / (double)n;
+            if (uy > 0.5) uy -= 1.0;
+            const double w = 1.0 + amp0 * exp(-2.0 * M_PI * M_PI * (ux * ux + uy * uy) * (amps * amps));
+            w2 = w * w;
         }
-        fbuf[e] = z;
-    }
-    __syncthreads();
-    fft_lines<true, L>(fbuf, pl, twl);
-#pragma unroll
-    for (int c = 0; c < L; c++)
-#pragma unroll 3
-        for (int yp = threadIdx.x; yp < ns; yp += FFT_NT) {  // V is stored [kx][y']
-        if (kx0 + c < nh) V[((long)t * nh + kx0 + c) * ns + yp] = fbuf[c * n + yp - nc + (yp < nc ? n : 0)];
-    }
+        return make_double2((a.x * b.x + a.y * b.y) * w2, (a.y * b.x - a.x * b.y) * w2);
+    };
+    auto storeN = [&](int i, cplx v) {
+        const int yp = i + nc - (i + nc >= n ? n : 0);
+        if (yp < ns) dst[(yp >> 1) * (2 * nh) + (yp & 1)] = v;
+    };
+    wf_line<true>(line, twl, pl, load0, storeN);
 }
 
 // inverse, along x: window rows 2l, 2l+1 of pair t from their Hermitian halves as one complex line; the real and the
 // imaginary part of the result are the two rows.  numpy's c2r ignores the imaginary parts of the DC and Nyquist
-// bins; so does this.  Stored rolled by nc, cropped to ns, scaled by 1/n^2, inside the 6-sample zero border.
-template <int L>
-__global__ __launch_bounds__(FFT_NT) void fft_inv_rows_kernel(const cplx *__restrict__ V, int ns, FftPlan pl,
-                                                           const cplx *__restrict__ tw, double *__restrict__ tables)
+// bins; so does this.  Stored rolled by nc, cropped to ns, scaled by 1/n^2, inside the 6-sample zero border (the
+// waves of a row pair write the side borders of their rows, the first and the last pair also the rows above / below).
+__global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_inv_rows_kernel(const cplx *__restrict__ V, int ns, FftPlan pl,
+                                                            const cplx *__restrict__ tw, double *__restrict__ tables)
 {
-    extern __shared__ cplx fbuf[];
-    const int n = pl.n, nh = n / 2 + 1, t = blockIdx.y, nc = ns / 2, ng = ns + 12;
-    cplx *twl = fbuf + L * n;  // the twiddle table rides in LDS behind the lines
-    for (int e = threadIdx.x; e < n; e += FFT_NT) twl[e] = tw[e];
-#pragma unroll 6
-    for (int e = threadIdx.x; e < L * n; e += FFT_NT) {  // the 2 L rows of this block are contiguous in V[kx][y']
-        const int k = e / L, line = e - k * L, r0 = 2 * (blockIdx.x * L + line);
+    IMCOM_WF_PROLOGUE;
+    const int t = blockIdx.x, r0 = 2 * (blockIdx.y * pl.waves + wave), nc = ns / 2, ng = ns + 12, lane = threadIdx.x & 63;
+    if (r0 >= ns) return;
+    const bool two = r0 + 1 < ns;
+    const cplx *src = V + ((long)t * ((ns + 1) / 2) + r0 / 2) * nh * 2;
+    double *tab = tables + (long)t * ng * ng;
+    const int bo = two ? 1 : 0;
+    const double bz = two ? 1.0 : 0.0;
+    auto load0 = [&](int k) {
         const int kk = k < nh ? k : n - k;
-        const bool edge = kk == 0 || 2 * kk == n;
-        cplx a = make_double2(0.0, 0.0), b = a;
-        if (r0 < ns) a = V[((long)t * nh + kk) * ns + r0];
-        if (r0 + 1 < ns) b = V[((long)t * nh + kk) * ns + r0 + 1];
-        if (k >= nh) { a.y = -a.y; b.y = -b.y; }
-        if (edge) { a.y = 0.0; b.y = 0.0; }
-        fbuf[line * n + k] = make_double2(a.x - b.y, a.y + b.x);
-    }
-    __syncthreads();
-    fft_lines<true, L>(fbuf, pl, twl);
+        const cplx *s2 = src + 2 * kk;
+        const cplx a = s2[0], b = s2[bo];  // branch free: a lone last row reads itself and is weighted by zero
+        const double sg = (k >= nh) ? -1.0 : ((kk == 0 || 2 * kk == n) ? 0.0 : 1.0);  // conjugate half; real DC / Nyquist bins
+        return make_double2(a.x - sg * bz * b.y, sg * a.y + bz * b.x);
+    };
     const double scale = 1.0 / ((double)n * (double)n);
-#pragma unroll
-    for (int line = 0; line < L; line++)
-#pragma unroll 3
-        for (int xp = threadIdx.x; xp < ns; xp += FFT_NT) {
-        const int r0 = 2 * (blockIdx.x * L + line);
-        if (r0 >= ns) continue;
-        const cplx z = fbuf[line * n + xp - nc + (xp < nc ? n : 0)];
-        tables[((long)t * ng + 6 + r0) * ng + 6 + xp] = z.x * scale;
-        if (r0 + 1 < ns) tables[((long)t * ng + 6 + r0 + 1) * ng + 6 + xp] = z.y * scale;
+    double *o0 = tab + (long)(6 + r0) * ng + 6, *o1 = o0 + ng;
+    auto storeN = [&](int i, cplx z) {
+        const int xp = i + nc - (i + nc >= n ? n : 0);
+        if (xp < ns) {
+            o0[xp] = z.x * scale;
+            if (two) o1[xp] = z.y * scale;
+        }
+    };
+    wf_line<true>(line, twl, pl, load0, storeN);
+    // zero border
+    if (lane < 12) {
+        const int c = lane < 6 ? lane - 6 : ns + lane - 6;
+        o0[c] = 0.0;
+        if (two) o1[c] = 0.0;
+    }
+    if (r0 == 0)
+        for (int e = lane; e < 6 * ng; e += 64) tab[e] = 0.0;
+    if (r0 + 2 >= ns) {
+        double *bot = tab + (long)(6 + ns) * ng;
+        for (int e = lane; e < 6 * ng; e += 64) bot[e] = 0.0;
     }
 }
 
-// nfft = product of radices 4, 2, 3, 5 with lines that fit the butterfly kernels?
+// nfft = product of radices 16, 8, 4, 2, 3, 5 (at least two stages) with lines that fit the wave engine?
 static bool fft_plan(int n, FftPlan *pl)
 {
-    if (n > FFT_MAXN) return false;
+    if (n > WF_MAXN || n < 6) return false;
     pl->n = n;
+    pl->npad = (n + 15) / 16 * 16;
     pl->nst = 0;
     int r = n;
-    const int cand[4] = {4, 2, 3, 5};
-    for (int ci = 0; ci < 4; ci++)
-        while (r % cand[ci] == 0 && !(cand[ci] == 4 && r % 4 != 0)) {
-            if (pl->nst >= 12) return false;
+    const int cand[6] = {16, 8, 4, 2, 3, 5};
+    for (int ci = 0; ci < 6; ci++)
+        while (r % cand[ci] == 0) {
+            if (pl->nst >= WF_MAXST) return false;
             pl->radix[pl->nst++] = cand[ci];
             r /= cand[ci];
         }
-    if (r != 1) return false;
-    for (int lines = 8; lines >= 4; lines /= 2) {
-        bool ok = (size_t)(lines + 1) * n * 16 <= 160 * 1024;
-        for (int st = 0; st < pl->nst; st++) ok = ok && n / pl->radix[st] <= 256 * (FFT_MAXIT / lines);
-        if (ok) { pl->lines = lines; return true; }
+    if (r != 1 || pl->nst < 2) return false;
+    int Ns = pl->radix[0], off = 0;
+    pl->twoff[0] = 0;
+    for (int s = 1; s < pl->nst; s++) {
+        pl->twoff[s] = off;
+        off += (pl->radix[s] - 1) * Ns;
+        Ns *= pl->radix[s];
     }
-    return false;
+    pl->twn = off;
+    // as many waves (= lines) per workgroup as LDS holds next to the tables, WF_MAXWAVES at most
+    const long line = (long)pl->npad * 16, lds = 160 * 1024;
+    pl->waves = (int)std::min<long>(WF_MAXWAVES, (lds - (long)pl->twn * 16) / line);
+    if (const char *e = getenv("IMCOM_FFT_WAVES")) pl->waves = std::max(1, std::min(pl->waves, atoi(e)));  // tuning runs
+    return pl->waves >= 1;
 }
-
 
 static bool fft_force_gemm()
 {
@@ -421,47 +291,235 @@ static bool fft_force_gemm()
     return f;
 }
 
-static size_t fft_lds_bytes(const FftPlan &pl) { return (size_t)(pl.lines + 1) * pl.n * 16; }  // lines + twiddle table
-
-template <int L>
-static int fft_set_lds_l(size_t lds)
-{
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_rows_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_cols_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_cols_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_rows_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    return IMCOM_OK;
-}
+static size_t fft_lds_bytes(const FftPlan &pl) { return ((size_t)pl.waves * pl.npad + pl.twn) * 16; }
 
 static int fft_set_lds(const FftPlan &pl)
 {
     const size_t lds = fft_lds_bytes(pl);
     if (lds <= 48 * 1024) return IMCOM_OK;
-    return pl.lines == 8 ? fft_set_lds_l<8>(lds) : fft_set_lds_l<4>(lds);
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_fwd_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_cols_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)fft_inv_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return IMCOM_OK;
+}
+
+// ---- static shape n = 256 r: persistent workgroups (one per CU), every wave loops over lines; the line index runs
+// pair-fastest for the column transforms (see above), row-fastest for the row transforms -------------------------------------------------
+#define IMCOM_WF16_PROLOGUE                                                                      \
+    extern __shared__ cplx fbuf[];                                                               \
+    constexpr int n = Wf16<R2>::N, nh = n / 2 + 1;                                               \
+    const int W = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; \
+    cplx *twl = fbuf + W * Wf16<R2>::LINE;                                                       \
+    for (int e = threadIdx.x; e < Wf16<R2>::TWN; e += blockDim.x) twl[e] = tw[e];                \
+    __syncthreads();                                                                             \
+    cplx *line = fbuf + wave * Wf16<R2>::LINE;                                                   \
+    (void)lane
+
+template <int R2>
+__global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_fwd_rows_kernel(const double *__restrict__ psf, int npsf, int ns,
+                                                                         const cplx *__restrict__ tw, cplx *__restrict__ Y1)
+{
+    IMCOM_WF16_PROLOGUE;
+    const long total = (long)npsf * ((ns + 1) / 2);
+    for (long L = (long)blockIdx.x * W + wave; L < total; L += (long)gridDim.x * W) {
+        const int rp = (ns + 1) / 2, p = (int)(L / rp), r0 = 2 * (int)(L % rp);  // neighbours write neighbouring pieces of Y1's lines
+        const double *row0 = psf + ((long)p * ns + r0) * ns, *row1 = row0 + ns;
+        const bool two = r0 + 1 < ns;
+        auto load0 = [&](int x) { return x < ns ? make_double2(row0[x], two ? row1[x] : 0.0) : make_double2(0.0, 0.0); };
+        auto keep = [line](int i, cplx v) { line[wf_pad16(i)] = v; };
+        wf16_line<R2, false>(line, twl, load0, keep);
+        // z = FFT(a + i b) of two real rows: A_k = (z_k + conj z_{n-k}) / 2, B_k = (z_k - conj z_{n-k}) / (2 i)
+        for (int k = lane; k < nh; k += 64) {
+            const cplx zk = line[wf_pad16(k)], zm = line[wf_pad16(k ? n - k : 0)];
+            cplx *dst = Y1 + ((long)p * nh + k) * ns + r0;
+            dst[0] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+            if (two) dst[1] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int R2>
+__global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_fwd_cols_kernel(const cplx *__restrict__ Y1, int npsf, int ns,
+                                                                         const cplx *__restrict__ tw, cplx *__restrict__ R)
+{
+    IMCOM_WF16_PROLOGUE;
+    const long total = (long)npsf * nh;
+    for (long L = (long)blockIdx.x * W + wave; L < total; L += (long)gridDim.x * W) {
+        const int p = (int)(L % npsf), kx = (int)(L / npsf);
+        const cplx *src = Y1 + ((long)p * nh + kx) * ns;
+        cplx *dst = R + ((long)p * nh + kx) * n;
+        auto load0 = [&](int y) { return y < ns ? src[y] : make_double2(0.0, 0.0); };
+        auto storeN = [&](int ky, cplx v) { dst[ky] = v; };
+        wf16_line<R2, false>(line, twl, load0, storeN);
+    }
+}
+
+template <int R2, bool AMP>
+__global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
+                                                                         const int *__restrict__ pairs, int npairs, int ns,
+                                                                         const cplx *__restrict__ tw, double amp0, double amps,
+                                                                         cplx *__restrict__ V)
+{
+    IMCOM_WF16_PROLOGUE;
+    const int nc = ns / 2, rp = (ns + 1) / 2;
+    // line order: four neighbouring columns of a pair, then the next pair, ...: the waves in flight share the spectrum
+    // columns they read through L2 (see above), and the 32-byte pieces four neighbouring columns write into V's 128-byte
+    // lines come from the same workgroup
+    const long total = 4L * npairs * ((nh + 3) / 4);
+    for (long L = (long)blockIdx.x * W + wave; L < total; L += (long)gridDim.x * W) {
+        const int g = (int)(L / (4L * npairs)), rem = (int)(L - 4L * npairs * g), t = rem >> 2, kx = 4 * g + (rem & 3);
+        if (kx >= nh) continue;
+        const cplx *R1 = Ra + ((long)pairs[2 * t] * nh + kx) * n, *R2p = Rb + ((long)pairs[2 * t + 1] * nh + kx) * n;
+        cplx *dst = V + ((long)t * rp * nh + kx) * 2;
+        double ux = (double)kx / (double)n;
+        if (ux > 0.5) ux -= 1.0;
+        auto load0 = [&](int ky) {
+            const cplx a = R1[ky], b = R2p[ky];
+            cplx z = make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+            if (AMP) {
+                double uy = (double)ky / (double)n;
+                if (uy > 0.5) uy -= 1.0;
+                const double w = 1.0 + amp0 * exp(-2.0 * M_PI * M_PI * (ux * ux + uy * uy) * (amps * amps));
+                z.x *= w * w;
+                z.y *= w * w;
+            }
+            return z;
+        };
+        auto storeN = [&](int i, cplx v) {
+            const int yp = i + nc - (i + nc >= n ? n : 0);
+            if (yp < ns) dst[(yp >> 1) * (2 * nh) + (yp & 1)] = v;
+        };
+        wf16_line<R2, true>(line, twl, load0, storeN);
+    }
+}
+
+template <int R2>
+__global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_rows_kernel(const cplx *__restrict__ V, int npairs, int ns,
+                                                                         const cplx *__restrict__ tw, double *__restrict__ tables)
+{
+    IMCOM_WF16_PROLOGUE;
+    const int nc = ns / 2, ng = ns + 12;
+    const double scale = 1.0 / ((double)n * (double)n);
+    const long total = (long)npairs * ((ns + 1) / 2);
+    for (long L = (long)blockIdx.x * W + wave; L < total; L += (long)gridDim.x * W) {
+        const int r0 = 2 * (int)(L % ((ns + 1) / 2));  // V is [pair][row pair][kx][2]: line L is one contiguous run
+        const int t = (int)(L / ((ns + 1) / 2));
+        const bool two = r0 + 1 < ns;
+        const cplx *src = V + L * nh * 2;
+        double *tab = tables + (long)t * ng * ng;
+        const int bo = two ? 1 : 0;
+        const double bz = two ? 1.0 : 0.0;
+        auto load0 = [&](int k) {
+            const int kk = k < nh ? k : n - k;
+            const cplx *s2 = src + 2 * kk;
+            const cplx a = s2[0], b = s2[bo];  // branch free: a lone last row reads itself and is weighted by zero
+            const double sg = (k >= nh) ? -1.0 : ((kk == 0 || 2 * kk == n) ? 0.0 : 1.0);  // conjugate half; real DC / Nyquist bins
+            return make_double2(a.x - sg * bz * b.y, sg * a.y + bz * b.x);
+        };
+        double *o0 = tab + (long)(6 + r0) * ng + 6, *o1 = o0 + ng;
+        auto storeN = [&](int i, cplx z) {
+            const int xp = i + nc - (i + nc >= n ? n : 0);
+            if (xp < ns) {
+                o0[xp] = z.x * scale;
+                if (two) o1[xp] = z.y * scale;
+            }
+        };
+        wf16_line<R2, true>(line, twl, load0, storeN);
+        if (lane < 12) {  // zero border
+            const int c = lane < 6 ? lane - 6 : ns + lane - 6;
+            o0[c] = 0.0;
+            if (two) o1[c] = 0.0;
+        }
+        if (r0 == 0)
+            for (int e = lane; e < 6 * ng; e += 64) tab[e] = 0.0;
+        if (r0 + 2 >= ns) {
+            double *bot = tab + (long)(6 + ns) * ng;
+            for (int e = lane; e < 6 * ng; e += 64) bot[e] = 0.0;
+        }
+    }
+}
+
+// n = 256 r with the plan {16, 16, r}?
+static int fft_static_r(const FftPlan &pl)
+{
+    static const bool off = getenv("IMCOM_FFT_GENERIC") != nullptr;  // A/B and test runs: the general kernels for every n
+    if (off || pl.nst != 3 || pl.radix[0] != 16 || pl.radix[1] != 16) return 0;
+    return pl.radix[2] >= 2 && pl.radix[2] <= 4 ? pl.radix[2] : 0;
+}
+template <int R2> static int wf16_waves()
+{
+    int w = (int)std::min<long>(WF_MAXWAVES, (160L * 1024 - Wf16<R2>::TWN * 16L) / (Wf16<R2>::LINE * 16L));
+    if (const char *e = getenv("IMCOM_FFT_WAVES")) w = std::max(1, std::min(w, atoi(e)));  // tuning runs
+    return w;
+}
+template <int R2> static size_t wf16_lds(int waves) { return ((size_t)waves * Wf16<R2>::LINE + Wf16<R2>::TWN) * 16; }
+
+template <int R2>
+static int wf16_forward(imcom_ctx *ctx, const double *psf, int npsf, int nsamp, const cplx *tw, cplx *Y1, cplx *R)
+{
+    const int W = wf16_waves<R2>(), nh = Wf16<R2>::N / 2 + 1;
+    const size_t lds = wf16_lds<R2>(W);
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_fwd_rows_kernel<R2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_fwd_cols_kernel<R2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long rows = (long)npsf * ((nsamp + 1) / 2), cols = (long)npsf * nh;
+    const int g1 = (int)std::min<long>(ctx->cu_count, (rows + W - 1) / W), g2 = (int)std::min<long>(ctx->cu_count, (cols + W - 1) / W);
+    hipLaunchKernelGGL(wf16_fwd_rows_kernel<R2>, dim3(g1), dim3(64 * W), lds, ctx->stream, psf, npsf, nsamp, tw, Y1);
+    hipLaunchKernelGGL(wf16_fwd_cols_kernel<R2>, dim3(g2), dim3(64 * W), lds, ctx->stream, (const cplx *)Y1, npsf, nsamp, tw, R);
+    return check_launch("psf spectra (16 x 16 x r lines)");
+}
+
+template <int R2>
+static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const int *pairs_dev, int npairs, int nsamp, const cplx *tw,
+                        double a0, double a1, cplx *V, double *tables)
+{
+    // the column kernel deals lines in groups of four neighbouring columns: a multiple of four waves keeps a group inside one
+    // workgroup (one L2), where its 32-byte pieces merge into whole lines of V
+    const int W = wf16_waves<R2>(), Wc = W >= 4 ? W / 4 * 4 : W, nh = Wf16<R2>::N / 2 + 1;
+    const size_t lds = wf16_lds<R2>(W);
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_rows_kernel<R2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long cols = (long)npairs * nh, rows = (long)npairs * ((nsamp + 1) / 2);
+    const int g1 = (int)std::min<long>(ctx->cu_count, (cols + Wc - 1) / Wc), g2 = (int)std::min<long>(ctx->cu_count, (rows + W - 1) / W);
+    if (a0 != 0.0)
+        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, true>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V);
+    else
+        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, false>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V);
+    hipLaunchKernelGGL(wf16_inv_rows_kernel<R2>, dim3(g2), dim3(64 * W), lds, ctx->stream, (const cplx *)V, npairs, nsamp, tw, tables);
+    return check_launch("psf_overlap (16 x 16 x r lines)");
 }
 
 static size_t fft_forward_ws(int n, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)n * nsamp * (nfft / 2 + 1) * 16 + 1024; }
-static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * nsamp * (nfft / 2 + 1) * 16 + (size_t)npairs * 8 + 1024; }
+static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * (nsamp + 1) * (nfft / 2 + 1) * 16 + (size_t)npairs * 8 + 1024; }
+
+static cplx *fft_twiddles(imcom_ctx *ctx, const FftPlan &pl)
+{
+    cplx *tw = (cplx *)ws_take(ctx, (size_t)pl.n * 16);  // twn < n
+    if (tw) hipLaunchKernelGGL(fft_twiddle_kernel, dim3((pl.twn + 255) / 256), dim3(256), 0, ctx->stream, pl, tw);
+    return tw;
+}
 
 // spectra R[n][nh][nfft] (complex) of n sampled PSFs; the caller has reserved fft_forward_ws() of workspace
 static int fft_forward(imcom_ctx *ctx, const FftPlan &pl, const double *psf, int n, int nsamp, cplx *R)
 {
     const int nfft = pl.n, nh = nfft / 2 + 1;
-    cplx *tw = (cplx *)ws_take(ctx, (size_t)nfft * 16);
+    cplx *tw = fft_twiddles(ctx, pl);
     cplx *Y1 = (cplx *)ws_take(ctx, (size_t)n * nsamp * nh * 16);
     if (!tw || !Y1) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
+    switch (fft_static_r(pl)) {
+    case 2: return wf16_forward<2>(ctx, psf, n, nsamp, tw, Y1, R);
+    case 3: return wf16_forward<3>(ctx, psf, n, nsamp, tw, Y1, R);
+    case 4: return wf16_forward<4>(ctx, psf, n, nsamp, tw, Y1, R);
+    default: break;
+    }
     IMCOM_TRY(fft_set_lds(pl));
     hipStream_t st = ctx->stream;
     const size_t lds = fft_lds_bytes(pl);
-    const int FL = pl.lines, row_blocks = ((nsamp + 1) / 2 + FL - 1) / FL, col_blocks = (nh + FL - 1) / FL;
-    hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
-    if (FL == 8) {
-        hipLaunchKernelGGL(fft_fwd_rows_kernel<8>, dim3(row_blocks, n), dim3(FFT_NT), lds, st, psf, nsamp, pl, tw, Y1);
-        hipLaunchKernelGGL(fft_fwd_cols_kernel<8>, dim3(col_blocks, n), dim3(FFT_NT), lds, st, Y1, nsamp, pl, tw, R);
-    } else {
-        hipLaunchKernelGGL(fft_fwd_rows_kernel<4>, dim3(row_blocks, n), dim3(FFT_NT), lds, st, psf, nsamp, pl, tw, Y1);
-        hipLaunchKernelGGL(fft_fwd_cols_kernel<4>, dim3(col_blocks, n), dim3(FFT_NT), lds, st, Y1, nsamp, pl, tw, R);
-    }
+    const int W = pl.waves, row_blocks = ((nsamp + 1) / 2 + W - 1) / W, col_blocks = (nh + W - 1) / W;
+    hipLaunchKernelGGL(fft_fwd_rows_kernel, dim3(n, row_blocks), dim3(64 * W), lds, st, psf, nsamp, pl, tw, Y1);
+    hipLaunchKernelGGL(fft_fwd_cols_kernel, dim3(n, col_blocks), dim3(64 * W), lds, st, Y1, nsamp, pl, tw, R);
     return check_launch("psf spectra (butterfly path)");
 }
 
@@ -469,26 +527,25 @@ static int fft_forward(imcom_ctx *ctx, const FftPlan &pl, const double *psf, int
 static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const cplx *Rb, const int *pairs_host, int npairs,
                        int nsamp, const double *amp_penalty, double *tables)
 {
-    const int nfft = pl.n, nh = nfft / 2 + 1, ng = nsamp + 12;
-    cplx *tw = (cplx *)ws_take(ctx, (size_t)nfft * 16);
-    cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * nsamp * nh * 16);
+    const int nfft = pl.n, nh = nfft / 2 + 1;
+    cplx *tw = fft_twiddles(ctx, pl);
+    cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * (nsamp + 1) * nh * 16);  // [pair][row pair][kx][2]
     int *pairs_dev = (int *)ws_take(ctx, (size_t)npairs * 8);
     if (!tw || !V || !pairs_dev) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
     IMCOM_TRY(fft_set_lds(pl));
     hipStream_t st = ctx->stream;
     IMCOM_TRY(upload(ctx, pairs_dev, pairs_host, 2 * (size_t)npairs));  // through the pinned ring: no stream drain
-    const size_t lds = fft_lds_bytes(pl);
-    const int FL = pl.lines, row_blocks = ((nsamp + 1) / 2 + FL - 1) / FL, col_blocks = (nh + FL - 1) / FL;
     const double a0 = amp_penalty ? amp_penalty[0] : 0.0, a1 = amp_penalty ? amp_penalty[1] : 0.0;
-    hipLaunchKernelGGL(fft_twiddle_kernel, dim3((nfft + 255) / 256), dim3(256), 0, st, nfft, tw);
-    IMCOM_HIP_CHECK(hipMemsetAsync(tables, 0, (size_t)npairs * ng * ng * 8, st));
-    if (FL == 8) {
-        hipLaunchKernelGGL(fft_inv_cols_kernel<8>, dim3(col_blocks, npairs), dim3(FFT_NT), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
-        hipLaunchKernelGGL(fft_inv_rows_kernel<8>, dim3(row_blocks, npairs), dim3(FFT_NT), lds, st, V, nsamp, pl, tw, tables);
-    } else {
-        hipLaunchKernelGGL(fft_inv_cols_kernel<4>, dim3(col_blocks, npairs), dim3(FFT_NT), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
-        hipLaunchKernelGGL(fft_inv_rows_kernel<4>, dim3(row_blocks, npairs), dim3(FFT_NT), lds, st, V, nsamp, pl, tw, tables);
+    switch (fft_static_r(pl)) {
+    case 2: return wf16_inverse<2>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V, tables);
+    case 3: return wf16_inverse<3>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V, tables);
+    case 4: return wf16_inverse<4>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V, tables);
+    default: break;
     }
+    const size_t lds = fft_lds_bytes(pl);
+    const int W = pl.waves, row_blocks = ((nsamp + 1) / 2 + W - 1) / W, col_blocks = (nh + W - 1) / W;
+    hipLaunchKernelGGL(fft_inv_cols_kernel, dim3(npairs, col_blocks), dim3(64 * W), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
+    hipLaunchKernelGGL(fft_inv_rows_kernel, dim3(npairs, row_blocks), dim3(64 * W), lds, st, V, nsamp, pl, tw, tables);
     return check_launch("psf_overlap (butterfly path)");
 }
 
@@ -640,7 +697,7 @@ extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, in
     fft_plan(nfft, &pl);
     // in chunks of pairs, so that the intermediate (nsamp x nh complex per pair) stays within ~4 GB however many
     // tables a caller asks for at once; the chunks run back to back on the stream and reuse the workspace in order
-    const size_t per_pair = (size_t)nsamp * (nfft / 2 + 1) * 16;
+    const size_t per_pair = (size_t)(nsamp + 1) * (nfft / 2 + 1) * 16;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs, ((size_t)4 << 30) / per_pair));
     IMCOM_TRY(ws_reserve(ctx, fft_inverse_ws(chunk, nsamp, nfft) + 8192));
     ProfScope ps(ctx, "psf_overlap");

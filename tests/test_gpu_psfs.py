@@ -106,12 +106,12 @@ def test_airy_known_answers_of_the_reference():
     assert 0.2 < mau / mg < 0.3 and 0.8 < mao / mau < 0.9
 
 
-@pytest.mark.parametrize("npixpsf,oversamp", [(5, 6), (10, 4), (9, 2), (7, 4), (3, 4), (4, 4), (32, 16)])
+@pytest.mark.parametrize("npixpsf,oversamp", [(5, 6), (10, 4), (9, 2), (7, 4), (3, 4), (4, 4), (30, 16), (32, 8), (24, 16), (32, 16)])
 def test_psf_overlap_mixed_radix_vs_oracle(npixpsf, oversamp):
-    """Table geometries whose nfft exercises every radix of the butterfly path (60 = 4 3 5, 80 = 4 4 5, 36 = 4 3 3) and
-    one that has none of them (56 = 8 7: the dense-DFT fallback), a radix-2 stage (24 = 4 2 3, 32 = 4 4 2) and the largest
-    butterfly size (1024, four lines per workgroup), all against the oracle's numpy FFTs, with the
-    amp_penalty weighting on."""
+    """Table geometries whose nfft exercises every radix of the general line-FFT kernels (60 = 4 3 5, 80 = 16 5, 36 = 4 3 3,
+    24 = 8 3, 32 = 16 2, 960 = 16 4 3 5), one that has none of them (56 = 8 7: the dense-DFT fallback), and the three static
+    16 x 16 x r shapes of the persistent kernels (512, 768, 1024), all against the oracle's numpy FFTs, with and without the
+    amp_penalty weighting."""
     import ctypes as C
 
     import torch
