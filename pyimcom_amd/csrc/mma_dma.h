@@ -11,9 +11,12 @@
 //   k-major operand  (element (r,k) at p[k*ld + r]):  [16][128 + 16]; one instruction = one 1 KB k-row; the
 //                    row pad makes lane (i = l&15, k = l>>4) reads hit 32 distinct banks.
 //   row-major operand (element (r,k) at p[r*ld + k]): [128][16], no pad; one instruction = 8 rows x 128 B.
-//                    Bank conflicts are removed by XOR-swizzling the 16-byte chunk index (0..7) with the low
-//                    three bits of the row -- applied to the per-lane GLOBAL address (the LDS side of a DMA is
-//                    linear) and again on the read.
+//                    Bank conflicts are removed by XOR-swizzling the 16-byte chunk index (0..7) with bits 1..3
+//                    of the row -- applied to the per-lane GLOBAL address (the LDS side of a DMA is linear) and
+//                    again on the read.  A ds_read_b64 is banked over lanes 0-31 / 32-63 and 64 banks: the 16 rows
+//                    x 2 k of a half-wave then hit (row & 1) * 32 + 4 * (chunk ^ (row >> 1 & 7)) + 2 * (k & 1), all
+//                    distinct (with the low three row bits as the key, rows r and r + 8 collided: two-way
+//                    conflicts on every row-major fragment read).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -66,7 +69,7 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     const double *ga[MMA_IQ], *gb[MMA_IQ];
 #pragma unroll
     for (int q = 0; q < MMA_IQ; q++) {
-        const int u = MMA_IQ * wave + q, row = 8 * u + (lane >> 3), ch = (lane & 7) ^ (row & 7);
+        const int u = MMA_IQ * wave + q, row = 8 * u + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
         ga[q] = AKM ? Ag + (long)u * lda + 2 * lane : Ag + (long)row * lda + 2 * ch;
         gb[q] = BKM ? Bg + (long)u * ldb + 2 * lane : Bg + (long)row * ldb + 2 * ch;
     }
@@ -93,12 +96,12 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int row = TRI ? (2 * i + wm) * 16 + li : wm * 64 + i * 16 + li;
-            ra[kk][i] = AKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ (row & 7)) << 1) + (lk & 1);
+            ra[kk][i] = AKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ ((row >> 1) & 7)) << 1) + (lk & 1);
         }
 #pragma unroll
         for (int i = 0; i < MMA_NJ; i++) {
             const int row = wn * (16 * MMA_NJ) + i * 16 + li;
-            rb[kk][i] = DIMG + (BKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ (row & 7)) << 1) + (lk & 1));
+            rb[kk][i] = DIMG + (BKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ ((row >> 1) & 7)) << 1) + (lk & 1));
         }
     }
 

@@ -367,9 +367,14 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const c
     // line order: four neighbouring columns of a pair, then the next pair, ...: the waves in flight share the spectrum
     // columns they read through L2 (see above), and the 32-byte pieces four neighbouring columns write into V's 128-byte
     // lines come from the same workgroup
-    const long total = 4L * npairs * ((nh + 3) / 4);
-    for (long L = (long)blockIdx.x * W + wave; L < total; L += (long)gridDim.x * W) {
-        const int g = (int)(L / (4L * npairs)), rem = (int)(L - 4L * npairs * g), t = rem >> 2, kx = 4 * g + (rem & 3);
+    // Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own L2: XCD x takes the pairs [p0, p1) -- an
+    // eighth of the list, in which the pairs of a table set (which share their 6-12 spectra) are neighbours -- so a spectrum
+    // column is fetched into ONE L2 and reused there by every pair of the set (the grid is a multiple of 8 workgroups)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int p0 = (int)((long)npairs * xcd / 8), np = (int)((long)npairs * (xcd + 1) / 8) - p0;
+    const long total = 4L * np * ((nh + 3) / 4);
+    for (long L = (long)slot * W + wave; L < total; L += (long)nslot * W) {
+        const int g = (int)(L / (4L * np)), rem = (int)(L - 4L * np * g), t = p0 + (rem >> 2), kx = 4 * g + (rem & 3);
         if (kx >= nh) continue;
         const cplx *R1 = Ra + ((long)pairs[2 * t] * nh + kx) * n, *R2p = Rb + ((long)pairs[2 * t + 1] * nh + kx) * n;
         cplx *dst = V + ((long)t * rp * nh + kx) * 2;
@@ -482,7 +487,8 @@ static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const in
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_rows_kernel<R2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long cols = (long)npairs * nh, rows = (long)npairs * ((nsamp + 1) / 2);
-    const int g1 = (int)std::min<long>(ctx->cu_count, (cols + Wc - 1) / Wc), g2 = (int)std::min<long>(ctx->cu_count, (rows + W - 1) / W);
+    const int g1 = (int)std::max<long>(8, std::min<long>(ctx->cu_count, (cols + Wc - 1) / Wc) / 8 * 8);  // a multiple of the 8 XCDs
+    const int g2 = (int)std::min<long>(ctx->cu_count, (rows + W - 1) / W);
     if (a0 != 0.0)
         hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, true>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V);
     else
@@ -698,7 +704,9 @@ extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, in
     // in chunks of pairs, so that the intermediate (nsamp x nh complex per pair) stays within ~4 GB however many
     // tables a caller asks for at once; the chunks run back to back on the stream and reuse the workspace in order
     const size_t per_pair = (size_t)(nsamp + 1) * (nfft / 2 + 1) * 16;
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs, ((size_t)4 << 30) / per_pair));
+    size_t budget = (size_t)4 << 30;
+    if (const char *e = getenv("IMCOM_FFT_CHUNK_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;  // tuning runs
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs, budget / per_pair));
     IMCOM_TRY(ws_reserve(ctx, fft_inverse_ws(chunk, nsamp, nfft) + 8192));
     ProfScope ps(ctx, "psf_overlap");
     const size_t tab = (size_t)(nsamp + 12) * (nsamp + 12);

@@ -174,7 +174,9 @@ class BlockTables:
         self.on_full, self.evictions = on_full, 0
         self.ctx = ctx or default_context()
         dev = self.dev = torch.device(device)
-        self.psf = {k: torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64), device=dev) for k, v in group_psfs.items()}
+        # sampled PSFs: device tensors are taken as they are, host arrays are uploaded when their group is first needed (a
+        # block's 81 groups are 570 MB at cfg-2 size: as one upload in front of the first batch that is 25 ms of idle GPU)
+        self.psf = dict(group_psfs)
         self.expo = {k: (list(range(v.shape[0])) if group_expo is None else [int(e) for e in group_expo[k]]) for k, v in self.psf.items()}
         assert all(len(self.expo[k]) == v.shape[0] for k, v in self.psf.items())
         first = next(iter(self.psf.values()))
@@ -210,7 +212,13 @@ class BlockTables:
         self.C = float(self.Cs[0])
 
     def _psf_of(self, g):
-        return self.pout if g is None else self.psf[g]
+        if g is None:
+            return self.pout
+        p = self.psf[g]
+        if not torch.is_tensor(p) or p.device != self.dev or p.dtype != torch.float64 or not p.is_contiguous():
+            p = self.psf[g] = (p.to(self.dev, torch.float64).contiguous() if torch.is_tensor(p)
+                               else torch.as_tensor(np.ascontiguousarray(p, dtype=np.float64), device=self.dev))
+        return p
 
     def _fill_spectra(self, g):
         if g in self._spec_done:
