@@ -132,6 +132,11 @@ __global__ void fft_twiddle_kernel(FftPlan pl, cplx *__restrict__ tw)
     tw[e] = make_double2(c, -sn);
 }
 
+// V, the intermediate between the two inverse transforms, is [pair][row pair l][kx][2]: rows 2l, 2l+1 of a column next to each
+// other (the row transform takes them as one complex line and reads its line as one contiguous run), columns padded to a
+// multiple of 4 so that four neighbouring columns of a row pair are exactly one aligned 128-byte line.
+__host__ __device__ constexpr int v_stride(int n) { return (n / 2 + 1 + 3) / 4 * 4; }
+
 #define IMCOM_WF_PROLOGUE                                                                        \
     extern __shared__ cplx fbuf[];                                                               \
     const int n = pl.n, nh = n / 2 + 1, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  \
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_inv_cols_kernel(const cp
     const int t = blockIdx.x, kx = blockIdx.y * pl.waves + wave, nc = ns / 2;
     if (kx >= nh) return;
     const cplx *R1 = Ra + ((long)pairs[2 * t] * nh + kx) * n, *R2 = Rb + ((long)pairs[2 * t + 1] * nh + kx) * n;
-    cplx *dst = V + ((long)t * ((ns + 1) / 2) * nh + kx) * 2;
+    const int nhp = v_stride(n);
+    cplx *dst = V + ((long)t * ((ns + 1) / 2) * nhp + kx) * 2;
     double ux = (double)kx / (double)n;
     if (ux > 0.5) ux -= 1.0;
     auto load0 = [&](int ky) {
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_inv_cols_kernel(const cp
     };
     auto storeN = [&](int i, cplx v) {
         const int yp = i + nc - (i + nc >= n ? n : 0);
-        if (yp < ns) dst[(yp >> 1) * (2 * nh) + (yp & 1)] = v;
+        if (yp < ns) dst[(yp >> 1) * (2 * nhp) + (yp & 1)] = v;
     };
     wf_line<true>(line, twl, pl, load0, storeN);
 }
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_inv_rows_kernel(const cp
     const int t = blockIdx.x, r0 = 2 * (blockIdx.y * pl.waves + wave), nc = ns / 2, ng = ns + 12, lane = threadIdx.x & 63;
     if (r0 >= ns) return;
     const bool two = r0 + 1 < ns;
-    const cplx *src = V + ((long)t * ((ns + 1) / 2) + r0 / 2) * nh * 2;
+    const cplx *src = V + ((long)t * ((ns + 1) / 2) + r0 / 2) * v_stride(n) * 2;
     double *tab = tables + (long)t * ng * ng;
     const int bo = two ? 1 : 0;
     const double bz = two ? 1.0 : 0.0;
@@ -364,39 +370,52 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const c
 {
     IMCOM_WF16_PROLOGUE;
     const int nc = ns / 2, rp = (ns + 1) / 2;
-    // line order: four neighbouring columns of a pair, then the next pair, ...: the waves in flight share the spectrum
-    // columns they read through L2 (see above), and the 32-byte pieces four neighbouring columns write into V's 128-byte
-    // lines come from the same workgroup
-    // Workgroups are dealt round-robin over the 8 XCDs (id % 8), each with its own L2: XCD x takes the pairs [p0, p1) -- an
-    // eighth of the list, in which the pairs of a table set (which share their 6-12 spectra) are neighbours -- so a spectrum
-    // column is fetched into ONE L2 and reused there by every pair of the set (the grid is a multiple of 8 workgroups)
+    constexpr int nhp = v_stride(n);
+    // Line order: four neighbouring columns of a pair, then the next pair, ...  Workgroups are dealt round-robin over the 8 XCDs
+    // (id % 8), each with its own L2: XCD x takes the pairs [p0, p1) -- an eighth of the list, in which the pairs of a table set
+    // (which share their 6-12 spectra) are neighbours -- so a spectrum column is fetched into ONE L2 and reused there by every
+    // pair of the set (the grid is a multiple of 8 workgroups).
+    // The workgroup (a multiple of four waves) works in rounds: every wave transforms one column and leaves the result in its
+    // LDS line; then each group of four waves -- four neighbouring columns of one pair -- writes V together, 128-byte line by
+    // line (a wave alone would scatter 32-byte pieces 12 KB apart: 1.5x the kernel's time).
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int p0 = (int)((long)npairs * xcd / 8), np = (int)((long)npairs * (xcd + 1) / 8) - p0;
-    const long total = 4L * np * ((nh + 3) / 4);
-    for (long L = (long)slot * W + wave; L < total; L += (long)nslot * W) {
+    const long total = 4L * np * ((nh + 3) / 4), per_round = (long)nslot * W;
+    for (long base = (long)slot * W; base < total; base += per_round) {  // base is a multiple of 4: uniform over the workgroup
+        const long L = base + wave;
         const int g = (int)(L / (4L * np)), rem = (int)(L - 4L * np * g), t = p0 + (rem >> 2), kx = 4 * g + (rem & 3);
-        if (kx >= nh) continue;
-        const cplx *R1 = Ra + ((long)pairs[2 * t] * nh + kx) * n, *R2p = Rb + ((long)pairs[2 * t + 1] * nh + kx) * n;
-        cplx *dst = V + ((long)t * rp * nh + kx) * 2;
-        double ux = (double)kx / (double)n;
-        if (ux > 0.5) ux -= 1.0;
-        auto load0 = [&](int ky) {
-            const cplx a = R1[ky], b = R2p[ky];
-            cplx z = make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
-            if (AMP) {
-                double uy = (double)ky / (double)n;
-                if (uy > 0.5) uy -= 1.0;
-                const double w = 1.0 + amp0 * exp(-2.0 * M_PI * M_PI * (ux * ux + uy * uy) * (amps * amps));
-                z.x *= w * w;
-                z.y *= w * w;
+        if (L < total && kx < nh) {
+            const cplx *R1 = Ra + ((long)pairs[2 * t] * nh + kx) * n, *R2p = Rb + ((long)pairs[2 * t + 1] * nh + kx) * n;
+            double ux = (double)kx / (double)n;
+            if (ux > 0.5) ux -= 1.0;
+            auto load0 = [&](int ky) {
+                const cplx a = R1[ky], b = R2p[ky];
+                cplx z = make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+                if (AMP) {
+                    double uy = (double)ky / (double)n;
+                    if (uy > 0.5) uy -= 1.0;
+                    const double w = 1.0 + amp0 * exp(-2.0 * M_PI * M_PI * (ux * ux + uy * uy) * (amps * amps));
+                    z.x *= w * w;
+                    z.y *= w * w;
+                }
+                return z;
+            };
+            auto keep = [line](int i, cplx v) { line[wf_pad16(i)] = v; };
+            wf16_line<R2, true>(line, twl, load0, keep);
+        }
+        __syncthreads();
+        // group q = wave >> 2 holds columns 4g .. 4g+3 of pair t in lines 4q .. 4q+3; lane = (row pair within a block of 8, column,
+        // row of the pair): one store instruction writes 8 whole 128-byte lines.  Row y' of the window is output (y' - nc) mod n.
+        if (L - (wave & 3) < total) {  // the group's first line exists (then so do g and t, the same for its four waves)
+            const int ncol = min(4, nh - 4 * g), c2 = (lane >> 1) & 3, h = lane & 1;
+            const cplx *src = fbuf + ((wave & ~3) + c2) * Wf16<R2>::LINE;
+            cplx *dst = V + ((long)t * rp * nhp + 4 * g) * 2 + (lane & 7);
+            for (int l = 8 * (wave & 3) + (lane >> 3); l < rp; l += 32) {
+                const int i = 2 * l + h - nc + (2 * l + h < nc ? n : 0);
+                if (c2 < ncol) dst[(long)l * (2 * nhp)] = src[wf_pad16(i)];
             }
-            return z;
-        };
-        auto storeN = [&](int i, cplx v) {
-            const int yp = i + nc - (i + nc >= n ? n : 0);
-            if (yp < ns) dst[(yp >> 1) * (2 * nh) + (yp & 1)] = v;
-        };
-        wf16_line<R2, true>(line, twl, load0, storeN);
+        }
+        __syncthreads();
     }
 }
 
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_rows_kernel(const c
         const int r0 = 2 * (int)(L % ((ns + 1) / 2));  // V is [pair][row pair][kx][2]: line L is one contiguous run
         const int t = (int)(L / ((ns + 1) / 2));
         const bool two = r0 + 1 < ns;
-        const cplx *src = V + L * nh * 2;
+        const cplx *src = V + L * v_stride(n) * 2;
         double *tab = tables + (long)t * ng * ng;
         const int bo = two ? 1 : 0;
         const double bz = two ? 1.0 : 0.0;
@@ -456,7 +475,7 @@ static int fft_static_r(const FftPlan &pl)
 template <int R2> static int wf16_waves()
 {
     int w = (int)std::min<long>(WF_MAXWAVES, (160L * 1024 - Wf16<R2>::TWN * 16L) / (Wf16<R2>::LINE * 16L));
-    if (const char *e = getenv("IMCOM_FFT_WAVES")) w = std::max(1, std::min(w, atoi(e)));  // tuning runs
+    if (const char *e = getenv("IMCOM_FFT_WAVES")) w = std::max(4, std::min(w, atoi(e)));  // tuning runs
     return w;
 }
 template <int R2> static size_t wf16_lds(int waves) { return ((size_t)waves * Wf16<R2>::LINE + Wf16<R2>::TWN) * 16; }
@@ -479,9 +498,8 @@ template <int R2>
 static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const int *pairs_dev, int npairs, int nsamp, const cplx *tw,
                         double a0, double a1, cplx *V, double *tables)
 {
-    // the column kernel deals lines in groups of four neighbouring columns: a multiple of four waves keeps a group inside one
-    // workgroup (one L2), where its 32-byte pieces merge into whole lines of V
-    const int W = wf16_waves<R2>(), Wc = W >= 4 ? W / 4 * 4 : W, nh = Wf16<R2>::N / 2 + 1;
+    // the column kernel's waves write V in groups of four (four neighbouring columns = one 128-byte line per row pair)
+    const int W = wf16_waves<R2>(), Wc = W / 4 * 4, nh = Wf16<R2>::N / 2 + 1;
     const size_t lds = wf16_lds<R2>(W);
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -498,7 +516,7 @@ static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const in
 }
 
 static size_t fft_forward_ws(int n, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)n * nsamp * (nfft / 2 + 1) * 16 + 1024; }
-static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * (nsamp + 1) * (nfft / 2 + 1) * 16 + (size_t)npairs * 8 + 1024; }
+static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * (nsamp + 1) * v_stride(nfft) * 16 + (size_t)npairs * 8 + 1024; }
 
 static cplx *fft_twiddles(imcom_ctx *ctx, const FftPlan &pl)
 {
@@ -535,7 +553,7 @@ static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const 
 {
     const int nfft = pl.n, nh = nfft / 2 + 1;
     cplx *tw = fft_twiddles(ctx, pl);
-    cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * (nsamp + 1) * nh * 16);  // [pair][row pair][kx][2]
+    cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * (nsamp + 1) * v_stride(nfft) * 16);  // [pair][row pair][kx, stride nhp][2]
     int *pairs_dev = (int *)ws_take(ctx, (size_t)npairs * 8);
     if (!tw || !V || !pairs_dev) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
     IMCOM_TRY(fft_set_lds(pl));
@@ -703,7 +721,7 @@ extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, in
     fft_plan(nfft, &pl);
     // in chunks of pairs, so that the intermediate (nsamp x nh complex per pair) stays within ~4 GB however many
     // tables a caller asks for at once; the chunks run back to back on the stream and reuse the workspace in order
-    const size_t per_pair = (size_t)(nsamp + 1) * (nfft / 2 + 1) * 16;
+    const size_t per_pair = (size_t)(nsamp + 1) * v_stride(nfft) * 16;
     size_t budget = (size_t)4 << 30;
     if (const char *e = getenv("IMCOM_FFT_CHUNK_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;  // tuning runs
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs, budget / per_pair));
