@@ -107,7 +107,7 @@ def pmc_traffic(batch, cfg_name):
     return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
 
 
-def block_leg(ctx, dev, n1P=16, batch=128, reps=2):
+def block_leg(ctx, dev, n1P=16, batch=256, reps=2):
     """The same path one level up, as a block of the reference runs it (coadd.py:2003-2084): cfg-2 geometry, a block of
     n1P x n1P output stamps whose PSFs change from one 2 x 2 group of InStamps to the next (SysMatA.ji_st2psf,
     psfutil.py:1803-1824), and everything the headline loop leaves out inside the timed region: PSF spectra and overlap
