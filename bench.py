@@ -112,8 +112,9 @@ def block_leg(ctx, dev, n1P=16, batch=256, reps=2):
     n1P x n1P output stamps whose PSFs change from one 2 x 2 group of InStamps to the next (SysMatA.ji_st2psf,
     psfutil.py:1803-1824), and everything the headline loop leaves out inside the timed region: PSF spectra and overlap
     tables per group (self / cross / input-output sets), pixel selection from the InStamp pool, per-stamp pair maps,
-    A, B, Cholesky, coaddition, block-map accumulation and boundary recovery.  Only the upload of the InStamp pool and of
-    the sampled PSFs is outside."""
+    A, B, Cholesky, coaddition, block-map accumulation and boundary recovery -- starting from the PSF images: their sampling
+    onto the PSFGrp grid runs inside the timed region too.  Only the upload of the InStamp pool, of the PSF images and of their
+    sampling positions is outside."""
     import numpy as np
     import torch
 
@@ -129,17 +130,34 @@ def block_leg(ctx, dev, n1P=16, batch=256, reps=2):
     psfs, target = synth.make_psfs(cfg, E)
     nst = n1P + 2
     ng = (nst + 1) // 2
-    lin = np.arange(psfs.shape[-1]) - psfs.shape[-1] // 2
-    groups = {}
+    # Every group has PSFs of its own.  As for the input pixels (InStampPool above), what is resident before the clock starts
+    # is the data and the geometry: per group the PSF images [E, ns + 16, ns + 16] (a smooth modulation of the analytic PSFs,
+    # zero padded) and their sampling positions yxco [E, 2, ns, ns] (a small rotation per exposure, psfutil.py:751-771).  The
+    # sampling itself (PSFGrp._sample_psf + normalisation, psfutil.py:709-795, 650-656: imcom_sample_psf) runs inside the timed
+    # region, when a group is first needed.
+    from pyimcom_amd import psfs as psfmod
+
+    ns = psfs.shape[-1]
+    lin = np.arange(ns) - ns // 2
+    base = torch.as_tensor(psfs, device=dev)
+    lt = torch.arange(ns, dtype=torch.float64, device=dev) - (ns - 1) / 2.0
+    yo, xo = torch.meshgrid(lt, lt, indexing="ij")
+    groups, counts = {}, {}
     for gj in range(ng):
-        for gi in range(ng):  # a smooth modulation per group: every group has PSFs of its own
+        for gi in range(ng):
             mod = 1.0 + 0.02 * np.sin(0.05 * lin * (1 + gi % 3))[None, None, :] + 0.02 * np.cos(0.04 * lin * (1 + gj % 3))[None, :, None]
-            q = psfs * mod
-            groups[(gj, gi)] = q / q.sum(axis=(1, 2), keepdims=True)
-    fams = ("psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize", "epilogue", "block_acc")
+            img = torch.zeros((E, ns + 16, ns + 16), dtype=torch.float64, device=dev)
+            img[:, 8 : 8 + ns, 8 : 8 + ns] = base * torch.as_tensor(mod, device=dev)
+            th = torch.as_tensor([0.004 * (e - E / 2) + 0.002 * (gi - gj) for e in range(E)], dtype=torch.float64, device=dev)
+            c, sn = torch.cos(th)[:, None, None], torch.sin(th)[:, None, None]
+            yxco = torch.stack([c * yo + sn * xo, -sn * yo + c * xo], dim=1).contiguous()
+            groups[(gj, gi)] = lambda img=img, yxco=yxco: psfmod.sample_psf(img, ns, yxco, psf_norm=True, ctx=ctx)
+            counts[(gj, gi)] = E
+    fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize", "epilogue", "block_acc")
 
     def one():
-        tabs = BlockTables(groups, target, cfg.nfft, capacity=13500, ctx=ctx, device=dev)  # table construction is part of the block
+        # table construction (PSF sampling, spectra, overlap tables) is part of the block
+        tabs = BlockTables(groups, target, cfg.nfft, capacity=13500, ctx=ctx, device=dev, group_count=counts)
         return coadd_block(cfg, pool, tabs, n1P, E, batch=batch)
 
     one()

@@ -9,6 +9,7 @@
 // circulant matrices applied from both sides: out = C I C^T with C[i][j] = k[(i - j) mod npad],
 // k[d] = (1/npad) sum_u h(u) cos(2 pi u d / npad) -- two products on the fp64 MFMA GEMM, exact twiddles.
 #include "common.h"
+#include "d5512.h"
 #include "launchers.h"
 
 namespace imcom {
@@ -23,14 +24,22 @@ __global__ void pad6_kernel(const double *__restrict__ psf, int ny, int nx, doub
     out[((long)p * gy + r) * gx + c] = (rr >= 0 && rr < ny && cc >= 0 && cc < nx) ? psf[((long)p * ny + rr) * nx + cc] : 0.0;
 }
 
-// interpolation positions: xpos = yxco[1] + xctr + 6, ypos = yxco[0] + yctr + 6   (psfutil.py:777-779)
-__global__ void sample_pos_kernel(const double *__restrict__ yxco, long npts, double xctr, double yctr, double *__restrict__ xpos,
-                                  double *__restrict__ ypos)
+// All PSFs of a call in one launch: PSF p = blockIdx.y is interpolated at its own positions (psfutil.py:777-783,
+// routine.py:125-181 with one layer); samples whose stencil leaves the padded image keep the zero they were set to.
+__global__ void sample_rot_kernel(const double *__restrict__ pad, int gy, int gx, const double *__restrict__ yxco, long npts, double xctr,
+                                  double yctr, double *__restrict__ out)
 {
+    const int p = blockIdx.y;
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= npts) return;
-    ypos[i] = yxco[i] + yctr + 6.0;
-    xpos[i] = yxco[npts + i] + xctr + 6.0;
+    const double *co = yxco + (long)p * 2 * npts;
+    const double y = co[i] + yctr + 6.0, x = co[npts + i] + xctr + 6.0;
+    const int xi = to_cell(x), yi = to_cell(y);
+    if (xi < 4 || xi >= gx - 5 || yi < 4 || yi >= gy - 5) return;
+    double wx[10], wy[10];
+    d5512_getw(wx, x - xi - 0.5);
+    d5512_getw(wy, y - yi - 0.5);
+    out[(long)p * npts + i] = stencil(pad + ((long)p * gy + (yi - 4)) * gx + (xi - 4), gx, 1, wx, wy);
 }
 
 // unrotated grid: lin[i] = i - (nsamp-1)/2 (PSFGrp.yxo), positions lin + ctr + 6   (psfutil.py:788-790)
@@ -43,22 +52,36 @@ __global__ void grid_pos_kernel(int nsamp, double xctr, double yctr, double *__r
     ypos[i] = lin + yctr + 6.0;
 }
 
-// circular cut-out and per-PSF sum; one block per PSF, then scale
-__global__ __launch_bounds__(256) void psf_circ_sum_kernel(double *__restrict__ arr, int nsamp, int circ, double *__restrict__ sums)
+// circular cut-out and per-PSF sum, then scale.  One block per (row, PSF) leaves the row's sum (rows = fixed units of the
+// reduction: the result does not depend on how many blocks run at once); a second pass adds the rows of a PSF in order.
+__global__ __launch_bounds__(256) void psf_circ_rowsum_kernel(double *__restrict__ arr, int nsamp, int circ, double *__restrict__ rowsum)
 {
     __shared__ double red[4];
-    const int p = blockIdx.x;
+    const int r = blockIdx.x, p = blockIdx.y;
     const double c0 = 0.5 * (double)(nsamp - 1), rmax = (double)(nsamp / 2) + 0.5;
+    double *row = arr + ((long)p * nsamp + r) * nsamp;
     double acc = 0.0;
-    for (long i = threadIdx.x; i < (long)nsamp * nsamp; i += 256) {
-        const int r = (int)(i / nsamp), c = (int)(i % nsamp);
-        double v = arr[(long)p * nsamp * nsamp + i];
+    for (int c = threadIdx.x; c < nsamp; c += 256) {
+        double v = row[c];
         if (circ && !(hypot((double)r - c0, (double)c - c0) < rmax)) {
             v = 0.0;
-            arr[(long)p * nsamp * nsamp + i] = 0.0;
+            row[c] = 0.0;
         }
         acc += v;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) rowsum[(long)p * nsamp + r] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void psf_sum_rows_kernel(const double *__restrict__ rowsum, int nsamp, double *__restrict__ sums)
+{
+    __shared__ double red[4];
+    const int p = blockIdx.x;
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < nsamp; r += 256) acc += rowsum[(long)p * nsamp + r];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -172,7 +195,7 @@ extern "C" int imcom_sample_psf(imcom_ctx *ctx, int n_psf, const double *psf, in
     const bool host = memspace == IMCOM_MEM_HOST;
     const long npts = (long)nsamp * nsamp, gy = ny + 12, gx = nx + 12;
     const size_t szin = (size_t)n_psf * ny * nx * 8, szout = (size_t)n_psf * npts * 8, szco = yxco ? (size_t)n_psf * 2 * npts * 8 : 0;
-    size_t total = 65536 + (size_t)n_psf * gy * gx * 8 + 2 * (size_t)npts * 8 + (size_t)n_psf * 8;
+    size_t total = 65536 + (size_t)n_psf * gy * gx * 8 + 2 * (size_t)npts * 8 + (size_t)n_psf * 8 + (size_t)n_psf * nsamp * 8;
     if (host) total += szin + szout + szco + 1024;
     IMCOM_TRY(ws_reserve(ctx, total));
     const double *psf_d = psf, *co_d = yxco;
@@ -192,9 +215,10 @@ extern "C" int imcom_sample_psf(imcom_ctx *ctx, int n_psf, const double *psf, in
     }
     double *pad = (double *)ws_take(ctx, (size_t)n_psf * gy * gx * 8);
     double *xpos = (double *)ws_take(ctx, (size_t)npts * 8), *ypos = (double *)ws_take(ctx, (size_t)npts * 8);
-    double *sums = (double *)ws_take(ctx, (size_t)n_psf * 8);
-    if (!pad || !xpos || !ypos || !sums) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    double *sums = (double *)ws_take(ctx, (size_t)n_psf * 8), *rowsum = (double *)ws_take(ctx, (size_t)n_psf * nsamp * 8);
+    if (!pad || !xpos || !ypos || !sums || !rowsum) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     const double xctr = (nx - 1) / 2.0, yctr = (ny - 1) / 2.0;
+    ProfScope ps(ctx, "psf_sample");
     hipLaunchKernelGGL(pad6_kernel, dim3((unsigned)((gx + 255) / 256), (unsigned)gy, n_psf), dim3(256), 0, ctx->stream, psf_d, ny, nx, pad);
     IMCOM_TRY(check_launch("pad6_kernel"));
     IMCOM_HIP_CHECK(hipMemsetAsync(out_d, 0, szout, ctx->stream));  // off-grid samples stay zero (psfutil.py:775, 785)
@@ -202,19 +226,17 @@ extern "C" int imcom_sample_psf(imcom_ctx *ctx, int n_psf, const double *psf, in
         hipLaunchKernelGGL(grid_pos_kernel, dim3((nsamp + 255) / 256), dim3(256), 0, ctx->stream, nsamp, xctr, yctr, xpos, ypos);
         IMCOM_TRY(check_launch("grid_pos_kernel"));
     }
-    for (int p = 0; p < n_psf; p++) {
-        const double *img = pad + (size_t)p * gy * gx;
-        if (co_d) {
-            hipLaunchKernelGGL(sample_pos_kernel, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, co_d + (size_t)p * 2 * npts, npts,
-                               xctr, yctr, xpos, ypos);
-            IMCOM_TRY(check_launch("sample_pos_kernel"));
-            IMCOM_TRY(launch_interp(ctx, img, 1, (int)gy, (int)gx, xpos, ypos, npts, out_d + (size_t)p * npts, 0));
-        } else {
-            IMCOM_TRY(launch_grid(ctx, img, (int)gy, (int)gx, xpos, ypos, 1, nsamp, nsamp, out_d + (size_t)p * npts));
-        }
+    if (co_d) {
+        hipLaunchKernelGGL(sample_rot_kernel, dim3((unsigned)((npts + 255) / 256), n_psf), dim3(256), 0, ctx->stream, (const double *)pad, (int)gy,
+                           (int)gx, co_d, npts, xctr, yctr, out_d);
+        IMCOM_TRY(check_launch("sample_rot_kernel"));
+    } else {
+        for (int p = 0; p < n_psf; p++)
+            IMCOM_TRY(launch_grid(ctx, pad + (size_t)p * gy * gx, (int)gy, (int)gx, xpos, ypos, 1, nsamp, nsamp, out_d + (size_t)p * npts));
     }
     if (psf_circ || psf_norm) {
-        hipLaunchKernelGGL(psf_circ_sum_kernel, dim3(n_psf), dim3(256), 0, ctx->stream, out_d, nsamp, psf_circ ? 1 : 0, sums);
+        hipLaunchKernelGGL(psf_circ_rowsum_kernel, dim3(nsamp, n_psf), dim3(256), 0, ctx->stream, out_d, nsamp, psf_circ ? 1 : 0, rowsum);
+        hipLaunchKernelGGL(psf_sum_rows_kernel, dim3(n_psf), dim3(256), 0, ctx->stream, (const double *)rowsum, nsamp, sums);
         if (psf_norm)
             hipLaunchKernelGGL(psf_scale_kernel, dim3((unsigned)((npts + 255) / 256), n_psf), dim3(256), 0, ctx->stream, out_d, npts, sums);
         IMCOM_TRY(check_launch("psf circ/norm"));

@@ -169,19 +169,22 @@ class BlockTables:
     counted in ``evictions`` and the kernels of earlier batches, queued on the same stream, have read their tables by the
     time the new ones are written -- or "raise" (ValueError: size the arena for the block instead)."""
 
-    def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict"):
+    def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict",
+                 group_count=None):
         assert on_full in ("evict", "raise")
         self.on_full, self.evictions = on_full, 0
         self.ctx = ctx or default_context()
         dev = self.dev = torch.device(device)
-        # sampled PSFs: device tensors are taken as they are, host arrays are uploaded when their group is first needed (a
-        # block's 81 groups are 570 MB at cfg-2 size: as one upload in front of the first batch that is 25 ms of idle GPU)
+        # sampled PSFs of a group: a device tensor (taken as it is), a host array (uploaded when the group is first needed: a
+        # block's 81 groups are 570 MB at cfg-2 size), or -- with ``group_count`` = {key: number of PSFs} -- a callable that
+        # returns the device tensor when the group is first needed (e.g. psfs.sample_psf on the resident PSF images: the
+        # samples are then produced where they are consumed, PSFGrp.__init__ psfutil.py:640-656)
         self.psf = dict(group_psfs)
-        self.expo = {k: (list(range(v.shape[0])) if group_expo is None else [int(e) for e in group_expo[k]]) for k, v in self.psf.items()}
-        assert all(len(self.expo[k]) == v.shape[0] for k, v in self.psf.items())
-        first = next(iter(self.psf.values()))
-        self.nsamp, self.nfft = first.shape[1], nfft
-        self.n_max = max(v.shape[0] for v in self.psf.values())
+        self._count_of = {k: (int(group_count[k]) if callable(v) else int(v.shape[0])) for k, v in self.psf.items()}
+        self.expo = {k: (list(range(self._count_of[k])) if group_expo is None else [int(e) for e in group_expo[k]]) for k in self.psf}
+        assert all(len(self.expo[k]) == self._count_of[k] for k in self.psf)
+        self.nsamp, self.nfft = int(psf_out.shape[-1]), nfft
+        self.n_max = max(self._count_of.values())
         self.n_psf = self.n_max
         self.n_blk_expo = 1 + max(max(v) for v in self.expo.values())
         self.pout = torch.as_tensor(np.ascontiguousarray(psf_out, dtype=np.float64), device=dev)
@@ -198,9 +201,9 @@ class BlockTables:
         # nfft 768).  size == 0: nfft has no butterfly plan, every set goes through imcom_psf_overlap on its own.
         size = int(lib.imcom_psf_spectra_size(self.nsamp, nfft))
         self._spec_row, row = {None: 0}, O
-        for k, v in self.psf.items():
+        for k in self.psf:
             self._spec_row[k] = row
-            row += v.shape[0]
+            row += self._count_of[k]
         self._spec_done = set()
         self._spec_all = torch.empty((row, size), dtype=torch.float64, device=dev) if size else None
         if size:
@@ -215,6 +218,9 @@ class BlockTables:
         if g is None:
             return self.pout
         p = self.psf[g]
+        if callable(p):
+            p = self.psf[g] = p()
+            assert tuple(p.shape) == (self._count_of[g], self.nsamp, self.nsamp), "group PSF provider returned the wrong shape"
         if not torch.is_tensor(p) or p.device != self.dev or p.dtype != torch.float64 or not p.is_contiguous():
             p = self.psf[g] = (p.to(self.dev, torch.float64).contiguous() if torch.is_tensor(p)
                                else torch.as_tensor(np.ascontiguousarray(p, dtype=np.float64), device=self.dev))
@@ -245,7 +251,7 @@ class BlockTables:
         overlap_tables(self.ctx, None, self._spec_all, None, self._spec_all, self.nsamp, self.nfft, np.concatenate(allp), self._amp, out)
 
     def _n(self, g):
-        return self.psf[g].shape[0]
+        return self._count_of[g]
 
     def _count(self, key):
         if key[0] == "self":

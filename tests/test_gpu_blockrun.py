@@ -252,3 +252,35 @@ def test_block_tables_eviction_policy():
                 t.require(b)
         with pytest.raises(ValueError, match="cannot hold"):
             BlockTables(groups, target, cfg.nfft, capacity=20, on_full=policy).require(a)
+
+
+@pytest.mark.gpu
+def test_block_tables_group_sources_agree():
+    """A group's sampled PSFs may come as a host array, as a device tensor, or from a callable evaluated when the group is
+    first needed (with ``group_count``): the three give the same tables, and the callable of a group nobody asks for is
+    never run."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import BlockTables
+
+    cfg = synth.CONFIGS["tiny"]
+    psfs, target = synth.make_psfs(cfg, 3)
+    host = {(0, 0): psfs, (0, 1): psfs[::-1].copy(), (1, 1): psfs[:2]}
+    keys = BlockTables.keys_for([(0, 0), (0, 1)])
+    ref = BlockTables(host, target, cfg.nfft, capacity=64)
+    want = ref.require(keys)
+    dev = {k: torch.as_tensor(v, device="cuda:0") for k, v in host.items()}
+    called = []
+
+    def provider(k):
+        def f():
+            called.append(k)
+            return torch.as_tensor(host[k], device="cuda:0")
+        return f
+
+    for groups, count in ((dev, None), ({k: provider(k) for k in host}, {k: v.shape[0] for k, v in host.items()})):
+        t = BlockTables(groups, target, cfg.nfft, capacity=64, group_count=count)
+        got = t.require(keys)
+        assert got == want and torch.equal(t.tables[: t.used], ref.tables[: ref.used])
+    assert sorted(called) == [(0, 0), (0, 1)]
