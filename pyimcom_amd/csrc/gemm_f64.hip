@@ -13,6 +13,9 @@
 namespace imcom {
 
 constexpr int BK = DBK;  // K granularity of the tile engine (mma_dma.h)
+// waves per SIMD a kernel is compiled for: two 8-wave workgroups per CU = 4 (the compiler keeps these kernels at 128 registers on
+// its own; the attribute only has to allow it), or three 4-wave ones (64 x 64 per wave: 128 accumulator registers of 168)
+constexpr int MMA_MINWAVES = MMA_WAVES == 4 ? 3 : 2;
 
 __device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][MMA_NJ])
 {
@@ -104,7 +107,7 @@ __device__ __forceinline__ void part_range(int kb, int p, int nparts, int &k0, i
     k1 = (int)((long)(p + 1) * kb / nparts);
 }
 
-__global__ __launch_bounds__(MMA_THREADS, 2) void chol_partial_kernel(const double *__restrict__ L, int ldn, int k,
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void chol_partial_kernel(const double *__restrict__ L, int ldn, int k,
                                                               const int *__restrict__ nblk, int nparts, double *__restrict__ partial)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void chol_partial_kernel(const doub
     store_partial(acc, partial + (((long)s * gridDim.x + c) * nparts + p) * NB * NB);
 }
 
-__global__ __launch_bounds__(MMA_THREADS, 2) void chol_update_kernel(const double *__restrict__ A,
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void chol_update_kernel(const double *__restrict__ A,
                                                              double *__restrict__ L, int ldn, int k,
                                                              const int *__restrict__ nblk,
                                                              const double *__restrict__ dshift,
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void chol_update_kernel(const doubl
     })
 }
 
-__global__ __launch_bounds__(MMA_THREADS, 2) void chol_trsm_kernel(double *__restrict__ L,
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void chol_trsm_kernel(double *__restrict__ L,
                                                            const double *__restrict__ Dinv, int ldn,
                                                            int k, const int *__restrict__ nblk)
 {
@@ -188,7 +191,7 @@ __device__ __forceinline__ void solve_dinv_tile(f64x4 (&acc)[4][MMA_NJ], const d
 
 // partial products of one block row of the triangular solves (split-K, see chol_partial_kernel)
 template <bool BWD>
-__global__ __launch_bounds__(MMA_THREADS, 2) void solve_partial_kernel(const double *__restrict__ L, const double *__restrict__ Y,
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_partial_kernel(const double *__restrict__ L, const double *__restrict__ Y,
                                                                int ldn, int ldm, int k, const int *__restrict__ nblk,
                                                                const int *__restrict__ n, int nparts, double *__restrict__ partial)
 {
@@ -234,7 +237,7 @@ __device__ __forceinline__ void tile_col_sumsq(const f64x4 (&acc)[4][MMA_NJ], do
     }
 }
 
-__global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double *__restrict__ L,
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_fwd_kernel(const double *__restrict__ L,
                                                            const double *__restrict__ Bt,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk, const int *__restrict__ n,
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_fwd_kernel(const double 
     }
 }
 
-__global__ __launch_bounds__(MMA_THREADS, 2) void solve_bwd_kernel(const double *__restrict__ L,
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_bwd_kernel(const double *__restrict__ L,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk,
                                                            const int *__restrict__ n, const double *__restrict__ Dinv,
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_bwd_kernel(const double 
 
 // Y_k <- Linv[k] Y_k (TRANS=false) or Linv[k]^T Y_k (TRANS=true), in place.
 template <bool TRANS>
-__global__ __launch_bounds__(MMA_THREADS, 2) void solve_dinv_kernel(const double *__restrict__ Dinv,
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_dinv_kernel(const double *__restrict__ Dinv,
                                                             double *__restrict__ Y, int ldn, int ldm,
                                                             int k, const int *__restrict__ nblk)
 {
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void solve_dinv_kernel(const double
 // Generic batched C = alpha * op(A) * op(B) + beta * C on 128-multiples (used by the eigen path:
 // P = B Q, T = (P/(lam+kappa)) Q^T).  Element (r,k) of a K-major operand is p[k*ld + r].
 template <bool AKM, bool BKM>
-__global__ __launch_bounds__(MMA_THREADS, 2) void gemm_kernel(const double *__restrict__ A, long lda,
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void gemm_kernel(const double *__restrict__ A, long lda,
                                                       long strideA, const double *__restrict__ B,
                                                       long ldb, long strideB, double *__restrict__ C,
                                                       long ldc, long strideC, int K, double alpha,

@@ -24,7 +24,12 @@ namespace imcom {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DBK = 16;                      // k-slice per stage
+#ifndef IMCOM_MMA_BK
+#define IMCOM_MMA_BK 16
+#endif
+constexpr int DBK = IMCOM_MMA_BK;            // k-slice per stage: 16, or 8 (half the LDS per workgroup: three 4-wave workgroups per CU)
+constexpr int DCH = DBK / 2;                 // 16-byte chunks per row of a row-major image
+constexpr int DRPI = 64 / DCH;               // rows of a row-major image per LDS-DMA instruction
 constexpr int DNS = 2;                       // stages (double buffer)
 constexpr int DKM_LD = 128 + 16;             // k-major image row stride (doubles)
 constexpr int DIMG = DBK * DKM_LD;           // doubles per operand image slot (2304; row-major needs 2048)
@@ -37,7 +42,10 @@ constexpr int MMA_WAVES = IMCOM_MMA_WAVES;   // 8: wave (wm = w >> 2, wn = w & 3
 constexpr int MMA_THREADS = 64 * MMA_WAVES;
 constexpr int MMA_WN = MMA_WAVES / 2;        // waves along the columns
 constexpr int MMA_NJ = 8 / MMA_WN;           // 16-column MFMA tiles per wave
-constexpr int MMA_IQ = 16 / MMA_WAVES;       // LDS-DMA instructions per operand, wave and stage
+constexpr int MMA_IQ = DBK / MMA_WAVES;      // LDS-DMA instructions per operand, wave and stage
+static_assert(MMA_IQ >= 1 && MMA_IQ * MMA_WAVES == DBK, "k-slice must be a multiple of the wave count");
+// swizzle key of a row-major image row (see above): distinct over any 16 consecutive rows together with the row's bank phase
+__device__ __forceinline__ int dma_key(int row) { return DCH == 8 ? (row >> 1) & 7 : (row >> 2) & 3; }
 
 #define IMCOM_GLDS16(gptr, ldsptr)                                                               \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),     \
@@ -69,14 +77,14 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     const double *ga[MMA_IQ], *gb[MMA_IQ];
 #pragma unroll
     for (int q = 0; q < MMA_IQ; q++) {
-        const int u = MMA_IQ * wave + q, row = 8 * u + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+        const int u = MMA_IQ * wave + q, row = DRPI * u + lane / DCH, ch = (lane % DCH) ^ dma_key(row);
         ga[q] = AKM ? Ag + (long)u * lda + 2 * lane : Ag + (long)row * lda + 2 * ch;
         gb[q] = BKM ? Bg + (long)u * ldb + 2 * lane : Bg + (long)row * ldb + 2 * ch;
     }
     const long ainc = AKM ? (long)DBK * lda : DBK, binc = BKM ? (long)DBK * ldb : DBK;
     // wave-uniform LDS destinations inside a stage
-    const int da0 = AKM ? MMA_IQ * wave * DKM_LD : 8 * MMA_IQ * wave * 16, dastep = AKM ? DKM_LD : 8 * 16;
-    const int db0 = DIMG + (BKM ? MMA_IQ * wave * DKM_LD : 8 * MMA_IQ * wave * 16), dbstep = BKM ? DKM_LD : 8 * 16;
+    const int da0 = AKM ? MMA_IQ * wave * DKM_LD : DRPI * MMA_IQ * wave * DBK, dastep = AKM ? DKM_LD : DRPI * DBK;
+    const int db0 = DIMG + (BKM ? MMA_IQ * wave * DKM_LD : DRPI * MMA_IQ * wave * DBK), dbstep = BKM ? DKM_LD : DRPI * DBK;
 
     auto issue = [&](int slot) {
         double *st = lds + slot * DSTAGE;
@@ -90,18 +98,19 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     };
 
     // fragment read offsets (doubles) inside a stage for the four k-quads kk (k = lk + 4 kk)
-    int ra[4][4], rb[4][MMA_NJ];
+    constexpr int NKK = DBK / 4;  // MFMA k-quads per slice
+    int ra[NKK][4], rb[NKK][MMA_NJ];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
+    for (int kk = 0; kk < NKK; kk++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int row = TRI ? (2 * i + wm) * 16 + li : wm * 64 + i * 16 + li;
-            ra[kk][i] = AKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ ((row >> 1) & 7)) << 1) + (lk & 1);
+            ra[kk][i] = AKM ? (lk + 4 * kk) * DKM_LD + row : row * DBK + ((((lk >> 1) + 2 * kk) ^ dma_key(row)) << 1) + (lk & 1);
         }
 #pragma unroll
         for (int i = 0; i < MMA_NJ; i++) {
             const int row = wn * (16 * MMA_NJ) + i * 16 + li;
-            rb[kk][i] = DIMG + (BKM ? (lk + 4 * kk) * DKM_LD + row : row * 16 + ((((lk >> 1) + 2 * kk) ^ ((row >> 1) & 7)) << 1) + (lk & 1));
+            rb[kk][i] = DIMG + (BKM ? (lk + 4 * kk) * DKM_LD + row : row * DBK + ((((lk >> 1) + 2 * kk) ^ dma_key(row)) << 1) + (lk & 1));
         }
     }
 
@@ -116,7 +125,7 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     for (int t = 0; t < nt; t++) {
         const double *st = lds + (t & 1) * DSTAGE;
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
+        for (int kk = 0; kk < NKK; kk++) {
             if constexpr (TRI != 0) {
                 double b[MMA_NJ];
 #pragma unroll
@@ -124,7 +133,7 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int g = 2 * i + wm;
-                    if (TRI == 1 ? t <= g : t >= g) {  // wave-uniform
+                    if (TRI == 1 ? DBK * t <= 16 * g + 15 : DBK * t + DBK - 1 >= 16 * g) {  // wave-uniform: the slice meets the group's triangle
                         const double a = st[ra[kk][i]];
 #pragma unroll
                         for (int j = 0; j < MMA_NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[j], acc[i][j], 0, 0, 0);
