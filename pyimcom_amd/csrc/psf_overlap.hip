@@ -722,9 +722,7 @@ extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, in
     // in chunks of pairs, so that the intermediate (nsamp x nh complex per pair) stays within ~4 GB however many
     // tables a caller asks for at once; the chunks run back to back on the stream and reuse the workspace in order
     const size_t per_pair = (size_t)(nsamp + 1) * v_stride(nfft) * 16;
-    size_t budget = (size_t)4 << 30;
-    if (const char *e = getenv("IMCOM_FFT_CHUNK_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;  // tuning runs
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs, budget / per_pair));
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs, ((size_t)4 << 30) / per_pair));
     if (const char *e = getenv("IMCOM_FFT_CHUNK_PAIRS")) chunk = std::max(1, std::min(npairs, atoi(e)));  // tuning runs
     IMCOM_TRY(ws_reserve(ctx, fft_inverse_ws(chunk, nsamp, nfft) + 8192));
     ProfScope ps(ctx, "psf_overlap");
