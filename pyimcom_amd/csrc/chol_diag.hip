@@ -3,7 +3,7 @@
 //
 // This kernel is the serial spine of the factorisation (18 dependent launches per cfg-2 stamp), so it is
 // organised around 16x16 sub-blocks to keep the dependent chain short:
-//   factor:  for b = 0..7: (a) 16x16 diagonal sub-block by 16 lanes of one wave (registers + LDS column),
+//   factor:  for b = 0..7: (a) 16x16 diagonal sub-block by 16 lanes of one wave (a row per lane in registers, v_readlane),
 //            (b) panel rows below solved against it (one thread per row), (c) trailing update of the
 //            remaining sub-blocks with v_mfma_f64_16x16x4_f64, tiles dealt over the 4 waves.
 //   invert:  16x16 diagonal inverses (one thread per column), then recursive doubling
@@ -32,6 +32,11 @@ __device__ __forceinline__ f64x4 mfma_16(FA a, FB b, int kt, f64x4 acc)
     return acc;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int l)  // l: wave-uniform
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, double *__restrict__ Dinv, int ldn, int k,
                                                         const int *__restrict__ nblk, int *__restrict__ fail)
 {
@@ -43,32 +48,56 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (k >= nblk[s] || fail[s] != 0) return;
     double *Lkk = L + (long)s * ldn * ldn + (long)k * NB * ldn + k * NB;
-    for (int t = tid; t < NB * NB; t += 256) S[(t >> 7) * SLD + (t & 127)] = Lkk[(long)(t >> 7) * ldn + (t & 127)];
+    // 128 x 128 doubles as 16-byte chunks, eight loads in flight per thread (one 8-byte load per trip was 15 % of the kernel)
+    {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+        for (int t0 = tid; t0 < NB * NB / 2; t0 += 8 * 256) {
+            f64x2 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int t = t0 + 256 * q;
+                v[q] = *(const f64x2 *)&Lkk[(long)(t >> 6) * ldn + 2 * (t & 63)];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int t = t0 + 256 * q;
+                *(f64x2 *)&S[(t >> 6) * SLD + 2 * (t & 63)] = v[q];
+            }
+        }
+    }
     if (tid == 0) bad = 0;
     __syncthreads();
 
     // ------------------------------------------------------------------ factor
     for (int b = 0; b < 8; b++) {
         const int o = 16 * b;
-        // (a) diagonal 16x16 sub-block: lanes 0..15 of wave 0, column by column through LDS
+        // (a) diagonal 16x16 sub-block: lanes 0..15 of wave 0 hold one row each in registers; right-looking, the column just
+        //     finished is handed round by v_readlane (everything unrolled: no LDS round trip inside the 16 dependent steps; the
+        //     left-looking form through LDS, a dot product of j dependent loads per column, was 40 % of this kernel).  Each
+        //     element still sees the same subtractions in the same order: S[r][c] - L[r][0] L[c][0] - L[r][1] L[c][1] - ...
         if (wave == 0) {
+            double row[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) row[c] = lane < 16 ? S[(o + lane) * SLD + o + c] : 1.0;
+            int failj = -1;  // first non-positive pivot (wave-uniform); the steps after it run on, their results are discarded
+#pragma unroll
             for (int j = 0; j < 16; j++) {
-                double v = 0.0;
-                if (lane < 16 && lane >= j) {
-                    v = S[(o + lane) * SLD + o + j];
-                    for (int c = 0; c < j; c++) v -= S[(o + lane) * SLD + o + c] * S[(o + j) * SLD + o + c];
-                }
-                const double d = __shfl(v, j, 64);
-                if (!(d > 0.0)) {  // also NaN
-                    if (lane == 0) { bad = 1; fail[s] = k * NB + o + j + 1; }
-                    break;
-                }
+                const double d = readlane_f64(row[j], j);
+                if (failj < 0 && !(d > 0.0)) failj = j;  // also NaN
                 const double ljj = sqrt(d), rl = 1.0 / ljj;
-                if (lane == j) { S[(o + j) * SLD + o + j] = ljj; dg[o + j] = ljj; rdg[o + j] = rl; }
-                else if (lane < 16 && lane > j) S[(o + lane) * SLD + o + j] = v * rl;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double xr = lane == j ? ljj : row[j] * rl;  // L[r][j] for r >= j (rows above j: unused)
+                row[j] = xr;
+                if (lane == j) { dg[o + j] = ljj; rdg[o + j] = rl; }
+#pragma unroll
+                for (int c = j + 1; c < 16; c++) row[c] -= xr * readlane_f64(xr, c);
+            }
+            if (failj >= 0) {
+                if (lane == 0) { bad = 1; fail[s] = k * NB + o + failj + 1; }
+            } else if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c++)
+                    if (c <= lane) S[(o + lane) * SLD + o + c] = row[c];
             }
         }
         __syncthreads();
@@ -112,9 +141,13 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
         __syncthreads();
     }
     // L[k,k] out (strict upper part zeroed)
-    for (int t = tid; t < NB * NB; t += 256) {
-        const int r = t >> 7, c = t & 127;
-        Lkk[(long)r * ldn + c] = (c <= r) ? S[r * SLD + c] : 0.0;
+    for (int t = tid; t < NB * NB / 2; t += 256) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const int r = t >> 6, c = 2 * (t & 63);
+        f64x2 v = *(const f64x2 *)&S[r * SLD + c];
+        if (c > r) v.x = 0.0;
+        if (c + 1 > r) v.y = 0.0;
+        *(f64x2 *)&Lkk[(long)r * ldn + c] = v;
     }
     // ------------------------------------------------------------------ invert
     // 16x16 diagonal inverses: thread (blk = tid>>4, col = tid&15) for tid < 128 computes column `col`
@@ -187,9 +220,13 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
         __syncthreads();
     }
     double *Di = Dinv + ((long)s * (ldn / NB) + k) * NB * NB;
-    for (int t = tid; t < NB * NB; t += 256) {
-        const int r = t >> 7, c = t & 127;
-        Di[t] = (c <= r) ? Xinv(r, c) : 0.0;
+    for (int t = tid; t < NB * NB / 2; t += 256) {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const int r = t >> 6, c = 2 * (t & 63);
+        f64x2 v;
+        v.x = (c <= r) ? Xinv(r, c) : 0.0;
+        v.y = (c + 1 <= r) ? Xinv(r, c + 1) : 0.0;
+        *(f64x2 *)&Di[2 * t] = v;
     }
 }
 
