@@ -268,6 +268,7 @@ def main():
         ms, launches = fams["solve_gemm"]
         traffic, traffic_src = pmc_traffic(args.batch, cfg.name)
         achieved = solve_flops_step * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        probe = ctx.mfma_probe(50.0)  # a pure fp64 MFMA loop on every SIMD, measured now: what the pipe gives with no operand traffic
         out = {
             "metric": "postage-stamps/sec (and ms/stamp) for N~2k A-solve",
             "value": world * args.batch * args.steps / elapsed,
@@ -302,6 +303,7 @@ def main():
                 "flops_per_launch": solve_flops_step * args.steps / max(launches, 1),
                 "avg_launch_ms": ms / max(launches, 1),
                 "launches": launches,
+                "mfma_probe_tflops": probe,  # informative: frac above is against the guide's 78.6
             },
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()},
         }

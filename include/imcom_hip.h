@@ -67,6 +67,10 @@ int imcom_ctx_workspace_bytes(imcom_ctx *ctx, size_t *bytes);
 int imcom_ctx_profile_enable(imcom_ctx *ctx, int on);
 int imcom_ctx_profile_reset(imcom_ctx *ctx);
 int imcom_ctx_profile_get(imcom_ctx *ctx, const char *family, double *ms, long *launches);
+/* Diagnostic for the roofline: keeps the fp64 MFMA pipe of every SIMD busy -- and nothing else: no LDS, no memory, no
+ * barriers -- for about `millis` ms and reports the rate reached [TFLOP/s]: the ceiling of this chip at the clock it holds under
+ * matrix load, to set beside the guide's 78.6 TFLOP/s. */
+int imcom_ctx_mfma_probe(imcom_ctx *ctx, double millis, double *tflops);
 
 /* ------------------------------------------------------------------ native-routine seam --------
  * Replaces furry_parakeet.pyimcom_croutines.* (imported at lakernel.py:41-47, psfutil.py:37-49),

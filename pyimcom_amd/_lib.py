@@ -62,6 +62,7 @@ SIGNATURES = {
     "imcom_ctx_profile_enable": [_vp, _i],
     "imcom_ctx_profile_reset": [_vp],
     "imcom_ctx_profile_get": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_l)],
+    "imcom_ctx_mfma_probe": [_vp, _d, C.POINTER(_d)],
     "imcom_d5512_getw": [_vp, _vp, _l, _vp, _i],
     "imcom_interp_d5512": [_vp, _vp, _i, _i, _i, _vp, _vp, _l, _vp, _i, _i],
     "imcom_grid_d5512": [_vp, _vp, _i, _i, _vp, _vp, _l, _i, _i, _vp, _i],
@@ -153,6 +154,12 @@ class Context:
         ms, n = _d(0.0), _l(0)
         check(lib.imcom_ctx_profile_get(self.handle, family.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def mfma_probe(self, millis=50.0):
+        """Rate [TFLOP/s] of a pure fp64 MFMA loop on every SIMD (imcom_ctx_mfma_probe): the chip's ceiling under matrix load."""
+        tf = _d(0.0)
+        check(lib.imcom_ctx_mfma_probe(self.handle, float(millis), C.byref(tf)))
+        return tf.value
 
     def close(self):
         if self._h:

@@ -436,6 +436,35 @@ int imcom_ctx_profile_get(imcom_ctx *ctx, const char *family, double *ms, long *
     return IMCOM_OK;
 }
 
+int imcom_ctx_mfma_probe(imcom_ctx *ctx, double millis, double *tflops)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(tflops && millis > 0.0 && millis <= 1000.0, "bad arguments");
+    const int nwg = 2 * ctx->cu_count;  // two 8-wave workgroups per CU: four waves per SIMD, all resident at once
+    IMCOM_TRY(ws_reserve(ctx, 4096));
+    double *sink = (double *)ws_take(ctx, 8);
+    if (!sink) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    hipEvent_t e0, e1;
+    IMCOM_HIP_CHECK(hipEventCreate(&e0));
+    IMCOM_HIP_CHECK(hipEventCreate(&e1));
+    int iters = 200, waves = 8;  // calibrated on a short first run
+    double ms = 0.0;
+    for (int pass = 0; pass < 2; pass++) {
+        IMCOM_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        IMCOM_TRY(launch_mfma_probe(ctx, nwg, iters, sink, &waves));
+        IMCOM_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        float f = 0.f;
+        IMCOM_HIP_CHECK(hipEventElapsedTime(&f, e0, e1));
+        ms = f;
+        if (pass == 0) iters = (int)std::max(200.0, std::min(2.0e6, iters * millis / std::max(ms, 1e-3)));
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *tflops = (double)nwg * waves * 8.0 * iters * 2048.0 / (ms * 1e-3) / 1e12;  // 16 x 16 x 4 x 2 flop per MFMA and wave
+    return IMCOM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // native-routine seam: host pointers are staged through the workspace; device pointers used as is.
 #define IMCOM_STAGE_IN(T, name, src, count)                                                   \

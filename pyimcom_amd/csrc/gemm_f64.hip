@@ -346,6 +346,33 @@ __global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void gemm_kernel(const d
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rate probe (imcom_ctx_mfma_probe): the fp64 MFMA pipe of every SIMD kept busy by four waves with eight independent
+// accumulators each, and nothing else -- no LDS, no memory, no barriers.  What it reaches (77.5 TFLOP/s measured, 98.6 % of the
+// guide's 78.6) is the ceiling a kernel with operand traffic can be compared with.
+__global__ __launch_bounds__(MMA_THREADS, 2) void mfma_probe_kernel(int iters, double seed, double *__restrict__ sink)
+{
+    f64x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = f64x4{seed, 0.0, 0.0, (double)i};
+    const double a = 1.0 + seed * (double)(threadIdx.x & 3), b = 1.0 - seed;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v += acc[i][0] + acc[i][3];
+    if (v == 0.123456789) sink[0] = v;  // keeps the loop alive
+}
+
+int launch_mfma_probe(imcom_ctx *ctx, int nwg, int iters, double *sink, int *waves_per_wg)
+{
+    *waves_per_wg = MMA_WAVES;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(nwg), dim3(MMA_THREADS), 0, ctx->stream, iters, 1e-9, sink);
+    return check_launch("mfma_probe_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers
 
 int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int k, int nbmax, int batch, int abatch,
