@@ -168,3 +168,36 @@ def test_smooth_and_pad_golden(golden):
     one = psfs.smooth_and_pad(img, w, sg)
     assert torch.equal(st[0], one) and torch.equal(st[2], one) and torch.allclose(st[1], 2.0 * one, rtol=1e-15, atol=0)
     assert np.abs(one.cpu().numpy() - g["b_out"]).max() <= 2e-14 * np.abs(g["b_out"]).max()
+
+
+@pytest.mark.parametrize("ns,nfft", [(201, 512), (301, 768), (255, 1024), (33, 80), (21, 60)])
+def test_psf_overlap_padding_beyond_twice_nsamp(ns, nfft):
+    """nfft only has to be >= 2 nsamp: tables with more zero padding than PSFGrp.setup uses (static and general line-FFT
+    kernels: the kept window is then a smaller part of the transform) against numpy's rfft2 / irfft2, borders exactly zero."""
+    import ctypes as C
+
+    import torch
+
+    from pyimcom_amd._lib import check, default_context, lib
+
+    rng = np.random.default_rng(ns + nfft)
+    yy, xx = np.mgrid[:ns, :ns] - ns // 2
+    p1 = np.stack([np.exp(-(xx**2 + yy**2) / (2.0 * (2.0 + 0.4 * k) ** 2)) + 0.01 * rng.standard_normal((ns, ns)) for k in range(3)])
+    p2 = np.stack([np.exp(-((xx - 0.5) ** 2 + (yy + 0.3) ** 2) / (2.0 * (2.3 + 0.3 * k) ** 2)) for k in range(2)])
+    f1, f2 = np.zeros((3, nfft, nfft)), np.zeros((2, nfft, nfft))
+    f1[:, :ns, :ns], f2[:, :ns, :ns] = p1, p2
+    r1, r2 = np.fft.rfft2(f1), np.fft.rfft2(f2)
+    pairs = np.array([(i, j) for i in range(3) for j in range(2)], dtype=np.int32)
+    ref = np.stack([np.roll(np.fft.irfft2(r1[i] * np.conj(r2[j]), s=(nfft, nfft)), (ns // 2, ns // 2), axis=(0, 1))[:ns, :ns] for i, j in pairs])
+    dev = torch.device("cuda:0")
+    ctx = default_context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    t1, t2 = torch.as_tensor(p1, device=dev), torch.as_tensor(p2, device=dev)
+    out = torch.full((len(pairs), ns + 12, ns + 12), np.nan, dtype=torch.float64, device=dev)
+    dp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    check(lib.imcom_psf_overlap(ctx.handle, dp(t1), 3, dp(t2), 2, ns, nfft, pairs.ctypes.data_as(C.c_void_p), len(pairs), None, dp(out)))
+    got = out.cpu().numpy()
+    assert np.abs(got[:, 6:-6, 6:-6] - ref).max() < 2e-13 * np.abs(ref).max()
+    border = got.copy()
+    border[:, 6:-6, 6:-6] = 0.0
+    assert np.all(border == 0.0)  # every border element written, none left at the NaN fill
