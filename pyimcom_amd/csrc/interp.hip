@@ -91,6 +91,7 @@ __device__ __forceinline__ void grid_pixel(const double *__restrict__ f, int ngy
     int *xis = sm_i, *yis = sm_i + nxo, *red = yis + nyo;  // red[0]=rlo, red[1]=rhi
     if (tid == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; }
     __syncthreads();
+    int lo = 0x7fffffff, hi = -0x7fffffff;  // touched table rows seen by this thread
     for (int t = tid; t < nxo + nyo; t += nth) {
         const bool isx = t < nxo;
         const int idx = isx ? t : t - nxo;
@@ -105,13 +106,20 @@ __device__ __forceinline__ void grid_pixel(const double *__restrict__ f, int ngy
             if (!isx) c = -1;  // marker: row window is taken from valid rows only
         } else {
             d5512_getw(w, v - c - 0.5);
-            if (!isx) { atomicMin(&red[0], c - 4); atomicMax(&red[1], c + 5); }
+            if (!isx) { lo = min(lo, c - 4); hi = max(hi, c + 5); }
         }
         double *dst = isx ? wxs + 10 * idx : wys + 10 * idx;
 #pragma unroll
         for (int k = 0; k < 10; k++) dst[k] = w[k];
         (isx ? xis : yis)[idx] = c;
     }
+    // one LDS atomic pair per wave (48 lanes hitting the same two words one after the other cost a quarter of this kernel)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, 64));
+        hi = max(hi, __shfl_xor(hi, off, 64));
+    }
+    if ((tid & 63) == 0 && hi >= lo) { atomicMin(&red[0], lo); atomicMax(&red[1], hi); }
     __syncthreads();
     const int rlo = red[0], rhi = red[1];
     const int nrows = rhi - rlo + 1;
@@ -120,11 +128,49 @@ __device__ __forceinline__ void grid_pixel(const double *__restrict__ f, int ngy
         return;
     }
     if (nrows <= max_rows) {
-        // x-pass over the touched table rows
+        // x-pass over the touched table rows.  A thread keeps one output column -- its ten weights in registers, its tap address
+        // advancing by whole rows -- and walks the rows three at a time (fifteen 16-byte loads in flight: the pass waits on
+        // their latency; one row at a time left the five loads of an iteration alone in flight).
+        // (ten taps as five 16-byte loads at an 8-byte aligned address: global memory takes them)
+        if (nxo <= nth) {
+            const int nlane = nth / nxo, ix = tid % nxo, rl = tid / nxo;
+            if (rl < nlane) {
+                double w[10];
+#pragma unroll
+                for (int j = 0; j < 10; j++) w[j] = wxs[10 * ix + j];
+                const double *col = f + (long)rlo * ngx + (xis[ix] - 4);
+                constexpr int U = 3;  // rows in flight per thread
+                int r = rl;
+                for (; r + (U - 1) * nlane < nrows; r += U * nlane) {
+                    f64x2u a[U][5];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const f64x2u *ra = (const f64x2u *)(col + (long)(r + u * nlane) * ngx);
+#pragma unroll
+                        for (int q = 0; q < 5; q++) a[u][q] = ra[q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        double sa = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 10; j++) sa += w[j] * a[u][j >> 1][j & 1];
+                        tmp[(r + u * nlane) * nxo + ix] = sa;
+                    }
+                }
+                for (; r < nrows; r += nlane) {
+                    const f64x2u *ra = (const f64x2u *)(col + (long)r * ngx);
+                    f64x2u a[5];
+#pragma unroll
+                    for (int q = 0; q < 5; q++) a[q] = ra[q];
+                    double sa = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 10; j++) sa += w[j] * a[j >> 1][j & 1];
+                    tmp[r * nxo + ix] = sa;
+                }
+            }
+        } else
         for (int t = tid; t < nrows * nxo; t += nth) {
             const int r = t / nxo, ix = t - r * nxo;
-            // the ten taps as five 16-byte loads at an 8-byte aligned address (global memory takes them): half the
-            // load instructions of ten 8-byte ones through the texture path that bounds this pass
             const f64x2u *row = (const f64x2u *)(f + (long)(rlo + r) * ngx + (xis[ix] - 4));
             const double *w = wxs + 10 * ix;
             f64x2u c[5];
@@ -136,6 +182,19 @@ __device__ __forceinline__ void grid_pixel(const double *__restrict__ f, int ngy
             tmp[t] = strip;
         }
         __syncthreads();
+        if (nxo <= nth) {
+            const int nlane = nth / nxo, ix = tid % nxo, yl = tid / nxo;
+            if (yl < nlane)
+                for (int iy = yl; iy < nyo; iy += nlane) {
+                    const int yc = yis[iy];
+                    const double *w = wys + 10 * iy;
+                    const double *col = tmp + (yc < 0 ? 0 : yc - 4 - rlo) * nxo + ix;  // invalid rows carry zero weights: any staged rows do
+                    double o = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 10; i++) o += col[i * nxo] * w[i];
+                    out[iy * nxo + ix] = o;
+                }
+        } else
         for (int t = tid; t < nxo * nyo; t += nth) {
             const int iy = t / nxo, ix = t - iy * nxo;
             const int yc = yis[iy];
