@@ -49,6 +49,7 @@ constexpr int NCH = 5;     // 16-byte chunks per stencil row
 #define IMCOM_A_RING 2
 #endif
 constexpr int A_RING = IMCOM_A_RING;
+constexpr int A_PMAX = 24;  // stamp-local PSFs (4 groups x 6 exposures) up to which the pair table is staged in LDS
 
 __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const int *__restrict__ n, int ldn,
                                                       const double *__restrict__ x,
@@ -64,6 +65,12 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     __shared__ int seg0[256];   // first element (ascending address order) of stencil row 0; < 0: no loads
     __shared__ int rstep[256];  // element step between stencil rows (+ng, or -ng for a flipped table)
     __shared__ double tile[16][17];
+    // the tile's 16 + 16 pixels and the stamp's pair table, fetched once by a few lanes in ONE round trip (every thread doing its
+    // own psf -> pair_tab -> pair_pen chain of dependent global loads made the prologue 40 % of this kernel)
+    __shared__ int pix_psf[32];
+    __shared__ double pix_x[32], pix_y[32];
+    __shared__ int ptab[A_PMAX * A_PMAX];
+    __shared__ double ppen[A_PMAX * A_PMAX];
     const int s = blockIdx.y, tid = threadIdx.x;
     int ti, tj;
     // Workgroups are dealt round-robin over the 8 XCDs (dispatch order % 8), each with its own L2: give every XCD a
@@ -86,53 +93,61 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
         return;
     }
     const long base = (long)s * ldn;
+    const bool ptab_lds = npsf_max <= A_PMAX;
+    if (tid < 32) {
+        const int p = (tid < 16 ? ti : tj) * 16 + (tid & 15);
+        const bool in = p < ns;
+        pix_psf[tid] = in ? psf[base + p] : 0;
+        pix_x[tid] = in ? x[base + p] : 0.0;
+        pix_y[tid] = in ? y[base + p] : 0.0;
+    }
+    if (ptab_lds)
+        for (int e = tid; e < npsf_max * npsf_max; e += 256) {
+            ptab[e] = pair_tab[(long)s * npsf_max * npsf_max + e];
+            ppen[e] = pair_pen[(long)s * npsf_max * npsf_max + e];
+        }
+    __syncthreads();
     double wx[10], wy[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) wx[k] = wy[k] = 0.0;  // samples without a stencil (off the table, lower triangle) add nothing
     double val = 0.0, pen = 0.0;
-    bool active = false;
+    bool active = false, rev = false;
     long my_seg0 = -1;
     int my_step = 0;
+    double fx = 0.0, fy = 0.0;  // fractional cell positions: the weights are formed after the first stencil row is on its way
     if (i < ns && j < ns && j >= i) {
-        const int pi = psf[base + i], pj = psf[base + j];
-        const long pidx = ((long)s * npsf_max + pi) * npsf_max + pj;
-        const int code = pair_tab[pidx];
-        pen = pair_pen[pidx];
+        const int pe = pix_psf[li] * npsf_max + pix_psf[16 + lj];
+        const int code = ptab_lds ? ptab[pe] : pair_tab[(long)s * npsf_max * npsf_max + pe];
+        pen = ptab_lds ? ppen[pe] : pair_pen[(long)s * npsf_max * npsf_max + pe];
         if (code >= 0) {
-            const bool swap = code & PAIR_SWAP, rev = code & PAIR_FLIP;
+            const bool swap = code & PAIR_SWAP;
+            rev = code & PAIR_FLIP;
             const int tab = code & PAIR_MASK;
-            double dx = swap ? x[base + j] - x[base + i] : x[base + i] - x[base + j];
-            double dy = swap ? y[base + j] - y[base + i] : y[base + i] - y[base + j];
+            double dx = swap ? pix_x[16 + lj] - pix_x[li] : pix_x[li] - pix_x[16 + lj];
+            double dy = swap ? pix_y[16 + lj] - pix_y[li] : pix_y[li] - pix_y[16 + lj];
             dx /= dscale; dx += nc; dx += 6.0;
             dy /= dscale; dy += nc; dy += 6.0;
             const int xi = to_cell(dx), yi = to_cell(dy);
             if (!(xi < 4 || xi >= ng - 5 || yi < 4 || yi >= ng - 5)) {
-                d5512_getw(wx, dx - xi - 0.5);
-                d5512_getw(wy, dy - yi - 0.5);
+                fx = dx - xi - 0.5;
+                fy = dy - yi - 0.5;
                 const long t0 = (long)tab * ng * ng, off = (long)(yi - 4) * ng + (xi - 4);
                 // flipped table: tap (r, c) is element last - (off + r*ng + c): row r is the ascending
                 // segment that starts at last - off - r*ng - 9, read back to front
                 my_seg0 = rev ? t0 + ((long)ng * ng - 1 - off - 9) : t0 + off;
                 my_step = rev ? -ng : ng;
-                if (rev) {  // reversed taps: flip the x weights once; the sum below then runs k = 9..0,
-                            // which is the reference's order over the flipped table's columns
-#pragma unroll
-                    for (int c = 0; c < 5; c++) { const double t = wx[c]; wx[c] = wx[9 - c]; wx[9 - c] = t; }
-                }
                 active = true;
             }
         }
     }
     seg0[tid] = (int)my_seg0;  // launch_build_A checks that the table stack fits 31 bits
     rstep[tid] = my_step;
+    double wt[10];  // the x weights as the row loop uses them (set below, once the first row is on its way)
     // A stencil row is staged as the FIVE 16-byte chunks that hold exactly its 10 taps: the LDS-DMA takes 8-byte aligned
     // global addresses, so a chunk may start on any double (round 1 fetched six aligned chunks per row and carried two
     // zero-weight doubles: 96 instead of 80 bytes through the L2 -> CU path that bounds this kernel, and two weight
     // tables for the alternating parity of the rows).  The five chunks of a sample are five consecutive 16-byte LDS slots:
     // stride 80 B = 20 banks, which takes the 16 lanes of a ds_read_b128 group through all 64 banks.
-    double wt[10];
-#pragma unroll
-    for (int m = 0; m < 10; m++) wt[m] = active ? wx[m] : 0.0;
     // does any stencil of this tile end within a chunk of the end of the table stack?  (block-uniform; almost never)
     const long my_last = my_seg0 < 0 ? 0 : (my_step > 0 ? my_seg0 + 9L * my_step : my_seg0) + 10;
     const int near_end = __syncthreads_or(my_last >= tab_elems);
@@ -177,10 +192,24 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
         val += strip * wyr;
     };
     if (!near_end) {
-        // One row (five DMA instructions of this wave) is in flight while the previous one is consumed: vmcnt(5)
-        // = the older row has landed.  lgkmcnt(0) before a buffer is refilled: its LDS reads have returned.
         stage(seg[0]);
         if (A_RING > 2) stage(seg[1]);
+    }
+    // the interpolation weights, formed while the first stencil row is in flight
+    if (active) {
+        d5512_getw(wx, fx);
+        d5512_getw(wy, fy);
+        if (rev) {  // reversed taps: flip the x weights once; the sum below then runs k = 9..0,
+                    // which is the reference's order over the flipped table's columns
+#pragma unroll
+            for (int c = 0; c < 5; c++) { const double t = wx[c]; wx[c] = wx[9 - c]; wx[9 - c] = t; }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 10; m++) wt[m] = active ? wx[m] : 0.0;
+    if (!near_end) {
+        // One row (five DMA instructions of this wave) is in flight while the previous one is consumed: vmcnt(5)
+        // = the older row has landed.  lgkmcnt(0) before a buffer is refilled: its LDS reads have returned.
 #pragma unroll
         for (int r = 0; r < 10; r++) {
             const int ahead = r + A_RING - 1;  // the row issued now; rows r+1 .. ahead are in flight while r is consumed
