@@ -79,16 +79,48 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
 
 
 
-def coadd_block(cfg, pool, tables, n1P, n_expo, batch=64, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None):
+def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap=256):
+    """Stamps per batch for a block: as many as memory holds (at most ``cap``), and among those the count for which the block's
+    passes -- the short last one included -- take the fewest rounds of workgroups.  A solve launch has batch x ldm/128 workgroups for 2 x ``cu_count`` resident ones: 256 cfg-2 stamps
+    are exactly 9 rounds, 128 are 4.5 (every launch ends with a half-empty round: cfg-4 ran 694 stamps/s at 128, 793 at 256),
+    64 are 2.25.  Per stamp: A, L (ldn^2 each), -B/2, Y (ldn x ldm per target, fp64), T (fp32), the inverted diagonal blocks."""
+    per_stamp = 8 * (2 * ldn * ldn + 2 * n_out * ldn * ldm + ldn * NB) + 4 * n_out * ldn * ldm + 64 * ldm * n_out
+    hi = min(int(n_stamps), int(cap))
+    if free_bytes is not None:
+        hi = max(1, min(hi, int(0.8 * free_bytes) // per_stamp))
+    if hi >= n_stamps:
+        return int(n_stamps)
+    tiles, slots = max(ldm // NB, 1), 2 * cu_count
+    rounds = lambda k: -(-k * tiles // slots)  # noqa: E731  rounds of workgroups of a launch over k stamps
+    best, best_cost = hi, None
+    for b in range(hi, max(hi // 2, 1) - 1, -1):  # not below half of what fits: every pass costs its launches' fixed parts again
+        cost = (n_stamps // b) * rounds(b) + (rounds(n_stamps % b) if n_stamps % b else 0)  # all passes of the block, the short last one too
+        if best_cost is None or cost < best_cost:
+            best, best_cost = b, cost
+    return best
+
+
+def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None):
     """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
     order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables or BlockTables.  ``stamps``: the (j_st, i_st) to
     coadd (default all n1P x n1P, row by row as coadd.py:2049-2052); ``pad_sides=None`` leaves the boundary recovery of
-    coadd.py:2163-2181 out.  Returns the BlockMaps."""
+    coadd.py:2163-2181 out.  ``batch``: stamps per pass (default: ``choose_batch`` from the block's largest stamp and the
+    free device memory).  Returns the BlockMaps."""
     nst = n1P + 2
     assert pool.n_inst == nst * nst
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
                      n_out=int(getattr(tables, "n_out", 1)))
     todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)] if stamps is None else [(int(j), int(i)) for j, i in stamps]
+    if batch is None:
+        import torch
+
+        counts = np.diff(pool.inst_off).reshape(nst, nst)
+        win = sum(counts[dj : dj + n1P, di : di + n1P] for dj in range(3) for di in range(3))  # pixels of the nine neighbours of every stamp
+        cap = int(max(win[j - 1, i - 1] for j, i in todo)) if todo else NB
+        ldn_max = ldn or max(NB, (cap + NB - 1) // NB * NB)
+        ldm = (cfg.m + NB - 1) // NB * NB
+        free = torch.cuda.mem_get_info(pool.device)[0]
+        batch = choose_batch(len(todo), ldn_max, ldm, int(getattr(tables, "n_out", 1)), free)
     prepare = lambda chunk: prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn)  # noqa: E731
 
     # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after

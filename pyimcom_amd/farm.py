@@ -68,7 +68,7 @@ def write_block(path, maps, meta=None):
     os.replace(tmp, path)
 
 
-def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=128, device=None, restart=True, log=print, coadd=None):
+def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=None, restart=True, log=print, coadd=None):
     """Coadd this rank's share of `blocks` (ids) and write block_<id>.npz files into `outdir`.
 
     costs[k]: relative cost of blocks[k] (estimate_cost summed over its stamps) for the static LPT partition;
@@ -162,7 +162,7 @@ def main(argv=None):
     ap.add_argument("--config", default="cfg4")
     ap.add_argument("--mosaic", type=int, default=4, help="blocks per side")
     ap.add_argument("--n1P", type=int, default=2, help="output stamps per block side")
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=None, help="stamps per pass (default: blockrun.choose_batch)")
     ap.add_argument("--seed", type=int, default=4)
     ap.add_argument("--psf-groups", action="store_true", help="a PSF group per 2x2 InStamps (BlockTables) instead of one per block")
     ap.add_argument("--no-restart", action="store_true", help="recompute blocks whose output exists")

@@ -111,7 +111,7 @@ def target_psfs(cfg, psfgrp, device):
     return psfs.sample_psf(imgs, ns, None, bool(cfg.psf_circ), bool(cfg.psf_norm))
 
 
-def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=128, device="cuda:0", stamps=None, finalize=True, table_capacity=None):
+def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None):
     """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  ``stamps``: optional list of
     (j_st, i_st) to coadd instead of all n1P x n1P (the reference's ``stoptile`` debugging aid stops early in the same
     way); ``finalize=False`` skips the boundary recovery of coadd.py:2163-2181.  Returns the ``BlockMaps``."""
@@ -135,7 +135,7 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=128, device="cuda:
     n_max = max(v.shape[0] for v in group_psfs.values())
     if table_capacity is None:  # the sets one batch of stamps can touch, with room to keep neighbouring groups resident
         per_group = n_max * (n_max + 1) // 2 + target.shape[0] * n_max + 4 * n_max * n_max
-        table_capacity = min(max(4 * per_group * max(1, batch // 4), 256), (2**31 - 1) // ((int(psfgrp.nsamp) + 12) ** 2))
+        table_capacity = min(max(4 * per_group * max(1, (batch or 256) // 4), 256), (2**31 - 1) // ((int(psfgrp.nsamp) + 12) ** 2))
     tables = BlockTables(group_psfs, target, int(psfgrp.nfft), group_expo=group_expo, capacity=int(table_capacity), amp_penalty=amp, device=device)
     maps = coadd_block(scfg, pool, tables, int(cfg.n1P), int(blk.n_inimage), batch=batch, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
                        postage_pad=int(getattr(cfg, "postage_pad", 0)), stamps=stamps)
