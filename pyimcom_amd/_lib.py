@@ -63,6 +63,7 @@ SIGNATURES = {
     "imcom_ctx_profile_reset": [_vp],
     "imcom_ctx_profile_get": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_l)],
     "imcom_ctx_mfma_probe": [_vp, _d, C.POINTER(_d)],
+    "imcom_ctx_gemm_probe": [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_d)],
     "imcom_d5512_getw": [_vp, _vp, _l, _vp, _i],
     "imcom_interp_d5512": [_vp, _vp, _i, _i, _i, _vp, _vp, _l, _vp, _i, _i],
     "imcom_grid_d5512": [_vp, _vp, _i, _i, _vp, _vp, _l, _i, _i, _vp, _i],
@@ -159,6 +160,12 @@ class Context:
         """Rate [TFLOP/s] of a pure fp64 MFMA loop on every SIMD (imcom_ctx_mfma_probe): the chip's ceiling under matrix load."""
         tf = _d(0.0)
         check(lib.imcom_ctx_mfma_probe(self.handle, float(millis), C.byref(tf)))
+        return tf.value
+
+    def gemm_probe(self, variant, M=2304, N=2304, K=2304, batch=8, reps=5):
+        """TFLOP/s of the tile engine's k loop as a plain batched product (imcom_ctx_gemm_probe): variant 0 = 128 x 128 tiles, 1 = 256 x 128."""
+        tf = _d(0.0)
+        check(lib.imcom_ctx_gemm_probe(self.handle, int(variant), int(M), int(N), int(K), int(batch), int(reps), C.byref(tf)))
         return tf.value
 
     def close(self):

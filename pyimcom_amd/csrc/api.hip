@@ -465,6 +465,37 @@ int imcom_ctx_mfma_probe(imcom_ctx *ctx, double millis, double *tflops)
     return IMCOM_OK;
 }
 
+int imcom_ctx_gemm_probe(imcom_ctx *ctx, int variant, int M, int N, int K, int batch, int reps, double *tflops)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(tflops && (variant == 0 || variant == 1) && M >= 256 && N >= 128 && K >= 16 && batch >= 1 && reps >= 1, "bad arguments");
+    IMCOM_REQUIRE(M % 256 == 0 && N % 128 == 0 && K % 16 == 0, "gemm probe: M % 256, N % 128, K % 16");
+    const size_t a = (size_t)batch * M * K * 8, b = (size_t)batch * K * N * 8, c = (size_t)batch * M * N * 8;
+    IMCOM_TRY(ws_reserve(ctx, a + b + c + 4096));
+    double *A = (double *)ws_take(ctx, a), *B = (double *)ws_take(ctx, b), *C = (double *)ws_take(ctx, c);
+    if (!A || !B || !C) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    IMCOM_HIP_CHECK(hipMemsetAsync(A, 0, a, ctx->stream));  // zeros: the pipe does not care, and nothing overflows
+    IMCOM_HIP_CHECK(hipMemsetAsync(B, 0, b, ctx->stream));
+    hipEvent_t e0, e1;
+    IMCOM_HIP_CHECK(hipEventCreate(&e0));
+    IMCOM_HIP_CHECK(hipEventCreate(&e1));
+    auto run = [&]() -> int {
+        if (variant == 1) return launch_gemm_probe16(ctx, M, N, K, batch, A, B, C);
+        return launch_gemm(ctx, false, true, M, N, K, batch, A, K, (long)M * K, B, N, (long)K * N, C, N, (long)M * N, 1.0, 0.0);
+    };
+    IMCOM_TRY(run());  // warm-up
+    IMCOM_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; r++) IMCOM_TRY(run());
+    IMCOM_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    IMCOM_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *tflops = 2.0 * M * N * K * batch * reps / (ms * 1e-3) / 1e12;
+    return IMCOM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // native-routine seam: host pointers are staged through the workspace; device pointers used as is.
 #define IMCOM_STAGE_IN(T, name, src, count)                                                   \

@@ -352,3 +352,18 @@ def test_croutines_shim_is_importable_as_top_level_module(golden):
     finally:
         sys.path.remove(shim_dir)
         sys.modules.pop("pyimcom_croutines", None)
+
+
+@pytest.mark.gpu
+def test_rate_probes_run():
+    """The two diagnostics behind the roofline discussion run and return sane rates: a pure fp64 MFMA loop
+    (imcom_ctx_mfma_probe) and the tile engine's k loop as a plain batched product, 128 x 128 against 256 x 128 tiles
+    (imcom_ctx_gemm_probe)."""
+    from pyimcom_amd._lib import default_context
+
+    ctx = default_context()
+    peak = ctx.mfma_probe(10.0)
+    assert 40.0 < peak < 90.0, peak
+    for variant in (0, 1):
+        rate = ctx.gemm_probe(variant, 1024, 1024, 1024, 8, 2)
+        assert 10.0 < rate < peak, (variant, rate, peak)
