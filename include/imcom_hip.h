@@ -71,8 +71,8 @@ int imcom_ctx_profile_get(imcom_ctx *ctx, const char *family, double *ms, long *
  * barriers -- for about `millis` ms and reports the rate reached [TFLOP/s]: the ceiling of this chip at the clock it holds under
  * matrix load, to set beside the guide's 78.6 TFLOP/s. */
 int imcom_ctx_mfma_probe(imcom_ctx *ctx, double millis, double *tflops);
-/* Diagnostic: the k loop of the tile engine as a plain batched product C[M][N] = A[M][K] (row-major) B[K][N] on zero-filled
- * workspace, `reps` launches; variant 0: the production 128 x 128 tiles (two 8-wave workgroups per CU), variant 1: 256 x 128
+/* Diagnostic: the k loop of the tile engine as a plain batched product C[M][N] = A[M][K] (row-major) B[K][N] on pseudo-random
+ * operands in workspace, `reps` launches; variant 0: the production 128 x 128 tiles (two 8-wave workgroups per CU), variant 1: 256 x 128
  * tiles by one 16-wave workgroup per CU (half the B traffic per flop).  M % 256 = N % 128 = K % 16 = 0. */
 int imcom_ctx_gemm_probe(imcom_ctx *ctx, int variant, int M, int N, int K, int batch, int reps, double *tflops);
 

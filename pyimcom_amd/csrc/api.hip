@@ -474,8 +474,8 @@ int imcom_ctx_gemm_probe(imcom_ctx *ctx, int variant, int M, int N, int K, int b
     IMCOM_TRY(ws_reserve(ctx, a + b + c + 4096));
     double *A = (double *)ws_take(ctx, a), *B = (double *)ws_take(ctx, b), *C = (double *)ws_take(ctx, c);
     if (!A || !B || !C) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
-    IMCOM_HIP_CHECK(hipMemsetAsync(A, 0, a, ctx->stream));  // zeros: the pipe does not care, and nothing overflows
-    IMCOM_HIP_CHECK(hipMemsetAsync(B, 0, b, ctx->stream));
+    IMCOM_TRY(launch_probe_fill(ctx, A, (long)(a / 8), 1u));  // pseudo-random operands: the power (and clock) of real data
+    IMCOM_TRY(launch_probe_fill(ctx, B, (long)(b / 8), 2u));
     hipEvent_t e0, e1;
     IMCOM_HIP_CHECK(hipEventCreate(&e0));
     IMCOM_HIP_CHECK(hipEventCreate(&e1));

@@ -16,6 +16,7 @@ int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ld
                      const int *nblk, const int *n, const double *Dinv, double *partial, int nparts, double *Npart, float *Tt);
 int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, int ldm, int k, int batch,
                       const int *nblk, bool trans);
+int launch_probe_fill(imcom_ctx *ctx, double *p, long count, unsigned seed);
 int launch_gemm_probe16(imcom_ctx *ctx, int M, int N, int K, int batch, const double *A, const double *B, double *C);
 int launch_mfma_probe(imcom_ctx *ctx, int nwg, int iters, double *sink, int *waves_per_wg);
 int launch_gemm(imcom_ctx *ctx, bool akm, bool bkm, int M, int N, int K, int batch, const double *A, long lda,
