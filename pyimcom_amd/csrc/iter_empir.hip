@@ -10,6 +10,14 @@
 
 namespace imcom {
 
+// iter_block.hip: the same solve for 4 x 4 patches of output pixels at a time (one MFMA product per CG step and patch)
+size_t iter_block_ws_bytes(int batch, int nblocks);
+int iter_block_count(int m, int W);
+int iter_block_umax();
+int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, const double *diag, long ldd, const double *B, long ldb,
+                      const double *oyx, const double *iy, const double *ix, long ldxy, const int *n, int m, int W, int batch,
+                      double rho, double rtol, int maxiter, float *T, long ldt, void *ws, int *max_union);
+
 constexpr int CG_MAXSEL = 4096;            // input pixels inside one acceptance disc (LDS: 16 KB indices + 32 KB p)
 constexpr int CG_SLOTS = CG_MAXSEL / 256;  // rows of the sub-system owned by one thread
 constexpr int IT_MAXNV = 8;
@@ -456,11 +464,27 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
     IMCOM_REQUIRE(nmax == 0 || (A && mBhalf && T && in_y && in_x), "null matrix / coordinate pointer");
     const bool host = memspace == IMCOM_MEM_HOST, exact = exact_UC != 0;
     const int np = (int)align_up((size_t)std::max(nmax, 1), NB), mp = (int)align_up((size_t)m, NB);
+    // Width of the output-pixel grid (pixels arrive row by row: yx_val.ravel(), lakernel.py:613-614): the first index whose y
+    // differs from pixel 0's.  It only decides which 16 pixels share a workgroup of the blocked solver; any value is correct.
+    static const bool per_pixel = getenv("IMCOM_ITER_PER_PIXEL") != nullptr;  // A/B and cross-check: the one-pixel-per-workgroup kernel
+    int gridW = m;
+    if (!per_pixel && nmax > 0) {
+        std::vector<double> y0((size_t)std::min(m, 8192));
+        if (host) std::copy(out_yx, out_yx + y0.size(), y0.begin());
+        else {
+            IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            IMCOM_HIP_CHECK(hipMemcpy(y0.data(), out_yx, y0.size() * 8, hipMemcpyDeviceToHost));
+        }
+        for (size_t a = 1; a < y0.size(); a++)
+            if (y0[a] != y0[0]) { gridW = (int)a; break; }
+    }
+    const int nblocks = iter_block_count(m, gridW);
     const size_t szA = (size_t)batch * ldn * ldn, szB = (size_t)batch * m * ldn, szM = (size_t)batch * m;
     const size_t big = (size_t)batch * mp * np * 8;
     size_t total = 65536 + (size_t)nv * szB * 4 + (size_t)batch * ldn * 8 + (size_t)batch * (MAX_INC + 4) * 8 + szM * 8 * (4 + nv + 2 * nv * nv);
     if (exact) total += big * (1 + nv) + (size_t)batch * np * np * 8;
     if (host) total += (szA + szB) * 8 + szB * 4 + szM * 12 + szM * 16 + (size_t)batch * ldn * 16 + 4096;
+    if (!per_pixel) total += iter_block_ws_bytes(batch, nblocks) + 4096;
     IMCOM_TRY(ws_reserve(ctx, total));
     Stage st{ctx, host};
     const double *A_d, *B_d, *yx_d, *iy_d, *ix_d;
@@ -480,7 +504,8 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
     int *ints = (int *)ws_take(ctx, (size_t)batch * 8 + 8);
     double *kc = (double *)ws_take(ctx, (size_t)(batch + nv) * 8);
     double *flat = (double *)ws_take(ctx, szM * 8 * (4 + nv + 2 * nv * nv));
-    if (!Tn || !dsh || !inc || !ints || !kc || !flat) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    void *blkws = per_pixel ? nullptr : ws_take(ctx, iter_block_ws_bytes(batch, nblocks));
+    if (!Tn || !dsh || !inc || !ints || !kc || !flat || (!per_pixel && !blkws)) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     int *n_dev = ints, *ninc = ints + batch, *status = ints + 2 * batch;
     double *Cs_d = kc, *kappaC_d = kc + batch;
     double *Nf = flat, *Df = Nf + szM * nv * nv, *Ef = Df + szM * nv, *ok = Ef + szM * nv * nv, *oS = ok + szM, *oU = oS + szM, *ow = oU + szM;
@@ -511,9 +536,19 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
             IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
             IMCOM_TRY(launch_diag_shift(ctx, A_d, ldn, inc, ninc, dsh, batch));
             ProfScope ps(ctx, "iter_cg");
-            hipLaunchKernelGGL(iter_cg_kernel, dim3(m, batch), dim3(256), 0, ctx->stream, A_d, (long)ldn, (long)ldn * ldn, dsh, (long)ldn, B_d,
-                               (long)ldn, yx_d, iy_d, ix_d, (long)ldn, n_dev, m, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, status);
-            IMCOM_TRY(check_launch("iter_cg_kernel"));
+            bool blocked = false;
+            if (!per_pixel) {  // 4 x 4 patches of output pixels per workgroup (iter_block.hip), unless a patch selects too many input pixels
+                int mx = 0;
+                IMCOM_HIP_CHECK(hipMemsetAsync(Tn + (size_t)p * szB, 0, szB * 4, ctx->stream));
+                IMCOM_TRY(launch_iter_block(ctx, A_d, (long)ldn, (long)ldn * ldn, dsh, (long)ldn, B_d, (long)ldn, yx_d, iy_d, ix_d, (long)ldn, n_dev, m,
+                                            gridW, batch, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, blkws, &mx));
+                blocked = mx <= iter_block_umax();
+            }
+            if (!blocked) {
+                hipLaunchKernelGGL(iter_cg_kernel, dim3(m, batch), dim3(256), 0, ctx->stream, A_d, (long)ldn, (long)ldn * ldn, dsh, (long)ldn, B_d,
+                                   (long)ldn, yx_d, iy_d, ix_d, (long)ldn, n_dev, m, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, status);
+                IMCOM_TRY(check_launch("iter_cg_kernel"));
+            }
         }
         int st_h = 0;
         IMCOM_HIP_CHECK(hipMemcpyAsync(&st_h, status, 4, hipMemcpyDeviceToHost, ctx->stream));

