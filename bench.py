@@ -142,7 +142,7 @@ def block_leg(ctx, dev, n1P=16, batch=256, reps=2):
     base = torch.as_tensor(psfs, device=dev)
     lt = torch.arange(ns, dtype=torch.float64, device=dev) - (ns - 1) / 2.0
     yo, xo = torch.meshgrid(lt, lt, indexing="ij")
-    groups, counts = {}, {}
+    groups, counts, imgs, yxcos = {}, {}, [], []
     for gj in range(ng):
         for gi in range(ng):
             mod = 1.0 + 0.02 * np.sin(0.05 * lin * (1 + gi % 3))[None, None, :] + 0.02 * np.cos(0.04 * lin * (1 + gj % 3))[None, :, None]
@@ -150,14 +150,29 @@ def block_leg(ctx, dev, n1P=16, batch=256, reps=2):
             img[:, 8 : 8 + ns, 8 : 8 + ns] = base * torch.as_tensor(mod, device=dev)
             th = torch.as_tensor([0.004 * (e - E / 2) + 0.002 * (gi - gj) for e in range(E)], dtype=torch.float64, device=dev)
             c, sn = torch.cos(th)[:, None, None], torch.sin(th)[:, None, None]
-            yxco = torch.stack([c * yo + sn * xo, -sn * yo + c * xo], dim=1).contiguous()
-            groups[(gj, gi)] = lambda img=img, yxco=yxco: psfmod.sample_psf(img, ns, yxco, psf_norm=True, ctx=ctx)
+            imgs.append(img)
+            yxcos.append(torch.stack([c * yo + sn * xo, -sn * yo + c * xo], dim=1))
+            groups[(gj, gi)] = None  # sampled by the bulk provider below
             counts[(gj, gi)] = E
+    img_all, yxco_all = torch.stack(imgs), torch.stack(yxcos).contiguous()  # [groups, E, ...]
+    del imgs, yxcos
+    order = {k: q for q, k in enumerate(groups)}
+
+    def sample_groups(keys):
+        # the groups a batch of stamps needs for the first time, sampled in one call (BlockTables hands over runs of neighbours)
+        q0, q1 = order[keys[0]], order[keys[-1]] + 1
+        if [order[k] for k in keys] == list(range(q0, q1)):
+            im, yx = img_all[q0:q1], yxco_all[q0:q1]
+        else:
+            idx = torch.as_tensor([order[k] for k in keys], device=dev)
+            im, yx = img_all[idx], yxco_all[idx]
+        return psfmod.sample_psf(im.reshape(-1, ns + 16, ns + 16), ns, yx.reshape(-1, 2, ns, ns), psf_norm=True, ctx=ctx)
+
     fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize", "epilogue", "block_acc")
 
     def one():
         # table construction (PSF sampling, spectra, overlap tables) is part of the block
-        tabs = BlockTables(groups, target, cfg.nfft, capacity=13500, ctx=ctx, device=dev, group_count=counts)
+        tabs = BlockTables(groups, target, cfg.nfft, capacity=13500, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups)
         return coadd_block(cfg, pool, tabs, n1P, E, batch=batch)
 
     one()

@@ -52,7 +52,8 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
         grp = [[(int(k) // nst >> 1, int(k) % nst >> 1) if k >= 0 else None for k in t[0]] for t in nb]
         local = [list(dict.fromkeys(g for g in gs if g is not None)) for gs in grp]  # distinct groups of each stamp
         tables.require([k for gs in local for k in BlockTables.keys_for(gs)])
-        per = [tables.stamp_maps(gs, cfg.flat_penalty) for gs in local]
+        memo = {}  # stamps with the same group list share their maps (at most one list per 2 x 2 cell of groups)
+        per = [memo[t] if (t := tuple(gs)) in memo else memo.setdefault(t, tables.stamp_maps(gs, cfg.flat_penalty)) for gs in local]
         maps_ = tuple(np.stack([p[q] for p in per]) for q in range(3))
         lg = np.array([[gs.index(g) if g is not None else 0 for g in row] for row, gs in zip(grp, local)], dtype=np.int64)
     x, y, indata, expo, cumsum = select_pixels(pool, ids, np.stack([t[1] for t in nb]), np.stack([t[2] for t in nb]), cfg.rho, ld,
@@ -111,6 +112,14 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
                      n_out=int(getattr(tables, "n_out", 1)))
     todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)] if stamps is None else [(int(j), int(i)) for j, i in stamps]
+    if isinstance(tables, BlockTables):
+        # The four stamps (2a-1..2a, 2b-1..2b) draw on the same four PSF groups (their InStamps 2a-2..2a+1 are group rows a-1, a):
+        # visited one after the other, the ~100 MB of tables a stamp's samples touch are still in the Infinity Cache for the
+        # next three (the maps are placed by coordinates, so the order of the visit does not show in the result).
+        todo.sort(key=lambda t: ((t[0] + 1) >> 1, (t[1] + 1) >> 1, t[0], t[1]))
+        # and the block's PSF groups are sampled / transformed before the host turns to the per-stamp bookkeeping
+        tables.prefetch({((j + dj) >> 1, (i + di) >> 1) for j, i in todo for dj in (-1, 0, 1) for di in (-1, 0, 1)
+                         if 0 <= j + dj < nst and 0 <= i + di < nst})
     if batch is None:
         import torch
 

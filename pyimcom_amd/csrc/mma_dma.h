@@ -38,6 +38,9 @@ constexpr int DMA_LDS_DOUBLES = DNS * DSTAGE;  // 9216 doubles = 73,728 B per wo
 #ifndef IMCOM_MMA_WAVES
 #define IMCOM_MMA_WAVES 8
 #endif
+#ifndef IMCOM_MMA_PIPE
+#define IMCOM_MMA_PIPE 0                     // software-pipelined fragment reads in the full-tile k loop (0: the compiler's own schedule)
+#endif
 constexpr int MMA_WAVES = IMCOM_MMA_WAVES;   // 8: wave (wm = w >> 2, wn = w & 3) owns rows 64 wm.., columns 32 wn..; 4: 2 x 2 waves of 64 x 64
 constexpr int MMA_THREADS = 64 * MMA_WAVES;
 constexpr int MMA_WN = MMA_WAVES / 2;        // waves along the columns
@@ -122,6 +125,55 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
+#if IMCOM_MMA_PIPE
+    if constexpr (TRI == 0 && !PARTIAL && MMA_NJ == 2 && NKK % 2 == 0) {
+        // Software-pipelined fragment reads, pinned by scheduling barriers.  Left alone, the machine scheduler puts the six
+        // reads of a k-quad in front of its eight MFMAs behind one lgkmcnt(0), and every wave stalls an LDS round trip per
+        // k-quad.  (Counted lgkmcnt waits are not to be had from the compiler: with an LDS-DMA in flight its waitcnt pass
+        // treats the counters as "pending FLAT" and waits for zero.)  So the fragments are double buffered: the reads of k-quad
+        // kk+1 are issued in front of the MFMAs of kk and have long returned when the wait for zero comes.  The per-slice
+        // barrier sits in front of the LAST k-quad's MFMAs -- every LDS read of the slice has returned by then -- so that the
+        // first fragments of the next slice are read behind those MFMAs as well.
+        double fa[2][4], fb[2][2];
+        auto rd = [&](const double *src, int kn, double (&a)[4], double (&b)[2]) {
+            b[0] = src[rb[kn][0]]; b[1] = src[rb[kn][1]];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = src[ra[kn][i]];
+        };
+        auto mm = [&](const double (&a)[4], const double (&b)[2], int i0, int i1) {
+#pragma unroll
+            for (int i = i0; i < i1; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        };
+        rd(lds, 0, fa[0], fb[0]);
+        for (int t = 0; t < nt; t++) {
+            const double *st = lds + (t & 1) * DSTAGE, *sn = lds + ((t + 1) & 1) * DSTAGE;
+#pragma unroll
+            for (int kk = 0; kk < NKK; kk++) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                // the wait the compiler puts here (for zero, see above) covers reads issued six MFMAs ago
+                __builtin_amdgcn_sched_barrier(0);
+                mm(fa[cur], fb[cur], 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < NKK - 1) rd(st, kk + 1, fa[nxt], fb[nxt]);
+                else if (t + 1 < nt) {
+                    // slice t+1 (this wave's part) has landed and every LDS read of slice t has returned: the barrier publishes
+                    // the one and frees the other
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 2 < nt) issue(t & 1);
+                    rd(sn, 0, fa[nxt], fb[nxt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mm(fa[cur], fb[cur], 1, 4);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+#endif
     for (int t = 0; t < nt; t++) {
         const double *st = lds + (t & 1) * DSTAGE;
 #pragma unroll

@@ -170,7 +170,7 @@ class BlockTables:
     time the new ones are written -- or "raise" (ValueError: size the arena for the block instead)."""
 
     def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict",
-                 group_count=None):
+                 group_count=None, bulk_provider=None):
         assert on_full in ("evict", "raise")
         self.on_full, self.evictions = on_full, 0
         self.ctx = ctx or default_context()
@@ -179,8 +179,12 @@ class BlockTables:
         # block's 81 groups are 570 MB at cfg-2 size), or -- with ``group_count`` = {key: number of PSFs} -- a callable that
         # returns the device tensor when the group is first needed (e.g. psfs.sample_psf on the resident PSF images: the
         # samples are then produced where they are consumed, PSFGrp.__init__ psfutil.py:640-656)
+        # ``bulk_provider(keys)`` -> device tensor [sum of the keys' counts, nsamp, nsamp]: the sampled PSFs of SEVERAL groups in one
+        # call (group_psfs may then map every key to None): a block's 81 groups are sampled and transformed by a handful of
+        # launches instead of five small ones per group
         self.psf = dict(group_psfs)
-        self._count_of = {k: (int(group_count[k]) if callable(v) else int(v.shape[0])) for k, v in self.psf.items()}
+        self._bulk = bulk_provider
+        self._count_of = {k: (int(group_count[k]) if (v is None or callable(v)) else int(v.shape[0])) for k, v in self.psf.items()}
         self.expo = {k: (list(range(self._count_of[k])) if group_expo is None else [int(e) for e in group_expo[k]]) for k in self.psf}
         assert all(len(self.expo[k]) == self._count_of[k] for k in self.psf)
         self.nsamp, self.nfft = int(psf_out.shape[-1]), nfft
@@ -211,13 +215,25 @@ class BlockTables:
         cc = torch.empty((O, ng, ng), dtype=torch.float64, device=dev)
         self._compute([(None, None, [(o, o) for o in range(O)])], cc)
         nc = self.nsamp // 2
-        self.Cs = cc[:, 6 + nc, 6 + nc].cpu().numpy().astype(np.float64)
-        self.C = float(self.Cs[0])
+        self._Cs_dev, self._Cs = cc[:, 6 + nc, 6 + nc].contiguous(), None  # read back when first asked for: no host wait here
+
+    @property
+    def Cs(self):
+        if self._Cs is None:
+            self._Cs = self._Cs_dev.cpu().numpy().astype(np.float64)
+        return self._Cs
+
+    @property
+    def C(self):
+        return float(self.Cs[0])
 
     def _psf_of(self, g):
         if g is None:
             return self.pout
         p = self.psf[g]
+        if p is None:
+            self._fill_bulk([g])
+            p = self.psf[g]
         if callable(p):
             p = self.psf[g] = p()
             assert tuple(p.shape) == (self._count_of[g], self.nsamp, self.nsamp), "group PSF provider returned the wrong shape"
@@ -234,8 +250,41 @@ class BlockTables:
         check(lib.imcom_psf_spectra(self.ctx.handle, _dp(p), p.shape[0], self.nsamp, self.nfft, _dp(self._spec_all[r0 : r0 + p.shape[0]])))
         self._spec_done.add(g)
 
+    def _fill_bulk(self, gs):
+        """Sample (bulk provider) and transform the groups `gs` that are not resident yet, one call per run of neighbouring
+        spectra rows."""
+        gs = sorted((g for g in dict.fromkeys(gs) if g is not None and g not in self._spec_done and self.psf[g] is None),
+                    key=lambda g: self._spec_row[g])
+        runs = []
+        for g in gs:
+            if runs and self._spec_row[g] == self._spec_row[runs[-1][-1]] + self._count_of[runs[-1][-1]]:
+                runs[-1].append(g)
+            else:
+                runs.append([g])
+        for run in runs:
+            p = self._bulk(run)
+            cnt = [self._count_of[g] for g in run]
+            assert tuple(p.shape) == (sum(cnt), self.nsamp, self.nsamp) and p.dtype == torch.float64 and p.is_contiguous(), \
+                "bulk PSF provider returned the wrong shape"
+            off = 0
+            for g, c in zip(run, cnt):
+                self.psf[g] = p[off : off + c]
+                off += c
+            if self._spec_all is not None:
+                r0 = self._spec_row[run[0]]
+                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                check(lib.imcom_psf_spectra(self.ctx.handle, _dp(p), p.shape[0], self.nsamp, self.nfft, _dp(self._spec_all[r0 : r0 + p.shape[0]])))
+                self._spec_done.update(run)
+
+    def prefetch(self, groups):
+        """Queue the sampling / spectra of `groups` now (bulk provider only; otherwise groups are materialised on first use)."""
+        if self._bulk is not None:
+            self._fill_bulk(sorted(g for g in groups if g in self.psf))
+
     def _compute(self, jobs, out):
         """jobs: list of (g1, g2, local pairs) whose tables fill `out` back to back (g = None: the target PSFs)."""
+        if self._bulk is not None:
+            self._fill_bulk([g for g1, g2, _ in jobs for g in (g1, g2)])
         if self._spec_all is None:
             off = 0
             for g1, g2, pairs in jobs:

@@ -284,3 +284,16 @@ def test_block_tables_group_sources_agree():
         got = t.require(keys)
         assert got == want and torch.equal(t.tables[: t.used], ref.tables[: ref.used])
     assert sorted(called) == [(0, 0), (0, 1)]
+    # a bulk provider serves runs of neighbouring groups in one call each (and only the groups somebody asked for)
+    runs = []
+
+    def bulk(ks):
+        runs.append(list(ks))
+        return torch.cat([torch.as_tensor(host[k], device="cuda:0") for k in ks]).contiguous()
+
+    t = BlockTables({k: None for k in host}, target, cfg.nfft, capacity=64, group_count={k: v.shape[0] for k, v in host.items()},
+                    bulk_provider=bulk)
+    assert t.require(keys) == want and torch.equal(t.tables[: t.used], ref.tables[: ref.used])
+    assert runs == [[(0, 0), (0, 1)]]
+    t.require(BlockTables.keys_for([(1, 1)]))
+    assert runs == [[(0, 0), (0, 1)], [(1, 1)]]
