@@ -49,7 +49,6 @@ constexpr int NCH = 5;     // 16-byte chunks per stencil row
 #define IMCOM_A_RING 2
 #endif
 constexpr int A_RING = IMCOM_A_RING;
-constexpr int A_SUP = 8;    // tiles per side of a super-tile (see the tile map in the kernel)
 constexpr int A_PMAX = 24;  // stamp-local PSFs (4 groups x 6 exposures) up to which the pair table is staged in LDS
 
 __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const int *__restrict__ n, int ldn,
@@ -74,23 +73,13 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     __shared__ double ppen[A_PMAX * A_PMAX];
     const int s = blockIdx.y, tid = threadIdx.x;
     int ti, tj;
-    // Workgroups are dealt round-robin over the 8 XCDs (dispatch order % 8), each with its own L2.  The upper triangle is cut
-    // into SUPER-TILES of A_SUP x A_SUP tiles (128 x 128 samples); every XCD takes a contiguous eighth of the super-tile list
-    // and walks each super-tile tile by tile, so that the ~100 workgroups an XCD runs at one time sit in one or two super-tiles:
-    // their separations -- one InStamp segment / exposure chunk against another -- share a few hundred KB of one or two tables,
-    // which stay in the XCD's 4 MB L2 (a row-by-row walk of the triangle swept all the stamp's tables once per tile row).
-    // (gridDim.x = 8 x super-tiles per XCD x A_SUP^2; slots of a diagonal super-tile below the diagonal exit at once.)
-    const int nsb = (ntile + A_SUP - 1) / A_SUP;
-    const long nsup = (long)nsb * (nsb + 1) / 2, per = (nsup + 7) / 8;
-    const long lin = (long)blockIdx.y * gridDim.x + blockIdx.x;
-    const long slot = (long)blockIdx.x >> 3;
-    const long sup = (lin & 7) * per + slot / (A_SUP * A_SUP);
-    if (slot / (A_SUP * A_SUP) >= per || sup >= nsup) return;
-    int si, sj;
-    tile_index(sup, nsb, si, sj);
-    ti = si * A_SUP + (int)(slot % (A_SUP * A_SUP)) / A_SUP;
-    tj = sj * A_SUP + (int)(slot % A_SUP);
-    if (ti >= ntile || tj >= ntile || tj < ti) return;
+    // Workgroups are dealt round-robin over the 8 XCDs (dispatch order % 8), each with its own L2: give every XCD a
+    // contiguous eighth of the tile list, so that the tiles it works on at one time use the same few tables.
+    // (gridDim.x is the tile count padded to a multiple of 8.)
+    const long ntri = (long)ntile * (ntile + 1) / 2, per = (ntri + 7) / 8;
+    const long t = (((long)blockIdx.y * gridDim.x + blockIdx.x) & 7) * per + ((long)blockIdx.x >> 3);
+    if (t >= ntri) return;
+    tile_index(t, ntile, ti, tj);
     const int ns = n[s];
     const int nfull = (ns + NB - 1) / NB * NB;  // rows/cols the factorisation will ever read
     const int li = tid >> 4, lj = tid & 15;
@@ -278,9 +267,9 @@ int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const d
     static const bool window = getenv("IMCOM_BUILD_A") && !strcmp(getenv("IMCOM_BUILD_A"), "window");
     if (window) return launch_build_A_win(ctx, batch, n_dev, ldn, x, y, psf, tables, ntab, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A);
     IMCOM_REQUIRE((long)ntab * ng * ng < (1L << 31), "table stack too large (%d tables of %d^2)", ntab, ng);
-    const int nt = (ldn + 15) / 16, nsb = (nt + A_SUP - 1) / A_SUP;
-    const long nsup = (long)nsb * (nsb + 1) / 2;
-    const long ngrid = 8 * ((nsup + 7) / 8) * A_SUP * A_SUP;  // 8 XCDs x super-tiles per XCD x tiles per super-tile
+    const int nt = (ldn + 15) / 16;
+    const long ntri = (long)nt * (nt + 1) / 2;
+    const long ngrid = (ntri + 7) / 8 * 8;  // padded to a multiple of 8 for the XCD-aware tile order
     hipLaunchKernelGGL(build_A_kernel, dim3((unsigned)ngrid, batch), dim3(256), 0, ctx->stream, n_dev, ldn, x, y, psf,
                        tables, (long)ntab * ng * ng, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A, nt);
     return check_launch("build_A_kernel");
