@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block", action="store_true", help="skip the block-level leg (tables + selection + stamps + block maps)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--ldn", type=int, default=None, help="leading dimension of A / L / -B/2 (experiments; default: N rounded up to 128)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal of the multi-rank path on a box with ONE GPU: every rank uses cuda:0 and the ranks "
                          "rendezvous over gloo (not a measurement)")
@@ -244,7 +245,7 @@ def main():
     n_expo = max(s.n_expo for s in stamps)
     psfs, target = synth.make_psfs(cfg, n_expo)
     tables = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=dev)
-    batch = StampBatch(cfg, stamps, tables, ctx=ctx, device=dev)
+    batch = StampBatch(cfg, stamps, tables, ctx=ctx, device=dev, ldn=args.ldn)
 
     def barrier():
         torch.cuda.synchronize()
