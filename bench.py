@@ -172,7 +172,7 @@ def block_leg(ctx, dev, n1P=16, batch=256, reps=2):
 
     def one():
         # table construction (PSF sampling, spectra, overlap tables) is part of the block
-        tabs = BlockTables(groups, target, cfg.nfft, capacity=13500, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups)
+        tabs = BlockTables(groups, target, cfg.nfft, capacity=13500, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True)
         return coadd_block(cfg, pool, tabs, n1P, E, batch=batch)
 
     one()

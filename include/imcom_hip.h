@@ -325,11 +325,19 @@ int imcom_psf_overlap(imcom_ctx *ctx, const double *psf1, int n1, const double *
  *                            factors than 2, 3, 5, or > 1024) -- then only imcom_psf_overlap (dense-DFT form) serves
  *   imcom_psf_spectra        spectra[n][size] (DEVICE) = rfft2 of the zero-padded PSFs psf[n][nsamp][nsamp] (DEVICE)
  *   imcom_psf_overlap_spectra  tables[npairs][nsamp+12][nsamp+12] (DEVICE) exactly as imcom_psf_overlap, from spectra;
- *                            pairs (HOST) index spec1 / spec2 */
+ *                            pairs (HOST) index spec1 / spec2
+ *   imcom_psf_overlap_spectra_win  the same with a window per pair, win (HOST) [npairs][4] = {row_lo, row_hi, col_lo, col_hi} in
+ *                            window coordinates 0..nsamp (table row = 6 + window row), or NULL: only that part of a table
+ *                            (and the zero border next to it) is guaranteed to be written.  For the cross tables of two
+ *                            PSF groups that own disjoint ranges of InStamp cells (SysMatA.ji_st2psf, psfutil.py:1803-1824):
+ *                            the separations between their pixels have one sign along every axis in which the groups
+ *                            differ, so half (a quarter) of such a table is never interpolated (psfutil.py:1401-1495). */
 long imcom_psf_spectra_size(int nsamp, int nfft);
 int imcom_psf_spectra(imcom_ctx *ctx, const double *psf, int n, int nsamp, int nfft, double *spectra);
 int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp, int nfft,
                               const int *pairs, int npairs, const double *amp_penalty, double *tables);
+int imcom_psf_overlap_spectra_win(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp, int nfft,
+                                  const int *pairs, int npairs, const double *amp_penalty, const int *win, double *tables);
 
 #ifdef __cplusplus
 }

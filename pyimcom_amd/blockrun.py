@@ -13,7 +13,7 @@ import numpy as np
 
 from .block import BlockMaps
 from .select import select_pixels
-from .stamps import NB, BlockTables, StampBatch
+from .stamps import NB, BlockTables, StampBatch, h2d
 
 
 def stamp_neighbours(j_st, i_st, n2, nst):
@@ -34,12 +34,24 @@ def stamp_neighbours(j_st, i_st, n2, nst):
     return ids, pvx, pvy
 
 
+def _neighbours_of(chunk, n2, nst):
+    """stamp_neighbours for a list of stamps, all at once (the same arrays, built by broadcasting)."""
+    ji = np.asarray(chunk, dtype=np.int64).reshape(-1, 2)
+    dj, di = np.repeat([-1, 0, 1], 3), np.tile([-1, 0, 1], 3)
+    jj, ii = ji[:, :1] + dj, ji[:, 1:] + di
+    ids = np.where((jj >= 0) & (jj < nst) & (ii >= 0) & (ii < nst), jj * nst + ii, -1).astype(np.int32)
+    left, bottom = (ji[:, 1:] - 1) * n2, (ji[:, :1] - 1) * n2
+    pvx = np.where(di < 0, left - 0.5, np.where(di > 0, left + n2 - 1 + 0.5, np.nan))
+    pvy = np.where(dj < 0, bottom - 0.5, np.where(dj > 0, bottom + n2 - 1 + 0.5, np.nan))
+    return [(ids[q], pvx[q], pvy[q]) for q in range(len(ji))]
+
+
 def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
     """Selection, table sets, pair maps and the StampBatch of one chunk of output stamps [(j_st, i_st), ...] of a block
     (everything up to StampBatch.build()); ``pool`` / ``tables`` as for coadd_block."""
     nst = n1P + 2
     counts = np.diff(pool.inst_off)
-    nb = [stamp_neighbours(j, i, cfg.n2, nst) for j, i in chunk]
+    nb = _neighbours_of(chunk, cfg.n2, nst)
     ids = np.stack([t[0] for t in nb])
     # capacity: every pixel of the nine neighbours at most
     cap = max(int(counts[t[0][t[0] >= 0]].sum()) for t in nb)
@@ -64,12 +76,12 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
         import torch
 
         # stamp-local PSF index of every pixel: lut[position of its InStamp's group in the stamp's list, exposure]
-        lut = torch.as_tensor(np.stack([p[3] for p in per]).astype(np.int64), device=x.device)  # [B, 4, n_blk_expo]
-        cs = torch.as_tensor(cumsum[:, 1:10].astype(np.int64), device=x.device)
+        lut = h2d(np.stack([p[3] for p in per]), x.device, np.int64)  # [B, 4, n_blk_expo]
+        cs = h2d(cumsum[:, 1:10], x.device, np.int64)
         seg = torch.searchsorted(cs, torch.arange(keep, device=x.device).expand(len(chunk), keep).contiguous(), right=True).clamp_(max=8)
-        lgp = torch.as_tensor(lg, device=x.device).gather(1, seg)  # group position of every pixel
+        lgp = h2d(lg, x.device).gather(1, seg)  # group position of every pixel
         flat = lut.reshape(len(chunk), -1).gather(1, lgp * lut.shape[2] + expo[:, :keep].long())
-        valid = torch.arange(keep, device=x.device)[None, :] < torch.as_tensor(n.astype(np.int64), device=x.device)[:, None]
+        valid = torch.arange(keep, device=x.device)[None, :] < h2d(n, x.device, np.int64)[:, None]
         if bool(((flat < 0) & valid).any()):
             raise ValueError("a pixel belongs to an exposure its PSF group holds no PSF for (BlockTables.group_expo)")
         psf_slot = flat.clamp_(min=0).to(torch.int32)

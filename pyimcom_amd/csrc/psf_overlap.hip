@@ -366,7 +366,7 @@ template <int R2, bool AMP>
 __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
                                                                          const int *__restrict__ pairs, int npairs, int ns,
                                                                          const cplx *__restrict__ tw, double amp0, double amps,
-                                                                         cplx *__restrict__ V)
+                                                                         const int *__restrict__ win, cplx *__restrict__ V)
 {
     IMCOM_WF16_PROLOGUE;
     const int nc = ns / 2, rp = (ns + 1) / 2;
@@ -410,9 +410,11 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const c
             const int ncol = min(4, nh - 4 * g), c2 = (lane >> 1) & 3, h = lane & 1;
             const cplx *src = fbuf + ((wave & ~3) + c2) * Wf16<R2>::LINE;
             cplx *dst = V + ((long)t * rp * nhp + 4 * g) * 2 + (lane & 7);
+            // window rows the caller will read (win: [row_lo, row_hi) of the pair's table window; the rest of V stays unwritten)
+            const int llo = win ? win[4 * t] >> 1 : 0, lhi = win ? (win[4 * t + 1] + 1) >> 1 : rp;
             for (int l = 8 * (wave & 3) + (lane >> 3); l < rp; l += 32) {
                 const int i = 2 * l + h - nc + (2 * l + h < nc ? n : 0);
-                if (c2 < ncol) dst[(long)l * (2 * nhp)] = src[wf_pad16(i)];
+                if (c2 < ncol && l >= llo && l < lhi) dst[(long)l * (2 * nhp)] = src[wf_pad16(i)];
             }
         }
         __syncthreads();
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const c
 
 template <int R2>
 __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_rows_kernel(const cplx *__restrict__ V, int npairs, int ns,
-                                                                         const cplx *__restrict__ tw, double *__restrict__ tables)
+                                                                         const cplx *__restrict__ tw, const int *__restrict__ win,
+                                                                         double *__restrict__ tables)
 {
     IMCOM_WF16_PROLOGUE;
     const int nc = ns / 2, ng = ns + 12;
@@ -430,6 +433,15 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_rows_kernel(const c
     for (long L = (long)blockIdx.x * W + wave; L < total; L += (long)gridDim.x * W) {
         const int r0 = 2 * (int)(L % ((ns + 1) / 2));  // V is [pair][row pair][kx][2]: line L is one contiguous run
         const int t = (int)(L / ((ns + 1) / 2));
+        // win: only rows [w0, w1) and columns [c0, c1) of this pair's window are ever read (cross tables of two PSF groups:
+        // the separations between their pixels have one sign); the rest of the table is left as it is
+        int c0 = 0, c1 = ns;
+        if (win) {
+            const int w0 = __builtin_amdgcn_readfirstlane(win[4 * t]), w1 = __builtin_amdgcn_readfirstlane(win[4 * t + 1]);
+            if (r0 + 1 < w0 || r0 >= w1) continue;
+            c0 = win[4 * t + 2];
+            c1 = win[4 * t + 3];
+        }
         const bool two = r0 + 1 < ns;
         const cplx *src = V + L * v_stride(n) * 2;
         double *tab = tables + (long)t * ng * ng;
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_rows_kernel(const c
         double *o0 = tab + (long)(6 + r0) * ng + 6, *o1 = o0 + ng;
         auto storeN = [&](int i, cplx z) {
             const int xp = i + nc - (i + nc >= n ? n : 0);
-            if (xp < ns) {
+            if (xp < c1 && xp >= c0) {
                 o0[xp] = z.x * scale;
                 if (two) o1[xp] = z.y * scale;
             }
@@ -496,7 +508,7 @@ static int wf16_forward(imcom_ctx *ctx, const double *psf, int npsf, int nsamp, 
 
 template <int R2>
 static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const int *pairs_dev, int npairs, int nsamp, const cplx *tw,
-                        double a0, double a1, cplx *V, double *tables)
+                        double a0, double a1, const int *win_dev, cplx *V, double *tables)
 {
     // the column kernel's waves write V in groups of four (four neighbouring columns = one 128-byte line per row pair)
     const int W = wf16_waves<R2>(), Wc = W / 4 * 4, nh = Wf16<R2>::N / 2 + 1;
@@ -508,15 +520,15 @@ static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const in
     const int g1 = (int)std::max<long>(8, std::min<long>(ctx->cu_count, (cols + Wc - 1) / Wc) / 8 * 8);  // a multiple of the 8 XCDs
     const int g2 = (int)std::min<long>(ctx->cu_count, (rows + W - 1) / W);
     if (a0 != 0.0)
-        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, true>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V);
+        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, true>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V);
     else
-        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, false>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V);
-    hipLaunchKernelGGL(wf16_inv_rows_kernel<R2>, dim3(g2), dim3(64 * W), lds, ctx->stream, (const cplx *)V, npairs, nsamp, tw, tables);
+        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, false>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V);
+    hipLaunchKernelGGL(wf16_inv_rows_kernel<R2>, dim3(g2), dim3(64 * W), lds, ctx->stream, (const cplx *)V, npairs, nsamp, tw, win_dev, tables);
     return check_launch("psf_overlap (16 x 16 x r lines)");
 }
 
 static size_t fft_forward_ws(int n, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)n * nsamp * (nfft / 2 + 1) * 16 + 1024; }
-static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * (nsamp + 1) * v_stride(nfft) * 16 + (size_t)npairs * 8 + 1024; }
+static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * (nsamp + 1) * v_stride(nfft) * 16 + (size_t)npairs * 24 + 2048; }
 
 static cplx *fft_twiddles(imcom_ctx *ctx, const FftPlan &pl)
 {
@@ -549,21 +561,23 @@ static int fft_forward(imcom_ctx *ctx, const FftPlan &pl, const double *psf, int
 
 // tables[t] from spectra pairs (Ra[pairs[2t]], Rb[pairs[2t+1]]); the caller has reserved fft_inverse_ws()
 static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const cplx *Rb, const int *pairs_host, int npairs,
-                       int nsamp, const double *amp_penalty, double *tables)
+                       int nsamp, const double *amp_penalty, double *tables, const int *win_host = nullptr)
 {
     const int nfft = pl.n, nh = nfft / 2 + 1;
     cplx *tw = fft_twiddles(ctx, pl);
     cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * (nsamp + 1) * v_stride(nfft) * 16);  // [pair][row pair][kx, stride nhp][2]
     int *pairs_dev = (int *)ws_take(ctx, (size_t)npairs * 8);
-    if (!tw || !V || !pairs_dev) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
+    int *win_dev = win_host ? (int *)ws_take(ctx, (size_t)npairs * 16) : nullptr;  // the static kernels honour it; the general ones fill whole tables
+    if (!tw || !V || !pairs_dev || (win_host && !win_dev)) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
     IMCOM_TRY(fft_set_lds(pl));
     hipStream_t st = ctx->stream;
     IMCOM_TRY(upload(ctx, pairs_dev, pairs_host, 2 * (size_t)npairs));  // through the pinned ring: no stream drain
+    if (win_host) IMCOM_TRY(upload(ctx, win_dev, win_host, 4 * (size_t)npairs));
     const double a0 = amp_penalty ? amp_penalty[0] : 0.0, a1 = amp_penalty ? amp_penalty[1] : 0.0;
     switch (fft_static_r(pl)) {
-    case 2: return wf16_inverse<2>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V, tables);
-    case 3: return wf16_inverse<3>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V, tables);
-    case 4: return wf16_inverse<4>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, V, tables);
+    case 2: return wf16_inverse<2>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V, tables);
+    case 3: return wf16_inverse<3>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V, tables);
+    case 4: return wf16_inverse<4>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V, tables);
     default: break;
     }
     const size_t lds = fft_lds_bytes(pl);
@@ -707,8 +721,9 @@ extern "C" int imcom_psf_spectra(imcom_ctx *ctx, const double *psf, int n, int n
     return fft_forward(ctx, pl, psf, n, nsamp, (cplx *)spectra);
 }
 
-extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp,
-                                         int nfft, const int *pairs_host, int npairs, const double *amp_penalty, double *tables)
+extern "C" int imcom_psf_overlap_spectra_win(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp,
+                                             int nfft, const int *pairs_host, int npairs, const double *amp_penalty,
+                                             const int *win_host, double *tables)
 {
     if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
     IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
@@ -717,6 +732,11 @@ extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, in
     for (int t = 0; t < npairs; t++)
         IMCOM_REQUIRE(pairs_host[2 * t] >= 0 && pairs_host[2 * t] < n1 && pairs_host[2 * t + 1] >= 0 && pairs_host[2 * t + 1] < n2,
                       "pair %d out of range", t);
+    if (win_host)
+        for (int t = 0; t < npairs; t++) {
+            const int *w = win_host + 4 * (size_t)t;
+            IMCOM_REQUIRE(0 <= w[0] && w[0] < w[1] && w[1] <= nsamp && 0 <= w[2] && w[2] < w[3] && w[3] <= nsamp, "window %d out of range", t);
+        }
     FftPlan pl;
     fft_plan(nfft, &pl);
     // in chunks of pairs, so that the intermediate (nsamp x nh complex per pair) stays within ~4 GB however many
@@ -730,7 +750,13 @@ extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, in
     for (int p0 = 0; p0 < npairs; p0 += chunk) {
         ctx->ws_used = 0;
         IMCOM_TRY(fft_inverse(ctx, pl, (const cplx *)spec1, (const cplx *)spec2, pairs_host + 2 * (size_t)p0, std::min(chunk, npairs - p0), nsamp,
-                              amp_penalty, tables + (size_t)p0 * tab));
+                              amp_penalty, tables + (size_t)p0 * tab, win_host ? win_host + 4 * (size_t)p0 : nullptr));
     }
     return IMCOM_OK;
+}
+
+extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp,
+                                         int nfft, const int *pairs_host, int npairs, const double *amp_penalty, double *tables)
+{
+    return imcom_psf_overlap_spectra_win(ctx, spec1, n1, spec2, n2, nsamp, nfft, pairs_host, npairs, amp_penalty, nullptr, tables);
 }

@@ -141,7 +141,7 @@ def synthetic_mosaic(config="cfg4", nblock=4, n1P=2, seed=4, psf_groups=False):
         psfs, target = synth.make_psfs(cfg, E, seed=20260723 + b)
         if psf_groups:
             ng = (n1P + 3) // 2
-            tables = BlockTables({(gj, gi): psfs for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, capacity=2048, ctx=ctx, device=device)
+            tables = BlockTables({(gj, gi): psfs for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, capacity=2048, ctx=ctx, device=device, cells=True)
         else:
             tables = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=device)
         return dict(cfg=cfg, pool=InStampPool(inst, cfg.n_inframe, device=device), tables=tables, n1P=n1P, n_expo=E,

@@ -136,7 +136,8 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     if table_capacity is None:  # the sets one batch of stamps can touch, with room to keep neighbouring groups resident
         per_group = n_max * (n_max + 1) // 2 + target.shape[0] * n_max + 4 * n_max * n_max
         table_capacity = min(max(4 * per_group * max(1, (batch or 256) // 4), 256), (2**31 - 1) // ((int(psfgrp.nsamp) + 12) ** 2))
-    tables = BlockTables(group_psfs, target, int(psfgrp.nfft), group_expo=group_expo, capacity=int(table_capacity), amp_penalty=amp, device=device)
+    tables = BlockTables(group_psfs, target, int(psfgrp.nfft), group_expo=group_expo, capacity=int(table_capacity), amp_penalty=amp, device=device,
+                         cells=True)  # groups of 2 x 2 InStamps: cells of the block's grid (coadd.py:207, 329-358)
     maps = coadd_block(scfg, pool, tables, int(cfg.n1P), int(blk.n_inimage), batch=batch, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
                        postage_pad=int(getattr(cfg, "postage_pad", 0)), stamps=stamps)
     blk.out_map, blk.T_weightmap = maps.out_map.cpu().numpy(), maps.T_weightmap.cpu().numpy()

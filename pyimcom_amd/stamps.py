@@ -32,6 +32,13 @@ def _hp(a):
 _GRIDS = {}
 
 
+def h2d(a, dev, dtype=None):
+    """Host array -> device tensor through pinned memory, queued on the current stream without a host wait (a plain
+    ``torch.as_tensor(a, device=dev)`` of pageable memory drains the stream first: 0.2-0.4 ms of idle GPU per call in a block)."""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def _index_grid(na, nb):
     if (na, nb) not in _GRIDS:
         _GRIDS[(na, nb)] = tuple(np.ascontiguousarray(a) for a in np.meshgrid(np.arange(na), np.arange(nb), indexing="ij"))
@@ -51,15 +58,21 @@ def psf_spectra(ctx, psf, nfft):
     return spec
 
 
-def overlap_tables(ctx, p1, s1, p2, s2, nsamp, nfft, pairs, amp, out):
+def overlap_tables(ctx, p1, s1, p2, s2, nsamp, nfft, pairs, amp, out, win=None):
     """Tables of the (i, j) `pairs` between two PSF sets, from their spectra when both are given (else from the
-    sampled PSFs through imcom_psf_overlap)."""
+    sampled PSFs through imcom_psf_overlap).  ``win`` [npairs, 4] (spectra form only): the part of every table's window
+    that will be read, imcom_psf_overlap_spectra_win."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     ampp = None if amp is None else _hp(amp)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if s1 is not None and s2 is not None:
-        check(lib.imcom_psf_overlap_spectra(ctx.handle, _dp(s1), s1.shape[0], _dp(s2), s2.shape[0], nsamp, nfft, _hp(pairs),
-                                            len(pairs), ampp, _dp(out)))
+        winp = None
+        if win is not None:
+            win = np.ascontiguousarray(win, dtype=np.int32)
+            assert win.shape == (len(pairs), 4)
+            winp = _hp(win)
+        check(lib.imcom_psf_overlap_spectra_win(ctx.handle, _dp(s1), s1.shape[0], _dp(s2), s2.shape[0], nsamp, nfft, _hp(pairs),
+                                                len(pairs), ampp, winp, _dp(out)))
     else:
         check(lib.imcom_psf_overlap(ctx.handle, _dp(p1), p1.shape[0], _dp(p2), p2.shape[0], nsamp, nfft, _hp(pairs), len(pairs),
                                     ampp, _dp(out)))
@@ -170,7 +183,7 @@ class BlockTables:
     time the new ones are written -- or "raise" (ValueError: size the arena for the block instead)."""
 
     def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict",
-                 group_count=None, bulk_provider=None):
+                 group_count=None, bulk_provider=None, cells=False):
         assert on_full in ("evict", "raise")
         self.on_full, self.evictions = on_full, 0
         self.ctx = ctx or default_context()
@@ -182,6 +195,11 @@ class BlockTables:
         # ``bulk_provider(keys)`` -> device tensor [sum of the keys' counts, nsamp, nsamp]: the sampled PSFs of SEVERAL groups in one
         # call (group_psfs may then map every key to None): a block's 81 groups are sampled and transformed by a handful of
         # launches instead of five small ones per group
+        # ``cells=True``: the caller asserts that group (gj, gi) owns a cell of a grid of InStamps -- every pixel of a group with
+        # smaller gi (gj) lies left of (below) every pixel of one with larger gi (gj), as for the reference's groups of 2 x 2
+        # InStamps (coadd.py:207, 329-358).  The separations between two different groups' pixels then have one sign along
+        # every axis in which the groups differ, and of their cross tables only that half (quarter) is computed.
+        self.cells = bool(cells)
         self.psf = dict(group_psfs)
         self._bulk = bulk_provider
         self._count_of = {k: (int(group_count[k]) if (v is None or callable(v)) else int(v.shape[0])) for k, v in self.psf.items()}
@@ -199,6 +217,9 @@ class BlockTables:
         if capacity * ng * ng >= 2**31:
             raise ValueError(f"capacity {capacity} x {ng}^2 table elements exceeds the 31-bit offsets of imcom_build_A (max {(2**31 - 1) // (ng * ng)})")
         self.tables = torch.empty((capacity, ng, ng), dtype=torch.float64, device=dev)  # the arena
+        # The A builder lets samples without a stencil fetch the arena's first elements under zero weights: they must be finite
+        # whatever is (partly, with ``cells``) written there later.
+        self.tables[0].zero_()
         self.index, self.used = {}, 0
         # forward spectra of the target PSFs and of every group in ONE arena, so that all the table sets a batch of
         # stamps needs come out of a single call; a group's rows are filled on first use (28 MB per group at E = 6,
@@ -292,15 +313,39 @@ class BlockTables:
                                out[off : off + len(pairs)])
                 off += len(pairs)
             return
-        allp = []
+        allp, allw = [], []
+        ns, nc, margin = self.nsamp, self.nsamp // 2, 8  # ten-tap stencils reach 4 below / 5 above the cell of a separation
+        rng = {-1: (0, min(ns, nc + margin)), 0: (0, ns), 1: (max(0, nc - margin), ns)}
+        sgn = lambda a, b: (a > b) - (a < b)  # noqa: E731
         for g1, g2, pairs in jobs:
             self._fill_spectra(g1)
             self._fill_spectra(g2)
-            allp.append(np.asarray(pairs, dtype=np.int64) + np.array([self._spec_row[g1], self._spec_row[g2]]))
-        overlap_tables(self.ctx, None, self._spec_all, None, self._spec_all, self.nsamp, self.nfft, np.concatenate(allp), self._amp, out)
+            allp.append(np.asarray(pairs, dtype=np.int64).reshape(-1, 2) + (self._spec_row[g1], self._spec_row[g2]))
+            if self.cells:
+                # tables are read at r(g1) - r(g2) (A builder: the group that sorts first on the left; input-output and self: any sign)
+                sy, sx = (0, 0) if g1 is None or g2 is None or g1 == g2 else (sgn(g1[0], g2[0]), sgn(g1[1], g2[1]))
+                allw.append(np.broadcast_to(np.array(rng[sy] + rng[sx], dtype=np.int32), (len(pairs), 4)))
+        overlap_tables(self.ctx, None, self._spec_all, None, self._spec_all, self.nsamp, self.nfft, np.concatenate(allp), self._amp, out,
+                       win=np.concatenate(allw) if self.cells else None)
 
     def _n(self, g):
         return self._count_of[g]
+
+    _pair_memo = {}
+
+    @classmethod
+    def _local_pairs(cls, kind, n1, n2):
+        """(i, j) PSF pairs of a table set in storage order, [count, 2] int64 (shared between all sets of the same shape)."""
+        key = (kind, n1, n2)
+        if key not in cls._pair_memo:
+            if kind == "self":
+                p = [(i, j) for i in range(n1) for j in range(i, n1)]
+            elif kind == "io":
+                p = [(i, o) for o in range(n2) for i in range(n1)]
+            else:
+                p = [(i, j) for i in range(n1) for j in range(n2)]
+            cls._pair_memo[key] = np.asarray(p, dtype=np.int64).reshape(-1, 2)
+        return cls._pair_memo[key]
 
     def _count(self, key):
         if key[0] == "self":
@@ -327,12 +372,11 @@ class BlockTables:
             if k in self.index:
                 continue
             if k[0] == "self":
-                n = self._n(k[1])
-                jobs.append((k[1], k[1], [(i, j) for i in range(n) for j in range(i, n)]))
+                jobs.append((k[1], k[1], self._local_pairs("self", self._n(k[1]), 0)))
             elif k[0] == "io":
-                jobs.append((k[1], None, [(i, o) for o in range(self.n_out) for i in range(self._n(k[1]))]))
+                jobs.append((k[1], None, self._local_pairs("io", self._n(k[1]), self.n_out)))
             else:
-                jobs.append((k[1], k[2], [(i, j) for i in range(self._n(k[1])) for j in range(self._n(k[2]))]))
+                jobs.append((k[1], k[2], self._local_pairs("cross", self._n(k[1]), self._n(k[2]))))
             self.index[k] = self.used
             self.used += self._count(k)
         if jobs:
@@ -453,8 +497,8 @@ class StampBatch:
         # selects the overlap tables.  One PSF group: the two coincide.
         self.x, self.y, self.expo, self.indata = x, y, expo, indata
         self.psf = expo if psf_slot is None else psf_slot.contiguous()
-        self.out_x0 = torch.as_tensor(out_x0, device=dev)
-        self.out_y0 = torch.as_tensor(out_y0, device=dev)
+        self.out_x0 = h2d(out_x0, dev)
+        self.out_y0 = h2d(out_y0, dev)
         O = self.n_out = int(getattr(tables, "n_out", 1))
         if maps is None:
             assert self.n_expo <= tables.n_psf
@@ -471,9 +515,9 @@ class StampBatch:
                 io = io.transpose(1, 0, 2)
             io = io.reshape(O, B, P)
             assert tab.shape == (B, P, P) and pen.shape == (B, P, P)
-            self.pair_tab = torch.as_tensor(np.ascontiguousarray(tab, dtype=np.int32), device=dev)
-            self.pair_pen = torch.as_tensor(np.ascontiguousarray(pen, dtype=np.float64), device=dev)
-        self.io_tab_o = torch.as_tensor(np.ascontiguousarray(io, dtype=np.int32), device=dev)  # [n_out, B, P]
+            self.pair_tab = h2d(tab, dev, np.int32)
+            self.pair_pen = h2d(pen, dev, np.float64)
+        self.io_tab_o = h2d(io, dev, np.int32)  # [n_out, B, P]
         self.geom = TableGeom(tables.nsamp, float(tables.nsamp // 2), float(cfg.dscale), float(cfg.flat_penalty))
         Cs = np.asarray(getattr(tables, "Cs", [tables.C]), dtype=np.float64)
         self.Cs_o = np.ascontiguousarray(np.broadcast_to(Cs[:, None], (O, B)))

@@ -175,6 +175,18 @@ def test_cfg2_block_groups_equal_single_group():
         x, y = one.maps[k].cpu().numpy(), grp.maps[k].cpu().numpy()
         assert np.allclose(x, y, rtol=1e-4, atol=1e-7 * np.abs(x).max()), k
     assert np.allclose(one.T_weightmap.cpu().numpy(), grp.T_weightmap.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    # cells=True: only the half (quarter) of a cross table that separations between two grid cells of InStamps can reach is
+    # computed.  The arena is filled with NaN first: a single interpolation outside the computed part would show in the maps --
+    # which must come out bit for bit as with whole tables.
+    tabs = BlockTables({(gj, gi): psfs for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, capacity=1500, cells=True)
+    tabs.tables[1:].fill_(float("nan"))
+    cel = coadd_block(cfg, pool, tabs, n1P, E, batch=5)
+    torch.cuda.synchronize()
+    part = tabs.tables[: tabs.used]
+    assert bool(torch.isnan(part).any()), "nothing was pruned"
+    assert torch.equal(cel.out_map, grp.out_map)
+    for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+        assert torch.equal(cel.maps[k], grp.maps[k]), k
 
 
 @pytest.mark.parametrize("kC", [(6e-4,), (1e-5, 1e-4, 1e-3)])
