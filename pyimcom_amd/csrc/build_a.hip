@@ -49,7 +49,11 @@ constexpr int NCH = 5;     // 16-byte chunks per stencil row
 #define IMCOM_A_RING 2
 #endif
 constexpr int A_RING = IMCOM_A_RING;
-constexpr int A_PMAX = 24;  // stamp-local PSFs (4 groups x 6 exposures) up to which the pair table is staged in LDS
+#ifndef IMCOM_A_PMAX
+#define IMCOM_A_PMAX 8
+#endif
+constexpr int A_PMAX = IMCOM_A_PMAX;  // stamp-local PSFs up to which the pair table is staged in LDS (one PSF group: 6 x 6 entries); a stamp of four
+                                      // groups (24 x 24) has every thread fetch its own entry instead: staging 576 entries per tile cost 1.3 ms per block
 
 __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const int *__restrict__ n, int ldn,
                                                       const double *__restrict__ x,
