@@ -468,7 +468,7 @@ int imcom_ctx_mfma_probe(imcom_ctx *ctx, double millis, double *tflops)
 int imcom_ctx_gemm_probe(imcom_ctx *ctx, int variant, int M, int N, int K, int batch, int reps, double *tflops)
 {
     IMCOM_TRY(check_ctx(ctx));
-    IMCOM_REQUIRE(tflops && variant >= 0 && variant <= 4 && M >= 256 && N >= 128 && K >= 16 && batch >= 1 && reps >= 1, "bad arguments");
+    IMCOM_REQUIRE(tflops && variant >= 0 && variant <= 8 && M >= 256 && N >= 128 && K >= 16 && batch >= 1 && reps >= 1, "bad arguments");
     IMCOM_REQUIRE(M % 256 == 0 && N % 128 == 0 && K % 16 == 0, "gemm probe: M % 256, N % 128, K % 16");
     const size_t a = (size_t)batch * M * K * 8, b = (size_t)batch * K * N * 8, c = (size_t)batch * M * N * 8;
     IMCOM_TRY(ws_reserve(ctx, a + b + c + 4096));
@@ -483,6 +483,7 @@ int imcom_ctx_gemm_probe(imcom_ctx *ctx, int variant, int M, int N, int K, int b
         if (variant == 1) return launch_gemm_probe16(ctx, M, N, K, batch, A, B, C);
         // variants 2-4: the engine's other operand layouts (2: both row-major, the Cholesky updates' form C = A B^T; 3: both k-major,
         // the backward solves'; 4: A k-major, B row-major) on the same buffers
+        if (variant >= 5) return launch_gemm_abl(ctx, variant - 4, M, N, K, batch, A, B, C);  // 5: no DMA, 6: no barrier, 7: neither, 8: DMA and barrier but no wait for the DMA
         if (variant == 2) return launch_gemm(ctx, false, false, M, N, K, batch, A, K, (long)M * K, B, K, (long)K * N, C, N, (long)M * N, 1.0, 0.0);
         if (variant == 3) return launch_gemm(ctx, true, true, M, N, K, batch, A, M, (long)M * K, B, N, (long)K * N, C, N, (long)M * N, 1.0, 0.0);
         if (variant == 4) return launch_gemm(ctx, true, false, M, N, K, batch, A, M, (long)M * K, B, K, (long)K * N, C, N, (long)M * N, 1.0, 0.0);

@@ -7,6 +7,8 @@
 // 64x32 sub-tile as 4x2 v_mfma_f64_16x16x4_f64 tiles (64 accumulator VGPRs, four waves per SIMD resident).
 // Operand slices of k = 16 stream global -> LDS by LDS-DMA through a double buffer (mma_dma.h).
 // fp64 MFMA runs at the fp64 vector rate on gfx950, so the point of MFMA here is operand reuse, not a higher peak.
+#include <cstdlib>
+
 #include "common.h"
 #include "mma_dma.h"
 
@@ -345,19 +347,76 @@ __global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void gemm_kernel(const d
     })
 }
 
+// diagnostic: the k-major x k-major product with parts of the k loop taken out (mma_tile_dma's ABL); the result is not a product
+template <int ABL>
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void gemm_abl_kernel(const double *__restrict__ A, long lda, long strideA,
+                                                                             const double *__restrict__ B, long ldb, long strideB,
+                                                                             double *__restrict__ C, long ldc, long strideC, int K)
+{
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
+    const int s = blockIdx.z, tm = blockIdx.y, tn = blockIdx.x;
+    f64x4 acc[4][MMA_NJ];
+    zero_acc(acc);
+    mma_tile_dma<true, true, false, 0, ABL>(acc, A + s * strideA + (long)tm * NB, lda, B + s * strideB + (long)tn * NB, ldb, K, smem);
+    double *Co = C + s * strideC + (long)tm * NB * ldc + (long)tn * NB;
+    IMCOM_FOR_ACC(row, col, v, { Co[(long)row * ldc + col] = v; })
+}
+
+int launch_gemm_abl(imcom_ctx *ctx, int abl, int M, int N, int K, int batch, const double *A, const double *B, double *C)
+{
+    dim3 grid(N / NB, M / NB, batch);
+#define IMCOM_ABL_CASE(a) hipLaunchKernelGGL(gemm_abl_kernel<a>, grid, dim3(MMA_THREADS), 0, ctx->stream, A, (long)M, (long)M * K, B, (long)N, (long)K * N, C, (long)N, (long)M * N, K)
+    if (abl == 1) IMCOM_ABL_CASE(1);
+    else if (abl == 2) IMCOM_ABL_CASE(2);
+    else if (abl == 4) IMCOM_ABL_CASE(4);
+    else IMCOM_ABL_CASE(3);
+#undef IMCOM_ABL_CASE
+    return check_launch("gemm_abl_kernel");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Rate probe (imcom_ctx_mfma_probe): the fp64 MFMA pipe of every SIMD kept busy by four waves with eight independent
 // accumulators each, and nothing else -- no LDS, no memory, no barriers.  What it reaches (77.5 TFLOP/s measured, 98.6 % of the
 // guide's 78.6) is the ceiling a kernel with operand traffic can be compared with.
+template <int MODE>
 __global__ __launch_bounds__(MMA_THREADS, 2) void mfma_probe_kernel(int iters, double seed, double *__restrict__ sink)
 {
+    // MODE 0: constant operands (the ceiling quoted in DESIGN.md).  MODE 1: four A and two B fragments with full pseudo-random
+    // mantissas, different in every lane (the switching activity of real data; same instruction stream otherwise).
+    // MODE 2: as 1, but the six fragments are re-read from LDS in front of every eight MFMAs (three 16-byte ds_reads per lane, as
+    // the tile engine's k-quad does; no DMA, no barriers).
+    __shared__ double frag[MODE == 2 ? 6 * 64 * MMA_WAVES : 1];
     f64x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = f64x4{seed, 0.0, 0.0, (double)i};
-    const double a = 1.0 + seed * (double)(threadIdx.x & 3), b = 1.0 - seed;
-    for (int it = 0; it < iters; it++) {
+    double a[4], b[2];
+    if (MODE == 0) {
+        a[0] = a[1] = a[2] = a[3] = 1.0 + seed * (double)(threadIdx.x & 3);
+        b[0] = b[1] = 1.0 - seed;
+    } else {
+        unsigned long h = 0x9E3779B97F4A7C15ul * (threadIdx.x + 1 + 977ul * blockIdx.x);
+        auto rnd = [&]() { h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ul; h ^= h >> 32; return 0.5 + (double)(h >> 11) * (1.0 / 9007199254740992.0); };
 #pragma unroll
-        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 4; i++) a[i] = rnd() * 1e-3;
+        b[0] = rnd() * 1e-3; b[1] = -rnd() * 1e-3;
+        if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) frag[(i * MMA_WAVES * 64) + threadIdx.x] = a[i];
+            frag[4 * MMA_WAVES * 64 + threadIdx.x] = b[0];
+            frag[5 * MMA_WAVES * 64 + threadIdx.x] = b[1];
+            __syncthreads();
+        }
+    }
+    for (int it = 0; it < iters; it++) {
+        if (MODE == 2) {
+            asm volatile("" ::: "memory");  // the reads stay inside the loop
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = frag[(i * MMA_WAVES * 64) + threadIdx.x];
+            b[0] = frag[4 * MMA_WAVES * 64 + threadIdx.x];
+            b[1] = frag[5 * MMA_WAVES * 64 + threadIdx.x];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i >> 1], b[i & 1], acc[i], 0, 0, 0);
     }
     double v = 0.0;
 #pragma unroll
@@ -368,7 +427,11 @@ __global__ __launch_bounds__(MMA_THREADS, 2) void mfma_probe_kernel(int iters, d
 int launch_mfma_probe(imcom_ctx *ctx, int nwg, int iters, double *sink, int *waves_per_wg)
 {
     *waves_per_wg = MMA_WAVES;
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(nwg), dim3(MMA_THREADS), 0, ctx->stream, iters, 1e-9, sink);
+    const char *e = getenv("IMCOM_MFMA_PROBE_MODE");  // diagnostic variants, see the kernel
+    const int mode = e ? atoi(e) : 0;
+    if (mode == 1) hipLaunchKernelGGL(mfma_probe_kernel<1>, dim3(nwg), dim3(MMA_THREADS), 0, ctx->stream, iters, 1e-9, sink);
+    else if (mode == 2) hipLaunchKernelGGL(mfma_probe_kernel<2>, dim3(nwg), dim3(MMA_THREADS), 0, ctx->stream, iters, 1e-9, sink);
+    else hipLaunchKernelGGL(mfma_probe_kernel<0>, dim3(nwg), dim3(MMA_THREADS), 0, ctx->stream, iters, 1e-9, sink);
     return check_launch("mfma_probe_kernel");
 }
 

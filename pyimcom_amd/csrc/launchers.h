@@ -7,6 +7,7 @@ namespace imcom {
 // gemm_f64.hip
 int launch_chol_update(imcom_ctx *ctx, const double *A, double *L, int ldn, int k, int nbmax, int batch, int abatch,
                        const int *nblk, const double *dshift, double *partial, int nparts);  // nparts > 1: split-K through `partial`
+int launch_gemm_abl(imcom_ctx *ctx, int abl, int M, int N, int K, int batch, const double *A, const double *B, double *C);  // diagnostic
 int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int k, int nbmax, int batch,
                      const int *nblk);
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,

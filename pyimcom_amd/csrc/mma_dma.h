@@ -61,7 +61,9 @@ __device__ __forceinline__ int dma_key(int row) { return DCH == 8 ? (row >> 1) &
 // 16-row group g only meets k-slices t <= g (lower) or t >= g (upper); the other products are skipped.  So that both
 // halves of the workgroup carry the same share, the wave's four row groups are then interleaved, g = 2 i + wm
 // (IMCOM_FOR_ACC_TRI is the matching accumulator map): 20 instead of 32 MFMA rounds on the critical path.
-template <bool AKM, bool BKM, bool PARTIAL = false, int TRI = 0>
+// ABL (diagnostic, imcom_ctx_gemm_probe variants 5-7; results are then meaningless): bit 0 = no LDS-DMA after the prologue,
+// bit 1 = no per-slice wait / barrier.
+template <bool AKM, bool BKM, bool PARTIAL = false, int TRI = 0, int ABL = 0>
 __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const double *__restrict__ Ag, long lda,
                                              const double *__restrict__ Bg, long ldb, int K, double *lds, int mrows = 128)
 {
@@ -217,10 +219,13 @@ __device__ __forceinline__ void mma_tile_dma(f64x4 (&acc)[4][MMA_NJ], const doub
         }
         if (t + 1 < nt) {
             // slice t+1 (this wave's part) has landed; the barrier publishes it and tells everybody that slot t&1 is free
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABL & 2)) {
+                if constexpr (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // bit 2: the barrier without the wait for the DMA
+                __builtin_amdgcn_s_barrier();
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < nt) issue(t & 1);  // slice t+2 streams in behind the 32 MFMAs per wave of slice t+1
+            if constexpr (!(ABL & 1))
+                if (t + 2 < nt) issue(t & 1);  // slice t+2 streams in behind the 32 MFMAs per wave of slice t+1
         }
     }
     // the caller's epilogue may reuse LDS: make sure every wave is done reading the last stage
