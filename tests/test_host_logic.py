@@ -18,6 +18,34 @@ def test_stamp_neighbours_and_pivots():
     assert ids.tolist() == [-1, -1, -1, -1, 0, 1, -1, nst, nst + 1]
 
 
+def test_neighbour_tables_of_a_batch_equal_the_per_stamp_ones():
+    """blockrun._neighbours_of builds the neighbour ids and pivots of a whole batch by broadcasting; it must give exactly what
+    stamp_neighbours gives stamp by stamp (block corners, edges and stamps outside the block included)."""
+    from pyimcom_amd.blockrun import _neighbours_of, stamp_neighbours
+
+    n2, nst = 48, 7
+    chunk = [(j, i) for j in range(0, nst) for i in range(0, nst)]
+    for (j, i), got in zip(chunk, _neighbours_of(chunk, n2, nst)):
+        for a, b in zip(stamp_neighbours(j, i, n2, nst), got):
+            assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True), (j, i)
+
+
+def test_block_table_pair_lists_and_windows():
+    """Storage order of the PSF pairs of a table set (triangle for a group's self overlap, psfutil.py:1175), and the window of a
+    cross table of two grid-cell groups: the half plane(s) the separations r(g1) - r(g2) can reach, ten-tap stencils included."""
+    from pyimcom_amd.stamps import BlockTables
+
+    assert BlockTables._local_pairs("self", 3, 0).tolist() == [[0, 0], [0, 1], [0, 2], [1, 1], [1, 2], [2, 2]]
+    assert BlockTables._local_pairs("io", 2, 2).tolist() == [[0, 0], [1, 0], [0, 1], [1, 1]]
+    assert BlockTables._local_pairs("cross", 2, 3).tolist() == [[i, j] for i in range(2) for j in range(3)]
+    assert BlockTables._local_pairs("cross", 2, 3) is BlockTables._local_pairs("cross", 2, 3)
+    ns, nc = 383, 191
+    lo, hi = (0, nc + 8), (nc - 8, ns)
+    # a separation d < 0 lands in cell floor(d + nc + 6) <= nc + 5 of the bordered table, its taps reach table index nc + 10 =
+    # window index nc + 4 < nc + 8; d > 0: cell >= nc + 6, taps from table index nc + 2 = window index nc - 4 >= nc - 8
+    assert lo[1] > nc + 4 and hi[0] <= nc - 4
+
+
 def test_visiting_order_matches_the_reference_loops():
     from pyimcom_amd.select import visiting_order
 
