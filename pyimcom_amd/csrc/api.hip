@@ -2,6 +2,7 @@
 // orchestration of the batched blocked Cholesky solve.
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 
 #include "common.h"
 #include "launchers.h"
@@ -171,10 +172,14 @@ static int lambda_min(imcom_ctx *ctx, const double *A_s, int n, int Np, double *
     return rc;
 }
 
+// before_solve (optional): called once, after the first factorisation's launches have been queued and before the first launch
+// that reads Bt -- the host-buffer entry uploads -B/2 there, behind the factorisation instead of in front of it.
 static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m, int mp, const double *A,
                      const double *Bt, const double *C_host, const double *kappaC_host, int nv, double ucmin,
-                     double smax, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host)
+                     double smax, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host,
+                     const std::function<int()> &before_solve = nullptr)
 {
+    bool bt_ready = !before_solve;
     const int nbmax_all = Np / NB;
     const int pb = nodes_per_pass(batch, mp, nv), eb = batch * pb;  // nodes per pass, stamps x nodes of a pass
     double *L = (double *)ws_take(ctx, (size_t)eb * Np * Np * 8);
@@ -255,6 +260,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                 { ProfScope ps(ctx, "chol_diag"); IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, eb, nblk_dev, failp)); }
                 { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, eb, nblk_dev)); }
             }
+            if (!bt_ready) { IMCOM_TRY(before_solve()); bt_ready = true; }
             double *Yp = Y + p0 * node_stride;
             // the diagonal blocks are applied inside the update launches; IMCOM_SOLVE_UNFUSED=1 keeps them apart (A/B runs)
             static const bool unfused = getenv("IMCOM_SOLVE_UNFUSED") != nullptr;
@@ -655,7 +661,13 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
     plan.add((size_t)batch * 4);            // n
     IMCOM_TRY(ws_reserve(ctx, plan.total + chol_core_bytes(batch, Np, m, mp, nv) + 8192));
     IMCOM_STAGE_IN(double, A_d, A, szA);
-    IMCOM_STAGE_IN(double, B_d, mBhalf, szB);
+    // -B/2 is not needed before the triangular solves: from host memory it is uploaded on the context's second queue while the
+    // factorisation runs (a third of a stamp's 100 MB over PCIe moves behind 3 ms of Cholesky)
+    double *B_d = (double *)mBhalf;
+    if (host) {
+        B_d = (double *)ws_take(ctx, szB * 8);
+        if (!B_d) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
+    }
     float *T_d = T, *UC_d = UC, *Sig_d = Sigma, *kap_d = kappa;
     if (host) {
         T_d = (float *)ws_take(ctx, szB * 4);
@@ -672,9 +684,27 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
     {
         ProfScope ps(ctx, "pack");
         IMCOM_TRY(launch_pack_A(ctx, A_d, ldn, n_dev, Ap, Np, batch));
-        IMCOM_TRY(launch_pack_Bt(ctx, B_d, ldn, m, n_dev, Bt, Np, mp, batch));
     }
-    IMCOM_TRY(chol_core(ctx, batch, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info));
+    auto stage_B = [&]() -> int {
+        if (host) {
+            if (ctx->sync_events.empty()) {
+                hipEvent_t e;
+                IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->sync_events.push_back(e);
+            }
+            hipEvent_t ev = ctx->sync_events[0];
+            IMCOM_HIP_CHECK(hipMemcpyAsync(B_d, mBhalf, szB * 8, hipMemcpyHostToDevice, ctx->aux_stream));
+            IMCOM_HIP_CHECK(hipEventRecord(ev, ctx->aux_stream));
+            IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
+        }
+        ProfScope ps(ctx, "pack");
+        return launch_pack_Bt(ctx, B_d, ldn, m, n_dev, Bt, Np, mp, batch);
+    };
+    const int rc_core = chol_core(ctx, batch, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info, stage_B);
+    if (rc_core != IMCOM_OK) {
+        if (host) hipStreamSynchronize(ctx->aux_stream);  // nothing of this call may still be copying into the workspace
+        return rc_core;
+    }
     if (ldn > 0) { ProfScope ps(ctx, "pack"); IMCOM_TRY(launch_unpack_T(ctx, Tt, Np, mp, n_dev, m, T_d, ldn, batch)); }
     IMCOM_STAGE_OUT(float, T_d, T, szB);
     IMCOM_STAGE_OUT(float, UC_d, UC, szM);
