@@ -686,7 +686,7 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
         IMCOM_TRY(launch_pack_A(ctx, A_d, ldn, n_dev, Ap, Np, batch));
     }
     auto stage_B = [&]() -> int {
-        if (host) {
+        if (host && szB > 0) {
             if (ctx->sync_events.empty()) {
                 hipEvent_t e;
                 IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
