@@ -201,3 +201,56 @@ def test_psf_overlap_padding_beyond_twice_nsamp(ns, nfft):
     border = got.copy()
     border[:, 6:-6, 6:-6] = 0.0
     assert np.all(border == 0.0)  # every border element written, none left at the NaN fill
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns,nfft", [(255, 512), (301, 768), (33, 80)])
+def test_psf_overlap_windows(ns, nfft):
+    """imcom_psf_overlap_spectra_win through the C-ABI: inside a pair's window the table is bit for bit the one of the plain call;
+    with the static line-FFT kernels (nfft = 512, 768) nothing outside the window (and the zero border next to it) is written, the
+    general kernels (nfft = 80) ignore the windows and fill whole tables; a window out of range is refused."""
+    import ctypes as C
+
+    import torch
+
+    from pyimcom_amd._lib import ImcomError, check, default_context, lib
+
+    rng = np.random.default_rng(ns)
+    yy, xx = np.mgrid[:ns, :ns] - ns // 2
+    p = np.stack([np.exp(-(xx**2 + yy**2) / (2.0 * (2.0 + 0.4 * k) ** 2)) + 0.01 * rng.standard_normal((ns, ns)) for k in range(3)])
+    dev = torch.device("cuda:0")
+    ctx = default_context()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    t = torch.as_tensor(p, device=dev)
+    size = int(lib.imcom_psf_spectra_size(ns, nfft))
+    assert size > 0
+    spec = torch.empty((3, size), dtype=torch.float64, device=dev)
+    dp = lambda a: C.c_void_p(a.data_ptr())  # noqa: E731
+    check(lib.imcom_psf_spectra(ctx.handle, dp(t), 3, ns, nfft, dp(spec)))
+    pairs = np.array([(0, 1), (1, 2), (2, 0), (1, 1)], dtype=np.int32)
+    nc = ns // 2
+    win = np.array([[0, nc + 8, 0, ns], [nc - 8, ns, nc - 8, ns], [3, nc, 0, nc + 8], [0, ns, 0, ns]], dtype=np.int32)
+    full = torch.empty((4, ns + 12, ns + 12), dtype=torch.float64, device=dev)
+    check(lib.imcom_psf_overlap_spectra(ctx.handle, dp(spec), 3, dp(spec), 3, ns, nfft, pairs.ctypes.data_as(C.c_void_p), 4, None, dp(full)))
+    part = torch.full((4, ns + 12, ns + 12), -7.0, dtype=torch.float64, device=dev)
+    check(lib.imcom_psf_overlap_spectra_win(ctx.handle, dp(spec), 3, dp(spec), 3, ns, nfft, pairs.ctypes.data_as(C.c_void_p), 4, None,
+                                            win.ctypes.data_as(C.c_void_p), dp(part)))
+    torch.cuda.synchronize()
+    f, g = full.cpu().numpy(), part.cpu().numpy()
+    static = nfft in (512, 768, 1024)
+    for q, (r0, r1, c0, c1) in enumerate(win):
+        assert np.array_equal(g[q, 6 + r0 : 6 + r1, 6 + c0 : 6 + c1], f[q, 6 + r0 : 6 + r1, 6 + c0 : 6 + c1]), q
+        if static:
+            inside = np.zeros(g[q].shape, bool)
+            lo, hi = 2 * (r0 // 2), min(2 * ((r1 + 1) // 2), ns)  # the row transform works on row pairs
+            inside[6 + lo : 6 + hi, 6 + c0 : 6 + c1] = True
+            untouched = g[q] == -7.0
+            assert np.all(untouched[~inside & (f[q] != 0.0)]), q  # outside the window only zero-border cells may have been written
+            assert not untouched[inside].any(), q
+        else:
+            assert np.array_equal(g[q], f[q])
+    bad = win.copy()
+    bad[0, 1] = ns + 1
+    with pytest.raises(ImcomError):
+        check(lib.imcom_psf_overlap_spectra_win(ctx.handle, dp(spec), 3, dp(spec), 3, ns, nfft, pairs.ctypes.data_as(C.c_void_p), 4, None,
+                                                bad.ctypes.data_as(C.c_void_p), dp(part)))
