@@ -242,6 +242,10 @@ def main():
     ctx = Context(local_rank)
     # each rank coadds its own stamps (block farming: stamp ids are disjoint across ranks)
     stamps = [synth.make_stamp(cfg, rank * args.batch + i) for i in range(args.batch)]
+    if os.environ.get("IMCOM_BENCH_SORT", "1") != "0":
+        # A block driver visits its stamps in the order it likes: deepest first.  The solve places stamp s on XCD s mod 8, and the
+        # late block rows of a ragged batch (cfg-4) are then shared evenly by the eight XCDs instead of binomially.
+        stamps.sort(key=lambda st: -st.n)
     n_expo = max(s.n_expo for s in stamps)
     psfs, target = synth.make_psfs(cfg, n_expo)
     tables = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=dev)

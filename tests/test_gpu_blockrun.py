@@ -297,3 +297,42 @@ def test_block_tables_group_sources_agree():
     assert runs == [[(0, 0), (0, 1)]]
     t.require(BlockTables.keys_for([(1, 1)]))
     assert runs == [[(0, 0), (0, 1)], [(1, 1)]]
+
+
+@pytest.mark.gpu
+def test_ragged_batches_are_reordered_without_a_trace(monkeypatch):
+    """A block whose exposure depth varies: prepare_batch visits the deepest stamps first (XCD balance of the late block rows).
+    The maps are placed by coordinates and a stamp's arithmetic does not depend on its position in the batch, so the block comes
+    out bit for bit as in coordinate order (IMCOM_BLOCK_KEEP_ORDER=1)."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import coadd_block, prepare_batch
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import PSFGroupTables
+
+    cfg = synth.CONFIGS["small"]
+    n1P, n_expo = 4, 4
+    nst = n1P + 2
+    inst = _instamps(cfg, n1P, n_expo, np.random.default_rng(77))
+    for jj in range(nst):  # the right half of the block loses exposures 2 and 3: half the depth there
+        for ii in range(nst // 2, nst):
+            xs, ys, dat, cum = inst[jj * nst + ii]
+            k = int(cum[2])
+            inst[jj * nst + ii] = (xs[:k], ys[:k], dat[:, :k], np.array([0, cum[1], cum[2], cum[2], cum[2]]))
+    pool = InStampPool(inst, cfg.n_inframe)
+    psfs, target = synth.make_psfs(cfg, n_expo)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    chunk = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    sb = prepare_batch(cfg, pool, tabs, chunk, n1P, n_expo)
+    assert sb.chunk != chunk and sorted(sb.chunk) == chunk and np.all(np.diff(sb.n.astype(np.int64)) <= 0)
+    assert (sb.n.max() + 127) // 128 > (sb.n.min() + 127) // 128, "the test block is not ragged in 128-blocks"
+    a = coadd_block(cfg, pool, tabs, n1P, n_expo, batch=16)
+    monkeypatch.setenv("IMCOM_BLOCK_KEEP_ORDER", "1")
+    assert prepare_batch(cfg, pool, tabs, chunk, n1P, n_expo).chunk == chunk
+    b = coadd_block(cfg, pool, tabs, n1P, n_expo, batch=16)
+    torch.cuda.synchronize()
+    assert torch.equal(a.out_map, b.out_map) and torch.equal(a.T_weightmap, b.T_weightmap)
+    for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+        assert torch.equal(a.maps[k], b.maps[k]), k
+    assert float(a.out_map.abs().max()) > 0
