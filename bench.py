@@ -242,6 +242,7 @@ def main():
     ctx = Context(local_rank)
     # each rank coadds its own stamps (block farming: stamp ids are disjoint across ranks)
     stamps = [synth.make_stamp(cfg, rank * args.batch + i) for i in range(args.batch)]
+    cpu_sample = stamps[:64]  # the CPU baseline's sample: the first stamps as generated, not the deepest
     if os.environ.get("IMCOM_BENCH_SORT", "1") != "0":
         # A block driver visits its stamps in the order it likes: deepest first.  The solve places stamp s on XCD s mod 8, and the
         # late block rows of a ragged batch (cfg-4) are then shared evenly by the eight XCDs instead of binomially.
@@ -332,7 +333,7 @@ def main():
             torch.cuda.empty_cache()
             out["block"] = block_leg(ctx, dev)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
-            out["cpu_baseline"] = cpu_baseline(cfg, stamps[:64], psfs, target, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(cfg, cpu_sample, psfs, target, args.cpu_budget)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
