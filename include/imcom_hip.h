@@ -47,6 +47,8 @@ typedef struct imcom_ctx imcom_ctx;
 
 /* ------------------------------------------------------------------ library / context --------- */
 int imcom_version(void);
+/* 1 when the library was built with the developer extras (make DEV=1: experimental kernels and cross-checks), else 0. */
+int imcom_dev_build(void);
 const char *imcom_last_error(void);
 int imcom_device_count(int *count);
 /* device: HIP device ordinal.  Creates the context's own stream; block->GPU farming uses one
@@ -338,6 +340,14 @@ int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, int n1, const
                               const int *pairs, int npairs, const double *amp_penalty, double *tables);
 int imcom_psf_overlap_spectra_win(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp, int nfft,
                                   const int *pairs, int npairs, const double *amp_penalty, const int *win, double *tables);
+/*   imcom_psf_overlap_spectra_slots  the same into an ARENA of tables: slots (HOST) [npairs] = index of the arena table that
+ *                            receives pair t's result, `tables` = the arena's first table, nslots its size (range check).
+ *                            A block keeps the PSFOvl sets of the PSF groups it is working on resident and replaces the least
+ *                            recently used ones (the reference's reference-counted SysMatA cache, psfutil.py:1868-1902,
+ *                            2012-2092): freed tables are reused one by one, so a set need not be contiguous. */
+int imcom_psf_overlap_spectra_slots(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp, int nfft,
+                                    const int *pairs, int npairs, const double *amp_penalty, const int *win, const int *slots,
+                                    int nslots, double *tables);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libimcom_hip.so")
+# IMCOM_HIP_LIB: another build of the same library (the developer build with its cross-check kernels, make DEV=1)
+LIB_PATH = os.environ.get("IMCOM_HIP_LIB") or os.path.join(_HERE, "lib", "libimcom_hip.so")
 
 MEM_HOST = 0
 MEM_DEVICE = 1
@@ -90,6 +91,7 @@ SIGNATURES = {
     "imcom_psf_spectra": [_vp, _vp, _i, _i, _i, _vp],
     "imcom_psf_overlap_spectra": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp],
     "imcom_psf_overlap_spectra_win": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "imcom_psf_overlap_spectra_slots": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
     "imcom_compress_map_f32": [_vp, _vp, _l, _i, _i, _vp],
     "imcom_trapezoid_recover_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i],
@@ -100,6 +102,8 @@ for _name, _args in SIGNATURES.items():
     _f.restype = C.c_int
 lib.imcom_version.argtypes = []
 lib.imcom_version.restype = C.c_int
+lib.imcom_dev_build.argtypes = []
+lib.imcom_dev_build.restype = C.c_int
 lib.imcom_psf_spectra_size.argtypes = [_i, _i]
 lib.imcom_psf_spectra_size.restype = C.c_long
 lib.imcom_smooth_pad_width.argtypes = [_d, _d]
@@ -107,7 +111,7 @@ lib.imcom_smooth_pad_width.restype = C.c_int
 lib.imcom_last_error.argtypes = []
 lib.imcom_last_error.restype = C.c_char_p
 
-EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_last_error", "imcom_psf_spectra_size", "imcom_smooth_pad_width"])
+EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_dev_build", "imcom_last_error", "imcom_psf_spectra_size", "imcom_smooth_pad_width"])
 
 
 def check(status):

@@ -111,17 +111,17 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
 
 
 
-def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap=256):
+def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap=256, kernel="Cholesky"):
     """Stamps per batch for a block: as many as memory holds (at most ``cap``), and among those the count for which the block's
     passes -- the short last one included -- take the fewest rounds of workgroups.  A solve launch has batch x ldm/128 workgroups for 2 x ``cu_count`` resident ones: 256 cfg-2 stamps
     are exactly 9 rounds, 128 are 4.5 (every launch ends with a half-empty round: cfg-4 ran 694 stamps/s at 128, 793 at 256),
-    64 are 2.25.  Per stamp: A, L (ldn^2 each), -B/2, Y (ldn x ldm per target, fp64), T (fp32), the inverted diagonal blocks."""
-    per_stamp = 8 * (2 * ldn * ldn + 2 * n_out * ldn * ldm + ldn * NB) + 4 * n_out * ldn * ldm + 64 * ldm * n_out
+    64 are 2.25.  Per stamp: A, L (ldn^2 each), -B/2, Y (ldn x ldm per target, fp64), T (fp32), the inverted diagonal blocks;
+    the other kernels work on copies in the reference's layout (``stamp_bytes``)."""
     hi = min(int(n_stamps), int(cap))
     if free_bytes is not None:
-        hi = max(1, min(hi, int(0.8 * free_bytes) // per_stamp))
+        hi = max(1, min(hi, int(0.8 * free_bytes) // stamp_bytes(ldn, ldm, n_out, kernel)))
     if hi >= n_stamps:
-        return int(n_stamps)
+        return max(int(n_stamps), 1)
     tiles, slots = max(ldm // NB, 1), 2 * cu_count
     rounds = lambda k: -(-k * tiles // slots)  # noqa: E731  rounds of workgroups of a launch over k stamps
     best, best_cost = hi, None
@@ -132,41 +132,180 @@ def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap
     return best
 
 
-def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None):
+def stamp_bytes(ldn, ldm, n_out=1, kernel="Cholesky", resident=2):
+    """Device bytes per stamp of a block's batches while an LA kernel runs: the StampBatch buffers of ``resident`` batches
+    (coadd_block prepares batch k + 1 while batch k is solved) + the library workspace of the one being solved."""
+    base = 8 * (ldn * ldn + n_out * ldn * ldm) + 4 * n_out * ldn * ldm + 64 * ldm * n_out  # A, -B/2, T (f32), maps
+    if kernel == "Cholesky":
+        return resident * base + 8 * (ldn * ldn + n_out * ldn * ldm + ldn * NB)  # L, Y, inverted diagonal blocks
+    extra = 12 * ldm * ldn  # -B/2 (f64) and T (f32) in the reference's [m][N] layout
+    if kernel == "Eigen":
+        return resident * base + extra + 8 * (4 * ldn * ldn + 2 * ldm * ldn) + (1 << 22)  # working copy, V, X, Q; the two padded m x N operands
+    if kernel == "Iterative":
+        return resident * base + extra + (ldm // 16 + 1) * ITER_PATCH_BYTES  # one dense union sub-matrix per 4 x 4 patch (csrc/iter_empir.hip)
+    return resident * base + extra + 8 * ldn * ldn
+
+
+ITER_PATCH_BYTES = 512 * 512 * 8 + 512 * 16 * 8 + 512 * 8  # iter_block_ws_bytes (csrc/iter_block.hip), per 4 x 4 patch
+
+
+def stamp_groups(j_st, i_st, nst):
+    """The PSF groups (2 x 2 InStamps, SysMatA.ji_st2psf psfutil.py:1803-1824) the nine InStamps of OutStamp (j_st, i_st)
+    belong to, in the order they are first met (coadd.py:853)."""
+    return tuple(dict.fromkeys((jj >> 1, ii >> 1) for jj in (j_st - 1, j_st, j_st + 1) for ii in (i_st - 1, i_st, i_st + 1)
+                               if 0 <= jj < nst and 0 <= ii < nst))
+
+
+def chunk_keys(chunk, nst):
+    """Table sets a chunk of stamps needs resident together."""
+    seen = dict.fromkeys(stamp_groups(j, i, nst) for j, i in chunk)
+    return list(dict.fromkeys(k for gs in seen for k in BlockTables.keys_for(gs)))
+
+
+def plan_batches(todo, nst, cap, tables=None, tiles_per_stamp=18, stamp_cost=0.6e-3, table_cost=2.3e-6, slots=512):
+    """Cut the stamps ``todo`` [(j_st, i_st), ...] of a block into batches of at most ``cap`` stamps.
+
+    With one PSF group for the whole block the order is kept.  With a group per 2 x 2 InStamps (``tables``: BlockTables) the
+    batches are rectangular TILES of cells of 2 x 2 stamps -- the four stamps of a cell draw on the same four groups, and a
+    tile of h x w cells touches (h + 1)(w + 1) groups where a row of the block 84 stamps wide would touch 2 x 43 for the same
+    number of stamps -- chosen among the balanced tilings of the block by a cost model: rounds of workgroups of the batch's
+    launches (``tiles_per_stamp`` workgroups per stamp, ``slots`` resident at once, ``stamp_cost`` seconds per stamp when
+    the rounds are full) plus ``table_cost`` per overlap table the tile needs.  Tiles whose table sets exceed the arena
+    (``tables.capacity``) are halved until they fit.  Tiles are visited boustrophedon, so that consecutive batches share a
+    column of groups whose sets are still resident."""
+    todo = list(todo)
+    if not todo:
+        return []
+    cap = max(1, int(cap))
+    if tables is None:
+        return [todo[c0 : c0 + cap] for c0 in range(0, len(todo), cap)]
+    cj = np.array([(j + 1) >> 1 for j, _ in todo])
+    ci = np.array([(i + 1) >> 1 for _, i in todo])
+    j0, i0 = int(cj.min()), int(ci.min())
+    H, W = int(cj.max()) - j0 + 1, int(ci.max()) - i0 + 1  # cells
+    n, S = tables.n_max, tables.n_max * (tables.n_max + 1) // 2 + tables.n_out * tables.n_max
+    per_round = stamp_cost * slots / tiles_per_stamp  # seconds per full round of workgroups
+    split = lambda L, k: [L * q // k for q in range(k + 1)]  # noqa: E731  balanced cut of L cells into k runs
+
+    def cost(nr, nc):
+        h, w = np.diff(split(H, nr)).astype(np.float64), np.diff(split(W, nc)).astype(np.float64)
+        st = 4.0 * np.outer(h, w)
+        if st.max() > cap or (st.max() < cap / 4 and nr * nc > 1):
+            return None  # a tile above the batch limit / a tiling far finer than needed
+        tabs = np.outer(h + 1, w + 1) * S + (np.outer(h + 1, w) + np.outer(h, w + 1) + 2.0 * np.outer(h, w)) * (n * n)
+        return float((np.ceil(st * tiles_per_stamp / slots) * per_round + tabs * table_cost).sum())
+
+    best = None
+    for nr in range(1, H + 1):
+        for nc in range(1, W + 1):
+            c = cost(nr, nc)
+            if c is not None and (best is None or c < best[0] - 1e-12):
+                best = (c, nr, nc)
+    _, nr, nc = best if best is not None else (0.0, H, W)
+    eh, ew = np.array(split(H, nr)), np.array(split(W, nc))
+    tj = np.searchsorted(eh, cj - j0, side="right") - 1
+    ti = np.searchsorted(ew, ci - i0, side="right") - 1
+    bins = {}
+    for q, key in enumerate(zip(tj.tolist(), ti.tolist())):
+        bins.setdefault(key, []).append(todo[q])
+    out = []
+
+    cell_of = lambda t: ((t[0] + 1) >> 1, (t[1] + 1) >> 1)  # noqa: E731
+
+    def emit(chunk):
+        # cells stay together and in order (the stamps of a cell share their pair maps and their tables in cache)
+        chunk.sort(key=lambda t: (cell_of(t), t))
+        if len(chunk) > cap or (len(chunk) > 1 and tables.demand(chunk_keys(chunk, nst)) > tables.capacity):
+            cells = list(dict.fromkeys(cell_of(t) for t in chunk))
+            if len(cells) > 1:  # halve along the longer side of the tile, on a cell boundary
+                js, is_ = sorted({c[0] for c in cells}), sorted({c[1] for c in cells})
+                if len(js) >= len(is_):
+                    first = set(js[: len(js) // 2])
+                    parts = [t for t in chunk if cell_of(t)[0] in first], [t for t in chunk if cell_of(t)[0] not in first]
+                else:
+                    first = set(is_[: len(is_) // 2])
+                    parts = [t for t in chunk if cell_of(t)[1] in first], [t for t in chunk if cell_of(t)[1] not in first]
+            else:
+                parts = chunk[: len(chunk) // 2], chunk[len(chunk) // 2 :]
+            emit(list(parts[0]))
+            emit(list(parts[1]))
+        else:
+            out.append(chunk)
+
+    for a in range(nr):
+        for b in (range(nc) if a % 2 == 0 else range(nc - 1, -1, -1)):
+            if (a, b) in bins:
+                emit(bins[(a, b)])
+    return out
+
+
+def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
+    """The batches coadd_block runs: list of lists of (j_st, i_st).  ``batch=None``: sized from the block's largest stamp, the
+    free device memory and -- with a BlockTables -- the table arena (``choose_batch`` / ``plan_batches``); an explicit ``batch``
+    cuts the visiting order every ``batch`` stamps (row by row as coadd.py:2049-2052; cell by cell with a BlockTables)."""
+    nst = n1P + 2
+    todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)] if stamps is None else [(int(j), int(i)) for j, i in stamps]
+    if not todo:
+        return []
+    grouped = isinstance(tables, BlockTables)
+    counts = np.diff(pool.inst_off).reshape(nst, nst)
+    win = sum(counts[dj : dj + n1P, di : di + n1P] for dj in range(3) for di in range(3))  # pixels of the nine neighbours of every stamp
+    cap_pix = int(max(win[j - 1, i - 1] for j, i in todo))
+    ldn_max = ldn or max(NB, (cap_pix + NB - 1) // NB * NB)
+    ldm = (cfg.m + NB - 1) // NB * NB
+    if batch is None:
+        import torch
+
+        free = torch.cuda.mem_get_info(pool.device)[0]
+        n_out = int(getattr(tables, "n_out", 1))
+        if grouped:  # tiles of 2 x 2-stamp cells, sized by memory and by the table arena (plan_batches)
+            cap = max(1, min(256, int(0.8 * free) // stamp_bytes(ldn_max, ldm, n_out, cfg.kernel)))
+        else:
+            cap = choose_batch(len(todo), ldn_max, ldm, n_out, free, kernel=cfg.kernel)
+    else:
+        cap = max(1, int(batch))
+    if not grouped:
+        return [todo[c0 : c0 + cap] for c0 in range(0, len(todo), cap)]
+    # The four stamps (2a-1..2a, 2b-1..2b) of a cell draw on the same four PSF groups (their InStamps 2a-2..2a+1 are group
+    # rows a-1, a): a batch is a tile of cells, visited cell by cell (the maps are placed by coordinates, so the order of the
+    # visit does not show in the result).  An explicit ``batch`` keeps the cell order and cuts it every ``batch`` stamps.
+    if batch is None:
+        nbar = float(np.mean([win[j - 1, i - 1] for j, i in todo]))
+        per_stamp = (2.0 * nbar * nbar * cfg.m + nbar**3 / 3.0 + 165.0 * nbar * nbar) / 45e12  # seconds at the rate the path reaches
+        return plan_batches(todo, nst, cap, tables, tiles_per_stamp=max(ldm // NB, 1), stamp_cost=per_stamp)
+    todo.sort(key=lambda t: ((t[0] + 1) >> 1, (t[1] + 1) >> 1, t[0], t[1]))
+    chunks = []
+    for c0 in range(0, len(todo), cap):
+        part = [todo[c0 : c0 + cap]]
+        while part:  # a chunk whose table sets exceed the arena is halved
+            c = part.pop(0)
+            if len(c) > 1 and tables.demand(chunk_keys(c, nst)) > tables.capacity:
+                part[:0] = [c[: len(c) // 2], c[len(c) // 2 :]]
+            else:
+                chunks.append(c)
+    return chunks
+
+
+def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None, chunks=None):
     """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
     order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables or BlockTables.  ``stamps``: the (j_st, i_st) to
-    coadd (default all n1P x n1P, row by row as coadd.py:2049-2052); ``pad_sides=None`` leaves the boundary recovery of
-    coadd.py:2163-2181 out.  ``batch``: stamps per pass (default: ``choose_batch`` from the block's largest stamp and the
-    free device memory).  Returns the BlockMaps."""
+    coadd (default all n1P x n1P); ``pad_sides=None`` leaves the boundary recovery of coadd.py:2163-2181 out.  ``batch``:
+    stamps per pass, or ``chunks``: the passes themselves (default: ``plan_block``).  Returns the BlockMaps."""
     nst = n1P + 2
     assert pool.n_inst == nst * nst
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
                      n_out=int(getattr(tables, "n_out", 1)))
-    todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)] if stamps is None else [(int(j), int(i)) for j, i in stamps]
-    if isinstance(tables, BlockTables):
-        # The four stamps (2a-1..2a, 2b-1..2b) draw on the same four PSF groups (their InStamps 2a-2..2a+1 are group rows a-1, a):
-        # visited one after the other, the ~100 MB of tables a stamp's samples touch are still in the Infinity Cache for the
-        # next three (the maps are placed by coordinates, so the order of the visit does not show in the result).
-        todo.sort(key=lambda t: ((t[0] + 1) >> 1, (t[1] + 1) >> 1, t[0], t[1]))
-        # and the block's PSF groups are sampled / transformed before the host turns to the per-stamp bookkeeping
-        tables.prefetch({((j + dj) >> 1, (i + di) >> 1) for j, i in todo for dj in (-1, 0, 1) for di in (-1, 0, 1)
-                         if 0 <= j + dj < nst and 0 <= i + di < nst})
-    if batch is None:
-        import torch
-
-        counts = np.diff(pool.inst_off).reshape(nst, nst)
-        win = sum(counts[dj : dj + n1P, di : di + n1P] for dj in range(3) for di in range(3))  # pixels of the nine neighbours of every stamp
-        cap = int(max(win[j - 1, i - 1] for j, i in todo)) if todo else NB
-        ldn_max = ldn or max(NB, (cap + NB - 1) // NB * NB)
-        ldm = (cfg.m + NB - 1) // NB * NB
-        free = torch.cuda.mem_get_info(pool.device)[0]
-        batch = choose_batch(len(todo), ldn_max, ldm, int(getattr(tables, "n_out", 1)), free)
+    if chunks is None:
+        chunks = plan_block(cfg, pool, tables, n1P, batch, ldn, stamps)
+    chunks = [[(int(j), int(i)) for j, i in c] for c in chunks if len(c)]
+    if isinstance(tables, BlockTables) and chunks:
+        # the PSF groups of the first batches are sampled / transformed before the host turns to the per-stamp bookkeeping
+        tables.prefetch(dict.fromkeys(g for c in chunks[:2] for t in c for g in stamp_groups(t[0], t[1], nst)))
     prepare = lambda chunk: prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn)  # noqa: E731
 
     # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after
     # the current one's A and B builds have been queued, i.e. while the GPU is busy with them; only then does the host
     # block in the solve's status read-back
-    chunks = [todo[c0 : c0 + batch] for c0 in range(0, len(todo), batch)]
     nxt = prepare(chunks[0]) if chunks else None
     for k, chunk in enumerate(chunks):
         sb = nxt

@@ -331,6 +331,14 @@ using namespace imcom;
 extern "C" {
 
 int imcom_version(void) { return IMCOM_HIP_VERSION; }
+int imcom_dev_build(void)
+{
+#ifdef IMCOM_DEV
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char *imcom_last_error(void) { return g_err; }
 
@@ -486,7 +494,11 @@ int imcom_ctx_gemm_probe(imcom_ctx *ctx, int variant, int M, int N, int K, int b
     IMCOM_HIP_CHECK(hipEventCreate(&e0));
     IMCOM_HIP_CHECK(hipEventCreate(&e1));
     auto run = [&]() -> int {
-        if (variant == 1) return launch_gemm_probe16(ctx, M, N, K, batch, A, B, C);
+#ifdef IMCOM_DEV
+        if (variant == 1) return launch_gemm_probe16(ctx, M, N, K, batch, A, B, C);  // probe_gemm.hip
+#else
+        if (variant == 1) { set_error("gemm probe variant 1 (256 x 128 tiles) is part of the developer build (make DEV=1)"); return IMCOM_ERR_ARG; }
+#endif
         // variants 2-4: the engine's other operand layouts (2: both row-major, the Cholesky updates' form C = A B^T; 3: both k-major,
         // the backward solves'; 4: A k-major, B row-major) on the same buffers
         if (variant >= 5) return launch_gemm_abl(ctx, variant - 4, M, N, K, batch, A, B, C);  // 5: no DMA, 6: no barrier, 7: neither, 8: DMA and barrier but no wait for the DMA

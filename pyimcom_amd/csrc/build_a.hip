@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
                                                       double *__restrict__ A, int ntile)
 {
     __shared__ __attribute__((aligned(16))) double seg[A_RING][256 * SEG_W];
-    __shared__ int seg0[256];   // first element (ascending address order) of stencil row 0; < 0: no loads
+    __shared__ long seg0[256];  // first element (ascending address order) of stencil row 0, as a 64-bit offset into the table stack
+                                // (a block of the reference's size keeps > 2^31 table elements resident); < 0: no loads
     __shared__ int rstep[256];  // element step between stencil rows (+ng, or -ng for a flipped table)
     __shared__ double tile[16][17];
     // the tile's 16 + 16 pixels and the stamp's pair table, fetched once by a few lanes in ONE round trip (every thread doing its
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
             }
         }
     }
-    seg0[tid] = (int)my_seg0;  // launch_build_A checks that the table stack fits 31 bits
+    seg0[tid] = my_seg0;
     rstep[tid] = my_step;
     double wt[10];  // the x weights as the row loop uses them (set below, once the first row is on its way)
     // A stencil row is staged as the FIVE 16-byte chunks that hold exactly its 10 taps: the LDS-DMA takes 8-byte aligned
@@ -158,20 +159,22 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     // the five (sample, chunk) pairs this thread fetches for every stencil row.  A wave stages the chunks of its
     // own 64 samples (work item w = lane + 64 q of the wave's 320), so that producer and consumer of an LDS row are
     // the same wave: no workgroup barrier in the row loop, only counted vmcnt waits, and the four waves drift freely.
-    int at[NCH], st1[NCH];  // first element of the chunk for the next row, and the step between rows
+    const double *at[NCH];  // the chunk of the next row
+    int st1[NCH];           // and the element step between rows
 #pragma unroll
     for (int q = 0; q < NCH; q++) {
         const int w = (tid & 63) + 64 * q, sm = (tid & ~63) + w / NCH, ch = w % NCH;
-        const int e0 = seg0[sm], stp = rstep[sm];
+        const long e0 = seg0[sm];
+        const int stp = rstep[sm];
         const bool on = e0 >= 0;  // samples without a stencil fetch element 0: harmless, and the fast path stays branch-free
-        at[q] = on ? e0 + 2 * ch : 0;
+        at[q] = tables + (on ? e0 + 2 * ch : 0);
         st1[q] = on ? stp : 0;
     }
     const int wave_base = (tid & ~63) * SEG_W;  // this wave's 64 x 10 doubles of a row buffer
     auto stage = [&](double *buf) {  // branch-free: every lane issues its five chunk loads
 #pragma unroll
         for (int q = 0; q < NCH; q++) {
-            IMCOM_GLDS16(tables + at[q], buf + 128 * q + wave_base);  // wave-uniform LDS base; lane l lands at +2 l
+            IMCOM_GLDS16(at[q], buf + 128 * q + wave_base);  // wave-uniform LDS base; lane l lands at +2 l
             at[q] += st1[q];
         }
     };
@@ -179,8 +182,8 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
 #pragma unroll
         for (int q = 0; q < NCH; q++) {
             double *dst = buf + 128 * q + wave_base;
-            const long a_ = at[q];
-            if (a_ >= 0 && a_ + 1 < tab_elems) IMCOM_GLDS16(tables + a_, dst);
+            const long a_ = at[q] - tables;
+            if (a_ >= 0 && a_ + 1 < tab_elems) IMCOM_GLDS16(at[q], dst);
             else { dst[2 * (tid & 63)] = (a_ >= 0 && a_ < tab_elems) ? tables[a_] : 0.0; dst[2 * (tid & 63) + 1] = 0.0; }
             at[q] += st1[q];
         }
@@ -258,19 +261,23 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     }
 }
 
+#ifdef IMCOM_DEV
 int launch_build_A_win(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y, const int *psf,
                        const double *tables, int ntab, int ng, double nc, double dscale, const int *pair_tab, const double *pair_pen,
                        int npsf_max, double *A);  // build_a_win.hip
+#endif
 
 int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y,
                    const int *psf, const double *tables, int ntab, int ng, double nc, double dscale,
                    const int *pair_tab, const double *pair_pen, int npsf_max, double *A)
 {
-    // IMCOM_BUILD_A=window selects the experimental LDS-window builder (build_a_win.hip: parity-tested, but slower than
-    // this file's per-sample DMA builder on rotated exposures -- DESIGN.md, "A builder, round 2")
+#ifdef IMCOM_DEV
+    // developer build (make DEV=1): IMCOM_BUILD_A=window selects the experimental LDS-window builder (build_a_win.hip:
+    // parity-tested, but slower than this file's per-sample DMA builder on rotated exposures -- DESIGN.md, "A builder, round 2")
     static const bool window = getenv("IMCOM_BUILD_A") && !strcmp(getenv("IMCOM_BUILD_A"), "window");
     if (window) return launch_build_A_win(ctx, batch, n_dev, ldn, x, y, psf, tables, ntab, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A);
-    IMCOM_REQUIRE((long)ntab * ng * ng < (1L << 31), "table stack too large (%d tables of %d^2)", ntab, ng);
+#endif
+    IMCOM_REQUIRE(ntab >= 1 && ntab <= PAIR_MASK + 1, "table stack of %d tables (pair codes carry 28-bit table indices)", ntab);
     const int nt = (ldn + 15) / 16;
     const long ntri = (long)nt * (nt + 1) / 2;
     const long ngrid = (ntri + 7) / 8 * 8;  // padded to a multiple of 8 for the XCD-aware tile order

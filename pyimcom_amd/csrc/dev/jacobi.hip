@@ -287,56 +287,8 @@ __global__ __launch_bounds__(256) void jacobi_lambda_kernel(const double *__rest
     if (lane == 0) lam_raw[(long)s * ld + a] = acc / vv;
 }
 
-// ascending rank of every eigenvalue (ties by index), lam[rank] = value
-__global__ void jacobi_rank_kernel(const double *__restrict__ lam_raw, int ld, const int *__restrict__ n,
-                                   int *__restrict__ rank, double *__restrict__ lam, long ldlam)
-{
-    const int s = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ns = n[s];
-    if (a >= ns) return;
-    const double *l = lam_raw + (long)s * ld;
-    const double mine = l[a];
-    int r = 0;
-    for (int b = 0; b < ns; b++) {
-        const double o = l[b];
-        r += (o < mine || (o == mine && b < a)) ? 1 : 0;
-    }
-    rank[(long)s * ld + a] = r;
-    lam[s * ldlam + r] = mine;
-}
-
-// Q[i][rank[a]] = Vt[a][i] (eigenvectors in columns, ascending); Q is [ldq][ldq], zero outside n x n
-__global__ __launch_bounds__(256) void jacobi_scatter_kernel(const double *__restrict__ Vt, int ld, const int *__restrict__ rank,
-                                                             const int *__restrict__ n, double *__restrict__ Q, long ldq,
-                                                             long strideQ)
-{
-    __shared__ double tile[32][33];
-    __shared__ int rk[32];
-    const int s = blockIdx.z, a0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int ns = n[s];
-    if (threadIdx.x < 32) rk[threadIdx.x] = (a0 + threadIdx.x < ns) ? rank[(long)s * ld + a0 + threadIdx.x] : -1;
-    for (int r = ty; r < 32; r += 8) {
-        const int a = a0 + r, i = i0 + tx;
-        tile[r][tx] = (a < ns && i < ns) ? Vt[(long)s * ld * ld + (long)a * ld + i] : 0.0;
-    }
-    __syncthreads();
-    // thread (ty, tx): row i = i0 + ty.., source column a = a0 + tx -> writes Q[i][rank[a]] (scattered within the row)
-    for (int r = ty; r < 32; r += 8) {
-        const int i = i0 + r;
-        if (i < ns && rk[tx] >= 0) Q[s * strideQ + (long)i * ldq + rk[tx]] = tile[tx][r];
-    }
-}
-
-// Shared tail of both eigensolvers: ascending order + eigenvectors scattered into the columns of Q (Q may be
-// null: eigenvalues only).  Vt rows are eigenvectors, lam_raw[s*ld + a] their eigenvalues.
 int launch_eig_sort_scatter(imcom_ctx *ctx, const double *Vt, int ld, const double *lam_raw, const int *n_dev, int *rank,
-                            double *lam, long ldlam, double *Q, long ldq, long strideQ, int batch)
-{
-    hipLaunchKernelGGL(jacobi_rank_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, ctx->stream, lam_raw, ld, n_dev, rank, lam, ldlam);
-    if (Q) hipLaunchKernelGGL(jacobi_scatter_kernel, dim3(ld / 32, ld / 32, batch), dim3(256), 0, ctx->stream, Vt, ld, rank, n_dev, Q, ldq, strideQ);
-    return check_launch("eig sort/scatter");
-}
+                            double *lam, long ldlam, double *Q, long ldq, long strideQ, int batch);  // tridiag.hip
 
 // -------------------------------------------------------------------------------------------------
 size_t jacobi_ws_bytes(int batch, int ld)

@@ -89,22 +89,6 @@ __global__ __launch_bounds__(PTHREADS, 4) void gemm_probe16_kernel(const double 
             for (int r = 0; r < 4; r++) Co[(long)(wm * 64 + i * 16 + lk + 4 * r) * ldc + wn * 32 + j * 16 + li] = acc[i][j][r];
 }
 
-// operands with full mantissas (a product of zeros draws half the power of one of real data and runs at a higher clock)
-__global__ void probe_fill_kernel(double *__restrict__ p, long count, unsigned seed)
-{
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    unsigned long long x = (unsigned long long)i * 6364136223846793005ULL + seed;
-    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
-    p[i] = ((double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5) * 1e-3;  // (-5e-4, 5e-4): no overflow over K <= 1e6
-}
-
-int launch_probe_fill(imcom_ctx *ctx, double *p, long count, unsigned seed)
-{
-    hipLaunchKernelGGL(probe_fill_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, p, count, seed);
-    return check_launch("probe_fill_kernel");
-}
-
 int launch_gemm_probe16(imcom_ctx *ctx, int M, int N, int K, int batch, const double *A, const double *B, double *C)
 {
     IMCOM_REQUIRE(M % PTM == 0 && N % PTN == 0 && K % DBK == 0 && DBK == 16, "gemm probe: M % 256, N % 128, K % 16");

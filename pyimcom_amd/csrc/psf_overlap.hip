@@ -219,14 +219,15 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_inv_cols_kernel(const cp
 // bins; so does this.  Stored rolled by nc, cropped to ns, scaled by 1/n^2, inside the 6-sample zero border (the
 // waves of a row pair write the side borders of their rows, the first and the last pair also the rows above / below).
 __global__ __launch_bounds__(WF_MAXWAVES * 64) void fft_inv_rows_kernel(const cplx *__restrict__ V, int ns, FftPlan pl,
-                                                            const cplx *__restrict__ tw, double *__restrict__ tables)
+                                                            const cplx *__restrict__ tw, const int *__restrict__ slot,
+                                                            double *__restrict__ tables)
 {
     IMCOM_WF_PROLOGUE;
     const int t = blockIdx.x, r0 = 2 * (blockIdx.y * pl.waves + wave), nc = ns / 2, ng = ns + 12, lane = threadIdx.x & 63;
     if (r0 >= ns) return;
     const bool two = r0 + 1 < ns;
     const cplx *src = V + ((long)t * ((ns + 1) / 2) + r0 / 2) * v_stride(n) * 2;
-    double *tab = tables + (long)t * ng * ng;
+    double *tab = tables + (long)(slot ? slot[t] : t) * ng * ng;  // slot: the arena table this pair's result goes to
     const int bo = two ? 1 : 0;
     const double bz = two ? 1.0 : 0.0;
     auto load0 = [&](int k) {
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const c
 template <int R2>
 __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_rows_kernel(const cplx *__restrict__ V, int npairs, int ns,
                                                                          const cplx *__restrict__ tw, const int *__restrict__ win,
-                                                                         double *__restrict__ tables)
+                                                                         const int *__restrict__ slot, double *__restrict__ tables)
 {
     IMCOM_WF16_PROLOGUE;
     const int nc = ns / 2, ng = ns + 12;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_rows_kernel(const c
         }
         const bool two = r0 + 1 < ns;
         const cplx *src = V + L * v_stride(n) * 2;
-        double *tab = tables + (long)t * ng * ng;
+        double *tab = tables + (long)(slot ? __builtin_amdgcn_readfirstlane(slot[t]) : t) * ng * ng;  // slot: the arena table of this pair
         const int bo = two ? 1 : 0;
         const double bz = two ? 1.0 : 0.0;
         auto load0 = [&](int k) {
@@ -508,7 +509,7 @@ static int wf16_forward(imcom_ctx *ctx, const double *psf, int npsf, int nsamp, 
 
 template <int R2>
 static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const int *pairs_dev, int npairs, int nsamp, const cplx *tw,
-                        double a0, double a1, const int *win_dev, cplx *V, double *tables)
+                        double a0, double a1, const int *win_dev, const int *slot_dev, cplx *V, double *tables)
 {
     // the column kernel's waves write V in groups of four (four neighbouring columns = one 128-byte line per row pair)
     const int W = wf16_waves<R2>(), Wc = W / 4 * 4, nh = Wf16<R2>::N / 2 + 1;
@@ -523,12 +524,12 @@ static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const in
         hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, true>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V);
     else
         hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, false>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V);
-    hipLaunchKernelGGL(wf16_inv_rows_kernel<R2>, dim3(g2), dim3(64 * W), lds, ctx->stream, (const cplx *)V, npairs, nsamp, tw, win_dev, tables);
+    hipLaunchKernelGGL(wf16_inv_rows_kernel<R2>, dim3(g2), dim3(64 * W), lds, ctx->stream, (const cplx *)V, npairs, nsamp, tw, win_dev, slot_dev, tables);
     return check_launch("psf_overlap (16 x 16 x r lines)");
 }
 
 static size_t fft_forward_ws(int n, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)n * nsamp * (nfft / 2 + 1) * 16 + 1024; }
-static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * (nsamp + 1) * v_stride(nfft) * 16 + (size_t)npairs * 24 + 2048; }
+static size_t fft_inverse_ws(int npairs, int nsamp, int nfft) { return (size_t)nfft * 16 + (size_t)npairs * (nsamp + 1) * v_stride(nfft) * 16 + (size_t)npairs * 28 + 4096; }
 
 static cplx *fft_twiddles(imcom_ctx *ctx, const FftPlan &pl)
 {
@@ -561,29 +562,31 @@ static int fft_forward(imcom_ctx *ctx, const FftPlan &pl, const double *psf, int
 
 // tables[t] from spectra pairs (Ra[pairs[2t]], Rb[pairs[2t+1]]); the caller has reserved fft_inverse_ws()
 static int fft_inverse(imcom_ctx *ctx, const FftPlan &pl, const cplx *Ra, const cplx *Rb, const int *pairs_host, int npairs,
-                       int nsamp, const double *amp_penalty, double *tables, const int *win_host = nullptr)
+                       int nsamp, const double *amp_penalty, double *tables, const int *win_host = nullptr, const int *slots_host = nullptr)
 {
     const int nfft = pl.n, nh = nfft / 2 + 1;
     cplx *tw = fft_twiddles(ctx, pl);
     cplx *V = (cplx *)ws_take(ctx, (size_t)npairs * (nsamp + 1) * v_stride(nfft) * 16);  // [pair][row pair][kx, stride nhp][2]
     int *pairs_dev = (int *)ws_take(ctx, (size_t)npairs * 8);
     int *win_dev = win_host ? (int *)ws_take(ctx, (size_t)npairs * 16) : nullptr;  // the static kernels honour it; the general ones fill whole tables
-    if (!tw || !V || !pairs_dev || (win_host && !win_dev)) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
+    int *slot_dev = slots_host ? (int *)ws_take(ctx, (size_t)npairs * 4) : nullptr;
+    if (!tw || !V || !pairs_dev || (win_host && !win_dev) || (slots_host && !slot_dev)) { set_error("internal: workspace plan too small"); return IMCOM_ERR_NOMEM; }
     IMCOM_TRY(fft_set_lds(pl));
     hipStream_t st = ctx->stream;
     IMCOM_TRY(upload(ctx, pairs_dev, pairs_host, 2 * (size_t)npairs));  // through the pinned ring: no stream drain
     if (win_host) IMCOM_TRY(upload(ctx, win_dev, win_host, 4 * (size_t)npairs));
+    if (slots_host) IMCOM_TRY(upload(ctx, slot_dev, slots_host, (size_t)npairs));
     const double a0 = amp_penalty ? amp_penalty[0] : 0.0, a1 = amp_penalty ? amp_penalty[1] : 0.0;
     switch (fft_static_r(pl)) {
-    case 2: return wf16_inverse<2>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V, tables);
-    case 3: return wf16_inverse<3>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V, tables);
-    case 4: return wf16_inverse<4>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V, tables);
+    case 2: return wf16_inverse<2>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, slot_dev, V, tables);
+    case 3: return wf16_inverse<3>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, slot_dev, V, tables);
+    case 4: return wf16_inverse<4>(ctx, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, slot_dev, V, tables);
     default: break;
     }
     const size_t lds = fft_lds_bytes(pl);
     const int W = pl.waves, row_blocks = ((nsamp + 1) / 2 + W - 1) / W, col_blocks = (nh + W - 1) / W;
     hipLaunchKernelGGL(fft_inv_cols_kernel, dim3(npairs, col_blocks), dim3(64 * W), lds, st, Ra, Rb, pairs_dev, nsamp, pl, tw, a0, a1, V);
-    hipLaunchKernelGGL(fft_inv_rows_kernel, dim3(npairs, row_blocks), dim3(64 * W), lds, st, V, nsamp, pl, tw, tables);
+    hipLaunchKernelGGL(fft_inv_rows_kernel, dim3(npairs, row_blocks), dim3(64 * W), lds, st, V, nsamp, pl, tw, slot_dev, tables);
     return check_launch("psf_overlap (butterfly path)");
 }
 
@@ -721,9 +724,9 @@ extern "C" int imcom_psf_spectra(imcom_ctx *ctx, const double *psf, int n, int n
     return fft_forward(ctx, pl, psf, n, nsamp, (cplx *)spectra);
 }
 
-extern "C" int imcom_psf_overlap_spectra_win(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp,
-                                             int nfft, const int *pairs_host, int npairs, const double *amp_penalty,
-                                             const int *win_host, double *tables)
+extern "C" int imcom_psf_overlap_spectra_slots(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp,
+                                               int nfft, const int *pairs_host, int npairs, const double *amp_penalty,
+                                               const int *win_host, const int *slots_host, int nslots, double *tables)
 {
     if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
     IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
@@ -737,6 +740,8 @@ extern "C" int imcom_psf_overlap_spectra_win(imcom_ctx *ctx, const double *spec1
             const int *w = win_host + 4 * (size_t)t;
             IMCOM_REQUIRE(0 <= w[0] && w[0] < w[1] && w[1] <= nsamp && 0 <= w[2] && w[2] < w[3] && w[3] <= nsamp, "window %d out of range", t);
         }
+    if (slots_host)
+        for (int t = 0; t < npairs; t++) IMCOM_REQUIRE(slots_host[t] >= 0 && slots_host[t] < nslots, "slot %d of pair %d outside the arena of %d tables", slots_host[t], t, nslots);
     FftPlan pl;
     fft_plan(nfft, &pl);
     // in chunks of pairs, so that the intermediate (nsamp x nh complex per pair) stays within ~4 GB however many
@@ -750,9 +755,17 @@ extern "C" int imcom_psf_overlap_spectra_win(imcom_ctx *ctx, const double *spec1
     for (int p0 = 0; p0 < npairs; p0 += chunk) {
         ctx->ws_used = 0;
         IMCOM_TRY(fft_inverse(ctx, pl, (const cplx *)spec1, (const cplx *)spec2, pairs_host + 2 * (size_t)p0, std::min(chunk, npairs - p0), nsamp,
-                              amp_penalty, tables + (size_t)p0 * tab, win_host ? win_host + 4 * (size_t)p0 : nullptr));
+                              amp_penalty, slots_host ? tables : tables + (size_t)p0 * tab, win_host ? win_host + 4 * (size_t)p0 : nullptr,
+                              slots_host ? slots_host + p0 : nullptr));
     }
     return IMCOM_OK;
+}
+
+extern "C" int imcom_psf_overlap_spectra_win(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp,
+                                             int nfft, const int *pairs_host, int npairs, const double *amp_penalty,
+                                             const int *win_host, double *tables)
+{
+    return imcom_psf_overlap_spectra_slots(ctx, spec1, n1, spec2, n2, nsamp, nfft, pairs_host, npairs, amp_penalty, win_host, nullptr, 0, tables);
 }
 
 extern "C" int imcom_psf_overlap_spectra(imcom_ctx *ctx, const double *spec1, int n1, const double *spec2, int n2, int nsamp,

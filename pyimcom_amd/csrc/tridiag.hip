@@ -30,8 +30,57 @@ constexpr int QRS = 16;         // QR sweeps per chunk = depth of the rotation w
 constexpr int ROTPAD = 4 * QRS; // identity margin of the rotation log on both sides
 constexpr int QR_RING = 4;      // rotation logs in flight between the QR chain and the rotation kernels
 
+// ascending rank of every eigenvalue (ties by index), lam[rank] = value
+__global__ void eig_rank_kernel(const double *__restrict__ lam_raw, int ld, const int *__restrict__ n,
+                                   int *__restrict__ rank, double *__restrict__ lam, long ldlam)
+{
+    const int s = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns = n[s];
+    if (a >= ns) return;
+    const double *l = lam_raw + (long)s * ld;
+    const double mine = l[a];
+    int r = 0;
+    for (int b = 0; b < ns; b++) {
+        const double o = l[b];
+        r += (o < mine || (o == mine && b < a)) ? 1 : 0;
+    }
+    rank[(long)s * ld + a] = r;
+    lam[s * ldlam + r] = mine;
+}
+
+// Q[i][rank[a]] = Vt[a][i] (eigenvectors in columns, ascending); Q is [ldq][ldq], zero outside n x n
+__global__ __launch_bounds__(256) void eig_scatter_kernel(const double *__restrict__ Vt, int ld, const int *__restrict__ rank,
+                                                             const int *__restrict__ n, double *__restrict__ Q, long ldq,
+                                                             long strideQ)
+{
+    __shared__ double tile[32][33];
+    __shared__ int rk[32];
+    const int s = blockIdx.z, a0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ns = n[s];
+    if (threadIdx.x < 32) rk[threadIdx.x] = (a0 + threadIdx.x < ns) ? rank[(long)s * ld + a0 + threadIdx.x] : -1;
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, i = i0 + tx;
+        tile[r][tx] = (a < ns && i < ns) ? Vt[(long)s * ld * ld + (long)a * ld + i] : 0.0;
+    }
+    __syncthreads();
+    // thread (ty, tx): row i = i0 + ty.., source column a = a0 + tx -> writes Q[i][rank[a]] (scattered within the row)
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r;
+        if (i < ns && rk[tx] >= 0) Q[s * strideQ + (long)i * ldq + rk[tx]] = tile[tx][r];
+    }
+}
+
+// Shared tail of both eigensolvers: ascending order + eigenvectors scattered into the columns of Q (Q may be
+// null: eigenvalues only).  Vt rows are eigenvectors, lam_raw[s*ld + a] their eigenvalues.
 int launch_eig_sort_scatter(imcom_ctx *ctx, const double *Vt, int ld, const double *lam_raw, const int *n_dev, int *rank,
-                            double *lam, long ldlam, double *Q, long ldq, long strideQ, int batch);
+                            double *lam, long ldlam, double *Q, long ldq, long strideQ, int batch)
+{
+    hipLaunchKernelGGL(eig_rank_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, ctx->stream, lam_raw, ld, n_dev, rank, lam, ldlam);
+    if (Q) hipLaunchKernelGGL(eig_scatter_kernel, dim3(ld / 32, ld / 32, batch), dim3(256), 0, ctx->stream, Vt, ld, rank, n_dev, Q, ldq, strideQ);
+    return check_launch("eig sort/scatter");
+}
+
 
 __device__ inline double block_sum_256(double v, double *red)
 {
@@ -795,8 +844,9 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
 }
 
 // -------------------------------------------------------------------------------------------------
-// Eigensolver used by the library.  The tridiagonal QR path is the product; IMCOM_EIGH=jacobi selects the
-// one-sided block Jacobi solver (jacobi.hip), kept as an independent cross-check.
+// Eigensolver used by the library.  The tridiagonal QR path is the product; a developer build (make DEV=1) also holds the
+// one-sided block Jacobi solver (jacobi.hip), an independent cross-check selected by IMCOM_EIGH=jacobi.
+#ifdef IMCOM_DEV
 size_t jacobi_ws_bytes(int batch, int ld);
 int jacobi_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA,
                        double *lam, long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out);
@@ -806,6 +856,14 @@ bool eigh_uses_jacobi()
     const char *e = getenv("IMCOM_EIGH");
     return e && strcmp(e, "jacobi") == 0;
 }
+#else
+static size_t jacobi_ws_bytes(int, int) { return 0; }
+static int jacobi_eigh_device(imcom_ctx *, int, const int *, int, const double *, long, long, double *, long, double *, long, long, int *)
+{
+    return IMCOM_ERR_ARG;
+}
+bool eigh_uses_jacobi() { return false; }
+#endif
 
 size_t eigh_ws_bytes(int batch, int ld, bool vectors)
 {

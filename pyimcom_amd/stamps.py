@@ -58,10 +58,11 @@ def psf_spectra(ctx, psf, nfft):
     return spec
 
 
-def overlap_tables(ctx, p1, s1, p2, s2, nsamp, nfft, pairs, amp, out, win=None):
+def overlap_tables(ctx, p1, s1, p2, s2, nsamp, nfft, pairs, amp, out, win=None, slots=None):
     """Tables of the (i, j) `pairs` between two PSF sets, from their spectra when both are given (else from the
     sampled PSFs through imcom_psf_overlap).  ``win`` [npairs, 4] (spectra form only): the part of every table's window
-    that will be read, imcom_psf_overlap_spectra_win."""
+    that will be read, imcom_psf_overlap_spectra_win.  ``slots`` [npairs] (spectra form only): pair t goes to table
+    ``out[slots[t]]`` of the arena ``out`` instead of ``out[t]``, imcom_psf_overlap_spectra_slots."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     ampp = None if amp is None else _hp(amp)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -71,9 +72,15 @@ def overlap_tables(ctx, p1, s1, p2, s2, nsamp, nfft, pairs, amp, out, win=None):
             win = np.ascontiguousarray(win, dtype=np.int32)
             assert win.shape == (len(pairs), 4)
             winp = _hp(win)
-        check(lib.imcom_psf_overlap_spectra_win(ctx.handle, _dp(s1), s1.shape[0], _dp(s2), s2.shape[0], nsamp, nfft, _hp(pairs),
-                                                len(pairs), ampp, winp, _dp(out)))
+        slp = None
+        if slots is not None:
+            slots = np.ascontiguousarray(slots, dtype=np.int32)
+            assert slots.shape == (len(pairs),)
+            slp = _hp(slots)
+        check(lib.imcom_psf_overlap_spectra_slots(ctx.handle, _dp(s1), s1.shape[0], _dp(s2), s2.shape[0], nsamp, nfft, _hp(pairs),
+                                                  len(pairs), ampp, winp, slp, out.shape[0], _dp(out)))
     else:
+        assert slots is None
         check(lib.imcom_psf_overlap(ctx.handle, _dp(p1), p1.shape[0], _dp(p2), p2.shape[0], nsamp, nfft, _hp(pairs), len(pairs),
                                     ampp, _dp(out)))
 
@@ -173,19 +180,24 @@ class BlockTables:
     ``group_psfs``: {(gj, gi): array [n_g, nsamp, nsamp]} sampled input PSFs of every group; group (gj, gi) serves
     the InStamps (2gj..2gj+1, 2gi..2gi+1).  ``group_expo``: {(gj, gi): block exposure index of each of those PSFs}
     (PSFGrp.idx_grp2blk, psfutil.py:820-832: the reference keeps only exposures with pixels in the group; default
-    0..n_g-1).  Tables live in one device arena and are computed on demand: a group's self overlap (triangle order)
-    and input-output overlap, and the cross overlap of two groups (all n_g1 x n_g2 pairs, stored for the ordered key
-    g_lo < g_hi).  ``capacity`` (tables) is bounded by the 31-bit element offsets of the A builder:
-    capacity * (nsamp + 12)^2 < 2^31, i.e. 13 763 tables (17 GB) at nsamp = 383; one batch of stamps must fit, else
-    ValueError.  When a later batch does not fit next to what is resident, ``on_full`` decides: "evict" (default) drops
-    every resident set and recomputes what the batch needs -- stamps are visited group by group, so that is rare; it is
-    counted in ``evictions`` and the kernels of earlier batches, queued on the same stream, have read their tables by the
-    time the new ones are written -- or "raise" (ValueError: size the arena for the block instead)."""
+    0..n_g-1).  Table sets are computed on demand: a group's self overlap (triangle order) and input-output overlap, and
+    the cross overlap of two groups (all n_g1 x n_g2 pairs, stored for the ordered key g_lo < g_hi).
 
-    def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=1024, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict",
-                 group_count=None, bulk_provider=None, cells=False):
+    The tables live in ONE device arena of ``capacity`` tables (+ a zero table at index 0) that is handed out table by table
+    (the builders address a table by its arena index, 64-bit element offsets: the arena may be as large as memory allows --
+    a block of the reference's size, n1P = 84 with 6 exposures, works on ~12 k tables = 15 GB per batch of 252 stamps and
+    would need 390 GB for all its sets at once).  ``capacity=None``: every set of the block if that fits into a third of the
+    free device memory, else that third.  When the sets a batch needs do not fit next to the resident ones, ``on_full``
+    decides: "evict" (default) frees the LEAST RECENTLY USED sets that the batch itself does not need -- what the reference's
+    reference-counted sub-block cache does when an OutStamp is finished (psfutil.py:1868-1902) -- counted in ``evictions`` (calls
+    that had to evict) and ``evicted_tables``; the kernels of earlier batches, queued on the same stream, have read their
+    tables by the time the freed ones are rewritten.  "raise": ValueError instead.  The sets of ONE batch must fit, else
+    ValueError (``blockrun.plan_batches`` sizes a block's batches by ``demand``)."""
+
+    def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=None, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict",
+                 group_count=None, bulk_provider=None, cells=False, spec_capacity=None):
         assert on_full in ("evict", "raise")
-        self.on_full, self.evictions = on_full, 0
+        self.on_full, self.evictions, self.evicted_tables, self.computed_tables = on_full, 0, 0, 0
         self.ctx = ctx or default_context()
         dev = self.dev = torch.device(device)
         # sampled PSFs of a group: a device tensor (taken as it is), a host array (uploaded when the group is first needed: a
@@ -201,6 +213,7 @@ class BlockTables:
         # every axis in which the groups differ, and of their cross tables only that half (quarter) is computed.
         self.cells = bool(cells)
         self.psf = dict(group_psfs)
+        self._order = {k: q for q, k in enumerate(self.psf)}
         self._bulk = bulk_provider
         self._count_of = {k: (int(group_count[k]) if (v is None or callable(v)) else int(v.shape[0])) for k, v in self.psf.items()}
         self.expo = {k: (list(range(self._count_of[k])) if group_expo is None else [int(e) for e in group_expo[k]]) for k in self.psf}
@@ -214,29 +227,47 @@ class BlockTables:
         amp = None if amp_penalty is None or 0.0 in tuple(amp_penalty) else np.array(amp_penalty, dtype=np.float64)
         self._amp = amp
         ng = self.nsamp + 12
-        if capacity * ng * ng >= 2**31:
-            raise ValueError(f"capacity {capacity} x {ng}^2 table elements exceeds the 31-bit offsets of imcom_build_A (max {(2**31 - 1) // (ng * ng)})")
-        self.tables = torch.empty((capacity, ng, ng), dtype=torch.float64, device=dev)  # the arena
-        # The A builder lets samples without a stencil fetch the arena's first elements under zero weights: they must be finite
-        # whatever is (partly, with ``cells``) written there later.
+        if capacity is None:
+            third = int(torch.cuda.mem_get_info(dev)[0] // 3 // (8 * ng * ng))
+            capacity = max(min(self.block_demand(), third), 1)
+        capacity = int(capacity)
+        if capacity + 1 > (1 << 28):
+            raise ValueError(f"capacity {capacity}: the pair codes of imcom_build_A carry 28-bit table indices")
+        self.capacity = capacity
+        # the arena; table 0 stays zero: the A builder lets samples without a stencil fetch the arena's first elements under
+        # zero weights, and they must be finite whatever is (partly, with ``cells``) written elsewhere
+        self.tables = torch.empty((capacity + 1, ng, ng), dtype=torch.float64, device=dev)
         self.tables[0].zero_()
-        self.index, self.used = {}, 0
-        # forward spectra of the target PSFs and of every group in ONE arena, so that all the table sets a batch of
-        # stamps needs come out of a single call; a group's rows are filled on first use (28 MB per group at E = 6,
-        # nfft 768).  size == 0: nfft has no butterfly plan, every set goes through imcom_psf_overlap on its own.
+        self.slots = {}                                                  # resident set -> arena indices of its tables (storage order)
+        self._lru = {}                                                   # resident sets, least recently used first
+        self._free = np.arange(capacity, 0, -1, dtype=np.int32)          # stack of free arena indices (handed out 1, 2, 3, ...)
+        self._nfree = capacity
+        # Forward spectra of the target PSFs and of the groups in use, in ONE arena of rows (a row = the spectrum of one PSF,
+        # 4.7 MB at nfft 768), so that all the table sets a batch of stamps needs come out of a single call.  A group's rows are
+        # assigned and filled when it is first needed; ``spec_capacity`` rows (default: the whole block if that fits into a sixth
+        # of the free memory -- a block of the reference's size holds 1849 groups = 52 GB of spectra at 6 exposures): when they
+        # are used up, every group the current request does not need is dropped and re-sampled / re-transformed if it comes
+        # back (2 x 25 us per PSF).  size == 0: nfft has no butterfly plan, every set goes through imcom_psf_overlap on its own.
         size = int(lib.imcom_psf_spectra_size(self.nsamp, nfft))
-        self._spec_row, row = {None: 0}, O
-        for k in self.psf:
-            self._spec_row[k] = row
-            row += self._count_of[k]
-        self._spec_done = set()
-        self._spec_all = torch.empty((row, size), dtype=torch.float64, device=dev) if size else None
+        rows_all = O + sum(self._count_of.values())
+        if spec_capacity is None and size:
+            spec_capacity = max(min(rows_all, int(torch.cuda.mem_get_info(dev)[0] // 6 // (8 * size))), O + 4 * self.n_max)
+        self._spec_cap = min(rows_all, int(spec_capacity)) if size else 0
+        self._spec_row, self._spec_next, self.spectra_resets = {None: 0}, O, 0
+        self._spec_all = torch.empty((self._spec_cap, size), dtype=torch.float64, device=dev) if size else None
+        self._dev_psf = {}  # device copies of the sampled PSFs, kept only when there are no spectra to keep instead
         if size:
-            self._fill_spectra(None)
+            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            check(lib.imcom_psf_spectra(self.ctx.handle, _dp(self.pout), O, self.nsamp, self.nfft, _dp(self._spec_all[:O])))
         cc = torch.empty((O, ng, ng), dtype=torch.float64, device=dev)
         self._compute([(None, None, [(o, o) for o in range(O)])], cc)
         nc = self.nsamp // 2
         self._Cs_dev, self._Cs = cc[:, 6 + nc, 6 + nc].contiguous(), None  # read back when first asked for: no host wait here
+
+    @property
+    def used(self):
+        """Resident tables."""
+        return self.capacity - self._nfree
 
     @property
     def Cs(self):
@@ -248,85 +279,102 @@ class BlockTables:
     def C(self):
         return float(self.Cs[0])
 
-    def _psf_of(self, g):
-        if g is None:
-            return self.pout
-        p = self.psf[g]
-        if p is None:
-            self._fill_bulk([g])
-            p = self.psf[g]
-        if callable(p):
-            p = self.psf[g] = p()
-            assert tuple(p.shape) == (self._count_of[g], self.nsamp, self.nsamp), "group PSF provider returned the wrong shape"
-        if not torch.is_tensor(p) or p.device != self.dev or p.dtype != torch.float64 or not p.is_contiguous():
-            p = self.psf[g] = (p.to(self.dev, torch.float64).contiguous() if torch.is_tensor(p)
-                               else torch.as_tensor(np.ascontiguousarray(p, dtype=np.float64), device=self.dev))
-        return p
-
-    def _fill_spectra(self, g):
-        if g in self._spec_done:
-            return
-        p, r0 = self._psf_of(g), self._spec_row[g]
-        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        check(lib.imcom_psf_spectra(self.ctx.handle, _dp(p), p.shape[0], self.nsamp, self.nfft, _dp(self._spec_all[r0 : r0 + p.shape[0]])))
-        self._spec_done.add(g)
-
-    def _fill_bulk(self, gs):
-        """Sample (bulk provider) and transform the groups `gs` that are not resident yet, one call per run of neighbouring
-        spectra rows."""
-        gs = sorted((g for g in dict.fromkeys(gs) if g is not None and g not in self._spec_done and self.psf[g] is None),
-                    key=lambda g: self._spec_row[g])
-        runs = []
-        for g in gs:
-            if runs and self._spec_row[g] == self._spec_row[runs[-1][-1]] + self._count_of[runs[-1][-1]]:
-                runs[-1].append(g)
-            else:
-                runs.append([g])
-        for run in runs:
-            p = self._bulk(run)
-            cnt = [self._count_of[g] for g in run]
+    def _sampled(self, gs):
+        """Sampled PSFs of the groups `gs` on the device, [sum of their counts, nsamp, nsamp]."""
+        todo = [g for g in gs if g not in self._dev_psf]
+        got = {}
+        if todo and self._bulk is not None and all(self.psf[g] is None for g in todo):
+            p = self._bulk(todo)
+            cnt = [self._count_of[g] for g in todo]
             assert tuple(p.shape) == (sum(cnt), self.nsamp, self.nsamp) and p.dtype == torch.float64 and p.is_contiguous(), \
                 "bulk PSF provider returned the wrong shape"
+            if len(todo) == len(gs):
+                return p
             off = 0
-            for g, c in zip(run, cnt):
-                self.psf[g] = p[off : off + c]
+            for g, c in zip(todo, cnt):
+                got[g] = p[off : off + c]
                 off += c
-            if self._spec_all is not None:
-                r0 = self._spec_row[run[0]]
-                self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-                check(lib.imcom_psf_spectra(self.ctx.handle, _dp(p), p.shape[0], self.nsamp, self.nfft, _dp(self._spec_all[r0 : r0 + p.shape[0]])))
-                self._spec_done.update(run)
+        for g in todo:
+            if g in got:
+                continue
+            p = self.psf[g]
+            if callable(p):
+                p = p()
+                assert tuple(p.shape) == (self._count_of[g], self.nsamp, self.nsamp), "group PSF provider returned the wrong shape"
+            got[g] = (p.to(self.dev, torch.float64).contiguous() if torch.is_tensor(p)
+                      else torch.as_tensor(np.ascontiguousarray(p, dtype=np.float64), device=self.dev))
+        parts = [self._dev_psf[g] if g in self._dev_psf else got[g] for g in gs]
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+    def _psf_of(self, g):
+        """Device tensor of a group's sampled PSFs, cached (the path without spectra)."""
+        if g is None:
+            return self.pout
+        if g not in self._dev_psf:
+            self._dev_psf[g] = self._sampled([g])
+        return self._dev_psf[g]
+
+    def _ensure_spectra(self, gs):
+        """Sample / upload and transform the groups of `gs` whose spectra are not resident, in one call."""
+        gs = [g for g in dict.fromkeys(gs) if g is not None]
+        miss = [g for g in gs if g not in self._spec_row]
+        if not miss:
+            return
+        if self._spec_next + sum(self._count_of[g] for g in miss) > self._spec_cap:
+            # out of rows: drop every group this request does not need (earlier requests' table kernels are queued ahead of the
+            # refill on the same stream)
+            self._spec_row, self._spec_next = {None: 0}, self.n_out
+            self.spectra_resets += 1
+            miss = gs
+            if self._spec_next + sum(self._count_of[g] for g in miss) > self._spec_cap:
+                raise ValueError(f"spectra arena of {self._spec_cap} rows cannot hold the PSF groups of one batch")
+        miss.sort(key=self._order.__getitem__)
+        p = self._sampled(miss)
+        r0 = self._spec_next
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        check(lib.imcom_psf_spectra(self.ctx.handle, _dp(p), p.shape[0], self.nsamp, self.nfft, _dp(self._spec_all[r0 : r0 + p.shape[0]])))
+        for g in miss:
+            self._spec_row[g] = self._spec_next
+            self._spec_next += self._count_of[g]
 
     def prefetch(self, groups):
-        """Queue the sampling / spectra of `groups` now (bulk provider only; otherwise groups are materialised on first use)."""
-        if self._bulk is not None:
-            self._fill_bulk(sorted(g for g in groups if g in self.psf))
+        """Queue the sampling / spectra of `groups` now (as far as the spectra arena holds them; otherwise groups are
+        materialised when first needed)."""
+        if self._spec_all is None:
+            return
+        gs, rows = [], self._spec_next
+        for g in sorted((g for g in groups if g in self.psf and g not in self._spec_row), key=self._order.__getitem__):
+            rows += self._count_of[g]
+            if rows > self._spec_cap:
+                break
+            gs.append(g)
+        self._ensure_spectra(gs)
 
-    def _compute(self, jobs, out):
-        """jobs: list of (g1, g2, local pairs) whose tables fill `out` back to back (g = None: the target PSFs)."""
-        if self._bulk is not None:
-            self._fill_bulk([g for g1, g2, _ in jobs for g in (g1, g2)])
+    def _compute(self, jobs, out, slots=None):
+        """jobs: list of (g1, g2, local pairs) (g = None: the target PSFs).  Their tables fill `out` back to back, or -- with
+        ``slots`` (int32, one arena index per table) -- the arena tables ``out[slots]``."""
         if self._spec_all is None:
             off = 0
             for g1, g2, pairs in jobs:
-                overlap_tables(self.ctx, self._psf_of(g1), None, self._psf_of(g2), None, self.nsamp, self.nfft, pairs, self._amp,
-                               out[off : off + len(pairs)])
+                dst = out[off : off + len(pairs)] if slots is None else torch.empty((len(pairs),) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+                overlap_tables(self.ctx, self._psf_of(g1), None, self._psf_of(g2), None, self.nsamp, self.nfft, pairs, self._amp, dst)
+                if slots is not None:
+                    out.index_copy_(0, h2d(slots[off : off + len(pairs)], out.device, np.int64), dst)
                 off += len(pairs)
             return
         allp, allw = [], []
         ns, nc, margin = self.nsamp, self.nsamp // 2, 8  # ten-tap stencils reach 4 below / 5 above the cell of a separation
         rng = {-1: (0, min(ns, nc + margin)), 0: (0, ns), 1: (max(0, nc - margin), ns)}
         sgn = lambda a, b: (a > b) - (a < b)  # noqa: E731
+        self._ensure_spectra([g for g1, g2, _ in jobs for g in (g1, g2)])
         for g1, g2, pairs in jobs:
-            self._fill_spectra(g1)
-            self._fill_spectra(g2)
             allp.append(np.asarray(pairs, dtype=np.int64).reshape(-1, 2) + (self._spec_row[g1], self._spec_row[g2]))
             if self.cells:
                 # tables are read at r(g1) - r(g2) (A builder: the group that sorts first on the left; input-output and self: any sign)
                 sy, sx = (0, 0) if g1 is None or g2 is None or g1 == g2 else (sgn(g1[0], g2[0]), sgn(g1[1], g2[1]))
                 allw.append(np.broadcast_to(np.array(rng[sy] + rng[sx], dtype=np.int32), (len(pairs), 4)))
         overlap_tables(self.ctx, None, self._spec_all, None, self._spec_all, self.nsamp, self.nfft, np.concatenate(allp), self._amp, out,
-                       win=np.concatenate(allw) if self.cells else None)
+                       win=np.concatenate(allw) if self.cells else None, slots=slots)
 
     def _n(self, g):
         return self._count_of[g]
@@ -354,34 +402,73 @@ class BlockTables:
             return self.n_out * self._n(key[1])
         return self._n(key[1]) * self._n(key[2])
 
+    def demand(self, keys):
+        """Tables the sets `keys` take together (what one batch of stamps needs resident at once)."""
+        return sum(self._count(k) for k in dict.fromkeys(keys))
+
+    def block_demand(self):
+        """Tables of every set of the block: self and input-output of every group, cross of every pair of neighbouring groups."""
+        gs = set(self.psf)
+        keys = [("self", g) for g in gs] + [("io", g) for g in gs]
+        keys += [("cross", g, h) for g in gs for h in ((g[0], g[1] + 1), (g[0] + 1, g[1] - 1), (g[0] + 1, g[1]), (g[0] + 1, g[1] + 1)) if h in gs]
+        return self.demand(keys)
+
+    def _release(self, key):
+        sl = self.slots.pop(key)
+        del self._lru[key]
+        self._free[self._nfree : self._nfree + len(sl)] = sl[::-1]
+        self._nfree += len(sl)
+        return len(sl)
+
+    def drop_all(self):
+        """Forget every resident set (the arena keeps its memory)."""
+        for k in list(self.slots):
+            self._release(k)
+
     def require(self, keys):
-        """Make sure the table sets `keys` are in the arena; returns {key: first table index}."""
+        """Make sure the table sets `keys` are in the arena; returns {key: arena indices of its tables, storage order}."""
         keys = list(dict.fromkeys(keys))
-        need = sum(self._count(k) for k in keys if k not in self.index)
-        if self.used + need > self.tables.shape[0]:
-            total = sum(self._count(k) for k in keys)
-            if total > self.tables.shape[0]:
-                raise ValueError(f"table arena of {self.tables.shape[0]} tables cannot hold the {total} of one batch")
-            if self.on_full == "raise":
-                raise ValueError(f"table arena full: {self.used} of {self.tables.shape[0]} tables resident, {need} more needed (on_full='raise')")
-            self.index, self.used = {}, 0
-            self.evictions += 1
-            need = total
-        jobs, first = [], self.used
+        missing = [k for k in keys if k not in self.slots]
+        need = sum(self._count(k) for k in missing)
         for k in keys:
-            if k in self.index:
-                continue
-            if k[0] == "self":
-                jobs.append((k[1], k[1], self._local_pairs("self", self._n(k[1]), 0)))
-            elif k[0] == "io":
-                jobs.append((k[1], None, self._local_pairs("io", self._n(k[1]), self.n_out)))
-            else:
-                jobs.append((k[1], k[2], self._local_pairs("cross", self._n(k[1]), self._n(k[2]))))
-            self.index[k] = self.used
-            self.used += self._count(k)
-        if jobs:
-            self._compute(jobs, self.tables[first : self.used])
-        return {k: self.index[k] for k in keys}
+            if k in self._lru:  # most recently used last
+                self._lru[k] = self._lru.pop(k)
+        if need > self._nfree:
+            total = self.demand(keys)
+            if total > self.capacity:
+                raise ValueError(f"table arena of {self.capacity} tables cannot hold the {total} of one batch")
+            if self.on_full == "raise":
+                raise ValueError(f"table arena full: {self.used} of {self.capacity} tables resident, {need} more needed (on_full='raise')")
+            wanted = set(keys)
+            for k in [k for k in self._lru if k not in wanted]:  # least recently used first
+                self.evicted_tables += self._release(k)
+                if need <= self._nfree:
+                    break
+            self.evictions += 1
+        if missing:
+            jobs = []
+            first = self._nfree - need
+            sl_all = self._free[first : self._nfree][::-1].copy()  # lowest stack entries last: indices come out in hand-out order
+            self._nfree = first
+            off = 0
+            for k in missing:
+                if k[0] == "self":
+                    jobs.append((k[1], k[1], self._local_pairs("self", self._n(k[1]), 0)))
+                elif k[0] == "io":
+                    jobs.append((k[1], None, self._local_pairs("io", self._n(k[1]), self.n_out)))
+                else:
+                    jobs.append((k[1], k[2], self._local_pairs("cross", self._n(k[1]), self._n(k[2]))))
+                c = self._count(k)
+                self.slots[k] = sl_all[off : off + c]
+                self._lru[k] = None
+                off += c
+            self._compute(jobs, self.tables, slots=sl_all)
+            self.computed_tables += need
+        return {k: self.slots[k] for k in keys}
+
+    def tables_of(self, key):
+        """The tables of a resident set as one tensor [count, ng, ng] (a copy, gathered from the arena)."""
+        return self.tables.index_select(0, h2d(self.slots[key], self.dev, np.int64))
 
     @staticmethod
     def keys_for(groups):
@@ -404,19 +491,18 @@ class BlockTables:
             na = self._n(ga)
             ea = np.asarray(self.expo[ga])
             lut[la, ea] = base[la] + np.arange(na)
-            for o in range(self.n_out):
-                io[o, base[la] : base[la] + na] = self.index[("io", ga)] + o * na + np.arange(na)
+            io[:, base[la] : base[la] + na] = self.slots[("io", ga)].reshape(self.n_out, na)
             for lb, gb in enumerate(groups):
                 nb = self._n(gb)
                 ka, kb = _index_grid(na, nb)
                 if ga == gb:  # triangle storage of the group's self overlap (psfutil.py:1175); (j, i) with j > i flipped
                     lo, hi = np.minimum(ka, kb), np.maximum(ka, kb)
-                    blk = self.index[("self", ga)] + (2 * na - lo + 1) * lo // 2 + hi - lo
+                    blk = self.slots[("self", ga)][(2 * na - lo + 1) * lo // 2 + hi - lo]
                     blk = np.where(ka <= kb, blk, blk | PAIR_FLIP)
                 elif ga < gb:
-                    blk = self.index[("cross", ga, gb)] + ka * nb + kb
+                    blk = self.slots[("cross", ga, gb)][ka * nb + kb]
                 else:  # evaluated from the other group's side (psfutil.py:1990-1996)
-                    blk = (self.index[("cross", gb, ga)] + kb * na + ka) | PAIR_SWAP
+                    blk = self.slots[("cross", gb, ga)][kb * na + ka] | PAIR_SWAP
                 tab[base[la] : base[la] + na, base[lb] : base[lb] + nb] = blk
                 if flat_penalty != 0.0:  # psfutil.py:1433, 1482-1486, 1705-1708
                     same = ea[:, None] == np.asarray(self.expo[gb])[None, :]

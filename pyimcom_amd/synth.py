@@ -236,30 +236,36 @@ def algorithmic_flops(cfg, n, nv=None):
     return out
 
 
-def make_instamps(cfg, n1P, n_expo, rng):
+def make_instamps(cfg, n1P, n_expo, rng, depth=None):
     """InStamps of the (n1P+2)^2 cells (coadd.py:207, 329-358): per exposure a rotated lattice of native pixels binned
-    by cell, exposure-major inside a cell, random data."""
+    by cell, exposure-major inside a cell, random data.  ``depth`` [nst, nst] int (optional): only the first depth[j, i]
+    exposures cover cell (j, i) (a mosaic whose exposure depth varies, BASELINE configs[3])."""
     nst, n2, p = n1P + 2, cfg.n2, NATIVE_ARCSEC / cfg.dtheta_as
     lo, hi = -n2 - 0.5, (n1P + 1) * n2 - 0.5
-    cells = [[[] for _ in range(nst)] for _ in range(nst)]
+    c0 = 0.5 * (lo + hi)
+    K = int(np.ceil((hi - lo) / np.sqrt(2.0) / p)) + 2  # the lattice covers the block at any rotation
+    xs, ys, cell, cnt = [], [], [], np.zeros((n_expo, nst * nst), np.int64)
     for e in range(n_expo):
         th = np.deg2rad(11.0 * e + 3.0)
-        g = np.arange(-nst * n2, 2 * nst * n2) * p
+        g = np.arange(-K, K + 1) * p
         xx, yy = np.meshgrid(g + rng.uniform(0, p), g + rng.uniform(0, p))
-        x = (np.cos(th) * xx - np.sin(th) * yy).ravel()
-        y = (np.sin(th) * xx + np.cos(th) * yy).ravel()
+        x = (c0 + np.cos(th) * xx - np.sin(th) * yy).ravel()
+        y = (c0 + np.sin(th) * xx + np.cos(th) * yy).ravel()
         ok = (x > lo) & (x < hi) & (y > lo) & (y < hi) & (rng.uniform(size=x.size) > 0.01)
         x, y = x[ok], y[ok]
-        ci, cj = ((x - lo) // n2).astype(int), ((y - lo) // n2).astype(int)
-        for j in range(nst):
-            for i in range(nst):
-                m = (ci == i) & (cj == j)
-                cells[j][i].append((x[m], y[m]))
+        c = ((y - lo) // n2).astype(np.int64) * nst + ((x - lo) // n2).astype(np.int64)
+        if depth is not None:
+            keep = e < np.asarray(depth).reshape(-1)[c]
+            x, y, c = x[keep], y[keep], c[keep]
+        order = np.argsort(c, kind="stable")  # lattice order inside a cell
+        xs.append(x[order]); ys.append(y[order]); cell.append(c[order])
+        cnt[e] = np.bincount(c, minlength=nst * nst)
+    # cell-major, exposure-major inside a cell
+    start = np.concatenate([np.zeros((n_expo, 1), np.int64), np.cumsum(cnt, axis=1)], axis=1)
     out = []
-    for j in range(nst):
-        for i in range(nst):
-            parts = cells[j][i]
-            cum = np.concatenate([[0], np.cumsum([len(q[0]) for q in parts])])
-            xs, ys = np.hstack([q[0] for q in parts]), np.hstack([q[1] for q in parts])
-            out.append((xs, ys, rng.standard_normal((cfg.n_inframe, xs.size)).astype(np.float32), cum))
+    for k in range(nst * nst):
+        px = np.concatenate([xs[e][start[e, k] : start[e, k + 1]] for e in range(n_expo)])
+        py = np.concatenate([ys[e][start[e, k] : start[e, k + 1]] for e in range(n_expo)])
+        cum = np.concatenate([[0], np.cumsum(cnt[:, k])])
+        out.append((px, py, rng.standard_normal((cfg.n_inframe, px.size)).astype(np.float32), cum))
     return out

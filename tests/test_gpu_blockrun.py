@@ -226,8 +226,10 @@ def test_full_chain_vs_reference_golden(golden, name):
 
 
 def test_block_tables_eviction_policy():
-    """The table arena says what it does when full: 'evict' drops the resident sets, recomputes and counts it; 'raise' refuses;
-    a request that can never fit raises under both."""
+    """The table arena says what it does when full: 'evict' frees the least recently used sets the request itself does not
+    need, recomputes on demand and counts it; 'raise' refuses; a request that can never fit raises under both."""
+    import torch
+
     from pyimcom_amd import synth
     from pyimcom_amd.stamps import BlockTables
 
@@ -235,23 +237,56 @@ def test_block_tables_eviction_policy():
     psfs, target = synth.make_psfs(cfg, 3)
     groups = {(0, 0): psfs, (0, 1): psfs * 1.0, (1, 0): psfs[:2]}
     a, b = BlockTables.keys_for([(0, 0), (0, 1)]), BlockTables.keys_for([(1, 0)])
+    same = lambda x, y: x.keys() == y.keys() and all(np.array_equal(x[k], y[k]) for k in x)  # noqa: E731
     for policy in ("evict", "raise"):
         t = BlockTables(groups, target, cfg.nfft, capacity=27, on_full=policy)  # the sets of `a` need 6 + 6 + 3 + 3 + 9 = 27 tables
-        first = t.require(a)
-        assert t.used == 27 and t.evictions == 0 and t.require(a) == first
+        first = {k: v.copy() for k, v in t.require(a).items()}
+        assert t.used == 27 and t.evictions == 0 and same(t.require(a), first)
+        assert sorted(np.concatenate(list(first.values())).tolist()) == list(range(1, 28))  # table 0 is the arena's zero table
+        keep = {k: t.tables_of(k).clone() for k in a}
         if policy == "evict":
-            got = t.require(b)  # 3 + 2 tables: no room next to the 27 resident ones
-            assert t.evictions == 1 and t.used == 5 and sorted(got.values()) == [0, 3]
+            got = t.require(b)  # 3 + 2 tables: the least recently used set of `a` (self overlap of (0, 0), 6 tables) makes room
+            assert t.evictions == 1 and t.evicted_tables == 6 and t.used == 26 and ("self", (0, 0)) not in t.slots
+            assert sorted(np.concatenate(list(got.values())).tolist()) == sorted(first[("self", (0, 0))].tolist())[:5]
             ref = BlockTables(groups, target, cfg.nfft, capacity=64)
-            idx = ref.require(b)
+            ref.require(b)
             for k in b:  # recomputed tables are the same tables
-                n = t._count(k)
-                assert np.array_equal(t.tables[got[k] : got[k] + n].cpu().numpy(), ref.tables[idx[k] : idx[k] + n].cpu().numpy())
+                assert torch.equal(t.tables_of(k), ref.tables_of(k))
+            for k in a[1:]:  # the sets that stayed are untouched
+                assert torch.equal(t.tables_of(k), keep[k])
+            t.require(a)  # one free table + the five of `b` (not wanted now): room for the six that come back
+            assert t.evictions == 2 and t.evicted_tables == 11 and t.used == 27 and not any(k in t.slots for k in b)
+            for k in a:
+                assert torch.equal(t.tables_of(k), keep[k])
         else:
             with pytest.raises(ValueError, match="arena full"):
                 t.require(b)
         with pytest.raises(ValueError, match="cannot hold"):
             BlockTables(groups, target, cfg.nfft, capacity=20, on_full=policy).require(a)
+
+
+def test_block_tables_spectra_arena_reset():
+    """The spectra of the PSF groups live in an arena of their own: when its rows are used up, the groups the current request
+    does not need are dropped and come back (re-uploaded / re-sampled, re-transformed) when asked for again -- same tables."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import BlockTables
+
+    cfg = synth.CONFIGS["tiny"]
+    psfs, target = synth.make_psfs(cfg, 3)
+    groups = {(0, q): psfs * (1.0 + 0.1 * q) for q in range(4)}
+    ref = BlockTables(groups, target, cfg.nfft, capacity=200)
+    t = BlockTables(groups, target, cfg.nfft, capacity=200, spec_capacity=1 + 2 * 3)  # the target's row + two groups
+    for pair in (((0, 0), (0, 1)), ((0, 2), (0, 3)), ((0, 1), (0, 2)), ((0, 0), (0, 1))):
+        keys = BlockTables.keys_for(pair)
+        t.require(keys)
+        ref.require(keys)
+        for k in keys:
+            assert torch.equal(t.tables_of(k), ref.tables_of(k)), k
+    assert t.spectra_resets == 3 and ref.spectra_resets == 0
+    with pytest.raises(ValueError, match="spectra arena"):
+        t.require(BlockTables.keys_for([(0, 0), (0, 1), (0, 2)]))
 
 
 @pytest.mark.gpu
@@ -270,6 +305,7 @@ def test_block_tables_group_sources_agree():
     keys = BlockTables.keys_for([(0, 0), (0, 1)])
     ref = BlockTables(host, target, cfg.nfft, capacity=64)
     want = ref.require(keys)
+    same = lambda x, y: x.keys() == y.keys() and all(np.array_equal(x[k], y[k]) for k in x)  # noqa: E731
     dev = {k: torch.as_tensor(v, device="cuda:0") for k, v in host.items()}
     called = []
 
@@ -282,7 +318,7 @@ def test_block_tables_group_sources_agree():
     for groups, count in ((dev, None), ({k: provider(k) for k in host}, {k: v.shape[0] for k, v in host.items()})):
         t = BlockTables(groups, target, cfg.nfft, capacity=64, group_count=count)
         got = t.require(keys)
-        assert got == want and torch.equal(t.tables[: t.used], ref.tables[: ref.used])
+        assert same(got, want) and torch.equal(t.tables[1 : t.used + 1], ref.tables[1 : ref.used + 1])
     assert sorted(called) == [(0, 0), (0, 1)]
     # a bulk provider serves runs of neighbouring groups in one call each (and only the groups somebody asked for)
     runs = []
@@ -293,7 +329,7 @@ def test_block_tables_group_sources_agree():
 
     t = BlockTables({k: None for k in host}, target, cfg.nfft, capacity=64, group_count={k: v.shape[0] for k, v in host.items()},
                     bulk_provider=bulk)
-    assert t.require(keys) == want and torch.equal(t.tables[: t.used], ref.tables[: ref.used])
+    assert same(t.require(keys), want) and torch.equal(t.tables[1 : t.used + 1], ref.tables[1 : ref.used + 1])
     assert runs == [[(0, 0), (0, 1)]]
     t.require(BlockTables.keys_for([(1, 1)]))
     assert runs == [[(0, 0), (0, 1)], [(1, 1)]]

@@ -169,15 +169,19 @@ def test_empty_stamp_in_resident_batch():
 
 def test_alternative_code_paths_in_subprocess():
     """The switches kept for A/B runs and as cross-checks must not rot: the unfused diagonal-block launches
-    (IMCOM_SOLVE_UNFUSED), the dense-DFT table path (IMCOM_PSF_OVERLAP=gemm), the Jacobi eigensolver (IMCOM_EIGH=jacobi) and the
-    experimental LDS-window A builder (IMCOM_BUILD_A=window)
+    (IMCOM_SOLVE_UNFUSED), the dense-DFT table path (IMCOM_PSF_OVERLAP=gemm) and -- in the developer build of the library
+    (make DEV=1 -> libimcom_hip_dev.so, selected by IMCOM_HIP_LIB; built by __graft_entry__.build()) -- the Jacobi eigensolver
+    (IMCOM_EIGH=jacobi) and the experimental LDS-window A builder (IMCOM_BUILD_A=window)
     are read once per process, so the parity check runs in a child process with all of them set."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, IMCOM_SOLVE_UNFUSED="1", IMCOM_PSF_OVERLAP="gemm", IMCOM_EIGH="jacobi", IMCOM_BUILD_A="window", PYTHONPATH=root)
+    env = dict(os.environ, IMCOM_SOLVE_UNFUSED="1", IMCOM_PSF_OVERLAP="gemm", PYTHONPATH=root)
+    dev_lib = os.path.join(root, "pyimcom_amd", "lib", "libimcom_hip_dev.so")
+    if os.path.exists(dev_lib):
+        env.update(IMCOM_HIP_LIB=dev_lib, IMCOM_EIGH="jacobi", IMCOM_BUILD_A="window")
     code = ("import dataclasses; from pyimcom_amd import synth; from tests import parity as smoke; "
             "smoke.check_batch(synth.CONFIGS['small'], 2); "
             "smoke.check_batch(dataclasses.replace(synth.CONFIGS['tiny'], kernel='Eigen'), 2); print('alt paths ok')")

@@ -103,3 +103,62 @@ def test_partition_golden(golden):
     got = orc.partition_pixels(ox, oy, in_x, in_y, mask, g["use_instamps"], int(g["n2"]), int(g["n1P"]), int(g["npixmax"]))
     for a, name in zip(got, ("y_idx", "x_idx", "y_val", "x_val", "pix_count")):
         assert a.dtype == g[name].dtype and np.array_equal(a, g[name]), name
+
+
+class _ArenaStandIn:
+    """What blockrun.plan_batches reads from a BlockTables: group sizes and the arena's capacity (no GPU needed)."""
+
+    def __init__(self, n, capacity, n_out=1):
+        self.n_max, self.n_out, self.capacity = n, n_out, capacity
+
+    def demand(self, keys):
+        n, o = self.n_max, self.n_out
+        return sum(n * (n + 1) // 2 if k[0] == "self" else o * n if k[0] == "io" else n * n for k in dict.fromkeys(keys))
+
+
+def test_plan_batches_tiles_cover_the_block_and_fit_the_arena():
+    """The batches of a block with a PSF group per 2 x 2 InStamps (SysMatA.ji_st2psf, psfutil.py:1803-1824) are tiles of
+    2 x 2-stamp cells: every stamp exactly once, no batch above the stamp limit, no batch whose table sets exceed the arena --
+    at the reference's production geometries (n1P = 84 / 52: configs/paper4_configs/H158_Chol_benchmark.json:28-34,
+    paper3_configs/H158_Chol_config.json:27-33) and exposure depths 6 - 10, where a row-by-row walk of 256 stamps needs more
+    tables than a 2-D tile (the advisor's case: n1P = 16 with 8 and 10 PSFs per group against an arena of 13 500)."""
+    from pyimcom_amd.blockrun import chunk_keys, plan_batches
+
+    for n1P, n, capacity, cap in ((16, 6, 13500, 256), (16, 8, 13500, 256), (16, 10, 13500, 256), (48, 8, 30000, 256), (48, 10, 40000, 256),
+                                  (84, 6, 13500, 256), (84, 10, 40000, 256), (52, 6, 6000, 256), (7, 6, 100000, 256), (84, 6, 10**6, 100)):
+        nst = n1P + 2
+        arena = _ArenaStandIn(n, capacity)
+        todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+        chunks = plan_batches(todo, nst, cap, arena)
+        assert sorted(t for c in chunks for t in c) == todo, (n1P, n)
+        assert max(len(c) for c in chunks) <= cap
+        dem = [arena.demand(chunk_keys(c, nst)) for c in chunks]
+        assert max(dem) <= capacity, (n1P, n, max(dem))
+        # the four stamps of a cell stay in one batch (they share their pair maps) unless a cell alone had to be split
+        if min(len(c) for c in chunks) >= 4 and n1P % 2 == 0:
+            where = {t: q for q, c in enumerate(chunks) for t in c}
+            assert all(len({where[(j + dj, i + di)] for dj in (0, 1) for di in (0, 1)}) == 1 for j in range(1, n1P, 2) for i in range(1, n1P, 2))
+        if n1P == 84 and n == 6 and capacity == 13500:
+            rounds = sum(-(-len(c) * 18 // 512) for c in chunks)
+            assert rounds <= 1.02 * -(-n1P * n1P * 18 // 512)  # whole rounds of workgroups: within 2 % of the block's minimum
+            rows = [arena.demand(chunk_keys(todo[c0 : c0 + 256], nst)) for c0 in range(0, len(todo), 256)]  # a row-by-row walk of the block
+            assert sum(dem) < 0.75 * sum(rows) and max(rows) > capacity
+    # an arbitrary subset (the reference's stoptile-style partial runs) and the single-group case
+    sub = [(j, i) for j in range(3, 30, 2) for i in range(5, 60, 3)]
+    chunks = plan_batches(sub, 86, 64, _ArenaStandIn(6, 5000))
+    assert sorted(t for c in chunks for t in c) == sorted(sub) and max(len(c) for c in chunks) <= 64
+    assert plan_batches(sub, 86, 100, None) == [sub[c0 : c0 + 100] for c0 in range(0, len(sub), 100)]
+    assert plan_batches([], 86, 100, None) == []
+
+
+def test_choose_batch_is_kernel_aware_and_never_zero():
+    from pyimcom_amd.blockrun import choose_batch, stamp_bytes
+
+    assert choose_batch(0, 2304, 2304) == 1  # an empty block must not produce a zero step (coadd_block returns before using it)
+    free = 100 << 30
+    chol = choose_batch(2304, 2304, 2304, 1, free)
+    assert chol == 256
+    it = choose_batch(2304, 2304, 2304, 1, free, kernel="Iterative")
+    assert it < chol and it * stamp_bytes(2304, 2304, 1, "Iterative") <= 0.8 * free  # ~0.4 GB of patch matrices per stamp
+    eig = choose_batch(2304, 2944, 2304, 1, free, kernel="Eigen")
+    assert eig * stamp_bytes(2944, 2304, 1, "Eigen") <= 0.8 * free

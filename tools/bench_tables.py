@@ -29,7 +29,7 @@ bt.require([("cross", (0, 0), (0, 1))])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
-    bt.index, bt.used = {}, 0
+    bt.drop_all()
     bt.require([("cross", (0, 0), (0, 1))])
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
