@@ -15,7 +15,7 @@ import numpy as np
 
 from .block import BlockMaps
 from .select import select_pixels
-from .stamps import NB, BlockTables, StampBatch, h2d
+from .stamps import NB, BlockTables, StampBatch, free_device_bytes, h2d
 
 
 def stamp_neighbours(j_st, i_st, n2, nst):
@@ -248,15 +248,18 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     if not todo:
         return []
     grouped = isinstance(tables, BlockTables)
-    counts = np.diff(pool.inst_off).reshape(nst, nst)
-    win = sum(counts[dj : dj + n1P, di : di + n1P] for dj in range(3) for di in range(3))  # pixels of the nine neighbours of every stamp
-    cap_pix = int(max(win[j - 1, i - 1] for j, i in todo))
+    # Pixels a stamp will select (coadd.py:886-977), estimated from its nine InStamps' counts: the centre cell whole, of the four
+    # edge cells the strip within rho (a fraction rho / n2 of their area), of the corner cells a quarter disc; + 10 %.  The
+    # batches are sized with it -- the buffers themselves are sized by the counts the selection kernel returns (prepare_batch).
+    counts = np.diff(pool.inst_off).reshape(nst, nst).astype(np.float64)
+    fe = min(1.0, cfg.rho / cfg.n2)
+    frac = {0: 1.0, 1: fe, 2: min(1.0, np.pi / 4.0 * fe * fe)}
+    win = sum(frac[(dj != 1) + (di != 1)] * counts[dj : dj + n1P, di : di + n1P] for dj in range(3) for di in range(3))
+    cap_pix = int(1.1 * max(win[j - 1, i - 1] for j, i in todo)) + 64
     ldn_max = ldn or max(NB, (cap_pix + NB - 1) // NB * NB)
     ldm = (cfg.m + NB - 1) // NB * NB
     if batch is None:
-        import torch
-
-        free = torch.cuda.mem_get_info(pool.device)[0]
+        free = free_device_bytes(pool.device)
         n_out = int(getattr(tables, "n_out", 1))
         if grouped:  # tiles of 2 x 2-stamp cells, sized by memory and by the table arena (plan_batches)
             cap = max(1, min(256, int(0.8 * free) // stamp_bytes(ldn_max, ldm, n_out, cfg.kernel)))

@@ -39,6 +39,13 @@ def h2d(a, dev, dtype=None):
     return t.pin_memory().to(dev, non_blocking=True)
 
 
+def free_device_bytes(dev):
+    """Device memory a new allocation can draw on: what the driver reports free plus what torch's caching allocator holds
+    without using it (mem_get_info alone shrinks with every buffer torch has cached, e.g. after an earlier block)."""
+    free = torch.cuda.mem_get_info(dev)[0]
+    return int(free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
+
+
 def _index_grid(na, nb):
     if (na, nb) not in _GRIDS:
         _GRIDS[(na, nb)] = tuple(np.ascontiguousarray(a) for a in np.meshgrid(np.arange(na), np.arange(nb), indexing="ij"))
@@ -228,7 +235,7 @@ class BlockTables:
         self._amp = amp
         ng = self.nsamp + 12
         if capacity is None:
-            third = int(torch.cuda.mem_get_info(dev)[0] // 3 // (8 * ng * ng))
+            third = int(free_device_bytes(dev) // 3 // (8 * ng * ng))
             capacity = max(min(self.block_demand(), third), 1)
         capacity = int(capacity)
         if capacity + 1 > (1 << 28):
@@ -251,7 +258,7 @@ class BlockTables:
         size = int(lib.imcom_psf_spectra_size(self.nsamp, nfft))
         rows_all = O + sum(self._count_of.values())
         if spec_capacity is None and size:
-            spec_capacity = max(min(rows_all, int(torch.cuda.mem_get_info(dev)[0] // 6 // (8 * size))), O + 4 * self.n_max)
+            spec_capacity = max(min(rows_all, int(free_device_bytes(dev) // 6 // (8 * size))), O + 4 * self.n_max)
         self._spec_cap = min(rows_all, int(spec_capacity)) if size else 0
         self._spec_row, self._spec_next, self.spectra_resets = {None: 0}, O, 0
         self._spec_all = torch.empty((self._spec_cap, size), dtype=torch.float64, device=dev) if size else None

