@@ -107,75 +107,87 @@ def pmc_traffic(batch, cfg_name):
     return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
 
 
-def block_leg(ctx, dev, n1P=16, batch=256, reps=2):
-    """The same path one level up, as a block of the reference runs it (coadd.py:2003-2084): cfg-2 geometry, a block of
-    n1P x n1P output stamps whose PSFs change from one 2 x 2 group of InStamps to the next (SysMatA.ji_st2psf,
-    psfutil.py:1803-1824), and everything the headline loop leaves out inside the timed region: PSF spectra and overlap
-    tables per group (self / cross / input-output sets), pixel selection from the InStamp pool, per-stamp pair maps,
-    A, B, Cholesky, coaddition, block-map accumulation and boundary recovery -- starting from the PSF images: their sampling
-    onto the PSFGrp grid runs inside the timed region too.  Only the upload of the InStamp pool, of the PSF images and of their
-    sampling positions is outside."""
+def block_workload(dev, n1P, identical=False, seed=5):
+    """Synthetic block at cfg-2 geometry for the block leg (and for tests/test_gpu_bigblock.py's check of it): the InStamp
+    pool of (n1P + 2)^2 InStamps, and per 2 x 2 group of InStamps PSF images [E, ns + 16, ns + 16] (a smooth modulation of the
+    analytic PSFs, zero padded; ``identical``: the same images for every group) with their sampling positions yxco [E, 2, ns, ns]
+    (a small rotation per exposure, psfutil.py:751-771; none with ``identical``), all resident on the device."""
     import numpy as np
     import torch
 
     from pyimcom_amd import synth
-    from pyimcom_amd.blockrun import coadd_block
     from pyimcom_amd.select import InStampPool
-    from pyimcom_amd.stamps import BlockTables
 
     cfg = synth.CONFIGS["cfg2"]
     E = cfg.n_expo
-    inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng(5))
+    inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng(seed))
     pool = InStampPool(inst, cfg.n_inframe, device=dev)
     psfs, target = synth.make_psfs(cfg, E)
-    nst = n1P + 2
-    ng = (nst + 1) // 2
-    # Every group has PSFs of its own.  As for the input pixels (InStampPool above), what is resident before the clock starts
-    # is the data and the geometry: per group the PSF images [E, ns + 16, ns + 16] (a smooth modulation of the analytic PSFs,
-    # zero padded) and their sampling positions yxco [E, 2, ns, ns] (a small rotation per exposure, psfutil.py:751-771).  The
-    # sampling itself (PSFGrp._sample_psf + normalisation, psfutil.py:709-795, 650-656: imcom_sample_psf) runs inside the timed
-    # region, when a group is first needed.
-    from pyimcom_amd import psfs as psfmod
-
+    ng = (n1P + 3) // 2
     ns = psfs.shape[-1]
-    lin = np.arange(ns) - ns // 2
+    lin = torch.arange(ns, dtype=torch.float64, device=dev) - ns // 2
     base = torch.as_tensor(psfs, device=dev)
     lt = torch.arange(ns, dtype=torch.float64, device=dev) - (ns - 1) / 2.0
     yo, xo = torch.meshgrid(lt, lt, indexing="ij")
-    groups, counts, imgs, yxcos = {}, {}, [], []
+    img_all = torch.zeros((ng * ng, E, ns + 16, ns + 16), dtype=torch.float64, device=dev)
+    yxco_all = torch.empty((ng * ng, E, 2, ns, ns), dtype=torch.float64, device=dev)
+    groups, counts = {}, {}
     for gj in range(ng):
         for gi in range(ng):
-            mod = 1.0 + 0.02 * np.sin(0.05 * lin * (1 + gi % 3))[None, None, :] + 0.02 * np.cos(0.04 * lin * (1 + gj % 3))[None, :, None]
-            img = torch.zeros((E, ns + 16, ns + 16), dtype=torch.float64, device=dev)
-            img[:, 8 : 8 + ns, 8 : 8 + ns] = base * torch.as_tensor(mod, device=dev)
-            th = torch.as_tensor([0.004 * (e - E / 2) + 0.002 * (gi - gj) for e in range(E)], dtype=torch.float64, device=dev)
+            q = gj * ng + gi
+            if identical:
+                mod = torch.ones((1, 1, 1), dtype=torch.float64, device=dev)
+                th = torch.zeros(E, dtype=torch.float64, device=dev)
+            else:
+                mod = 1.0 + 0.02 * torch.sin(0.05 * lin * (1 + gi % 3))[None, None, :] + 0.02 * torch.cos(0.04 * lin * (1 + gj % 3))[None, :, None]
+                th = torch.as_tensor([0.004 * (e - E / 2) + 0.002 * ((gi - gj) % 7 - 3) for e in range(E)], dtype=torch.float64, device=dev)
+            img_all[q, :, 8 : 8 + ns, 8 : 8 + ns] = base * mod
             c, sn = torch.cos(th)[:, None, None], torch.sin(th)[:, None, None]
-            imgs.append(img)
-            yxcos.append(torch.stack([c * yo + sn * xo, -sn * yo + c * xo], dim=1))
-            groups[(gj, gi)] = None  # sampled by the bulk provider below
+            yxco_all[q] = torch.stack([c * yo + sn * xo, -sn * yo + c * xo], dim=1)
+            groups[(gj, gi)] = None  # sampled by the bulk provider
             counts[(gj, gi)] = E
-    img_all, yxco_all = torch.stack(imgs), torch.stack(yxcos).contiguous()  # [groups, E, ...]
-    del imgs, yxcos
+    return cfg, inst, pool, psfs, target, groups, counts, img_all, yxco_all
+
+
+def block_leg(ctx, dev, n1P=48, reps=1):
+    """The same path one level up, as a block of the reference runs it (coadd.py:2003-2084): cfg-2 geometry, ONE block of
+    n1P x n1P = 48 x 48 output stamps ("one block = 48 x 48 stamps") whose PSFs change from one 2 x 2 group of
+    InStamps to the next (SysMatA.ji_st2psf, psfutil.py:1803-1824: 625 groups, ~100 k overlap tables), and everything the
+    headline loop leaves out inside the timed region: the batch plan (2-D tiles of cells against the table arena), PSF sampling
+    onto the PSFGrp grid (PSFGrp._sample_psf + normalisation, psfutil.py:709-795, 650-656), spectra and overlap tables per group
+    (self / cross / input-output sets, least recently used sets replaced), pixel selection from the InStamp pool, per-stamp pair
+    maps, A, B, Cholesky, coaddition, block-map accumulation and boundary recovery.  Outside: the upload of the InStamp pool, of
+    the PSF images and of their sampling positions, and the allocation of the two arenas (tables, spectra), which a block
+    driver keeps from block to block (BlockTables.reset)."""
+    import torch
+
+    from pyimcom_amd import psfs as psfmod
+    from pyimcom_amd.blockrun import coadd_block, plan_block
+    from pyimcom_amd.stamps import BlockTables
+
+    cfg, inst, pool, psfs, target, groups, counts, img_all, yxco_all = block_workload(dev, n1P)
+    E, ns = cfg.n_expo, psfs.shape[-1]
     order = {k: q for q, k in enumerate(groups)}
 
     def sample_groups(keys):
-        # the groups a batch of stamps needs for the first time, sampled in one call (BlockTables hands over runs of neighbours)
+        # the groups a batch of stamps needs for the first time, sampled in one call
         q0, q1 = order[keys[0]], order[keys[-1]] + 1
         if [order[k] for k in keys] == list(range(q0, q1)):
             im, yx = img_all[q0:q1], yxco_all[q0:q1]
         else:
-            idx = torch.as_tensor([order[k] for k in keys], device=dev)
+            idx = torch.tensor([order[k] for k in keys]).pin_memory().to(dev, non_blocking=True)
             im, yx = img_all[idx], yxco_all[idx]
         return psfmod.sample_psf(im.reshape(-1, ns + 16, ns + 16), ns, yx.reshape(-1, 2, ns, ns), psf_norm=True, ctx=ctx)
 
     fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize", "epilogue", "block_acc")
+    tabs = BlockTables(groups, target, cfg.nfft, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True)
 
     def one():
-        # table construction (PSF sampling, spectra, overlap tables) is part of the block
-        tabs = BlockTables(groups, target, cfg.nfft, capacity=13500, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True)
-        return coadd_block(cfg, pool, tabs, n1P, E, batch=batch)
+        tabs.reset()  # table construction (PSF sampling, spectra, overlap tables) is part of the block
+        return coadd_block(cfg, pool, tabs, n1P, E)
 
-    one()
+    # warm-up on a corner of the block (kernels loaded, workspaces grown), then the timed block(s)
+    coadd_block(cfg, pool, tabs, n1P, E, stamps=[(j, i) for j in range(1, 17) for i in range(1, 17)])
     torch.cuda.synchronize()
     ctx.profile_enable(True)
     ctx.profile_reset()
@@ -186,11 +198,14 @@ def block_leg(ctx, dev, n1P=16, batch=256, reps=2):
     dt = (time.perf_counter() - t0) / reps
     stages = {f: ctx.profile_get(f)[0] / reps for f in fams}
     ctx.profile_enable(False)
+    chunks = plan_block(cfg, pool, tabs, n1P)
     return {
-        "value": n1P * n1P / dt, "unit": "postage-stamps/s", "ms_per_block": dt * 1e3, "stamps_per_block": n1P * n1P, "psf_groups": ng * ng,
-        "batch": batch, "input_pixels": int(pool.npool),
-        "workload": f"cfg2 geometry, block of {n1P}x{n1P} output stamps, PSF group per 2x2 InStamps; tables + selection + pair maps + A, B, Cholesky, "
-                    "coaddition + block maps inside the timed region",
+        "value": n1P * n1P / dt, "unit": "postage-stamps/s", "ms_per_block": dt * 1e3, "stamps_per_block": n1P * n1P, "psf_groups": len(groups),
+        "batches": [len(c) for c in chunks], "input_pixels": int(pool.npool),
+        "tables": {"computed": int(tabs.computed_tables), "block_total": int(tabs.block_demand()), "arena": int(tabs.capacity),
+                   "evicted": int(tabs.evicted_tables), "spectra_resets": int(tabs.spectra_resets)},
+        "workload": f"cfg2 geometry, block of {n1P}x{n1P} output stamps, PSF group per 2x2 InStamps; batch plan + PSF sampling + tables + selection + "
+                    "pair maps + A, B, Cholesky, coaddition + block maps inside the timed region",
         "stage_ms_per_block": stages, "host_and_gaps_ms_per_block": dt * 1e3 - sum(stages.values()),
         "out_map_rms": float(maps.out_map.square().mean().sqrt()),
     }

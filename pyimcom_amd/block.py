@@ -48,8 +48,8 @@ class BlockMaps:
 
         results = list(res) if isinstance(res, (list, tuple)) else [res]
         assert len(results) == self.n_out
-        jj = torch.as_tensor(jst.astype(np.int64) - 1, device=self.T_weightmap.device)
-        ii = torch.as_tensor(ist.astype(np.int64) - 1, device=self.T_weightmap.device)
+        up = lambda a: torch.from_numpy(a).pin_memory().to(self.T_weightmap.device, non_blocking=True)  # noqa: E731  (no stream drain)
+        jj, ii = up(jst.astype(np.int64) - 1), up(ist.astype(np.int64) - 1)
         for o, r in enumerate(results):
             acc(r.outimage, self.n_inframe, self.out_map[o])
             acc(r.UC, 1, self.maps["UC"][o])

@@ -15,7 +15,7 @@ import numpy as np
 
 from .block import BlockMaps
 from .select import select_pixels
-from .stamps import NB, BlockTables, StampBatch, free_device_bytes, h2d
+from .stamps import NB, BatchBuffers, BlockTables, StampBatch, free_device_bytes, h2d
 
 
 def stamp_neighbours(j_st, i_st, n2, nst):
@@ -48,7 +48,7 @@ def _neighbours_of(chunk, n2, nst):
     return [(ids[q], pvx[q], pvy[q]) for q in range(len(ji))]
 
 
-def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
+def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None, buffers=None):
     """Selection, table sets, pair maps and the StampBatch of one chunk of output stamps [(j_st, i_st), ...] of a block
     (everything up to StampBatch.build()); ``pool`` / ``tables`` as for coadd_block."""
     nst = n1P + 2
@@ -70,8 +70,16 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
         per = [memo[t] if (t := tuple(gs)) in memo else memo.setdefault(t, tables.stamp_maps(gs, cfg.flat_penalty)) for gs in local]
         maps_ = tuple(np.stack([p[q] for p in per]) for q in range(3))
         lg = np.array([[gs.index(g) if g is not None else 0 for g in row] for row, gs in zip(grp, local)], dtype=np.int64)
-    x, y, indata, expo, cumsum = select_pixels(pool, ids, np.stack([t[1] for t in nb]), np.stack([t[2] for t in nb]), cfg.rho, ld,
-                                               ctx=tables.ctx)
+    # The selection runs on a side stream with a context of its own: the host has to wait for its pixel counts, and on the
+    # main stream that wait would last until the previous batch's builders (queued just before this call) have finished.
+    import torch
+
+    main = torch.cuda.current_stream(pool.device)
+    side, side_ctx = _side_stream(pool.device)
+    with torch.cuda.stream(side):
+        x, y, indata, expo, cumsum = select_pixels(pool, ids, np.stack([t[1] for t in nb]), np.stack([t[2] for t in nb]), cfg.rho, ld, ctx=side_ctx)
+    for t_ in (x, y, indata, expo):  # produced (and complete: the call returns after its status read-back) on the side stream, used on the main one
+        t_.record_stream(main)
     n = cumsum[:, 9]
     keep = (n.max() + NB - 1) // NB * NB if n.max() > 0 else NB  # trim the padding to what the batch needs
     nblk = (n.astype(np.int64) + NB - 1) // NB
@@ -100,14 +108,51 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None):
         lgp = h2d(lg, x.device).gather(1, seg)  # group position of every pixel
         flat = lut.reshape(len(chunk), -1).gather(1, lgp * lut.shape[2] + expo[:, :keep].long())
         valid = torch.arange(keep, device=x.device)[None, :] < h2d(n, x.device, np.int64)[:, None]
-        if bool(((flat < 0) & valid).any()):
-            raise ValueError("a pixel belongs to an exposure its PSF group holds no PSF for (BlockTables.group_expo)")
+        bad = ((flat < 0) & valid).any()  # read by StampBatch.check() once the batch has been solved: no host wait here
         psf_slot = flat.clamp_(min=0).to(torch.int32)
     sb = StampBatch.from_device(cfg, tables, n, x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep],
                                 [(i - 1) * cfg.n2 - cfg.fade for _, i in chunk], [(j - 1) * cfg.n2 - cfg.fade for j, _ in chunk],
-                                n_expo, ctx=tables.ctx, psf_slot=psf_slot, maps=maps_)
+                                n_expo, ctx=tables.ctx, psf_slot=psf_slot, maps=maps_, buffers=buffers)
     sb.chunk = chunk  # the batch's stamps in the order of its rows (a ragged batch is reordered above)
+    sb.bad_psf = bad if grouped else None
     return sb
+
+
+_SIDE, _BUFS = {}, {}
+
+
+def _batch_buffers(device):
+    import torch
+
+    key = torch.device(device).index or 0
+    if key not in _BUFS:
+        _BUFS[key] = (BatchBuffers(device), BatchBuffers(device))
+    return _BUFS[key]
+
+
+def release_buffers():
+    """Give the per-batch arrays kept between blocks back to torch's allocator."""
+    _BUFS.clear()
+
+
+def _side_stream(device):
+    """A second stream with a library context of its own (workspace, pinned ring) per device, for work the host waits on."""
+    import torch
+
+    from ._lib import Context
+
+    dev = torch.device(device)
+    key = dev.index or 0
+    if key not in _SIDE:
+        _SIDE[key] = (torch.cuda.Stream(dev), Context(key))
+    return _SIDE[key]
+
+
+def check_batch(sb):
+    """Raise if a pixel of the batch belongs to an exposure its PSF group holds no PSF for (call after the solve: the flag
+    is read back from the device)."""
+    if getattr(sb, "bad_psf", None) is not None and bool(sb.bad_psf):
+        raise ValueError("a pixel belongs to an exposure its PSF group holds no PSF for (BlockTables.group_expo)")
 
 
 
@@ -239,6 +284,18 @@ def plan_batches(todo, nst, cap, tables=None, tiles_per_stamp=18, stamp_cost=0.6
     return out
 
 
+def estimate_pixels(cfg, pool, n1P):
+    """Pixels every stamp of a block will select (coadd.py:886-977), [n1P, n1P] float, estimated from its nine InStamps' counts:
+    the centre cell whole, of the four edge cells the strip within rho (a fraction rho / n2 of their area), of the corner cells
+    a quarter disc.  Batches are sized with it (+ 10 %); the leading dimension a batch really gets comes from the counts the
+    selection kernel returns (prepare_batch)."""
+    nst = n1P + 2
+    counts = np.diff(pool.inst_off).reshape(nst, nst).astype(np.float64)
+    fe = min(1.0, cfg.rho / cfg.n2)
+    frac = {0: 1.0, 1: fe, 2: min(1.0, np.pi / 4.0 * fe * fe)}
+    return sum(frac[(dj != 1) + (di != 1)] * counts[dj : dj + n1P, di : di + n1P] for dj in range(3) for di in range(3))
+
+
 def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     """The batches coadd_block runs: list of lists of (j_st, i_st).  ``batch=None``: sized from the block's largest stamp, the
     free device memory and -- with a BlockTables -- the table arena (``choose_batch`` / ``plan_batches``); an explicit ``batch``
@@ -248,13 +305,7 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     if not todo:
         return []
     grouped = isinstance(tables, BlockTables)
-    # Pixels a stamp will select (coadd.py:886-977), estimated from its nine InStamps' counts: the centre cell whole, of the four
-    # edge cells the strip within rho (a fraction rho / n2 of their area), of the corner cells a quarter disc; + 10 %.  The
-    # batches are sized with it -- the buffers themselves are sized by the counts the selection kernel returns (prepare_batch).
-    counts = np.diff(pool.inst_off).reshape(nst, nst).astype(np.float64)
-    fe = min(1.0, cfg.rho / cfg.n2)
-    frac = {0: 1.0, 1: fe, 2: min(1.0, np.pi / 4.0 * fe * fe)}
-    win = sum(frac[(dj != 1) + (di != 1)] * counts[dj : dj + n1P, di : di + n1P] for dj in range(3) for di in range(3))
+    win = estimate_pixels(cfg, pool, n1P)
     cap_pix = int(1.1 * max(win[j - 1, i - 1] for j, i in todo)) + 64
     ldn_max = ldn or max(NB, (cap_pix + NB - 1) // NB * NB)
     ldm = (cfg.m + NB - 1) // NB * NB
@@ -304,21 +355,37 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     if isinstance(tables, BlockTables) and chunks:
         # the PSF groups of the first batches are sampled / transformed before the host turns to the per-stamp bookkeeping
         tables.prefetch(dict.fromkeys(g for c in chunks[:2] for t in c for g in stamp_groups(t[0], t[1], nst)))
-    prepare = lambda chunk: prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn)  # noqa: E731
+    # two sets of the large per-batch arrays, used alternately (batch k + 1 is prepared while batch k is solved) and kept from
+    # block to block
+    bufs = _batch_buffers(pool.device)
+    if chunks and ldn is None:
+        # sized once for the block's largest batch (estimated, as the plan's): a buffer that has to grow in the middle of the
+        # block costs a device allocation of ~10 GB, 0.1 s with the GPU idle
+        win = estimate_pixels(cfg, pool, n1P)
+        ld_pre = (int(1.05 * max(win[j - 1, i - 1] for c in chunks for j, i in c)) + 32 + NB - 1) // NB * NB
+        bmax, ldm, O = max(len(c) for c in chunks), (cfg.m + NB - 1) // NB * NB, int(getattr(tables, "n_out", 1))
+        import torch
+
+        for b_ in bufs:
+            b_.take("A", (bmax, ld_pre, ld_pre), torch.float64)
+            b_.take("Bt", (O, bmax, ld_pre, ldm), torch.float64)
+            b_.take("Tt", (O, bmax, ld_pre, ldm), torch.float32)
+    prepare = lambda q: prepare_batch(cfg, pool, tables, chunks[q], n1P, n_expo, ldn, buffers=bufs[q & 1])  # noqa: E731
 
     # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after
     # the current one's A and B builds have been queued, i.e. while the GPU is busy with them; only then does the host
     # block in the solve's status read-back
-    nxt = prepare(chunks[0]) if chunks else None
-    for k, chunk in enumerate(chunks):
+    nxt = prepare(0) if chunks else None
+    for k in range(len(chunks)):
         sb = nxt
         sb.build()
         if pipeline:
-            nxt = prepare(chunks[k + 1]) if k + 1 < len(chunks) else None
+            nxt = prepare(k + 1) if k + 1 < len(chunks) else None
         sb.solve()
+        check_batch(sb)
         sb.coadd()
         if not pipeline:
-            nxt = prepare(chunks[k + 1]) if k + 1 < len(chunks) else None
+            nxt = prepare(k + 1) if k + 1 < len(chunks) else None
         maps.add(sb.results(), [j for j, _ in sb.chunk], [i for _, i in sb.chunk])
     if pad_sides is not None:
         maps.finalize(pad_sides, postage_pad)

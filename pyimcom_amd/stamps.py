@@ -432,6 +432,15 @@ class BlockTables:
         for k in list(self.slots):
             self._release(k)
 
+    def reset(self):
+        """Forget every table set, every group's spectra and cached samples: the next block (or the next repetition of a
+        timing loop) computes everything again in the memory this object already holds."""
+        self.drop_all()
+        self._free[:] = np.arange(self.capacity, 0, -1, dtype=np.int32)
+        self._spec_row, self._spec_next = {None: 0}, self.n_out
+        self._dev_psf = {}
+        self.evictions = self.evicted_tables = self.computed_tables = self.spectra_resets = 0
+
     def require(self, keys):
         """Make sure the table sets `keys` are in the arena; returns {key: arena indices of its tables, storage order}."""
         keys = list(dict.fromkeys(keys))
@@ -517,6 +526,24 @@ class BlockTables:
         return tab, pen, (io[0] if self.n_out == 1 else io), lut
 
 
+class BatchBuffers:
+    """Device memory for the large per-batch arrays (A, -B/2, T: 27 GB for 256 cfg-2 stamps), kept from one batch of a
+    block to the next: a block's batches differ in their leading dimension, so torch's caching allocator would satisfy none of
+    them from the previous batch's blocks (measured: 100 ms of hipMalloc per batch).  ``take`` returns a view of the named
+    flat buffer, which grows when a batch needs more than any before it."""
+
+    def __init__(self, device):
+        self.dev, self._flat = torch.device(device), {}
+
+    def take(self, name, shape, dtype):
+        n = int(np.prod(shape))
+        f = self._flat.get(name)
+        if f is None or f.dtype != dtype or f.numel() < n:
+            self._flat[name] = None  # drop the old block before the larger one is requested
+            f = self._flat[name] = torch.empty(n, dtype=dtype, device=self.dev)
+        return f[:n].view(*shape)
+
+
 @dataclass
 class StampBatchResult:
     """Outputs of a batch for ONE target PSF (StampBatch.results() lists them for n_out > 1)."""
@@ -562,21 +589,22 @@ class StampBatch:
                     np.array([s.out_x0 for s in stamps], dtype=np.float64), np.array([s.out_y0 for s in stamps], dtype=np.float64))
 
     @classmethod
-    def from_device(cls, cfg, tables, n, x, y, expo, indata, out_x0, out_y0, n_expo, ctx=None, psf_slot=None, maps=None):
+    def from_device(cls, cfg, tables, n, x, y, expo, indata, out_x0, out_y0, n_expo, ctx=None, psf_slot=None, maps=None, buffers=None):
         """Batch whose pixel lists are already on the GPU (e.g. from pyimcom_amd.select.select_pixels): x, y f64 and
         expo i32 [B, ldn], indata f32 [B, n_inframe, ldn] with ldn a multiple of 128 and zero padding; n, out_x0,
         out_y0 host arrays [B].  Stamps whose pixels belong to several PSF groups pass ``psf_slot`` (i32 [B, ldn],
         stamp-local PSF index of each pixel) and ``maps`` = (pair_tab [B,P,P] i32, pair_pen [B,P,P] f64, io_tab [B,P] i32)
-        as documented at imcom_build_A / imcom_build_B; ``tables`` then only needs .tables, .nsamp, .C, .ctx."""
+        as documented at imcom_build_A / imcom_build_B; ``tables`` then only needs .tables, .nsamp, .C, .ctx.  ``buffers``: a
+        BatchBuffers the large arrays are taken from (they are then valid until its next use)."""
         self = cls.__new__(cls)
         ldn = x.shape[1]
         assert ldn % NB == 0 and tuple(indata.shape) == (x.shape[0], cfg.n_inframe, ldn)
         self._setup(cfg, tables, ctx, x.device, np.ascontiguousarray(n, dtype=np.int32), ldn, int(n_expo), x.contiguous(), y.contiguous(),
                     expo.contiguous(), indata.contiguous(), np.ascontiguousarray(out_x0, dtype=np.float64),
-                    np.ascontiguousarray(out_y0, dtype=np.float64), psf_slot=psf_slot, maps=maps)
+                    np.ascontiguousarray(out_y0, dtype=np.float64), psf_slot=psf_slot, maps=maps, buffers=buffers)
         return self
 
-    def _setup(self, cfg, tables, ctx, dev, n, ldn, n_expo, x, y, expo, indata, out_x0, out_y0, psf_slot=None, maps=None):
+    def _setup(self, cfg, tables, ctx, dev, n, ldn, n_expo, x, y, expo, indata, out_x0, out_y0, psf_slot=None, maps=None, buffers=None):
         self.cfg, self.tables = cfg, tables
         self.ctx = ctx or tables.ctx
         self.dev = dev
@@ -616,9 +644,10 @@ class StampBatch:
         self.Cs_o = np.ascontiguousarray(np.broadcast_to(Cs[:, None], (O, B)))
         self.kappaC = np.ascontiguousarray(cfg.kappaC, dtype=np.float64)
         # device buffers
-        self.A = torch.empty((B, self.ldn, self.ldn), dtype=f64, device=dev)
-        self.Bt_o = torch.empty((O, B, self.ldn, self.ldm), dtype=f64, device=dev)
-        self.Tt_o = torch.empty((O, B, self.ldn, self.ldm), dtype=f32, device=dev)
+        big = buffers.take if buffers is not None else (lambda name, shape, dtype: torch.empty(shape, dtype=dtype, device=dev))
+        self.A = big("A", (B, self.ldn, self.ldn), f64)
+        self.Bt_o = big("Bt", (O, B, self.ldn, self.ldm), f64)
+        self.Tt_o = big("Tt", (O, B, self.ldn, self.ldm), f32)
         self.UC_o = torch.empty((O, B, self.m), dtype=f32, device=dev)
         self.Sigma_o = torch.empty((O, B, self.m), dtype=f32, device=dev)
         self.kappa_o = torch.empty((O, B, self.m), dtype=f32, device=dev)
