@@ -46,6 +46,8 @@ def check_supported(cfg):
     kernel = getattr(cfg, "linear_algebra", "Cholesky")
     if kernel not in ("Cholesky", "Eigen", "Iterative", "Empirical"):
         raise ImcomError(IMCOM_ERR_UNSUPPORTED, f"LAKERNEL = {kernel!r}")
+    if int(getattr(cfg, "n1P", 0)) % 2:  # the reference asserts n1 % 2 == 0 (config.py:503): the PSF groups are pairs of InStamp rows / columns
+        raise ImcomError(IMCOM_ERR_UNSUPPORTED, f"n1P = {cfg.n1P} is odd: PSF groups are 2 x 2 InStamps (psfutil.py:1803-1824)")
     if kernel == "Empirical" and getattr(cfg, "no_qlt_ctrl", False):
         raise ImcomError(IMCOM_ERR_UNSUPPORTED, "Empirical kernel without quality control on the block seam "
                          "(use the kernel-class seam, pyimcom_amd.lakernel.HipEmpirKernel)")
@@ -60,9 +62,13 @@ def stamp_config(cfg, psfgrp, n_inimage, flat_penalty, name="block"):
                           sigmamax=float(cfg.sigmamax), flat_penalty=float(flat_penalty), n_inframe=int(cfg.n_inframe), n_out=targets)
 
 
-def input_psf_groups(blk, psfgrp, device):
-    """PSFGrp._build_inpsfgrp for every 2x2 group of InStamps (psfutil.py:797-851): the exposures with pixels in the group,
-    their PSF images at the group's computation point (host: file broker, WCS), sampled on the device."""
+def input_psf_groups(blk, psfgrp, device, ctx=None):
+    """PSFGrp._build_inpsfgrp for the 2x2 groups of InStamps (psfutil.py:797-851), on demand: returns (count, expo, provider)
+    with count[(gj, gi)] = number of exposures with pixels in the group, expo[(gj, gi)] = their block indices, and
+    ``provider(keys)`` -> device tensor [sum of the keys' counts, nsamp, nsamp] of sampled PSFs: the host fetches the groups'
+    PSF images at their computation points and evaluates the sampling positions (file broker, WCS: InImage.get_psf_pos,
+    outpix2world2inpix), uploads both, and the sampling + cut-out + normalisation (psfutil.py:709-795, 650-656) run on the
+    device in one call.  Nothing is read back; a group is fetched when a batch of stamps first needs it (BlockTables)."""
     import torch
 
     from . import psfs
@@ -72,7 +78,7 @@ def input_psf_groups(blk, psfgrp, device):
     lin = np.arange(ns) - (ns - 1) / 2.0
     gx, gy = np.meshgrid(lin, lin)
     xy = np.stack([gx.ravel(), gy.ravel()], axis=1) * float(psfgrp.dscale)  # psfutil.py:751-771
-    group_psfs, group_expo = {}, {}
+    count, expo = {}, {}
     for gj in range(nst // 2):
         for gi in range(nst // 2):
             used = np.zeros(int(blk.n_inimage), bool)
@@ -82,21 +88,33 @@ def input_psf_groups(blk, psfgrp, device):
                     cnt = getattr(st, "pix_count", None)
                     used |= (np.diff(st.pix_cumsum) if cnt is None else np.asarray(cnt)).astype(bool)
             expos = [int(e) for e in np.flatnonzero(used)]
-            if not expos:
-                continue
+            if expos:
+                count[(gj, gi)], expo[(gj, gi)] = len(expos), expos
+    circ, norm = bool(blk.cfg.psf_circ), bool(blk.cfg.psf_norm)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).pin_memory().to(device, non_blocking=True)  # noqa: E731
+
+    def provider(keys):
+        imgs, yxco = [], []
+        for gj, gi in keys:
             p0 = np.array(blk.instamps[2 * gj][2 * gi].psf_compute_point_pix, dtype=np.float64)
             world = blk.outwcs.all_pix2world(np.array([p0]), 0)[0]
-            imgs, yxco = [], []
-            for e in expos:
+            for e in expo[(gj, gi)]:
                 im = blk.inimages[e]
                 imgs.append(np.asarray(im.get_psf_pos(world, use_shortrange=True), dtype=np.float64))
                 d = (np.asarray(im.outpix2world2inpix(xy + p0)) - np.asarray(im.outpix2world2inpix(p0[None]))) * float(psfgrp.oversamp)
                 yxco.append(np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)]))
-            group_psfs[(gj, gi)] = psfs.sample_psf(torch.as_tensor(np.stack(imgs), device=device), ns,
-                                                   torch.as_tensor(np.stack(yxco), device=device), bool(blk.cfg.psf_circ),
-                                                   bool(blk.cfg.psf_norm)).cpu().numpy()
-            group_expo[(gj, gi)] = expos
-    return group_psfs, group_expo
+        out = torch.empty((len(imgs), ns, ns), dtype=torch.float64, device=device)
+        shapes = {}
+        for q, im in enumerate(imgs):  # PSF images of one size are sampled together (normally all of them)
+            shapes.setdefault(im.shape, []).append(q)
+        for idx in shapes.values():
+            got = psfs.sample_psf(up(np.stack([imgs[q] for q in idx])), ns, up(np.stack([yxco[q] for q in idx])), circ, norm, ctx)
+            if len(shapes) == 1:
+                return got
+            out[torch.as_tensor(idx, device=device)] = got
+        return out
+
+    return count, expo, provider
 
 
 def target_psfs(cfg, psfgrp, device):
@@ -114,7 +132,9 @@ def target_psfs(cfg, psfgrp, device):
 def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None):
     """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  ``stamps``: optional list of
     (j_st, i_st) to coadd instead of all n1P x n1P (the reference's ``stoptile`` debugging aid stops early in the same
-    way); ``finalize=False`` skips the boundary recovery of coadd.py:2163-2181.  Returns the ``BlockMaps``."""
+    way); ``finalize=False`` skips the boundary recovery of coadd.py:2163-2181.  ``batch``: stamps per pass (default: sized
+    from the device memory and the table arena, blockrun.plan_block); ``table_capacity``: overlap tables kept resident
+    (default: the whole block's, or a third of the free device memory).  Returns the ``BlockMaps``."""
     from .blockrun import coadd_block
     from .select import InStampPool
     from .stamps import BlockTables
@@ -128,15 +148,12 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
         if hasattr(cfg, k):
             setattr(scfg, k, getattr(cfg, k))
     pool = InStampPool([(st.x_val, st.y_val, st.data, st.pix_cumsum) for row in blk.instamps for st in row], scfg.n_inframe, device=device)
-    group_psfs, group_expo = input_psf_groups(blk, psfgrp, device)
-    target = target_psfs(cfg, psfgrp, device).cpu().numpy()
+    count, expo, provider = input_psf_groups(blk, psfgrp, device)
+    target = target_psfs(cfg, psfgrp, device)
     amp = getattr(cfg, "amp_penalty", None)
     amp = None if amp is None or 0.0 in tuple(amp) else (float(amp[0]), float(amp[1]) * float(psfgrp.oversamp))  # psfutil.py:661-671
-    n_max = max(v.shape[0] for v in group_psfs.values())
-    if table_capacity is None:  # the sets one batch of stamps can touch, with room to keep neighbouring groups resident
-        per_group = n_max * (n_max + 1) // 2 + target.shape[0] * n_max + 4 * n_max * n_max
-        table_capacity = min(max(4 * per_group * max(1, (batch or 256) // 4), 256), (2**31 - 1) // ((int(psfgrp.nsamp) + 12) ** 2))
-    tables = BlockTables(group_psfs, target, int(psfgrp.nfft), group_expo=group_expo, capacity=int(table_capacity), amp_penalty=amp, device=device,
+    tables = BlockTables({k: None for k in count}, target, int(psfgrp.nfft), group_expo=expo, group_count=count, bulk_provider=provider,
+                         capacity=None if table_capacity is None else int(table_capacity), amp_penalty=amp, device=device,
                          cells=True)  # groups of 2 x 2 InStamps: cells of the block's grid (coadd.py:207, 329-358)
     maps = coadd_block(scfg, pool, tables, int(cfg.n1P), int(blk.n_inimage), batch=batch, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
                        postage_pad=int(getattr(cfg, "postage_pad", 0)), stamps=stamps)

@@ -229,7 +229,8 @@ class BlockTables:
         self.n_max = max(self._count_of.values())
         self.n_psf = self.n_max
         self.n_blk_expo = 1 + max(max(v) for v in self.expo.values())
-        self.pout = torch.as_tensor(np.ascontiguousarray(psf_out, dtype=np.float64), device=dev)
+        self.pout = (psf_out.to(dev, torch.float64).contiguous() if torch.is_tensor(psf_out)
+                     else torch.as_tensor(np.ascontiguousarray(psf_out, dtype=np.float64), device=dev))
         O = self.n_out = self.pout.shape[0]
         amp = None if amp_penalty is None or 0.0 in tuple(amp_penalty) else np.array(amp_penalty, dtype=np.float64)
         self._amp = amp
