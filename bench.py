@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (spec); 77.2 measured with tools/mfma_f64_bench
+CONFIG_INDEX = {"cfg1": 0, "cfg2": 1, "cfg2f": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}  # BASELINE.json configs[] of each workload
 
 
 def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
@@ -65,6 +66,13 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
         return done, dt, {k: v / done * 1e3 for k, v in stages.items()}
 
     cores = os.cpu_count()
+    blas = "default"
+    try:  # threads the BLAS / LAPACK behind numpy and scipy will use (threadpoolctl reads the loaded libraries)
+        from threadpoolctl import threadpool_info
+
+        blas = ", ".join(f"{p_.get('internal_api', p_.get('user_api'))} {p_.get('num_threads')} threads" for p_ in threadpool_info() if p_.get("user_api") == "blas") or "default"
+    except Exception:  # pragma: no cover
+        pass
     # the C interpolators are called once per exposure pair (~80k samples): more than ~32 OpenMP threads only add
     # start-up and spinning next to the BLAS threads (measured: 256 threads 5.7 s per stamp, 1 thread 0.3 s)
     omp = min(cores, 32)
@@ -81,7 +89,8 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
         "cores": cores,
         "kind": "port",
         "sample": f"{done} whole {cfg.name} stamps (N~{stamps[0].n}, m={cfg.m}) through oracle/ on {cores} cores ({dt:.1f} s): C interpolators "
-                  f"with {omp} OpenMP threads, scipy potrf/potrs with the BLAS default; then {done1} stamps on 1 thread ({dt1:.1f} s)",
+                  f"with {omp} OpenMP threads, scipy potrf/potrs on {blas}; then {done1} stamps on 1 thread ({dt1:.1f} s)",
+        "blas": blas,
         "stage_ms_per_stamp": stages,
     }
     if done1:
@@ -93,15 +102,18 @@ def pmc_traffic(batch, cfg_name):
     """HBM bytes per launch of the solve kernels from the newest committed rocprofv3 --pmc passes (separate FETCH_SIZE /
     WRITE_SIZE runs of this very command, corrected as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_traffic.py).
     Counters cannot be read from inside the process: the figure is reported with the file it came from, and only when
-    that measurement was taken on the same workload and batch; otherwise null."""
+    that measurement was taken on the same workload and batch AND on the same kernel sources (the file carries the SHA-256
+    of csrc/ at measurement time); otherwise null."""
     import glob
 
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None, None
     doc = json.load(open(files[-1]))
-    if doc.get("batch") != batch or doc.get("workload") != cfg_name:
-        return None, None
+    from pyimcom_amd._lib import source_sha16
+
+    if doc.get("batch") != batch or doc.get("workload") != cfg_name or doc.get("csrc_sha16") != source_sha16():
+        return None, None  # another workload, or counters taken on other kernel sources than the ones this run was built from
     ks = [doc["kernels"][k] for k in ("solve_fwd_kernel", "solve_bwd_kernel") if k in doc["kernels"]]
     n = sum(k["launches"] for k in ks)
     return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
@@ -209,6 +221,71 @@ def block_leg(ctx, dev, n1P=48, reps=1):
         "stage_ms_per_block": stages, "host_and_gaps_ms_per_block": dt * 1e3 - sum(stages.values()),
         "out_map_rms": float(maps.out_map.square().mean().sqrt()),
     }
+
+
+def seam_legs(ctx, dev, cfg, batch):
+    """The two seams a pyimcom user reaches the library through, timed the way they are used (never the headline):
+    ``kernel_seam`` -- the drop-in LA kernel class (OutStamp.LAKERNEL, coadd.py:839-844, 1091-1093): ONE stamp per call, A and -B/2
+    handed over as host arrays (100 MB over PCIe), T and the maps returned as host arrays; ``block_seam`` -- the reference's
+    Block containers through ``refblock.coadd_output_stamps`` (coadd.py:2003-2084): a duck-typed 16 x 16-stamp block at cfg-2
+    geometry, PSF images fetched per 2 x 2 group and exposure from the host-side objects (get_psf_pos, outpix2world2inpix on
+    nsamp^2 positions each: the host share is the reference's own WCS / file-broker work, here an affine map), block maps
+    returned as host arrays."""
+    import numpy as np
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.lakernel import HipCholKernel
+    from pyimcom_amd.refblock import coadd_output_stamps
+
+    out = {}
+    # kernel-class seam on the first stamp of the headline batch
+    n, m = int(batch.n[0]), cfg.m
+    A = batch.A[0, :n, :n].cpu().numpy().copy()
+    mB = np.ascontiguousarray(batch.Bt[0, :n, :m].cpu().numpy().T)[None]
+
+    class O:
+        pass
+
+    def outst():
+        o, o.blk = O(), O()
+        o.blk.cfg = O()
+        c = o.blk.cfg
+        c.n_out, c.n2f, c.kappaC_arr, c.uctarget, c.sigmamax = 1, cfg.n2f, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax
+        o.sysmata, o.mhalfb, o.outovlc, o.inpix_cumsum = A, mB, np.array([batch.tables.C]), np.array([n])
+        return o
+
+    best = None
+    for _ in range(4):
+        o = outst()
+        t0 = time.perf_counter()
+        HipCholKernel(o, ctx=ctx)()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["kernel_seam"] = {"ms_per_stamp": best * 1e3, "value": 1.0 / best, "unit": "postage-stamps/s", "N": n, "m": m,
+                          "what": "HipCholKernel(outst)() on host arrays, one stamp per call, PCIe-inclusive (best of 4)"}
+    # Block seam
+    n1P = 16
+    blk, psfgrp, _, _ = synth.duck_block(cfg, n1P, cfg.n_expo if isinstance(cfg.n_expo, int) else cfg.n_expo[1], seed=5)
+    fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize", "epilogue", "block_acc")
+    dctx = ctx
+    coadd_output_stamps(blk, psfgrp, device=dev, ctx=ctx)
+    torch.cuda.synchronize()
+    dctx.profile_enable(True)
+    dctx.profile_reset()
+    t0 = time.perf_counter()
+    maps = coadd_output_stamps(blk, psfgrp, device=dev, ctx=ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gpu_ms = sum(dctx.profile_get(f)[0] for f in fams)
+    dctx.profile_enable(False)
+    out["block_seam"] = {"value": n1P * n1P / dt, "unit": "postage-stamps/s", "ms_per_block": dt * 1e3, "stamps_per_block": n1P * n1P,
+                         "gpu_ms_per_block": gpu_ms, "host_share": 1.0 - gpu_ms * 1e-3 / dt,
+                         "what": "refblock.coadd_output_stamps(blk, PSFGrp) on a duck-typed 16x16-stamp Block (cfg-2 geometry, 81 PSF groups): pool upload, "
+                                 "PSF images + sampling positions per group from host objects, everything else on the device, maps back to host",
+                         "out_map_rms": float(np.sqrt(np.mean(np.square(blk.out_map))))}
+    del maps
+    return out
 
 
 def main():
@@ -320,8 +397,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1] ({cfg.name}): one batch of {args.batch} 48x48-output stamps per GPU per step, "
-                            f"{cfg.n_expo} exposures, analytic Roman-like PSF, Cholesky kappa/C={cfg.kappaC[0]:g}, fp64",
+                "workload": f"BASELINE configs[{CONFIG_INDEX.get(cfg.name, '?')}] ({cfg.name}): one batch of {args.batch} {cfg.n2}x{cfg.n2}-output stamps "
+                            f"(fade {cfg.fade}) per GPU per step, {cfg.n_expo} exposures, "
+                            f"{'Gaussian' if cfg.psf == 'gauss' else 'analytic Roman-like'} PSF, Cholesky kappa/C={cfg.kappaC[0]:g}, fp64",
                 "stamps_per_step_per_gpu": args.batch,
                 "N_mean": float(n_arr.mean()),
                 "m": cfg.m,
@@ -344,6 +422,7 @@ def main():
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()},
         }
         if not args.no_block and world == 1 and args.config == "cfg2":
+            out.update(seam_legs(ctx, dev, cfg, batch))
             del batch
             torch.cuda.empty_cache()
             out["block"] = block_leg(ctx, dev)

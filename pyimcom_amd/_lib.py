@@ -114,6 +114,21 @@ lib.imcom_last_error.restype = C.c_char_p
 EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_dev_build", "imcom_last_error", "imcom_psf_spectra_size", "imcom_smooth_pad_width"])
 
 
+def source_sha16():
+    """First 16 hex digits of the SHA-256 over the kernel sources (csrc/*.hip, *.h, the C-ABI header): stamps measurements
+    (profiles/r*_pmc_traffic.json) with the build they were taken on."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
+                   + glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def check(status):
     if status != 0:
         raise ImcomError(status, lib.imcom_last_error().decode("utf-8", "replace"))

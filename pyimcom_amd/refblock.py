@@ -117,7 +117,7 @@ def input_psf_groups(blk, psfgrp, device, ctx=None):
     return count, expo, provider
 
 
-def target_psfs(cfg, psfgrp, device):
+def target_psfs(cfg, psfgrp, device, ctx=None):
     """The output PSF group (psfutil.py:898-929): OUTPSF plus the cfg.outpsf_extra entries."""
     import torch
 
@@ -125,16 +125,17 @@ def target_psfs(cfg, psfgrp, device):
 
     ns = int(psfgrp.nsamp)
     specs = [(cfg.outpsf, cfg.sigmatarget)] + list(zip(getattr(cfg, "outpsf_extra", []) or [], getattr(cfg, "sigmatarget_extra", []) or []))
-    imgs = torch.stack([psfs.get_outpsf(o, s, cfg.use_filter, ns, int(psfgrp.oversamp), device=device) for o, s in specs])
-    return psfs.sample_psf(imgs, ns, None, bool(cfg.psf_circ), bool(cfg.psf_norm))
+    imgs = torch.stack([psfs.get_outpsf(o, s, cfg.use_filter, ns, int(psfgrp.oversamp), device=device, ctx=ctx) for o, s in specs])
+    return psfs.sample_psf(imgs, ns, None, bool(cfg.psf_circ), bool(cfg.psf_norm), ctx)
 
 
-def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None):
+def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None, ctx=None):
     """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  ``stamps``: optional list of
     (j_st, i_st) to coadd instead of all n1P x n1P (the reference's ``stoptile`` debugging aid stops early in the same
     way); ``finalize=False`` skips the boundary recovery of coadd.py:2163-2181.  ``batch``: stamps per pass (default: sized
     from the device memory and the table arena, blockrun.plan_block); ``table_capacity``: overlap tables kept resident
-    (default: the whole block's, or a third of the free device memory).  Returns the ``BlockMaps``."""
+    (default: the whole block's, or a third of the free device memory); ``ctx``: the library context to run on (default: the
+    process-wide one of the device).  Returns the ``BlockMaps``."""
     from .blockrun import coadd_block
     from .select import InStampPool
     from .stamps import BlockTables
@@ -148,12 +149,12 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
         if hasattr(cfg, k):
             setattr(scfg, k, getattr(cfg, k))
     pool = InStampPool([(st.x_val, st.y_val, st.data, st.pix_cumsum) for row in blk.instamps for st in row], scfg.n_inframe, device=device)
-    count, expo, provider = input_psf_groups(blk, psfgrp, device)
-    target = target_psfs(cfg, psfgrp, device)
+    count, expo, provider = input_psf_groups(blk, psfgrp, device, ctx)
+    target = target_psfs(cfg, psfgrp, device, ctx)
     amp = getattr(cfg, "amp_penalty", None)
     amp = None if amp is None or 0.0 in tuple(amp) else (float(amp[0]), float(amp[1]) * float(psfgrp.oversamp))  # psfutil.py:661-671
     tables = BlockTables({k: None for k in count}, target, int(psfgrp.nfft), group_expo=expo, group_count=count, bulk_provider=provider,
-                         capacity=None if table_capacity is None else int(table_capacity), amp_penalty=amp, device=device,
+                         capacity=None if table_capacity is None else int(table_capacity), amp_penalty=amp, device=device, ctx=ctx,
                          cells=True)  # groups of 2 x 2 InStamps: cells of the block's grid (coadd.py:207, 329-358)
     maps = coadd_block(scfg, pool, tables, int(cfg.n1P), int(blk.n_inimage), batch=batch, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
                        postage_pad=int(getattr(cfg, "postage_pad", 0)), stamps=stamps)

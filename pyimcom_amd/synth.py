@@ -269,3 +269,61 @@ def make_instamps(cfg, n1P, n_expo, rng, depth=None):
         cum = np.concatenate([[0], np.cumsum(cnt[:, k])])
         out.append((px, py, rng.standard_normal((cfg.n_inframe, px.size)).astype(np.float32), cum))
     return out
+
+
+class _Obj:
+    """Plain attribute container (the duck-typed stand-ins below)."""
+
+
+def duck_block(wl, n1P, E, seed=3, kernel="Cholesky", pad_sides="all"):
+    """A duck-typed ``pyimcom.coadd.Block`` + ``PSFGrp`` class attributes for ``refblock.coadd_output_stamps`` without FITS /
+    WCS machinery: synthetic InStamps (``make_instamps``), per exposure an affine output-pixel -> input-pixel map (a small
+    rotation) and a PSF image that varies smoothly with the position it is asked for, an identity output WCS.  What the
+    reference's Block constructor would leave behind (coadd.py:1560-1937), as far as the stamp loop reads it.
+    Returns (blk, psfgrp, inst, image_at)."""
+    ARCSEC = np.pi / 180.0 / 3600.0
+    inst = make_instamps(wl, n1P, E, np.random.default_rng(seed))
+    base, _ = make_psfs(wl, E)
+    ns, nst = wl.nsamp, n1P + 2
+    pad = np.zeros((E, ns + 9, ns + 9))
+    pad[:, 4 : 4 + ns, 4 : 4 + ns] = base
+    lin = np.arange(ns + 9) - (ns + 8) / 2.0
+    psfgrp = _Obj()
+    psfgrp.npixpsf, psfgrp.oversamp, psfgrp.nsamp, psfgrp.nfft, psfgrp.dscale = wl.npixpsf, wl.oversamp, ns, wl.nfft, wl.dscale
+    cfg = _Obj()
+    cfg.n1P, cfg.n2, cfg.fade_kernel, cfg.n2f, cfg.n_inframe = n1P, wl.n2, wl.fade, wl.n2f, wl.n_inframe
+    cfg.dtheta, cfg.instamp_pad = wl.dtheta_as / 3600.0, wl.inpad_as * ARCSEC
+    cfg.linear_algebra, cfg.no_qlt_ctrl, cfg.kappaC_arr, cfg.uctarget, cfg.sigmamax = kernel, False, np.array(wl.kappaC), wl.uctarget, wl.sigmamax
+    cfg.psf_circ, cfg.psf_norm, cfg.amp_penalty = False, True, [0.0, 0.0]
+    cfg.n_out, cfg.outpsf, cfg.sigmatarget, cfg.use_filter = 1, "GAUSSIAN", wl.extrasmooth, 2
+    cfg.outpsf_extra, cfg.sigmatarget_extra, cfg.postage_pad, cfg.psfsplit, cfg.psf_interp = [], [], 0, None, "D5512"
+    cfg.flat_penalty = wl.flat_penalty
+    blk = _Obj()
+    blk.cfg, blk.n_inimage, blk.pad_sides = cfg, E, pad_sides
+    blk.outwcs = _Obj()
+    blk.outwcs.all_pix2world = lambda arr, origin: np.asarray(arr, dtype=np.float64)
+    scale = wl.dtheta_as / NATIVE_ARCSEC
+
+    def image_at(e, point):  # the PSF of exposure e varies smoothly over the block
+        u, v = point[0] / (n1P * wl.n2), point[1] / (n1P * wl.n2)
+        return pad[e] * (1.0 + 0.02 * np.sin(0.05 * lin * (1 + u))[None, :] + 0.02 * np.cos(0.04 * lin * (1 + v))[:, None])
+
+    blk.inimages = []
+    for e in range(E):
+        im = _Obj()
+        th = 0.004 * (e - E / 2)
+        M = scale * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        im.get_psf_pos = (lambda e_: (lambda point, use_shortrange=True: image_at(e_, point)))(e)
+        im.outpix2world2inpix = (lambda M_: (lambda xy: np.asarray(xy) @ M_.T))(M)
+        blk.inimages.append(im)
+    blk.instamps = [[None] * nst for _ in range(nst)]
+    for j in range(nst):
+        for i in range(nst):
+            st = _Obj()
+            st.x_val, st.y_val, st.data, cum = inst[j * nst + i]
+            st.pix_cumsum = np.asarray(cum, dtype=np.uint32)
+            st.pix_count = np.diff(np.asarray(cum, dtype=np.int64)).astype(np.uint32)
+            if j % 2 == 0 and i % 2 == 0:
+                st.psf_compute_point_pix = [i * wl.n2 - 0.5, j * wl.n2 - 0.5]  # coadd.py:710-714
+            blk.instamps[j][i] = st
+    return blk, psfgrp, inst, image_at

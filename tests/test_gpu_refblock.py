@@ -221,50 +221,8 @@ def test_block_seam_at_reference_block_size():
     # (PSF grid of 24 native pixels instead of 48: the host evaluates nsamp^2 sampling positions per group and exposure,
     # 11 094 times for this block, as the reference does -- the point here is the block, not the PSF postage stamp)
     wl = dataclasses.replace(synth.CONFIGS["cfg2"], n2=32, fade=3, dtheta_as=0.0390625, n_expo=E, n_inframe=2, npixpsf=24, psf="gauss")  # (Gaussian PSFs: an Airy pattern cut at +-12 pixels makes A indefinite beyond kappa -- every stamp would take the repair path)
-    inst = synth.make_instamps(wl, n1P, E, np.random.default_rng(3))
-    base, _ = synth.make_psfs(wl, E)
-    ns, nst = wl.nsamp, n1P + 2
-    pad = np.zeros((E, ns + 9, ns + 9))
-    pad[:, 4 : 4 + ns, 4 : 4 + ns] = base
-    lin = np.arange(ns + 9) - (ns + 8) / 2.0
-
-    psfgrp = Empty()
-    psfgrp.npixpsf, psfgrp.oversamp, psfgrp.nsamp, psfgrp.nfft, psfgrp.dscale = wl.npixpsf, wl.oversamp, ns, wl.nfft, wl.dscale
-    cfg = Empty()
-    cfg.n1P, cfg.n2, cfg.fade_kernel, cfg.n2f, cfg.n_inframe = n1P, wl.n2, wl.fade, wl.n2f, wl.n_inframe
-    cfg.dtheta, cfg.instamp_pad = wl.dtheta_as / 3600.0, wl.inpad_as * ARCSEC
-    cfg.linear_algebra, cfg.no_qlt_ctrl, cfg.kappaC_arr, cfg.uctarget, cfg.sigmamax = "Cholesky", False, np.array(wl.kappaC), 1e-6, 0.5
-    cfg.psf_circ, cfg.psf_norm, cfg.amp_penalty = False, True, [0.0, 0.0]
-    cfg.n_out, cfg.outpsf, cfg.sigmatarget, cfg.use_filter = 1, "GAUSSIAN", wl.extrasmooth, 2
-    cfg.outpsf_extra, cfg.sigmatarget_extra, cfg.postage_pad, cfg.psfsplit, cfg.psf_interp = [], [], 0, None, "D5512"
-    blk = Empty()
-    blk.cfg, blk.n_inimage, blk.pad_sides = cfg, E, "all"
-    blk.outwcs = Empty()
-    blk.outwcs.all_pix2world = lambda arr, origin: np.asarray(arr, dtype=np.float64)
-    scale = wl.dtheta_as / synth.NATIVE_ARCSEC
-
-    def image_at(e, point):  # the PSF of exposure e varies smoothly over the block
-        u, v = point[0] / (n1P * wl.n2), point[1] / (n1P * wl.n2)
-        return pad[e] * (1.0 + 0.02 * np.sin(0.05 * lin * (1 + u))[None, :] + 0.02 * np.cos(0.04 * lin * (1 + v))[:, None])
-
-    blk.inimages = []
-    for e in range(E):
-        im = Empty()
-        th = 0.004 * (e - E / 2)
-        M = scale * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
-        im.get_psf_pos = (lambda e_: (lambda point, use_shortrange=True: image_at(e_, point)))(e)
-        im.outpix2world2inpix = (lambda M_: (lambda xy: np.asarray(xy) @ M_.T))(M)
-        blk.inimages.append(im)
-    blk.instamps = [[None] * nst for _ in range(nst)]
-    for j in range(nst):
-        for i in range(nst):
-            st = Empty()
-            st.x_val, st.y_val, st.data, cum = inst[j * nst + i]
-            st.pix_cumsum = np.asarray(cum, dtype=np.uint32)
-            st.pix_count = np.diff(np.asarray(cum, dtype=np.int64)).astype(np.uint32)
-            if j % 2 == 0 and i % 2 == 0:
-                st.psf_compute_point_pix = [i * wl.n2 - 0.5, j * wl.n2 - 0.5]  # coadd.py:710-714
-            blk.instamps[j][i] = st
+    blk, psfgrp, inst, image_at = synth.duck_block(wl, n1P, E, seed=3)
+    cfg, ns, nst = blk.cfg, wl.nsamp, n1P + 2
     torch.cuda.empty_cache()
     maps = coadd_output_stamps(blk, psfgrp, flat_penalty=wl.flat_penalty)
     assert np.isfinite(blk.out_map).all() and np.abs(blk.out_map).max() > 0 and blk.out_map.shape == (1, 2, maps.nside, maps.nside)

@@ -6,8 +6,11 @@ WRITE_SIZE is exact for 16-B stores.
     python pmc_traffic.py FETCH.db WRITE.db OUT.json WORKLOAD BATCH [note]
 """
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def per_kernel(db, counter):
@@ -33,7 +36,9 @@ def main():
         fb, wb = 2.0 * f["kb"] * 1024.0 / n, (w["kb"] * 1024.0 / w["launches"] if w["launches"] else 0.0)
         out[short(k)] = dict(launches=n, fetch_kb_raw_per_launch=f["kb"] / n, write_kb_per_launch=(w["kb"] / w["launches"] if w["launches"] else 0.0),
                              traffic_bytes_per_launch=fb + wb, avg_us_under_pmc=f["ns"] / n / 1e3)
-    doc = dict(workload=sys.argv[4], batch=int(sys.argv[5]), note=sys.argv[6] if len(sys.argv) > 6 else "", correction="traffic = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950, wide reads)",
+    from pyimcom_amd._lib import source_sha16
+
+    doc = dict(workload=sys.argv[4], batch=int(sys.argv[5]), csrc_sha16=source_sha16(), note=sys.argv[6] if len(sys.argv) > 6 else "", correction="traffic = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950, wide reads)",
                kernels=out)
     json.dump(doc, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"])[:12]:
