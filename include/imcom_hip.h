@@ -136,6 +136,12 @@ int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, c
                       const double *mBhalf, const double *C, const double *kappaC, int nv,
                       double ucmin, double smax, int nbis, float *T, float *UC, float *Sigma,
                       float *kappa, int *info, int memspace);
+/* The same kernel on the resident layouts of imcom_build_A / imcom_build_B (DEVICE pointers): A [batch][ldn][ldn], Bt = -B/2
+ * input-pixel-major [batch][ldn][ldm] (zero padded), output Tt [batch][ldn][ldm] float32; ldn, ldm multiples of 128.
+ * EigenKernel._call_single_kappa / _call_multi_kappa (lakernel.py:154-223) without the transposes of the reference layout. */
+int imcom_solve_eigen_resident(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm, const double *A,
+                               const double *Bt, const double *C_host, const double *kappaC_host, int nv, double ucmin,
+                               double smax, int nbis, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host);
 
 /* ---- secondary LA kernels: lakernel.IterKernel 533-744, lakernel.EmpirKernel 747-805 ----------------------
  * Geometry (all in output-pixel units, as the reference computes them at lakernel.py:617-622 / 757-761):

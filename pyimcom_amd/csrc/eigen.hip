@@ -1,84 +1,160 @@
 // eigen.hip -- the eigendecomposition LA path (reference src/pyimcom/lakernel.py:141-223 EigenKernel)
 // and the public batched eigensolver entry point.
 //
-//   lam, Q = eigh(A)                     tridiag.hip (Householder tridiagonalisation + implicit QR)
-//   P = (-B/2) Q                         fp64 MFMA GEMM
-//   single kappa (154-172): Sigma_a = sum_i (P_ai/(lam_i+kappa))^2, UC_a = 1 - sum_i (lam_i+2 kappa) P_ai^2/(lam_i+kappa)^2 / C
-//   multi kappa  (174-223): routine.lakernel1 per output pixel, then kappa *= C (line 222)
-//   T = (P/(lam+kappa)) Q^T              fp64 MFMA GEMM, stored float32
+// The reference diagonalises A = Q diag(lam) Q^T, takes P = (-B/2) Q and evaluates, per output pixel a and trial kappa,
+//     Sigma_a = sum_i P_ai^2 / (lam_i + kappa)^2,    UC_a = 1 - sum_i (lam_i + 2 kappa) P_ai^2 / (lam_i + kappa)^2 / C
+// (single kappa 154-172; multi kappa 174-223: routine.lakernel1 bisects kappa per pixel, then kappa *= C, line 222),
+// and T = (P / (lam + kappa)) Q^T.  Both sums are invariants of b_a = (-B/2)[a] under any orthogonal change of basis:
+//     D(kappa) = b^T (A + kappa)^-1 b,   S(kappa) = b^T (A + kappa)^-2 b,   Sigma = S,   UC = 1 - (D + kappa S) / C,
+// so the eigenvectors are never needed.  Here the work is done in the TRIDIAGONAL basis A = Qh T Qh^T (tridiag.hip: the
+// Householder reduction alone, Qh kept as reflectors):
+//     c_a = Qh^T b_a                                  block reflectors applied to -B/2 [N][m]: fp64 MFMA GEMMs (trd_apply_q)
+//     D, S at a trial kappa                           ONE forward sweep of the LDL^T of T + kappa I per pixel, O(N), with the
+//                                                     derivative of the sweep carried along: S = -dD/dkappa  (tri_search_kernel)
+//     y_a = (T + kappa_a I)^-1 c_a at the final kappa forward + backward substitution                     (tri_solve_kernel)
+//     T_a = Qh y_a                                    block reflectors again, stored float32
+// which removes the implicit QR iteration, the rotations of the eigenvector matrix and the explicit Qh (a third of the
+// old path's time at N = 2.9k) and all of their workspace.  T + kappa I is positive definite for kappa > -lam_min, which
+// the bracket kappa >= kappaC[0] C > 0 guarantees for the positive semi-definite A of this problem, so the LDL^T needs no
+// pivoting.  The bisection takes the same decisions as lakernel1 except where udc or sum2 sits within rounding of its bound.
 #include "common.h"
 #include "launchers.h"
 
 namespace imcom {
 
-// Bp[s][a][j] = B[s][a*ldb + j] for a < m, j < n[s]; zero elsewhere   ([mp][np] row-major)
-__global__ void pad_B_kernel(const double *__restrict__ B, long ldb, int m, const int *__restrict__ n, double *__restrict__ Bp,
-                             int mp, int np)
+// Cb[s][i][a] = B[s][a][i] (reference layout -B/2 [m][ldb] -> input-pixel-major [np][mp]); zero for a >= m, i >= n[s]
+__global__ __launch_bounds__(256) void tri_pack_kernel(const double *__restrict__ B, long ldb, int m, const int *__restrict__ n,
+                                                       double *__restrict__ Cb, int np, int mp)
 {
-    const int s = blockIdx.z, a = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= np) return;
-    double v = 0.0;
-    if (a < m && j < n[s]) v = B[(long)s * m * ldb + (long)a * ldb + j];
-    Bp[((long)s * mp + a) * np + j] = v;
-}
-
-// single kappa: one wave per output pixel
-__global__ __launch_bounds__(256) void eigen_single_kernel(const double *__restrict__ lam, const double *__restrict__ P, int mp,
-                                                           int np, int m, const int *__restrict__ n,
-                                                           const double *__restrict__ kap, const double *__restrict__ Cs,
-                                                           double *__restrict__ S, float *__restrict__ UC,
-                                                           float *__restrict__ Sigma, float *__restrict__ kappa)
-{
-    const int s = blockIdx.y, a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (a >= m) return;
+    __shared__ double tile[32][33];
+    const int s = blockIdx.z, i0 = blockIdx.y * 32, a0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int ns = n[s];
-    const double k = kap[s], C = Cs[s];
-    const double *l = lam + (long)s * np, *p = P + ((long)s * mp + a) * np;
-    double *o = S + ((long)s * mp + a) * np;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = lane; i < np; i += 64) {
-        double v = 0.0;
-        if (i < ns) {
-            const double li = l[i];
-            v = p[i] / (li + k);
-            s2 += v * v;
-            s1 += (li + 2.0 * k) * v * v;
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, i = i0 + tx;
+        tile[r][tx] = (a < m && i < ns) ? B[(long)s * m * ldb + (long)a * ldb + i] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, a = a0 + tx;
+        if (i < np && a < mp) Cb[((long)s * np + i) * mp + a] = tile[tx][r];
+    }
+}
+
+// One forward sweep of the LDL^T of T + kappa I against c, with its kappa-derivative:
+//   delta_0 = d_0 + kappa, l_i = e_i / delta_i, delta_{i+1} = d_{i+1} + kappa - l_i e_i, z_{i+1} = c_{i+1} - l_i z_i
+//   D = sum z_i^2 / delta_i = c^T (T + kappa)^-1 c,     S = -dD/dkappa = c^T (T + kappa)^-2 c
+__device__ __forceinline__ void tri_sweep(const double *__restrict__ d, const double *__restrict__ e, const double *__restrict__ c,
+                                          long cstride, int ns, double kap, double &D, double &S)
+{
+    double delta = d[0] + kap, dp = 1.0, z = c[0], zp = 0.0, cn = ns > 1 ? c[cstride] : 0.0;
+    D = 0.0;
+    S = 0.0;
+    for (int i = 0; i < ns; i++) {
+        const double cnext = i + 2 < ns ? c[(long)(i + 2) * cstride] : 0.0;  // one row ahead of its use
+        const double r = 1.0 / delta, t = z * r;
+        D += z * t;
+        S += t * (t * dp - 2.0 * zp);
+        if (i + 1 < ns) {
+            const double b = e[i], l = b * r, lp = -l * r * dp;
+            const double zn = cn - l * z, zpn = -lp * z - l * zp;
+            delta = d[i + 1] + kap - l * b;
+            dp = 1.0 - lp * b;
+            z = zn;
+            zp = zpn;
+            cn = cnext;
         }
-        o[i] = v;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-    if (lane == 0) {
-        const long pa = (long)s * m + a;
-        if (ns == 0) { UC[pa] = 1.0f; Sigma[pa] = 0.0f; kappa[pa] = 1.0f; }
-        else { kappa[pa] = (float)k; Sigma[pa] = (float)s2; UC[pa] = (float)(1.0 - s1 / C); }
     }
 }
 
-// multi kappa post-processing: float32 stores as the reference does (lakernel.py:216-222)
-__global__ void eigen_multi_store_kernel(const double *__restrict__ k64, const double *__restrict__ S64,
-                                         const double *__restrict__ U64, int m, int ns, double C, float *__restrict__ UC,
-                                         float *__restrict__ Sigma, float *__restrict__ kappa)
+// multi kappa: routine.lakernel1's bisection (routine.py:405-419) per output pixel, D and S from tri_sweep
+__global__ __launch_bounds__(64) void tri_search_kernel(const double *__restrict__ dvec, const double *__restrict__ evec,
+                                                        const double *__restrict__ Cb, int np, int mp, int m,
+                                                        const int *__restrict__ n, const double *__restrict__ Cs,
+                                                        const double *__restrict__ kmin, const double *__restrict__ kmax,
+                                                        double targetleak, double smax, int nbis, double *__restrict__ kap_out)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y, a = blockIdx.x * 64 + threadIdx.x;
+    const int ns = n[s];
+    if (a >= m || ns == 0) return;
+    const double *d = dvec + (long)s * np, *e = evec + (long)s * np, *c = Cb + (long)s * np * mp + a;
+    const double C = Cs[s], kCmin = kmin[s], kCmax = kmax[s];
+    double factor = sqrt(kCmax / kCmin), kap = sqrt(kCmax * kCmin);
+    for (int it = 0; it < nbis; it++) {
+        double D, S;
+        tri_sweep(d, e, c, mp, ns, kap, D, S);
+        const double udc = 1.0 - (D + kap * S) / C;
+        factor = sqrt(factor);
+        kap *= (udc > targetleak && S < smax) ? 1.0 / factor : factor;
+    }
+    kap_out[(long)s * m + a] = kap;
+}
+
+// y = (T + kappa I)^-1 c per output pixel, in place (Cb: c -> y), with the maps.  kap_pix == null: one kappa per stamp
+// (kap_stamp, single-kappa path); else kappa per pixel (multi: kappa stored as float32 and THEN multiplied by C, the
+// quirk of lakernel.py:216-222).  Lb [np][mp]: the l_i of every pixel's factorisation between the two passes.
+__global__ __launch_bounds__(64) void tri_solve_kernel(const double *__restrict__ dvec, const double *__restrict__ evec,
+                                                       double *__restrict__ Cb, double *__restrict__ Lb, int np, int mp, int m,
+                                                       const int *__restrict__ n, const double *__restrict__ Cs,
+                                                       const double *__restrict__ kap_stamp, const double *__restrict__ kap_pix,
+                                                       float *__restrict__ UC, float *__restrict__ Sigma, float *__restrict__ kappa)
+{
+    const int s = blockIdx.y, a = blockIdx.x * 64 + threadIdx.x;
+    const int ns = n[s];
     if (a >= m) return;
-    if (ns == 0) { UC[a] = 1.0f; Sigma[a] = 0.0f; kappa[a] = 1.0f; return; }
-    const float k32 = (float)k64[a];
-    kappa[a] = (float)((double)k32 * C);
-    Sigma[a] = (float)S64[a];
-    UC[a] = (float)U64[a];
+    const long pa = (long)s * m + a;
+    if (ns == 0) { UC[pa] = 1.0f; Sigma[pa] = 0.0f; kappa[pa] = 1.0f; return; }  // lakernel.py:110-119
+    const double *d = dvec + (long)s * np, *e = evec + (long)s * np;
+    double *c = Cb + (long)s * np * mp + a, *lb = Lb + (long)s * np * mp + a;
+    const double C = Cs[s], kap = kap_pix ? kap_pix[pa] : kap_stamp[s];
+    double delta = d[0] + kap, z = c[0], D = 0.0;
+    for (int i = 0; i < ns; i++) {
+        const double r = 1.0 / delta, t = z * r;
+        D += z * t;
+        c[(long)i * mp] = t;  // w_i = z_i / delta_i
+        if (i + 1 < ns) {
+            const double b = e[i], l = b * r;
+            lb[(long)i * mp] = l;
+            z = c[(long)(i + 1) * mp] - l * z;
+            delta = d[i + 1] + kap - l * b;
+        }
+    }
+    double y = c[(long)(ns - 1) * mp], S = y * y;
+    for (int i = ns - 2; i >= 0; i--) {
+        y = c[(long)i * mp] - lb[(long)i * mp] * y;
+        c[(long)i * mp] = y;
+        S += y * y;
+    }
+    const double udc = 1.0 - (D + kap * S) / C;
+    Sigma[pa] = (float)S;
+    UC[pa] = (float)udc;
+    kappa[pa] = kap_pix ? (float)((double)(float)kap * C) : (float)kap;
 }
 
-// T[s][a][i] (float32, [m][ldt]) = Tp[s][a][i] (float64, [mp][np]); columns i >= n[s] zero
-__global__ void cast_T_kernel(const double *__restrict__ Tp, int mp, int np, int m, const int *__restrict__ n,
-                              float *__restrict__ T, long ldt)
+// X [np][mp] float64 -> resident layout Tt [ldn][ldm] float32 (rows >= n[s], columns >= m zero)
+__global__ void tri_store_resident_kernel(const double *__restrict__ X, int np, int mp, int m, const int *__restrict__ n,
+                                          float *__restrict__ Tt, int ldn, int ldm)
 {
-    const int s = blockIdx.z, a = blockIdx.y;
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= ldt) return;
-    float v = 0.0f;
-    if (i < n[s]) v = (float)Tp[((long)s * mp + a) * np + i];
-    T[(long)s * m * ldt + (long)a * ldt + i] = v;
+    const int s = blockIdx.z, i = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= ldm) return;
+    Tt[((long)s * ldn + i) * ldm + a] = (i < n[s] && a < m) ? (float)X[((long)s * np + i) * mp + a] : 0.0f;
+}
+
+// X [np][mp] float64 -> reference layout T [m][ldt] float32 (columns >= n[s] zero)
+__global__ __launch_bounds__(256) void tri_store_ref_kernel(const double *__restrict__ X, int np, int mp, int m,
+                                                            const int *__restrict__ n, float *__restrict__ T, long ldt)
+{
+    __shared__ double tile[32][33];
+    const int s = blockIdx.z, i0 = blockIdx.y * 32, a0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ns = n[s];
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, a = a0 + tx;
+        tile[r][tx] = (i < ns && i < np && a < mp) ? X[((long)s * np + i) * mp + a] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, i = i0 + tx;
+        if (a < m && i < ldt) T[(long)s * m * ldt + (long)a * ldt + i] = (float)tile[tx][r];
+    }
 }
 
 }  // namespace imcom
@@ -126,6 +202,59 @@ extern "C" int imcom_eigh(imcom_ctx *ctx, int batch, const int *n, int ldn, cons
     return IMCOM_OK;
 }
 
+// Shared body of the two entries.  Bt_res: -B/2 in the resident layout [np][mp] (then Tt_res [np][mp] float32 is the output);
+// else B_ref [m][ldn] and T_ref [m][ldn] in the reference's layout.
+static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, int np, int mp, const double *A_d, const double *Bt_res,
+                            const double *B_ref, const double *C, const double *kappaC, int nv, double ucmin, double smax, int nbis,
+                            float *Tt_res, float *T_ref, float *UC_d, float *Sig_d, float *kap_d, int nmax)
+{
+    const size_t big = (size_t)batch * np * mp * 8, szM = (size_t)batch * m;
+    TrdBasis tb;
+    IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
+    double *Cb = (double *)ws_take(ctx, big), *Lb = (double *)ws_take(ctx, big);
+    double *kpix = (double *)ws_take(ctx, szM * 8), *par = (double *)ws_take(ctx, (size_t)batch * 8 * 4);
+    if (!Cb || !Lb || !kpix || !par) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    std::vector<double> ph(4 * (size_t)batch);
+    for (int s = 0; s < batch; s++) {
+        ph[s] = C[s];
+        ph[batch + s] = kappaC[0] * C[s];           // single kappa / kCmin C (lakernel.py:166, 213)
+        ph[2 * batch + s] = kappaC[nv - 1] * C[s];  // kCmax C (214)
+    }
+    IMCOM_TRY(upload(ctx, par, ph.data(), ph.size()));
+    hipStream_t st = ctx->stream;
+    if (Bt_res) IMCOM_HIP_CHECK(hipMemcpyAsync(Cb, Bt_res, big, hipMemcpyDeviceToDevice, st));
+    else {
+        hipLaunchKernelGGL(tri_pack_kernel, dim3(mp / 32, np / 32, batch), dim3(256), 0, st, B_ref, (long)ldn, m, tb.n_dev, Cb, np, mp);
+        IMCOM_TRY(check_launch("tri_pack_kernel"));
+    }
+    if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Qh^T b
+    {
+        ProfScope ps(ctx, "lakernel1");
+        if (nv > 1) {
+            hipLaunchKernelGGL(tri_search_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, np, mp, m, tb.n_dev, par,
+                               par + batch, par + 2 * batch, ucmin, smax, nbis, kpix);
+            IMCOM_TRY(check_launch("tri_search_kernel"));
+        }
+        hipLaunchKernelGGL(tri_solve_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, Lb, np, mp, m, tb.n_dev, par,
+                           par + batch, nv > 1 ? kpix : nullptr, UC_d, Sig_d, kap_d);
+        IMCOM_TRY(check_launch("tri_solve_kernel"));
+    }
+    if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, false));  // x = Qh y
+    if (Tt_res) {
+        hipLaunchKernelGGL(tri_store_resident_kernel, dim3((mp + 255) / 256, np, batch), dim3(256), 0, st, Cb, np, mp, m, tb.n_dev, Tt_res, np, mp);
+        IMCOM_TRY(check_launch("tri_store_resident_kernel"));
+    } else if (ldn > 0) {
+        hipLaunchKernelGGL(tri_store_ref_kernel, dim3(mp / 32, (unsigned)((ldn + 31) / 32), batch), dim3(256), 0, st, Cb, np, mp, m, tb.n_dev, T_ref, (long)ldn);
+        IMCOM_TRY(check_launch("tri_store_ref_kernel"));
+    }
+    return IMCOM_OK;
+}
+
+static size_t solve_eigen_ws(int batch, int np, int mp, int m)
+{
+    return trd_basis_ws_bytes(batch, np, mp) + 2 * (size_t)batch * np * mp * 8 + (size_t)batch * m * 8 + (size_t)batch * 64 + 65536;
+}
+
 extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A, const double *mBhalf,
                                  const double *C, const double *kappaC, int nv, double ucmin, double smax, int nbis, float *T,
                                  float *UC, float *Sigma, float *kappa, int *info, int memspace)
@@ -143,9 +272,8 @@ extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ld
     const bool host = memspace == IMCOM_MEM_HOST;
     const int np = (int)align_up((size_t)std::max(nmax, 1), NB), mp = (int)align_up((size_t)m, NB);
     const size_t szA = (size_t)batch * ldn * ldn, szB = (size_t)batch * m * ldn, szM = (size_t)batch * m;
-    const size_t big = (size_t)batch * mp * np * 8;
-    size_t total = eigh_ws_bytes(batch, np, true) + 4 * big + (size_t)batch * np * np * 8 + (size_t)batch * np * 8 + 3 * szM * 8 + 65536;
-    if (host) total += szA * 8 + szB * 8 + szB * 4 + szM * 12;
+    size_t total = solve_eigen_ws(batch, np, mp, m);
+    if (host) total += szA * 8 + szB * 8 + szB * 4 + szM * 12 + 4096;
     IMCOM_TRY(ws_reserve(ctx, total));
     const double *A_d = A, *B_d = mBhalf;
     float *T_d = T, *UC_d = UC, *Sig_d = Sigma, *kap_d = kappa;
@@ -161,57 +289,8 @@ extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ld
         A_d = ta;
         B_d = tb;
     }
-    double *lam = (double *)ws_take(ctx, (size_t)batch * np * 8);
-    double *Q = (double *)ws_take(ctx, (size_t)batch * np * np * 8);
-    double *Bp = (double *)ws_take(ctx, big), *P = (double *)ws_take(ctx, big), *S = (double *)ws_take(ctx, big);
-    double *Tp = (double *)ws_take(ctx, big);
-    double *pix = (double *)ws_take(ctx, 3 * szM * 8);
-    int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
-    double *kc = (double *)ws_take(ctx, (size_t)batch * 16);
-    if (!lam || !Q || !Bp || !P || !S || !Tp || !pix || !n_dev || !kc) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
-    std::vector<double> kch(2 * (size_t)batch);
-    for (int s = 0; s < batch; s++) { kch[s] = kappaC[0] * C[s]; kch[batch + s] = C[s]; }
-    IMCOM_HIP_CHECK(hipMemcpyAsync(n_dev, n, (size_t)batch * 4, hipMemcpyHostToDevice, ctx->stream));
-    IMCOM_HIP_CHECK(hipMemcpyAsync(kc, kch.data(), kch.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    IMCOM_HIP_CHECK(hipMemsetAsync(Q, 0, (size_t)batch * np * np * 8, ctx->stream));
-    IMCOM_HIP_CHECK(hipMemsetAsync(lam, 0, (size_t)batch * np * 8, ctx->stream));
-    if (nmax > 0) {
-        int sweeps = 0;
-        IMCOM_TRY(eigh_device(ctx, batch, n, np, A_d, ldn, (long)ldn * ldn, lam, np, Q, np, (long)np * np, &sweeps));
-    }
-    hipLaunchKernelGGL(pad_B_kernel, dim3((np + 255) / 256, mp, batch), dim3(256), 0, ctx->stream, B_d, (long)ldn, m, n_dev, Bp, mp, np);
-    IMCOM_TRY(check_launch("pad_B_kernel"));
-    {   // P = Bp Q
-        ProfScope ps(ctx, "eigen_gemm");
-        IMCOM_TRY(launch_gemm(ctx, false, true, mp, np, np, batch, Bp, np, (long)mp * np, Q, np, (long)np * np, P, np, (long)mp * np, 1.0, 0.0));
-    }
-    if (nv == 1) {
-        ProfScope ps(ctx, "lakernel1");
-        hipLaunchKernelGGL(eigen_single_kernel, dim3((m + 3) / 4, batch), dim3(256), 0, ctx->stream, lam, P, mp, np, m, n_dev, kc, kc + batch, S,
-                           UC_d, Sig_d, kap_d);
-        IMCOM_TRY(check_launch("eigen_single_kernel"));
-    } else {
-        ProfScope ps(ctx, "lakernel1");
-        IMCOM_HIP_CHECK(hipMemsetAsync(S, 0, big, ctx->stream));
-        for (int s = 0; s < batch; s++) {
-            double *k64 = pix + (size_t)s * m, *S64 = pix + szM + (size_t)s * m, *U64 = pix + 2 * szM + (size_t)s * m;
-            if (n[s] > 0)
-                IMCOM_TRY(launch_lakernel1(ctx, lam + (size_t)s * np, P + (size_t)s * mp * np, m, n[s], np, C[s], ucmin, kappaC[0] * C[s],
-                                           kappaC[nv - 1] * C[s], nbis, k64, S64, U64, S + (size_t)s * mp * np, np, smax));
-            hipLaunchKernelGGL(eigen_multi_store_kernel, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, k64, S64, U64, m, n[s], C[s],
-                               UC_d + (size_t)s * m, Sig_d + (size_t)s * m, kap_d + (size_t)s * m);
-        }
-        IMCOM_TRY(check_launch("eigen_multi_store_kernel"));
-    }
-    {   // T = S Q^T
-        ProfScope ps(ctx, "eigen_gemm");
-        IMCOM_TRY(launch_gemm(ctx, false, false, mp, np, np, batch, S, np, (long)mp * np, Q, np, (long)np * np, Tp, np, (long)mp * np, 1.0, 0.0));
-    }
-    if (ldn > 0) {
-        hipLaunchKernelGGL(cast_T_kernel, dim3((unsigned)((ldn + 255) / 256), m, batch), dim3(256), 0, ctx->stream, Tp, mp, np, m, n_dev, T_d, (long)ldn);
-        IMCOM_TRY(check_launch("cast_T_kernel"));
-    }
+    IMCOM_TRY(solve_eigen_core(ctx, batch, n, ldn, m, np, mp, A_d, nullptr, B_d, C, kappaC, nv, ucmin, smax, nbis, nullptr, T_d, UC_d, Sig_d,
+                               kap_d, nmax));
     if (host) {
         if (szB) IMCOM_HIP_CHECK(hipMemcpyAsync(T, T_d, szB * 4, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipMemcpyAsync(UC, UC_d, szM * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -220,4 +299,21 @@ extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ld
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     return IMCOM_OK;
+}
+
+extern "C" int imcom_solve_eigen_resident(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, int ldm, const double *A,
+                                          const double *Bt, const double *C, const double *kappaC, int nv, double ucmin, double smax,
+                                          int nbis, float *Tt, float *UC, float *Sigma, float *kappa, int *info)
+{
+    IMCOM_TRY(ctx_ok(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n && C && kappaC && A && Bt && Tt && UC && Sigma && kappa && info, "null pointer / empty batch");
+    IMCOM_REQUIRE(m >= 1 && nv >= 1 && nbis >= 0 && ldn >= NB && ldn % NB == 0 && ldm % NB == 0 && ldm >= m, "bad sizes (ldn, ldm multiples of 128)");
+    int nmax = 0;
+    for (int s = 0; s < batch; s++) {
+        IMCOM_REQUIRE(n[s] >= 0 && n[s] <= ldn, "n[%d]=%d exceeds ldn=%d", s, n[s], ldn);
+        nmax = std::max(nmax, n[s]);
+        info[s] = 0;
+    }
+    IMCOM_TRY(ws_reserve(ctx, solve_eigen_ws(batch, ldn, ldm, m)));
+    return solve_eigen_core(ctx, batch, n, ldn, m, ldn, ldm, A, Bt, nullptr, C, kappaC, nv, ucmin, smax, nbis, Tt, nullptr, UC, Sigma, kappa, nmax);
 }

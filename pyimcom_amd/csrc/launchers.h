@@ -30,6 +30,17 @@ size_t eigh_ws_bytes(int batch, int ld, bool vectors);
 int eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const double *A, long lda, long strideA, double *lam,
                 long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out);
 
+// tridiag.hip: the tridiagonal basis A = Qh T Qh^T without eigenvectors (eigen.hip works in it)
+struct TrdBasis {
+    double *Vall, *dvec, *evec, *tauvec;  // reflectors [batch][ld][ld] (row j = v_j), T's diagonal / off-diagonal, tau [batch][ld]
+    double *Tm, *Sm, *W1, *W2;            // triangular factors of the 128-reflector panels [npanels][batch][128][128]; scratch of trd_apply_q
+    int *n_dev;
+    int ld, nmax, npanels;
+};
+size_t trd_basis_ws_bytes(int batch, int ld, int mp);
+int trd_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out);
+int trd_apply_q(imcom_ctx *ctx, const TrdBasis &b, int batch, double *C, int mp, bool transpose);
+
 // la_kernels.hip
 int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail);
 int launch_diag_shift(imcom_ctx *ctx, const double *A, int ldn, const double *inc, const int *ninc, double *dshift,

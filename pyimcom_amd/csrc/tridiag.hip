@@ -637,22 +637,177 @@ __global__ void rot_identity_kernel(double2 *cs, long count)
 }
 
 // -------------------------------------------------------------------------------------------------
-size_t tridiag_ws_bytes(int batch, int ld, bool vectors)
+size_t tridiag_ws_bytes(int batch, int ld, bool vectors);
+
+// The tridiagonalisation proper: At (working copy of A, already initialised) -> d, e, reflectors Vall / tauvec.
+struct TrdScratch {
+    double *At, *Wp, *part, *ubuf, *pvec, *wprime, *wv, *hd, *pnorm, *pdot;
+};
+
+static size_t trd_scratch_bytes(int batch, int ld)
 {
-    const int ldr = ld + 2 * ROTPAD, npart = (ld + 255) / 256;
+    const int npart = (ld + 255) / 256;
     size_t t = 0;
     auto add = [&](size_t b) { t = align_up(t, 256) + b; };
     add((size_t)batch * ld * ld * 8);                      // At
-    add((size_t)batch * ld * ld * 8);                      // Vall
-    if (vectors) add((size_t)batch * ld * ld * 8 + (size_t)batch * ld * 8);  // X + one scratch row per stamp
     add((size_t)batch * TPL * ld * 8);                     // Wp
     add((size_t)batch * (ld / 32) * ld * 8);               // per-strip partials of the symmetric product
-    if (vectors) { add((size_t)batch * ld * TP * 8); add((size_t)batch * ld * TP * 8); }  // W1, W2
-    if (vectors) { add((size_t)batch * TP * TP * 8); add((size_t)batch * TP * TP * 8); }  // S, T
-    for (int q = 0; q < 6; q++) add((size_t)batch * ld * 8);  // u, p, w', d, e, tau
+    for (int q = 0; q < 3; q++) add((size_t)batch * ld * 8);  // u, p, w'
     add((size_t)batch * 2 * TP * 8);                       // V^T v, W^T v
     add((size_t)batch * 4 * 8);                            // hd
     add((size_t)batch * npart * 8 * 2);                    // pnorm, pdot
+    return t + 4096;
+}
+
+static bool trd_take_scratch(imcom_ctx *ctx, int batch, int ld, TrdScratch *t)
+{
+    const int npart = (ld + 255) / 256;
+    const size_t vecb = (size_t)batch * ld * 8;
+    t->At = (double *)ws_take(ctx, (size_t)batch * ld * ld * 8);
+    t->Wp = (double *)ws_take(ctx, (size_t)batch * TPL * ld * 8);
+    t->part = (double *)ws_take(ctx, (size_t)batch * (ld / 32) * ld * 8);
+    t->ubuf = (double *)ws_take(ctx, vecb);
+    t->pvec = (double *)ws_take(ctx, vecb);
+    t->wprime = (double *)ws_take(ctx, vecb);
+    t->wv = (double *)ws_take(ctx, (size_t)batch * 2 * TP * 8);
+    t->hd = (double *)ws_take(ctx, (size_t)batch * 4 * 8);
+    t->pnorm = (double *)ws_take(ctx, (size_t)batch * npart * 8);
+    t->pdot = (double *)ws_take(ctx, (size_t)batch * npart * 8);
+    return t->At && t->Wp && t->part && t->ubuf && t->pvec && t->wprime && t->wv && t->hd && t->pnorm && t->pdot;
+}
+
+// A (device, lda / strideA) -> At, then the column steps.  Vall, dvec, evec, tauvec [batch][ld(x ld)] are outputs; X
+// (optional) is set to the identity by the same initialisation kernel.
+static int trd_reduce(imcom_ctx *ctx, int batch, int nmax, int ld, const double *A, long lda, long strideA, const int *n_dev,
+                      const TrdScratch &t, double *Vall, double *dvec, double *evec, double *tauvec, double *X)
+{
+    const int npart = (ld + 255) / 256;
+    const size_t mat = (size_t)batch * ld * ld * 8, vecb = (size_t)batch * ld * 8;
+    hipStream_t st = ctx->stream;
+    double *At = t.At, *Wp = t.Wp, *part = t.part, *ubuf = t.ubuf, *pvec = t.pvec, *wprime = t.wprime, *wv = t.wv, *hd = t.hd,
+           *pnorm = t.pnorm, *pdot = t.pdot;
+    IMCOM_HIP_CHECK(hipMemsetAsync(Vall, 0, mat, st));
+    for (double *v : {ubuf, pvec, wprime, dvec, evec, tauvec}) IMCOM_HIP_CHECK(hipMemsetAsync(v, 0, vecb, st));
+    IMCOM_HIP_CHECK(hipMemsetAsync(hd, 0, (size_t)batch * 32, st));
+    hipLaunchKernelGGL(trd_init_kernel, dim3((ld + 255) / 256, ld, batch), dim3(256), 0, st, A, lda, strideA, n_dev, At, X, ld);
+    IMCOM_TRY(check_launch("trd_init_kernel"));
+    ProfScope ps_(ctx, "eigen_trd", nmax);
+    for (int ps = 0; ps < nmax; ps += TPL) {
+        const int pe = std::min(ps + TPL, nmax);
+        IMCOM_HIP_CHECK(hipMemsetAsync(Wp, 0, (size_t)batch * TPL * ld * 8, st));
+        for (int j = ps; j < pe; j++) {
+            hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
+                               n_dev, ld, j, ps, npart, 1);
+            if (j + 1 >= nmax) break;
+            const int nrowtiles = ((nmax - 1) >> 5) - ((j + 1) >> 5) + 1, ndot = (2 * (j - ps) + 3) / 4;
+            hipLaunchKernelGGL(trd_symv_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, Vall, Wp, ubuf, pnorm, pvec, part, hd,
+                               evec, tauvec, wv, n_dev, ld, j, ps, npart, nrowtiles);
+            hipLaunchKernelGGL(trd_w_kernel, dim3(npart, batch), dim3(256), 0, st, Vall, Wp, ubuf, pvec, hd, wv, part, wprime, pdot, n_dev, ld,
+                               j, ps, npart);
+        }
+        IMCOM_TRY(check_launch("trd column step"));
+        if (ps + TPL < nmax) {  // trailing two-sided update A[pe:, pe:] -= V W^T + W V^T
+            const int pe2 = ps + TPL;
+            hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
+                               n_dev, ld, pe2, ps, npart, 0);
+            // The GEMM tiles are 128-aligned: start at the tile boundary at or below pe.  The extra rows/columns
+            // it touches are already reduced and only ever read again under a zero multiplier.
+            const int pa = pe2 / NB * NB, rem = ld - pa;
+            const double *Vp = Vall + (long)ps * ld + pa, *Wq = Wp + pa;
+            double *C = At + (long)pa * ld + pa;
+            IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TPL, batch, Vp, ld, (long)ld * ld, Wq, ld, (long)TPL * ld, C, ld, (long)ld * ld, -1.0, 1.0));
+            IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TPL, batch, Wq, ld, (long)TPL * ld, Vp, ld, (long)ld * ld, C, ld, (long)ld * ld, -1.0, 1.0));
+        }
+    }
+    return IMCOM_OK;
+}
+
+// ---- the tridiagonal basis for callers that never need eigenvectors (eigen.hip): A = Qh T Qh^T with T = (d, e) and Qh
+// kept as its reflectors; trd_apply_q multiplies a tall matrix by Qh or Qh^T panel by panel (compact WY, three GEMMs each).
+size_t trd_basis_ws_bytes(int batch, int ld, int mp)
+{
+    const int npanels = (ld + TP - 1) / TP;
+    size_t t = 0;
+    auto add = [&](size_t b) { t = align_up(t, 256) + b; };
+    add((size_t)batch * ld * ld * 8);                      // Vall
+    for (int q = 0; q < 3; q++) add((size_t)batch * ld * 8);  // d, e, tau
+    add((size_t)batch * 4);                                // n
+    add((size_t)batch * npanels * TP * TP * 8);            // T factors of all panels
+    add((size_t)batch * TP * TP * 8);                      // S = V V^T of one panel
+    add((size_t)batch * TP * mp * 8 * 2);                  // W1, W2
+    return t + 4096 + trd_scratch_bytes(batch, ld);
+}
+
+int trd_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out)
+{
+    IMCOM_REQUIRE(ld % NB == 0 && ld >= NB && mp % NB == 0, "tridiag: ld=%d, mp=%d must be multiples of %d", ld, mp, NB);
+    const size_t mat = (size_t)batch * ld * ld * 8, vecb = (size_t)batch * ld * 8;
+    const int npanels = (ld + TP - 1) / TP;
+    out->Vall = (double *)ws_take(ctx, mat);
+    out->dvec = (double *)ws_take(ctx, vecb);
+    out->evec = (double *)ws_take(ctx, vecb);
+    out->tauvec = (double *)ws_take(ctx, vecb);
+    out->n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
+    out->Tm = (double *)ws_take(ctx, (size_t)batch * npanels * TP * TP * 8);
+    out->Sm = (double *)ws_take(ctx, (size_t)batch * TP * TP * 8);
+    out->W1 = (double *)ws_take(ctx, (size_t)batch * TP * mp * 8);
+    out->W2 = (double *)ws_take(ctx, (size_t)batch * TP * mp * 8);
+    out->ld = ld;
+    out->nmax = 0;
+    for (int s = 0; s < batch; s++) out->nmax = std::max(out->nmax, n_host[s]);
+    out->npanels = (std::max(out->nmax - 2, 0) + TP - 1) / TP;
+    if (!out->Vall || !out->dvec || !out->evec || !out->tauvec || !out->n_dev || !out->Tm || !out->Sm || !out->W1 || !out->W2) {
+        set_error("internal: tridiag workspace");
+        return IMCOM_ERR_NOMEM;
+    }
+    hipStream_t st = ctx->stream;
+    IMCOM_TRY(upload(ctx, out->n_dev, n_host, (size_t)batch));
+    const size_t mark = ctx->ws_used;
+    TrdScratch t;
+    if (!trd_take_scratch(ctx, batch, ld, &t)) { set_error("internal: tridiag workspace"); return IMCOM_ERR_NOMEM; }
+    IMCOM_TRY(trd_reduce(ctx, batch, out->nmax, ld, A, lda, strideA, out->n_dev, t, out->Vall, out->dvec, out->evec, out->tauvec, nullptr));
+    ctx->ws_used = mark;  // the scratch is free again (everything queued so far runs before whatever reuses it, same stream)
+    // the panels' triangular factors, once for both directions
+    ProfScope ps_(ctx, "eigen_applyq");
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TP * TP * 8));
+    for (int p = 0; p < out->npanels; p++) {
+        const int ps = p * TP, rem = ld - ps;
+        const double *Vp = out->Vall + (long)ps * ld + ps;
+        IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, rem, batch, Vp, ld, (long)ld * ld, Vp, ld, (long)ld * ld, out->Sm, TP, (long)TP * TP, 1.0, 0.0));
+        hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), TP * TP * 8, st, out->Sm, out->tauvec, ld, ps, out->Tm + (size_t)p * batch * TP * TP);
+        IMCOM_TRY(check_launch("trd_larft_kernel"));
+    }
+    return IMCOM_OK;
+}
+
+// C [batch][ld][mp] <- Qh^T C (transpose) or Qh C: Qh = H_0 H_1 ... and a panel's H_ps ... H_pe-1 = I - V T V^T, so
+//   Qh^T C: panels in ascending order, C[ps:] -= V^T (T^T (V C[ps:]));   Qh C: descending order, C[ps:] -= V^T (T (V C[ps:]))
+int trd_apply_q(imcom_ctx *ctx, const TrdBasis &b, int batch, double *C, int mp, bool transpose)
+{
+    ProfScope ps_(ctx, "eigen_applyq");
+    const int ld = b.ld;
+    for (int q = 0; q < b.npanels; q++) {
+        const int p = transpose ? q : b.npanels - 1 - q, ps = p * TP, rem = ld - ps;
+        const double *Vp = b.Vall + (long)ps * ld + ps;  // [TP][rem] with row stride ld: reflectors ps.., components ps..
+        const double *Tm = b.Tm + (size_t)p * batch * TP * TP;
+        double *Cp = C + (long)ps * mp;
+        IMCOM_TRY(launch_gemm(ctx, false, true, TP, mp, rem, batch, Vp, ld, (long)ld * ld, Cp, mp, (long)ld * mp, b.W1, mp, (long)TP * mp, 1.0, 0.0));
+        IMCOM_TRY(launch_gemm(ctx, transpose, true, TP, mp, TP, batch, Tm, TP, (long)TP * TP, b.W1, mp, (long)TP * mp, b.W2, mp, (long)TP * mp, 1.0, 0.0));
+        IMCOM_TRY(launch_gemm(ctx, true, true, rem, mp, TP, batch, Vp, ld, (long)ld * ld, b.W2, mp, (long)TP * mp, Cp, mp, (long)ld * mp, -1.0, 1.0));
+    }
+    return IMCOM_OK;
+}
+
+size_t tridiag_ws_bytes(int batch, int ld, bool vectors)
+{
+    const int ldr = ld + 2 * ROTPAD;
+    size_t t = trd_scratch_bytes(batch, ld);
+    auto add = [&](size_t b) { t = align_up(t, 256) + b; };
+    add((size_t)batch * ld * ld * 8);                      // Vall
+    if (vectors) add((size_t)batch * ld * ld * 8 + (size_t)batch * ld * 8);  // X + one scratch row per stamp
+    if (vectors) { add((size_t)batch * ld * TP * 8); add((size_t)batch * ld * TP * 8); }  // W1, W2
+    if (vectors) { add((size_t)batch * TP * TP * 8); add((size_t)batch * TP * TP * 8); }  // S, T
+    for (int q = 0; q < 3; q++) add((size_t)batch * ld * 8);  // d, e, tau
     if (vectors) add((size_t)batch * QRS * ldr * 16 * QR_RING);  // rotation logs
     add((size_t)QR_RING * batch * 3 * 4);                  // per-slot {LO, HI, dirty}
     add((size_t)batch * 8 * 4 + (size_t)batch * 8 + (size_t)batch * 4);  // state, tol, n
@@ -668,12 +823,12 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
 {
     IMCOM_REQUIRE(ld % NB == 0 && ld >= NB, "tridiag: ld=%d must be a multiple of %d", ld, NB);
     const bool vectors = Q != nullptr;
-    const int ldr = ld + 2 * ROTPAD, npart = (ld + 255) / 256;
+    const int ldr = ld + 2 * ROTPAD;
     const size_t mat = (size_t)batch * ld * ld * 8, vecb = (size_t)batch * ld * 8;
-    double *At = (double *)ws_take(ctx, mat), *Vall = (double *)ws_take(ctx, mat);
+    TrdScratch t;
+    const bool have_scratch = trd_take_scratch(ctx, batch, ld, &t);
+    double *Vall = (double *)ws_take(ctx, mat);
     double *X = vectors ? (double *)ws_take(ctx, mat + (size_t)batch * ld * 8) : nullptr;
-    double *Wp = (double *)ws_take(ctx, (size_t)batch * TPL * ld * 8);
-    double *part = (double *)ws_take(ctx, (size_t)batch * (ld / 32) * ld * 8);
     double *W1 = nullptr, *W2 = nullptr, *Sm = nullptr, *Tm = nullptr;
     if (vectors) {
         W1 = (double *)ws_take(ctx, (size_t)batch * ld * TP * 8);
@@ -681,19 +836,15 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
         Sm = (double *)ws_take(ctx, (size_t)batch * TP * TP * 8);
         Tm = (double *)ws_take(ctx, (size_t)batch * TP * TP * 8);
     }
-    double *ubuf = (double *)ws_take(ctx, vecb), *pvec = (double *)ws_take(ctx, vecb), *wprime = (double *)ws_take(ctx, vecb);
     double *dvec = (double *)ws_take(ctx, vecb), *evec = (double *)ws_take(ctx, vecb), *tauvec = (double *)ws_take(ctx, vecb);
-    double *wv = (double *)ws_take(ctx, (size_t)batch * 2 * TP * 8);
-    double *hd = (double *)ws_take(ctx, (size_t)batch * 4 * 8);
-    double *pnorm = (double *)ws_take(ctx, (size_t)batch * npart * 8), *pdot = (double *)ws_take(ctx, (size_t)batch * npart * 8);
     double2 *cs = vectors ? (double2 *)ws_take(ctx, (size_t)batch * QRS * ldr * 16 * QR_RING) : nullptr;
     int *info = (int *)ws_take(ctx, (size_t)QR_RING * batch * 3 * 4);
     int *state = (int *)ws_take(ctx, (size_t)batch * 8 * 4);
     double *tolv = (double *)ws_take(ctx, (size_t)batch * 8);
     int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
     int *rank = (int *)ws_take(ctx, (size_t)batch * ld * 4);
-    if (!At || !Vall || (vectors && (!X || !W1 || !W2 || !Sm || !Tm || !cs)) || !Wp || !part || !ubuf || !pvec || !wprime || !dvec || !evec ||
-        !tauvec || !wv || !hd || !pnorm || !pdot || !info || !state || !tolv || !n_dev || !rank) {
+    if (!have_scratch || !Vall || (vectors && (!X || !W1 || !W2 || !Sm || !Tm || !cs)) || !dvec || !evec || !tauvec || !info || !state || !tolv ||
+        !n_dev || !rank) {
         set_error("internal: tridiag workspace");
         return IMCOM_ERR_NOMEM;
     }
@@ -702,43 +853,7 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
     hipStream_t st = ctx->stream;
     IMCOM_HIP_CHECK(hipMemcpyAsync(n_dev, n_host, (size_t)batch * 4, hipMemcpyHostToDevice, st));
     IMCOM_HIP_CHECK(hipStreamSynchronize(st));  // n_host may be a caller local
-    IMCOM_HIP_CHECK(hipMemsetAsync(Vall, 0, mat, st));
-    for (double *v : {ubuf, pvec, wprime, dvec, evec, tauvec}) IMCOM_HIP_CHECK(hipMemsetAsync(v, 0, vecb, st));
-    IMCOM_HIP_CHECK(hipMemsetAsync(hd, 0, (size_t)batch * 32, st));
-    hipLaunchKernelGGL(trd_init_kernel, dim3((ld + 255) / 256, ld, batch), dim3(256), 0, st, A, lda, strideA, n_dev, At, X, ld);
-    IMCOM_TRY(check_launch("trd_init_kernel"));
-
-    // ---- tridiagonalisation
-    {
-        ProfScope ps_(ctx, "eigen_trd", nmax);
-        for (int ps = 0; ps < nmax; ps += TPL) {
-            const int pe = std::min(ps + TPL, nmax);
-            IMCOM_HIP_CHECK(hipMemsetAsync(Wp, 0, (size_t)batch * TPL * ld * 8, st));
-            for (int j = ps; j < pe; j++) {
-                hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
-                                   n_dev, ld, j, ps, npart, 1);
-                if (j + 1 >= nmax) break;
-                const int nrowtiles = ((nmax - 1) >> 5) - ((j + 1) >> 5) + 1, ndot = (2 * (j - ps) + 3) / 4;
-                hipLaunchKernelGGL(trd_symv_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, Vall, Wp, ubuf, pnorm, pvec, part, hd,
-                                   evec, tauvec, wv, n_dev, ld, j, ps, npart, nrowtiles);
-                hipLaunchKernelGGL(trd_w_kernel, dim3(npart, batch), dim3(256), 0, st, Vall, Wp, ubuf, pvec, hd, wv, part, wprime, pdot, n_dev, ld,
-                                   j, ps, npart);
-            }
-            IMCOM_TRY(check_launch("trd column step"));
-            if (ps + TPL < nmax) {  // trailing two-sided update A[pe:, pe:] -= V W^T + W V^T
-                const int pe2 = ps + TPL;
-                hipLaunchKernelGGL(trd_column_kernel, dim3(npart, batch), dim3(256), 0, st, At, Vall, Wp, wprime, ubuf, dvec, hd, pdot, pnorm,
-                                   n_dev, ld, pe2, ps, npart, 0);
-                // The GEMM tiles are 128-aligned: start at the tile boundary at or below pe.  The extra rows/columns
-                // it touches are already reduced and only ever read again under a zero multiplier.
-                const int pa = pe2 / NB * NB, rem = ld - pa;
-                const double *Vp = Vall + (long)ps * ld + pa, *Wq = Wp + pa;
-                double *C = At + (long)pa * ld + pa;
-                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TPL, batch, Vp, ld, (long)ld * ld, Wq, ld, (long)TPL * ld, C, ld, (long)ld * ld, -1.0, 1.0));
-                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, TPL, batch, Wq, ld, (long)TPL * ld, Vp, ld, (long)ld * ld, C, ld, (long)ld * ld, -1.0, 1.0));
-            }
-        }
-    }
+    IMCOM_TRY(trd_reduce(ctx, batch, nmax, ld, A, lda, strideA, n_dev, t, Vall, dvec, evec, tauvec, X));
 
     // ---- X = Qh^T: X <- X (I - V T^T V^T) panel by panel, last panel first
     if (vectors) {

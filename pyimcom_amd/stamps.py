@@ -687,16 +687,10 @@ class StampBatch:
     def _solve_target(self, Bt, Cs, Tt, UC, Sigma, kappa, info):
         cfg = self.cfg
         if cfg.kernel == "Eigen":
-            # lakernel.EigenKernel (lakernel.py:141-223) on device pointers.  imcom_solve_eigen speaks the
-            # reference layout (-B/2 as [m][N], T as [m][N]); torch only re-strides the buffers.
-            mB = Bt[:, :, : self.m].transpose(1, 2).contiguous()
-            T = torch.empty((self.batch, self.m, self.ldn), dtype=torch.float32, device=self.dev)
-            check(lib.imcom_solve_eigen(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, _dp(self.A), _dp(mB),
-                                        _hp(Cs), _hp(self.kappaC), len(self.kappaC), float(cfg.uctarget),
-                                        float(cfg.sigmamax), 13, _dp(T), _dp(UC), _dp(Sigma), _dp(kappa),
-                                        _hp(info), 1))
-            Tt.zero_()
-            Tt[:, :, : self.m] = T.transpose(1, 2)
+            # lakernel.EigenKernel (lakernel.py:141-223) on the resident layouts
+            check(lib.imcom_solve_eigen_resident(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, _dp(self.A), _dp(Bt),
+                                                 _hp(Cs), _hp(self.kappaC), len(self.kappaC), float(cfg.uctarget), float(cfg.sigmamax), 13,
+                                                 _dp(Tt), _dp(UC), _dp(Sigma), _dp(kappa), _hp(info)))
         elif cfg.kernel in ("Iterative", "Empirical"):
             # lakernel.IterKernel / EmpirKernel (lakernel.py:533-805) on device pointers; the output pixel centres
             # are the integer grid starting at (out_y0, out_x0), the acceptance radius is INPAD in output pixels
