@@ -40,6 +40,15 @@ __global__ __launch_bounds__(256) void tri_pack_kernel(const double *__restrict_
     }
 }
 
+// 1 / x for the pivots of the search sweeps: hardware reciprocal + two Newton steps (relative error ~1e-16; the dependent
+// chain of the sweep is a third shorter than with the IEEE division sequence).  The final solve divides exactly.
+__device__ __forceinline__ double fast_recip(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 // One forward sweep of the LDL^T of T + kappa I against c, with its kappa-derivative:
 //   delta_0 = d_0 + kappa, l_i = e_i / delta_i, delta_{i+1} = d_{i+1} + kappa - l_i e_i, z_{i+1} = c_{i+1} - l_i z_i
 //   D = sum z_i^2 / delta_i = c^T (T + kappa)^-1 c,     S = -dD/dkappa = c^T (T + kappa)^-2 c
@@ -51,7 +60,7 @@ __device__ __forceinline__ void tri_sweep(const double *__restrict__ d, const do
     S = 0.0;
     for (int i = 0; i < ns; i++) {
         const double cnext = i + 2 < ns ? c[(long)(i + 2) * cstride] : 0.0;  // one row ahead of its use
-        const double r = 1.0 / delta, t = z * r;
+        const double r = fast_recip(delta), t = z * r;
         D += z * t;
         S += t * (t * dp - 2.0 * zp);
         if (i + 1 < ns) {

@@ -29,6 +29,7 @@ constexpr int TPL = 64;         // reflectors per tridiagonalisation panel (the 
 constexpr int QRS = 16;         // QR sweeps per chunk = depth of the rotation wavefront
 constexpr int ROTPAD = 4 * QRS; // identity margin of the rotation log on both sides
 constexpr int QR_RING = 4;      // rotation logs in flight between the QR chain and the rotation kernels
+constexpr int LARFT_LDS = TP * (TP + 1) * 8;  // trd_larft_kernel: T with padded rows
 
 // ascending rank of every eigenvalue (ties by index), lam[rank] = value
 __global__ void eig_rank_kernel(const double *__restrict__ lam_raw, int ld, const int *__restrict__ n,
@@ -335,24 +336,25 @@ __global__ __launch_bounds__(256) void trd_w_kernel(double *__restrict__ Vall, c
 __global__ __launch_bounds__(128) void trd_larft_kernel(const double *__restrict__ S, const double *__restrict__ tauvec, int ld,
                                                         int ps, double *__restrict__ T)
 {
-    extern __shared__ double Ts[];  // [TP][TP]
+    // T in LDS as [TP][TP + 1]: thread r walks row r, stride 129 doubles = conflict free; S[q][c] has the same address in every
+    // lane (scalar loads).  Row r of T depends on row r alone, so the 128 column steps need no barrier.  (The first version
+    // kept T unpadded and synchronised twice per step: 685 us per panel.)
+    extern __shared__ double Ts[];
     const int s = blockIdx.x, r = threadIdx.x;
     const double *Ss = S + (long)s * TP * TP;
-    for (int q = 0; q < TP; q++) Ts[r * TP + q] = 0.0;
-    __syncthreads();
+    for (int q = 0; q < TP; q++) Ts[r * (TP + 1) + q] = 0.0;
     for (int c = 0; c < TP; c++) {
         const int j = ps + c;
         const double tau = j < ld ? tauvec[(long)s * ld + j] : 0.0;
         double t = 0.0;
         if (r < c) {
-            for (int q = r; q < c; q++) t += Ts[r * TP + q] * Ss[(long)q * TP + c];
+            for (int q = 0; q < c; q++) t += Ts[r * (TP + 1) + q] * Ss[(long)q * TP + c];  // (T[r][q] = 0 for q < r: uniform trip count and addresses of S)
             t *= -tau;
         } else if (r == c) t = tau;
-        __syncthreads();
-        if (r <= c) Ts[r * TP + c] = t;
-        __syncthreads();
+        if (r <= c) Ts[r * (TP + 1) + c] = t;  // row r of T depends on row r alone: no barrier in this loop
     }
-    for (int q = 0; q < TP; q++) T[(long)s * TP * TP + (long)r * TP + q] = Ts[r * TP + q];
+    __syncthreads();
+    for (int q = 0; q < TP; q++) T[(long)s * TP * TP + (long)q * TP + r] = Ts[q * (TP + 1) + r];
 }
 
 // One Givens step of the implicit QR bulge chase at position k of the block [lo, hi].  Carried state: (x, z) the
@@ -769,12 +771,12 @@ int trd_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int m
     ctx->ws_used = mark;  // the scratch is free again (everything queued so far runs before whatever reuses it, same stream)
     // the panels' triangular factors, once for both directions
     ProfScope ps_(ctx, "eigen_applyq");
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TP * TP * 8));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LARFT_LDS));
     for (int p = 0; p < out->npanels; p++) {
         const int ps = p * TP, rem = ld - ps;
         const double *Vp = out->Vall + (long)ps * ld + ps;
         IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, rem, batch, Vp, ld, (long)ld * ld, Vp, ld, (long)ld * ld, out->Sm, TP, (long)TP * TP, 1.0, 0.0));
-        hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), TP * TP * 8, st, out->Sm, out->tauvec, ld, ps, out->Tm + (size_t)p * batch * TP * TP);
+        hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), LARFT_LDS, st, out->Sm, out->tauvec, ld, ps, out->Tm + (size_t)p * batch * TP * TP);
         IMCOM_TRY(check_launch("trd_larft_kernel"));
     }
     return IMCOM_OK;
@@ -858,14 +860,14 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
     // ---- X = Qh^T: X <- X (I - V T^T V^T) panel by panel, last panel first
     if (vectors) {
         ProfScope ps_(ctx, "eigen_orgtr");
-        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TP * TP * 8));
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LARFT_LDS));
         const int npanels = (std::max(nmax - 2, 0) + TP - 1) / TP;
         for (int p = npanels - 1; p >= 0; p--) {
             const int ps = p * TP, rem = ld - ps;
             const double *Vp = Vall + (long)ps * ld + ps;  // rows (reflectors) ps.., components ps..
             double *Xb = X + (long)ps * ld + ps;
             IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, rem, batch, Vp, ld, (long)ld * ld, Vp, ld, (long)ld * ld, Sm, TP, (long)TP * TP, 1.0, 0.0));
-            hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), TP * TP * 8, st, Sm, tauvec, ld, ps, Tm);
+            hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), LARFT_LDS, st, Sm, tauvec, ld, ps, Tm);
             IMCOM_TRY(check_launch("trd_larft_kernel"));
             IMCOM_TRY(launch_gemm(ctx, false, false, rem, TP, rem, batch, Xb, ld, (long)ld * ld, Vp, ld, (long)ld * ld, W1, TP, (long)ld * TP, 1.0, 0.0));
             IMCOM_TRY(launch_gemm(ctx, false, false, rem, TP, TP, batch, W1, TP, (long)ld * TP, Tm, TP, (long)TP * TP, W2, TP, (long)ld * TP, 1.0, 0.0));
