@@ -340,19 +340,23 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     return chunks
 
 
-def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None, chunks=None):
+def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None, chunks=None,
+                claim=None):
     """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
     order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables or BlockTables.  ``stamps``: the (j_st, i_st) to
     coadd (default all n1P x n1P); ``pad_sides=None`` leaves the boundary recovery of coadd.py:2163-2181 out.  ``batch``:
-    stamps per pass, or ``chunks``: the passes themselves (default: ``plan_block``).  Returns the BlockMaps."""
+    stamps per pass, or ``chunks``: the passes themselves (default: ``plan_block``).  ``claim(q) -> bool`` (optional) is asked
+    right before pass q is prepared; a pass it refuses is left out (another process coadds it: pyimcom_amd.farm shares a block's
+    passes between the GPUs of a node) -- the passes that were run are listed in ``maps.chunks_done``.  Returns the BlockMaps."""
     nst = n1P + 2
     assert pool.n_inst == nst * nst
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
                      n_out=int(getattr(tables, "n_out", 1)))
     if chunks is None:
         chunks = plan_block(cfg, pool, tables, n1P, batch, ldn, stamps)
-    chunks = [[(int(j), int(i)) for j, i in c] for c in chunks if len(c)]
-    if isinstance(tables, BlockTables) and chunks:
+    chunks = [[(int(j), int(i)) for j, i in c] for c in chunks]
+    maps.chunks_done = []
+    if isinstance(tables, BlockTables) and chunks and claim is None:
         # the PSF groups of the first batches are sampled / transformed before the host turns to the per-stamp bookkeeping
         tables.prefetch(dict.fromkeys(g for c in chunks[:2] for t in c for g in stamp_groups(t[0], t[1], nst)))
     # two sets of the large per-batch arrays, used alternately (batch k + 1 is prepared while batch k is solved) and kept from
@@ -370,23 +374,34 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
             b_.take("A", (bmax, ld_pre, ld_pre), torch.float64)
             b_.take("Bt", (O, bmax, ld_pre, ldm), torch.float64)
             b_.take("Tt", (O, bmax, ld_pre, ldm), torch.float32)
-    prepare = lambda q: prepare_batch(cfg, pool, tables, chunks[q], n1P, n_expo, ldn, buffers=bufs[q & 1])  # noqa: E731
+    todo = iter(range(len(chunks)))
+    count = [0]
+
+    def next_batch():
+        for q in todo:  # the next pass this process may run
+            if chunks[q] and (claim is None or claim(q)):
+                sb = prepare_batch(cfg, pool, tables, chunks[q], n1P, n_expo, ldn, buffers=bufs[count[0] & 1])
+                sb.chunk_index = q
+                count[0] += 1
+                return sb
+        return None
 
     # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after
     # the current one's A and B builds have been queued, i.e. while the GPU is busy with them; only then does the host
     # block in the solve's status read-back
-    nxt = prepare(0) if chunks else None
-    for k in range(len(chunks)):
+    nxt = next_batch()
+    while nxt is not None:
         sb = nxt
         sb.build()
         if pipeline:
-            nxt = prepare(k + 1) if k + 1 < len(chunks) else None
+            nxt = next_batch()
         sb.solve()
         check_batch(sb)
         sb.coadd()
         if not pipeline:
-            nxt = prepare(k + 1) if k + 1 < len(chunks) else None
+            nxt = next_batch()
         maps.add(sb.results(), [j for j, _ in sb.chunk], [i for _, i in sb.chunk])
+        maps.chunks_done.append(sb.chunk_index)
     if pad_sides is not None:
         maps.finalize(pad_sides, postage_pad)
     return maps

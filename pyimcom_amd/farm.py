@@ -1,4 +1,5 @@
-"""Block farming over the GPUs of a node: one process per GPU, static partition, no data-path collective.
+"""Block farming over the GPUs of a node: one process per GPU, blocks claimed on start (or a static partition), no data-path
+collective.
 
 The reference's only parallelism is one OS process per block (docs/run_README.rst:81-100,
 examples/multiblock_norep.pl:42-66); blocks share read-only inputs and write separate outputs, so ranks never
@@ -68,44 +69,337 @@ def write_block(path, maps, meta=None):
     os.replace(tmp, path)
 
 
-def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=None, restart=True, log=print, coadd=None):
+# ---- dynamic schedule: blocks claimed on start, the passes of a block shared when whole blocks run out ------------------
+#
+# Coordination is by files in a hidden directory of the output directory (atomic O_EXCL creation = a claim; atomic rename =
+# a result) -- the reference's own mechanism, generalised: its block runner skips a block whose output file exists
+# (examples/multiblock_norep.pl:25-27).  No rank ever waits for another and nothing is exchanged between ranks in memory.
+#
+#   .farm-<token>/b<id>.claim          a rank has taken block <id> (it builds the inputs, plans the passes, writes the plan)
+#   .farm-<token>/b<id>.plan.json      the block's passes (lists of stamps): helpers run the same plan
+#   .farm-<token>/b<id>.c<q>.claim     pass q of the block is taken
+#   .farm-<token>/b<id>.part.<rank>.npz  a rank's partial block maps (the sum of the passes it ran) + the list of those passes
+#   .farm-<token>/b<id>.merge          the rank that found every pass of the block in part files and sums them
+#
+# A rank walks the blocks in order of decreasing cost and claims the first free one (list scheduling: what a static LPT
+# partition computes in advance, but from the real durations); when no unclaimed block is left it joins the blocks still in
+# progress, most remaining work first, and takes passes from the END of their plans while their owners walk from the front.
+# Partial maps are sums over stamps, so parts add up to the block's maps; the boundary recovery runs once, on the sum.  A
+# block that one rank coadded alone is bit-identical to the static schedule's; a shared block differs by float32 rounding
+# where stamps of different parts overlap.  <token> identifies the launch (default: the parent process id, which the ranks
+# of one torch.distributed.run share): claims of a killed launch never block a restart, finished blocks are skipped by
+# their output files.
+def _try_create(path, text=""):
+    import os
+
+    try:
+        fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+    except FileExistsError:
+        return False
+    with os.fdopen(fd, "w") as f:
+        f.write(text)
+    return True
+
+
+def _atomic_write(path, write):
+    import os
+
+    tmp = f"{path}.tmp{os.getpid()}"
+    write(tmp)
+    os.replace(tmp, path)
+
+
+def _save_npz(path, arrays):
+    """np.savez under a temporary name, then renamed: a reader never sees a partial file."""
+    import os
+
+    import numpy as np
+
+    tmp = f"{path}.tmp{os.getpid()}.npz"
+    np.savez(tmp, **arrays)
+    os.replace(tmp, path)
+
+
+class _GpuBackend:
+    """How the driver touches the device; the host-logic tests substitute plain-Python stand-ins."""
+
+    def __init__(self, batch):
+        self.batch = batch
+
+    def plan(self, spec):
+        from .blockrun import plan_block
+
+        return plan_block(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], self.batch)
+
+    def coadd(self, spec, chunks, claim):
+        """-> ({name: array}, passes run): partial maps, not recovered at the block boundary."""
+        import torch
+
+        from .blockrun import coadd_block
+
+        maps = coadd_block(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], spec["n_expo"], chunks=chunks, claim=claim, pad_sides=None)
+        torch.cuda.synchronize()
+        out = {"out_map": maps.out_map.cpu().numpy(), "T_weightmap": maps.T_weightmap.cpu().numpy()}
+        out.update({k: v.cpu().numpy() for k, v in maps.maps.items()})
+        return out, list(maps.chunks_done)
+
+    def finalize(self, spec, arrays):
+        """Boundary recovery (coadd.py:2163-2181) of summed partial maps -> the block's arrays."""
+        import torch
+
+        from .block import BlockMaps
+
+        cfg = spec["cfg"]
+        n_out = arrays["out_map"].shape[0]
+        maps = BlockMaps(spec["n1P"], cfg.n2, cfg.fade, cfg.n_inframe, spec["n_expo"], ctx=spec["tables"].ctx, device=str(spec["pool"].device), n_out=n_out)
+        maps.out_map.copy_(torch.as_tensor(arrays["out_map"]))
+        maps.T_weightmap.copy_(torch.as_tensor(arrays["T_weightmap"]))
+        for k in maps.maps:
+            maps.maps[k].copy_(torch.as_tensor(arrays[k]))
+        maps.finalize(spec.get("pad_sides", ""), spec.get("postage_pad", 0))
+        torch.cuda.synchronize()
+        out = {"out_map": maps.out_map.cpu().numpy(), "T_weightmap": maps.T_weightmap.cpu().numpy()}
+        out.update({k: v.cpu().numpy() for k, v in maps.maps.items()})
+        return out
+
+
+class _Prefetch:
+    """make_block(b) split in a host part and a device part (optional attributes ``make_block.host(b)`` and
+    ``make_block.device(b, host_data)``): the host part of the block a rank will probably take next runs on a thread while
+    the current block is on the GPU."""
+
+    def __init__(self, make_block, enabled):
+        self.mk = make_block
+        self.split = enabled and hasattr(make_block, "host") and hasattr(make_block, "device")
+        self.b, self.thread, self.box = None, None, {}
+
+    def start(self, b):
+        import threading
+
+        if not self.split or b is None or self.b == b:
+            return
+        self.join()
+        self.b, self.box = b, {}
+
+        def work(b=b, box=self.box):
+            try:
+                box["host"] = self.mk.host(b)
+            except Exception as exc:  # re-raised by get() on the main thread
+                box["error"] = exc
+
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+
+    def join(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+
+    def get(self, b):
+        if not self.split:
+            return self.mk(b)
+        if self.b == b:
+            self.join()
+            box, self.b = self.box, None
+            if "error" in box:
+                raise box["error"]
+            return self.mk.device(b, box["host"])
+        return self.mk.device(b, self.mk.host(b))
+
+
+def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=None, restart=True, log=print, coadd=None,
+        schedule="dynamic", token=None, backend=None, prefetch=True):
     """Coadd this rank's share of `blocks` (ids) and write block_<id>.npz files into `outdir`.
 
-    costs[k]: relative cost of blocks[k] (estimate_cost summed over its stamps) for the static LPT partition;
+    costs[k]: relative cost of blocks[k] (estimate_cost summed over its stamps);
     make_block(b) -> dict(cfg=, pool=, tables=, n1P=, n_expo=, [pad_sides=, postage_pad=, meta=]) -- the arguments of
-    pyimcom_amd.blockrun.coadd_block -- called on the rank that owns b, right before b is coadded;
-    restart: skip blocks whose file exists (multiblock_norep.pl:25-27).  `coadd` replaces
-    pyimcom_amd.blockrun.coadd_block (the host-logic tests run the driver without a GPU that way).
-    Returns the list of block ids done here."""
+    pyimcom_amd.blockrun.coadd_block -- called on a rank that works on b, right before it starts;
+    restart: skip blocks whose file exists (multiblock_norep.pl:25-27).
+    schedule "dynamic" (default): blocks are claimed on start in order of decreasing cost and the passes of the last blocks
+    are shared (see above); "static": the longest-processing-time partition of `costs`, computed identically by every rank
+    -- no files besides the outputs.  `coadd` (static) / `backend` (dynamic) replace the device calls (the host-logic tests run
+    the driver without a GPU that way).  Returns the list of block ids whose output file this rank wrote."""
+    import json
     import os
     import time
 
-    import torch
+    import numpy as np
 
     os.makedirs(outdir, exist_ok=True)
-    on_gpu = coadd is None
+    on_gpu = coadd is None and backend is None
     if on_gpu:
-        from .blockrun import coadd_block as coadd
+        import torch
 
         dev = device or f"cuda:{rank % max(torch.cuda.device_count(), 1)}"
         torch.cuda.set_device(dev)
-    mine = [blocks[k] for k in my_units(costs, rank, world)]
+    t_start, busy = time.perf_counter(), 0.0
     done = []
-    for b in mine:
-        path = block_path(outdir, b)
-        if restart and os.path.exists(path):
-            log(f"[farm rank {rank}] block {b}: {path} exists, skipped")
-            continue
+    if schedule == "static":
+        if coadd is None:
+            from .blockrun import coadd_block as coadd
+        for b in [blocks[k] for k in my_units(costs, rank, world)]:
+            path = block_path(outdir, b)
+            if restart and os.path.exists(path):
+                log(f"[farm rank {rank}] block {b}: {path} exists, skipped")
+                continue
+            t0 = time.perf_counter()
+            spec = make_block(b)
+            maps = coadd(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], spec["n_expo"], batch=batch,
+                         pad_sides=spec.get("pad_sides", ""), postage_pad=spec.get("postage_pad", 0))
+            if on_gpu:
+                torch.cuda.synchronize()
+            write_block(path, maps, spec.get("meta"))
+            done.append(b)
+            busy += time.perf_counter() - t0
+            log(f"[farm rank {rank}] block {b}: {spec['n1P'] ** 2} stamps, {spec['n_expo']} exposures, {time.perf_counter() - t0:.2f} s -> {path}")
+        log(f"[farm rank {rank}] busy {busy:.2f} s of {time.perf_counter() - t_start:.2f} s (static schedule)")
+        return done
+    assert schedule == "dynamic"
+    be = backend or _GpuBackend(batch)
+    token = str(token if token is not None else os.environ.get("IMCOM_FARM_RUN", os.getppid()))
+    cdir = os.path.join(outdir, f".farm-{token}")
+    os.makedirs(cdir, exist_ok=True)
+    cp = lambda b, what: os.path.join(cdir, f"b{int(b):04d}.{what}")  # noqa: E731
+    order = [blocks[k] for k in sorted(range(len(blocks)), key=lambda k: (-costs[k], k))]
+    cost_of = dict(zip(blocks, costs))
+    pre = _Prefetch(make_block, prefetch)
+
+    done_parts = []
+
+    def finished(b):  # by this launch, or (restart) by an earlier one
+        return os.path.exists(cp(b, "done")) or (restart and os.path.exists(block_path(outdir, b)))
+
+    def free_blocks():
+        return [b for b in order if not finished(b) and not os.path.exists(cp(b, "claim"))]
+
+    def run_passes(b, spec, chunks, from_end):
+        """Claim and run passes of block b, write the part file, try to merge.  -> passes run"""
+        nonlocal busy
+        idx = list(range(len(chunks)))
+        if from_end:
+            idx.reverse()
+        view = [chunks[q] for q in idx]
         t0 = time.perf_counter()
-        spec = make_block(b)
-        maps = coadd(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], spec["n_expo"], batch=batch,
-                     pad_sides=spec.get("pad_sides", ""), postage_pad=spec.get("postage_pad", 0))
-        if on_gpu:
-            torch.cuda.synchronize()
-        write_block(path, maps, spec.get("meta"))
-        done.append(b)
-        log(f"[farm rank {rank}] block {b}: {spec['n1P'] ** 2} stamps, {spec['n_expo']} exposures, {time.perf_counter() - t0:.2f} s -> {path}")
+        arrays, ran = be.coadd(spec, view, lambda k: _try_create(cp(b, f"c{idx[k]:04d}.claim"), str(rank)))
+        ran = [idx[k] for k in ran]
+        busy += time.perf_counter() - t0
+        if ran:
+            _save_npz(cp(b, f"part.{rank}.{len(done_parts)}.npz"), dict(arrays, passes=np.asarray(ran)))
+            done_parts.append(b)
+        return ran
+
+    def try_merge(b, spec, nchunks):
+        nonlocal busy
+        parts = [f for f in os.listdir(cdir) if f.startswith(f"b{int(b):04d}.part.") and f.endswith(".npz")]
+        loaded = [np.load(os.path.join(cdir, f)) for f in parts]
+        have = sorted(int(q) for z in loaded for q in z["passes"])
+        if have != list(range(nchunks)) or not _try_create(cp(b, "merge"), str(rank)):
+            return False
+        t0 = time.perf_counter()
+        names = [k for k in loaded[0].files if k != "passes"]
+        total = {k: loaded[0][k].copy() for k in names}
+        for z in sorted(loaded[1:], key=lambda z_: int(z_["passes"][0])):  # a fixed order of the sum
+            for k in names:
+                total[k] += z[k]
+        out = be.finalize(spec, total)
+        for k, v in (spec.get("meta") or {}).items():
+            out["meta_" + k] = np.asarray(v)
+        out["meta_ranks"] = np.asarray(sorted(int(f.split(".")[2]) for f in parts))
+        _save_npz(block_path(outdir, b), out)
+        _try_create(cp(b, "done"), str(rank))
+        busy += time.perf_counter() - t0
+        return True
+
+    for b in order:
+        if restart and os.path.exists(block_path(outdir, b)):
+            log(f"[farm rank {rank}] block {b}: {block_path(outdir, b)} exists, skipped")
+    # phase 1: whole blocks, largest first
+    while True:
+        cand = free_blocks()
+        mine = next((b for b in cand if _try_create(cp(b, "claim"), str(rank))), None)
+        if mine is None:
+            break
+        t0 = time.perf_counter()
+        spec = pre.get(mine)
+        rest = [b for b in free_blocks() if b != mine]
+        pre.start(rest[0] if rest else None)  # the host part of the block this rank will most likely take next
+        chunks = be.plan(spec)
+        _atomic_write(cp(mine, "plan.json"), lambda tmp: json.dump([[list(map(int, t)) for t in c] for c in chunks], open(tmp, "w")))
+        ran = run_passes(mine, spec, chunks, from_end=False)
+        wrote = try_merge(mine, spec, len(chunks))
+        if wrote:
+            done.append(mine)
+        log(f"[farm rank {rank}] block {mine}: {len(ran)} of {len(chunks)} passes, {spec['n_expo']} exposures, {time.perf_counter() - t0:.2f} s"
+            + (f" -> {block_path(outdir, mine)}" if wrote else " (shared: merged by the rank that finishes last)"))
+    # phase 2: help with the blocks still in progress, most remaining work first
+    tried = set()
+    while True:
+        open_blocks = []
+        for b in order:
+            if b in tried or finished(b) or not os.path.exists(cp(b, "plan.json")) or os.path.exists(cp(b, "merge")):
+                continue
+            chunks = [[tuple(t) for t in c] for c in json.load(open(cp(b, "plan.json")))]
+            left = [q for q in range(len(chunks)) if not os.path.exists(cp(b, f"c{q:04d}.claim"))]
+            if left:
+                open_blocks.append((cost_of[b] * len(left) / len(chunks), -order.index(b), b, chunks))
+        if not open_blocks:
+            break
+        _, _, b, chunks = max(open_blocks, key=lambda t: t[:2])
+        tried.add(b)
+        t0 = time.perf_counter()
+        spec = pre.get(b)
+        ran = run_passes(b, spec, chunks, from_end=True)
+        wrote = try_merge(b, spec, len(chunks)) if ran else False
+        if wrote:
+            done.append(b)
+        log(f"[farm rank {rank}] block {b}: helped with {len(ran)} of {len(chunks)} passes, {time.perf_counter() - t0:.2f} s"
+            + (f" -> {block_path(outdir, b)}" if wrote else ""))
+    pre.join()
+    wall = time.perf_counter() - t_start
+    log(f"[farm rank {rank}] busy {busy:.2f} s of {wall:.2f} s ({100.0 * busy / max(wall, 1e-9):.0f} %), wrote {len(done)} block files")
     return done
+
+
+def simulate(costs, passes, world, overhead=0.0):
+    """Makespan of the dynamic schedule for blocks of cost `costs[k]` split in `passes[k]` equal passes on `world` ranks, every
+    rank following run()'s rules (largest free block first; then the block with the most work left, passes from the end; a
+    helper pays `overhead` -- building the block's inputs -- when it joins a block).  -> (makespan, per-rank busy time)"""
+    import heapq
+
+    n = len(costs)
+    order = sorted(range(n), key=lambda k: (-costs[k], k))
+    front, back = [0] * n, list(passes)  # [front, back): the passes nobody has taken (owner from the front, helpers from the end)
+    owner = {}
+    busy = [0.0] * world
+    ev = [(0.0, r, None) for r in range(world)]  # (time a rank becomes free, rank, block it is working on)
+    heapq.heapify(ev)
+    end = 0.0
+    while ev:
+        t, r, cur = heapq.heappop(ev)
+        end = max(end, t)
+        dt = None
+        if cur is not None and front[cur] < back[cur]:  # stay on the block: next pass
+            if owner[cur] == r:
+                front[cur] += 1
+            else:
+                back[cur] -= 1
+            dt = costs[cur] / passes[cur]
+        else:
+            nxt = next((k for k in order if k not in owner), None)
+            if nxt is not None:  # a whole block, largest first
+                owner[nxt] = r
+                front[nxt] += 1
+                cur, dt = nxt, costs[nxt] / passes[nxt]
+            else:  # help: the block with the most work left
+                left = [(costs[k] * (back[k] - front[k]) / passes[k], -order.index(k), k) for k in owner if front[k] < back[k]]
+                if left:
+                    cur = max(left)[2]
+                    back[cur] -= 1
+                    dt = overhead + costs[cur] / passes[cur]
+        if dt is not None:
+            busy[r] += dt
+            heapq.heappush(ev, (t + dt, r, cur))
+    return end, busy
 
 
 def synthetic_mosaic(config="cfg4", nblock=4, n1P=2, seed=4, psf_groups=False):
@@ -127,26 +421,36 @@ def synthetic_mosaic(config="cfg4", nblock=4, n1P=2, seed=4, psf_groups=False):
     n_pix = lambda e: e * (base.n2 + 2 * base.rho) ** 2 / p**2  # noqa: E731  input pixels of one stamp, roughly
     costs = [n1P * n1P * estimate_cost(n_pix(int(e)), base.m, len(base.kappaC)) for e in depth]
 
-    def make_block(b, device="cuda:0"):
+    def host(b):
+        """The host part of a block's inputs (InStamps, sampled PSFs): what a prefetch thread can prepare."""
+        E = int(depth[b])
+        cfg = dataclasses.replace(base, n_expo=E, name=f"{base.name}_b{b}")
+        inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng([seed, b]))
+        psfs, target = synth.make_psfs(cfg, E, seed=20260723 + b)
+        return cfg, inst, psfs, target
+
+    def device_part(b, host_data, device="cuda:0"):
         import torch
 
         from ._lib import default_context
         from .select import InStampPool
         from .stamps import BlockTables, PSFGroupTables
 
+        cfg, inst, psfs, target = host_data
         ctx = default_context(torch.device(device).index or 0)  # one context per GPU
         E = int(depth[b])
-        cfg = dataclasses.replace(base, n_expo=E, name=f"{base.name}_b{b}")
-        inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng([seed, b]))
-        psfs, target = synth.make_psfs(cfg, E, seed=20260723 + b)
         if psf_groups:
             ng = (n1P + 3) // 2
-            tables = BlockTables({(gj, gi): psfs for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, capacity=2048, ctx=ctx, device=device, cells=True)
+            tables = BlockTables({(gj, gi): psfs for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, ctx=ctx, device=device, cells=True)
         else:
             tables = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=device)
         return dict(cfg=cfg, pool=InStampPool(inst, cfg.n_inframe, device=device), tables=tables, n1P=n1P, n_expo=E,
                     meta=dict(block=b, n_expo=E, config=config))
 
+    def make_block(b, device="cuda:0"):
+        return device_part(b, host(b), device)
+
+    make_block.host, make_block.device = host, device_part
     return blocks, costs, make_block
 
 
@@ -167,13 +471,18 @@ def main(argv=None):
     ap.add_argument("--psf-groups", action="store_true", help="a PSF group per 2x2 InStamps (BlockTables) instead of one per block")
     ap.add_argument("--no-restart", action="store_true", help="recompute blocks whose output exists")
     ap.add_argument("--shared-gpu", action="store_true")
+    ap.add_argument("--schedule", choices=("dynamic", "static"), default="dynamic",
+                    help="dynamic: blocks claimed on start, passes of the last blocks shared; static: LPT partition of the estimated costs")
+    ap.add_argument("--token", default=None, help="identifies the launch for the dynamic schedule's claim files (default: the parent process id)")
     a = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if a.shared_gpu else int(os.environ.get("LOCAL_RANK", str(rank)))
     blocks, costs, make_block = synthetic_mosaic(a.config, a.mosaic, a.n1P, a.seed, a.psf_groups)
     dev = f"cuda:{local}"
-    done = run(blocks, costs, lambda b: make_block(b, dev), a.out, rank, world, a.batch, device=dev, restart=not a.no_restart)
-    print(f"[farm rank {rank}/{world}] done: {done}")
+    mk = lambda b: make_block(b, dev)  # noqa: E731
+    mk.host, mk.device = make_block.host, (lambda b, h: make_block.device(b, h, dev))
+    done = run(blocks, costs, mk, a.out, rank, world, a.batch, device=dev, restart=not a.no_restart, schedule=a.schedule, token=a.token)
+    print(f"[farm rank {rank}/{world}] done: {sorted(done)}")
     return 0
 
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _farm(out, rank, world, extra=()):
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "pyimcom_amd.farm", "--out", out, "--config", "smallm", "--mosaic", "2", "--n1P", "2", "--batch", "3",
-           "--shared-gpu", *extra]
+           "--shared-gpu", "--schedule", "static", *extra]
     return subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
 
@@ -49,6 +49,45 @@ def test_farm_two_processes_equal_one(tmp_path):
     o = p.communicate(timeout=600)[0]
     assert p.returncode == 0 and o.count("skipped") == 3 and "done: [2]" in o, o
     assert np.array_equal(np.load(farm.block_path(one, 2))["out_map"], keep)
+
+
+def test_farm_dynamic_schedule_shares_a_block(tmp_path):
+    """The dynamic schedule with more ranks than blocks left: ONE block of 6 x 6 stamps in passes of 5 stamps, two processes on
+    cuda:0.  The first rank to claim the block plans it; the other joins and takes passes from the end of the plan; the rank that
+    finds every pass in part files sums them, recovers the boundary and writes the block -- equal to the single process's
+    block up to the float32 rounding of the partial sums where stamps of different parts overlap."""
+    from pyimcom_amd import farm
+
+    def go(out, rank, world, token):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", PYTHONPATH=ROOT)
+        cmd = [sys.executable, "-m", "pyimcom_amd.farm", "--out", out, "--config", "small", "--mosaic", "1", "--n1P", "6", "--batch", "5",
+               "--shared-gpu", "--token", token, "--psf-groups"]
+        return subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+    two, one = str(tmp_path / "two"), str(tmp_path / "one")
+    procs = [go(two, r, 2, "t2") for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    p1 = go(one, 0, 1, "t1")
+    o1 = p1.communicate(timeout=600)[0]
+    assert p1.returncode == 0, o1
+    a, c = np.load(farm.block_path(two, 0)), np.load(farm.block_path(one, 0))
+    assert sorted(k for k in a.files if k != "meta_ranks") == sorted(k for k in c.files if k != "meta_ranks")
+    for k in c.files:
+        if k.startswith("meta_"):
+            continue
+        assert np.allclose(a[k], c[k], rtol=2e-6, atol=2e-6 * np.abs(c[k]).max()), k
+    assert np.isfinite(c["out_map"]).all() and np.abs(c["out_map"]).max() > 0
+    assert sum(o.count("done: [0]") for o in outs) == 1  # exactly one rank wrote the block
+    # both ranks worked on it unless one was so late that every pass was gone (then the block is the single process's, bit for bit)
+    ranks = a["meta_ranks"].tolist()
+    assert ranks in ([0], [1], [0, 1])
+    if len(ranks) == 1:
+        assert all(np.array_equal(a[k], c[k]) for k in c.files if not k.startswith("meta_"))
+    # restart with a new token: the finished block is skipped
+    p = go(two, 0, 1, "t3")
+    o = p.communicate(timeout=600)[0]
+    assert p.returncode == 0 and "skipped" in o and "done: []" in o, o
 
 
 def test_bench_multi_rank_rehearsal():
