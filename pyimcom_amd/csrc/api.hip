@@ -105,6 +105,7 @@ int pin_reserve(imcom_ctx *ctx, size_t bytes)
 //   A  [batch][Np][Np]   identity-padded, never modified
 //   Bt [batch][Np][mp]   input-pixel-major -B/2, zero padded
 // Produces Tt (float32 [batch][Np][mp]) and the per-pixel maps.
+constexpr int REPAIR_GROUP = 32;  // failed stamps whose smallest eigenvalues are computed in one batch of the eigensolver (repair path)
 constexpr int CHOL_MAXNV = 8;  // kappa nodes of the multi-kappa Cholesky kernel (launch_multi's MAXNV; 3 nv diagonal increments <= MAX_INC)
 static_assert(3 * CHOL_MAXNV <= MAX_INC_HOST, "diagonal increments of the repair sequence");
 
@@ -147,24 +148,34 @@ static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
         p.add((size_t)batch * m * nv * nv * 8);  // Npq
         p.add((size_t)batch * m * nv * 8);       // W
     }
-    // repair path (lakernel.py:262-279): eigenvalues of ONE stamp's A at a time
-    p.add(eigh_ws_bytes(1, Np, false) + (size_t)Np * Np * 8 + (size_t)Np * 8 + 1024);
+    // repair path (lakernel.py:262-279): eigenvalues of up to REPAIR_GROUP failed stamps' A at a time
+    const int rg = std::min(batch, REPAIR_GROUP);
+    p.add(eigh_ws_bytes(rg, Np, false) + (size_t)rg * Np * Np * 8 * (eigh_uses_jacobi() ? 2 : 1) + (size_t)rg * Np * 8 + 4096);
     p.add(splitk_bytes((int)eb, Np, mp));
     if (nv == 1) p.add((size_t)batch * 2 * nb * mp * 8 * 2);  // per-block-row column sums of Y^2 and X^2
     return p.total + 4096;
 }
 
-// smallest eigenvalue of A[s] (leading n x n of the padded matrix), computed on the device
-static int lambda_min(imcom_ctx *ctx, const double *A_s, int n, int Np, double *w0)
+// smallest eigenvalues of the matrices A[idx[q]] (leading n x n of the padded ones), computed on the device: the stamps are
+// gathered into one batch of the eigensolver (eigenvalues only).  (One call per failed stamp, as the first version did, made a
+// batch in which every factorisation fails -- PSFs cut too tight -- take 0.3 s per stamp.)
+static int lambda_min_group(imcom_ctx *ctx, const double *A, const int *n_host, int Np, const int *idx, int count, double *w0)
 {
     const size_t mark = ctx->ws_used;
-    double *lam = (double *)ws_take(ctx, (size_t)Np * 8);
-    double *Q = eigh_uses_jacobi() ? (double *)ws_take(ctx, (size_t)Np * Np * 8) : nullptr;  // eigenvalues only otherwise
-    if (!lam || (eigh_uses_jacobi() && !Q)) { set_error("internal: workspace (repair)"); return IMCOM_ERR_NOMEM; }
-    if (Q) IMCOM_HIP_CHECK(hipMemsetAsync(Q, 0, (size_t)Np * Np * 8, ctx->stream));
-    int rc = eigh_device(ctx, 1, &n, Np, A_s, Np, (long)Np * Np, lam, Np, Q, Np, (long)Np * Np, nullptr);
+    const size_t mat = (size_t)Np * Np;
+    double *G = (double *)ws_take(ctx, (size_t)count * mat * 8);
+    double *lam = (double *)ws_take(ctx, (size_t)count * Np * 8);
+    double *Q = eigh_uses_jacobi() ? (double *)ws_take(ctx, (size_t)count * mat * 8) : nullptr;  // eigenvalues only otherwise
+    if (!G || !lam || (eigh_uses_jacobi() && !Q)) { set_error("internal: workspace (repair)"); return IMCOM_ERR_NOMEM; }
+    std::vector<int> ng(count);
+    for (int q = 0; q < count; q++) {
+        ng[q] = n_host[idx[q]];
+        IMCOM_HIP_CHECK(hipMemcpyAsync(G + (size_t)q * mat, A + (size_t)idx[q] * mat, mat * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (Q) IMCOM_HIP_CHECK(hipMemsetAsync(Q, 0, (size_t)count * mat * 8, ctx->stream));
+    int rc = eigh_device(ctx, count, ng.data(), Np, G, Np, (long)mat, lam, Np, Q, Np, (long)mat, nullptr);
     if (rc == IMCOM_OK) {
-        hipError_t e = hipMemcpyAsync(w0, lam, 8, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipMemcpy2DAsync(w0, 8, lam, (size_t)Np * 8, 8, count, hipMemcpyDeviceToHost, ctx->stream);  // lam[q][0]
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { set_error("repair: %s", hipGetErrorString(e)); rc = IMCOM_ERR_HIP; }
     }
@@ -286,21 +297,33 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         IMCOM_HIP_CHECK(hipMemcpyAsync(fail.data(), fail_dev, fail.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         bool any = false;
-        for (int p = 0; p < nv; p++)
-            for (int s = 0; s < batch; s++) {
+        std::vector<int> need;  // stamps whose smallest eigenvalue is wanted: w, v = eigh(A); shift by |w[0]| + 1e-16
+        for (int s = 0; s < batch; s++) {
+            bool f = false;
+            for (int p = 0; p < nv; p++) {
                 if (fail[(size_t)p * batch + s] == 0) continue;
                 if (repaired[(size_t)p * batch + s]) {
                     set_error("stamp %d node %d: Cholesky failed again after the lakernel.py:262-279 repair (pivot %d)", s, p,
                               fail[(size_t)p * batch + s]);
                     return IMCOM_ERR_NUMERIC;
                 }
-                if (!have_w0[s]) {  // w, v = eigh(A); shift by |w[0]| + 1e-16
-                    double w0 = 0.0;
-                    ProfScope ps(ctx, "eigen_repair");
-                    IMCOM_TRY(lambda_min(ctx, A + (size_t)s * Np * Np, n_host[s], Np, &w0));
-                    rep[s] = fabs(w0) + 1e-16;
-                    have_w0[s] = 1;
-                }
+                f = true;
+            }
+            if (f && !have_w0[s]) need.push_back(s);
+        }
+        for (size_t g0 = 0; g0 < need.size(); g0 += REPAIR_GROUP) {
+            const int cnt = (int)std::min<size_t>(REPAIR_GROUP, need.size() - g0);
+            std::vector<double> w0(cnt, 0.0);
+            ProfScope ps(ctx, "eigen_repair");
+            IMCOM_TRY(lambda_min_group(ctx, A, n_host, Np, need.data() + g0, cnt, w0.data()));
+            for (int q = 0; q < cnt; q++) {
+                rep[need[g0 + q]] = fabs(w0[q]) + 1e-16;
+                have_w0[need[g0 + q]] = 1;
+            }
+        }
+        for (int p = 0; p < nv; p++)
+            for (int s = 0; s < batch; s++) {
+                if (fail[(size_t)p * batch + s] == 0) continue;
                 repaired[(size_t)p * batch + s] = 1;
                 if (info_host[s] == 0) info_host[s] = p + 1;
                 any = true;
@@ -697,14 +720,23 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
         ProfScope ps(ctx, "pack");
         IMCOM_TRY(launch_pack_A(ctx, A_d, ldn, n_dev, Ap, Np, batch));
     }
+    hipEvent_t ev_entry = nullptr;
+    if (host && szB > 0) {
+        while (ctx->sync_events.size() < 2) {
+            hipEvent_t e;
+            IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->sync_events.push_back(e);
+        }
+        ev_entry = ctx->sync_events[1];
+        IMCOM_HIP_CHECK(hipEventRecord(ev_entry, ctx->stream));  // everything earlier calls left on the main stream
+    }
     auto stage_B = [&]() -> int {
         if (host && szB > 0) {
-            if (ctx->sync_events.empty()) {
-                hipEvent_t e;
-                IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                ctx->sync_events.push_back(e);
-            }
             hipEvent_t ev = ctx->sync_events[0];
+            // the copy lands in workspace that kernels of an EARLIER, un-synchronised device-mode call on this context may still be
+            // using: it waits for the point the main stream had reached when this call began (ev_entry) -- not for this call's own
+            // factorisation, behind which it is meant to hide
+            IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ev_entry, 0));
             IMCOM_HIP_CHECK(hipMemcpyAsync(B_d, mBhalf, szB * 8, hipMemcpyHostToDevice, ctx->aux_stream));
             IMCOM_HIP_CHECK(hipEventRecord(ev, ctx->aux_stream));
             IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));

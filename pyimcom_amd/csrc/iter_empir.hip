@@ -484,7 +484,11 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
     size_t total = 65536 + (size_t)nv * szB * 4 + (size_t)batch * ldn * 8 + (size_t)batch * (MAX_INC + 4) * 8 + szM * 8 * (4 + nv + 2 * nv * nv);
     if (exact) total += big * (1 + nv) + (size_t)batch * np * np * 8;
     if (host) total += (szA + szB) * 8 + szB * 4 + szM * 12 + szM * 16 + (size_t)batch * ldn * 16 + 4096;
-    if (!per_pixel) total += iter_block_ws_bytes(batch, nblocks) + 4096;
+    // The blocked solver keeps one dense sub-matrix per 4 x 4 patch (2.2 MB; 144 patches per cfg-2 stamp): the stamps of a call go
+    // through it in sub-batches that fit a fixed share of workspace instead of batch x 0.3 GB (80 GB for 256 cfg-2 stamps).
+    const size_t blk_budget = (size_t)8 << 30;
+    const int sub = per_pixel ? batch : (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, blk_budget / std::max<size_t>(iter_block_ws_bytes(1, nblocks), 1)));
+    if (!per_pixel) total += iter_block_ws_bytes(sub, nblocks) + 4096;
     IMCOM_TRY(ws_reserve(ctx, total));
     Stage st{ctx, host};
     const double *A_d, *B_d, *yx_d, *iy_d, *ix_d;
@@ -504,7 +508,7 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
     int *ints = (int *)ws_take(ctx, (size_t)batch * 8 + 8);
     double *kc = (double *)ws_take(ctx, (size_t)(batch + nv) * 8);
     double *flat = (double *)ws_take(ctx, szM * 8 * (4 + nv + 2 * nv * nv));
-    void *blkws = per_pixel ? nullptr : ws_take(ctx, iter_block_ws_bytes(batch, nblocks));
+    void *blkws = per_pixel ? nullptr : ws_take(ctx, iter_block_ws_bytes(sub, nblocks));
     if (!Tn || !dsh || !inc || !ints || !kc || !flat || (!per_pixel && !blkws)) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     int *n_dev = ints, *ninc = ints + batch, *status = ints + 2 * batch;
     double *Cs_d = kc, *kappaC_d = kc + batch;
@@ -540,9 +544,16 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
             if (!per_pixel) {  // 4 x 4 patches of output pixels per workgroup (iter_block.hip), unless a patch selects too many input pixels
                 int mx = 0;
                 IMCOM_HIP_CHECK(hipMemsetAsync(Tn + (size_t)p * szB, 0, szB * 4, ctx->stream));
-                IMCOM_TRY(launch_iter_block(ctx, A_d, (long)ldn, (long)ldn * ldn, dsh, (long)ldn, B_d, (long)ldn, yx_d, iy_d, ix_d, (long)ldn, n_dev, m,
-                                            gridW, batch, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, blkws, &mx));
-                blocked = mx <= iter_block_umax();
+                for (int s0 = 0; s0 < batch && mx <= iter_block_umax(); s0 += sub) {
+                    const int sb = std::min(sub, batch - s0);
+                    int mxs = 0;
+                    IMCOM_TRY(launch_iter_block(ctx, A_d + (size_t)s0 * ldn * ldn, (long)ldn, (long)ldn * ldn, dsh + (size_t)s0 * ldn, (long)ldn,
+                                                B_d + (size_t)s0 * m * ldn, (long)ldn, yx_d + (size_t)s0 * 2 * m, iy_d + (size_t)s0 * ldn, ix_d + (size_t)s0 * ldn,
+                                                (long)ldn, n_dev + s0, m, gridW, sb, rho_acc, rtol, maxiter, Tn + (size_t)p * szB + (size_t)s0 * m * ldn, (long)ldn,
+                                                blkws, &mxs));
+                    mx = std::max(mx, mxs);
+                }
+                blocked = mx <= iter_block_umax();  // else: some patch selects more input pixels than the blocked solver holds -- the per-pixel kernel redoes the node
             }
             if (!blocked) {
                 hipLaunchKernelGGL(iter_cg_kernel, dim3(m, batch), dim3(256), 0, ctx->stream, A_d, (long)ldn, (long)ldn * ldn, dsh, (long)ldn, B_d,

@@ -329,6 +329,46 @@ def test_chol_repair_multi_kappa_vs_oracle(orc):
     assert np.allclose(UC[0], Uo, rtol=1e-3, atol=1e-6) and np.allclose(Sg[0], So, rtol=1e-3, atol=1e-6)
 
 
+def test_chol_repair_of_many_stamps_in_one_batch(orc):
+    """A batch in which most factorisations fail (different matrices, different shifts, one healthy stamp in between and a
+    shorter one): the smallest eigenvalues of the failed stamps are computed in groups by one eigensolver batch
+    (lambda_min_group) and every stamp is repaired as the reference repairs it alone (lakernel.py:262-279)."""
+    import ctypes as C
+
+    from pyimcom_amd._lib import MEM_HOST, check, default_context, lib
+
+    A0, mB0, Cc = gaussian_system(11, 7, sigma=1.2, off=3.0, step=0.7)
+    n, m = A0.shape[0], mB0.shape[0]
+    lam0 = np.linalg.eigvalsh(A0)[0]
+    batch = 37  # more than one group of 32
+    ns = np.full(batch, n, np.int32)
+    ns[5] = n - 9  # a ragged stamp
+    A = np.zeros((batch, n, n)); mB = np.zeros((batch, m, n)); Cs = np.full(batch, Cc)
+    kC = np.array([1e-5, 1e-3])
+    want = []
+    for s in range(batch):
+        k = int(ns[s])
+        scale = 1.0 + 0.03 * s
+        shift = 0.0 if s == 3 else (np.linalg.eigvalsh(A0[:k, :k])[0] + (1.5e-4 + 1e-5 * s) * Cc)  # stamp 3 needs no repair
+        A[s, :k, :k] = scale * (A0[:k, :k] - shift * np.eye(k))
+        mB[s, :, :k] = scale * mB0[:, :k]
+        Cs[s] = scale * Cc
+        want.append(orc.chol_kernel(A[s, :k, :k].copy(), mB[s, :, :k].copy(), Cs[s], kC, 1e-6, 0.5))
+    T = np.zeros((batch, m, n), np.float32); UC = np.zeros((batch, m), np.float32)
+    Sg = np.zeros((batch, m), np.float32); kp = np.zeros((batch, m), np.float32); info = np.zeros(batch, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib.imcom_solve_chol(default_context().handle, batch, p(ns), n, m, p(A), p(mB), p(Cs), p(kC), 2, 1e-6, 0.5, p(T), p(UC), p(Sg),
+                               p(kp), p(info), MEM_HOST))
+    assert info[3] == 0 and want[3][4] == 0
+    for s in range(batch):
+        To, Uo, So, ko, info_o = want[s]
+        k = int(ns[s])
+        assert int(info[s]) == info_o, s
+        assert np.abs(T[s, :, :k] - To).max() <= 1e-4 * np.abs(To).max(), s
+        assert np.all(T[s, :, k:] == 0)
+        assert np.allclose(UC[s], Uo, rtol=1e-3, atol=1e-6) and np.allclose(Sg[s], So, rtol=1e-3, atol=1e-6) and np.allclose(kp[s], ko, rtol=1e-5), s
+
+
 def test_croutines_shim_is_importable_as_top_level_module(golden):
     """The injection seam of the reference (lakernel.py:41-47, psfutil.py:37-49; tests/pyimcom/test_missing.py): with
     furry_parakeet absent, a top-level module named `pyimcom_croutines` on sys.path is picked up unchanged."""
