@@ -146,3 +146,51 @@ def test_block_of_reference_size(name, n1P, E):
         for k, mine in (("kappa", res.kappa), ("UC", res.UC), ("Sigma", res.Sigma)):
             blk = ref.maps[k][0, y0 + f2 : y0 + cfg.n2f - f2, x0 + f2 : x0 + cfg.n2f - f2]
             assert torch.allclose(blk, mine[q][inner], rtol=1e-4, atol=1e-9), (k, j, i)
+
+
+def test_bench_block_leg_workload_with_identical_groups_equals_one_group():
+    """bench.py's block leg, checked numerically: its workload generator with the SAME PSF images and unrotated sampling
+    positions in every 2 x 2 group, through the leg's own route (resident PSF images -> bulk sampling -> spectra -> per-group
+    self / cross / input-output table sets -> pair maps -> tiles of cells), must reproduce the block coadded with ONE PSF
+    group (PSFGroupTables of the same sampled PSFs; stamps against the oracle at this size: test_gpu_fullsize.py) -- to the
+    conditioning of the solve, since the tables of a pair come from different FFT evaluations on the two routes."""
+    import torch
+
+    import bench
+    from pyimcom_amd import psfs as psfmod
+    from pyimcom_amd.blockrun import coadd_block
+    from pyimcom_amd.stamps import BlockTables, PSFGroupTables
+
+    dev = "cuda:0"
+    n1P = 16
+    torch.cuda.empty_cache()
+    cfg, inst, pool, psfs, target, groups, counts, img_all, yxco_all = bench.block_workload(dev, n1P, identical=True)
+    E, ns = cfg.n_expo, psfs.shape[-1]
+    order = {k: q for q, k in enumerate(groups)}
+
+    def sample_groups(keys):
+        idx = torch.as_tensor([order[k] for k in keys], device=dev)
+        return psfmod.sample_psf(img_all[idx].reshape(-1, ns + 16, ns + 16), ns, yxco_all[idx].reshape(-1, 2, ns, ns), psf_norm=True)
+
+    tabs = BlockTables(groups, target, cfg.nfft, group_count=counts, bulk_provider=sample_groups, cells=True)
+    grp = coadd_block(cfg, pool, tabs, n1P, E)
+    sampled = sample_groups([(0, 0)])
+    one = coadd_block(cfg, pool, PSFGroupTables(sampled, target, cfg.nfft), n1P, E)
+    torch.cuda.synchronize()
+    a, b = one.out_map, grp.out_map
+    assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+        x, y = one.maps[k], grp.maps[k]
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-7 * float(x.abs().max())), k
+    assert torch.allclose(one.T_weightmap, grp.T_weightmap, rtol=1e-5, atol=1e-8)
+    # and with the leg's real workload (a PSF of its own per group) the block differs: the groups matter
+    cfg2, _, pool2, _, target2, groups2, counts2, img2, yx2 = bench.block_workload(dev, n1P)
+    order2 = {k: q for q, k in enumerate(groups2)}
+
+    def sample2(keys):
+        idx = torch.as_tensor([order2[k] for k in keys], device=dev)
+        return psfmod.sample_psf(img2[idx].reshape(-1, ns + 16, ns + 16), ns, yx2[idx].reshape(-1, 2, ns, ns), psf_norm=True)
+
+    var = coadd_block(cfg2, pool2, BlockTables(groups2, target2, cfg2.nfft, group_count=counts2, bulk_provider=sample2, cells=True), n1P, E)
+    assert float((var.out_map - a).abs().max()) > 1e-3 * float(a.abs().max())

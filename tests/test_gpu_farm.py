@@ -90,6 +90,56 @@ def test_farm_dynamic_schedule_shares_a_block(tmp_path):
     assert p.returncode == 0 and "skipped" in o and "done: []" in o, o
 
 
+def test_farm_cfg4_block_with_psf_groups_vs_oracle(tmp_path):
+    """ONE real block of the cfg-4 mosaic (BASELINE configs[3]: 48 x 48-output stamps, this block's own exposure depth in
+    6 - 10, N = 2.2 - 3.7k) through the farm driver with a PSF group per 2 x 2 InStamps (`--config cfg4 --psf-groups`), and
+    one of its stamps against the oracle: A and -B/2 assembled the reference's way from the groups' PSFOvl objects
+    (stamp_system_groups), CholKernel, tapers, coaddition -- compared inside the block file the driver wrote."""
+    from oracle import oracle as orc
+    from pyimcom_amd import farm, synth
+    from pyimcom_amd.blockrun import stamp_neighbours
+
+    out = str(tmp_path / "cfg4")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "pyimcom_amd.farm", "--out", out, "--config", "cfg4", "--mosaic", "1", "--n1P", "2", "--psf-groups", "--seed", "9"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "done: [0]" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    blk = np.load(farm.block_path(out, 0))
+    E = int(blk["meta_n_expo"])
+    assert 6 <= E <= 10
+    # the block's inputs, as the driver built them
+    blocks, costs, make_block = farm.synthetic_mosaic("cfg4", 1, 2, 9, True)
+    cfg, inst, psfs, target = make_block.host(0)
+    n1P, nst, n2 = 2, 4, cfg.n2
+    geo = orc.Geom(cfg.npixpsf, cfg.oversamp, cfg.dtheta_as / 3600.0, cfg.flat_penalty)
+    rft = orc.pad_and_rfft2(psfs, geo)
+    rft_in = {(gj, gi): rft for gj in range(2) for gi in range(2)}  # the synthetic mosaic gives every group the same PSFs
+    rft_out = orc.pad_and_rfft2(target, geo)
+    C = float(orc.overlap_out_C(rft_out, geo)[0])
+    j, i = 2, 1
+    ids, pvx, pvy = stamp_neighbours(j, i, n2, nst)
+    piv = [(None if np.isnan(a) else a, None if np.isnan(b) else b) for a, b in zip(pvx, pvy)]
+    nine = [inst[k] if k >= 0 else None for k in ids]
+    sels = [None if t is None else orc.select_pixels(t[0], t[1], pv, cfg.rho) for t, pv in zip(nine, piv)]
+    groups = [None if k < 0 else (int(k) // nst >> 1, int(k) % nst >> 1) for k in ids]
+    x, y, indata, expo, cum = orc.process_input_stamps(nine, piv, cfg.rho)
+    g1 = np.arange(cfg.n2f, dtype=np.float64)
+    A, mB = orc.stamp_system_groups(nine, sels, groups, rft_in, rft_out, geo, (i - 1) * n2 + g1, (j - 1) * n2 + g1)
+    assert 2000 < A.shape[0] < 4000
+    T, UC, Sg, kp, _ = orc.chol_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax)
+    outimage, Tst, Tin, Neff = orc.perform_coaddition(T[None].copy(), indata, expo, E, cfg.n2f, n2, 0, cum)
+    ys, xs = slice((j - 1) * n2, j * n2), slice((i - 1) * n2, i * n2)
+    lam = np.linalg.eigvalsh(A)
+    cond = (lam[-1] + cfg.kappaC[0] * C) / (max(lam[0], 0.0) + cfg.kappaC[0] * C)
+    scale = np.abs(T) @ np.abs(indata.T).astype(np.float64)
+    err = np.abs(blk["out_map"][0][:, ys, xs].reshape(cfg.n_inframe, -1) - outimage[0].reshape(cfg.n_inframe, -1)) / np.maximum(scale.T, 1e-30)
+    assert err.max() <= 2e-5 + 50 * cond * 2.2e-16, err.max()
+    s2 = (cfg.n2f, cfg.n2f)
+    rt = 1e-5 + 50 * cond * 2.2e-16
+    assert np.allclose(blk["UC"][0, ys, xs], UC.reshape(s2), rtol=rt, atol=1e-9) and np.allclose(blk["Sigma"][0, ys, xs], Sg.reshape(s2), rtol=rt, atol=1e-9)
+    assert np.allclose(blk["kappa"][0, ys, xs], kp.reshape(s2), rtol=1e-6) and np.allclose(blk["T_weightmap"][0, :, j - 1, i - 1], Tst[0], rtol=2e-5, atol=2e-5 * np.abs(Tst).max())
+
+
 def test_bench_multi_rank_rehearsal():
     """bench.py's N > 1 path (torch.distributed.run, one rank per GPU, barrier + max-over-ranks timing, rank 0 prints
     the one JSON line) rehearsed on this one-GPU box: two ranks share cuda:0 and rendezvous over gloo.  Not a

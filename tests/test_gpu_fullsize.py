@@ -10,8 +10,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,nst", [("cfg1", 1), ("cfg2", 2), ("cfg2f", 1), ("cfg4", 3)])
+@pytest.mark.parametrize("name,nst", [("cfg1", 1), ("cfg2", 2), ("cfg2f", 1), ("cfg4", 3), ("cfg5", 1)])
 def test_baseline_config_vs_oracle(name, nst):
+    """Every Cholesky configuration of BASELINE.json at its full stamp size -- cfg-5 included: ONE deep-field stamp, 16 exposures,
+    N ~ 5.9k (lakernel.py:281-323 on a 5.9k system: the oracle needs about half a minute on the box's host cores) -- A, B, T,
+    maps and image against the oracle, from the device's tables and (stamp 0) from the oracle's own."""
     from pyimcom_amd import synth
     from tests import parity as smoke
 
