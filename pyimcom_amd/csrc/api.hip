@@ -778,7 +778,8 @@ int imcom_build_A(imcom_ctx *ctx, int batch, const int *n_host, int ldn, const d
     IMCOM_TRY(check_ctx(ctx));
     IMCOM_REQUIRE(batch >= 1 && n_host && x && y && psf && tables && geom && pair_tab && pair_pen && A, "null pointer");
     IMCOM_REQUIRE(ldn >= 1 && ntab >= 1 && npsf_max >= 1 && geom->nsamp >= 1 && geom->dscale > 0, "bad sizes");
-    IMCOM_TRY(ws_reserve(ctx, (size_t)batch * 4 + 1024));
+    const long nt_ = (ldn + 15) / 16, tiles_ = nt_ * (nt_ + 1) / 2 * batch;  // per-stamp tile order by PSF pair: key + descriptor per tile, bins per stamp
+    IMCOM_TRY(ws_reserve(ctx, (size_t)batch * 4 + (size_t)tiles_ * 8 + (size_t)batch * ((size_t)npsf_max * npsf_max + 1) * 4 + 8192));
     int *n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
     IMCOM_TRY(upload(ctx, n_dev, n_host, batch));
     ProfScope ps(ctx, "build_A");

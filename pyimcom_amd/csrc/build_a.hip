@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
                                                       int ng, double nc, double dscale,
                                                       const int *__restrict__ pair_tab,
                                                       const double *__restrict__ pair_pen, int npsf_max,
-                                                      double *__restrict__ A, int ntile)
+                                                      double *__restrict__ A, int ntile, const int *__restrict__ desc)
 {
     __shared__ __attribute__((aligned(16))) double seg[A_RING][256 * SEG_W];
     __shared__ long seg0[256];  // first element (ascending address order) of stencil row 0, as a 64-bit offset into the table stack
@@ -82,8 +82,11 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     // contiguous eighth of the tile list, so that the tiles it works on at one time use the same few tables.
     // (gridDim.x is the tile count padded to a multiple of 8.)
     const long ntri = (long)ntile * (ntile + 1) / 2, per = (ntri + 7) / 8;
-    const long t = (((long)blockIdx.y * gridDim.x + blockIdx.x) & 7) * per + ((long)blockIdx.x >> 3);
+    long t = (((long)blockIdx.y * gridDim.x + blockIdx.x) & 7) * per + ((long)blockIdx.x >> 3);
     if (t >= ntri) return;
+    // desc (optional): this stamp's tiles ordered by the PSF pair of their first sample, so that the tiles an XCD works on at one
+    // time read the same table (the stamps of a block spread their samples over ~300 tables of four PSF groups)
+    if (desc) t = desc[(long)s * ntri + t];
     tile_index(t, ntile, ti, tj);
     const int ns = n[s];
     const int nfull = (ns + NB - 1) / NB * NB;  // rows/cols the factorisation will ever read
@@ -261,6 +264,53 @@ __global__ __launch_bounds__(256, A_RING == 2 ? 3 : 2) void build_A_kernel(const
     }
 }
 
+// ---- per-stamp tile order by PSF pair (counting sort: key, exclusive scan per stamp, scatter) -------------------------------
+__global__ void a_tile_key_kernel(const int *__restrict__ n, int ldn, const int *__restrict__ psf, int npsf_max, int ntile, long total,
+                                  int *__restrict__ key, int *__restrict__ hist)
+{
+    const long g = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const long ntri = (long)ntile * (ntile + 1) / 2;
+    const int s = (int)(g / ntri), nbin = npsf_max * npsf_max + 1;
+    int ti, tj;
+    tile_index(g - (long)s * ntri, ntile, ti, tj);
+    const int ns = n[s];
+    int k = nbin - 1;  // tiles beyond the stamp's pixels
+    if (ti * 16 < ns && tj * 16 < ns) k = psf[(long)s * ldn + ti * 16] * npsf_max + psf[(long)s * ldn + tj * 16];
+    key[g] = k;
+    atomicAdd(hist + (long)s * nbin + k, 1);
+}
+
+__global__ __launch_bounds__(256) void a_tile_scan_kernel(int *__restrict__ hist, int nbin)  // one workgroup per stamp: exclusive scan of its bins in place
+{
+    __shared__ int part[256];
+    int *h = hist + (long)blockIdx.x * nbin;
+    const int per = (nbin + 255) / 256, b0 = threadIdx.x * per;
+    int sum = 0;
+    for (int q = 0; q < per; q++) sum += b0 + q < nbin ? h[b0 + q] : 0;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int q = 0; q < per; q++)
+        if (b0 + q < nbin) { const int v = h[b0 + q]; h[b0 + q] = run; run += v; }
+}
+
+__global__ void a_tile_scatter_kernel(const int *__restrict__ key, int *__restrict__ cursor, int npsf_max, int ntile, long total,
+                                      int *__restrict__ desc)
+{
+    const long g = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const long ntri = (long)ntile * (ntile + 1) / 2;
+    const int s = (int)(g / ntri), nbin = npsf_max * npsf_max + 1;
+    desc[(long)s * ntri + atomicAdd(cursor + (long)s * nbin + key[g], 1)] = (int)(g - (long)s * ntri);  // the order inside a bucket decides only the schedule
+}
+
 #ifdef IMCOM_DEV
 int launch_build_A_win(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const double *x, const double *y, const int *psf,
                        const double *tables, int ntab, int ng, double nc, double dscale, const int *pair_tab, const double *pair_pen,
@@ -281,8 +331,26 @@ int launch_build_A(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, const d
     const int nt = (ldn + 15) / 16;
     const long ntri = (long)nt * (nt + 1) / 2;
     const long ngrid = (ntri + 7) / 8 * 8;  // padded to a multiple of 8 for the XCD-aware tile order
+    int *desc = nullptr;
+    // Every stamp's tiles ordered by the PSF pair of their first sample (three small kernels: counting sort per stamp), so that the
+    // tiles an XCD works on at one time read ONE table: 27.85 against 29.25 ms per 256 cfg-2 stamps, three A/B pairs on one box
+    // (ordering the whole BATCH by table instead lost 1.8x: profiles/r03_negative_results.txt).  IMCOM_A_ORDER=rows: row by row.
+    static const bool by_pair = !(getenv("IMCOM_A_ORDER") && !strcmp(getenv("IMCOM_A_ORDER"), "rows"));
+    if (by_pair) {
+        const long total = ntri * batch;
+        const int nbin = npsf_max * npsf_max + 1;
+        int *key = (int *)ws_take(ctx, (size_t)total * 4), *hist = (int *)ws_take(ctx, (size_t)batch * nbin * 4);
+        desc = (int *)ws_take(ctx, (size_t)total * 4);
+        if (key && hist && desc) {
+            IMCOM_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)batch * nbin * 4, ctx->stream));
+            hipLaunchKernelGGL(a_tile_key_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, n_dev, ldn, psf, npsf_max, nt, total, key, hist);
+            hipLaunchKernelGGL(a_tile_scan_kernel, dim3(batch), dim3(256), 0, ctx->stream, hist, nbin);
+            hipLaunchKernelGGL(a_tile_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, key, hist, npsf_max, nt, total, desc);
+            IMCOM_TRY(check_launch("build_A tile order"));
+        } else desc = nullptr;
+    }
     hipLaunchKernelGGL(build_A_kernel, dim3((unsigned)ngrid, batch), dim3(256), 0, ctx->stream, n_dev, ldn, x, y, psf,
-                       tables, (long)ntab * ng * ng, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A, nt);
+                       tables, (long)ntab * ng * ng, ng, nc, dscale, pair_tab, pair_pen, npsf_max, A, nt, (const int *)desc);
     return check_launch("build_A_kernel");
 }
 
