@@ -136,6 +136,13 @@ int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, c
                       const double *mBhalf, const double *C, const double *kappaC, int nv,
                       double ucmin, double smax, int nbis, float *T, float *UC, float *Sigma,
                       float *kappa, int *info, int memspace);
+/* Householder reduction of symmetric matrices to band form, the basis the Eigen kernel's kappa search works in
+ * (numpy.linalg.eigh at lakernel.py:162, 201 is not needed for it: DESIGN.md "Eigen path"): A = Q B Q^T, B[i][j] = 0 for
+ * |i - j| > 4, Q = H_0 H_1 ... with H_r = I - tau_r v_r v_r^T, v_r zero above its pivot row r + 4 (v_r[r+4] = 1).
+ *   A     [batch][ldn][ldn] symmetric, leading n[s] x n[s] used; ldn a multiple of 128, at most 4864 (the N x 4 panel lives in LDS)
+ *   band  [batch][5][ldn] out: band[t][i] = B[i+t][i];  V [batch][ldn][ldn] out: row r = v_r;  tau [batch][ldn] out */
+int imcom_band_reduce(imcom_ctx *ctx, int batch, const int *n_host, int ldn, const double *A, double *band, double *V,
+                      double *tau, int memspace);
 /* The same kernel on the resident layouts of imcom_build_A / imcom_build_B (DEVICE pointers): A [batch][ldn][ldn], Bt = -B/2
  * input-pixel-major [batch][ldn][ldm] (zero padded), output Tt [batch][ldn][ldm] float32; ldn, ldm multiples of 128.
  * EigenKernel._call_single_kappa / _call_multi_kappa (lakernel.py:154-223) without the transposes of the reference layout. */

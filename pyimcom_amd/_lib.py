@@ -76,6 +76,7 @@ SIGNATURES = {
     "imcom_solve_iter": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _d, _d, _i, _i, _vp, _vp, _vp, _vp, _i],
     "imcom_solve_empir": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _i],
     "imcom_eigh": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i],
+    "imcom_band_reduce": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i],
     "imcom_partition_pixels": [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp],
     "imcom_select_pixels": [_vp, _i, _vp, _vp, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _i],
     "imcom_build_A": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(TableGeom), _vp, _vp, _i, _vp],

@@ -17,6 +17,9 @@
 // old path's time at N = 2.9k) and all of their workspace.  T + kappa I is positive definite for kappa > -lam_min, which
 // the bracket kappa >= kappaC[0] C > 0 guarantees for the positive semi-definite A of this problem, so the LDL^T needs no
 // pivoting.  The bisection takes the same decisions as lakernel1 except where udc or sum2 sits within rounding of its bound.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 #include "launchers.h"
 
@@ -139,6 +142,159 @@ __global__ __launch_bounds__(64) void tri_solve_kernel(const double *__restrict_
     kappa[pa] = kap_pix ? (float)((double)(float)kap * C) : (float)kap;
 }
 
+// ---- the same in the BAND basis of band.hip (bandwidth BW = BAND_BW: B[i+t][i] = band[t][i], t = 0..BW) ------------------------------
+// LDL^T of B + kappa I, left-looking over the last BW columns kept in registers:
+//   d_i = B_ii + kappa - sum_q l_{i,j}^2 d_j,   l_{i+t,i} = (B_{i+t,i} - sum_q l_{i+t,j} l_{i,j} d_j) / d_i   (j = i-1-q, q < BW),
+//   z_i = c_i - sum_q l_{i,j} z_j,   D = sum z_i^2 / d_i,   S = -dD/dkappa with every quantity's kappa-derivative carried along.
+// History slot q holds column j = i-1-q: dh[q], lh[q][t] = l_{j+t,j} (t = 1..BW), zh[q], and their derivatives; slots of columns
+// before the first are zero, so the sums need no guards.
+template <int B_>
+struct BandState {
+    double dh[B_], dph[B_], zh[B_], zph[B_], lh[B_][B_ + 1], lph[B_][B_ + 1];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int q = 0; q < B_; q++) {
+            dh[q] = 1.0; dph[q] = 0.0; zh[q] = 0.0; zph[q] = 0.0;
+#pragma unroll
+            for (int t = 0; t <= B_; t++) { lh[q][t] = 0.0; lph[q][t] = 0.0; }
+        }
+    }
+};
+
+// one row of the sweep with derivative; bd[t] = B[i+t][i] (zero beyond the matrix), ci = c_i; returns the contributions to D and S
+template <int B_, bool FAST>
+__device__ __forceinline__ void band_row(BandState<B_> &h, const double (&bd)[B_ + 1], double ci, double kap, double &D, double &S)
+{
+    double d = bd[0] + kap, dp = 1.0, z = ci, zp = 0.0;
+#pragma unroll
+    for (int q = 0; q < B_; q++) {
+        const double l = h.lh[q][q + 1], lp = h.lph[q][q + 1], ld_ = l * h.dh[q];
+        d -= l * ld_;
+        dp -= 2.0 * lp * ld_ + l * l * h.dph[q];
+        z -= l * h.zh[q];
+        zp -= lp * h.zh[q] + l * h.zph[q];
+    }
+    const double r = FAST ? fast_recip(d) : 1.0 / d, t = z * r;
+    D += z * t;
+    S += t * (t * dp - 2.0 * zp);
+    double ln[B_ + 1], lpn[B_ + 1];
+    ln[0] = lpn[0] = 0.0;
+#pragma unroll
+    for (int tt = 1; tt <= B_; tt++) {
+        double num = bd[tt], nump = 0.0;
+#pragma unroll
+        for (int q = 0; q < B_; q++)
+            if (q + 1 + tt <= B_) {
+                const double a = h.lh[q][q + 1 + tt], ap = h.lph[q][q + 1 + tt], b = h.lh[q][q + 1], bp = h.lph[q][q + 1], dq = h.dh[q];
+                num -= a * b * dq;
+                nump -= (ap * b + a * bp) * dq + a * b * h.dph[q];
+            }
+        ln[tt] = num * r;
+        lpn[tt] = (nump - ln[tt] * dp) * r;
+    }
+#pragma unroll
+    for (int q = B_ - 1; q > 0; q--) {
+        h.dh[q] = h.dh[q - 1]; h.dph[q] = h.dph[q - 1]; h.zh[q] = h.zh[q - 1]; h.zph[q] = h.zph[q - 1];
+#pragma unroll
+        for (int tt = 0; tt <= B_; tt++) { h.lh[q][tt] = h.lh[q - 1][tt]; h.lph[q][tt] = h.lph[q - 1][tt]; }
+    }
+    h.dh[0] = d; h.dph[0] = dp; h.zh[0] = z; h.zph[0] = zp;
+#pragma unroll
+    for (int tt = 0; tt <= B_; tt++) { h.lh[0][tt] = ln[tt]; h.lph[0][tt] = lpn[tt]; }
+}
+
+template <int B_>
+__device__ __forceinline__ void band_sweep(const double *__restrict__ band, int np, const double *__restrict__ c, long cstride, int ns, double kap,
+                                           double &D, double &S)
+{
+    BandState<B_> h;
+    h.clear();
+    D = 0.0;
+    S = 0.0;
+    double cn = c[0];
+    for (int i = 0; i < ns; i++) {
+        const double ci = cn;
+        cn = i + 1 < ns ? c[(long)(i + 1) * cstride] : 0.0;  // one row ahead of its use
+        double bd[B_ + 1];
+#pragma unroll
+        for (int t = 0; t <= B_; t++) bd[t] = band[(long)t * np + i];  // wave-uniform
+        band_row<B_, true>(h, bd, ci, kap, D, S);
+    }
+}
+
+template <int B_>
+__global__ __launch_bounds__(64) void band_search_kernel(const double *__restrict__ band, const double *__restrict__ Cb, int np, int mp, int m,
+                                                         const int *__restrict__ n, const double *__restrict__ Cs, const double *__restrict__ kmin,
+                                                         const double *__restrict__ kmax, double targetleak, double smax, int nbis,
+                                                         double *__restrict__ kap_out)
+{
+    const int s = blockIdx.y, a = blockIdx.x * 64 + threadIdx.x;
+    const int ns = n[s];
+    if (a >= m || ns == 0) return;
+    const double *bs = band + (long)s * (B_ + 1) * np, *c = Cb + (long)s * np * mp + a;
+    const double C = Cs[s], kCmin = kmin[s], kCmax = kmax[s];
+    double factor = sqrt(kCmax / kCmin), kap = sqrt(kCmax * kCmin);
+    for (int it = 0; it < nbis; it++) {
+        double D, S;
+        band_sweep<B_>(bs, np, c, mp, ns, kap, D, S);
+        const double udc = 1.0 - (D + kap * S) / C;
+        factor = sqrt(factor);
+        kap *= (udc > targetleak && S < smax) ? 1.0 / factor : factor;
+    }
+    kap_out[(long)s * m + a] = kap;
+}
+
+// y = (B + kappa I)^-1 c per output pixel, in place, with the maps (tri_solve_kernel's contract).  Lb [B_][np][mp]: l_{i+t,i} of
+// every pixel's factorisation between the forward and the backward pass.
+template <int B_>
+__global__ __launch_bounds__(64) void band_solve_kernel(const double *__restrict__ band, double *__restrict__ Cb, double *__restrict__ Lb, int np,
+                                                        int mp, int m, const int *__restrict__ n, const double *__restrict__ Cs,
+                                                        const double *__restrict__ kap_stamp, const double *__restrict__ kap_pix,
+                                                        float *__restrict__ UC, float *__restrict__ Sigma, float *__restrict__ kappa)
+{
+    const int s = blockIdx.y, a = blockIdx.x * 64 + threadIdx.x;
+    const int ns = n[s];
+    if (a >= m) return;
+    const long pa = (long)s * m + a;
+    if (ns == 0) { UC[pa] = 1.0f; Sigma[pa] = 0.0f; kappa[pa] = 1.0f; return; }  // lakernel.py:110-119
+    const double *bs = band + (long)s * (B_ + 1) * np;
+    double *c = Cb + (long)s * np * mp + a, *lb = Lb + (long)s * B_ * np * mp + a;
+    const double C = Cs[s], kap = kap_pix ? kap_pix[pa] : kap_stamp[s];
+    BandState<B_> h;
+    h.clear();
+    double D = 0.0, Sd = 0.0;
+    for (int i = 0; i < ns; i++) {
+        double bd[B_ + 1];
+#pragma unroll
+        for (int t = 0; t <= B_; t++) bd[t] = bs[(long)t * np + i];
+        const double D0 = D;
+        band_row<B_, false>(h, bd, c[(long)i * mp], kap, D, Sd);
+        (void)D0;
+        c[(long)i * mp] = h.zh[0] / h.dh[0];  // w_i = z_i / d_i
+#pragma unroll
+        for (int t = 1; t <= B_; t++) lb[((long)(t - 1) * np + i) * mp] = h.lh[0][t];
+    }
+    double yh[B_];  // y_{i+1} .. y_{i+B_}
+#pragma unroll
+    for (int q = 0; q < B_; q++) yh[q] = 0.0;
+    double S = 0.0;
+    for (int i = ns - 1; i >= 0; i--) {
+        double y = c[(long)i * mp];
+#pragma unroll
+        for (int t = 1; t <= B_; t++) y -= lb[((long)(t - 1) * np + i) * mp] * yh[t - 1];  // l_{i+t,i} is zero beyond the matrix
+        c[(long)i * mp] = y;
+        S += y * y;
+#pragma unroll
+        for (int q = B_ - 1; q > 0; q--) yh[q] = yh[q - 1];
+        yh[0] = y;
+    }
+    const double udc = 1.0 - (D + kap * S) / C;
+    Sigma[pa] = (float)S;
+    UC[pa] = (float)udc;
+    kappa[pa] = kap_pix ? (float)((double)(float)kap * C) : (float)kap;
+}
+
 // X [np][mp] float64 -> resident layout Tt [ldn][ldm] float32 (rows >= n[s], columns >= m zero)
 __global__ void tri_store_resident_kernel(const double *__restrict__ X, int np, int mp, int m, const int *__restrict__ n,
                                           float *__restrict__ Tt, int ldn, int ldm)
@@ -211,6 +367,41 @@ extern "C" int imcom_eigh(imcom_ctx *ctx, int batch, const int *n, int ldn, cons
     return IMCOM_OK;
 }
 
+// The band basis (band.hip) whenever its N x 4 panel fits the LDS (N <= 4.8k); IMCOM_EIGEN_BASIS=tridiagonal keeps round 3's first form
+// (A/B runs and a cross-check: the two bases share nothing but the block-reflector GEMMs).
+static bool eigen_uses_band(int np)
+{
+    static const bool tri = getenv("IMCOM_EIGEN_BASIS") && !strcmp(getenv("IMCOM_EIGEN_BASIS"), "tridiagonal");
+    return !tri && band_basis_fits(np);
+}
+
+// Householder reduction to band form alone (tests, diagnostics): band [batch][BAND_BW + 1][ldn] with band[t][i] = B[i + t][i], the
+// reflectors V [batch][ldn][ldn] (row r = v_r) and tau [batch][ldn]; A = Q B Q^T with Q = H_0 H_1 ...; ldn a multiple of 128.
+extern "C" int imcom_band_reduce(imcom_ctx *ctx, int batch, const int *n, int ldn, const double *A, double *band, double *V, double *tau, int memspace)
+{
+    IMCOM_TRY(ctx_ok(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n && A && band && V && tau && ldn >= NB && ldn % NB == 0 && band_basis_fits(ldn), "bad arguments (ldn a multiple of 128, <= 4.8k)");
+    for (int s = 0; s < batch; s++) IMCOM_REQUIRE(n[s] >= 0 && n[s] <= ldn, "n[%d]=%d exceeds ldn", s, n[s]);
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const size_t szA = (size_t)batch * ldn * ldn * 8, szB = (size_t)batch * (BAND_BW + 1) * ldn * 8, szT = (size_t)batch * ldn * 8;
+    IMCOM_TRY(ws_reserve(ctx, band_basis_ws_bytes(batch, ldn, NB) + (host ? szA : 0) + 65536));
+    const double *A_d = A;
+    if (host) {
+        double *t = (double *)ws_take(ctx, szA);
+        if (!t) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+        IMCOM_HIP_CHECK(hipMemcpyAsync(t, A, szA, hipMemcpyHostToDevice, ctx->stream));
+        A_d = t;
+    }
+    TrdBasis tb;
+    IMCOM_TRY(band_basis_device(ctx, batch, n, ldn, NB, A_d, ldn, (long)ldn * ldn, &tb));
+    const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    IMCOM_HIP_CHECK(hipMemcpyAsync(band, tb.band, szB, kind, ctx->stream));
+    IMCOM_HIP_CHECK(hipMemcpyAsync(V, tb.Vall, szA, kind, ctx->stream));
+    IMCOM_HIP_CHECK(hipMemcpyAsync(tau, tb.tauvec, szT, kind, ctx->stream));
+    if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
 // Shared body of the two entries.  Bt_res: -B/2 in the resident layout [np][mp] (then Tt_res [np][mp] float32 is the output);
 // else B_ref [m][ldn] and T_ref [m][ldn] in the reference's layout.
 static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, int np, int mp, const double *A_d, const double *Bt_res,
@@ -219,8 +410,10 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
 {
     const size_t big = (size_t)batch * np * mp * 8, szM = (size_t)batch * m;
     TrdBasis tb;
-    IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
-    double *Cb = (double *)ws_take(ctx, big), *Lb = (double *)ws_take(ctx, big);
+    const bool banded = eigen_uses_band(np);
+    if (banded) IMCOM_TRY(band_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
+    else IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
+    double *Cb = (double *)ws_take(ctx, big), *Lb = (double *)ws_take(ctx, banded ? big * BAND_BW : big);
     double *kpix = (double *)ws_take(ctx, szM * 8), *par = (double *)ws_take(ctx, (size_t)batch * 8 * 4);
     if (!Cb || !Lb || !kpix || !par) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     std::vector<double> ph(4 * (size_t)batch);
@@ -239,6 +432,16 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
     if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Qh^T b
     {
         ProfScope ps(ctx, "lakernel1");
+        if (banded) {
+            if (nv > 1) {
+                hipLaunchKernelGGL(band_search_kernel<BAND_BW>, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.band, Cb, np, mp, m, tb.n_dev, par, par + batch,
+                                   par + 2 * batch, ucmin, smax, nbis, kpix);
+                IMCOM_TRY(check_launch("band_search_kernel"));
+            }
+            hipLaunchKernelGGL(band_solve_kernel<BAND_BW>, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.band, Cb, Lb, np, mp, m, tb.n_dev, par, par + batch,
+                               nv > 1 ? kpix : nullptr, UC_d, Sig_d, kap_d);
+            IMCOM_TRY(check_launch("band_solve_kernel"));
+        } else {
         if (nv > 1) {
             hipLaunchKernelGGL(tri_search_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, np, mp, m, tb.n_dev, par,
                                par + batch, par + 2 * batch, ucmin, smax, nbis, kpix);
@@ -247,6 +450,7 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         hipLaunchKernelGGL(tri_solve_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, Lb, np, mp, m, tb.n_dev, par,
                            par + batch, nv > 1 ? kpix : nullptr, UC_d, Sig_d, kap_d);
         IMCOM_TRY(check_launch("tri_solve_kernel"));
+        }
     }
     if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, false));  // x = Qh y
     if (Tt_res) {
@@ -261,7 +465,9 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
 
 static size_t solve_eigen_ws(int batch, int np, int mp, int m)
 {
-    return trd_basis_ws_bytes(batch, np, mp) + 2 * (size_t)batch * np * mp * 8 + (size_t)batch * m * 8 + (size_t)batch * 64 + 65536;
+    const bool banded = eigen_uses_band(np);
+    return (banded ? band_basis_ws_bytes(batch, np, mp) : trd_basis_ws_bytes(batch, np, mp)) + (size_t)(banded ? 1 + BAND_BW : 2) * batch * np * mp * 8 +
+           (size_t)batch * m * 8 + (size_t)batch * 64 + 65536;
 }
 
 extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A, const double *mBhalf,

@@ -31,15 +31,21 @@ int eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, const doub
                 long ldlam, double *Q, long ldq, long strideQ, int *sweeps_out);
 
 // tridiag.hip: the tridiagonal basis A = Qh T Qh^T without eigenvectors (eigen.hip works in it)
+constexpr int BAND_BW = 4;  // bandwidth of band.hip's reduction
 struct TrdBasis {
     double *Vall, *dvec, *evec, *tauvec;  // reflectors [batch][ld][ld] (row j = v_j), T's diagonal / off-diagonal, tau [batch][ld]
     double *Tm, *Sm, *W1, *W2;            // triangular factors of the 128-reflector panels [npanels][batch][128][128]; scratch of trd_apply_q
+    double *band = nullptr;               // band.hip: [batch][bw + 1][ld], band[t][i] = B[i + t][i]
     int *n_dev;
-    int ld, nmax, npanels;
+    int ld, nmax, npanels, bw = 1;        // bw: rows between a reflector's column and its pivot (1: tridiagonal basis)
 };
 size_t trd_basis_ws_bytes(int batch, int ld, int mp);
 int trd_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out);
 int trd_apply_q(imcom_ctx *ctx, const TrdBasis &b, int batch, double *C, int mp, bool transpose);
+// band.hip: the same with A = Q B Q^T, B of bandwidth BAND_BW (a quarter of the passes over the matrix); ld up to what the panel's LDS holds
+bool band_basis_fits(int ld);
+size_t band_basis_ws_bytes(int batch, int ld, int mp);
+int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out);
 
 // la_kernels.hip
 int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail);

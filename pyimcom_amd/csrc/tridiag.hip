@@ -740,6 +740,8 @@ size_t trd_basis_ws_bytes(int batch, int ld, int mp)
     return t + 4096 + trd_scratch_bytes(batch, ld);
 }
 
+int trd_panel_factors(imcom_ctx *ctx, TrdBasis *out, int batch);
+
 int trd_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out)
 {
     IMCOM_REQUIRE(ld % NB == 0 && ld >= NB && mp % NB == 0, "tridiag: ld=%d, mp=%d must be multiples of %d", ld, mp, NB);
@@ -762,14 +764,20 @@ int trd_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int m
         set_error("internal: tridiag workspace");
         return IMCOM_ERR_NOMEM;
     }
-    hipStream_t st = ctx->stream;
     IMCOM_TRY(upload(ctx, out->n_dev, n_host, (size_t)batch));
     const size_t mark = ctx->ws_used;
     TrdScratch t;
     if (!trd_take_scratch(ctx, batch, ld, &t)) { set_error("internal: tridiag workspace"); return IMCOM_ERR_NOMEM; }
     IMCOM_TRY(trd_reduce(ctx, batch, out->nmax, ld, A, lda, strideA, out->n_dev, t, out->Vall, out->dvec, out->evec, out->tauvec, nullptr));
     ctx->ws_used = mark;  // the scratch is free again (everything queued so far runs before whatever reuses it, same stream)
-    // the panels' triangular factors, once for both directions
+    return trd_panel_factors(ctx, out, batch);
+}
+
+// the triangular factors of the 128-reflector panels of a basis (Vall, tauvec), once for both directions of trd_apply_q
+int trd_panel_factors(imcom_ctx *ctx, TrdBasis *out, int batch)
+{
+    const int ld = out->ld;
+    hipStream_t st = ctx->stream;
     ProfScope ps_(ctx, "eigen_applyq");
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LARFT_LDS));
     for (int p = 0; p < out->npanels; p++) {

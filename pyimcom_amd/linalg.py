@@ -23,3 +23,16 @@ def eigh(A, ctx=None):
     if n > 0:
         check(lib.imcom_eigh((ctx or default_context()).handle, b, p(ns), n, p(A), p(lam), p(Q), MEM_HOST))
     return (lam[0], Q[0]) if single else (lam, Q)
+
+
+def band_reduce(A, n=None, ctx=None):
+    """Householder reduction to band form (bandwidth 4), the basis of the Eigen kernel's kappa search: A [b, ld, ld] (ld a
+    multiple of 128; the leading n[s] x n[s] of every matrix is used) -> band [b, 5, ld] with band[t][i] = B[i+t][i], the
+    reflectors V [b, ld, ld] (row r = v_r, pivot at r + 4) and tau [b, ld]; A = Q B Q^T, Q = H_0 H_1 ..."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b, ld, _ = A.shape
+    ns = np.full((b,), ld, dtype=np.int32) if n is None else np.ascontiguousarray(n, dtype=np.int32)
+    band, V, tau = np.zeros((b, 5, ld)), np.zeros((b, ld, ld)), np.zeros((b, ld))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib.imcom_band_reduce((ctx or default_context()).handle, b, p(ns), ld, p(A), p(band), p(V), p(tau), MEM_HOST))
+    return band, V, tau

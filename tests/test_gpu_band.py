@@ -1,0 +1,89 @@
+"""The band basis of the Eigen path (csrc/band.hip): Householder reduction A = Q B Q^T to bandwidth 4 with lazy rank-2k
+updates, against numpy -- the reflectors are multiplied out on the host, so Q^T A Q is checked entry by entry."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_band(band, n):
+    B = np.zeros((n, n))
+    for t in range(band.shape[0]):
+        for i in range(n - t):
+            B[i + t, i] = B[i, i + t] = band[t, i]
+    return B
+
+
+def _Q(V, tau, n):
+    Q = np.eye(n)
+    for r in range(n):
+        if tau[r] != 0.0:
+            v = V[r, :n]
+            Q -= tau[r] * np.outer(Q @ v, v)  # Q <- Q H_r
+    return Q
+
+
+def test_band_reduce_vs_numpy_ragged_batch():
+    """Matrices of 300, 193, 129, 70, 6, 5, 1 and 0 rows in one batch of ld = 384 (several lazy super-panels of 64 reflectors, a
+    trailing GEMM update, groups cut by the matrix end, matrices too small for any reflector): band entries, zero fill outside
+    the band, orthogonality of Q and the eigenvalues."""
+    from pyimcom_amd.linalg import band_reduce
+
+    rng = np.random.default_rng(4)
+    ld = 384
+    ns = [300, 193, 129, 70, 6, 5, 1, 0]
+    A = np.zeros((len(ns), ld, ld))
+    for s, n in enumerate(ns):
+        X = rng.standard_normal((n, n))
+        A[s, :n, :n] = X @ X.T / max(n, 1) + 0.01 * np.eye(n)
+    A[:, np.arange(ld), np.arange(ld)] += (np.arange(ld)[None, :] >= np.array(ns)[:, None]) * 1.0  # identity padding, as the builders leave it
+    band, V, tau = band_reduce(A, ns)
+    for s, n in enumerate(ns):
+        if n == 0:
+            continue
+        As = A[s, :n, :n]
+        Q = _Q(V[s], tau[s], n)
+        B = _dense_band(band[s][:, :n], n)
+        M = Q.T @ As @ Q
+        scale = np.abs(As).max()
+        assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-13, s
+        assert np.abs(np.triu(M, 5)).max() < 1e-13 * scale, s          # nothing outside the band
+        assert np.abs(M - B).max() < 1e-13 * scale, (s, np.abs(M - B).max())
+        assert np.abs(np.linalg.eigvalsh(B) - np.linalg.eigvalsh(As)).max() < 1e-13 * scale
+        assert np.all(V[s][:, :4] == 0) and all(np.all(V[s][r, : r + 4] == 0) for r in range(n))  # zero above the pivots
+        assert np.all(band[s][:, n:] == 0)
+
+
+def test_band_reduce_on_cfg3_matrix():
+    """The A of a cfg-3 stamp (N ~ 2.9k, ld = 2944) built on the device: the band's eigenvalues against LAPACK's of A, 2e-14 |A|."""
+    import ctypes as C
+
+    import torch
+    from scipy.linalg import eigvals_banded
+
+    from pyimcom_amd import synth
+    from pyimcom_amd._lib import MEM_DEVICE, check, lib
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    cfg = synth.CONFIGS["cfg3"]
+    st = synth.make_stamp(cfg, 3)
+    psfs, target = synth.make_psfs(cfg, st.n_expo)
+    sb = StampBatch(cfg, [st], PSFGroupTables(psfs, target, cfg.nfft))
+    sb.build()
+    torch.cuda.synchronize()
+    ld, n = sb.ldn, st.n
+    band = torch.zeros((1, 5, ld), dtype=torch.float64, device="cuda:0")
+    V = torch.zeros((1, ld, ld), dtype=torch.float64, device="cuda:0")
+    tau = torch.zeros((1, ld), dtype=torch.float64, device="cuda:0")
+    ns = np.array([n], dtype=np.int32)
+    sb._stream()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    check(lib.imcom_band_reduce(sb.ctx.handle, 1, ns.ctypes.data_as(C.c_void_p), ld, p(sb.A), p(band), p(V), p(tau), MEM_DEVICE))
+    torch.cuda.synchronize()
+    Ah = sb.A[0, :n, :n].cpu().numpy()
+    w = np.linalg.eigvalsh(Ah)
+    wb = eigvals_banded(band[0, :, :n].cpu().numpy(), lower=True)
+    norm = max(abs(w[0]), abs(w[-1]))
+    print(f"[band n={n}] |A|={norm:.3g} max |dlam|/|A| = {np.abs(wb - w).max() / norm:.2e}")
+    assert np.abs(wb - w).max() <= 2e-14 * norm
