@@ -11,12 +11,15 @@
 // multiplies it by all BW of them: a quarter of the passes.  The kappa search then solves banded instead of tridiagonal
 // systems per output pixel (eigen.hip) -- a few times the (small) work of the tridiagonal sweeps.
 //
-// Structure (per stamp; all kernels run the whole batch):
-//   band_step_kernel   one workgroup per stamp, the N x BW panel in LDS.  Phase W finishes the w vectors of the previous group
-//                      (w_c = tau (p_c - corrections) - 1/2 tau^2 (p_c . v_c) v_c, the lazy two-sided update of LAPACK's latrd with
-//                      the products M v_c from symv4); phase P forms the next group's BW reflectors from its panel
-//   symv4_kernel       the one pass over the trailing lower triangle: Z = At [v_0 .. v_3] (row sums + transposed partials per strip)
-//   GEMM               every TPL = 64 reflectors the trailing matrix gets its rank-2 x 64 update (the tile engine)
+// Structure (all kernels run the whole batch), per group of BW columns:
+//   symv4_kernel       the one pass over the trailing lower triangle: Z = At [v_0 .. v_3] (row sums + transposed partials per strip
+//                      of 32 rows); extra "dot blocks" of the same launch form V_k . v_c, W_k . v_c for the lazy super-panel's earlier
+//                      reflectors and the group's own v_c' . v_c
+//   band_apply_kernel  many workgroups per stamp: p_c = Z + the strips' partials - sum_k (v_k (w_k . v_c) + w_k (v_k . v_c))
+//   band_step_kernel   ONE workgroup per stamp.  Phase W: what is sequential inside the group -- w_c = tau (p_c - in-group
+//                      corrections) - 1/2 tau^2 (p_c . v_c) v_c (the lazy two-sided update of LAPACK's latrd).  Phase P: the next
+//                      group's N x BW panel into LDS with the super-panel's corrections, its BW reflectors one after the other
+//   GEMM               every BTPL = 64 reflectors the trailing matrix gets its rank-2 x 64 update (the tile engine)
 // Verified step by step against a numpy restatement of exactly this decomposition (band to 3e-15, eigenvalues to 6e-15).
 #include <algorithm>
 
@@ -72,93 +75,43 @@ __device__ inline void block_sums(double (&v)[NV], double *red)
 // columns g0 .. g0+BW-1 (needs Z4 / part4 from symv4_kernel); r0 >= 0: form the reflectors of columns r0 .. r0+BW-1.
 __global__ __launch_bounds__(BTHREADS) void band_step_kernel(const double *__restrict__ At, double *__restrict__ Vall, double *__restrict__ Wp,
                                                              double *__restrict__ tau, double *__restrict__ band, double *__restrict__ Z4,
-                                                             const double *__restrict__ part4, const int *__restrict__ n, int ld, int ps, int g0,
+                                                             const double *__restrict__ gramG, const int *__restrict__ n, int ld, int ps, int g0,
                                                              int r0)
 {
     extern __shared__ double sm[];
     double *vl = sm;                        // [BW][ld]: phase W the group's v_c, phase P the panel's columns
     double *coef = sm + (size_t)BW * ld;    // [2][BTPL][BW]
     double *red = coef + 2 * BTPL * BW;     // [16][4]
-    double *sc = red + 16 * 4;              // [BW][BW] w_c' . v_c, then [BW][BW] v_c' . v_c
-    const int s = blockIdx.x, ns = n[s], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *sc = red + 16 * 4;              // [BW][BW] w_c' . v_c
+    const int s = blockIdx.x, ns = n[s], tid = threadIdx.x;
     const long so = (long)s * ld * ld;
     const double *A = At + so;
     double *V = Vall + so, *W = Wp + (long)s * BTPL * ld, *tv = tau + (long)s * ld, *bd = band + (long)s * (BW + 1) * ld;
     double *Z = Z4 + (long)s * BW * ld;
-    const double *part = part4 + (long)s * (ld / BSTRIP) * BW * ld;
 
     // ------------------------------------------------------------------ phase W
+    // p_c = M v_c without the group's own corrections arrives in Z (symv4_kernel + band_apply_kernel: row sums, the strips'
+    // transposed partials and the super-panel's earlier reflectors are already in); what is left is the part that is
+    // sequential inside the group: w_c = tau_c (p_c - sum_{c' < c} (v_c' (w_c' . v_c) + w_c' (v_c' . v_c))) + alpha_c v_c.
     if (g0 >= 0 && g0 + BW + 1 < ns) {  // (a group whose first pivot has nothing below it has no reflector: tau = 0, w = 0)
         const int G = min(BW, ns - g0), kc = g0 - ps;
-        for (int i = g0 + tid; i < ns; i += BTHREADS)
-#pragma unroll
-            for (int c = 0; c < BW; c++) vl[c * ld + i] = c < G ? V[(long)(g0 + c) * ld + i] : 0.0;
-        __syncthreads();
-        // dots of the group's v_c with the super-panel's earlier reflectors and their w's: one wave per earlier reflector
-        for (int k = wave; k < kc; k += BTHREADS / 64) {
-            double dv[BW], dw[BW];
-#pragma unroll
-            for (int c = 0; c < BW; c++) dv[c] = dw[c] = 0.0;
-            const double *vk = V + (long)(ps + k) * ld, *wk = W + (long)k * ld;
-            for (int i = g0 + BW + lane; i < ns; i += 64) {
-                const double a = vk[i], b = wk[i];
-#pragma unroll
-                for (int c = 0; c < BW; c++) { const double x = vl[c * ld + i]; dv[c] += a * x; dw[c] += b * x; }
-            }
-#pragma unroll
-            for (int c = 0; c < BW; c++) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { dv[c] += __shfl_xor(dv[c], off, 64); dw[c] += __shfl_xor(dw[c], off, 64); }
-            }
-            if (lane == 0)
-#pragma unroll
-                for (int c = 0; c < BW; c++) { coef[k * BW + c] = dv[c]; coef[(BTPL + k) * BW + c] = dw[c]; }
-        }
-        // v_c' . v_c inside the group (c' < c): wave q takes pair q
-        if (wave < BW * (BW - 1) / 2) {
-            int c1 = 0, c2 = 1, q = wave;
-            while (q >= BW - 1 - c1) { q -= BW - 1 - c1; c1++; }
-            c2 = c1 + 1 + q;
-            double d = 0.0;
-            for (int i = g0 + BW + lane; i < ns; i += 64) d += vl[c1 * ld + i] * vl[c2 * ld + i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-            if (lane == 0) sc[BW * BW + c1 * BW + c2] = d;
-        }
-        __syncthreads();
-        // p_c without the group's own corrections: row sums + transposed partials of the strips below - earlier reflectors
-        const int slast = (ns - 1) / BSTRIP;
-        for (int i = g0 + 1 + tid; i < ns; i += BTHREADS) {
-            double p[BW];
-#pragma unroll
-            for (int c = 0; c < BW; c++) p[c] = Z[c * ld + i];
-            for (int st = i / BSTRIP + 1; st <= slast; st++)
-#pragma unroll
-                for (int c = 0; c < BW; c++) p[c] += part[((long)st * BW + c) * ld + i];
-            for (int k = 0; k < kc; k++) {
-                const double a = V[(long)(ps + k) * ld + i], b = W[(long)k * ld + i];
-#pragma unroll
-                for (int c = 0; c < BW; c++) p[c] -= a * coef[(BTPL + k) * BW + c] + b * coef[k * BW + c];
-            }
-#pragma unroll
-            for (int c = 0; c < BW; c++) Z[c * ld + i] = p[c];
-        }
-        // the group's w vectors, one after the other
+        const double *gram = gramG + (long)s * BW * BW;  // v_c' . v_c (c' < c), from the dot blocks of symv4_kernel
         for (int c = 0; c < G; c++) {
             const double tc = tv[g0 + c];
             double *wc = W + (long)(kc + c) * ld;
+            const double *vc = V + (long)(g0 + c) * ld;
             double a_[BW], b_[BW];
 #pragma unroll
-            for (int q = 0; q < BW; q++) { a_[q] = q < c ? sc[q * BW + c] : 0.0; b_[q] = q < c ? sc[BW * BW + q * BW + c] : 0.0; }
+            for (int q = 0; q < BW; q++) { a_[q] = q < c ? sc[q * BW + c] : 0.0; b_[q] = q < c ? gram[q * BW + c] : 0.0; }
             double dot[1] = {0.0};
             for (int i = g0 + 1 + tid; i < ns; i += BTHREADS) {
                 double p = Z[c * ld + i];
 #pragma unroll
                 for (int q = 0; q < BW; q++)
-                    if (q < c) p -= vl[q * ld + i] * a_[q] + W[(long)(kc + q) * ld + i] * b_[q];
+                    if (q < c) p -= V[(long)(g0 + q) * ld + i] * a_[q] + W[(long)(kc + q) * ld + i] * b_[q];
                 const double wprime = tc * p;
                 wc[i] = wprime;
-                dot[0] += wprime * vl[c * ld + i];
+                dot[0] += wprime * vc[i];
             }
             block_sums<1>(dot, red);
             const double alpha = -0.5 * tc * dot[0];
@@ -166,11 +119,11 @@ __global__ __launch_bounds__(BTHREADS) void band_step_kernel(const double *__res
 #pragma unroll
             for (int q = 0; q < BW; q++) d3[q] = 0.0;
             for (int i = g0 + 1 + tid; i < ns; i += BTHREADS) {
-                const double w = wc[i] + alpha * vl[c * ld + i];
+                const double w = wc[i] + alpha * vc[i];
                 wc[i] = w;
 #pragma unroll
                 for (int q = 0; q < BW; q++)
-                    if (q > c) d3[q] += w * vl[q * ld + i];
+                    if (q > c && q < G) d3[q] += w * V[(long)(g0 + q) * ld + i];
             }
             block_sums<BW>(d3, red);
             if (tid == 0)
@@ -245,14 +198,53 @@ __global__ __launch_bounds__(BTHREADS) void band_step_kernel(const double *__res
 // A workgroup takes a strip of 32 rows (4 waves x 8 rows), walks its columns in chunks of 128 (a double2 per lane) and
 // leaves (a) the row sums over the columns up to the strip's diagonal block and (b), from the same loads, the strip's
 // contributions to the rows left of it (part4[strip][c][column]); band_step_kernel adds the strips up.
-__global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ At, const double *__restrict__ Vall, const int *__restrict__ n,
-                                                    int ld, int r0, int nrowtiles, double *__restrict__ Z4, double *__restrict__ part4)
+__global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ At, const double *__restrict__ Vall, const double *__restrict__ Wp,
+                                                    const int *__restrict__ n, int ld, int r0, int ps, int nrowtiles, double *__restrict__ Z4,
+                                                    double *__restrict__ part4, double *__restrict__ coefG, double *__restrict__ gramG)
 {
     __shared__ double y2s[2][4][BW][128];
     const int s = blockIdx.y, ns = n[s];
     if (r0 + BW + 1 >= ns) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long so = (long)s * ld * ld;
+    if ((int)blockIdx.x >= nrowtiles) {
+        // dot blocks, one wave per task: (V_k . v_c, W_k . v_c) for the super-panel's earlier reflectors k (coefG[s][0 / 1][k][c]),
+        // then the group's own v_c' . v_c (gramG[s][c'][c])
+        const int task = ((int)blockIdx.x - nrowtiles) * 4 + wave, kc = r0 - ps;
+        const double *v0 = Vall + so + (long)r0 * ld;
+        if (task < kc) {
+            const double *vk = Vall + so + (long)(ps + task) * ld, *wk = Wp + ((long)s * BTPL + task) * ld;
+            double dv[BW], dw[BW];
+#pragma unroll
+            for (int c = 0; c < BW; c++) dv[c] = dw[c] = 0.0;
+            for (int i = r0 + BW + lane; i < ns; i += 64) {
+                const double a = vk[i], b = wk[i];
+#pragma unroll
+                for (int c = 0; c < BW; c++) { const double x = v0[(long)c * ld + i]; dv[c] += a * x; dw[c] += b * x; }
+            }
+#pragma unroll
+            for (int c = 0; c < BW; c++) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { dv[c] += __shfl_xor(dv[c], off, 64); dw[c] += __shfl_xor(dw[c], off, 64); }
+            }
+            if (lane == 0)
+#pragma unroll
+                for (int c = 0; c < BW; c++) {
+                    coefG[(((long)s * 2 + 0) * BTPL + task) * BW + c] = dv[c];
+                    coefG[(((long)s * 2 + 1) * BTPL + task) * BW + c] = dw[c];
+                }
+        } else if (task - kc < BW * (BW - 1) / 2) {
+            int c1 = 0, q = task - kc;
+            while (q >= BW - 1 - c1) { q -= BW - 1 - c1; c1++; }
+            const int c2 = c1 + 1 + q;
+            double d = 0.0;
+            for (int i = r0 + BW + lane; i < ns; i += 64) d += v0[(long)c1 * ld + i] * v0[(long)c2 * ld + i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+            if (lane == 0) gramG[(long)s * BW * BW + c1 * BW + c2] = d;
+        }
+        return;
+    }
     // longest strips (bottom of the matrix) first: they bound the launch's critical path
     const int strip = ((r0 + 1) / BSTRIP) + (nrowtiles - 1 - (int)blockIdx.x), rb = strip * BSTRIP;
     if (rb >= ns) return;
@@ -331,6 +323,44 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
     }
 }
 
+// Z[c][i] <- row sums + the transposed partials of the strips below row i - the super-panel's earlier reflectors:
+// p_c = (At - sum_k (v_k w_k^T + w_k v_k^T)) v_c on the rows i > g0, many workgroups per stamp (in the first version ONE
+// workgroup per stamp did this inside band_step_kernel: 8.8 MB per group and stamp through one CU, 147 us per launch).
+__global__ __launch_bounds__(256) void band_apply_kernel(const double *__restrict__ Vall, const double *__restrict__ Wp, const double *__restrict__ part4,
+                                                         const double *__restrict__ coefG, const int *__restrict__ n, int ld, int g0, int ps,
+                                                         double *__restrict__ Z4)
+{
+    __shared__ double cf[2 * BTPL * BW];
+    const int s = blockIdx.y, ns = n[s];
+    if (g0 + BW + 1 >= ns) return;
+    const int kc = g0 - ps;
+    for (int e = threadIdx.x; e < kc * BW; e += 256) {
+        cf[e] = coefG[((long)s * 2 + 0) * BTPL * BW + e];
+        cf[BTPL * BW + e] = coefG[((long)s * 2 + 1) * BTPL * BW + e];
+    }
+    __syncthreads();
+    const int i = g0 + 1 + blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const long so = (long)s * ld * ld;
+    const double *V = Vall + so + (long)ps * ld, *W = Wp + (long)s * BTPL * ld;
+    const double *part = part4 + (long)s * (ld / BSTRIP) * BW * ld;
+    double *Z = Z4 + (long)s * BW * ld;
+    double p[BW];
+#pragma unroll
+    for (int c = 0; c < BW; c++) p[c] = Z[(long)c * ld + i];
+    const int slast = (ns - 1) / BSTRIP;
+    for (int st = i / BSTRIP + 1; st <= slast; st++)
+#pragma unroll
+        for (int c = 0; c < BW; c++) p[c] += part[((long)st * BW + c) * ld + i];
+    for (int k = 0; k < kc; k++) {
+        const double a = V[(long)k * ld + i], b = W[(long)k * ld + i];
+#pragma unroll
+        for (int c = 0; c < BW; c++) p[c] -= a * cf[(BTPL + k) * BW + c] + b * cf[k * BW + c];
+    }
+#pragma unroll
+    for (int c = 0; c < BW; c++) Z[(long)c * ld + i] = p[c];
+}
+
 // At = A on the leading n x n (zero elsewhere)
 __global__ void band_init_kernel(const double *__restrict__ A, long lda, long strideA, const int *__restrict__ n, double *__restrict__ At, int ld)
 {
@@ -340,7 +370,7 @@ __global__ void band_init_kernel(const double *__restrict__ A, long lda, long st
     At[(long)s * ld * ld + (long)i * ld + j] = (i < ns && j < ns) ? A[s * strideA + (long)i * lda + j] : 0.0;
 }
 
-bool band_basis_fits(int ld) { return ((size_t)BW * ld + 2 * BTPL * BW + 16 * 4 + 2 * BW * BW) * 8 <= 160 * 1024; }
+bool band_basis_fits(int ld) { return ((size_t)BW * ld + 2 * BTPL * BW + 16 * 4 + BW * BW) * 8 <= 160 * 1024; }
 
 size_t band_basis_ws_bytes(int batch, int ld, int mp)
 {
@@ -358,6 +388,7 @@ size_t band_basis_ws_bytes(int batch, int ld, int mp)
     add((size_t)batch * BTPL * ld * 8);                     // Wp
     add((size_t)batch * BW * ld * 8);                       // Z4
     add((size_t)batch * (ld / BSTRIP) * BW * ld * 8);       // part4
+    add((size_t)batch * (2 * BTPL * BW + BW * BW) * 8);     // dots with the super-panel's reflectors, the group's Gram matrix
     return t + 8192;
 }
 
@@ -396,23 +427,31 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
     double *Wp = (double *)ws_take(ctx, (size_t)batch * BTPL * ld * 8);
     double *Z4 = (double *)ws_take(ctx, (size_t)batch * BW * ld * 8);
     double *part4 = (double *)ws_take(ctx, (size_t)batch * (ld / BSTRIP) * BW * ld * 8);
-    if (!At || !Wp || !Z4 || !part4) { set_error("internal: band workspace"); return IMCOM_ERR_NOMEM; }
+    double *coefG = (double *)ws_take(ctx, (size_t)batch * 2 * BTPL * BW * 8), *gramG = (double *)ws_take(ctx, (size_t)batch * BW * BW * 8);
+    if (!At || !Wp || !Z4 || !part4 || !coefG || !gramG) { set_error("internal: band workspace"); return IMCOM_ERR_NOMEM; }
     IMCOM_HIP_CHECK(hipMemsetAsync(out->Vall, 0, mat, st));
     IMCOM_HIP_CHECK(hipMemsetAsync(out->tauvec, 0, vecb, st));
     IMCOM_HIP_CHECK(hipMemsetAsync(out->band, 0, (size_t)batch * (BW + 1) * ld * 8, st));
     IMCOM_HIP_CHECK(hipMemsetAsync(Wp, 0, (size_t)batch * BTPL * ld * 8, st));
     hipLaunchKernelGGL(band_init_kernel, dim3((ld + 255) / 256, ld, batch), dim3(256), 0, st, A, lda, strideA, out->n_dev, At, ld);
     IMCOM_TRY(check_launch("band_init_kernel"));
-    const size_t lds = ((size_t)BW * ld + 2 * BTPL * BW + 16 * 4 + 2 * BW * BW) * 8;
+    const size_t lds = ((size_t)BW * ld + 2 * BTPL * BW + 16 * 4 + BW * BW) * 8;
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)band_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         ProfScope ps_(ctx, "eigen_trd", nmax);
         int ps = 0;
+        auto step = [&](int ps_, int g0, int r0) {
+            hipLaunchKernelGGL(band_step_kernel, dim3(batch), dim3(BTHREADS), lds, st, At, out->Vall, Wp, out->tauvec, out->band, Z4, gramG,
+                               out->n_dev, ld, ps_, g0, r0);
+        };
         for (int r0 = 0; r0 < nmax; r0 += BW) {
+            const int g0 = r0 - BW;  // the group whose w vectors are due
+            if (g0 >= 0 && g0 + BW + 1 < nmax)
+                hipLaunchKernelGGL(band_apply_kernel, dim3((nmax - g0 - 1 + 255) / 256, batch), dim3(256), 0, st, out->Vall, Wp, part4, coefG, out->n_dev, ld,
+                                   g0, ps, Z4);
             if (r0 - ps >= BTPL) {
                 // the previous group's w vectors, then the trailing two-sided update A[pe:, pe:] -= V W^T + W V^T; a new lazy panel
-                hipLaunchKernelGGL(band_step_kernel, dim3(batch), dim3(BTHREADS), lds, st, At, out->Vall, Wp, out->tauvec, out->band, Z4, part4,
-                                   out->n_dev, ld, ps, r0 - BW, -1);
+                step(ps, g0, -1);
                 IMCOM_TRY(check_launch("band_step_kernel"));
                 // The GEMM tiles are 128-aligned: start at the tile boundary at or below the panel's end.  The extra rows / columns
                 // it touches are already reduced (their band entries have been taken out) and are never read again.
@@ -423,14 +462,13 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
                 IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, BTPL, batch, Wq, ld, (long)BTPL * ld, Vp, ld, (long)ld * ld, C, ld, (long)ld * ld, -1.0, 1.0));
                 IMCOM_HIP_CHECK(hipMemsetAsync(Wp, 0, (size_t)batch * BTPL * ld * 8, st));
                 ps = r0;
-                hipLaunchKernelGGL(band_step_kernel, dim3(batch), dim3(BTHREADS), lds, st, At, out->Vall, Wp, out->tauvec, out->band, Z4, part4,
-                                   out->n_dev, ld, ps, -1, r0);
+                step(ps, -1, r0);
             } else
-                hipLaunchKernelGGL(band_step_kernel, dim3(batch), dim3(BTHREADS), lds, st, At, out->Vall, Wp, out->tauvec, out->band, Z4, part4,
-                                   out->n_dev, ld, ps, r0 > 0 ? r0 - BW : -1, r0);
+                step(ps, g0, r0);
             if (r0 + BW + 1 < nmax) {
-                const int nrowtiles = (nmax - 1) / BSTRIP - (r0 + 1) / BSTRIP + 1;
-                hipLaunchKernelGGL(symv4_kernel, dim3(nrowtiles, batch), dim3(256), 0, st, At, out->Vall, out->n_dev, ld, r0, nrowtiles, Z4, part4);
+                const int nrowtiles = (nmax - 1) / BSTRIP - (r0 + 1) / BSTRIP + 1, ndot = (r0 - ps + BW * (BW - 1) / 2 + 3) / 4;
+                hipLaunchKernelGGL(symv4_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, out->Vall, Wp, out->n_dev, ld, r0, ps, nrowtiles, Z4,
+                                   part4, coefG, gramG);
             }
             IMCOM_TRY(check_launch("band step"));
         }
