@@ -396,7 +396,8 @@ int trd_panel_factors(imcom_ctx *ctx, TrdBasis *out, int batch);  // tridiag.hip
 
 // A -> band B (out->band: [batch][BW+1][ld], band[t][i] = B[i+t][i]) and the reflectors of Q (out->Vall, out->tauvec), ready for
 // trd_apply_q.  Same contract as trd_basis_device; the caller has reserved band_basis_ws_bytes().
-int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out)
+int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out,
+                      const std::function<int(int)> &on_panel)
 {
     IMCOM_REQUIRE(ld % NB == 0 && ld >= NB && mp % NB == 0 && band_basis_fits(ld), "band reduction: ld=%d, mp=%d", ld, mp);
     const size_t mat = (size_t)batch * ld * ld * 8, vecb = (size_t)batch * ld * 8;
@@ -471,10 +472,13 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
                                    part4, coefG, gramG);
             }
             IMCOM_TRY(check_launch("band step"));
+            // the reflectors of columns < r0 + BW are final (phase P of this group has been queued): a whole panel of 128?
+            if (on_panel && (r0 + BW) % NB == 0 && (r0 + BW) / NB - 1 < out->npanels) IMCOM_TRY(on_panel((r0 + BW) / NB - 1));
         }
+        if (on_panel && out->npanels > 0 && ((nmax + BW - 1) / BW * BW) / NB - 1 < out->npanels - 1) IMCOM_TRY(on_panel(out->npanels - 1));  // the last, partial panel
     }
     ctx->ws_used = mark;  // the scratch is free again (same stream: everything queued so far runs before whatever reuses it)
-    return trd_panel_factors(ctx, out, batch);
+    return on_panel ? IMCOM_OK : trd_panel_factors(ctx, out, batch);
 }
 
 }  // namespace imcom

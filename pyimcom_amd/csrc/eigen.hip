@@ -411,11 +411,11 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
     const size_t big = (size_t)batch * np * mp * 8, szM = (size_t)batch * m;
     TrdBasis tb;
     const bool banded = eigen_uses_band(np);
-    if (banded) IMCOM_TRY(band_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
-    else IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
+    // buffers that outlive the reduction first (its scratch is handed back afterwards and must not lie under them)
     double *Cb = (double *)ws_take(ctx, big), *Lb = (double *)ws_take(ctx, banded ? big * BAND_BW : big);
     double *kpix = (double *)ws_take(ctx, szM * 8), *par = (double *)ws_take(ctx, (size_t)batch * 8 * 4);
-    if (!Cb || !Lb || !kpix || !par) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    int *n_early = (int *)ws_take(ctx, (size_t)batch * 4);
+    if (!Cb || !Lb || !kpix || !par || !n_early) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     std::vector<double> ph(4 * (size_t)batch);
     for (int s = 0; s < batch; s++) {
         ph[s] = C[s];
@@ -423,13 +423,46 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         ph[2 * batch + s] = kappaC[nv - 1] * C[s];  // kCmax C (214)
     }
     IMCOM_TRY(upload(ctx, par, ph.data(), ph.size()));
+    IMCOM_TRY(upload(ctx, n_early, n, (size_t)batch));
     hipStream_t st = ctx->stream;
     if (Bt_res) IMCOM_HIP_CHECK(hipMemcpyAsync(Cb, Bt_res, big, hipMemcpyDeviceToDevice, st));
     else {
-        hipLaunchKernelGGL(tri_pack_kernel, dim3(mp / 32, np / 32, batch), dim3(256), 0, st, B_ref, (long)ldn, m, tb.n_dev, Cb, np, mp);
+        hipLaunchKernelGGL(tri_pack_kernel, dim3(mp / 32, np / 32, batch), dim3(256), 0, st, B_ref, (long)ldn, m, n_early, Cb, np, mp);
         IMCOM_TRY(check_launch("tri_pack_kernel"));
     }
-    if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Qh^T b
+    if (banded) {
+        // c = Qh^T b panel by panel ON THE SECOND STREAM while the reduction goes on: a panel of 128 reflectors is final long
+        // before the matrix is reduced, its GEMMs are matrix-pipe work, the reduction's passes are memory work
+        while (ctx->sync_events.size() < 2) {
+            hipEvent_t e;
+            IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->sync_events.push_back(e);
+        }
+        hipEvent_t ev_main = ctx->sync_events[0], ev_aux = ctx->sync_events[1];
+        hipStream_t aux = ctx->aux_stream;
+        struct AuxDrain {  // whatever path leaves this scope, nothing may still run on the second stream (the workspace is reused)
+            hipStream_t s;
+            bool armed = true;
+            ~AuxDrain() { if (armed) hipStreamSynchronize(s); }
+        } drain{aux};
+        auto on_panel = [&](int p) -> int {
+            IMCOM_HIP_CHECK(hipEventRecord(ev_main, st));
+            IMCOM_HIP_CHECK(hipStreamWaitEvent(aux, ev_main, 0));
+            ctx->stream = aux;
+            const int rc = trd_panel_step(ctx, tb, batch, p, Cb, mp);
+            ctx->stream = st;
+            return rc;
+        };
+        const int rc = band_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb, nmax > 0 ? std::function<int(int)>(on_panel) : nullptr);
+        ctx->stream = st;
+        IMCOM_TRY(rc);
+        IMCOM_HIP_CHECK(hipEventRecord(ev_aux, aux));
+        IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_aux, 0));  // join: c is complete when the main stream goes on
+        drain.armed = false;
+    } else {
+        IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
+        if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Qh^T b
+    }
     {
         ProfScope ps(ctx, "lakernel1");
         if (banded) {

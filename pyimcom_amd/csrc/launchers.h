@@ -1,5 +1,7 @@
 // launchers.h -- host-side launch functions implemented next to their kernels.
 #pragma once
+#include <functional>
+
 #include "common.h"
 
 namespace imcom {
@@ -45,7 +47,11 @@ int trd_apply_q(imcom_ctx *ctx, const TrdBasis &b, int batch, double *C, int mp,
 // band.hip: the same with A = Q B Q^T, B of bandwidth BAND_BW (a quarter of the passes over the matrix); ld up to what the panel's LDS holds
 bool band_basis_fits(int ld);
 size_t band_basis_ws_bytes(int batch, int ld, int mp);
-int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out);
+// on_panel(p) (optional) is called on the host as soon as the launches that complete the 128 reflectors of panel p have been queued:
+// the caller may start applying them on another stream; the panels' T factors are then the caller's job (trd_panel_step)
+int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out,
+                      const std::function<int(int)> &on_panel = nullptr);
+int trd_panel_step(imcom_ctx *ctx, const TrdBasis &b, int batch, int p, double *C, int mp);  // T factor of panel p, then C <- (I - V T^T V^T) C (one step of Qh^T C)
 
 // la_kernels.hip
 int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail);

@@ -790,6 +790,24 @@ int trd_panel_factors(imcom_ctx *ctx, TrdBasis *out, int batch)
     return IMCOM_OK;
 }
 
+// One step of Qh^T C for a caller that overlaps it with the reduction: the triangular factor of panel p, then C <- (I - V T^T V^T) C
+int trd_panel_step(imcom_ctx *ctx, const TrdBasis &b, int batch, int p, double *C, int mp)
+{
+    ProfScope ps_(ctx, "eigen_applyq");
+    const int ld = b.ld, ps = p * TP, rem = ld - ps;
+    const double *Vp = b.Vall + (long)ps * ld + ps;
+    double *Tm = b.Tm + (size_t)p * batch * TP * TP;
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LARFT_LDS));
+    IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, rem, batch, Vp, ld, (long)ld * ld, Vp, ld, (long)ld * ld, b.Sm, TP, (long)TP * TP, 1.0, 0.0));
+    hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), LARFT_LDS, ctx->stream, b.Sm, b.tauvec, ld, ps, Tm);
+    IMCOM_TRY(check_launch("trd_larft_kernel"));
+    double *Cp = C + (long)ps * mp;
+    IMCOM_TRY(launch_gemm(ctx, false, true, TP, mp, rem, batch, Vp, ld, (long)ld * ld, Cp, mp, (long)ld * mp, b.W1, mp, (long)TP * mp, 1.0, 0.0));
+    IMCOM_TRY(launch_gemm(ctx, true, true, TP, mp, TP, batch, Tm, TP, (long)TP * TP, b.W1, mp, (long)TP * mp, b.W2, mp, (long)TP * mp, 1.0, 0.0));
+    IMCOM_TRY(launch_gemm(ctx, true, true, rem, mp, TP, batch, Vp, ld, (long)ld * ld, b.W2, mp, (long)TP * mp, Cp, mp, (long)ld * mp, -1.0, 1.0));
+    return IMCOM_OK;
+}
+
 // C [batch][ld][mp] <- Qh^T C (transpose) or Qh C: Qh = H_0 H_1 ... and a panel's H_ps ... H_pe-1 = I - V T V^T, so
 //   Qh^T C: panels in ascending order, C[ps:] -= V^T (T^T (V C[ps:]));   Qh C: descending order, C[ps:] -= V^T (T (V C[ps:]))
 int trd_apply_q(imcom_ctx *ctx, const TrdBasis &b, int batch, double *C, int mp, bool transpose)
