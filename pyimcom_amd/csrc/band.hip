@@ -19,7 +19,7 @@
 //   band_step_kernel   ONE workgroup per stamp.  Phase W: what is sequential inside the group -- w_c = tau (p_c - in-group
 //                      corrections) - 1/2 tau^2 (p_c . v_c) v_c (the lazy two-sided update of LAPACK's latrd).  Phase P: the next
 //                      group's N x BW panel into LDS with the super-panel's corrections, its BW reflectors one after the other
-//   GEMM               every BTPL = 64 reflectors the trailing matrix gets its rank-2 x 64 update (the tile engine)
+//   syr2k (tile engine) every BTPL = 64 reflectors the trailing matrix gets its rank-2 x 64 update, lower 128-tiles only
 // Verified step by step against a numpy restatement of exactly this decomposition (band to 3e-15, eigenvalues to 6e-15).
 #include <algorithm>
 
@@ -32,6 +32,7 @@ constexpr int BW = BAND_BW;      // bandwidth = reflectors per group
 constexpr int BTPL = 64;         // reflectors per lazy super-panel (multiple of BW)
 constexpr int BTHREADS = 1024;   // band_step_kernel: one workgroup per stamp
 constexpr int BSTRIP = 32;       // rows per strip of the symmetric product
+static_assert(BW == 4, "the panel loads of band_step_kernel take four columns as two double2");
 
 struct BHouse {
     double beta, tau, scale;
@@ -145,9 +146,13 @@ __global__ __launch_bounds__(BTHREADS) void band_step_kernel(const double *__res
         }
         __syncthreads();
         for (int i = r0 + tid; i < ns; i += BTHREADS) {
-            double x[BW];
+            // columns r0 .. r0+BW-1 of row i: the lower triangle (the trailing updates leave the upper tiles behind), 32 bytes per row
+            const double2 *ap = (const double2 *)(A + (long)i * ld + r0);
+            const double2 a01 = ap[0], a23 = ap[1];
+            double x[BW] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
-            for (int c = 0; c < BW; c++) x[c] = c < G ? A[(long)(r0 + c) * ld + i] : 0.0;  // row r0+c read as column (symmetric)
+            for (int c = 0; c < BW; c++)
+                if (c >= G) x[c] = 0.0;
             for (int k = 0; k < kc; k++) {
                 const double a = V[(long)(ps + k) * ld + i], b = W[(long)k * ld + i];
 #pragma unroll
@@ -459,8 +464,8 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
                 const int pa = r0 / NB * NB, rem = ld - pa;
                 const double *Vp = out->Vall + (long)ps * ld + pa, *Wq = Wp + pa;
                 double *C = At + (long)pa * ld + pa;
-                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, BTPL, batch, Vp, ld, (long)ld * ld, Wq, ld, (long)BTPL * ld, C, ld, (long)ld * ld, -1.0, 1.0));
-                IMCOM_TRY(launch_gemm(ctx, true, true, rem, rem, BTPL, batch, Wq, ld, (long)BTPL * ld, Vp, ld, (long)ld * ld, C, ld, (long)ld * ld, -1.0, 1.0));
+                // (lower tiles only: the symmetric product and the panels read the trailing matrix from its lower triangle)
+                IMCOM_TRY(launch_syr2k_lower(ctx, rem, BTPL, batch, Vp, ld, (long)ld * ld, Wq, ld, (long)BTPL * ld, C, ld, (long)ld * ld, -1.0));
                 IMCOM_HIP_CHECK(hipMemsetAsync(Wp, 0, (size_t)batch * BTPL * ld * 8, st));
                 ps = r0;
                 step(ps, -1, r0);

@@ -347,6 +347,41 @@ __global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void gemm_kernel(const d
     })
 }
 
+// Symmetric rank-2K update of the LOWER 128-tiles only: C[i][j] += alpha sum_k (V[k][i] W[k][j] + W[k][i] V[k][j]) for the tiles
+// with tile column <= tile row (diagonal tiles whole).  Both products go through the same accumulators; the band reduction's
+// trailing matrix is only ever read from its lower triangle, so half the tiles of a square update are enough.
+__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void syr2k_lower_kernel(const double *__restrict__ V, long ldv, long strideV,
+                                                                                const double *__restrict__ W, long ldw, long strideW,
+                                                                                double *__restrict__ C, long ldc, long strideC, int K, double alpha)
+{
+    __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
+    const int s = blockIdx.y, t = blockIdx.x;
+    int tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
+    while (tm * (tm + 1) / 2 > t) tm--;
+    const int tn = t - tm * (tm + 1) / 2;
+    const double *Vs = V + s * strideV, *Ws = W + s * strideW;
+    f64x4 acc[4][MMA_NJ];
+    zero_acc(acc);
+    mma_tile_dma<true, true>(acc, Vs + (long)tm * NB, ldv, Ws + (long)tn * NB, ldw, K, smem);
+    mma_tile_dma<true, true>(acc, Ws + (long)tm * NB, ldw, Vs + (long)tn * NB, ldv, K, smem);
+    double *Co = C + s * strideC + (long)tm * NB * ldc + (long)tn * NB;
+    IMCOM_FOR_ACC(row, col, v, {
+        double *p = Co + (long)row * ldc + col;
+        *p += alpha * v;
+    })
+}
+
+int launch_syr2k_lower(imcom_ctx *ctx, int N, int K, int batch, const double *V, long ldv, long strideV, const double *W, long ldw, long strideW,
+                       double *C, long ldc, long strideC, double alpha)
+{
+    IMCOM_REQUIRE(N % NB == 0 && K % BK == 0 && N > 0, "launch_syr2k_lower: sizes must be padded (N=%d K=%d)", N, K);
+    const int nt = N / NB;
+    hipLaunchKernelGGL(syr2k_lower_kernel, dim3(nt * (nt + 1) / 2, batch), dim3(MMA_THREADS), 0, ctx->stream, V, ldv, strideV, W, ldw, strideW, C, ldc,
+                       strideC, K, alpha);
+    return check_launch("syr2k_lower_kernel");
+}
+
 // diagnostic: the k-major x k-major product with parts of the k loop taken out (mma_tile_dma's ABL); the result is not a product
 template <int ABL>
 __global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void gemm_abl_kernel(const double *__restrict__ A, long lda, long strideA,

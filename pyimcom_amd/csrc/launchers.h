@@ -22,6 +22,8 @@ int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, in
 int launch_probe_fill(imcom_ctx *ctx, double *p, long count, unsigned seed);
 int launch_gemm_probe16(imcom_ctx *ctx, int M, int N, int K, int batch, const double *A, const double *B, double *C);
 int launch_mfma_probe(imcom_ctx *ctx, int nwg, int iters, double *sink, int *waves_per_wg);
+int launch_syr2k_lower(imcom_ctx *ctx, int N, int K, int batch, const double *V, long ldv, long strideV, const double *W, long ldw, long strideW,
+                       double *C, long ldc, long strideC, double alpha);  // lower 128-tiles of C += alpha (V^T W + W^T V), V, W k-major
 int launch_gemm(imcom_ctx *ctx, bool akm, bool bkm, int M, int N, int K, int batch, const double *A, long lda,
                 long strideA, const double *B, long ldb, long strideB, double *C, long ldc, long strideC,
                 double alpha, double beta);
