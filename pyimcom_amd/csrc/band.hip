@@ -31,6 +31,7 @@ namespace imcom {
 constexpr int BW = BAND_BW;      // bandwidth = reflectors per group
 constexpr int BTPL = 64;         // reflectors per lazy super-panel (multiple of BW)
 constexpr int BTHREADS = 1024;   // band_step_kernel: one workgroup per stamp
+constexpr int RTHREADS = 512;    // band_step_reg_kernel (256 registers per thread)
 constexpr int BSTRIP = 32;       // rows per strip of the symmetric product
 static_assert(BW == 4, "the panel loads of band_step_kernel take four columns as two double2");
 
@@ -49,8 +50,8 @@ __device__ inline BHouse bhouse(double a0, double xn2)
     return h;
 }
 
-// sums of NV values over the workgroup (1024 threads), returned to every thread; red: [16][NV] doubles of LDS
-template <int NV>
+// sums of NV values over the workgroup (NT threads), returned to every thread; red: [NT / 64][NV] doubles of LDS
+template <int NV, int NT = BTHREADS>
 __device__ inline void block_sums(double (&v)[NV], double *red)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,7 +68,8 @@ __device__ inline void block_sums(double (&v)[NV], double *red)
 #pragma unroll
     for (int q = 0; q < NV; q++) {
         double t = 0.0;
-        for (int w = 0; w < BTHREADS / 64; w++) t += red[w * NV + q];
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) t += red[w * NV + q];
         v[q] = t;
     }
 }
@@ -76,8 +78,8 @@ __device__ inline void block_sums(double (&v)[NV], double *red)
 // columns g0 .. g0+BW-1 (needs Z4 / part4 from symv4_kernel); r0 >= 0: form the reflectors of columns r0 .. r0+BW-1.
 __global__ __launch_bounds__(BTHREADS) void band_step_kernel(const double *__restrict__ At, double *__restrict__ Vall, double *__restrict__ Wp,
                                                              double *__restrict__ tau, double *__restrict__ band, double *__restrict__ Z4,
-                                                             const double *__restrict__ gramG, const int *__restrict__ n, int ld, int ps, int g0,
-                                                             int r0)
+                                                             const double *__restrict__ gramG, const double *__restrict__ Xp,
+                                                             const int *__restrict__ n, int ld, int ps, int g0, int r0)
 {
     extern __shared__ double sm[];
     double *vl = sm;                        // [BW][ld]: phase W the group's v_c, phase P the panel's columns
@@ -138,25 +140,35 @@ __global__ __launch_bounds__(BTHREADS) void band_step_kernel(const double *__res
     // ------------------------------------------------------------------ phase P
     if (r0 >= 0 && r0 < ns) {
         const int G = min(BW, ns - r0), kc = r0 - ps;
-        for (int e = tid; e < kc * BW; e += BTHREADS) {
-            const int k = e / BW, c = e % BW;
+        // the panel arrives from band_apply_kernel with the corrections of the super-panel's reflectors before the previous group;
+        // that group's own (their w vectors come from phase W of this launch) are added here.  First group of a super-panel: At itself.
+        const int k0 = kc > 0 ? kc - BW : 0;
+        for (int e = tid; e < (kc - k0) * BW; e += BTHREADS) {
+            const int k = k0 + e / BW, c = e % BW;
             const bool in = c < G;
-            coef[k * BW + c] = in ? V[(long)(ps + k) * ld + r0 + c] : 0.0;         // v_k[column]
-            coef[(BTPL + k) * BW + c] = in ? W[(long)k * ld + r0 + c] : 0.0;      // w_k[column]
+            coef[e] = in ? V[(long)(ps + k) * ld + r0 + c] : 0.0;            // v_k[column]
+            coef[BTPL * BW + e] = in ? W[(long)k * ld + r0 + c] : 0.0;      // w_k[column]
         }
         __syncthreads();
+        const double *X = Xp + (long)s * BW * ld;
         for (int i = r0 + tid; i < ns; i += BTHREADS) {
-            // columns r0 .. r0+BW-1 of row i: the lower triangle (the trailing updates leave the upper tiles behind), 32 bytes per row
-            const double2 *ap = (const double2 *)(A + (long)i * ld + r0);
-            const double2 a01 = ap[0], a23 = ap[1];
-            double x[BW] = {a01.x, a01.y, a23.x, a23.y};
+            double x[BW];
+            if (kc > 0) {
 #pragma unroll
-            for (int c = 0; c < BW; c++)
-                if (c >= G) x[c] = 0.0;
-            for (int k = 0; k < kc; k++) {
+                for (int c = 0; c < BW; c++) x[c] = X[(long)c * ld + i];
+            } else {
+                // columns r0 .. r0+BW-1 of row i: the lower triangle (the trailing updates leave the upper tiles behind), 32 bytes per row
+                const double2 *ap = (const double2 *)(A + (long)i * ld + r0);
+                const double2 a01 = ap[0], a23 = ap[1];
+                x[0] = a01.x; x[1] = a01.y; x[2] = a23.x; x[3] = a23.y;
+#pragma unroll
+                for (int c = 0; c < BW; c++)
+                    if (c >= G) x[c] = 0.0;
+            }
+            for (int k = k0; k < kc; k++) {
                 const double a = V[(long)(ps + k) * ld + i], b = W[(long)k * ld + i];
 #pragma unroll
-                for (int c = 0; c < BW; c++) x[c] -= a * coef[(BTPL + k) * BW + c] + b * coef[k * BW + c];
+                for (int c = 0; c < BW; c++) x[c] -= a * coef[(BTPL + k - k0) * BW + c] + b * coef[(k - k0) * BW + c];
             }
 #pragma unroll
             for (int c = 0; c < BW; c++) vl[c * ld + i] = x[c];
@@ -199,15 +211,184 @@ __global__ __launch_bounds__(BTHREADS) void band_step_kernel(const double *__res
     }
 }
 
+// The same step with every vector in REGISTERS or the thread's own LDS slots (512 threads, ld <= NR x 512: thread t owns the rows
+// base + t + 512 r): the group's reflectors,
+// w vectors and the panel never touch LDS or memory between the passes, and the algebra is arranged so that each column needs
+// ONE reduction over the workgroup -- phase W: sum_i w'_c v_q for q >= c gives the dot (q = c) and, with the group's Gram
+// matrix, w_c . v_q = w'_c . v_q + alpha v_c . v_q; phase P: S_q = sum_{i > piv} x_q x_c and the pivot row x_q[piv] give the norm
+// (q = c) and (M v)[q] = x_q[piv] + scale S_q.  8 reductions per launch instead of 16, no passes over memory in between.
+template <int NR>
+__global__ __launch_bounds__(RTHREADS) void band_step_reg_kernel(const double *__restrict__ At, double *__restrict__ Vall, double *__restrict__ Wp,
+                                                                 double *__restrict__ tau, double *__restrict__ band, const double *__restrict__ Z4,
+                                                                 const double *__restrict__ gramG, const double *__restrict__ Xp,
+                                                                 const int *__restrict__ n, int ld, int ps, int g0, int r0)
+{
+    extern __shared__ double sm[];
+    double *vs = sm;                                  // [BW][NR][512]: the group's reflectors at this thread's rows (only their owner touches them)
+    double *red = sm + (size_t)BW * NR * RTHREADS;    // [8][2 BW]
+    double (*cw)[BW][BW] = (double (*)[BW][BW])(red + 16 * 2 * BW);  // v_q[r0 + c], w_q[r0 + c] of the group whose w vectors phase W has just made
+#define VS_(c, r) vs[((c) * NR + (r)) * RTHREADS + tid]
+    const int s = blockIdx.x, ns = n[s], tid = threadIdx.x;
+    const long so = (long)s * ld * ld;
+    const double *A = At + so;
+    double *V = Vall + so, *W = Wp + (long)s * BTPL * ld, *tv = tau + (long)s * ld, *bd = band + (long)s * (BW + 1) * ld;
+    const int base = g0 >= 0 ? g0 + 1 : r0;
+    double w[BW][NR];
+#pragma unroll
+    for (int c = 0; c < BW; c++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) { VS_(c, r) = 0.0; w[c][r] = 0.0; }
+    // ------------------------------------------------------------------ phase W (see band_step_kernel)
+    if (g0 >= 0 && g0 + BW + 1 < ns) {
+        const int kc = g0 - ps;
+        const double *Z = Z4 + (long)s * BW * ld, *gram = gramG + (long)s * BW * BW;
+        double z[BW][NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = base + tid + r * RTHREADS;
+#pragma unroll
+            for (int c = 0; c < BW; c++) {
+                z[c][r] = i < ns ? Z[(long)c * ld + i] : 0.0;
+                VS_(c, r) = i < ns ? V[(long)(g0 + c) * ld + i] : 0.0;
+            }
+        }
+        double gq[BW][BW], wv[BW][BW];  // v_q . v_c and w_q . v_c (q < c)
+#pragma unroll
+        for (int q = 0; q < BW; q++)
+#pragma unroll
+            for (int c = 0; c < BW; c++) { gq[q][c] = q < c ? gram[q * BW + c] : 0.0; wv[q][c] = 0.0; }
+#pragma unroll
+        for (int c = 0; c < BW; c++) {
+            const double tc = tv[g0 + c];
+            double sums[BW];
+#pragma unroll
+            for (int q = 0; q < BW; q++) sums[q] = 0.0;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                double p = z[c][r];
+#pragma unroll
+                for (int q = 0; q < BW; q++)
+                    if (q < c) p -= VS_(q, r) * wv[q][c] + w[q][r] * gq[q][c];
+                const double wp = tc * p;
+                w[c][r] = wp;
+#pragma unroll
+                for (int q = 0; q < BW; q++)
+                    if (q >= c) sums[q] += wp * VS_(q, r);
+            }
+            block_sums<BW, RTHREADS>(sums, red);
+            const double alpha = -0.5 * tc * sums[c];
+#pragma unroll
+            for (int r = 0; r < NR; r++) w[c][r] += alpha * VS_(c, r);
+#pragma unroll
+            for (int q = 0; q < BW; q++)
+                if (q > c) wv[c][q] = sums[q] + alpha * gq[c][q];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = base + tid + r * RTHREADS;
+            if (i < ns)
+#pragma unroll
+                for (int c = 0; c < BW; c++) W[(long)(kc + c) * ld + i] = w[c][r];
+        }
+    }
+    // ------------------------------------------------------------------ phase P
+    if (r0 >= 0 && r0 < ns) {
+        const int G = min(BW, ns - r0), kc = r0 - ps;
+        // The panel arrives from band_apply_kernel with the corrections of the super-panel's reflectors before the previous group;
+        // that group's own are in this thread's registers, their entries at the panel's columns come from the rows' owners.
+        // (kc > 0 implies that phase W ran in this launch; a group without reflectors left zeros.)  kc = 0: At itself.
+        if (kc > 0) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int i = base + tid + r * RTHREADS;
+                if (i >= r0 && i < r0 + BW)
+#pragma unroll
+                    for (int q = 0; q < BW; q++) { cw[0][q][i - r0] = VS_(q, r); cw[1][q][i - r0] = w[q][r]; }
+            }
+        }
+        __syncthreads();
+        const double *X = Xp + (long)s * BW * ld;
+        double x[BW][NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int i = base + tid + r * RTHREADS;
+            const bool act = i >= r0 && i < ns;
+            if (kc > 0) {
+#pragma unroll
+                for (int c = 0; c < BW; c++) x[c][r] = act && c < G ? X[(long)c * ld + i] : 0.0;
+#pragma unroll
+                for (int q = 0; q < BW; q++)
+#pragma unroll
+                    for (int c = 0; c < BW; c++) x[c][r] -= VS_(q, r) * cw[1][q][c] + w[q][r] * cw[0][q][c];
+#pragma unroll
+                for (int c = 0; c < BW; c++)
+                    if (!(act && c < G)) x[c][r] = 0.0;
+            } else if (act) {
+                const double2 *ap = (const double2 *)(A + (long)i * ld + r0);  // the lower triangle: 32 bytes per row
+                const double2 a01 = ap[0], a23 = ap[1];
+                x[0][r] = a01.x; x[1][r] = a01.y; x[2][r] = a23.x; x[3][r] = a23.y;
+#pragma unroll
+                for (int c = 0; c < BW; c++)
+                    if (c >= G) x[c][r] = 0.0;
+            } else {
+#pragma unroll
+                for (int c = 0; c < BW; c++) x[c][r] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < BW; c++) {
+            if (c >= G) break;
+            const int rr = r0 + c, piv = rr + BW;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int i = base + tid + r * RTHREADS;
+                if (i >= rr && i < rr + BW && i < ns) bd[(long)(i - rr) * ld + rr] = x[c][r];  // final: later reflectors start below
+            }
+            if (piv < ns) {
+                double sums[2 * BW];
+#pragma unroll
+                for (int q = 0; q < 2 * BW; q++) sums[q] = 0.0;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const int i = base + tid + r * RTHREADS;
+#pragma unroll
+                    for (int q = 0; q < BW; q++)
+                        if (q >= c) {
+                            if (i > piv) sums[q] += x[q][r] * x[c][r];
+                            if (i == piv) sums[BW + q] = x[q][r];
+                        }
+                }
+                block_sums<2 * BW, RTHREADS>(sums, red);
+                const BHouse h = bhouse(sums[BW + c], sums[c]);
+                if (tid == 0) { bd[(long)BW * ld + rr] = h.beta; tv[rr] = h.tau; }
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const int i = base + tid + r * RTHREADS;
+                    const double vv = i == piv ? 1.0 : (i > piv ? h.scale * x[c][r] : 0.0);  // (x is zero beyond the stamp)
+                    if (i >= piv && i < ns) V[(long)rr * ld + i] = vv;
+#pragma unroll
+                    for (int q = 0; q < BW; q++)
+                        if (q > c) x[q][r] -= vv * (h.tau * (sums[BW + q] + h.scale * sums[q]));
+                }
+            } else if (tid == 0) {
+                bd[(long)BW * ld + rr] = 0.0;
+                tv[rr] = 0.0;
+            }
+        }
+    }
+}
+#undef VS_
+
 // Z[c][i] = (At v_c)[i] for the BW reflectors of columns r0 .. r0+BW-1, rows i > r0: one pass over the trailing lower triangle.
-// A workgroup takes a strip of 32 rows (4 waves x 8 rows), walks its columns in chunks of 128 (a double2 per lane) and
+// A workgroup takes a strip of 32 rows, walks its columns in chunks of 128 (32 per wave, a double2 per lane and row) and
 // leaves (a) the row sums over the columns up to the strip's diagonal block and (b), from the same loads, the strip's
-// contributions to the rows left of it (part4[strip][c][column]); band_step_kernel adds the strips up.
+// contributions to the rows left of it (part4[strip][c][column]); band_apply_kernel adds the strips up.
 __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ At, const double *__restrict__ Vall, const double *__restrict__ Wp,
                                                     const int *__restrict__ n, int ld, int r0, int ps, int nrowtiles, double *__restrict__ Z4,
                                                     double *__restrict__ part4, double *__restrict__ coefG, double *__restrict__ gramG)
 {
-    __shared__ double y2s[2][4][BW][128];
+    __shared__ __attribute__((aligned(16))) double urs[BSTRIP][BW];
+    __shared__ double racc[4][BSTRIP][BW];
     const int s = blockIdx.y, ns = n[s];
     if (r0 + BW + 1 >= ns) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -253,14 +434,17 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
     // longest strips (bottom of the matrix) first: they bound the launch's critical path
     const int strip = ((r0 + 1) / BSTRIP) + (nrowtiles - 1 - (int)blockIdx.x), rb = strip * BSTRIP;
     if (rb >= ns) return;
-    const int rw = rb + wave * 8;
-    const double *v0 = Vall + so + (long)r0 * ld;
-    double ur[BW][8];  // the reflectors at this wave's rows (wave-uniform)
-#pragma unroll
-    for (int c = 0; c < BW; c++)
-#pragma unroll
-        for (int i = 0; i < 8; i++) ur[c][i] = rw + i < ns ? v0[(long)c * ld + rw + i] : 0.0;
-    const double *A = At + so + (long)rw * ld;
+    if (threadIdx.x < BSTRIP * BW) {
+        const int i = threadIdx.x / BW, c = threadIdx.x % BW;
+        urs[i][c] = rb + i < ns ? Vall[so + (long)(r0 + c) * ld + rb + i] : 0.0;  // the reflectors at the strip's rows
+    }
+    __syncthreads();
+    // A chunk is 32 rows x 128 columns; wave w takes ALL 32 rows of columns [32 w, 32 w + 32): lane = (row group g of 8 rows,
+    // column pair lp).  The transposed contributions of a column are then complete inside the wave (two shuffles over g) and go
+    // straight to memory -- the main loop has no LDS exchange and no barrier (the first version split the chunk by rows: one
+    // barrier per chunk, 3.6 TB/s at best).  The row sums meet once, at the end of the strip.
+    const int g = lane >> 4, lp = lane & 15;
+    const int colw = wave * 32 + lp * 2;
     double *part_s = part4 + (((long)s * (ld / BSTRIP) + strip) * BW) * ld;
     double acc[BW][8];
 #pragma unroll
@@ -268,102 +452,146 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[c][i] = 0.0;
     const int cend = rb + BSTRIP, cfirst = (r0 + 1) & ~127;
-    int buf = 0;
-    double2 an[8], un[BW];
-    auto fetch = [&](int c0) {
-        const int cc = c0 + 2 * lane;
+    // Buffer loads: one descriptor per operand (wave-uniform), the chunk's part of the address in a scalar offset, the lane's in ONE
+    // vector register (with 64-bit pointers the 12 loads of a chunk hold 24 registers of addresses per register set)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(At + so), 0, (int)((long)ld * ld * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(Vall + so), 0, (int)((long)ld * ld * 8), 0x00020000);
+    const int voff_a = ((g * 8) * ld + colw) * 8, voff_u = colw * 8;
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        const v4i_ q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return __builtin_bit_cast(double2, q);
+    };
+    auto fetch = [&](double2 (&an)[8], double2 (&un)[BW], int c0) {
+        if (c0 >= cend) return;
 #pragma unroll
         for (int c = 0; c < BW; c++) {
-            un[c] = *(const double2 *)(v0 + (long)c * ld + cc);
-            if (cc >= cend) un[c].x = 0.0;
-            if (cc + 1 >= cend) un[c].y = 0.0;
+            un[c] = ld2(rv, voff_u, ((r0 + c) * ld + c0) * 8);
+            if (c0 + colw >= cend) un[c].x = 0.0;
+            if (c0 + colw + 1 >= cend) un[c].y = 0.0;
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) an[i] = *(const double2 *)(A + (long)i * ld + cc);
+        for (int i = 0; i < 8; i++) an[i] = ld2(ra, voff_a, ((rb + i) * ld + c0) * 8);
     };
-    fetch(cfirst);
-    for (int c0 = cfirst; c0 < cend; c0 += 128, buf ^= 1) {
-        double2 a[8], uu[BW];
-#pragma unroll
-        for (int c = 0; c < BW; c++) uu[c] = un[c];
-#pragma unroll
-        for (int i = 0; i < 8; i++) a[i] = an[i];
-        if (c0 + 128 < cend) fetch(c0 + 128);
+    auto process = [&](const double2 (&a)[8], const double2 (&uu)[BW], int c0) {
         double2 y2[BW];
 #pragma unroll
         for (int c = 0; c < BW; c++) y2[c] = make_double2(0.0, 0.0);
+        asm volatile("" ::: "memory");  // the reflector rows are re-read from LDS in every chunk: hoisted out of the loop they take 64 registers
 #pragma unroll
         for (int i = 0; i < 8; i++) {
+            const double2 u01 = *(const double2 *)&urs[g * 8 + i][0], u23 = *(const double2 *)&urs[g * 8 + i][2];
+            const double ur[BW] = {u01.x, u01.y, u23.x, u23.y};
 #pragma unroll
             for (int c = 0; c < BW; c++) {
                 acc[c][i] += a[i].x * uu[c].x + a[i].y * uu[c].y;
-                y2[c].x += a[i].x * ur[c][i];
-                y2[c].y += a[i].y * ur[c][i];
+                y2[c].x += a[i].x * ur[c];
+                y2[c].y += a[i].y * ur[c];
             }
         }
-        if (c0 < rb) {  // columns strictly left of the diagonal block receive the transposed contributions
+        if (c0 + wave * 32 < rb) {  // (wave-uniform) columns left of the diagonal block receive the transposed contributions
 #pragma unroll
-            for (int c = 0; c < BW; c++) *(double2 *)&y2s[buf][wave][c][2 * lane] = y2[c];
-            __syncthreads();
-            for (int e = threadIdx.x; e < BW * 128; e += 256) {
-                const int c = e >> 7, t = e & 127;
-                if (c0 + t < rb) part_s[(long)c * ld + c0 + t] = (y2s[buf][0][c][t] + y2s[buf][1][c][t]) + (y2s[buf][2][c][t] + y2s[buf][3][c][t]);
+            for (int c = 0; c < BW; c++) {
+                y2[c].x += __shfl_xor(y2[c].x, 16, 64);
+                y2[c].y += __shfl_xor(y2[c].y, 16, 64);
+                y2[c].x += __shfl_xor(y2[c].x, 32, 64);
+                y2[c].y += __shfl_xor(y2[c].y, 32, 64);
             }
+            if (g == 0)
+#pragma unroll
+                for (int c = 0; c < BW; c++) *(double2 *)(part_s + (long)c * ld + c0 + colw) = y2[c];
         }
+    };
+    double2 s0[8], s1[8], u0[BW], u1[BW];
+    fetch(s0, u0, cfirst);
+    for (int c0 = cfirst; c0 < cend; c0 += 256) {
+        fetch(s1, u1, c0 + 128);
+        process(s0, u0, c0);
+        if (c0 + 128 >= cend) break;
+        fetch(s0, u0, c0 + 256);
+        process(s1, u1, c0 + 128);
     }
+    // row sums: over the 16 column pairs of the wave, then over the four waves
 #pragma unroll
     for (int c = 0; c < BW; c++)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc[c][i] += __shfl_xor(acc[c][i], off, 64);
+            for (int off = 8; off > 0; off >>= 1) acc[c][i] += __shfl_xor(acc[c][i], off, 64);
         }
-    if (lane == 0) {
-        double *Zs = Z4 + (long)s * BW * ld;
+    if (lp == 0)
 #pragma unroll
         for (int c = 0; c < BW; c++)
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (rw + i < ns) Zs[(long)c * ld + rw + i] = acc[c][i];
+            for (int i = 0; i < 8; i++) racc[wave][g * 8 + i][c] = acc[c][i];
+    __syncthreads();
+    if (threadIdx.x < BSTRIP * BW) {
+        const int i = threadIdx.x / BW, c = threadIdx.x % BW;
+        if (rb + i < ns) Z4[((long)s * BW + c) * ld + rb + i] = (racc[0][i][c] + racc[1][i][c]) + (racc[2][i][c] + racc[3][i][c]);
     }
 }
 
 // Z[c][i] <- row sums + the transposed partials of the strips below row i - the super-panel's earlier reflectors:
 // p_c = (At - sum_k (v_k w_k^T + w_k v_k^T)) v_c on the rows i > g0, many workgroups per stamp (in the first version ONE
 // workgroup per stamp did this inside band_step_kernel: 8.8 MB per group and stamp through one CU, 147 us per launch).
-__global__ __launch_bounds__(256) void band_apply_kernel(const double *__restrict__ Vall, const double *__restrict__ Wp, const double *__restrict__ part4,
-                                                         const double *__restrict__ coefG, const int *__restrict__ n, int ld, int g0, int ps,
-                                                         double *__restrict__ Z4)
+// From the same loads of v_k, w_k: the NEXT group's panel, Xp[c][i] = (At - sum_k (v_k w_k^T + w_k v_k^T))[i][g0 + BW + c] for the
+// reflectors k of the super-panel before group g0 (band_step_kernel adds group g0's own four when its w vectors exist; it
+// used to read all of them, up to 2 x 60 vectors per stamp through one CU).
+__global__ __launch_bounds__(256) void band_apply_kernel(const double *__restrict__ At, const double *__restrict__ Vall, const double *__restrict__ Wp,
+                                                         const double *__restrict__ part4, const double *__restrict__ coefG, const int *__restrict__ n,
+                                                         int ld, int g0, int ps, double *__restrict__ Z4, double *__restrict__ Xp)
 {
-    __shared__ double cf[2 * BTPL * BW];
-    const int s = blockIdx.y, ns = n[s];
-    if (g0 + BW + 1 >= ns) return;
-    const int kc = g0 - ps;
+    __shared__ double cf[4 * BTPL * BW];
+    const int s = blockIdx.y, ns = n[s], r0 = g0 + BW;
+    if (r0 >= ns) return;
+    const bool doz = g0 + BW + 1 < ns;  // (otherwise the group has no reflectors: only the last panel is due)
+    const int kc = g0 - ps, G = min(BW, ns - r0);
+    const long so = (long)s * ld * ld;
+    const double *V = Vall + so + (long)ps * ld, *W = Wp + (long)s * BTPL * ld;
     for (int e = threadIdx.x; e < kc * BW; e += 256) {
+        const int k = e / BW, c = e % BW;
         cf[e] = coefG[((long)s * 2 + 0) * BTPL * BW + e];
         cf[BTPL * BW + e] = coefG[((long)s * 2 + 1) * BTPL * BW + e];
+        cf[2 * BTPL * BW + e] = c < G ? V[(long)k * ld + r0 + c] : 0.0;  // v_k[column]
+        cf[3 * BTPL * BW + e] = c < G ? W[(long)k * ld + r0 + c] : 0.0;  // w_k[column]
     }
     __syncthreads();
     const int i = g0 + 1 + blockIdx.x * 256 + threadIdx.x;
     if (i >= ns) return;
-    const long so = (long)s * ld * ld;
-    const double *V = Vall + so + (long)ps * ld, *W = Wp + (long)s * BTPL * ld;
     const double *part = part4 + (long)s * (ld / BSTRIP) * BW * ld;
     double *Z = Z4 + (long)s * BW * ld;
-    double p[BW];
+    double p[BW], x[BW];
 #pragma unroll
-    for (int c = 0; c < BW; c++) p[c] = Z[(long)c * ld + i];
-    const int slast = (ns - 1) / BSTRIP;
-    for (int st = i / BSTRIP + 1; st <= slast; st++)
+    for (int c = 0; c < BW; c++) p[c] = doz ? Z[(long)c * ld + i] : 0.0;
+    {
+        // columns r0 .. r0+BW-1 of row i: the lower triangle (the trailing updates leave the upper tiles behind), 32 bytes per row
+        const double2 *ap = (const double2 *)(At + so + (long)i * ld + r0);
+        const double2 a01 = ap[0], a23 = ap[1];
+        x[0] = a01.x; x[1] = a01.y; x[2] = a23.x; x[3] = a23.y;
 #pragma unroll
-        for (int c = 0; c < BW; c++) p[c] += part[((long)st * BW + c) * ld + i];
+        for (int c = 0; c < BW; c++)
+            if (c >= G) x[c] = 0.0;
+    }
+    if (doz) {
+        const int slast = (ns - 1) / BSTRIP;
+        for (int st = i / BSTRIP + 1; st <= slast; st++)
+#pragma unroll
+            for (int c = 0; c < BW; c++) p[c] += part[((long)st * BW + c) * ld + i];
+    }
     for (int k = 0; k < kc; k++) {
         const double a = V[(long)k * ld + i], b = W[(long)k * ld + i];
 #pragma unroll
-        for (int c = 0; c < BW; c++) p[c] -= a * cf[(BTPL + k) * BW + c] + b * cf[k * BW + c];
+        for (int c = 0; c < BW; c++) {
+            p[c] -= a * cf[(BTPL + k) * BW + c] + b * cf[k * BW + c];
+            x[c] -= a * cf[(3 * BTPL + k) * BW + c] + b * cf[(2 * BTPL + k) * BW + c];
+        }
     }
+    double *X = Xp + (long)s * BW * ld;
 #pragma unroll
-    for (int c = 0; c < BW; c++) Z[(long)c * ld + i] = p[c];
+    for (int c = 0; c < BW; c++) {
+        if (doz) Z[(long)c * ld + i] = p[c];
+        if (i >= r0) X[(long)c * ld + i] = x[c];
+    }
 }
 
 // At = A on the leading n x n (zero elsewhere)
@@ -392,6 +620,7 @@ size_t band_basis_ws_bytes(int batch, int ld, int mp)
     add((size_t)batch * ld * ld * 8);                       // At
     add((size_t)batch * BTPL * ld * 8);                     // Wp
     add((size_t)batch * BW * ld * 8);                       // Z4
+    add((size_t)batch * BW * ld * 8);                       // Xp
     add((size_t)batch * (ld / BSTRIP) * BW * ld * 8);       // part4
     add((size_t)batch * (2 * BTPL * BW + BW * BW) * 8);     // dots with the super-panel's reflectors, the group's Gram matrix
     return t + 8192;
@@ -431,10 +660,10 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
     const size_t mark = ctx->ws_used;
     double *At = (double *)ws_take(ctx, mat);
     double *Wp = (double *)ws_take(ctx, (size_t)batch * BTPL * ld * 8);
-    double *Z4 = (double *)ws_take(ctx, (size_t)batch * BW * ld * 8);
+    double *Z4 = (double *)ws_take(ctx, (size_t)batch * BW * ld * 8), *Xp = (double *)ws_take(ctx, (size_t)batch * BW * ld * 8);
     double *part4 = (double *)ws_take(ctx, (size_t)batch * (ld / BSTRIP) * BW * ld * 8);
     double *coefG = (double *)ws_take(ctx, (size_t)batch * 2 * BTPL * BW * 8), *gramG = (double *)ws_take(ctx, (size_t)batch * BW * BW * 8);
-    if (!At || !Wp || !Z4 || !part4 || !coefG || !gramG) { set_error("internal: band workspace"); return IMCOM_ERR_NOMEM; }
+    if (!At || !Wp || !Z4 || !Xp || !part4 || !coefG || !gramG) { set_error("internal: band workspace"); return IMCOM_ERR_NOMEM; }
     IMCOM_HIP_CHECK(hipMemsetAsync(out->Vall, 0, mat, st));
     IMCOM_HIP_CHECK(hipMemsetAsync(out->tauvec, 0, vecb, st));
     IMCOM_HIP_CHECK(hipMemsetAsync(out->band, 0, (size_t)batch * (BW + 1) * ld * 8, st));
@@ -446,15 +675,25 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
     {
         ProfScope ps_(ctx, "eigen_trd", nmax);
         int ps = 0;
+        auto reg_lds = [](int nr) { return (size_t)(BW * nr * RTHREADS + 16 * 2 * BW + 2 * BW * BW) * 8; };
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)band_step_reg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds(4)));
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)band_step_reg_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds(6)));
         auto step = [&](int ps_, int g0, int r0) {
-            hipLaunchKernelGGL(band_step_kernel, dim3(batch), dim3(BTHREADS), lds, st, At, out->Vall, Wp, out->tauvec, out->band, Z4, gramG,
-                               out->n_dev, ld, ps_, g0, r0);
+            if (ld <= 4 * RTHREADS)
+                hipLaunchKernelGGL(band_step_reg_kernel<4>, dim3(batch), dim3(RTHREADS), reg_lds(4), st, At, out->Vall, Wp, out->tauvec, out->band, Z4, gramG, Xp,
+                                   out->n_dev, ld, ps_, g0, r0);
+            else if (ld <= 6 * RTHREADS)
+                hipLaunchKernelGGL(band_step_reg_kernel<6>, dim3(batch), dim3(RTHREADS), reg_lds(6), st, At, out->Vall, Wp, out->tauvec, out->band, Z4, gramG, Xp,
+                                   out->n_dev, ld, ps_, g0, r0);
+            else
+                hipLaunchKernelGGL(band_step_kernel, dim3(batch), dim3(BTHREADS), lds, st, At, out->Vall, Wp, out->tauvec, out->band, Z4, gramG,
+                                   Xp, out->n_dev, ld, ps_, g0, r0);
         };
         for (int r0 = 0; r0 < nmax; r0 += BW) {
             const int g0 = r0 - BW;  // the group whose w vectors are due
-            if (g0 >= 0 && g0 + BW + 1 < nmax)
-                hipLaunchKernelGGL(band_apply_kernel, dim3((nmax - g0 - 1 + 255) / 256, batch), dim3(256), 0, st, out->Vall, Wp, part4, coefG, out->n_dev, ld,
-                                   g0, ps, Z4);
+            if (g0 >= 0)
+                hipLaunchKernelGGL(band_apply_kernel, dim3((nmax - g0 - 1 + 255) / 256, batch), dim3(256), 0, st, At, out->Vall, Wp, part4, coefG, out->n_dev,
+                                   ld, g0, ps, Z4, Xp);
             if (r0 - ps >= BTPL) {
                 // the previous group's w vectors, then the trailing two-sided update A[pe:, pe:] -= V W^T + W V^T; a new lazy panel
                 step(ps, g0, -1);
