@@ -393,7 +393,13 @@ int imcom_ctx_create(int device, imcom_ctx **out)
     ctx->device = device;
     ctx->cu_count = prop.multiProcessorCount;
     IMCOM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    IMCOM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    {
+        // the second queue carries work that FILLS gaps of the main stream (copies, the Eigen path's reflector products): lowest
+        // priority, so that a short kernel of the main stream's dependent chain does not queue behind its long tiles
+        int least = 0, greatest = 0;
+        IMCOM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        IMCOM_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, least));
+    }
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return IMCOM_OK;
