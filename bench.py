@@ -264,6 +264,21 @@ def seam_legs(ctx, dev, cfg, batch):
         best = dt if best is None else min(best, dt)
     out["kernel_seam"] = {"ms_per_stamp": best * 1e3, "value": 1.0 / best, "unit": "postage-stamps/s", "N": n, "m": m,
                           "what": "HipCholKernel(outst)() on host arrays, one stamp per call, PCIe-inclusive (best of 4)"}
+    # the same seam with the four OutStamps of a 2 x 2 group handed over in one call (each with its own host arrays)
+    from pyimcom_amd.lakernel import solve_chol_stamps
+
+    best4, single = None, None
+    for _ in range(4):
+        group = [outst() for _ in range(4)]
+        t0 = time.perf_counter()
+        solve_chol_stamps(group, ctx=ctx)
+        dt = time.perf_counter() - t0
+        best4 = dt if best4 is None else min(best4, dt)
+        single = group[0]
+    dT = float(np.abs(single.T - o.T).max() / np.abs(o.T).max())
+    out["kernel_seam"].update({"ms_per_stamp_group4": best4 * 1e3 / 4, "value_group4": 4.0 / best4, "group4_vs_single_T": dT,
+                               "what_group4": "lakernel.solve_chol_stamps([four OutStamps]) on host arrays, one batched factorisation / solve per "
+                                              "call, PCIe-inclusive (best of 4)"})
     # Block seam
     n1P = 16
     blk, psfgrp, _, _ = synth.duck_block(cfg, n1P, cfg.n_expo if isinstance(cfg.n_expo, int) else cfg.n_expo[1], seed=5)

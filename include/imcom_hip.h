@@ -130,6 +130,15 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
                      const double *mBhalf, const double *C, const double *kappaC, int nv,
                      double ucmin, double smax, float *T, float *UC, float *Sigma, float *kappa,
                      int *info, int memspace);
+/* lakernel.CholKernel (lakernel.py:226-394) for SEVERAL OutStamps per call -- e.g. the four OutStamps that share the PSF overlap
+ * of a 2 x 2 group (coadd.py:1091-1093 calls the kernel of one OutStamp at a time) -- each with its own HOST arrays as the
+ * reference holds them: A[s] = outst.sysmata [n[s]][n[s]], mBhalf[s] = outst.mhalfb[j_out] [m][n[s]], T[s] [m][n[s]] float32,
+ * UC[s] / Sigma[s] / kappa[s] [m] float32; C[nst], info[nst] as in imcom_solve_chol.  One batched factorisation and solve for
+ * all stamps; -B/2 crosses PCIe behind the factorisation.  n[s] == 0 gives the lakernel.py:110-119 outputs and no T. */
+int imcom_solve_chol_stamps(imcom_ctx *ctx, int nst, const int *n, int m, const double *const *A,
+                            const double *const *mBhalf, const double *C, const double *kappaC, int nv, double ucmin,
+                            double smax, float *const *T, float *const *UC, float *const *Sigma, float *const *kappa,
+                            int *info);
 /* Same contract, eigendecomposition path; nv==1: lakernel.py:154-172, nv>1: 174-223 with nbis
  * bisections (reference default 13) and the kappa *= C quirk of line 222. */
 int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "imcom_lakernel1": [_vp, _vp, _vp, _l, _l, _d, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _d, _i],
     "imcom_build_reduced_T": [_vp, _vp, _vp, _vp, _vp, _i, _l, _d, _d, _vp, _vp, _vp, _vp, _i],
     "imcom_solve_chol": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i],
+    "imcom_solve_chol_stamps": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp],
     "imcom_solve_eigen": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _i],
     "imcom_solve_eigen_resident": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp],
     "imcom_solve_iter": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _d, _d, _i, _i, _vp, _vp, _vp, _vp, _i],

@@ -1,5 +1,6 @@
 // api.hip -- extern "C" entry points of libimcom_hip.so (see include/imcom_hip.h) and the host-side
 // orchestration of the batched blocked Cholesky solve.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <functional>
@@ -761,6 +762,105 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
     IMCOM_STAGE_OUT(float, Sig_d, Sigma, szM);
     IMCOM_STAGE_OUT(float, kap_d, kappa, szM);
     if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+// The same kernel for SEVERAL OutStamps per call, each with its own host arrays (the four OutStamps of a 2 x 2 group, say): one
+// batched factorisation / solve for all of them, -B/2 uploaded behind the factorisation.  See imcom_hip.h.
+int imcom_solve_chol_stamps(imcom_ctx *ctx, int nst, const int *n, int m, const double *const *A, const double *const *mBhalf,
+                            const double *C, const double *kappaC, int nv, double ucmin, double smax, float *const *T,
+                            float *const *UC, float *const *Sigma, float *const *kappa, int *info)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(nst >= 1 && n && A && mBhalf && C && kappaC && T && UC && Sigma && kappa && info, "null pointer / no stamps");
+    IMCOM_REQUIRE(m >= 1 && nv >= 1, "bad sizes");
+    IMCOM_REQUIRE(nv <= CHOL_MAXNV, "nv=%d kappa nodes: at most %d", nv, CHOL_MAXNV);
+    int nmax = 0;
+    size_t totA = 0, totB = 0;
+    for (int s = 0; s < nst; s++) {
+        IMCOM_REQUIRE(n[s] >= 0, "n[%d]=%d", s, n[s]);
+        IMCOM_REQUIRE(UC[s] && Sigma[s] && kappa[s] && (n[s] == 0 || (A[s] && mBhalf[s] && T[s])), "null pointer for stamp %d", s);
+        nmax = std::max(nmax, n[s]);
+        totA += align_up((size_t)n[s] * n[s], 32);
+        totB += align_up((size_t)m * n[s], 32);
+    }
+    const int Np = (int)align_up((size_t)(nmax > 0 ? nmax : 1), NB), mp = (int)align_up((size_t)m, NB);
+    const size_t szM = (size_t)nst * m;
+    WsPlan plan;
+    plan.add(totA * 8); plan.add(totB * 8); plan.add(totB * 4); plan.add(szM * 4 * 3);
+    plan.add((size_t)nst * Np * Np * 8);  // Ap
+    plan.add((size_t)nst * Np * mp * 8);  // Bt
+    plan.add((size_t)nst * Np * mp * 4);  // Tt
+    plan.add((size_t)nst * 4);            // n
+    IMCOM_TRY(ws_reserve(ctx, plan.total + chol_core_bytes(nst, Np, m, mp, nv) + 8192));
+    double *rawA = (double *)ws_take(ctx, totA * 8), *rawB = (double *)ws_take(ctx, totB * 8);
+    float *rawT = (float *)ws_take(ctx, totB * 4), *maps = (float *)ws_take(ctx, szM * 4 * 3);
+    double *Ap = (double *)ws_take(ctx, (size_t)nst * Np * Np * 8), *Bt = (double *)ws_take(ctx, (size_t)nst * Np * mp * 8);
+    float *Tt = (float *)ws_take(ctx, (size_t)nst * Np * mp * 4);
+    int *n_dev = (int *)ws_take(ctx, (size_t)nst * 4);
+    if (!rawA || !rawB || !rawT || !maps || !Ap || !Bt || !Tt || !n_dev) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    float *UC_d = maps, *Sig_d = maps + szM, *kap_d = maps + 2 * szM;
+    IMCOM_TRY(upload(ctx, n_dev, n, nst));
+    std::vector<size_t> offA(nst), offB(nst);
+    {
+        size_t a = 0, b = 0;
+        for (int s = 0; s < nst; s++) { offA[s] = a; offB[s] = b; a += align_up((size_t)n[s] * n[s], 32); b += align_up((size_t)m * n[s], 32); }
+    }
+    while (ctx->sync_events.size() < 2) {
+        hipEvent_t e;
+        IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_events.push_back(e);
+    }
+    const bool timing = getenv("IMCOM_SEAM_TIMING") != nullptr;  // host-side timeline of the call on stderr (adds a synchronisation)
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    double tA = 0, tB0 = 0, tB1 = 0, tcore = 0, tsync = 0;
+    // the system matrices one after the other on the main stream, each packed as soon as it is there
+    for (int s = 0; s < nst; s++) {
+        if (n[s] == 0) continue;
+        IMCOM_HIP_CHECK(hipMemcpyAsync(rawA + offA[s], A[s], (size_t)n[s] * n[s] * 8, hipMemcpyHostToDevice, ctx->stream));
+        ProfScope ps(ctx, "pack");
+        IMCOM_TRY(launch_pack_A(ctx, rawA + offA[s], n[s], n_dev + s, Ap + (size_t)s * Np * Np, Np, 1));
+    }
+    hipEvent_t ev_entry = ctx->sync_events[1];
+    IMCOM_HIP_CHECK(hipEventRecord(ev_entry, ctx->stream));
+    tA = now();
+    // -B/2 is called for when the factorisation's launches are queued: its upload (host-blocking from pageable memory) runs on the
+    // second queue while the GPU factors
+    auto stage_B = [&]() -> int {
+        hipEvent_t ev = ctx->sync_events[0];
+        tB0 = now();
+        IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ev_entry, 0));
+        for (int s = 0; s < nst; s++)
+            if (n[s] > 0) IMCOM_HIP_CHECK(hipMemcpyAsync(rawB + offB[s], mBhalf[s], (size_t)m * n[s] * 8, hipMemcpyHostToDevice, ctx->aux_stream));
+        IMCOM_HIP_CHECK(hipEventRecord(ev, ctx->aux_stream));
+        IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
+        tB1 = now();
+        ProfScope ps(ctx, "pack");
+        for (int s = 0; s < nst; s++)
+            IMCOM_TRY(launch_pack_Bt(ctx, rawB + offB[s], n[s], m, n_dev + s, Bt + (size_t)s * Np * mp, Np, mp, 1));
+        return IMCOM_OK;
+    };
+    const int rc_core = chol_core(ctx, nst, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info, stage_B);
+    tcore = now();
+    if (timing) { hipStreamSynchronize(ctx->stream); tsync = now(); }
+    if (rc_core != IMCOM_OK) {
+        hipStreamSynchronize(ctx->aux_stream);  // nothing of this call may still be copying into the workspace
+        return rc_core;
+    }
+    for (int s = 0; s < nst; s++) {
+        if (n[s] > 0) {
+            { ProfScope ps(ctx, "pack"); IMCOM_TRY(launch_unpack_T(ctx, Tt + (size_t)s * Np * mp, Np, mp, n_dev + s, m, rawT + offB[s], n[s], 1)); }
+            IMCOM_HIP_CHECK(hipMemcpyAsync(T[s], rawT + offB[s], (size_t)m * n[s] * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        IMCOM_HIP_CHECK(hipMemcpyAsync(UC[s], UC_d + (size_t)s * m, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipMemcpyAsync(Sigma[s], Sig_d + (size_t)s * m, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipMemcpyAsync(kappa[s], kap_d + (size_t)s * m, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (timing)
+        fprintf(stderr, "[imcom] solve_chol_stamps nst=%d: A up + pack queued %.2f ms, B copies start %.2f end %.2f, core queued %.2f, compute done %.2f, T down %.2f\n",
+                nst, tA - t0, tB0 - t0, tB1 - t0, tcore - t0, tsync - t0, now() - t0);
     return IMCOM_OK;
 }
 

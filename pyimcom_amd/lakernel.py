@@ -27,8 +27,23 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _host_out(shape, dtype=np.float32, zero=False):
+    """Output array for the device to write into: page-locked memory from torch's caching host allocator, seen as a numpy array
+    (the block goes back to the cache when the array dies).  Into fresh pageable memory a 20 MB T arrives at ~16 GB/s (page
+    faults under the driver's staging copy), and freeing such an array later costs the next call ~20 ms (the driver had
+    registered its pages; unmapping them stops the process's GPU queues until they are revalidated)."""
+    if int(np.prod(shape)) == 0:
+        return np.zeros(shape, dtype=dtype)
+    import torch
+
+    make = torch.zeros if zero else torch.empty
+    return make(tuple(int(v) for v in shape), dtype=getattr(torch, np.dtype(dtype).name), pin_memory=True).numpy()
+
+
 class _HipLAKernel:
     """Shared constructor / output handling (lakernel.py:68-138)."""
+
+    writes_all_of_T = False  # (the device call fills every entry of T: the output array need not be zeroed first)
 
     def __init__(self, outst, ctx=None):
         self.outst = outst
@@ -61,7 +76,7 @@ class _HipLAKernel:
         Cs = np.ascontiguousarray(np.atleast_1d(self.outst.outovlc), dtype=np.float64)
         if A.shape != (n, n) or mBhalf.shape != (self.n_out, m, n) or Cs.shape != (self.n_out,):
             raise ValueError("sysmata / mhalfb / outovlc shapes do not match the stamp")
-        T = np.zeros((self.n_out, m, n), dtype=np.float32)
+        T = _host_out((self.n_out, m, n), zero=not self.writes_all_of_T)
         UC = np.zeros((self.n_out, m), dtype=np.float32)
         Sigma = np.zeros((self.n_out, m), dtype=np.float32)
         kappa = np.zeros((self.n_out, m), dtype=np.float32)
@@ -78,6 +93,8 @@ class _HipLAKernel:
 class HipCholKernel(_HipLAKernel):
     """Cholesky path: lakernel.CholKernel (lakernel.py:226-394), single- and multi-kappa."""
 
+    writes_all_of_T = True
+
     def _solve(self, A, B, C_, T, UC, Sigma, kappa, info):
         n_arr = np.array([self.n], dtype=np.int32)
         check(lib.imcom_solve_chol(self.ctx.handle, 1, _ptr(n_arr), self.n, self.m, _ptr(A), _ptr(B), _ptr(C_),
@@ -85,10 +102,62 @@ class HipCholKernel(_HipLAKernel):
                                    _ptr(Sigma), _ptr(kappa), _ptr(info), MEM_HOST))
 
 
+def solve_chol_stamps(outstamps, ctx=None):
+    """``HipCholKernel(outst)()`` for several OutStamps in ONE call: the reference runs the kernel of one OutStamp at a time
+    (coadd.py:1091-1093); a caller that holds the system matrices of several -- the four OutStamps of a 2 x 2 group share their
+    PSF overlaps, coadd.py:839-844 -- hands them over together and gets one batched factorisation and solve, -B/2 crossing PCIe
+    behind the factorisation.  Same outputs on every OutStamp as the single call (T, UC, Sigma, kappa; lakernel.py:122-138);
+    returns the kernels (``info`` set)."""
+    kernels = [HipCholKernel(o, ctx) for o in outstamps]
+    if not kernels:
+        return kernels
+    k0 = kernels[0]
+    for k in kernels:
+        if k.m != k0.m or k.n_out != k0.n_out or not np.array_equal(k.kappaC_arr, k0.kappaC_arr) or k.ucmin != k0.ucmin or k.smax != k0.smax:
+            raise ValueError("the OutStamps of one call must share the output grid, the kappa nodes and the targets")
+    nst, m, n_out = len(kernels), k0.m, k0.n_out
+    shape = (n_out, k0.n2f, k0.n2f)
+    n_arr = np.array([k.n for k in kernels], dtype=np.int32)
+    As, Bs, Cs = [], [], np.zeros((nst, n_out))
+    for i, k in enumerate(kernels):
+        A = np.ascontiguousarray(k.outst.sysmata, dtype=np.float64) if k.n else np.zeros((0, 0))
+        B = np.ascontiguousarray(k.outst.mhalfb, dtype=np.float64) if k.n else np.zeros((n_out, m, 0))
+        Cs[i] = np.atleast_1d(k.outst.outovlc)
+        if A.shape != (k.n, k.n) or B.shape != (n_out, m, k.n):
+            raise ValueError("sysmata / mhalfb shapes do not match the stamp")
+        As.append(A)
+        Bs.append(B)
+    T = [_host_out((n_out, m, k.n)) for k in kernels]
+    UC = np.zeros((nst, n_out, m), dtype=np.float32)
+    Sigma = np.zeros((nst, n_out, m), dtype=np.float32)
+    kappa = np.zeros((nst, n_out, m), dtype=np.float32)
+    info = np.zeros((n_out, nst), dtype=np.int32)
+    PP = C.c_void_p * nst
+
+    def ptrs(arrs):
+        return PP(*[a.ctypes.data for a in arrs])
+
+    pA = ptrs(As)
+    # one factorisation per target PSF since kappa = kappaC * C[j_out] (lakernel.py:291-299, 349-353)
+    for j in range(n_out):
+        Cj = np.ascontiguousarray(Cs[:, j])
+        check(lib.imcom_solve_chol_stamps(k0.ctx.handle, nst, _ptr(n_arr), m, pA, ptrs([b[j] for b in Bs]), _ptr(Cj), _ptr(k0.kappaC_arr), k0.nv,
+                                          k0.ucmin, k0.smax, ptrs([t[j] for t in T]), ptrs([UC[i, j] for i in range(nst)]),
+                                          ptrs([Sigma[i, j] for i in range(nst)]), ptrs([kappa[i, j] for i in range(nst)]), _ptr(info[j])))
+    for i, k in enumerate(kernels):
+        k.info = np.ascontiguousarray(info[:, i])
+        k.outst.T = T[i]
+        k.outst.UC = UC[i].reshape(shape)
+        k.outst.Sigma = Sigma[i].reshape(shape)
+        k.outst.kappa = kappa[i].reshape(shape)
+    return kernels
+
+
 class HipEigenKernel(_HipLAKernel):
     """Eigendecomposition path: lakernel.EigenKernel (lakernel.py:141-223); nbis as line 174."""
 
     nbis = 13
+    writes_all_of_T = True
 
     def _solve(self, A, B, C_, T, UC, Sigma, kappa, info):
         n_arr = np.array([self.n], dtype=np.int32)

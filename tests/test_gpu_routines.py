@@ -215,6 +215,42 @@ def test_chol_ragged_batch_vs_oracle(orc, nv):
         assert np.allclose(kp[s], ko, rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("nv", [1, 3])
+def test_chol_stamps_seam_vs_oracle(orc, nv):
+    """solve_chol_stamps: four OutStamps of different N (one empty, one spanning several 128-blocks), each with its own host arrays,
+    in ONE call -- every output against the oracle and against the kernel called stamp by stamp as the reference does
+    (coadd.py:1091-1093)."""
+    from pyimcom_amd.lakernel import HipCholKernel, solve_chol_stamps
+
+    rng = np.random.default_rng(21 + nv)
+    ns, m, n2f = [300, 0, 131, 257], 144, 12
+    kC = np.array([6e-4]) if nv == 1 else np.array([1e-5, 1e-4, 1e-3])
+    outs, singles, sys_ = [], [], []
+    for n in ns:
+        Cc = float(rng.uniform(0.8, 1.3))
+        pts = rng.uniform(0, 12, (n, 2)); outp = rng.uniform(2, 10, (m, 2))
+        A = Cc * np.exp(-((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1) / 3.0)
+        B = (Cc * np.exp(-((outp[:, None, :] - pts[None, :, :]) ** 2).sum(-1) / 3.5))[None]
+        sys_.append((A, B, Cc))
+        outs.append(make_outst(A.copy(), B.copy(), np.array([Cc]), n2f, kC, 1e-6, 0.5))
+        singles.append(make_outst(A.copy(), B.copy(), np.array([Cc]), n2f, kC, 1e-6, 0.5))
+    ks = solve_chol_stamps(outs)
+    assert len(ks) == 4 and all(k.info.shape == (1,) for k in ks)
+    for o, o1, (A, B, Cc), n in zip(outs, singles, sys_, ns):
+        HipCholKernel(o1)()
+        assert np.array_equal(o.sysmata, A)  # caller-owned, unmodified
+        assert o.T.shape == (1, m, n) and o.T.dtype == np.float32 and o.UC.shape == (1, n2f, n2f)
+        if n == 0:
+            assert np.all(o.UC == 1) and np.all(o.Sigma == 0) and np.all(o.kappa == 1)
+            continue
+        To, Uo, So, ko, _ = orc.chol_kernel(A.copy(), np.ascontiguousarray(B[0]), Cc, kC, 1e-6, 0.5)
+        assert np.abs(o.T[0] - To).max() <= TOL_T * np.abs(To).max()
+        assert np.allclose(o.UC.ravel(), Uo, rtol=RTOL_MAP, atol=ATOL_MAP) and np.allclose(o.Sigma.ravel(), So, rtol=RTOL_MAP, atol=ATOL_MAP)
+        assert np.allclose(o.kappa.ravel(), ko, rtol=1e-5, atol=0)
+        # the batch only changes the order of the factorisation's partial sums
+        assert np.abs(o.T - o1.T).max() <= TOL_T * np.abs(To).max() and np.allclose(o.kappa, o1.kappa, rtol=1e-5, atol=0)
+
+
 # ------------------------------------------------------------------------------------------------ eigen path
 def test_eigh_vs_numpy():
     from pyimcom_amd.linalg import eigh
