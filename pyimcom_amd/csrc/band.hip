@@ -32,7 +32,11 @@ constexpr int BW = BAND_BW;      // bandwidth = reflectors per group
 constexpr int BTPL = 64;         // reflectors per lazy super-panel (multiple of BW)
 constexpr int BTHREADS = 1024;   // band_step_kernel: one workgroup per stamp
 constexpr int RTHREADS = 512;    // band_step_reg_kernel (256 registers per thread)
-constexpr int BSTRIP = 32;       // rows per strip of the symmetric product
+constexpr int BSTRIP = 64;       // rows per strip of the symmetric product
+constexpr int SLPW = 64 / (BSTRIP / 8);  // symv4_kernel: lanes (column pairs) per group of 8 rows inside a wave
+constexpr int SWCOLS = 2 * SLPW;        // columns per wave and chunk;  4 waves: chunks of 4 * SWCOLS columns
+constexpr int SCHUNK = 4 * SWCOLS;
+static_assert(BSTRIP == 32 || BSTRIP == 64, "strip of 4 or 8 row groups per wave");
 static_assert(BW == 4, "the panel loads of band_step_kernel take four columns as two double2");
 
 struct BHouse {
@@ -439,19 +443,19 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
         urs[i][c] = rb + i < ns ? Vall[so + (long)(r0 + c) * ld + rb + i] : 0.0;  // the reflectors at the strip's rows
     }
     __syncthreads();
-    // A chunk is 32 rows x 128 columns; wave w takes ALL 32 rows of columns [32 w, 32 w + 32): lane = (row group g of 8 rows,
+    // A chunk is BSTRIP rows x SCHUNK columns; wave w takes ALL rows of its SWCOLS columns: lane = (row group g of 8 rows,
     // column pair lp).  The transposed contributions of a column are then complete inside the wave (two shuffles over g) and go
     // straight to memory -- the main loop has no LDS exchange and no barrier (the first version split the chunk by rows: one
     // barrier per chunk, 3.6 TB/s at best).  The row sums meet once, at the end of the strip.
-    const int g = lane >> 4, lp = lane & 15;
-    const int colw = wave * 32 + lp * 2;
+    const int g = lane / SLPW, lp = lane % SLPW;
+    const int colw = wave * SWCOLS + lp * 2;
     double *part_s = part4 + (((long)s * (ld / BSTRIP) + strip) * BW) * ld;
     double acc[BW][8];
 #pragma unroll
     for (int c = 0; c < BW; c++)
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[c][i] = 0.0;
-    const int cend = rb + BSTRIP, cfirst = (r0 + 1) & ~127;
+    const int cend = rb + BSTRIP, cfirst = (r0 + 1) & ~(SCHUNK - 1);
     // Buffer loads: one descriptor per operand (wave-uniform), the chunk's part of the address in a scalar offset, the lane's in ONE
     // vector register (with 64-bit pointers the 12 loads of a chunk hold 24 registers of addresses per register set)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(At + so), 0, (int)((long)ld * ld * 8), 0x00020000);
@@ -489,13 +493,14 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
                 y2[c].y += a[i].y * ur[c];
             }
         }
-        if (c0 + wave * 32 < rb) {  // (wave-uniform) columns left of the diagonal block receive the transposed contributions
+        if (c0 + wave * SWCOLS < rb) {  // (wave-uniform) columns left of the diagonal block receive the transposed contributions
 #pragma unroll
             for (int c = 0; c < BW; c++) {
-                y2[c].x += __shfl_xor(y2[c].x, 16, 64);
-                y2[c].y += __shfl_xor(y2[c].y, 16, 64);
-                y2[c].x += __shfl_xor(y2[c].x, 32, 64);
-                y2[c].y += __shfl_xor(y2[c].y, 32, 64);
+#pragma unroll
+                for (int off = SLPW; off < 64; off <<= 1) {
+                    y2[c].x += __shfl_xor(y2[c].x, off, 64);
+                    y2[c].y += __shfl_xor(y2[c].y, off, 64);
+                }
             }
             if (g == 0)
 #pragma unroll
@@ -504,12 +509,12 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
     };
     double2 s0[8], s1[8], u0[BW], u1[BW];
     fetch(s0, u0, cfirst);
-    for (int c0 = cfirst; c0 < cend; c0 += 256) {
-        fetch(s1, u1, c0 + 128);
+    for (int c0 = cfirst; c0 < cend; c0 += 2 * SCHUNK) {
+        fetch(s1, u1, c0 + SCHUNK);
         process(s0, u0, c0);
-        if (c0 + 128 >= cend) break;
-        fetch(s0, u0, c0 + 256);
-        process(s1, u1, c0 + 128);
+        if (c0 + SCHUNK >= cend) break;
+        fetch(s0, u0, c0 + 2 * SCHUNK);
+        process(s1, u1, c0 + SCHUNK);
     }
     // row sums: over the 16 column pairs of the wave, then over the four waves
 #pragma unroll
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
 #pragma unroll
         for (int i = 0; i < 8; i++) {
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) acc[c][i] += __shfl_xor(acc[c][i], off, 64);
+            for (int off = SLPW / 2; off > 0; off >>= 1) acc[c][i] += __shfl_xor(acc[c][i], off, 64);
         }
     if (lp == 0)
 #pragma unroll
