@@ -445,6 +445,11 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
             bool armed = true;
             ~AuxDrain() { if (armed) hipStreamSynchronize(s); }
         } drain{aux};
+        // Worth it while the reduction's one-workgroup-per-stamp step leaves most CUs idle: the products' tiles monopolise a CU
+        // (registers, LDS) and the reduction's dependent chain queues behind them.  cfg-3, with / without: batch 32 251 / 265 ms,
+        // 64 418 / 430, 128 762 / 772, 256 1485 / 1458.  IMCOM_EIGEN_OVERLAP=0 / 1 forces it.
+        const char *ov = getenv("IMCOM_EIGEN_OVERLAP");
+        const bool overlap = nmax > 0 && (ov ? atoi(ov) != 0 : batch <= 128);
         auto on_panel = [&](int p) -> int {
             IMCOM_HIP_CHECK(hipEventRecord(ev_main, st));
             IMCOM_HIP_CHECK(hipStreamWaitEvent(aux, ev_main, 0));
@@ -453,12 +458,13 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
             ctx->stream = st;
             return rc;
         };
-        const int rc = band_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb, nmax > 0 ? std::function<int(int)>(on_panel) : nullptr);
+        const int rc = band_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb, overlap ? std::function<int(int)>(on_panel) : nullptr);
         ctx->stream = st;
         IMCOM_TRY(rc);
         IMCOM_HIP_CHECK(hipEventRecord(ev_aux, aux));
         IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_aux, 0));  // join: c is complete when the main stream goes on
         drain.armed = false;
+        if (nmax > 0 && !overlap) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Q^T b after the reduction
     } else {
         IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
         if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Qh^T b
