@@ -87,3 +87,52 @@ def test_band_reduce_on_cfg3_matrix():
     norm = max(abs(w[0]), abs(w[-1]))
     print(f"[band n={n}] |A|={norm:.3g} max |dlam|/|A| = {np.abs(wb - w).max() / norm:.2e}")
     assert np.abs(wb - w).max() <= 2e-14 * norm
+
+
+def test_band_reduce_wide_matrix_generic_step_kernel():
+    """ld = 3200 > 3072: the step kernel with the panel in LDS (band_step_kernel) instead of the register-resident one; the band's
+    eigenvalues against LAPACK's of A and a sample of Q's columns for orthogonality."""
+    from scipy.linalg import eigvals_banded
+
+    from pyimcom_amd.linalg import band_reduce
+
+    rng = np.random.default_rng(11)
+    ld, n = 3200, 3125
+    X = rng.standard_normal((n, 400))
+    A = np.zeros((1, ld, ld))
+    A[0, :n, :n] = X @ X.T / 400 + 0.05 * np.eye(n)
+    A[0, np.arange(n, ld), np.arange(n, ld)] = 1.0
+    band, V, tau = band_reduce(A, [n])
+    w = np.linalg.eigvalsh(A[0, :n, :n])
+    wb = eigvals_banded(band[0][:, :n], lower=True)
+    assert np.abs(wb - w).max() <= 2e-14 * w[-1]
+    # Q e_j for a few j: apply the reflectors in reverse order to unit vectors
+    E = np.zeros((n, 3))
+    E[[0, n // 2, n - 1], [0, 1, 2]] = 1.0
+    for r in range(n - 1, -1, -1):
+        if tau[0][r] != 0.0:
+            v = V[0][r, :n]
+            E -= tau[0][r] * np.outer(v, v @ E)
+    assert np.abs(E.T @ E - np.eye(3)).max() < 1e-13
+
+
+def test_eigen_kernel_same_with_and_without_overlap(monkeypatch):
+    """c = Q^T b formed on the second stream while the reduction runs (default up to 128 stamps) or after it: same kernels on the
+    same data, so every output is bit-identical."""
+    from tests.golden.make_golden import make_outst
+
+    from pyimcom_amd.lakernel import HipEigenKernel
+
+    rng = np.random.default_rng(5)
+    n, m = 700, 256
+    pts = rng.uniform(0, 30, (n, 2)); outp = rng.uniform(3, 27, (m, 2))
+    A = np.exp(-((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1) / 3.0)
+    B = np.exp(-((outp[:, None, :] - pts[None, :, :]) ** 2).sum(-1) / 3.5)[None]
+    res = []
+    for ov in ("0", "1"):
+        monkeypatch.setenv("IMCOM_EIGEN_OVERLAP", ov)
+        o = make_outst(A.copy(), B.copy(), np.array([1.0]), 16, np.array([1e-5, 1e-4, 1e-3]), 1e-6, 0.5)
+        HipEigenKernel(o)()
+        res.append(o)
+    for name in ("T", "UC", "Sigma", "kappa"):
+        assert np.array_equal(getattr(res[0], name), getattr(res[1], name)), name
