@@ -621,7 +621,8 @@ size_t band_basis_ws_bytes(int batch, int ld, int mp)
     add((size_t)batch * 4);                                 // n
     add((size_t)batch * npanels * NB * NB * 8);             // T factors of all panels
     add((size_t)batch * NB * NB * 8);                       // S = V V^T of one panel
-    add((size_t)batch * NB * mp * 8 * 2);                   // W1, W2
+    add((size_t)batch * 2 * NB * mp * 8 * 2);               // W1, W2 (256 rows: pairs of panels)
+    add((size_t)batch * (npanels / 2) * 4 * NB * NB * 8);   // factors of the pairs
     add((size_t)batch * ld * ld * 8);                       // At
     add((size_t)batch * BTPL * ld * 8);                     // Wp
     add((size_t)batch * BW * ld * 8);                       // Z4
@@ -647,8 +648,9 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
     out->n_dev = (int *)ws_take(ctx, (size_t)batch * 4);
     out->Tm = (double *)ws_take(ctx, (size_t)batch * npanels_max * NB * NB * 8);
     out->Sm = (double *)ws_take(ctx, (size_t)batch * NB * NB * 8);
-    out->W1 = (double *)ws_take(ctx, (size_t)batch * NB * mp * 8);
-    out->W2 = (double *)ws_take(ctx, (size_t)batch * NB * mp * 8);
+    out->W1 = (double *)ws_take(ctx, (size_t)batch * 2 * NB * mp * 8);
+    out->W2 = (double *)ws_take(ctx, (size_t)batch * 2 * NB * mp * 8);
+    out->T2 = (double *)ws_take(ctx, (size_t)batch * (npanels_max / 2) * 4 * NB * NB * 8);
     out->dvec = out->evec = nullptr;
     out->ld = ld;
     out->bw = BW;
@@ -656,7 +658,7 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
     for (int s = 0; s < batch; s++) out->nmax = std::max(out->nmax, n_host[s]);
     const int nmax = out->nmax;
     out->npanels = (std::max(nmax - BW - 1, 0) + NB - 1) / NB;
-    if (!out->Vall || !out->tauvec || !out->band || !out->n_dev || !out->Tm || !out->Sm || !out->W1 || !out->W2) {
+    if (!out->Vall || !out->tauvec || !out->band || !out->n_dev || !out->Tm || !out->Sm || !out->W1 || !out->W2 || (npanels_max >= 2 && !out->T2)) {
         set_error("internal: band workspace");
         return IMCOM_ERR_NOMEM;
     }

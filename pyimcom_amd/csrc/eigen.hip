@@ -464,7 +464,8 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         IMCOM_HIP_CHECK(hipEventRecord(ev_aux, aux));
         IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_aux, 0));  // join: c is complete when the main stream goes on
         drain.armed = false;
-        if (nmax > 0 && !overlap) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Q^T b after the reduction
+        if (overlap) IMCOM_TRY(trd_pair_factors(ctx, &tb, batch));  // (the panels' own factors were made on the second stream)
+        else if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Q^T b after the reduction
     } else {
         IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
         if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Qh^T b

@@ -40,12 +40,14 @@ struct TrdBasis {
     double *Vall, *dvec, *evec, *tauvec;  // reflectors [batch][ld][ld] (row j = v_j), T's diagonal / off-diagonal, tau [batch][ld]
     double *Tm, *Sm, *W1, *W2;            // triangular factors of the 128-reflector panels [npanels][batch][128][128]; scratch of trd_apply_q
     double *band = nullptr;               // band.hip: [batch][bw + 1][ld], band[t][i] = B[i + t][i]
+    double *T2 = nullptr;                 // factors of PAIRS of panels (256 reflectors) [npanels / 2][batch][256][256]; W1, W2 then hold 256 rows
     int *n_dev;
     int ld, nmax, npanels, bw = 1;        // bw: rows between a reflector's column and its pivot (1: tridiagonal basis)
 };
 size_t trd_basis_ws_bytes(int batch, int ld, int mp);
 int trd_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out);
 int trd_apply_q(imcom_ctx *ctx, const TrdBasis &b, int batch, double *C, int mp, bool transpose);
+int trd_pair_factors(imcom_ctx *ctx, TrdBasis *out, int batch);  // T2 from Tm (all panels' factors must be there)
 // band.hip: the same with A = Q B Q^T, B of bandwidth BAND_BW (a quarter of the passes over the matrix); ld up to what the panel's LDS holds
 bool band_basis_fits(int ld);
 size_t band_basis_ws_bytes(int batch, int ld, int mp);

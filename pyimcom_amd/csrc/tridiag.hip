@@ -787,7 +787,7 @@ int trd_panel_factors(imcom_ctx *ctx, TrdBasis *out, int batch)
         hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), LARFT_LDS, st, out->Sm, out->tauvec, ld, ps, out->Tm + (size_t)p * batch * TP * TP);
         IMCOM_TRY(check_launch("trd_larft_kernel"));
     }
-    return IMCOM_OK;
+    return trd_pair_factors(ctx, out, batch);
 }
 
 // One step of Qh^T C for a caller that overlaps it with the reduction: the triangular factor of panel p, then C <- (I - V T^T V^T) C
@@ -808,20 +808,61 @@ int trd_panel_step(imcom_ctx *ctx, const TrdBasis &b, int batch, int p, double *
     return IMCOM_OK;
 }
 
+// Two consecutive panels a, b as ONE block reflector of 256: H_a H_b = I - V T V^T with V = [V_a; V_b] (consecutive rows of Vall) and
+// T = [[T_a, -T_a (V_a V_b^T) T_b], [0, T_b]].  The update C -= V^T W then has K = 256: half the trips of C through HBM per flop.
+__global__ __launch_bounds__(2 * TP) void t2_assemble_kernel(const double *__restrict__ Ta, const double *__restrict__ Tb, double *__restrict__ T2)
+{
+    const int s = blockIdx.y, r = blockIdx.x, c = threadIdx.x;
+    double v = 0.0;
+    if (r < TP && c >= TP) return;  // the upper right block comes from the products
+    if (r < TP) v = Ta[(long)s * TP * TP + r * TP + c];
+    else if (c >= TP) v = Tb[(long)s * TP * TP + (r - TP) * TP + c - TP];
+    T2[(long)s * 4 * TP * TP + r * 2 * TP + c] = v;
+}
+
+int trd_pair_factors(imcom_ctx *ctx, TrdBasis *out, int batch)
+{
+    if (!out->T2) return IMCOM_OK;
+    ProfScope ps_(ctx, "eigen_applyq");
+    const int ld = out->ld;
+    const long tt = (long)TP * TP;
+    for (int q = 0; 2 * q + 1 < out->npanels; q++) {
+        const int psa = 2 * q * TP, psb = psa + TP, remb = ld - psb;
+        const double *Va = out->Vall + (long)psa * ld + psb, *Vb = out->Vall + (long)psb * ld + psb;  // components psb.. of both
+        const double *Ta = out->Tm + (size_t)(2 * q) * batch * tt, *Tb = Ta + (size_t)batch * tt;
+        double *T2 = out->T2 + (size_t)q * batch * 4 * tt;
+        IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, remb, batch, Va, ld, (long)ld * ld, Vb, ld, (long)ld * ld, out->Sm, TP, tt, 1.0, 0.0));  // V_a V_b^T
+        IMCOM_TRY(launch_gemm(ctx, false, true, TP, TP, TP, batch, out->Sm, TP, tt, Tb, TP, tt, out->W1, TP, tt, 1.0, 0.0));                   // ... T_b
+        IMCOM_TRY(launch_gemm(ctx, false, true, TP, TP, TP, batch, Ta, TP, tt, out->W1, TP, tt, T2 + TP, 2 * TP, 4 * tt, -1.0, 0.0));          // -T_a ...
+        hipLaunchKernelGGL(t2_assemble_kernel, dim3(2 * TP, batch), dim3(2 * TP), 0, ctx->stream, Ta, Tb, T2);
+        IMCOM_TRY(check_launch("t2_assemble_kernel"));
+    }
+    return IMCOM_OK;
+}
+
 // C [batch][ld][mp] <- Qh^T C (transpose) or Qh C: Qh = H_0 H_1 ... and a panel's H_ps ... H_pe-1 = I - V T V^T, so
 //   Qh^T C: panels in ascending order, C[ps:] -= V^T (T^T (V C[ps:]));   Qh C: descending order, C[ps:] -= V^T (T (V C[ps:]))
+// With pair factors (b.T2) two panels go as one of 256 reflectors; an odd last panel alone.
 int trd_apply_q(imcom_ctx *ctx, const TrdBasis &b, int batch, double *C, int mp, bool transpose)
 {
     ProfScope ps_(ctx, "eigen_applyq");
     const int ld = b.ld;
-    for (int q = 0; q < b.npanels; q++) {
-        const int p = transpose ? q : b.npanels - 1 - q, ps = p * TP, rem = ld - ps;
-        const double *Vp = b.Vall + (long)ps * ld + ps;  // [TP][rem] with row stride ld: reflectors ps.., components ps..
-        const double *Tm = b.Tm + (size_t)p * batch * TP * TP;
+    auto apply = [&](int ps, int rows, const double *T) -> int {
+        const int rem = ld - ps;
+        const double *Vp = b.Vall + (long)ps * ld + ps;  // [rows][rem] with row stride ld: reflectors ps.., components ps..
         double *Cp = C + (long)ps * mp;
-        IMCOM_TRY(launch_gemm(ctx, false, true, TP, mp, rem, batch, Vp, ld, (long)ld * ld, Cp, mp, (long)ld * mp, b.W1, mp, (long)TP * mp, 1.0, 0.0));
-        IMCOM_TRY(launch_gemm(ctx, transpose, true, TP, mp, TP, batch, Tm, TP, (long)TP * TP, b.W1, mp, (long)TP * mp, b.W2, mp, (long)TP * mp, 1.0, 0.0));
-        IMCOM_TRY(launch_gemm(ctx, true, true, rem, mp, TP, batch, Vp, ld, (long)ld * ld, b.W2, mp, (long)TP * mp, Cp, mp, (long)ld * mp, -1.0, 1.0));
+        IMCOM_TRY(launch_gemm(ctx, false, true, rows, mp, rem, batch, Vp, ld, (long)ld * ld, Cp, mp, (long)ld * mp, b.W1, mp, (long)rows * mp, 1.0, 0.0));
+        IMCOM_TRY(launch_gemm(ctx, transpose, true, rows, mp, rows, batch, T, rows, (long)rows * rows, b.W1, mp, (long)rows * mp, b.W2, mp, (long)rows * mp, 1.0, 0.0));
+        return launch_gemm(ctx, true, true, rem, mp, rows, batch, Vp, ld, (long)ld * ld, b.W2, mp, (long)rows * mp, Cp, mp, (long)ld * mp, -1.0, 1.0);
+    };
+    const int nunits = b.T2 ? (b.npanels + 1) / 2 : b.npanels;  // pairs (and an odd last panel), or single panels
+    for (int q = 0; q < nunits; q++) {
+        const int u = transpose ? q : nunits - 1 - q;
+        if (b.T2 && 2 * u + 1 < b.npanels) IMCOM_TRY(apply(2 * u * TP, 2 * TP, b.T2 + (size_t)u * batch * 4 * TP * TP));
+        else {
+            const int p = b.T2 ? 2 * u : u;
+            IMCOM_TRY(apply(p * TP, TP, b.Tm + (size_t)p * batch * TP * TP));
+        }
     }
     return IMCOM_OK;
 }
