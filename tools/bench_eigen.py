@@ -13,7 +13,8 @@ if len(sys.argv) > 3:
 stamps = [synth.make_stamp(cfg, i) for i in range(nb)]
 psfs, target = synth.make_psfs(cfg, max(s.n_expo for s in stamps))
 tabs = PSFGroupTables(psfs, target, cfg.nfft)
-b = StampBatch(cfg, stamps, tabs)
+import os
+b = StampBatch(cfg, stamps, tabs, ldn=int(os.environ['BENCH_LDN']) if os.environ.get('BENCH_LDN') else None)
 b.ctx.profile_enable(True)
 fams = ("eigen_trd", "eigen_applyq", "lakernel1", "eigen_orgtr", "eigen_qr", "eigen_gemm", "build_A", "build_B", "epilogue")
 best = None
