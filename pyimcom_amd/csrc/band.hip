@@ -78,6 +78,32 @@ __device__ inline void block_sums(double (&v)[NV], double *red)
     }
 }
 
+// The same with ONE barrier: consecutive calls alternate between two buffers (red: [2][NT / 64][NV]; flip toggles) -- a buffer is
+// written again only behind the barrier of the call in between, which every thread passes after its reads.
+template <int NV, int NT>
+__device__ inline void block_sums_alt(double (&v)[NV], double *red, int &flip)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *r = red + flip * (NT / 64) * NV;
+    flip ^= 1;
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off, 64);
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < NV; q++) r[wave * NV + q] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; q++) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) t += r[w * NV + q];
+        v[q] = t;
+    }
+}
+
 // ps: first reflector of the current lazy super-panel (Wp row k - ps holds w_k); g0 >= 0: finish the w vectors of the group of
 // columns g0 .. g0+BW-1 (needs Z4 / part4 from symv4_kernel); r0 >= 0: form the reflectors of columns r0 .. r0+BW-1.
 __global__ __launch_bounds__(BTHREADS) void band_step_kernel(const double *__restrict__ At, double *__restrict__ Vall, double *__restrict__ Wp,
@@ -229,10 +255,11 @@ __global__ __launch_bounds__(RTHREADS) void band_step_reg_kernel(const double *_
 {
     extern __shared__ double sm[];
     double *vs = sm;                                  // [BW][NR][512]: the group's reflectors at this thread's rows (only their owner touches them)
-    double *red = sm + (size_t)BW * NR * RTHREADS;    // [8][2 BW]
-    double (*cw)[BW][BW] = (double (*)[BW][BW])(red + 16 * 2 * BW);  // v_q[r0 + c], w_q[r0 + c] of the group whose w vectors phase W has just made
+    double *red = sm + (size_t)BW * NR * RTHREADS;    // [2][8][2 BW]: two buffers, block_sums_alt
+    double (*cw)[BW][BW] = (double (*)[BW][BW])(red + 2 * 16 * 2 * BW);  // v_q[r0 + c], w_q[r0 + c] of the group whose w vectors phase W has just made
 #define VS_(c, r) vs[((c) * NR + (r)) * RTHREADS + tid]
     const int s = blockIdx.x, ns = n[s], tid = threadIdx.x;
+    int flip = 0;
     const long so = (long)s * ld * ld;
     const double *A = At + so;
     double *V = Vall + so, *W = Wp + (long)s * BTPL * ld, *tv = tau + (long)s * ld, *bd = band + (long)s * (BW + 1) * ld;
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(RTHREADS) void band_step_reg_kernel(const double *_
                 for (int q = 0; q < BW; q++)
                     if (q >= c) sums[q] += wp * VS_(q, r);
             }
-            block_sums<BW, RTHREADS>(sums, red);
+            block_sums_alt<BW, RTHREADS>(sums, red, flip);
             const double alpha = -0.5 * tc * sums[c];
 #pragma unroll
             for (int r = 0; r < NR; r++) w[c][r] += alpha * VS_(c, r);
@@ -362,7 +389,7 @@ __global__ __launch_bounds__(RTHREADS) void band_step_reg_kernel(const double *_
                             if (i == piv) sums[BW + q] = x[q][r];
                         }
                 }
-                block_sums<2 * BW, RTHREADS>(sums, red);
+                block_sums_alt<2 * BW, RTHREADS>(sums, red, flip);
                 const BHouse h = bhouse(sums[BW + c], sums[c]);
                 if (tid == 0) { bd[(long)BW * ld + rr] = h.beta; tv[rr] = h.tau; }
 #pragma unroll
@@ -682,7 +709,7 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
     {
         ProfScope ps_(ctx, "eigen_trd", nmax);
         int ps = 0;
-        auto reg_lds = [](int nr) { return (size_t)(BW * nr * RTHREADS + 16 * 2 * BW + 2 * BW * BW) * 8; };
+        auto reg_lds = [](int nr) { return (size_t)(BW * nr * RTHREADS + 2 * 16 * 2 * BW + 2 * BW * BW) * 8; };
         IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)band_step_reg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds(4)));
         IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)band_step_reg_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds(6)));
         auto step = [&](int ps_, int g0, int r0) {
