@@ -493,16 +493,18 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
         const v4i_ q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
         return __builtin_bit_cast(double2, q);
     };
+    // Always twelve loads, past the strip's end the last chunk once more (unused): with the fetch under a branch the compiler
+    // merges "twelve more loads in flight" with "none" at the join and lets the arithmetic of chunk k wait for chunk k+1's loads
+    // (vmcnt(7) .. vmcnt(0) where 19 .. 12 were due) -- the prefetch was there in the source and not in the machine code.  For the
+    // same reason nothing may consume a loaded value here (a mask on the reflector columns waited for the load just issued);
+    // a chunk never reaches past the strip's diagonal block, so there is nothing to mask.
+    const int clast = cend - SCHUNK;
     auto fetch = [&](double2 (&an)[8], double2 (&un)[BW], int c0) {
-        if (c0 >= cend) return;
+        const int cc = min(c0, clast);
 #pragma unroll
-        for (int c = 0; c < BW; c++) {
-            un[c] = ld2(rv, voff_u, ((r0 + c) * ld + c0) * 8);
-            if (c0 + colw >= cend) un[c].x = 0.0;
-            if (c0 + colw + 1 >= cend) un[c].y = 0.0;
-        }
+        for (int c = 0; c < BW; c++) un[c] = ld2(rv, voff_u, ((r0 + c) * ld + cc) * 8);
 #pragma unroll
-        for (int i = 0; i < 8; i++) an[i] = ld2(ra, voff_a, ((rb + i) * ld + c0) * 8);
+        for (int i = 0; i < 8; i++) an[i] = ld2(ra, voff_a, ((rb + i) * ld + cc) * 8);
     };
     auto process = [&](const double2 (&a)[8], const double2 (&uu)[BW], int c0) {
         double2 y2[BW];
