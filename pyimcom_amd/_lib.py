@@ -96,6 +96,8 @@ SIGNATURES = {
     "imcom_psf_overlap_spectra_win": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "imcom_psf_overlap_spectra_slots": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
+    "imcom_block_place": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
+    "imcom_block_combine": [_vp, _i, _i, _i, _l, _vp, _i, _vp, _i],
     "imcom_compress_map_f32": [_vp, _vp, _l, _i, _i, _vp],
     "imcom_trapezoid_recover_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i],
 }

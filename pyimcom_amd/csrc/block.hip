@@ -27,6 +27,47 @@ __global__ void block_accumulate_kernel(int npass, const int *__restrict__ list,
     *d = (float)((double)*d + (double)v);
 }
 
+// Overlapping stamps, any visiting order (fade > 0).  A pixel of the block belongs to at most four stamps, one of each index
+// parity (2 * fade <= n2).  Every stamp's tile is STORED -- in the dtype it arrives in -- into the layer of its parity
+// (block_place_kernel; tiles of one parity never overlap, so nothing is summed there), and block_combine_kernel then adds a
+// pixel's layers in the order in which the reference's loop meets their stamps (coadd.py:2049-2052: j_st outer, i_st inner),
+// each addition rounded as numpy's `f32_map[...] += tile` rounds it.  The block's maps therefore do not depend on how the
+// stamps were dealt to batches, passes or processes, and carry the reference's own rounding.
+template <typename SRC>
+__global__ void block_place_kernel(int batch, const int *__restrict__ jst, const int *__restrict__ ist, int n2, int n2f,
+                                   int nlayer, const SRC *__restrict__ src, SRC *__restrict__ layers, int nside)
+{
+    // grid: (pixels of one tile, stamps, layers)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n2f * n2f || (int)blockIdx.y >= batch) return;
+    const int s = blockIdx.y, layer = blockIdx.z;
+    const int r = t / n2f, c = t - r * n2f;
+    const int row = (jst[s] - 1) * n2 + r, col = (ist[s] - 1) * n2 + c;
+    const int par = ((jst[s] & 1) << 1) | (ist[s] & 1);
+    layers[(((long)par * nlayer + layer) * nside + row) * nside + col] = src[((long)s * nlayer + layer) * n2f * n2f + t];
+}
+
+template <typename SRC>
+__global__ void block_combine_kernel(int n1P, int n2, int n2f, long nlayer, const SRC *__restrict__ layers,
+                                     float *__restrict__ dst, int nside)
+{
+    const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (t >= nlayer * nside * nside) return;
+    const int col = (int)(t % nside), row = (int)((t / nside) % nside);
+    const long layer = t / ((long)nside * nside);
+    // 1-based stamps covering a row: (j-1) n2 <= row <= (j-1) n2 + n2f - 1
+    auto first = [&](int r) { const int lo = r - n2f + 1; return (lo <= 0 ? 0 : (lo + n2 - 1) / n2) + 1; };
+    auto last = [&](int r) { const int hi = r / n2 + 1; return hi < n1P ? hi : n1P; };
+    float d = 0.0f;
+    for (int j = first(row); j <= last(row); j++)
+        for (int i = first(col); i <= last(col); i++) {
+            const int par = ((j & 1) << 1) | (i & 1);
+            const SRC v = layers[(((long)par * nlayer + layer) * nside + row) * nside + col];
+            d = (float)((double)d + (double)v);
+        }
+    dst[t] = d;
+}
+
 // coadd.py:1284-1292 with pad widths (1262-1267): divide the 2f boundary rows/cols by the taper, B, T, L, R
 __global__ void trapezoid_recover_kernel(float *__restrict__ maps, long nmaps, int ny, int nx, int fade, int pb, int pt,
                                          int pl, int pr)
@@ -87,6 +128,49 @@ extern "C" int imcom_block_accumulate(imcom_ctx *ctx, int batch, const int *jst_
         off += cnt[p];
     }
     return check_launch("block_accumulate_kernel");
+}
+
+extern "C" int imcom_block_place(imcom_ctx *ctx, int batch, const int *jst_host, const int *ist_host, int n2, int fade, int nlayer,
+                                 const void *src, int src_is_f64, void *layers, int nside_pf)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
+    IMCOM_REQUIRE(batch >= 1 && jst_host && ist_host && src && layers && n2 >= 1 && fade >= 0 && nlayer >= 1, "bad arguments");
+    const int n2f = n2 + 2 * fade;
+    IMCOM_REQUIRE(2 * fade <= n2, "fade=%d: neighbouring stamps must overlap by less than a stamp", fade);
+    for (int s = 0; s < batch; s++)
+        IMCOM_REQUIRE(jst_host[s] >= 1 && ist_host[s] >= 1 && jst_host[s] * n2 + 2 * fade <= nside_pf && ist_host[s] * n2 + 2 * fade <= nside_pf,
+                      "stamp %d (%d,%d) outside the block", s, jst_host[s], ist_host[s]);
+    IMCOM_TRY(ws_reserve(ctx, (size_t)batch * 8 + 1024));
+    int *jd = (int *)ws_take(ctx, (size_t)batch * 4), *id = (int *)ws_take(ctx, (size_t)batch * 4);
+    IMCOM_TRY(upload(ctx, jd, jst_host, (size_t)batch));
+    IMCOM_TRY(upload(ctx, id, ist_host, (size_t)batch));
+    ProfScope ps(ctx, "block_acc");
+    dim3 grid((n2f * n2f + 255) / 256, batch, nlayer);
+    if (src_is_f64)
+        hipLaunchKernelGGL(block_place_kernel<double>, grid, dim3(256), 0, ctx->stream, batch, jd, id, n2, n2f, nlayer, (const double *)src,
+                           (double *)layers, nside_pf);
+    else
+        hipLaunchKernelGGL(block_place_kernel<float>, grid, dim3(256), 0, ctx->stream, batch, jd, id, n2, n2f, nlayer, (const float *)src,
+                           (float *)layers, nside_pf);
+    return check_launch("block_place_kernel");
+}
+
+extern "C" int imcom_block_combine(imcom_ctx *ctx, int n1P, int n2, int fade, long nlayer, const void *layers, int src_is_f64, float *dst,
+                                   int nside_pf)
+{
+    if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
+    IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
+    IMCOM_REQUIRE(n1P >= 1 && n2 >= 1 && fade >= 0 && nlayer >= 1 && layers && dst, "bad arguments");
+    IMCOM_REQUIRE(2 * fade <= n2 && nside_pf == n1P * n2 + 2 * fade, "nside_pf = %d is not n1P * n2 + 2 fade (or 2 fade > n2)", nside_pf);
+    const long tot = nlayer * nside_pf * nside_pf;
+    if (src_is_f64)
+        hipLaunchKernelGGL(block_combine_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n1P, n2, n2 + 2 * fade,
+                           nlayer, (const double *)layers, dst, nside_pf);
+    else
+        hipLaunchKernelGGL(block_combine_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n1P, n2, n2 + 2 * fade,
+                           nlayer, (const float *)layers, dst, nside_pf);
+    return check_launch("block_combine_kernel");
 }
 
 extern "C" int imcom_trapezoid_recover_f32(imcom_ctx *ctx, float *maps, long nmaps, int ny, int nx, int fade, int pad_b, int pad_t,

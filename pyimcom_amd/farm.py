@@ -64,31 +64,36 @@ def write_block(path, maps, meta=None):
     out.update({k: v.cpu().numpy() for k, v in maps.maps.items()})
     for k, v in (meta or {}).items():
         out["meta_" + k] = np.asarray(v)
-    tmp = path + f".tmp{os.getpid()}.npz"
-    np.savez(tmp, **out)
-    os.replace(tmp, path)
+    _save_npz(path, out)
 
 
 # ---- dynamic schedule: blocks claimed on start, the passes of a block shared when whole blocks run out ------------------
 #
 # Coordination is by files in a hidden directory of the output directory (atomic O_EXCL creation = a claim; atomic rename =
 # a result) -- the reference's own mechanism, generalised: its block runner skips a block whose output file exists
-# (examples/multiblock_norep.pl:25-27).  No rank ever waits for another and nothing is exchanged between ranks in memory.
+# (examples/multiblock_norep.pl:25-27).  Nothing is exchanged between ranks in memory, and no rank waits for another while
+# there is work it could do.
 #
-#   .farm-<token>/b<id>.claim          a rank has taken block <id> (it builds the inputs, plans the passes, writes the plan)
-#   .farm-<token>/b<id>.plan.json      the block's passes (lists of stamps): helpers run the same plan
-#   .farm-<token>/b<id>.c<q>.claim     pass q of the block is taken
-#   .farm-<token>/b<id>.part.<rank>.npz  a rank's partial block maps (the sum of the passes it ran) + the list of those passes
-#   .farm-<token>/b<id>.merge          the rank that found every pass of the block in part files and sums them
+#   .farm-<token>/b<id>.claim            a rank has taken block <id> (it builds the inputs, plans the passes, writes the plan)
+#   .farm-<token>/b<id>.plan.json        the block's passes (lists of stamps): helpers run the same plan
+#   .farm-<token>/b<id>.c<q>.claim       pass q of the block is taken
+#   .farm-<token>/b<id>.part.<rank>.<k>.npz  what a rank has coadded of a SHARED block (BlockMaps.state(): arrays that add
+#                                        exactly between ranks) + the list of its passes; a block one rank coadds alone has none
+#   .farm-<token>/b<id>.merge            the rank that found every pass of the block in part files and sums them
+#   .farm-<token>/b<id>.done             the block's file has been written by this launch
 #
 # A rank walks the blocks in order of decreasing cost and claims the first free one (list scheduling: what a static LPT
 # partition computes in advance, but from the real durations); when no unclaimed block is left it joins the blocks still in
 # progress, most remaining work first, and takes passes from the END of their plans while their owners walk from the front.
-# Partial maps are sums over stamps, so parts add up to the block's maps; the boundary recovery runs once, on the sum.  A
-# block that one rank coadded alone is bit-identical to the static schedule's; a shared block differs by float32 rounding
-# where stamps of different parts overlap.  <token> identifies the launch (default: the parent process id, which the ranks
-# of one torch.distributed.run share): claims of a killed launch never block a restart, finished blocks are skipped by
-# their output files.
+# The parts of a shared block add up EXACTLY (with fade > 0 they hold the stamps' tiles apart in parity layers, block.py), the
+# sums of overlapping stamps are formed once, in the reference's stamp order, by the rank that merges: a shared block is the
+# single process's block bit for bit, whoever ran which pass.
+# Every claim names its owner (rank, pid, the process's start time, host).  A claim whose owner no longer exists on this host
+# -- a killed launch that used the same <token>, a rank that died in this one -- is taken over (atomic rename, one winner), so
+# stale claims never hide a block; a rank that has nothing left to do stays until every block file exists, taking over what
+# dying ranks leave behind, and run() raises if blocks remain that nobody works on.
+# <token> identifies the launch: IMCOM_FARM_RUN, else a value broadcast by rank 0 when torch.distributed is initialised, else
+# the process itself (one rank) or its parent (pid and start time; the ranks of one torch.distributed.run share it).
 def _try_create(path, text=""):
     import os
 
@@ -110,14 +115,98 @@ def _atomic_write(path, write):
 
 
 def _save_npz(path, arrays):
-    """np.savez under a temporary name, then renamed: a reader never sees a partial file."""
+    """np.savez under a temporary name (which no reader's pattern matches), then renamed: a reader never sees a partial file."""
     import os
 
     import numpy as np
 
-    tmp = f"{path}.tmp{os.getpid()}.npz"
-    np.savez(tmp, **arrays)
+    d, f = os.path.split(path)
+    tmp = os.path.join(d, f".tmp{os.getpid()}.{f}")
+    with open(tmp, "wb") as fh:
+        np.savez(fh, **arrays)
     os.replace(tmp, path)
+
+
+def _proc_start(pid):
+    """Start time of process `pid` in clock ticks since boot (/proc/<pid>/stat field 22); None if there is no such process
+    (or no /proc): with the pid it names ONE process, whatever the kernel does with the number later."""
+    try:
+        with open(f"/proc/{int(pid)}/stat") as f:
+            s = f.read()
+        fields = s[s.rindex(")") + 2 :].split()
+        return None if fields[0] in "ZX" else fields[19]  # a zombie (exited, not yet reaped by its parent) works no more
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def _owner(rank):
+    import json
+    import os
+    import socket
+
+    return json.dumps({"rank": int(rank), "pid": os.getpid(), "start": _proc_start(os.getpid()), "host": socket.gethostname()})
+
+
+def _claim_state(path, grace=10.0):
+    """None: no such claim; True: its owner is (or may be) alive; False: the owner is gone -- the claim is stale."""
+    import json
+    import os
+    import socket
+    import time
+
+    try:
+        with open(path) as f:
+            text = f.read()
+        rec = json.loads(text) if text.strip() else None
+    except FileNotFoundError:
+        return None
+    except (OSError, ValueError):
+        rec = None
+    if not isinstance(rec, dict) or "pid" not in rec:
+        # being written right now (created, not yet filled), or written by a process that died in between
+        try:
+            return time.time() - os.path.getmtime(path) < grace
+        except OSError:
+            return None
+    if rec.get("host") != socket.gethostname() or rec.get("start") is None or _proc_start(os.getpid()) is None:
+        return True  # cannot tell from here
+    return _proc_start(rec["pid"]) == rec["start"]
+
+
+def _take_stale(path):
+    """Remove a stale claim; True for the one process that did it."""
+    import os
+
+    try:
+        os.rename(path, f"{path}.stale{os.getpid()}")
+    except OSError:
+        return False
+    os.remove(f"{path}.stale{os.getpid()}")
+    return True
+
+
+def launch_token(world, token=None):
+    """The name of this launch's coordination directory (see above)."""
+    import os
+
+    if token is not None:
+        return str(token)
+    if os.environ.get("IMCOM_FARM_RUN"):
+        return os.environ["IMCOM_FARM_RUN"]
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() == world and world > 1:
+            import uuid
+
+            box = [uuid.uuid4().hex[:12] if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return f"d{box[0]}"
+    except ImportError:
+        pass
+    pid = os.getpid() if world == 1 else os.getppid()
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    return f"{pid}.{_proc_start(pid) or 0}" + (f".{run_id}" if world > 1 and run_id != "none" else "")
 
 
 class _GpuBackend:
@@ -132,35 +221,30 @@ class _GpuBackend:
         return plan_block(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], self.batch)
 
     def coadd(self, spec, chunks, claim):
-        """-> ({name: array}, passes run): partial maps, not recovered at the block boundary."""
+        """-> ({name: array}, passes run): what this process coadded of the block, as arrays that add exactly between
+        processes (BlockMaps.state()); nothing is summed over overlapping stamps or recovered at the boundary yet."""
         import torch
 
         from .blockrun import coadd_block
 
         maps = coadd_block(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], spec["n_expo"], chunks=chunks, claim=claim, pad_sides=None)
         torch.cuda.synchronize()
-        out = {"out_map": maps.out_map.cpu().numpy(), "T_weightmap": maps.T_weightmap.cpu().numpy()}
-        out.update({k: v.cpu().numpy() for k, v in maps.maps.items()})
-        return out, list(maps.chunks_done)
+        return maps.state(), list(maps.chunks_done)
 
     def finalize(self, spec, arrays):
-        """Boundary recovery (coadd.py:2163-2181) of summed partial maps -> the block's arrays."""
+        """The summed states -> the block's arrays: overlap sums in the reference's stamp order, boundary recovery
+        (coadd.py:2163-2181)."""
         import torch
 
         from .block import BlockMaps
 
         cfg = spec["cfg"]
-        n_out = arrays["out_map"].shape[0]
+        n_out = arrays["T_weightmap"].shape[0]
         maps = BlockMaps(spec["n1P"], cfg.n2, cfg.fade, cfg.n_inframe, spec["n_expo"], ctx=spec["tables"].ctx, device=str(spec["pool"].device), n_out=n_out)
-        maps.out_map.copy_(torch.as_tensor(arrays["out_map"]))
-        maps.T_weightmap.copy_(torch.as_tensor(arrays["T_weightmap"]))
-        for k in maps.maps:
-            maps.maps[k].copy_(torch.as_tensor(arrays[k]))
+        maps.load_state(arrays)
         maps.finalize(spec.get("pad_sides", ""), spec.get("postage_pad", 0))
         torch.cuda.synchronize()
-        out = {"out_map": maps.out_map.cpu().numpy(), "T_weightmap": maps.T_weightmap.cpu().numpy()}
-        out.update({k: v.cpu().numpy() for k, v in maps.maps.items()})
-        return out
+        return maps.arrays()
 
 
 class _Prefetch:
@@ -208,7 +292,7 @@ class _Prefetch:
 
 
 def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=None, restart=True, log=print, coadd=None,
-        schedule="dynamic", token=None, backend=None, prefetch=True):
+        schedule="dynamic", token=None, backend=None, prefetch=True, poll=0.05):
     """Coadd this rank's share of `blocks` (ids) and write block_<id>.npz files into `outdir`.
 
     costs[k]: relative cost of blocks[k] (estimate_cost summed over its stamps);
@@ -222,6 +306,7 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
     import json
     import os
     import time
+    import zipfile
 
     import numpy as np
 
@@ -255,109 +340,213 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
         log(f"[farm rank {rank}] busy {busy:.2f} s of {time.perf_counter() - t_start:.2f} s (static schedule)")
         return done
     assert schedule == "dynamic"
+    import re
+
     be = backend or _GpuBackend(batch)
-    token = str(token if token is not None else os.environ.get("IMCOM_FARM_RUN", os.getppid()))
+    token = launch_token(world, token)
     cdir = os.path.join(outdir, f".farm-{token}")
     os.makedirs(cdir, exist_ok=True)
+    _sweep_dead_launches(outdir, cdir)
+    me = _owner(rank)
     cp = lambda b, what: os.path.join(cdir, f"b{int(b):04d}.{what}")  # noqa: E731
     order = [blocks[k] for k in sorted(range(len(blocks)), key=lambda k: (-costs[k], k))]
     cost_of = dict(zip(blocks, costs))
     pre = _Prefetch(make_block, prefetch)
-
-    done_parts = []
+    nparts = [0]
 
     def finished(b):  # by this launch, or (restart) by an earlier one
-        return os.path.exists(cp(b, "done")) or (restart and os.path.exists(block_path(outdir, b)))
+        return os.path.exists(block_path(outdir, b)) and (restart or os.path.exists(cp(b, "done")))
+
+    def take(path):
+        """Claim `path`: create it, or take it over from an owner that no longer exists."""
+        if _try_create(path, me):
+            return True
+        return _claim_state(path) is False and _take_stale(path) and _try_create(path, me)
+
+    def claimable(path):
+        return _claim_state(path) in (None, False)
 
     def free_blocks():
-        return [b for b in order if not finished(b) and not os.path.exists(cp(b, "claim"))]
+        return [b for b in order if not finished(b) and claimable(cp(b, "claim"))]
+
+    def parts_of(b):
+        """The readable part files of block b: [(name, passes, arrays)] in the order of their first pass."""
+        pat = re.compile(rf"^b{int(b):04d}\.part\.\d+\.\d+\.npz$")
+        out = []
+        for f in sorted(os.listdir(cdir)):
+            if not pat.match(f):
+                continue
+            try:
+                with np.load(os.path.join(cdir, f)) as z:
+                    out.append((f, [int(q) for q in z["passes"]], {k: z[k] for k in z.files if k != "passes"}))
+            except (OSError, ValueError, EOFError, KeyError, zipfile.BadZipFile):
+                continue  # not a complete file (yet): its passes do not count
+        out.sort(key=lambda t: min(t[1]))
+        return out
+
+    def covered(b):
+        return sorted(q for _, ps, _ in parts_of(b) for q in ps)
+
+    def write_out(b, spec, total, ranks):
+        out = be.finalize(spec, total)
+        for k, v in (spec.get("meta") or {}).items():
+            out["meta_" + k] = np.asarray(v)
+        out["meta_ranks"] = np.asarray(sorted(ranks))
+        _save_npz(block_path(outdir, b), out)
+        _try_create(cp(b, "done"), me)
 
     def run_passes(b, spec, chunks, from_end):
-        """Claim and run passes of block b, write the part file, try to merge.  -> passes run"""
+        """Claim and run passes of block b.  The whole block by this rank alone: written right away; else the part file.
+        -> (passes run, block file written)"""
         nonlocal busy
         idx = list(range(len(chunks)))
         if from_end:
             idx.reverse()
         view = [chunks[q] for q in idx]
         t0 = time.perf_counter()
-        arrays, ran = be.coadd(spec, view, lambda k: _try_create(cp(b, f"c{idx[k]:04d}.claim"), str(rank)))
+
+        def claim(k):
+            path = cp(b, f"c{idx[k]:04d}.claim")
+            if _try_create(path, me):
+                return True
+            # the pass of a rank that died before it wrote its part
+            return _claim_state(path) is False and idx[k] not in covered(b) and _take_stale(path) and _try_create(path, me)
+
+        arrays, ran = be.coadd(spec, view, claim)
         ran = [idx[k] for k in ran]
+        wrote = False
+        if len(ran) == len(chunks) and take(cp(b, "merge")):
+            write_out(b, spec, arrays, [rank])
+            wrote = True
+        elif ran:
+            _save_npz(cp(b, f"part.{rank}.{nparts[0]}.npz"), dict(arrays, passes=np.asarray(ran)))
+            nparts[0] += 1
         busy += time.perf_counter() - t0
-        if ran:
-            _save_npz(cp(b, f"part.{rank}.{len(done_parts)}.npz"), dict(arrays, passes=np.asarray(ran)))
-            done_parts.append(b)
-        return ran
+        return ran, wrote
 
     def try_merge(b, spec, nchunks):
         nonlocal busy
-        parts = [f for f in os.listdir(cdir) if f.startswith(f"b{int(b):04d}.part.") and f.endswith(".npz")]
-        loaded = [np.load(os.path.join(cdir, f)) for f in parts]
-        have = sorted(int(q) for z in loaded for q in z["passes"])
-        if have != list(range(nchunks)) or not _try_create(cp(b, "merge"), str(rank)):
+        parts = parts_of(b)
+        have = sorted(q for _, ps, _ in parts for q in ps)
+        if len(set(have)) != len(have):
+            raise RuntimeError(f"block {b}: passes {have} were coadded more than once")
+        if have != list(range(nchunks)) or finished(b) or not take(cp(b, "merge")):
             return False
         t0 = time.perf_counter()
-        names = [k for k in loaded[0].files if k != "passes"]
-        total = {k: loaded[0][k].copy() for k in names}
-        for z in sorted(loaded[1:], key=lambda z_: int(z_["passes"][0])):  # a fixed order of the sum
-            for k in names:
-                total[k] += z[k]
-        out = be.finalize(spec, total)
-        for k, v in (spec.get("meta") or {}).items():
-            out["meta_" + k] = np.asarray(v)
-        out["meta_ranks"] = np.asarray(sorted(int(f.split(".")[2]) for f in parts))
-        _save_npz(block_path(outdir, b), out)
-        _try_create(cp(b, "done"), str(rank))
+        total = {k: v.copy() for k, v in parts[0][2].items()}
+        for _, _, arrays in parts[1:]:  # in the order of the parts' first passes
+            for k in total:
+                total[k] += arrays[k]
+        write_out(b, spec, total, {int(f.split(".")[2]) for f, _, _ in parts})
         busy += time.perf_counter() - t0
         return True
+
+    def load_plan(b):
+        try:
+            with open(cp(b, "plan.json")) as f:
+                return [[tuple(t) for t in c] for c in json.load(f)]
+        except (OSError, ValueError):
+            return None
+
+    def phase1():
+        """Whole blocks, largest first.  -> something was done"""
+        did = False
+        while True:
+            mine = next((b for b in free_blocks() if take(cp(b, "claim"))), None)
+            if mine is None:
+                return did
+            did = True
+            t0 = time.perf_counter()
+            spec = pre.get(mine)
+            rest = [b for b in free_blocks() if b != mine]
+            pre.start(rest[0] if rest else None)  # the host part of the block this rank will most likely take next
+            chunks = load_plan(mine)  # left by an owner that died: its helpers and their parts follow that plan
+            if chunks is None:
+                chunks = be.plan(spec)
+                _atomic_write(cp(mine, "plan.json"), lambda tmp: json.dump([[list(map(int, t)) for t in c] for c in chunks], open(tmp, "w")))
+            ran, wrote = run_passes(mine, spec, chunks, from_end=False)
+            wrote = wrote or try_merge(mine, spec, len(chunks))
+            if wrote:
+                done.append(mine)
+            log(f"[farm rank {rank}] block {mine}: {len(ran)} of {len(chunks)} passes, {spec['n_expo']} exposures, {time.perf_counter() - t0:.2f} s"
+                + (f" -> {block_path(outdir, mine)}" if wrote else " (shared: merged by the rank that finishes last)"))
+
+    def phase2():
+        """Help with the blocks in progress, most remaining work first; merge what dying ranks left complete.  -> something was done"""
+        did, tried = False, set()
+        while True:
+            open_blocks = []
+            for b in order:
+                if b in tried or finished(b) or _claim_state(cp(b, "merge")):
+                    continue
+                chunks = load_plan(b)
+                if chunks is None:
+                    continue
+                have = covered(b)
+                left = [q for q in range(len(chunks)) if q not in have and claimable(cp(b, f"c{q:04d}.claim"))]
+                if left or have == list(range(len(chunks))):
+                    open_blocks.append((cost_of[b] * len(left) / len(chunks), -order.index(b), b, chunks, left))
+            if not open_blocks:
+                return did
+            _, _, b, chunks, left = max(open_blocks, key=lambda t: t[:2])
+            tried.add(b)
+            t0 = time.perf_counter()
+            spec = pre.get(b)
+            ran, wrote = run_passes(b, spec, chunks, from_end=True) if left else ([], False)
+            wrote = wrote or try_merge(b, spec, len(chunks))
+            did = did or bool(ran) or wrote
+            if wrote:
+                done.append(b)
+            log(f"[farm rank {rank}] block {b}: helped with {len(ran)} of {len(chunks)} passes, {time.perf_counter() - t0:.2f} s"
+                + (f" -> {block_path(outdir, b)}" if wrote else ""))
 
     for b in order:
         if restart and os.path.exists(block_path(outdir, b)):
             log(f"[farm rank {rank}] block {b}: {block_path(outdir, b)} exists, skipped")
-    # phase 1: whole blocks, largest first
+    waiting = None
     while True:
-        cand = free_blocks()
-        mine = next((b for b in cand if _try_create(cp(b, "claim"), str(rank))), None)
-        if mine is None:
+        did = phase1()
+        did = phase2() or did
+        pending = [b for b in order if not finished(b)]
+        if not pending:
             break
-        t0 = time.perf_counter()
-        spec = pre.get(mine)
-        rest = [b for b in free_blocks() if b != mine]
-        pre.start(rest[0] if rest else None)  # the host part of the block this rank will most likely take next
-        chunks = be.plan(spec)
-        _atomic_write(cp(mine, "plan.json"), lambda tmp: json.dump([[list(map(int, t)) for t in c] for c in chunks], open(tmp, "w")))
-        ran = run_passes(mine, spec, chunks, from_end=False)
-        wrote = try_merge(mine, spec, len(chunks))
-        if wrote:
-            done.append(mine)
-        log(f"[farm rank {rank}] block {mine}: {len(ran)} of {len(chunks)} passes, {spec['n_expo']} exposures, {time.perf_counter() - t0:.2f} s"
-            + (f" -> {block_path(outdir, mine)}" if wrote else " (shared: merged by the rank that finishes last)"))
-    # phase 2: help with the blocks still in progress, most remaining work first
-    tried = set()
-    while True:
-        open_blocks = []
-        for b in order:
-            if b in tried or finished(b) or not os.path.exists(cp(b, "plan.json")) or os.path.exists(cp(b, "merge")):
-                continue
-            chunks = [[tuple(t) for t in c] for c in json.load(open(cp(b, "plan.json")))]
-            left = [q for q in range(len(chunks)) if not os.path.exists(cp(b, f"c{q:04d}.claim"))]
-            if left:
-                open_blocks.append((cost_of[b] * len(left) / len(chunks), -order.index(b), b, chunks))
-        if not open_blocks:
-            break
-        _, _, b, chunks = max(open_blocks, key=lambda t: t[:2])
-        tried.add(b)
-        t0 = time.perf_counter()
-        spec = pre.get(b)
-        ran = run_passes(b, spec, chunks, from_end=True)
-        wrote = try_merge(b, spec, len(chunks)) if ran else False
-        if wrote:
-            done.append(b)
-        log(f"[farm rank {rank}] block {b}: helped with {len(ran)} of {len(chunks)} passes, {time.perf_counter() - t0:.2f} s"
-            + (f" -> {block_path(outdir, b)}" if wrote else ""))
+        if did:
+            continue
+        # nothing this rank could take: either other ranks are at work on the rest (stay: if one of them dies its claims go
+        # stale and are taken over above), or the rest is lost
+        def live(b):
+            names = [f for f in os.listdir(cdir) if f.startswith(f"b{int(b):04d}.") and f.endswith((".claim", ".merge"))]
+            return any(_claim_state(os.path.join(cdir, f)) for f in names)
+
+        lost = [b for b in pending if not live(b)]
+        if lost and lost == [b for b in lost if not finished(b) and not live(b)]:  # (looked twice: a merge may have ended in between)
+            raise RuntimeError(f"[farm rank {rank}] blocks {lost} have no output file and nobody works on them")
+        if waiting != pending:
+            log(f"[farm rank {rank}] nothing left to take; blocks {pending} are in other ranks' hands")
+            waiting = pending
+        time.sleep(poll)
     pre.join()
     wall = time.perf_counter() - t_start
     log(f"[farm rank {rank}] busy {busy:.2f} s of {wall:.2f} s ({100.0 * busy / max(wall, 1e-9):.0f} %), wrote {len(done)} block files")
     return done
+
+
+def _sweep_dead_launches(outdir, keep):
+    """Remove the coordination directories of earlier launches in which no claim has a live owner (a killed launch leaves one
+    behind; its finished blocks are the block files, which stay)."""
+    import os
+    import shutil
+
+    for d in os.listdir(outdir):
+        path = os.path.join(outdir, d)
+        if not d.startswith(".farm-") or path == keep or not os.path.isdir(path):
+            continue
+        try:
+            names = [f for f in os.listdir(path) if f.endswith((".claim", ".merge"))]
+            if not any(_claim_state(os.path.join(path, f)) for f in names):
+                shutil.rmtree(path, ignore_errors=True)
+        except OSError:
+            pass
 
 
 def simulate(costs, passes, world, overhead=0.0):

@@ -228,3 +228,110 @@ def test_dynamic_schedule_projected_makespan():
             worst_dyn = max(worst_dyn, mk / mean)
         worst_static = max(worst_static, static)
     assert worst_dyn <= 1.05 and worst_static >= 1.08, (worst_dyn, worst_static)
+
+
+def _dying_worker(outdir, die_in_pass):
+    """One rank of a launch that is killed inside a block: it claims the most expensive block and dies in pass `die_in_pass`."""
+    blocks, costs, make_block, _ = _dyn_mosaic()
+
+    class Dying(_HostBackend):
+        def coadd(self, spec, chunks, claim):
+            for q in range(len(chunks)):
+                assert claim(q)
+                if q == die_in_pass:
+                    os._exit(17)
+
+    farm.run(blocks, costs, make_block, outdir, 0, 2, backend=Dying(4), token="same", log=lambda *a: None)
+
+
+def test_dynamic_schedule_survives_a_killed_launch_with_the_same_token(tmp_path):
+    """The advisor's round-3 scenario: a launch is killed inside its first block and the next launch reuses the token (same
+    shell, same job script).  The dead rank's block claim and pass claims name a process that no longer exists; they are taken
+    over, every block file is written and equals the single process's.  A half-written part file (the temporary name of
+    _save_npz, or a truncated zip under a part's name) is not mistaken for a part."""
+    import multiprocessing as mp
+
+    outdir, single = str(tmp_path / "dyn"), str(tmp_path / "single")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_dying_worker, args=(outdir, 1))
+    p.start()
+    p.join(timeout=60)
+    assert p.exitcode == 17
+    cdir = os.path.join(outdir, ".farm-same")
+    left = sorted(os.listdir(cdir))
+    assert sum(f.count(".") == 1 and f.endswith(".claim") for f in left) == 1 and sum(".c000" in f for f in left) == 2, left  # block + two passes
+    blocks, costs, make_block, made = _dyn_mosaic()
+    dead = sorted(blocks, key=lambda b: (-costs[b], b))[0]
+    with open(os.path.join(cdir, f".tmp999.b{dead:04d}.part.0.0.npz"), "wb") as f:  # what a writer in progress leaves
+        f.write(b"PK\x03\x04 half a zip")
+    with open(os.path.join(cdir, f"b{dead:04d}.part.7.0.npz"), "wb") as f:  # a truncated file under a part's own name
+        f.write(b"PK\x03\x04 half a zip")
+    logs = []
+    done = farm.run(blocks, costs, make_block, outdir, backend=_HostBackend(4), token="same", log=logs.append)
+    assert sorted(done) == blocks, logs
+    farm.run(blocks, costs, make_block, single, backend=_HostBackend(4), token="s", log=lambda *a: None)
+    for b in blocks:
+        a, c = np.load(farm.block_path(outdir, b)), np.load(farm.block_path(single, b))
+        assert all(np.array_equal(a[k], c[k]) for k in ("out_map", "T_weightmap", "UC")), b
+        assert np.all(a["UC"] == 2.0)  # every stamp exactly once (the dead rank's passes were redone, not doubled)
+
+
+def _slow_then_die_worker(outdir, q):
+    blocks, costs, make_block, _ = _dyn_mosaic(nblocks=2)
+
+    class Dying(_HostBackend):
+        def coadd(self, spec, chunks, claim):
+            import time
+
+            assert claim(0)
+            q.put("claimed")
+            time.sleep(1.0)
+            os._exit(17)
+
+    farm.run(blocks, costs, make_block, outdir, 1, 2, backend=Dying(4), token="L", log=lambda *a: None)
+
+
+def test_dynamic_schedule_takes_over_from_a_rank_that_dies_in_this_launch(tmp_path):
+    """Two ranks, two blocks: rank 1 claims a block and dies in it while rank 0 is at work.  Rank 0 finishes its own block,
+    finds nothing free, stays while the other block's owner is alive, and takes the block over once the owner is gone: run()
+    returns with every block written (before: the block was silently missing and the exit code 0)."""
+    import multiprocessing as mp
+
+    outdir = str(tmp_path / "dyn")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_slow_then_die_worker, args=(outdir, q))
+    p.start()
+    assert q.get(timeout=60) == "claimed"
+    blocks, costs, make_block, _ = _dyn_mosaic(nblocks=2)
+    logs = []
+    done = farm.run(blocks, costs, make_block, outdir, 0, 2, backend=_HostBackend(4), token="L", log=logs.append)
+    p.join(timeout=60)
+    assert p.exitcode == 17
+    assert sorted(done) == blocks, logs
+    assert any("in other ranks' hands" in l for l in logs), logs  # it did wait for the live owner first
+    for b in blocks:
+        assert np.all(np.load(farm.block_path(outdir, b))["UC"] == 2.0)
+
+
+def test_launch_token_and_claim_liveness(tmp_path):
+    import json
+
+    assert farm.launch_token(1) != farm.launch_token(2)  # one rank: the process itself; several: their common parent
+    assert farm.launch_token(4, "x") == "x"
+    mine = tmp_path / "a.claim"
+    assert farm._try_create(str(mine), farm._owner(3)) and farm._claim_state(str(mine)) is True
+    assert not farm._try_create(str(mine), farm._owner(3))
+    gone = tmp_path / "b.claim"
+    rec = json.loads(farm._owner(0))
+    rec["start"] = "1"  # this pid, but not this process: the number has been reused
+    gone.write_text(json.dumps(rec))
+    assert farm._claim_state(str(gone)) is False and farm._take_stale(str(gone)) and not gone.exists()
+    other = tmp_path / "c.claim"
+    rec["host"] = "elsewhere"
+    other.write_text(json.dumps(rec))
+    assert farm._claim_state(str(other)) is True  # cannot be checked from here: respected
+    assert farm._claim_state(str(tmp_path / "none.claim")) is None
+    empty = tmp_path / "d.claim"
+    empty.write_text("")
+    assert farm._claim_state(str(empty)) is True and farm._claim_state(str(empty), grace=0.0) is False

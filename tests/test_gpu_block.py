@@ -38,14 +38,37 @@ def test_block_maps_vs_oracle():
         orc.block_accumulate(ref_out, res.outimage[k].cpu().numpy()[None], j, i, cfg.n2, cfg.fade)
         for name in ref:
             orc.block_accumulate(ref[name], src[name][k].cpu().numpy()[None], j, i, cfg.n2, cfg.fade)
-    # float32 sums of up to four overlapping stamps: the order may differ from the reference's visiting order,
-    # so allow a few float32 ulps of the largest term (signed images can cancel)
+    # float32 sums of up to four overlapping stamps: the tiles are kept apart in parity layers and added per pixel in the
+    # reference's visiting order (j_st outer, i_st inner), each addition rounded as numpy's `f32 += tile`: the same bits
+    assert np.array_equal(bm.out_map[0].cpu().numpy(), ref_out[0])
+    for name in ref:
+        assert np.array_equal(bm.maps[name].cpu().numpy(), ref[name]), name
+    # ... whatever calls the stamps arrive in: one by one in a scrambled order, and all at once
+    perm = np.random.default_rng(3).permutation(len(ids))
+    for groups in ([[int(k)] for k in perm], [list(range(len(ids)))]):
+        other = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3)
+        for grp in groups:
+            sub = dataclasses.replace(res, outimage=res.outimage[grp], UC=res.UC[grp], Sigma=res.Sigma[grp], kappa=res.kappa[grp],
+                                      Tsum_inpix=res.Tsum_inpix[grp], Neff=res.Neff[grp], Tsum_stamp=res.Tsum_stamp[grp])
+            other.add(sub, [ids[k][0] for k in grp], [ids[k][1] for k in grp])
+        assert torch.equal(other.out_map, bm.out_map) and torch.equal(other.T_weightmap, bm.T_weightmap)
+        assert all(torch.equal(other.maps[k], bm.maps[k]) for k in ref)
+    # the state two processes would exchange adds up exactly: the first half's + the second half's = the whole block's
+    parts = []
+    for sl in (slice(0, half), slice(half, None)):
+        pm = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3)
+        sub = dataclasses.replace(res, outimage=res.outimage[sl], UC=res.UC[sl], Sigma=res.Sigma[sl], kappa=res.kappa[sl],
+                                  Tsum_inpix=res.Tsum_inpix[sl], Neff=res.Neff[sl], Tsum_stamp=res.Tsum_stamp[sl])
+        pm.add(sub, [j for j, _ in ids[sl]], [i for _, i in ids[sl]])
+        parts.append(pm.state())
+    assert all(k.startswith("L_") or k == "T_weightmap" for k in parts[0])
+    merged = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3)
+    merged.load_state({k: parts[0][k] + parts[1][k] for k in parts[0]})
+    assert torch.equal(merged.out_map, bm.out_map) and all(torch.equal(merged.maps[k], bm.maps[k]) for k in ref)
+
     def close(a, b):
         return np.abs(a - b).max() <= 4e-7 * np.abs(b).max()
 
-    assert close(bm.out_map[0].cpu().numpy(), ref_out[0])
-    for name in ref:
-        assert close(bm.maps[name].cpu().numpy(), ref[name]), name
     tw = bm.T_weightmap[0].cpu().numpy()
     assert np.allclose(tw[:, 1, 2], res.Tsum_stamp[1 * n1P + 2].cpu().numpy().astype(np.float32))
     bm.finalize(pad_sides="BL", postage_pad=1)
@@ -117,8 +140,8 @@ def test_recover_and_compress_vs_reference_golden(golden):
 
 def test_block_maps_vs_reference_golden(golden):
     """BlockMaps.add / finalize against the maps the reference's own _output_stamp_wrapper and build_output_file code
-    produced for nine finished stamps with two target PSFs (block_maps.npz).  The adds of overlapping stamps may come in
-    another order than the reference's stamp loop: a few float32 ulps of the largest term."""
+    produced for nine finished stamps with two target PSFs (block_maps.npz): the accumulated maps bit for bit (parity layers,
+    added in the reference's stamp order), the recovered ones to float32 rounding of the division."""
     import torch
 
     from pyimcom_amd.block import BlockMaps
@@ -138,11 +161,12 @@ def test_block_maps_vs_reference_golden(golden):
     def close(a, b):
         return np.abs(a - b).max() <= 4e-7 * np.abs(b).max()
 
+    # overlapping stamps are added per pixel in the reference's stamp order with numpy's rounding: the reference's own bits
     names = dict(UC="UC_map", Sigma="Sigma_map", kappa="kappa_map", Tsum="Tsum_map", Neff="Neff_map")
-    assert close(bm.out_map.cpu().numpy(), g["acc_out_map"])
+    assert np.array_equal(bm.out_map.cpu().numpy(), g["acc_out_map"])
     assert np.array_equal(bm.T_weightmap.cpu().numpy(), g["acc_T_weightmap"])
     for k, nm in names.items():
-        assert close(bm.maps[k].cpu().numpy(), g[f"acc_{nm}"]), k
+        assert np.array_equal(bm.maps[k].cpu().numpy(), g[f"acc_{nm}"]), k
     bm.finalize(pad_sides=str(g["pad_sides"]), postage_pad=int(g["postage_pad"]))
     torch.cuda.synchronize()
     assert close(bm.out_map.cpu().numpy(), g["fin_out_map"])
