@@ -140,7 +140,12 @@ int imcom_solve_chol_stamps(imcom_ctx *ctx, int nst, const int *n, int m, const 
                             double smax, float *const *T, float *const *UC, float *const *Sigma, float *const *kappa,
                             int *info);
 /* Same contract, eigendecomposition path; nv==1: lakernel.py:154-172, nv>1: 174-223 with nbis
- * bisections (reference default 13) and the kappa *= C quirk of line 222. */
+ * bisections (reference default 13) and the kappa *= C quirk of line 222.
+ * info[s]: 0 = A + kappaC[0] C I is positive definite (the PSF-overlap matrices of this problem): solved in the band basis
+ * (DESIGN.md "Eigen path"); 1 = it is NOT -- A has an eigenvalue at or below -kappaC[0] C, every pivot of the reduced matrix
+ * is checked -- and the stamp was solved through the eigendecomposition itself with the reference's own formulas, which
+ * divide by lam_i + kappa whatever its sign (numpy.linalg.eigh at lakernel.py:162, 201; routine.lakernel1): the kernel a
+ * user falls back to when Cholesky fails serves any symmetric A.  Results are valid either way; never an error. */
 int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A,
                       const double *mBhalf, const double *C, const double *kappaC, int nv,
                       double ucmin, double smax, int nbis, float *T, float *UC, float *Sigma,

@@ -14,9 +14,17 @@
 //     y_a = (T + kappa_a I)^-1 c_a at the final kappa forward + backward substitution                     (tri_solve_kernel)
 //     T_a = Qh y_a                                    block reflectors again, stored float32
 // which removes the implicit QR iteration, the rotations of the eigenvector matrix and the explicit Qh (a third of the
-// old path's time at N = 2.9k) and all of their workspace.  T + kappa I is positive definite for kappa > -lam_min, which
-// the bracket kappa >= kappaC[0] C > 0 guarantees for the positive semi-definite A of this problem, so the LDL^T needs no
-// pivoting.  The bisection takes the same decisions as lakernel1 except where udc or sum2 sits within rounding of its bound.
+// old path's time at N = 2.9k) and all of their workspace.  T + kappa I is positive definite for kappa > -lam_min, and then the
+// LDL^T needs no pivoting (it is a Cholesky factorisation in disguise: backward stable).  The positive semi-definite A of this
+// problem guarantees that for the whole bracket kappa >= kappaC[0] C > 0 -- but the reference serves ANY symmetric A: it
+// diagonalises with numpy.linalg.eigh and divides by lam + kappa whatever its sign (lakernel.py:154-172, 199-223), and it is
+// the kernel users turn to when the Cholesky factorisation fails.  So every stamp is CHECKED, not assumed: one sweep of the
+// reduced matrix at the lowest kappa of the call (pd_check kernels; every kappa the bisection visits is larger) decides
+// whether all pivots are positive.  Stamps that fail -- A + kappa_min I not positive definite, where an unpivoted LDL^T is only
+// conditionally stable -- are re-solved, in the same call, through the eigendecomposition itself (eigen_fallback: tridiag.hip's
+// eigensolver, P = (-B/2) Q, the reference's formulas / lakernel1 in the eigenbasis, T = (P / (lam + kappa)) Q^T) and reported
+// with info[s] = 1.
+// The bisection takes the same decisions as lakernel1 except where udc or sum2 sits within rounding of its bound.
 #include <cstdlib>
 #include <cstring>
 
@@ -295,6 +303,100 @@ __global__ __launch_bounds__(64) void band_solve_kernel(const double *__restrict
     kappa[pa] = kap_pix ? (float)((double)(float)kap * C) : (float)kap;
 }
 
+// Is M + kappa_min I positive definite?  One thread per stamp sweeps the LDL^T of the reduced matrix at the lowest kappa of the
+// call: flag[s] = 1 at the first pivot that is not positive (NaN included), minpiv[s] = the smallest pivot met.
+template <int B_>
+__global__ __launch_bounds__(64) void band_pd_kernel(const double *__restrict__ band, int np, int batch, const int *__restrict__ n,
+                                                     const double *__restrict__ kap_stamp, int *__restrict__ flag, double *__restrict__ minpiv)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= batch) return;
+    const double *bs = band + (long)s * (B_ + 1) * np;
+    const double kap = kap_stamp[s];
+    BandState<B_> h;
+    h.clear();
+    double D = 0.0, S = 0.0, mn = 1.0 / 0.0;
+    int bad = 0;
+    for (int i = 0; i < n[s]; i++) {
+        double bd[B_ + 1];
+#pragma unroll
+        for (int t = 0; t <= B_; t++) bd[t] = bs[(long)t * np + i];
+        band_row<B_, false>(h, bd, 0.0, kap, D, S);
+        mn = fmin(mn, h.dh[0]);
+        if (!(h.dh[0] > 0.0)) { bad = 1; mn = h.dh[0]; break; }
+    }
+    flag[s] = bad;
+    minpiv[s] = mn;
+}
+
+__global__ __launch_bounds__(64) void tri_pd_kernel(const double *__restrict__ dvec, const double *__restrict__ evec, int np, int batch,
+                                                    const int *__restrict__ n, const double *__restrict__ kap_stamp, int *__restrict__ flag,
+                                                    double *__restrict__ minpiv)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= batch) return;
+    const double *d = dvec + (long)s * np, *e = evec + (long)s * np;
+    const double kap = kap_stamp[s];
+    const int ns = n[s];
+    double mn = 1.0 / 0.0;
+    int bad = 0;
+    double delta = ns > 0 ? d[0] + kap : 1.0;
+    for (int i = 0; i < ns; i++) {
+        mn = fmin(mn, delta);
+        if (!(delta > 0.0)) { bad = 1; mn = delta; break; }
+        if (i + 1 < ns) delta = d[i + 1] + kap - e[i] * e[i] / delta;
+    }
+    flag[s] = bad;
+    minpiv[s] = mn;
+}
+
+// ---- the eigenbasis route (EigenKernel as the reference writes it), for the stamps the check above turns away ---------------
+// single kappa (lakernel.py:154-172): one wave per output pixel; S[a][i] = P[a][i] / (lam_i + kappa) (zero for i >= n), the maps
+// go to the stamp's own slot (map[f] = its index in the caller's batch)
+__global__ __launch_bounds__(256) void eigen_single_kernel(const double *__restrict__ lam, const double *__restrict__ P, int mp, int np, int m,
+                                                           const int *__restrict__ map, const int *__restrict__ n,
+                                                           const double *__restrict__ kap, const double *__restrict__ Cs,
+                                                           double *__restrict__ S, float *__restrict__ UC, float *__restrict__ Sigma,
+                                                           float *__restrict__ kappa)
+{
+    const int f = blockIdx.y, a = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (a >= mp) return;
+    const int s = map[f], ns = n[s];
+    const double k = kap[s], C = Cs[s];
+    const double *l = lam + (long)f * np, *p = P + ((long)f * mp + a) * np;
+    double *o = S + ((long)f * mp + a) * np;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < np; i += 64) {
+        double v = 0.0;
+        if (i < ns && a < m) {
+            const double li = l[i];
+            v = p[i] / (li + k);
+            s2 += v * v;
+            s1 += (li + 2.0 * k) * v * v;
+        }
+        o[i] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    if (lane == 0 && a < m) {
+        const long pa = (long)s * m + a;
+        kappa[pa] = (float)k;
+        Sigma[pa] = (float)s2;
+        UC[pa] = (float)(1.0 - s1 / C);
+    }
+}
+
+// multi kappa: float32 stores as the reference makes them (lakernel.py:216-222: kappa stored float32, THEN multiplied by C)
+__global__ void eigen_multi_store_kernel(const double *__restrict__ k64, const double *__restrict__ S64, const double *__restrict__ U64, int m,
+                                         double C, float *__restrict__ UC, float *__restrict__ Sigma, float *__restrict__ kappa)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    kappa[a] = (float)((double)(float)k64[a] * C);
+    Sigma[a] = (float)S64[a];
+    UC[a] = (float)U64[a];
+}
+
 // X [np][mp] float64 -> resident layout Tt [ldn][ldm] float32 (rows >= n[s], columns >= m zero)
 __global__ void tri_store_resident_kernel(const double *__restrict__ X, int np, int mp, int m, const int *__restrict__ n,
                                           float *__restrict__ Tt, int ldn, int ldm)
@@ -402,20 +504,109 @@ extern "C" int imcom_band_reduce(imcom_ctx *ctx, int batch, const int *n, int ld
     return IMCOM_OK;
 }
 
+static size_t eigen_fallback_bytes(int nf, int np, int mp, int m)
+{
+    size_t t = 0;
+    auto add = [&](size_t b) { t = align_up(t, 256) + b; };
+    add((size_t)nf * np * np * 8);       // A of the stamps, gathered
+    add((size_t)nf * np * 8);            // lam
+    add((size_t)nf * np * np * 8);       // Q
+    for (int q = 0; q < 3; q++) add((size_t)nf * np * mp * 8);  // b^T / x^T [np][mp], P [mp][np], S [mp][np]
+    add((size_t)nf * m * 8 * 3);         // kappa, Sigma, UC of lakernel1 (float64)
+    add((size_t)nf * 4);
+    return t + eigh_ws_bytes(nf, np, true) + 16384;
+}
+
+// The stamps `idx` of the batch through the eigendecomposition (see the head of the file).  Their x = T^T [np][mp] (float64) goes
+// to Xout + idx * np * mp (the layout every stamp's result has before the final store), their maps to the stamps' own slots.  The
+// workspace is taken from ctx->ws_used on and handed back; as many stamps at a time as it holds.
+static int eigen_fallback(imcom_ctx *ctx, const std::vector<int> &idx, const int *n, const int *n_dev, int ldn, int m, int np, int mp,
+                          const double *A_d, const double *Bt_res, const double *B_ref, const double *C, const double *kappaC, int nv,
+                          double ucmin, double smax, int nbis, const double *par, int batch, double *Xout, float *UC_d, float *Sig_d,
+                          float *kap_d)
+{
+    hipStream_t st = ctx->stream;
+    const size_t mark = ctx->ws_used, room = ctx->ws_bytes - std::min(ctx->ws_bytes, align_up(mark, 256));
+    int cap = (int)idx.size();
+    while (cap > 1 && eigen_fallback_bytes(cap, np, mp, m) > room) cap = (cap + 1) / 2;
+    if (eigen_fallback_bytes(cap, np, mp, m) > room) { set_error("internal: no workspace for the eigendecomposition of a stamp"); return IMCOM_ERR_NOMEM; }
+    const size_t mat = (size_t)np * np, big = (size_t)np * mp;
+    for (size_t f0 = 0; f0 < idx.size(); f0 += cap) {
+        const int nf = (int)std::min((size_t)cap, idx.size() - f0);
+        ctx->ws_used = mark;
+        double *Ag = (double *)ws_take(ctx, nf * mat * 8), *lam = (double *)ws_take(ctx, (size_t)nf * np * 8), *Q = (double *)ws_take(ctx, nf * mat * 8);
+        double *X = (double *)ws_take(ctx, nf * big * 8), *P = (double *)ws_take(ctx, nf * big * 8), *S = (double *)ws_take(ctx, nf * big * 8);
+        double *pix = (double *)ws_take(ctx, (size_t)nf * m * 8 * 3);
+        int *map = (int *)ws_take(ctx, (size_t)nf * 4);
+        if (!Ag || !lam || !Q || !X || !P || !S || !pix || !map) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+        std::vector<int> nsub(nf);
+        IMCOM_HIP_CHECK(hipMemsetAsync(Ag, 0, nf * mat * 8, st));
+        IMCOM_HIP_CHECK(hipMemsetAsync(Q, 0, nf * mat * 8, st));
+        IMCOM_HIP_CHECK(hipMemsetAsync(lam, 0, (size_t)nf * np * 8, st));
+        for (int f = 0; f < nf; f++) {
+            const int s = idx[f0 + f];
+            nsub[f] = n[s];
+            IMCOM_HIP_CHECK(hipMemcpy2DAsync(Ag + f * mat, (size_t)np * 8, A_d + (size_t)s * ldn * ldn, (size_t)ldn * 8, (size_t)n[s] * 8, (size_t)n[s],
+                                             hipMemcpyDeviceToDevice, st));
+            if (Bt_res) IMCOM_HIP_CHECK(hipMemcpyAsync(X + f * big, Bt_res + (size_t)s * big, big * 8, hipMemcpyDeviceToDevice, st));
+            else {
+                hipLaunchKernelGGL(tri_pack_kernel, dim3(mp / 32, np / 32, 1), dim3(256), 0, st, B_ref + (size_t)s * m * ldn, (long)ldn, m, n_dev + s,
+                                   X + f * big, np, mp);
+                IMCOM_TRY(check_launch("tri_pack_kernel"));
+            }
+        }
+        IMCOM_TRY(upload(ctx, map, &idx[f0], (size_t)nf));
+        IMCOM_TRY(eigh_device(ctx, nf, nsub.data(), np, Ag, np, (long)mat, lam, np, Q, np, (long)mat, nullptr));
+        {   // P [mp][np] = b Q  (b^T = X is input-pixel-major: the k-major A operand)
+            ProfScope ps(ctx, "eigen_gemm");
+            IMCOM_TRY(launch_gemm(ctx, true, true, mp, np, np, nf, X, mp, (long)big, Q, np, (long)mat, P, np, (long)big, 1.0, 0.0));
+        }
+        {
+            ProfScope ps(ctx, "lakernel1");
+            if (nv == 1) {
+                hipLaunchKernelGGL(eigen_single_kernel, dim3(mp / 4, nf), dim3(256), 0, st, lam, P, mp, np, m, map, n_dev, par + batch, par, S, UC_d, Sig_d, kap_d);
+                IMCOM_TRY(check_launch("eigen_single_kernel"));
+            } else {
+                IMCOM_HIP_CHECK(hipMemsetAsync(S, 0, nf * big * 8, st));
+                for (int f = 0; f < nf; f++) {
+                    const int s = idx[f0 + f];
+                    double *k64 = pix + (size_t)f * m * 3, *S64 = k64 + m, *U64 = S64 + m;
+                    IMCOM_TRY(launch_lakernel1(ctx, lam + (size_t)f * np, P + f * big, m, n[s], np, C[s], ucmin, kappaC[0] * C[s], kappaC[nv - 1] * C[s], nbis,
+                                               k64, S64, U64, S + f * big, np, smax));
+                    hipLaunchKernelGGL(eigen_multi_store_kernel, dim3((m + 255) / 256), dim3(256), 0, st, k64, S64, U64, m, C[s], UC_d + (size_t)s * m,
+                                       Sig_d + (size_t)s * m, kap_d + (size_t)s * m);
+                }
+                IMCOM_TRY(check_launch("eigen_multi_store_kernel"));
+            }
+        }
+        {   // x [np][mp] = Q S^T
+            ProfScope ps(ctx, "eigen_gemm");
+            IMCOM_TRY(launch_gemm(ctx, false, false, np, mp, np, nf, Q, np, (long)mat, S, np, (long)big, X, mp, (long)big, 1.0, 0.0));
+        }
+        for (int f = 0; f < nf; f++)
+            IMCOM_HIP_CHECK(hipMemcpyAsync(Xout + (size_t)idx[f0 + f] * big, X + f * big, big * 8, hipMemcpyDeviceToDevice, st));
+    }
+    ctx->ws_used = mark;
+    return IMCOM_OK;
+}
+
 // Shared body of the two entries.  Bt_res: -B/2 in the resident layout [np][mp] (then Tt_res [np][mp] float32 is the output);
 // else B_ref [m][ldn] and T_ref [m][ldn] in the reference's layout.
 static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, int np, int mp, const double *A_d, const double *Bt_res,
                             const double *B_ref, const double *C, const double *kappaC, int nv, double ucmin, double smax, int nbis,
-                            float *Tt_res, float *T_ref, float *UC_d, float *Sig_d, float *kap_d, int nmax)
+                            float *Tt_res, float *T_ref, float *UC_d, float *Sig_d, float *kap_d, int nmax, int *info)
 {
     const size_t big = (size_t)batch * np * mp * 8, szM = (size_t)batch * m;
     TrdBasis tb;
     const bool banded = eigen_uses_band(np);
-    // buffers that outlive the reduction first (its scratch is handed back afterwards and must not lie under them)
-    double *Cb = (double *)ws_take(ctx, big), *Lb = (double *)ws_take(ctx, banded ? big * BAND_BW : big);
-    double *kpix = (double *)ws_take(ctx, szM * 8), *par = (double *)ws_take(ctx, (size_t)batch * 8 * 4);
-    int *n_early = (int *)ws_take(ctx, (size_t)batch * 4);
-    if (!Cb || !Lb || !kpix || !par || !n_early) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    // buffers that outlive everything first; from `keep` on the workspace belongs to the basis (whose own scratch is handed back
+    // after the reduction) and, once the band path has finished, to the eigenbasis route of the stamps that failed the check
+    double *Cb = (double *)ws_take(ctx, big);
+    double *kpix = (double *)ws_take(ctx, szM * 8), *par = (double *)ws_take(ctx, (size_t)batch * 8 * 5);
+    int *n_early = (int *)ws_take(ctx, (size_t)batch * 4), *flag = (int *)ws_take(ctx, (size_t)batch * 4);
+    const size_t keep = ctx->ws_used;
+    double *Lb = (double *)ws_take(ctx, banded ? big * BAND_BW : big);
+    if (!Cb || !Lb || !kpix || !par || !n_early || !flag) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     std::vector<double> ph(4 * (size_t)batch);
     for (int s = 0; s < batch; s++) {
         ph[s] = C[s];
@@ -470,6 +661,15 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
         if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Qh^T b
     }
+    // is A + kappa_min I positive definite?  (par + batch = the lowest kappa of the call; the answer is read after the search has
+    // been queued, so the host's wait hides behind it)
+    std::vector<int> flagged;
+    std::vector<int> flag_h(batch, 0);
+    if (nmax > 0) {
+        if (banded) hipLaunchKernelGGL(band_pd_kernel<BAND_BW>, dim3((batch + 63) / 64), dim3(64), 0, st, tb.band, np, batch, n_early, par + batch, flag, par + 4 * batch);
+        else hipLaunchKernelGGL(tri_pd_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, tb.dvec, tb.evec, np, batch, n_early, par + batch, flag, par + 4 * batch);
+        IMCOM_TRY(check_launch("pd_check"));
+    }
     {
         ProfScope ps(ctx, "lakernel1");
         if (banded) {
@@ -493,11 +693,23 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         }
     }
     if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, false));  // x = Qh y
+    if (nmax > 0) {
+        IMCOM_HIP_CHECK(hipMemcpyAsync(flag_h.data(), flag, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(st));
+        for (int s = 0; s < batch; s++)
+            if (flag_h[s]) { flagged.push_back(s); info[s] = 1; }
+    }
+    if (!flagged.empty()) {
+        // the band path's buffers are dead now (same stream: everything queued so far runs before whatever reuses them)
+        ctx->ws_used = keep;
+        IMCOM_TRY(eigen_fallback(ctx, flagged, n, n_early, ldn, m, np, mp, A_d, Bt_res, B_ref, C, kappaC, nv, ucmin, smax, nbis, par, batch, Cb, UC_d, Sig_d,
+                                 kap_d));
+    }
     if (Tt_res) {
-        hipLaunchKernelGGL(tri_store_resident_kernel, dim3((mp + 255) / 256, np, batch), dim3(256), 0, st, Cb, np, mp, m, tb.n_dev, Tt_res, np, mp);
+        hipLaunchKernelGGL(tri_store_resident_kernel, dim3((mp + 255) / 256, np, batch), dim3(256), 0, st, Cb, np, mp, m, n_early, Tt_res, np, mp);
         IMCOM_TRY(check_launch("tri_store_resident_kernel"));
     } else if (ldn > 0) {
-        hipLaunchKernelGGL(tri_store_ref_kernel, dim3(mp / 32, (unsigned)((ldn + 31) / 32), batch), dim3(256), 0, st, Cb, np, mp, m, tb.n_dev, T_ref, (long)ldn);
+        hipLaunchKernelGGL(tri_store_ref_kernel, dim3(mp / 32, (unsigned)((ldn + 31) / 32), batch), dim3(256), 0, st, Cb, np, mp, m, n_early, T_ref, (long)ldn);
         IMCOM_TRY(check_launch("tri_store_ref_kernel"));
     }
     return IMCOM_OK;
@@ -506,8 +718,10 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
 static size_t solve_eigen_ws(int batch, int np, int mp, int m)
 {
     const bool banded = eigen_uses_band(np);
-    return (banded ? band_basis_ws_bytes(batch, np, mp) : trd_basis_ws_bytes(batch, np, mp)) + (size_t)(banded ? 1 + BAND_BW : 2) * batch * np * mp * 8 +
-           (size_t)batch * m * 8 + (size_t)batch * 64 + 65536;
+    const size_t big = (size_t)batch * np * mp * 8;
+    const size_t basis = (banded ? band_basis_ws_bytes(batch, np, mp) : trd_basis_ws_bytes(batch, np, mp)) + (size_t)(banded ? BAND_BW : 1) * big;
+    // what stays (c -> y -> x, kappa per pixel, parameters) + the larger of the basis route and ONE stamp's eigendecomposition
+    return big + (size_t)batch * m * 8 + (size_t)batch * 64 + std::max(basis, eigen_fallback_bytes(1, np, mp, m)) + 65536;
 }
 
 extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A, const double *mBhalf,
@@ -545,7 +759,7 @@ extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ld
         B_d = tb;
     }
     IMCOM_TRY(solve_eigen_core(ctx, batch, n, ldn, m, np, mp, A_d, nullptr, B_d, C, kappaC, nv, ucmin, smax, nbis, nullptr, T_d, UC_d, Sig_d,
-                               kap_d, nmax));
+                               kap_d, nmax, info));
     if (host) {
         if (szB) IMCOM_HIP_CHECK(hipMemcpyAsync(T, T_d, szB * 4, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipMemcpyAsync(UC, UC_d, szM * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -570,5 +784,5 @@ extern "C" int imcom_solve_eigen_resident(imcom_ctx *ctx, int batch, const int *
         info[s] = 0;
     }
     IMCOM_TRY(ws_reserve(ctx, solve_eigen_ws(batch, ldn, ldm, m)));
-    return solve_eigen_core(ctx, batch, n, ldn, m, ldn, ldm, A, Bt, nullptr, C, kappaC, nv, ucmin, smax, nbis, Tt, nullptr, UC, Sigma, kappa, nmax);
+    return solve_eigen_core(ctx, batch, n, ldn, m, ldn, ldm, A, Bt, nullptr, C, kappaC, nv, ucmin, smax, nbis, Tt, nullptr, UC, Sigma, kappa, nmax, info);
 }

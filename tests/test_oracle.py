@@ -102,6 +102,34 @@ def test_la_kernels(golden, name, kind, sysn, kC, uct, smax, n2f):
     assert np.allclose(kappa, g[f"{name}_kappa"], rtol=1e-6, atol=0)
 
 
+def indef_case(golden, name):
+    """Inputs of tests/golden/eigen_indef.npz: the existing fixtures' systems minus shift * I (make_golden_eigen_indef.py)."""
+    g = golden("eigen_indef")
+    if name == "chain":
+        ch = golden("stamp_chain_mid")
+        A, mB, C, n2f = ch["A"], ch["mBhalf"], ch["C"], 14
+    else:
+        la = golden("lakernel")
+        A, mB, C, n2f = (la["repair_A"], la["cos_mBhalf"], np.atleast_1d(la["cos_C"]), 4) if name == "repair" else (la["gau_A"], la["gau_mBhalf"], la["gau_C"], 9)
+    return g, A - float(g[f"{name}_shift"]) * np.identity(A.shape[0]), mB, C, n2f
+
+
+@pytest.mark.parametrize("name", ["repair", "gau", "chain"])
+@pytest.mark.parametrize("tag", ["eig1", "eigm"])
+def test_eigen_kernel_on_indefinite_matrices(golden, name, tag):
+    """EigenKernel on A with eigenvalues below -kappa (lakernel.py:154-223 divides by lam + kappa whatever its sign): the
+    oracle against outputs of the reference itself -- a 6 x 6 known system, a Gaussian one with two target PSFs, and a real
+    PSF-overlap matrix (N = 220) with 133 of its eigenvalues negative."""
+    g, A, mB, C, n2f = indef_case(golden, name)
+    kC = g[f"{name}_{tag}_kappaC"]
+    assert np.linalg.eigvalsh(A)[0] + kC[0] * C.min() < 0
+    T, UC, Sigma, kappa = orc.la_kernel("Eigen", A, mB, C, n2f, kC, float(g[f"{name}_uctarget"]), float(g[f"{name}_sigmamax"]))
+    ref = {k: g[f"{name}_{tag}_{k}"] for k in ("T", "UC", "Sigma", "kappa")}
+    assert np.abs(T - ref["T"]).max() <= 2e-6 * np.abs(ref["T"]).max()
+    assert np.allclose(UC, ref["UC"], rtol=2e-5, atol=1e-9) and np.allclose(Sigma, ref["Sigma"], rtol=2e-5, atol=1e-9)
+    assert np.allclose(kappa, ref["kappa"], rtol=1e-6, atol=0)
+
+
 def test_la_known_answers(golden):
     """The range assertions of tests/pyimcom/test_la.py:92-99 and 153-160 on the oracle's outputs."""
     A, mB, C = cosine_system()
