@@ -95,7 +95,80 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
     }
     if done1:
         out["one_thread"] = {"value": done1 / dt1, "unit": "postage-stamps/s", "cores": 1, "stage_ms_per_stamp": stages1}
+    out["processes"] = cpu_processes(cfg.name, cores, budget_s * 0.5)
     return out
+
+
+def cpu_worker(cfg_name, budget_s):
+    """One single-threaded oracle process of cpu_processes(): whole stamps of the workload for `budget_s` seconds -> one JSON line."""
+    import numpy as np
+
+    from oracle import oracle as orc
+    from pyimcom_amd import synth
+
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limit = threadpool_limits(limits=1)
+    except ImportError:  # pragma: no cover
+        limit = None
+    orc.set_threads(1)
+    cfg = synth.CONFIGS[cfg_name]
+    first = int(os.environ.get("IMCOM_CPU_WORKER_FIRST", "0"))
+    E = cfg.n_expo if isinstance(cfg.n_expo, int) else cfg.n_expo[1]
+    psfs, target = synth.make_psfs(cfg, E)
+    g, tabs, C = orc.stamp_tables(cfg, psfs, target)
+    tri = lambda i, j: (2 * E - i + 1) * i // 2 + j - i
+    tab = np.array([[tri(a, b) if a <= b else (tri(b, a) | (1 << 30)) for b in range(E)] for a in range(E)], dtype=np.int32)
+    pen = np.array([[-cfg.flat_penalty / E + (cfg.flat_penalty if a == b else 0.0) for b in range(E)] for a in range(E)])
+    io = np.arange(E) + E * (E + 1) // 2
+    print("ready", flush=True)
+    sys.stdin.readline()  # every worker starts its clock at the parent's signal
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        orc.stamp_full(cfg, g, tabs, float(C[0]), synth.make_stamp(cfg, first + done), tab, pen, io)
+        done += 1
+    print(json.dumps({"done": done, "seconds": time.perf_counter() - t0}), flush=True)
+    del limit
+    return 0
+
+
+def cpu_processes(cfg_name, cores, budget_s):
+    """The reference's own way of using a many-core host is one process per block (docs/run_README.rst:81-100): P single-threaded
+    oracle processes side by side, each coadding whole stamps for `budget_s` seconds (started as child processes; tables are built
+    before the clock starts).  P = half the logical cores, at most 64 (memory: ~0.4 GB per process at cfg-2)."""
+    import subprocess
+
+    P = max(1, min(64, cores // 2))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = []
+    for k in range(P):
+        e = dict(env, IMCOM_CPU_WORKER_FIRST=str(1000 * k))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--config", cfg_name, "--cpu-worker", str(budget_s)], env=e, cwd=ROOT,
+                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+    try:
+        for p_ in procs:
+            assert p_.stdout.readline().strip() == "ready"
+        t0 = time.perf_counter()
+        for p_ in procs:
+            p_.stdin.write("go\n")
+            p_.stdin.flush()
+        res = [json.loads(p_.stdout.readline()) for p_ in procs]
+        wall = time.perf_counter() - t0
+    except Exception as exc:  # a worker that died: report, do not fail the bench line
+        for p_ in procs:
+            p_.kill()
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        for p_ in procs:
+            try:
+                p_.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+    done = sum(r["done"] for r in res)
+    return {"value": done / wall, "unit": "postage-stamps/s", "processes": P, "threads_per_process": 1, "cores": P,
+            "sample": f"{done} whole {cfg_name} stamps by {P} single-threaded oracle processes in {wall:.1f} s (one process per block is how the reference "
+                      "uses a many-core host)"}
 
 
 def pmc_traffic(batch, cfg_name):
@@ -119,7 +192,7 @@ def pmc_traffic(batch, cfg_name):
     return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
 
 
-def block_workload(dev, n1P, identical=False, seed=5):
+def block_workload(dev, n1P, identical=False, seed=5, config="cfg2"):
     """Synthetic block at cfg-2 geometry for the block leg (and for tests/test_gpu_bigblock.py's check of it): the InStamp
     pool of (n1P + 2)^2 InStamps, and per 2 x 2 group of InStamps PSF images [E, ns + 16, ns + 16] (a smooth modulation of the
     analytic PSFs, zero padded; ``identical``: the same images for every group) with their sampling positions yxco [E, 2, ns, ns]
@@ -130,7 +203,7 @@ def block_workload(dev, n1P, identical=False, seed=5):
     from pyimcom_amd import synth
     from pyimcom_amd.select import InStampPool
 
-    cfg = synth.CONFIGS["cfg2"]
+    cfg = synth.CONFIGS[config]
     E = cfg.n_expo
     inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng(seed))
     pool = InStampPool(inst, cfg.n_inframe, device=dev)
@@ -161,23 +234,25 @@ def block_workload(dev, n1P, identical=False, seed=5):
     return cfg, inst, pool, psfs, target, groups, counts, img_all, yxco_all
 
 
-def block_leg(ctx, dev, n1P=48, reps=1):
+def block_leg(ctx, dev, n1P=48, reps=3, config="cfg2", warm=16):
     """The same path one level up, as a block of the reference runs it (coadd.py:2003-2084): cfg-2 geometry, ONE block of
     n1P x n1P = 48 x 48 output stamps ("one block = 48 x 48 stamps") whose PSFs change from one 2 x 2 group of
     InStamps to the next (SysMatA.ji_st2psf, psfutil.py:1803-1824: 625 groups, ~100 k overlap tables), and everything the
     headline loop leaves out inside the timed region: the batch plan (2-D tiles of cells against the table arena), PSF sampling
     onto the PSFGrp grid (PSFGrp._sample_psf + normalisation, psfutil.py:709-795, 650-656), spectra and overlap tables per group
     (self / cross / input-output sets, least recently used sets replaced), pixel selection from the InStamp pool, per-stamp pair
-    maps, A, B, Cholesky, coaddition, block-map accumulation and boundary recovery.  Outside: the upload of the InStamp pool, of
-    the PSF images and of their sampling positions, and the allocation of the two arenas (tables, spectra), which a block
-    driver keeps from block to block (BlockTables.reset)."""
+    maps, A, B, the LA kernel of the configuration, coaddition, block-map accumulation and boundary recovery.  Outside: the upload
+    of the InStamp pool, of the PSF images and of their sampling positions, and the allocation of the two arenas (tables,
+    spectra), which a block driver keeps from block to block (BlockTables.reset).  ``reps`` timed blocks: the MEDIAN is reported
+    (all of them listed).  ``config="cfg3"``: BASELINE configs[2] "batched across one block" -- the Eigen kernel with its kappa sweep."""
+    import numpy as np
     import torch
 
     from pyimcom_amd import psfs as psfmod
     from pyimcom_amd.blockrun import coadd_block, plan_block
     from pyimcom_amd.stamps import BlockTables
 
-    cfg, inst, pool, psfs, target, groups, counts, img_all, yxco_all = block_workload(dev, n1P)
+    cfg, inst, pool, psfs, target, groups, counts, img_all, yxco_all = block_workload(dev, n1P, config=config)
     E, ns = cfg.n_expo, psfs.shape[-1]
     order = {k: q for q, k in enumerate(groups)}
 
@@ -191,7 +266,8 @@ def block_leg(ctx, dev, n1P=48, reps=1):
             im, yx = img_all[idx], yxco_all[idx]
         return psfmod.sample_psf(im.reshape(-1, ns + 16, ns + 16), ns, yx.reshape(-1, 2, ns, ns), psf_norm=True, ctx=ctx)
 
-    fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize", "epilogue", "block_acc")
+    fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize",
+            "eigen_trd", "eigen_applyq", "lakernel1", "eigen_gemm", "epilogue", "block_acc")
     tabs = BlockTables(groups, target, cfg.nfft, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True)
 
     def one():
@@ -199,28 +275,116 @@ def block_leg(ctx, dev, n1P=48, reps=1):
         return coadd_block(cfg, pool, tabs, n1P, E)
 
     # warm-up on a corner of the block (kernels loaded, workspaces grown), then the timed block(s)
-    coadd_block(cfg, pool, tabs, n1P, E, stamps=[(j, i) for j in range(1, 17) for i in range(1, 17)])
+    w = min(warm, n1P)
+    coadd_block(cfg, pool, tabs, n1P, E, stamps=[(j, i) for j in range(1, w + 1) for i in range(1, w + 1)])
     torch.cuda.synchronize()
     ctx.profile_enable(True)
-    ctx.profile_reset()
-    t0 = time.perf_counter()
+    runs = []
     for _ in range(reps):
+        ctx.profile_reset()
+        t0 = time.perf_counter()
         maps = one()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    stages = {f: ctx.profile_get(f)[0] / reps for f in fams}
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        runs.append((dt, {f: ctx.profile_get(f)[0] for f in fams}))
     ctx.profile_enable(False)
+    dt, stages = sorted(runs, key=lambda r: r[0])[len(runs) // 2]
+    stages = {f: v for f, v in stages.items() if v > 0}
     chunks = plan_block(cfg, pool, tabs, n1P)
     return {
-        "value": n1P * n1P / dt, "unit": "postage-stamps/s", "ms_per_block": dt * 1e3, "stamps_per_block": n1P * n1P, "psf_groups": len(groups),
+        "value": n1P * n1P / dt, "unit": "postage-stamps/s", "ms_per_block": dt * 1e3, "ms_per_stamp": dt * 1e3 / (n1P * n1P), "stamps_per_block": n1P * n1P,
+        "reps": reps, "ms_per_block_all_reps": [r[0] * 1e3 for r in runs], "psf_groups": len(groups), "kernel": cfg.kernel,
         "batches": [len(c) for c in chunks], "input_pixels": int(pool.npool),
         "tables": {"computed": int(tabs.computed_tables), "block_total": int(tabs.block_demand()), "arena": int(tabs.capacity),
                    "evicted": int(tabs.evicted_tables), "spectra_resets": int(tabs.spectra_resets)},
-        "workload": f"cfg2 geometry, block of {n1P}x{n1P} output stamps, PSF group per 2x2 InStamps; batch plan + PSF sampling + tables + selection + "
-                    "pair maps + A, B, Cholesky, coaddition + block maps inside the timed region",
+        "workload": f"{config} geometry ({E} exposures, {cfg.kernel}), block of {n1P}x{n1P} output stamps, PSF group per 2x2 InStamps; batch plan + PSF sampling + "
+                    "tables + selection + pair maps + A, B, LA kernel, coaddition + block maps inside the timed region; median of the timed blocks",
         "stage_ms_per_block": stages, "host_and_gaps_ms_per_block": dt * 1e3 - sum(stages.values()),
         "out_map_rms": float(maps.out_map.square().mean().sqrt()),
     }
+
+
+def config_legs(ctx, dev, which=("cfg1", "cfg4", "cfg5", "cfg3")):
+    """The other BASELINE configurations on the same clock as the headline, each with its own roofline:
+    compact legs, inputs resident, one warm-up step and a few timed ones.  cfg-1 / 4 / 5 are the Cholesky path (roofline: the
+    solve family, algorithmic 2 N^2 m per stamp over the HIP-event time of its launches); cfg-3 is the Eigen path with its
+    three-node kappa sweep at batch 32 and 256 (roofline: the path's OWN count 4 N^3 / 3 + 4 N^2 m -- reduction + the two
+    applications of the reflectors -- over the time of reduction + applications + search; and the HBM roofline of its one
+    bandwidth-bound kernel, symv4: N^3 / 3 bytes of trailing triangle per stamp over the HIP-event time of those launches,
+    taken in a second pass because the events sit between 737 dependent launches)."""
+    import numpy as np
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    plan = {"cfg1": [(256, 5)], "cfg4": [(256, 3)], "cfg5": [(170, 1)], "cfg3": [(32, 2), (256, 1)]}
+    out = {}
+    for name in which:
+        cfg = synth.CONFIGS[name]
+        legs = {}
+        for nb, steps in plan[name]:
+            stamps = sorted((synth.make_stamp(cfg, i) for i in range(nb)), key=lambda st: -st.n)  # deepest first (cfg-4 is ragged)
+            psfs, target = synth.make_psfs(cfg, max(s.n_expo for s in stamps))
+            tables = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=dev)
+            b = StampBatch(cfg, stamps, tables, ctx=ctx, device=dev)
+            b.run()
+            torch.cuda.synchronize()
+            ctx.profile_enable(True)
+            ctx.profile_reset()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                b.run()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            fam_names = ("solve_gemm", "chol_gemm", "chol_diag", "build_A", "build_B", "finalize", "eigen_trd", "eigen_applyq", "lakernel1", "eigen_gemm", "epilogue")
+            fams = {f: ctx.profile_get(f) for f in fam_names}
+            n = b.n.astype(np.float64)
+            leg = {"value": nb / dt, "unit": "postage-stamps/s", "ms_per_stamp": dt / nb * 1e3, "ms_per_step": dt * 1e3, "batch": nb, "steps": steps,
+                   "N_mean": float(n.mean()), "N_max": int(n.max()), "m": cfg.m, "kernel": cfg.kernel, "kappaC": list(cfg.kappaC),
+                   "n_expo": list(cfg.n_expo) if isinstance(cfg.n_expo, tuple) else cfg.n_expo,
+                   "stage_ms_per_step": {k: v[0] / steps for k, v in fams.items() if v[0] > 0}, "info_nonzero": int((b.info != 0).sum())}
+            if cfg.kernel == "Cholesky":
+                flops = float((2.0 * cfg.m * n**2).sum())
+                ms, launches = fams["solve_gemm"]
+                ach = flops * steps / (ms * 1e-3) / 1e12
+                leg["roofline"] = {"kernel": "solve_fwd_kernel+solve_bwd_kernel", "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / FP64_MFMA_PEAK_TFLOPS, "flops_per_launch": flops * steps / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
+                                   "launches": launches, "traffic": None}
+                job = float((n**3 / 3.0 + 2.0 * cfg.m * n**2 + 165.0 * n * (n + 1) + 220.0 * n * cfg.m).sum())
+            else:
+                flops = float((4.0 * n**3 / 3.0 + 4.0 * n**2 * cfg.m).sum())
+                ms = sum(fams[k][0] for k in ("eigen_trd", "eigen_applyq", "lakernel1"))
+                ach = flops * steps / (ms * 1e-3) / 1e12
+                leg["roofline"] = {"kernel": "Eigen solve: band reduction (symv4 / band_step / band_apply / syr2k) + reflector GEMMs + kappa search", "bound": "mfma",
+                                   "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                                   "flops_per_stamp": flops / nb, "count": "4 N^3 / 3 + 4 N^2 m (the path's own; SURVEY 8d's 9 N^3 + 4 N^2 m would read "
+                                   f"{(9.0 * n**3 + 4.0 * n**2 * cfg.m).sum() * steps / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS:.2f})", "traffic": None}
+                job = flops + float((165.0 * n * (n + 1) + 220.0 * n * cfg.m).sum())
+                # second pass with HIP events around every symv4 launch (profile level 2)
+                ctx.profile_enable(2)
+                ctx.profile_reset()
+                b.solve()
+                torch.cuda.synchronize()
+                ms4, l4 = ctx.profile_get("symv4")
+                trd2 = ctx.profile_get("eigen_trd")[0]
+                if l4:
+                    nbytes = float((n**3 / 3.0).sum())  # sum over the groups of four columns of the trailing lower triangle, 8 B per entry
+                    leg["roofline_hbm"] = {"kernel": "symv4_kernel", "bound": "hbm", "achieved": nbytes / (ms4 * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                           "frac": nbytes / (ms4 * 1e-3) / 8e12, "bytes_per_launch": nbytes / l4, "avg_launch_ms": ms4 / l4, "launches": l4,
+                                           "ms_per_step": ms4, "reduction_ms_in_this_pass": trd2, "traffic": None,
+                                           "note": "algorithmic bytes N^3/3 per stamp; HIP events around each launch, taken in a separate pass"}
+            leg["job_roofline_frac"] = job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS
+            ctx.profile_enable(False)
+            legs[f"b{nb}"] = leg
+            del b, tables
+            torch.cuda.empty_cache()
+        out[name] = legs[next(iter(legs))] if len(legs) == 1 else legs
+        if len(legs) > 1:  # the headline of a configuration with several batches: the larger one
+            big = legs[f"b{max(nb for nb, _ in plan[name])}"]
+            out[name] = dict(legs, value=big["value"], unit=big["unit"], ms_per_stamp=big["ms_per_stamp"], roofline=big["roofline"])
+        out[name]["config"] = f"BASELINE configs[{CONFIG_INDEX[name]}]"
+    return out
 
 
 def seam_legs(ctx, dev, cfg, batch):
@@ -312,12 +476,17 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="stamps per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block", action="store_true", help="skip the block-level leg (tables + selection + stamps + block maps)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the legs of the other BASELINE configurations (cfg-1, 3, 4, 5; Eigen block)")
+    ap.add_argument("--block-reps", type=int, default=3, help="timed blocks of the block leg (the median is reported)")
+    ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)  # one single-threaded oracle process (cpu_baseline's P-process figure)
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--ldn", type=int, default=None, help="leading dimension of A / L / -B/2 (experiments; default: N rounded up to 128)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal of the multi-rank path on a box with ONE GPU: every rank uses cuda:0 and the ranks "
                          "rendezvous over gloo (not a measurement)")
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        return cpu_worker(args.config, args.cpu_worker)
 
     import numpy as np
     import torch
@@ -378,10 +547,24 @@ def main():
     fams = {f: ctx.profile_get(f) for f in ("solve_gemm", "solve_dinv", "chol_gemm", "chol_diag", "build_A", "build_B",
                                             "finalize", "epilogue")}
     ctx.profile_enable(False)
+    ranks_seen, per_rank = 1, [args.batch * args.steps / elapsed]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_shared_gpu else dev)
+        cdev = "cpu" if args.rehearse_shared_gpu else dev
+        mine = elapsed
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # proof that the collective library saw N ranks (the JSON's n_gpus is not just WORLD_SIZE from the environment), and every
+        # rank's own rate (its own clock around the same K steps)
+        one = torch.ones(1, dtype=torch.float64, device=cdev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
+        rates = torch.zeros(world, dtype=torch.float64, device=cdev)
+        rates[rank] = args.batch * args.steps / mine
+        dist.all_reduce(rates, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in rates.cpu()]
+        if ranks_seen != world:
+            raise SystemExit(f"the all-reduce saw {ranks_seen} ranks, WORLD_SIZE says {world}")
 
     if rank == 0:
         n_arr = batch.n.astype(np.float64)
@@ -402,6 +585,8 @@ def main():
             "value": world * args.batch * args.steps / elapsed,
             "unit": "postage-stamps/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,  # all_reduce(SUM) of ones over the process group
+            "per_rank_value": per_rank,  # each rank's own stamps/s over its own clock; `value` uses the slowest rank's time
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -440,7 +625,18 @@ def main():
             out.update(seam_legs(ctx, dev, cfg, batch))
             del batch
             torch.cuda.empty_cache()
-            out["block"] = block_leg(ctx, dev)
+            out["block"] = block_leg(ctx, dev, reps=args.block_reps)
+        if not args.no_configs and world == 1 and args.config == "cfg2":
+            batch = None
+            torch.cuda.empty_cache()
+            from pyimcom_amd.blockrun import release_buffers
+
+            release_buffers()
+            out["configs"] = config_legs(ctx, dev)
+            out["configs"]["cfg2"] = {"config": "BASELINE configs[1]", "value": out["value"], "unit": out["unit"], "ms_per_stamp": out["ms_per_stamp"],
+                                      "roofline": {k: out["roofline"][k] for k in ("kernel", "achieved", "peak", "frac")}, "see": "the top level of this line"}
+            # BASELINE configs[2] "batched across one block": the Eigen kernel with its kappa sweep through coadd_block, PSF group per 2 x 2 InStamps
+            out["eigen_block"] = block_leg(ctx, dev, n1P=16, reps=1, config="cfg3", warm=8)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = cpu_baseline(cfg, cpu_sample, psfs, target, args.cpu_budget)
         print(json.dumps(out))
@@ -450,4 +646,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())

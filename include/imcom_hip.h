@@ -66,7 +66,7 @@ int imcom_ctx_workspace_bytes(imcom_ctx *ctx, size_t *bytes);
  * HIP events on the context's stream when profiling is enabled (bench.py's roofline leg).
  * family: "solve_gemm", "chol_gemm", "chol_diag", "build_A", "build_B", "finalize", "epilogue",
  *         "eigen", "lakernel1", ... ; launches receives the number of launches accumulated. */
-int imcom_ctx_profile_enable(imcom_ctx *ctx, int on);
+int imcom_ctx_profile_enable(imcom_ctx *ctx, int on); /* on = 2: also per-launch scopes inside long stages ("symv4": the band reduction's pass over the trailing matrix) */
 int imcom_ctx_profile_reset(imcom_ctx *ctx);
 int imcom_ctx_profile_get(imcom_ctx *ctx, const char *family, double *ms, long *launches);
 /* Diagnostic for the roofline: keeps the fp64 MFMA pipe of every SIMD busy -- and nothing else: no LDS, no memory, no
@@ -150,6 +150,9 @@ int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, c
                       const double *mBhalf, const double *C, const double *kappaC, int nv,
                       double ucmin, double smax, int nbis, float *T, float *UC, float *Sigma,
                       float *kappa, int *info, int memspace);
+/* Bytes of device workspace imcom_solve_eigen_resident takes for `batch` stamps of these leading dimensions (a planner adds
+ * them to its own buffers: pyimcom_amd.blockrun.stamp_bytes).  Pure arithmetic: no context, no device call. */
+int imcom_solve_eigen_workspace(int batch, int ldn, int ldm, int m, size_t *bytes);
 /* Householder reduction of symmetric matrices to band form, the basis the Eigen kernel's kappa search works in
  * (numpy.linalg.eigh at lakernel.py:162, 201 is not needed for it: DESIGN.md "Eigen path"): A = Q B Q^T, B[i][j] = 0 for
  * |i - j| > 4, Q = H_0 H_1 ... with H_r = I - tau_r v_r v_r^T, v_r zero above its pivot row r + 4 (v_r[r+4] = 1).

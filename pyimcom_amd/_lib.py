@@ -96,6 +96,7 @@ SIGNATURES = {
     "imcom_psf_overlap_spectra_win": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "imcom_psf_overlap_spectra_slots": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
+    "imcom_solve_eigen_workspace": [_i, _i, _i, _i, _vp],
     "imcom_block_place": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
     "imcom_block_combine": [_vp, _i, _i, _i, _l, _vp, _i, _vp, _i],
     "imcom_compress_map_f32": [_vp, _vp, _l, _i, _i, _vp],
@@ -171,7 +172,8 @@ class Context:
         return b.value
 
     def profile_enable(self, on=True):
-        check(lib.imcom_ctx_profile_enable(self.handle, 1 if on else 0))
+        """on = 2: also the per-launch scopes inside long stages (the band reduction's "symv4")."""
+        check(lib.imcom_ctx_profile_enable(self.handle, int(on)))
 
     def profile_reset(self):
         check(lib.imcom_ctx_profile_reset(self.handle))

@@ -184,8 +184,14 @@ def stamp_bytes(ldn, ldm, n_out=1, kernel="Cholesky", resident=2):
     if kernel == "Cholesky":
         return resident * base + 8 * (ldn * ldn + n_out * ldn * ldm + ldn * NB)  # L, Y, inverted diagonal blocks
     extra = 12 * ldm * ldn  # -B/2 (f64) and T (f32) in the reference's [m][N] layout
-    if kernel == "Eigen":
-        return resident * base + extra + 8 * (4 * ldn * ldn + 2 * ldm * ldn) + (1 << 22)  # working copy, V, X, Q; the two padded m x N operands
+    if kernel == "Eigen":  # the resident entry works on the StampBatch layouts themselves: no copies; its workspace by the library's own count
+        import ctypes
+
+        from ._lib import check, lib
+
+        nb, ws = 32, ctypes.c_size_t(0)
+        check(lib.imcom_solve_eigen_workspace(nb, int(ldn), int(ldm), int(ldm), ctypes.byref(ws)))
+        return resident * base + ws.value // nb + (1 << 20)
     if kernel == "Iterative":
         return resident * base + extra + (ldm // 16 + 1) * ITER_PATCH_BYTES  # one dense union sub-matrix per 4 x 4 patch (csrc/iter_empir.hip)
     return resident * base + extra + 8 * ldn * ldn

@@ -53,9 +53,9 @@ struct WsPlan {
     size_t add(size_t bytes) { total = align_up(total, 256) + bytes; return total; }
 };
 
-ProfScope::ProfScope(imcom_ctx *c, const char *fam, long n) : ctx(c), family(fam), launches(n)
+ProfScope::ProfScope(imcom_ctx *c, const char *fam, long n, bool fine) : ctx(c), family(fam), launches(n)
 {
-    if (!ctx->profile) return;
+    if (!ctx->profile || (fine && !ctx->profile_fine)) return;
     auto get = [&]() {
         hipEvent_t e;
         if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
@@ -458,6 +458,7 @@ int imcom_ctx_profile_enable(imcom_ctx *ctx, int on)
     IMCOM_TRY(check_ctx(ctx));
     IMCOM_TRY(profile_collect(ctx));
     ctx->profile = on != 0;
+    ctx->profile_fine = on >= 2;
     return IMCOM_OK;
 }
 

@@ -748,6 +748,7 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
                 step(ps, g0, r0);
             if (r0 + BW + 1 < nmax) {
                 const int nrowtiles = (nmax - 1) / BSTRIP - (r0 + 1) / BSTRIP + 1, ndot = (r0 - ps + BW * (BW - 1) / 2 + 3) / 4;
+                ProfScope pf(ctx, "symv4", 1, true);  // (profile level 2: HIP events around this launch alone, for the HBM roofline of the pass)
                 hipLaunchKernelGGL(symv4_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, out->Vall, Wp, out->n_dev, ld, r0, ps, nrowtiles, Z4,
                                    part4, coefG, gramG);
             }

@@ -72,6 +72,7 @@ struct imcom_ctx {
     size_t pin_bytes = 0;
     size_t pin_used = 0;
     bool profile = false;
+    bool profile_fine = false;  // imcom_ctx_profile_enable(ctx, 2): also the per-launch scopes inside long stages (symv4)
     std::map<std::string, imcom::ProfileSlot> prof;
     std::vector<imcom::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
@@ -119,7 +120,7 @@ struct ProfScope {
     hipEvent_t start = nullptr, stop = nullptr;
     const char *family;
     long launches;
-    ProfScope(imcom_ctx *c, const char *fam, long n = 1);
+    ProfScope(imcom_ctx *c, const char *fam, long n = 1, bool fine = false);  // fine: only at profile level 2
     ~ProfScope();
 };
 

@@ -724,6 +724,14 @@ static size_t solve_eigen_ws(int batch, int np, int mp, int m)
     return big + (size_t)batch * m * 8 + (size_t)batch * 64 + std::max(basis, eigen_fallback_bytes(1, np, mp, m)) + 65536;
 }
 
+// Device workspace imcom_solve_eigen_resident takes for a batch (what a planner adds to its own buffers; no device call is made)
+extern "C" int imcom_solve_eigen_workspace(int batch, int ldn, int ldm, int m, size_t *bytes)
+{
+    IMCOM_REQUIRE(batch >= 1 && ldn >= NB && ldn % NB == 0 && ldm >= NB && ldm % NB == 0 && m >= 1 && m <= ldm && bytes, "bad sizes (ldn, ldm multiples of 128)");
+    *bytes = solve_eigen_ws(batch, ldn, ldm, m);
+    return IMCOM_OK;
+}
+
 extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, const double *A, const double *mBhalf,
                                  const double *C, const double *kappaC, int nv, double ucmin, double smax, int nbis, float *T,
                                  float *UC, float *Sigma, float *kappa, int *info, int memspace)
