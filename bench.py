@@ -636,6 +636,8 @@ def main():
             out["configs"]["cfg2"] = {"config": "BASELINE configs[1]", "value": out["value"], "unit": out["unit"], "ms_per_stamp": out["ms_per_stamp"],
                                       "roofline": {k: out["roofline"][k] for k in ("kernel", "achieved", "peak", "frac")}, "see": "the top level of this line"}
             # BASELINE configs[2] "batched across one block": the Eigen kernel with its kappa sweep through coadd_block, PSF group per 2 x 2 InStamps
+            ctx.release_workspace()  # (the 256-stamp Eigen leg left 130 GB of workspace on the context: the block planner sizes passes by free memory)
+            torch.cuda.empty_cache()
             out["eigen_block"] = block_leg(ctx, dev, n1P=16, reps=1, config="cfg3", warm=8)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = cpu_baseline(cfg, cpu_sample, psfs, target, args.cpu_budget)

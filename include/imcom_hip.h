@@ -62,6 +62,9 @@ int imcom_ctx_sync(imcom_ctx *ctx);
 /* Bytes of device workspace currently held by the context (grows on demand, never inside a call
  * whose sizes were seen before). */
 int imcom_ctx_workspace_bytes(imcom_ctx *ctx, size_t *bytes);
+/* Give the workspace back to the device (after draining the context's streams); the next call allocates what it needs.
+ * For drivers that change kernel or batch size between blocks: the workspace otherwise keeps the size of the largest call. */
+int imcom_ctx_workspace_release(imcom_ctx *ctx);
 /* Elapsed device milliseconds spent in the named kernel family since the last reset, measured with
  * HIP events on the context's stream when profiling is enabled (bench.py's roofline leg).
  * family: "solve_gemm", "chol_gemm", "chol_diag", "build_A", "build_B", "finalize", "epilogue",
@@ -311,15 +314,16 @@ int imcom_block_accumulate(imcom_ctx *ctx, int batch, const int *jst_host, const
  * to at most four stamps, one of each index parity ((jst & 1) << 1 | (ist & 1)).  imcom_block_place STORES every stamp's
  * tile, in the dtype it arrives in, into the layer of its parity: layers [4][nlayer][nside_pf][nside_pf] float32 or
  * float64 (src_is_f64), zero before the first call.  imcom_block_combine then forms dst[layer][row][col] by adding the
- * layers of a pixel in the order in which the reference's loop meets their stamps (coadd.py:2049-2052: j_st outer, i_st
- * inner), every addition rounded as numpy's `f32_map[window] += tile` (float32 + float32 -> float32; float32 + float64 in
- * double, rounded once): the result carries the reference's own rounding whatever batches, passes or processes the stamps
- * were dealt to (pyimcom_amd.farm shares a block's passes between GPUs).  dst: [nlayer][nside_pf][nside_pf] float32,
- * nside_pf = n1P * n2 + 2 * fade. */
+ * layers of a pixel in the order in which the reference's loop meets their stamps -- order = 1: coadd.py:2056-2059, cells of
+ * 2 x 2 stamps from (j_st_min, i_st_min) on (coadd.py:1808-1838), row by row of cells, inside a cell dj outer, di inner;
+ * order = 0: plain rows, j_st outer, i_st inner -- every addition rounded as numpy's `f32_map[window] += tile` (float32 +
+ * float32 -> float32; float32 + float64 in double, rounded once): the result carries the reference's own rounding whatever
+ * batches, passes or processes the stamps were dealt to (pyimcom_amd.farm shares a block's passes between GPUs).
+ * dst: [nlayer][nside_pf][nside_pf] float32, nside_pf = n1P * n2 + 2 * fade. */
 int imcom_block_place(imcom_ctx *ctx, int batch, const int *jst_host, const int *ist_host, int n2, int fade, int nlayer,
                       const void *src, int src_is_f64, void *layers, int nside_pf);
 int imcom_block_combine(imcom_ctx *ctx, int n1P, int n2, int fade, long nlayer, const void *layers, int src_is_f64,
-                        float *dst, int nside_pf);
+                        float *dst, int nside_pf, int order, int j_st_min, int i_st_min);
 /* Block.build_output_file boundary recovery (coadd.py:2163-2181): OutStamp.trapezoid(maps, fade,
  * recover_mode=True, pad_widths=(b,t,l,r)) on float32 maps [nmaps][ny][nx]. */
 int imcom_trapezoid_recover_f32(imcom_ctx *ctx, float *maps, long nmaps, int ny, int nx, int fade, int pad_b,

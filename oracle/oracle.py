@@ -620,6 +620,21 @@ def block_accumulate(dst, src, j_st, i_st, n2, fade_kernel):
     dst[..., bottom:top, left:right] += src
 
 
+def stamp_loop_order(j_st_min, j_st_max, i_st_min, i_st_max, nrun=None):
+    """The stamps Block.coadd_output_stamps visits, in its order (coadd.py:2056-2064): cells of 2 x 2 stamps, row by row of
+    cells; inside a cell product(range(2), range(2)) = dj outer, di inner; the loop returns after nrun stamps."""
+    from itertools import product
+
+    out = []
+    for j_st in range(j_st_min, j_st_max + 1, 2):
+        for i_st in range(i_st_min, i_st_max + 1, 2):
+            for dj, di in product(range(2), range(2)):
+                out.append((j_st + dj, i_st + di))
+                if len(out) == nrun:
+                    return out
+    return out
+
+
 def compress_map(map_, coef, dtype):
     """Block.compress_map (coadd.py:2087-2138) without the FITS wrapping."""
     a_min, a_max = (0, 65535) if dtype == np.uint16 else (-32768, 32767)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "imcom_ctx_set_stream": [_vp, _vp],
     "imcom_ctx_sync": [_vp],
     "imcom_ctx_workspace_bytes": [_vp, C.POINTER(C.c_size_t)],
+    "imcom_ctx_workspace_release": [_vp],
     "imcom_ctx_profile_enable": [_vp, _i],
     "imcom_ctx_profile_reset": [_vp],
     "imcom_ctx_profile_get": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_l)],
@@ -98,7 +99,7 @@ SIGNATURES = {
     "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
     "imcom_solve_eigen_workspace": [_i, _i, _i, _i, _vp],
     "imcom_block_place": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
-    "imcom_block_combine": [_vp, _i, _i, _i, _l, _vp, _i, _vp, _i],
+    "imcom_block_combine": [_vp, _i, _i, _i, _l, _vp, _i, _vp, _i, _i, _i, _i],
     "imcom_compress_map_f32": [_vp, _vp, _l, _i, _i, _vp],
     "imcom_trapezoid_recover_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i],
 }
@@ -170,6 +171,10 @@ class Context:
         b = C.c_size_t(0)
         check(lib.imcom_ctx_workspace_bytes(self.handle, C.byref(b)))
         return b.value
+
+    def release_workspace(self):
+        """Hand the device workspace back (it otherwise keeps the size of the largest call made on this context)."""
+        check(lib.imcom_ctx_workspace_release(self.handle))
 
     def profile_enable(self, on=True):
         """on = 2: also the per-launch scopes inside long stages (the band reduction's "symv4")."""

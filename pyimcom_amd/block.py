@@ -24,14 +24,18 @@ class BlockMaps:
 
     With fade > 0 neighbouring stamps overlap and a float32 sum depends on its order.  The stamps' tiles are therefore kept
     apart in four index-parity LAYERS (stamps of equal parity never overlap; ``layers[name]``: [n_out, 4, ...] in the dtype
-    the tiles arrive in) and added per pixel in the order of the reference's loop (j_st outer, i_st inner, coadd.py:2049-2052)
-    when the maps are read: ``out_map`` / ``maps`` are the same bits whatever batches, passes or processes the stamps were dealt
-    to, and the reference's own rounding.  With fade == 0 every pixel has one contribution and the tiles go straight to the maps."""
+    the tiles arrive in) and added per pixel in the order of the reference's loop when the maps are read -- ``order="cells"``:
+    coadd.py:2056-2059, cells of 2 x 2 stamps from ``origin`` = (j_st_min, i_st_min) on, row by row of cells, inside a cell
+    dj outer, di inner; ``order="rows"``: j_st outer, i_st inner -- so ``out_map`` / ``maps`` are the same bits whatever batches,
+    passes or processes the stamps were dealt to, and the reference's own rounding.  With fade == 0 every pixel has one
+    contribution and the tiles go straight to the maps."""
 
     NAMES = ("UC", "Sigma", "kappa", "Tsum", "Neff")
 
-    def __init__(self, n1P, n2, fade, n_inframe, n_expo, ctx=None, device="cuda:0", n_out=1):
+    def __init__(self, n1P, n2, fade, n_inframe, n_expo, ctx=None, device="cuda:0", n_out=1, order="cells", origin=(1, 1)):
         self.n1P, self.n2, self.fade, self.n_inframe, self.n_expo, self.n_out = n1P, n2, fade, n_inframe, n_expo, n_out
+        assert order in ("cells", "rows")
+        self.order, self.origin = order, (int(origin[0]), int(origin[1]))
         self.nside = n1P * n2 + 2 * fade  # NsidePf (coadd.py:2029)
         self.ctx = ctx or default_context()
         self.device = dev = torch.device(device)
@@ -103,7 +107,8 @@ class BlockMaps:
             for o in range(self.n_out):
                 dst = self._out_map[o] if name == "out_map" else self._maps[name][o]
                 check(lib.imcom_block_combine(self.ctx.handle, self.n1P, self.n2, self.fade, lay.shape[2], _dp(lay[o]),
-                                              1 if lay.dtype == torch.float64 else 0, _dp(dst), self.nside))
+                                              1 if lay.dtype == torch.float64 else 0, _dp(dst), self.nside, 1 if self.order == "cells" else 0,
+                                              self.origin[0], self.origin[1]))
         self._dirty, self._recovered = False, False
 
     def state(self):

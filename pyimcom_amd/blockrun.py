@@ -302,6 +302,23 @@ def estimate_pixels(cfg, pool, n1P):
     return sum(frac[(dj != 1) + (di != 1)] * counts[dj : dj + n1P, di : di + n1P] for dj in range(3) for di in range(3))
 
 
+def reference_stamp_order(j_st_min, j_st_max, i_st_min, i_st_max, nrun=None):
+    """The (j_st, i_st) the reference's stamp loop visits, in its order (coadd.py:2056-2064): cells of 2 x 2 stamps, row by row of
+    cells, the four stamps of a cell in product(range(2), range(2)) order, stopping after ``nrun`` stamps (cfg.stoptile,
+    coadd.py:1840-1842).  The window comes from Block._handle_postage_pad (1808-1838)."""
+    if (j_st_max + 1 - j_st_min) % 2 or (i_st_max + 1 - i_st_min) % 2:
+        raise ValueError(f"Size must be even: y={j_st_min}..{j_st_max}, x={i_st_min}..{i_st_max}")  # coadd.py:2052-2055
+    out = []
+    for j in range(j_st_min, j_st_max + 1, 2):
+        for i in range(i_st_min, i_st_max + 1, 2):
+            for dj in range(2):
+                for di in range(2):
+                    out.append((j + dj, i + di))
+                    if nrun is not None and len(out) == nrun:
+                        return out
+    return out
+
+
 def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     """The batches coadd_block runs: list of lists of (j_st, i_st).  ``batch=None``: sized from the block's largest stamp, the
     free device memory and -- with a BlockTables -- the table arena (``choose_batch`` / ``plan_batches``); an explicit ``batch``
@@ -347,17 +364,19 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
 
 
 def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None, chunks=None,
-                claim=None):
+                claim=None, origin=(1, 1)):
     """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
     order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables or BlockTables.  ``stamps``: the (j_st, i_st) to
     coadd (default all n1P x n1P); ``pad_sides=None`` leaves the boundary recovery of coadd.py:2163-2181 out.  ``batch``:
     stamps per pass, or ``chunks``: the passes themselves (default: ``plan_block``).  ``claim(q) -> bool`` (optional) is asked
     right before pass q is prepared; a pass it refuses is left out (another process coadds it: pyimcom_amd.farm shares a block's
-    passes between the GPUs of a node) -- the passes that were run are listed in ``maps.chunks_done``.  Returns the BlockMaps."""
+    passes between the GPUs of a node) -- the passes that were run are listed in ``maps.chunks_done``.  ``origin``: (j_st_min,
+    i_st_min) of the reference's loop (coadd.py:1808-1838): with fade > 0 overlapping stamps are summed in the order of that loop
+    whatever the batches are (block.py).  Returns the BlockMaps."""
     nst = n1P + 2
     assert pool.n_inst == nst * nst
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
-                     n_out=int(getattr(tables, "n_out", 1)))
+                     n_out=int(getattr(tables, "n_out", 1)), origin=origin)
     if chunks is None:
         chunks = plan_block(cfg, pool, tables, n1P, batch, ldn, stamps)
     chunks = [[(int(j), int(i)) for j, i in c] for c in chunks]

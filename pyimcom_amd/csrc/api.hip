@@ -453,6 +453,17 @@ int imcom_ctx_workspace_bytes(imcom_ctx *ctx, size_t *bytes)
     return IMCOM_OK;
 }
 
+int imcom_ctx_workspace_release(imcom_ctx *ctx)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
+    if (ctx->ws) IMCOM_HIP_CHECK(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = ctx->ws_used = 0;
+    return IMCOM_OK;
+}
+
 int imcom_ctx_profile_enable(imcom_ctx *ctx, int on)
 {
     IMCOM_TRY(check_ctx(ctx));

@@ -30,8 +30,9 @@ __global__ void block_accumulate_kernel(int npass, const int *__restrict__ list,
 // Overlapping stamps, any visiting order (fade > 0).  A pixel of the block belongs to at most four stamps, one of each index
 // parity (2 * fade <= n2).  Every stamp's tile is STORED -- in the dtype it arrives in -- into the layer of its parity
 // (block_place_kernel; tiles of one parity never overlap, so nothing is summed there), and block_combine_kernel then adds a
-// pixel's layers in the order in which the reference's loop meets their stamps (coadd.py:2049-2052: j_st outer, i_st inner),
-// each addition rounded as numpy's `f32_map[...] += tile` rounds it.  The block's maps therefore do not depend on how the
+// pixel's layers in the order in which the reference's loop meets their stamps (coadd.py:2056-2059: cells of 2 x 2 stamps from
+// (j_st_min, i_st_min) on, row by row of cells; inside a cell dj outer, di inner), each addition rounded as numpy's
+// `f32_map[...] += tile` rounds it.  The block's maps therefore do not depend on how the
 // stamps were dealt to batches, passes or processes, and carry the reference's own rounding.
 template <typename SRC>
 __global__ void block_place_kernel(int batch, const int *__restrict__ jst, const int *__restrict__ ist, int n2, int n2f,
@@ -49,7 +50,7 @@ __global__ void block_place_kernel(int batch, const int *__restrict__ jst, const
 
 template <typename SRC>
 __global__ void block_combine_kernel(int n1P, int n2, int n2f, long nlayer, const SRC *__restrict__ layers,
-                                     float *__restrict__ dst, int nside)
+                                     float *__restrict__ dst, int nside, int cells, int pj, int pi)
 {
     const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (t >= nlayer * nside * nside) return;
@@ -58,13 +59,22 @@ __global__ void block_combine_kernel(int n1P, int n2, int n2f, long nlayer, cons
     // 1-based stamps covering a row: (j-1) n2 <= row <= (j-1) n2 + n2f - 1
     auto first = [&](int r) { const int lo = r - n2f + 1; return (lo <= 0 ? 0 : (lo + n2 - 1) / n2) + 1; };
     auto last = [&](int r) { const int hi = r / n2 + 1; return hi < n1P ? hi : n1P; };
-    float d = 0.0f;
+    // the visiting order of the reference's loop as a sort key: cells of 2 x 2 stamps starting at (pj, pi), row by row of cells,
+    // inside a cell dj outer, di inner (coadd.py:2056-2059); cells = 0: plain rows (j outer, i inner)
+    int key[4], nk = 0;
+    SRC val[4];
     for (int j = first(row); j <= last(row); j++)
         for (int i = first(col); i <= last(col); i++) {
             const int par = ((j & 1) << 1) | (i & 1);
+            const int k = cells ? (((((j - pj) >> 1) + 1) * 32768 + (((i - pi) >> 1) + 1)) * 2 + ((j - pj) & 1)) * 2 + ((i - pi) & 1) : j * 32768 + i;
+            int q = nk++;
             const SRC v = layers[(((long)par * nlayer + layer) * nside + row) * nside + col];
-            d = (float)((double)d + (double)v);
+            while (q > 0 && key[q - 1] > k) { key[q] = key[q - 1]; val[q] = val[q - 1]; q--; }
+            key[q] = k;
+            val[q] = v;
         }
+    float d = 0.0f;
+    for (int q = 0; q < nk; q++) d = (float)((double)d + (double)val[q]);
     dst[t] = d;
 }
 
@@ -157,19 +167,21 @@ extern "C" int imcom_block_place(imcom_ctx *ctx, int batch, const int *jst_host,
 }
 
 extern "C" int imcom_block_combine(imcom_ctx *ctx, int n1P, int n2, int fade, long nlayer, const void *layers, int src_is_f64, float *dst,
-                                   int nside_pf)
+                                   int nside_pf, int order, int j_st_min, int i_st_min)
 {
     if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
     IMCOM_HIP_CHECK(hipSetDevice(ctx->device));
-    IMCOM_REQUIRE(n1P >= 1 && n2 >= 1 && fade >= 0 && nlayer >= 1 && layers && dst, "bad arguments");
+    IMCOM_REQUIRE(n1P >= 1 && n1P < 32000 && n2 >= 1 && fade >= 0 && nlayer >= 1 && layers && dst && (order == 0 || order == 1) && j_st_min >= 1 && i_st_min >= 1,
+                  "bad arguments");
+    const int cells = order, pj = j_st_min & 1, pi = i_st_min & 1;  // (only the parity of the window's origin decides which stamps share a cell)
     IMCOM_REQUIRE(2 * fade <= n2 && nside_pf == n1P * n2 + 2 * fade, "nside_pf = %d is not n1P * n2 + 2 fade (or 2 fade > n2)", nside_pf);
     const long tot = nlayer * nside_pf * nside_pf;
     if (src_is_f64)
         hipLaunchKernelGGL(block_combine_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n1P, n2, n2 + 2 * fade,
-                           nlayer, (const double *)layers, dst, nside_pf);
+                           nlayer, (const double *)layers, dst, nside_pf, cells, pj, pi);
     else
         hipLaunchKernelGGL(block_combine_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n1P, n2, n2 + 2 * fade,
-                           nlayer, (const float *)layers, dst, nside_pf);
+                           nlayer, (const float *)layers, dst, nside_pf, cells, pj, pi);
     return check_launch("block_combine_kernel");
 }
 

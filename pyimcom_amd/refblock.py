@@ -130,9 +130,12 @@ def target_psfs(cfg, psfgrp, device, ctx=None):
 
 
 def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None, ctx=None):
-    """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  ``stamps``: optional list of
-    (j_st, i_st) to coadd instead of all n1P x n1P (the reference's ``stoptile`` debugging aid stops early in the same
-    way); ``finalize=False`` skips the boundary recovery of coadd.py:2163-2181.  ``batch``: stamps per pass (default: sized
+    """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  The stamps are those of the
+    reference's loop: the window ``blk.j_st_min .. j_st_max, i_st_min .. i_st_max`` of Block._handle_postage_pad (coadd.py:1808-1838;
+    default: all n1P x n1P) in cells of 2 x 2, stopping after ``blk.nrun`` stamps when the block carries one (cfg.stoptile,
+    1840-1842); ``stamps``: an explicit list of (j_st, i_st) instead.  Of the five quality maps only those named in ``cfg.outmaps``
+    ("U", "S", "K", "T", "N"; default all) are written to ``blk``, as coadd.py:1979-1990, 2038-2047 allocate and fill them.
+    ``finalize=False`` skips the boundary recovery of coadd.py:2163-2181.  ``batch``: stamps per pass (default: sized
     from the device memory and the table arena, blockrun.plan_block); ``table_capacity``: overlap tables kept resident
     (default: the whole block's, or a third of the free device memory); ``ctx``: the library context to run on (default: the
     process-wide one of the device).  Returns the ``BlockMaps``."""
@@ -156,9 +159,17 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     tables = BlockTables({k: None for k in count}, target, int(psfgrp.nfft), group_expo=expo, group_count=count, bulk_provider=provider,
                          capacity=None if table_capacity is None else int(table_capacity), amp_penalty=amp, device=device, ctx=ctx,
                          cells=True)  # groups of 2 x 2 InStamps: cells of the block's grid (coadd.py:207, 329-358)
-    maps = coadd_block(scfg, pool, tables, int(cfg.n1P), int(blk.n_inimage), batch=batch, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
-                       postage_pad=int(getattr(cfg, "postage_pad", 0)), stamps=stamps)
+    n1P = int(cfg.n1P)
+    window = [int(getattr(blk, k, d)) for k, d in (("j_st_min", 1), ("j_st_max", n1P), ("i_st_min", 1), ("i_st_max", n1P))]
+    if stamps is None and (window != [1, n1P, 1, n1P] or getattr(blk, "nrun", None) not in (None, n1P * n1P)):
+        from .blockrun import reference_stamp_order
+
+        stamps = reference_stamp_order(*window, nrun=getattr(blk, "nrun", None))
+    maps = coadd_block(scfg, pool, tables, n1P, int(blk.n_inimage), batch=batch, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
+                       postage_pad=int(getattr(cfg, "postage_pad", 0)), stamps=stamps, origin=(window[0], window[2]))
     blk.out_map, blk.T_weightmap = maps.out_map.cpu().numpy(), maps.T_weightmap.cpu().numpy()
-    blk.UC_map, blk.Sigma_map, blk.kappa_map = (maps.maps[k].cpu().numpy() for k in ("UC", "Sigma", "kappa"))
-    blk.Tsum_map, blk.Neff_map = maps.maps["Tsum"].cpu().numpy(), maps.maps["Neff"].cpu().numpy()
+    outmaps = getattr(cfg, "outmaps", "USKTN")
+    for c, name, key in (("U", "UC_map", "UC"), ("S", "Sigma_map", "Sigma"), ("K", "kappa_map", "kappa"), ("T", "Tsum_map", "Tsum"), ("N", "Neff_map", "Neff")):
+        if c in outmaps:
+            setattr(blk, name, maps.maps[key].cpu().numpy())
     return maps

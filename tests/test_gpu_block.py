@@ -23,7 +23,7 @@ def test_block_maps_vs_oracle():
     psfs, target = synth.make_psfs(cfg, 3)
     tabs = PSFGroupTables(psfs, target, cfg.nfft)
     res = StampBatch(cfg, stamps, tabs).run()
-    bm = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3)
+    bm = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3, order="rows")  # (the oracle loop below visits the stamps row by row)
     half = len(ids) // 2  # two calls: overlaps both inside a call and across calls
     for sl in (slice(0, half), slice(half, None)):
         sub = dataclasses.replace(res, outimage=res.outimage[sl], UC=res.UC[sl], Sigma=res.Sigma[sl], kappa=res.kappa[sl],
@@ -46,7 +46,7 @@ def test_block_maps_vs_oracle():
     # ... whatever calls the stamps arrive in: one by one in a scrambled order, and all at once
     perm = np.random.default_rng(3).permutation(len(ids))
     for groups in ([[int(k)] for k in perm], [list(range(len(ids)))]):
-        other = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3)
+        other = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3, order="rows")
         for grp in groups:
             sub = dataclasses.replace(res, outimage=res.outimage[grp], UC=res.UC[grp], Sigma=res.Sigma[grp], kappa=res.kappa[grp],
                                       Tsum_inpix=res.Tsum_inpix[grp], Neff=res.Neff[grp], Tsum_stamp=res.Tsum_stamp[grp])
@@ -56,13 +56,13 @@ def test_block_maps_vs_oracle():
     # the state two processes would exchange adds up exactly: the first half's + the second half's = the whole block's
     parts = []
     for sl in (slice(0, half), slice(half, None)):
-        pm = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3)
+        pm = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3, order="rows")
         sub = dataclasses.replace(res, outimage=res.outimage[sl], UC=res.UC[sl], Sigma=res.Sigma[sl], kappa=res.kappa[sl],
                                   Tsum_inpix=res.Tsum_inpix[sl], Neff=res.Neff[sl], Tsum_stamp=res.Tsum_stamp[sl])
         pm.add(sub, [j for j, _ in ids[sl]], [i for _, i in ids[sl]])
         parts.append(pm.state())
     assert all(k.startswith("L_") or k == "T_weightmap" for k in parts[0])
-    merged = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3)
+    merged = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, 3, order="rows")
     merged.load_state({k: parts[0][k] + parts[1][k] for k in parts[0]})
     assert torch.equal(merged.out_map, bm.out_map) and all(torch.equal(merged.maps[k], bm.maps[k]) for k in ref)
 
@@ -149,7 +149,7 @@ def test_block_maps_vs_reference_golden(golden):
 
     g = golden("block_maps")
     n1P, n2, fk, n_out, n_inframe, n_inimage = (int(v) for v in g["pars"])
-    bm = BlockMaps(n1P, n2, fk, n_inframe, n_inimage, n_out=n_out)
+    bm = BlockMaps(n1P, n2, fk, n_inframe, n_inimage, n_out=n_out, order="rows")  # (block_maps.npz was generated by calling _output_stamp_wrapper row by row)
     ids = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
     dev = "cuda:0"
     t = lambda key, o: torch.as_tensor(np.stack([g[f"st{j}{i}_{key}"][o] for j, i in ids]), device=dev)  # noqa: E731
@@ -172,3 +172,42 @@ def test_block_maps_vs_reference_golden(golden):
     assert close(bm.out_map.cpu().numpy(), g["fin_out_map"])
     for k, nm in names.items():
         assert close(bm.maps[k].cpu().numpy(), g[f"fin_{nm}"]), k
+
+
+@pytest.mark.parametrize("case", ["whole", "inner", "stop"])
+def test_block_maps_follow_the_reference_loop_order(golden, case):
+    """The ORDER of the reference's stamp loop (coadd.py:2056-2081: cells of 2 x 2 stamps from (j_st_min, i_st_min), row by row of
+    cells; inside a cell dj outer, di inner; stop after nrun stamps) decides the float32 sums where three or four stamps overlap.
+    tests/golden/block_loop.npz was made by executing that loop statement itself on stamps of mixed magnitude; BlockMaps --
+    stamps added in a scrambled order -- reproduces its maps bit for bit, for the whole block, for an inner window starting at
+    an even index, and for a loop that stops inside a cell (cfg.stoptile)."""
+    import torch
+
+    from pyimcom_amd.block import BlockMaps
+    from pyimcom_amd.blockrun import reference_stamp_order
+    from pyimcom_amd.stamps import StampBatchResult
+
+    g = golden("block_loop")
+    n1P, n2, fk, n_out, n_inframe, n_inimage = (int(v) for v in g["pars"])
+    lo_j, hi_j, lo_i, hi_i = (int(v) for v in g[f"{case}_window"])
+    ids = reference_stamp_order(lo_j, hi_j, lo_i, hi_i, int(g[f"{case}_nrun"]))
+    assert np.array_equal(np.array(ids), g[f"{case}_visited"])  # the host mirror of the loop visits what the reference visited
+    bm = BlockMaps(n1P, n2, fk, n_inframe, n_inimage, n_out=n_out, origin=(lo_j, lo_i))
+    perm = [ids[k] for k in np.random.default_rng(9).permutation(len(ids))]
+    dev = "cuda:0"
+    for part in (perm[: len(perm) // 2], perm[len(perm) // 2 :]):
+        t = lambda key: torch.as_tensor(np.stack([g[f"st{j}{i}_{key}"][0] for j, i in part]), device=dev)  # noqa: E731
+        bm.add(StampBatchResult(None, t("UC"), t("Sigma"), t("kappa"), t("outimage"), t("Tsum_stamp"), t("Tsum_inpix"), t("Neff"), None, None),
+               [j for j, _ in part], [i for _, i in part])
+    torch.cuda.synchronize()
+    assert np.array_equal(bm.out_map.cpu().numpy(), g[f"{case}_out_map"])
+    assert np.array_equal(bm.T_weightmap.cpu().numpy(), g[f"{case}_T_weightmap"])
+    for k, nm in dict(UC="UC_map", Sigma="Sigma_map", kappa="kappa_map", Tsum="Tsum_map", Neff="Neff_map").items():
+        if f"{case}_{nm}" in g.files:  # (cfg.outmaps of the case: the reference allocates the named maps only)
+            assert np.array_equal(bm.maps[k].cpu().numpy(), g[f"{case}_{nm}"]), k
+    if case == "whole":  # the order matters: row by row gives other bits somewhere in the overlaps
+        rows = BlockMaps(n1P, n2, fk, n_inframe, n_inimage, n_out=n_out, order="rows")
+        t = lambda key: torch.as_tensor(np.stack([g[f"st{j}{i}_{key}"][0] for j, i in ids]), device=dev)  # noqa: E731
+        rows.add(StampBatchResult(None, t("UC"), t("Sigma"), t("kappa"), t("outimage"), t("Tsum_stamp"), t("Tsum_inpix"), t("Neff"), None, None),
+                 [j for j, _ in ids], [i for _, i in ids])
+        assert not torch.equal(rows.out_map, bm.out_map)

@@ -434,3 +434,31 @@ def test_iterative_clamp_golden(golden):
     assert np.array_equal(UC, g["UC_Iterative"], equal_nan=True) and np.array_equal(Sigma, g["Sigma_Iterative"], equal_nan=True)
     assert np.array_equal(g["UC_Cholesky"], g["UC_in"], equal_nan=True)
     assert np.nanmin(UC) == np.float32(1e-32) and np.isnan(UC).sum() == np.isnan(g["UC_in"]).sum()
+
+
+@pytest.mark.parametrize("case", ["whole", "inner", "stop"])
+def test_block_loop_order_golden(golden, case):
+    """The reference's stamp loop statement (coadd.py:2056-2081, executed by tests/golden/make_golden_block_loop.py) against the
+    oracle's restatement of its order + block_accumulate: visited stamps and every map bit for bit (float32 sums of three or
+    four overlapping stamps of mixed magnitude: the order shows)."""
+    g = golden("block_loop")
+    n1P, n2, fk, n_out, n_inframe, n_inimage = (int(v) for v in g["pars"])
+    lo_j, hi_j, lo_i, hi_i = (int(v) for v in g[f"{case}_window"])
+    ids = orc.stamp_loop_order(lo_j, hi_j, lo_i, hi_i, int(g[f"{case}_nrun"]))
+    assert np.array_equal(np.array(ids), g[f"{case}_visited"])
+    ns = n1P * n2 + 2 * fk
+    out_map = np.zeros((n_out, n_inframe, ns, ns), np.float32)
+    names = dict(UC="UC_map", Sigma="Sigma_map", kappa="kappa_map", Tsum_inpix="Tsum_map", Neff="Neff_map")
+    maps = {k: np.zeros((n_out, ns, ns), np.float32) for k in names}
+    for j, i in ids:
+        orc.block_accumulate(out_map, g[f"st{j}{i}_outimage"], j, i, n2, fk)
+        for k in names:
+            orc.block_accumulate(maps[k], g[f"st{j}{i}_{k}"], j, i, n2, fk)
+    assert np.array_equal(out_map, g[f"{case}_out_map"])
+    for k, nm in names.items():
+        if f"{case}_{nm}" in g.files:
+            assert np.array_equal(maps[k], g[f"{case}_{nm}"]), k
+    rows = np.zeros_like(out_map)
+    for j, i in sorted(ids):
+        orc.block_accumulate(rows, g[f"st{j}{i}_outimage"], j, i, n2, fk)
+    assert case != "whole" or not np.array_equal(rows, out_map)  # row by row is another sum
