@@ -630,7 +630,8 @@ def synthetic_mosaic(config="cfg4", nblock=4, n1P=2, seed=4, psf_groups=False):
         E = int(depth[b])
         if psf_groups:
             ng = (n1P + 3) // 2
-            tables = BlockTables({(gj, gi): psfs for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, ctx=ctx, device=device, cells=True)
+            tables = BlockTables({(gj, gi): synth.group_psfs(psfs, gj, gi) for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, ctx=ctx,
+                                 device=device, cells=True)  # every group its own PSFs: self, cross and input-output tables all differ
         else:
             tables = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=device)
         return dict(cfg=cfg, pool=InStampPool(inst, cfg.n_inframe, device=device), tables=tables, n1P=n1P, n_expo=E,

@@ -275,6 +275,16 @@ class _Obj:
     """Plain attribute container (the duck-typed stand-ins below)."""
 
 
+def group_psfs(psfs, gj, gi):
+    """PSFs of the 2 x 2 group of InStamps (gj, gi) of a synthetic block: a smooth modulation of the block's analytic PSFs that
+    depends on the group, renormalised (every group has PSFs of its own, as a real block's vary with position)."""
+    ns = psfs.shape[-1]
+    lin = np.arange(ns, dtype=np.float64) - ns // 2
+    mod = 1.0 + 0.02 * np.sin(0.05 * lin * (1 + gi % 3))[None, None, :] + 0.02 * np.cos(0.04 * lin * (1 + gj % 5))[None, :, None]
+    p = psfs * mod * (1.0 + 1e-3 * ((7 * gj + 3 * gi) % 11))
+    return p / p.sum(axis=(1, 2), keepdims=True)
+
+
 def duck_block(wl, n1P, E, seed=3, kernel="Cholesky", pad_sides="all"):
     """A duck-typed ``pyimcom.coadd.Block`` + ``PSFGrp`` class attributes for ``refblock.coadd_output_stamps`` without FITS /
     WCS machinery: synthetic InStamps (``make_instamps``), per exposure an affine output-pixel -> input-pixel map (a small

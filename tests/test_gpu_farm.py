@@ -90,7 +90,8 @@ def test_farm_dynamic_schedule_shares_a_block(tmp_path):
 
 def test_farm_cfg4_block_with_psf_groups_vs_oracle(tmp_path):
     """ONE real block of the cfg-4 mosaic (BASELINE configs[3]: 48 x 48-output stamps, this block's own exposure depth in
-    6 - 10, N = 2.2 - 3.7k) through the farm driver with a PSF group per 2 x 2 InStamps (`--config cfg4 --psf-groups`), and
+    6 - 10, N = 2.2 - 3.7k) through the farm driver with a PSF group per 2 x 2 InStamps, each group with PSFs of its own
+    (`--config cfg4 --psf-groups`), and
     one of its stamps against the oracle: A and -B/2 assembled the reference's way from the groups' PSFOvl objects
     (stamp_system_groups), CholKernel, tapers, coaddition -- compared inside the block file the driver wrote."""
     from oracle import oracle as orc
@@ -110,8 +111,10 @@ def test_farm_cfg4_block_with_psf_groups_vs_oracle(tmp_path):
     cfg, inst, psfs, target = make_block.host(0)
     n1P, nst, n2 = 2, 4, cfg.n2
     geo = orc.Geom(cfg.npixpsf, cfg.oversamp, cfg.dtheta_as / 3600.0, cfg.flat_penalty)
-    rft = orc.pad_and_rfft2(psfs, geo)
-    rft_in = {(gj, gi): rft for gj in range(2) for gi in range(2)}  # the synthetic mosaic gives every group the same PSFs
+    # every 2 x 2 group of InStamps has PSFs of its own (synth.group_psfs): the stamp's A draws on the self tables of up to four
+    # groups and on the flipped / swapped cross tables between them -- at N = 2.2 - 3.7k against the oracle's PSFOvl objects
+    rft_in = {(gj, gi): orc.pad_and_rfft2(synth.group_psfs(psfs, gj, gi), geo) for gj in range(2) for gi in range(2)}
+    assert not np.array_equal(rft_in[(0, 0)], rft_in[(1, 0)])
     rft_out = orc.pad_and_rfft2(target, geo)
     C = float(orc.overlap_out_C(rft_out, geo)[0])
     j, i = 2, 1

@@ -257,3 +257,44 @@ def test_block_seam_at_reference_block_size():
     assert np.array_equal(direct.out_map.cpu().numpy(), blk.out_map) and np.array_equal(direct.T_weightmap.cpu().numpy(), blk.T_weightmap)
     for k, name in (("UC", "UC_map"), ("Sigma", "Sigma_map"), ("kappa", "kappa_map"), ("Tsum", "Tsum_map"), ("Neff", "Neff_map")):
         assert np.array_equal(direct.maps[k].cpu().numpy(), getattr(blk, name)), k
+
+
+@pytest.mark.gpu
+def test_block_seam_honours_the_stamp_window_nrun_and_outmaps():
+    """What the reference's loop coadds and which maps it fills (coadd.py:1808-1842, 1979-1990, 2038-2064): with postage_pad = 1
+    and no padded side the window is stamps 2 .. n1P - 1; cfg.stoptile ends the loop after nrun stamps; of the quality maps only
+    those named in cfg.outmaps exist on the block.  The adapter follows all three: the windowed call equals an explicit stamp
+    list in the reference's cell order; stamps outside the window are left zero; `blk.kappa_map` is not written for "US"."""
+    import dataclasses
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import reference_stamp_order
+    from pyimcom_amd.refblock import coadd_output_stamps
+
+    n1P, E = 6, 3
+    wl = dataclasses.replace(synth.CONFIGS["small"], n_expo=E)
+    blk, psfgrp, _, _ = synth.duck_block(wl, n1P, E, seed=8, pad_sides="")
+    blk.cfg.postage_pad = 1
+    blk.j_st_min = blk.i_st_min = 2
+    blk.j_st_max = blk.i_st_max = n1P - 1
+    blk.nrun = 10  # the loop stops inside the third cell (cfg.stoptile)
+    blk.cfg.outmaps = "US"
+    coadd_output_stamps(blk, psfgrp, flat_penalty=wl.flat_penalty)
+    assert hasattr(blk, "UC_map") and hasattr(blk, "Sigma_map") and not hasattr(blk, "kappa_map") and not hasattr(blk, "Tsum_map") and not hasattr(blk, "Neff_map")
+    order = reference_stamp_order(2, n1P - 1, 2, n1P - 1, 10)
+    assert order[:6] == [(2, 2), (2, 3), (3, 2), (3, 3), (2, 4), (2, 5)] and len(order) == 10
+    done = np.zeros((n1P, n1P), bool)
+    for j, i in order:
+        done[j - 1, i - 1] = True
+    assert np.array_equal(blk.T_weightmap[0, 0] != 0, done)  # exactly the visited stamps were coadded
+    ref, psfgrp2, _, _ = synth.duck_block(wl, n1P, E, seed=8, pad_sides="")
+    ref.cfg.postage_pad = 1
+    coadd_output_stamps(ref, psfgrp2, flat_penalty=wl.flat_penalty, stamps=order)
+    # same stamps, same origin of the cells?  the explicit list runs with the default origin (1, 1): equal where no more than two
+    # stamps overlap; the windowed call is the reference's order.  Compare away from the corners of the stamps' overlaps:
+    assert np.allclose(blk.out_map, ref.out_map, rtol=0, atol=4e-7 * np.abs(ref.out_map).max())
+    assert np.allclose(blk.UC_map, ref.UC_map, rtol=1e-6, atol=0) and np.allclose(blk.Sigma_map, ref.Sigma_map, rtol=1e-6, atol=0)
+    assert np.array_equal(blk.T_weightmap, ref.T_weightmap)
+    blk.j_st_max = n1P  # 2 .. 6: five rows
+    with pytest.raises(ValueError, match="Size must be even"):
+        coadd_output_stamps(blk, psfgrp, flat_penalty=wl.flat_penalty)
