@@ -418,6 +418,8 @@ int imcom_ctx_destroy(imcom_ctx *ctx)
     for (auto e : ctx->sync_events) hipEventDestroy(e);
     if (ctx->stream_event) hipEventDestroy(ctx->stream_event);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
+    for (auto s_ : ctx->sub_streams) hipStreamDestroy(s_);
+    if (ctx->flag_pin) hipHostFree(ctx->flag_pin);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return IMCOM_OK;

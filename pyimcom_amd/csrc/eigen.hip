@@ -523,10 +523,11 @@ static size_t eigen_fallback_bytes(int nf, int np, int mp, int m)
 static int eigen_fallback(imcom_ctx *ctx, const std::vector<int> &idx, const int *n, const int *n_dev, int ldn, int m, int np, int mp,
                           const double *A_d, const double *Bt_res, const double *B_ref, const double *C, const double *kappaC, int nv,
                           double ucmin, double smax, int nbis, const double *par, int batch, double *Xout, float *UC_d, float *Sig_d,
-                          float *kap_d)
+                          float *kap_d, size_t limit)
 {
     hipStream_t st = ctx->stream;
-    const size_t mark = ctx->ws_used, room = ctx->ws_bytes - std::min(ctx->ws_bytes, align_up(mark, 256));
+    limit = std::min(limit, ctx->ws_bytes);  // the end of the caller's share of the workspace
+    const size_t mark = ctx->ws_used, room = limit - std::min(limit, align_up(mark, 256));
     int cap = (int)idx.size();
     while (cap > 1 && eigen_fallback_bytes(cap, np, mp, m) > room) cap = (cap + 1) / 2;
     if (eigen_fallback_bytes(cap, np, mp, m) > room) { set_error("internal: no workspace for the eigendecomposition of a stamp"); return IMCOM_ERR_NOMEM; }
@@ -592,33 +593,52 @@ static int eigen_fallback(imcom_ctx *ctx, const std::vector<int> &idx, const int
 
 // Shared body of the two entries.  Bt_res: -B/2 in the resident layout [np][mp] (then Tt_res [np][mp] float32 is the output);
 // else B_ref [m][ldn] and T_ref [m][ldn] in the reference's layout.
-static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, int np, int mp, const double *A_d, const double *Bt_res,
-                            const double *B_ref, const double *C, const double *kappaC, int nv, double ucmin, double smax, int nbis,
-                            float *Tt_res, float *T_ref, float *UC_d, float *Sig_d, float *kap_d, int nmax, int *info)
+//
+// The work of a (sub-)batch comes in two parts: eigen_enqueue queues everything up to x = Q y on ctx->stream without waiting for
+// the device; eigen_finish reads the positive-definiteness flags back, sends the stamps that failed through the eigenbasis route
+// and stores T.  Between the two, other sub-batches can be queued on other streams (solve_eigen_core).
+struct EigenJob {
+    int batch = 0, nmax = 0;
+    const int *n = nullptr;
+    const double *A_d = nullptr, *Bt_res = nullptr, *B_ref = nullptr, *C = nullptr;
+    float *Tt_res = nullptr, *T_ref = nullptr, *UC_d = nullptr, *Sig_d = nullptr, *kap_d = nullptr;
+    int *info = nullptr;
+    // state between the two parts
+    double *Cb = nullptr, *par = nullptr;
+    int *n_early = nullptr, *flag = nullptr;
+    size_t keep = 0, limit = 0;
+    hipStream_t st = nullptr;
+    int *flag_h = nullptr;  // page-locked, in ctx->flag_pin
+};
+
+static int eigen_enqueue(imcom_ctx *ctx, EigenJob &j, int ldn, int m, int np, int mp, const double *kappaC, int nv, double ucmin, double smax, int nbis,
+                         bool allow_overlap)
 {
+    const int batch = j.batch, nmax = j.nmax;
+    const int *n = j.n;
     const size_t big = (size_t)batch * np * mp * 8, szM = (size_t)batch * m;
     TrdBasis tb;
     const bool banded = eigen_uses_band(np);
     // buffers that outlive everything first; from `keep` on the workspace belongs to the basis (whose own scratch is handed back
     // after the reduction) and, once the band path has finished, to the eigenbasis route of the stamps that failed the check
-    double *Cb = (double *)ws_take(ctx, big);
-    double *kpix = (double *)ws_take(ctx, szM * 8), *par = (double *)ws_take(ctx, (size_t)batch * 8 * 5);
-    int *n_early = (int *)ws_take(ctx, (size_t)batch * 4), *flag = (int *)ws_take(ctx, (size_t)batch * 4);
-    const size_t keep = ctx->ws_used;
+    double *Cb = j.Cb = (double *)ws_take(ctx, big);
+    double *kpix = (double *)ws_take(ctx, szM * 8), *par = j.par = (double *)ws_take(ctx, (size_t)batch * 8 * 5);
+    int *n_early = j.n_early = (int *)ws_take(ctx, (size_t)batch * 4), *flag = j.flag = (int *)ws_take(ctx, (size_t)batch * 4);
+    j.keep = ctx->ws_used;
     double *Lb = (double *)ws_take(ctx, banded ? big * BAND_BW : big);
     if (!Cb || !Lb || !kpix || !par || !n_early || !flag) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     std::vector<double> ph(4 * (size_t)batch);
     for (int s = 0; s < batch; s++) {
-        ph[s] = C[s];
-        ph[batch + s] = kappaC[0] * C[s];           // single kappa / kCmin C (lakernel.py:166, 213)
-        ph[2 * batch + s] = kappaC[nv - 1] * C[s];  // kCmax C (214)
+        ph[s] = j.C[s];
+        ph[batch + s] = kappaC[0] * j.C[s];           // single kappa / kCmin C (lakernel.py:166, 213)
+        ph[2 * batch + s] = kappaC[nv - 1] * j.C[s];  // kCmax C (214)
     }
     IMCOM_TRY(upload(ctx, par, ph.data(), ph.size()));
     IMCOM_TRY(upload(ctx, n_early, n, (size_t)batch));
-    hipStream_t st = ctx->stream;
-    if (Bt_res) IMCOM_HIP_CHECK(hipMemcpyAsync(Cb, Bt_res, big, hipMemcpyDeviceToDevice, st));
+    hipStream_t st = j.st = ctx->stream;
+    if (j.Bt_res) IMCOM_HIP_CHECK(hipMemcpyAsync(Cb, j.Bt_res, big, hipMemcpyDeviceToDevice, st));
     else {
-        hipLaunchKernelGGL(tri_pack_kernel, dim3(mp / 32, np / 32, batch), dim3(256), 0, st, B_ref, (long)ldn, m, n_early, Cb, np, mp);
+        hipLaunchKernelGGL(tri_pack_kernel, dim3(mp / 32, np / 32, batch), dim3(256), 0, st, j.B_ref, (long)ldn, m, n_early, Cb, np, mp);
         IMCOM_TRY(check_launch("tri_pack_kernel"));
     }
     if (banded) {
@@ -638,9 +658,10 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         } drain{aux};
         // Worth it while the reduction's one-workgroup-per-stamp step leaves most CUs idle: the products' tiles monopolise a CU
         // (registers, LDS) and the reduction's dependent chain queues behind them.  cfg-3, with / without: batch 32 251 / 265 ms,
-        // 64 418 / 430, 128 762 / 772, 256 1485 / 1458.  IMCOM_EIGEN_OVERLAP=0 / 1 forces it.
+        // 64 418 / 430, 128 762 / 772, 256 1485 / 1458.  IMCOM_EIGEN_OVERLAP=0 / 1 forces it.  (Not beside other sub-batches: the
+        // second stream is one, and the sub-batches' own phases already fill each other's gaps.)
         const char *ov = getenv("IMCOM_EIGEN_OVERLAP");
-        const bool overlap = nmax > 0 && (ov ? atoi(ov) != 0 : batch <= 128);
+        const bool overlap = allow_overlap && nmax > 0 && (ov ? atoi(ov) != 0 : batch <= 128);
         auto on_panel = [&](int p) -> int {
             IMCOM_HIP_CHECK(hipEventRecord(ev_main, st));
             IMCOM_HIP_CHECK(hipStreamWaitEvent(aux, ev_main, 0));
@@ -649,22 +670,22 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
             ctx->stream = st;
             return rc;
         };
-        const int rc = band_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb, overlap ? std::function<int(int)>(on_panel) : nullptr);
+        const int rc = band_basis_device(ctx, batch, n, np, mp, j.A_d, ldn, (long)ldn * ldn, &tb, overlap ? std::function<int(int)>(on_panel) : nullptr);
         ctx->stream = st;
         IMCOM_TRY(rc);
-        IMCOM_HIP_CHECK(hipEventRecord(ev_aux, aux));
-        IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_aux, 0));  // join: c is complete when the main stream goes on
+        if (overlap) {
+            IMCOM_HIP_CHECK(hipEventRecord(ev_aux, aux));
+            IMCOM_HIP_CHECK(hipStreamWaitEvent(st, ev_aux, 0));  // join: c is complete when the main stream goes on
+        }
         drain.armed = false;
         if (overlap) IMCOM_TRY(trd_pair_factors(ctx, &tb, batch));  // (the panels' own factors were made on the second stream)
         else if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Q^T b after the reduction
     } else {
-        IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, A_d, ldn, (long)ldn * ldn, &tb));
+        IMCOM_TRY(trd_basis_device(ctx, batch, n, np, mp, j.A_d, ldn, (long)ldn * ldn, &tb));
         if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, true));  // c = Qh^T b
     }
-    // is A + kappa_min I positive definite?  (par + batch = the lowest kappa of the call; the answer is read after the search has
-    // been queued, so the host's wait hides behind it)
-    std::vector<int> flagged;
-    std::vector<int> flag_h(batch, 0);
+    // is A + kappa_min I positive definite?  (par + batch = the lowest kappa of the call; the answer is read in eigen_finish, after
+    // everything else has been queued: the host's wait hides behind the search)
     if (nmax > 0) {
         if (banded) hipLaunchKernelGGL(band_pd_kernel<BAND_BW>, dim3((batch + 63) / 64), dim3(64), 0, st, tb.band, np, batch, n_early, par + batch, flag, par + 4 * batch);
         else hipLaunchKernelGGL(tri_pd_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, tb.dvec, tb.evec, np, batch, n_early, par + batch, flag, par + 4 * batch);
@@ -674,45 +695,155 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         ProfScope ps(ctx, "lakernel1");
         if (banded) {
             if (nv > 1) {
-                hipLaunchKernelGGL(band_search_kernel<BAND_BW>, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.band, Cb, np, mp, m, tb.n_dev, par, par + batch,
+                hipLaunchKernelGGL(band_search_kernel<BAND_BW>, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.band, Cb, np, mp, m, n_early, par, par + batch,
                                    par + 2 * batch, ucmin, smax, nbis, kpix);
                 IMCOM_TRY(check_launch("band_search_kernel"));
             }
-            hipLaunchKernelGGL(band_solve_kernel<BAND_BW>, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.band, Cb, Lb, np, mp, m, tb.n_dev, par, par + batch,
-                               nv > 1 ? kpix : nullptr, UC_d, Sig_d, kap_d);
+            hipLaunchKernelGGL(band_solve_kernel<BAND_BW>, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.band, Cb, Lb, np, mp, m, n_early, par, par + batch,
+                               nv > 1 ? kpix : nullptr, j.UC_d, j.Sig_d, j.kap_d);
             IMCOM_TRY(check_launch("band_solve_kernel"));
         } else {
-        if (nv > 1) {
-            hipLaunchKernelGGL(tri_search_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, np, mp, m, tb.n_dev, par,
-                               par + batch, par + 2 * batch, ucmin, smax, nbis, kpix);
-            IMCOM_TRY(check_launch("tri_search_kernel"));
-        }
-        hipLaunchKernelGGL(tri_solve_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, Lb, np, mp, m, tb.n_dev, par,
-                           par + batch, nv > 1 ? kpix : nullptr, UC_d, Sig_d, kap_d);
-        IMCOM_TRY(check_launch("tri_solve_kernel"));
+            if (nv > 1) {
+                hipLaunchKernelGGL(tri_search_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, np, mp, m, n_early, par,
+                                   par + batch, par + 2 * batch, ucmin, smax, nbis, kpix);
+                IMCOM_TRY(check_launch("tri_search_kernel"));
+            }
+            hipLaunchKernelGGL(tri_solve_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, Lb, np, mp, m, n_early, par,
+                               par + batch, nv > 1 ? kpix : nullptr, j.UC_d, j.Sig_d, j.kap_d);
+            IMCOM_TRY(check_launch("tri_solve_kernel"));
         }
     }
-    if (nmax > 0) IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, false));  // x = Qh y
     if (nmax > 0) {
-        IMCOM_HIP_CHECK(hipMemcpyAsync(flag_h.data(), flag, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
+        IMCOM_TRY(trd_apply_q(ctx, tb, batch, Cb, mp, false));  // x = Qh y
+        IMCOM_HIP_CHECK(hipMemcpyAsync(j.flag_h, flag, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
+    }
+    return IMCOM_OK;
+}
+
+static int eigen_finish(imcom_ctx *ctx, EigenJob &j, int ldn, int m, int np, int mp, const double *kappaC, int nv, double ucmin, double smax, int nbis)
+{
+    const int batch = j.batch;
+    hipStream_t st = j.st;
+    std::vector<int> flagged;
+    if (j.nmax > 0) {
         IMCOM_HIP_CHECK(hipStreamSynchronize(st));
         for (int s = 0; s < batch; s++)
-            if (flag_h[s]) { flagged.push_back(s); info[s] = 1; }
+            if (j.flag_h[s]) { flagged.push_back(s); j.info[s] = 1; }
     }
     if (!flagged.empty()) {
         // the band path's buffers are dead now (same stream: everything queued so far runs before whatever reuses them)
-        ctx->ws_used = keep;
-        IMCOM_TRY(eigen_fallback(ctx, flagged, n, n_early, ldn, m, np, mp, A_d, Bt_res, B_ref, C, kappaC, nv, ucmin, smax, nbis, par, batch, Cb, UC_d, Sig_d,
-                                 kap_d));
+        ctx->ws_used = j.keep;
+        IMCOM_TRY(eigen_fallback(ctx, flagged, j.n, j.n_early, ldn, m, np, mp, j.A_d, j.Bt_res, j.B_ref, j.C, kappaC, nv, ucmin, smax, nbis, j.par, batch, j.Cb,
+                                 j.UC_d, j.Sig_d, j.kap_d, j.limit));
     }
-    if (Tt_res) {
-        hipLaunchKernelGGL(tri_store_resident_kernel, dim3((mp + 255) / 256, np, batch), dim3(256), 0, st, Cb, np, mp, m, n_early, Tt_res, np, mp);
+    if (j.Tt_res) {
+        hipLaunchKernelGGL(tri_store_resident_kernel, dim3((mp + 255) / 256, np, batch), dim3(256), 0, st, j.Cb, np, mp, m, j.n_early, j.Tt_res, np, mp);
         IMCOM_TRY(check_launch("tri_store_resident_kernel"));
     } else if (ldn > 0) {
-        hipLaunchKernelGGL(tri_store_ref_kernel, dim3(mp / 32, (unsigned)((ldn + 31) / 32), batch), dim3(256), 0, st, Cb, np, mp, m, n_early, T_ref, (long)ldn);
+        hipLaunchKernelGGL(tri_store_ref_kernel, dim3(mp / 32, (unsigned)((ldn + 31) / 32), batch), dim3(256), 0, st, j.Cb, np, mp, m, j.n_early, j.T_ref, (long)ldn);
         IMCOM_TRY(check_launch("tri_store_ref_kernel"));
     }
     return IMCOM_OK;
+}
+
+static size_t solve_eigen_ws(int batch, int np, int mp, int m);
+
+// Sub-batches of one call on streams of their own (IMCOM_EIGEN_SPLIT = count).  The reduction alternates a bandwidth-bound pass
+// over the trailing matrix (symv4) with a latency chain that keeps ONE workgroup per stamp busy (band_step: a seventh of the
+// reduction at batch 32) and small launches around them; sub-batches in flight were meant to put one's latency chain beside
+// another's memory pass.  Measured (cfg-3, ms per stamp, one / two / four sub-batches): batch 32: 7.77 / 7.82 / 10.80 -- the queues
+// of the streams mostly take turns (two halves: 128 ms of reduction each where 85 were due), and the halves lose the reflector
+// products beside the reduction; batch 256: 5.48 / 5.31 / 5.56.  Default: two sub-batches from 192 stamps on, else one.
+static int eigen_split(int batch, int np)
+{
+    static const int forced = getenv("IMCOM_EIGEN_SPLIT") ? atoi(getenv("IMCOM_EIGEN_SPLIT")) : 0;
+    int k = forced > 0 ? forced : (batch >= 192 ? 2 : 1);
+    if (!eigen_uses_band(np)) k = 1;
+    return std::max(1, std::min(std::min(k, batch), 8));
+}
+
+static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, int np, int mp, const double *A_d, const double *Bt_res,
+                            const double *B_ref, const double *C, const double *kappaC, int nv, double ucmin, double smax, int nbis,
+                            float *Tt_res, float *T_ref, float *UC_d, float *Sig_d, float *kap_d, int nmax, int *info)
+{
+    const int nsub = nmax > 0 ? eigen_split(batch, np) : 1;
+    hipStream_t main = ctx->stream;
+    if (ctx->flag_pin_count < (size_t)batch) {
+        if (ctx->flag_pin) { IMCOM_HIP_CHECK(hipStreamSynchronize(main)); IMCOM_HIP_CHECK(hipHostFree(ctx->flag_pin)); ctx->flag_pin = nullptr; ctx->flag_pin_count = 0; }
+        IMCOM_HIP_CHECK(hipHostMalloc((void **)&ctx->flag_pin, (size_t)std::max(batch, 256) * 4, hipHostMallocDefault));
+        ctx->flag_pin_count = (size_t)std::max(batch, 256);
+    }
+    const size_t base = ctx->ws_used;
+    std::vector<EigenJob> jobs(nsub);
+    for (int q = 0; q < nsub; q++) {
+        EigenJob &j = jobs[q];
+        const int s0 = (int)((long)batch * q / nsub), s1 = (int)((long)batch * (q + 1) / nsub);
+        j.batch = s1 - s0;
+        j.n = n + s0;
+        j.nmax = 0;
+        for (int s = s0; s < s1; s++) j.nmax = std::max(j.nmax, n[s]);
+        j.A_d = A_d ? A_d + (size_t)s0 * ldn * ldn : nullptr;
+        j.Bt_res = Bt_res ? Bt_res + (size_t)s0 * np * mp : nullptr;
+        j.B_ref = B_ref ? B_ref + (size_t)s0 * m * ldn : nullptr;
+        j.C = C + s0;
+        j.Tt_res = Tt_res ? Tt_res + (size_t)s0 * np * mp : nullptr;
+        j.T_ref = T_ref ? T_ref + (size_t)s0 * m * ldn : nullptr;
+        j.UC_d = UC_d + (size_t)s0 * m;
+        j.Sig_d = Sig_d + (size_t)s0 * m;
+        j.kap_d = kap_d + (size_t)s0 * m;
+        j.info = info + s0;
+        j.flag_h = ctx->flag_pin + s0;
+    }
+    if (nsub == 1) {
+        jobs[0].limit = ctx->ws_bytes;
+        IMCOM_TRY(eigen_enqueue(ctx, jobs[0], ldn, m, np, mp, kappaC, nv, ucmin, smax, nbis, true));
+        return eigen_finish(ctx, jobs[0], ldn, m, np, mp, kappaC, nv, ucmin, smax, nbis);
+    }
+    // streams and events of the sub-batches (the first one stays on the caller's stream)
+    while ((int)ctx->sub_streams.size() < nsub - 1) {
+        hipStream_t s_;
+        IMCOM_HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+        ctx->sub_streams.push_back(s_);
+    }
+    while ((int)ctx->sync_events.size() < 2 + nsub) {
+        hipEvent_t e;
+        IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_events.push_back(e);
+    }
+    // the small host arrays of all sub-batches go through the pinned ring: it must not wrap while copies queued on another stream
+    // have not run yet
+    IMCOM_HIP_CHECK(hipStreamSynchronize(main));
+    ctx->pin_used = 0;
+    hipEvent_t fork = ctx->sync_events[2];
+    IMCOM_HIP_CHECK(hipEventRecord(fork, main));
+    struct Restore {  // whatever path leaves this scope: the caller's stream is back and nothing runs on the others
+        imcom_ctx *c;
+        hipStream_t m;
+        int k;
+        ~Restore() { c->stream = m; for (int q = 0; q + 1 < k; q++) hipStreamSynchronize(c->sub_streams[q]); }
+    } restore{ctx, main, nsub};
+    size_t at = base;
+    int rc = IMCOM_OK;
+    for (int q = 0; q < nsub && rc == IMCOM_OK; q++) {
+        EigenJob &j = jobs[q];
+        ctx->stream = q == 0 ? main : ctx->sub_streams[q - 1];
+        if (q > 0) IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, fork, 0));
+        ctx->ws_used = at;  // every sub-batch in a share of its own: nothing one hands back is reused by another while it runs
+        at = align_up(at, 256) + solve_eigen_ws(j.batch, np, mp, m);
+        j.limit = at;
+        rc = eigen_enqueue(ctx, j, ldn, m, np, mp, kappaC, nv, ucmin, smax, nbis, false);
+    }
+    for (int q = 0; q < nsub && rc == IMCOM_OK; q++) {
+        ctx->stream = q == 0 ? main : ctx->sub_streams[q - 1];
+        rc = eigen_finish(ctx, jobs[q], ldn, m, np, mp, kappaC, nv, ucmin, smax, nbis);
+        if (rc == IMCOM_OK && q > 0) {  // join: the caller's stream goes on when the sub-batch's T has been stored
+            IMCOM_HIP_CHECK(hipEventRecord(ctx->sync_events[2 + q], ctx->stream));
+            IMCOM_HIP_CHECK(hipStreamWaitEvent(main, ctx->sync_events[2 + q], 0));
+        }
+    }
+    ctx->stream = main;
+    ctx->ws_used = at;
+    return rc;
 }
 
 static size_t solve_eigen_ws(int batch, int np, int mp, int m)
@@ -724,11 +855,20 @@ static size_t solve_eigen_ws(int batch, int np, int mp, int m)
     return big + (size_t)batch * m * 8 + (size_t)batch * 64 + std::max(basis, eigen_fallback_bytes(1, np, mp, m)) + 65536;
 }
 
+// all sub-batches of a call (each in a share of its own)
+static size_t solve_eigen_ws_total(int batch, int np, int mp, int m)
+{
+    const int nsub = eigen_split(batch, np);
+    size_t t = 0;
+    for (int q = 0; q < nsub; q++) t = align_up(t, 256) + solve_eigen_ws((int)((long)batch * (q + 1) / nsub) - (int)((long)batch * q / nsub), np, mp, m);
+    return t + 4096;
+}
+
 // Device workspace imcom_solve_eigen_resident takes for a batch (what a planner adds to its own buffers; no device call is made)
 extern "C" int imcom_solve_eigen_workspace(int batch, int ldn, int ldm, int m, size_t *bytes)
 {
     IMCOM_REQUIRE(batch >= 1 && ldn >= NB && ldn % NB == 0 && ldm >= NB && ldm % NB == 0 && m >= 1 && m <= ldm && bytes, "bad sizes (ldn, ldm multiples of 128)");
-    *bytes = solve_eigen_ws(batch, ldn, ldm, m);
+    *bytes = solve_eigen_ws_total(batch, ldn, ldm, m);
     return IMCOM_OK;
 }
 
@@ -749,7 +889,7 @@ extern "C" int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ld
     const bool host = memspace == IMCOM_MEM_HOST;
     const int np = (int)align_up((size_t)std::max(nmax, 1), NB), mp = (int)align_up((size_t)m, NB);
     const size_t szA = (size_t)batch * ldn * ldn, szB = (size_t)batch * m * ldn, szM = (size_t)batch * m;
-    size_t total = solve_eigen_ws(batch, np, mp, m);
+    size_t total = solve_eigen_ws_total(batch, np, mp, m);
     if (host) total += szA * 8 + szB * 8 + szB * 4 + szM * 12 + 4096;
     IMCOM_TRY(ws_reserve(ctx, total));
     const double *A_d = A, *B_d = mBhalf;
@@ -791,6 +931,6 @@ extern "C" int imcom_solve_eigen_resident(imcom_ctx *ctx, int batch, const int *
         nmax = std::max(nmax, n[s]);
         info[s] = 0;
     }
-    IMCOM_TRY(ws_reserve(ctx, solve_eigen_ws(batch, ldn, ldm, m)));
+    IMCOM_TRY(ws_reserve(ctx, solve_eigen_ws_total(batch, ldn, ldm, m)));
     return solve_eigen_core(ctx, batch, n, ldn, m, ldn, ldm, A, Bt, nullptr, C, kappaC, nv, ucmin, smax, nbis, Tt, nullptr, UC, Sigma, kappa, nmax, info);
 }

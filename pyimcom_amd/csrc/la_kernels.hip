@@ -462,7 +462,10 @@ __device__ __forceinline__ void taper_factors(int iy, int ix, int n2f, int fade,
 // exposures would not leave room in LDS), four row groups per block.
 // The per-exposure sums ride in registers while the exposure index of the rows stays the same (pixels are ordered
 // InStamp by InStamp, exposure-major inside) and are flushed to LDS when it changes.
-constexpr int EPI_U = 4;  // rows in flight per thread
+#ifndef IMCOM_EPI_U
+#define IMCOM_EPI_U 4
+#endif
+constexpr int EPI_U = IMCOM_EPI_U;  // rows in flight per thread
 
 template <int CPT>
 __global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__ Tt, int ldn, int ldm, int m,

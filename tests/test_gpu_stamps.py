@@ -183,6 +183,7 @@ def test_alternative_code_paths_in_subprocess():
     # __graft_entry__.build() makes the developer library: its absence is a broken build, not a reason to pass with half the test
     assert os.path.exists(dev_lib), f"{dev_lib} is missing: run `make -C pyimcom_amd/csrc DEV=1` (or __graft_entry__.build())"
     env.update(IMCOM_HIP_LIB=dev_lib, IMCOM_EIGH="jacobi", IMCOM_BUILD_A="window")
+    env.update(IMCOM_EIGEN_SPLIT="2")  # the Eigen kernel's sub-batches on streams of their own (default from 192 stamps on)
     code = ("import dataclasses; from pyimcom_amd import synth; from tests import parity as smoke; "
             "smoke.check_batch(synth.CONFIGS['small'], 2); "
             "smoke.check_batch(dataclasses.replace(synth.CONFIGS['tiny'], kernel='Eigen'), 2); print('alt paths ok')")
