@@ -62,13 +62,58 @@ def stamp_config(cfg, psfgrp, n_inimage, flat_penalty, name="block"):
                           sigmamax=float(cfg.sigmamax), flat_penalty=float(flat_penalty), n_inframe=int(cfg.n_inframe), n_out=targets)
 
 
-def input_psf_groups(blk, psfgrp, device, ctx=None):
-    """PSFGrp._build_inpsfgrp for the 2x2 groups of InStamps (psfutil.py:797-851), on demand: returns (count, expo, provider)
-    with count[(gj, gi)] = number of exposures with pixels in the group, expo[(gj, gi)] = their block indices, and
-    ``provider(keys)`` -> device tensor [sum of the keys' counts, nsamp, nsamp] of sampled PSFs: the host fetches the groups'
-    PSF images at their computation points and evaluates the sampling positions (file broker, WCS: InImage.get_psf_pos,
-    outpix2world2inpix), uploads both, and the sampling + cut-out + normalisation (psfutil.py:709-795, 650-656) run on the
-    device in one call.  Nothing is read back; a group is fetched when a batch of stamps first needs it (BlockTables)."""
+class _HostAhead:
+    """The host half of a PSF group -- the reference's own work: the PSF file broker (InImage.get_psf_pos) and the WCS evaluation
+    of the nsamp^2 sampling positions (outpix2world2inpix, psfutil.py:751-771) -- for the groups the coming batches will need,
+    on worker threads while the GPU is busy with the current batch.  ``threads=1`` (default): ONE worker, which then makes every
+    call into the block's objects (the main thread hands on-demand requests to it too), so objects that are not thread-safe
+    -- wcslib structures behind astropy WCS -- are never entered from two threads; more workers only for callers whose
+    ``inimages`` are (``bench.py``'s duck-typed block: plain numpy).  At most ``ahead`` groups are held ready (21 MB each at
+    six exposures)."""
+
+    def __init__(self, work, threads=1, ahead=48):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.work, self.ahead = work, max(1, int(ahead))
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(threads)), thread_name_prefix="imcom-psf")
+        self.futures, self.queue = {}, []
+
+    def schedule(self, keys):
+        """The order in which groups will first be needed (from the block's plan)."""
+        self.queue = [k for k in dict.fromkeys(keys) if k not in self.futures]
+        self._top_up()
+
+    def _top_up(self):
+        while self.queue and len(self.futures) < self.ahead:
+            k = self.queue.pop(0)
+            if k not in self.futures:
+                self.futures[k] = self.pool.submit(self.work, k)
+
+    def get(self, key):
+        f = self.futures.pop(key, None)
+        if f is None:  # not foreseen (a group that comes back after its spectra were dropped): still on a worker thread
+            if key in self.queue:
+                self.queue.remove(key)
+            f = self.pool.submit(self.work, key)
+        out = f.result()
+        self._top_up()
+        return out
+
+    def close(self):
+        for f in self.futures.values():
+            f.cancel()
+        self.pool.shutdown(wait=True)
+        self.futures, self.queue = {}, []
+
+
+def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1):
+    """PSFGrp._build_inpsfgrp for the 2x2 groups of InStamps (psfutil.py:797-851), on demand: returns (count, expo, provider,
+    ahead) with count[(gj, gi)] = number of exposures with pixels in the group, expo[(gj, gi)] = their block indices,
+    ``provider(keys)`` -> device tensor [sum of the keys' counts, nsamp, nsamp] of sampled PSFs, and ``ahead`` the _HostAhead that
+    prepares the host half of coming groups (``ahead.schedule(keys in the order they will be needed)``): the host fetches the
+    groups' PSF images at their computation points and evaluates the sampling positions (file broker, WCS: InImage.get_psf_pos,
+    outpix2world2inpix), the provider uploads both, and the sampling + cut-out + normalisation (psfutil.py:709-795, 650-656) run
+    on the device in one call.  Nothing is read back; a group is fetched when a batch of stamps first needs it (BlockTables)."""
     import torch
 
     from . import psfs
@@ -92,17 +137,29 @@ def input_psf_groups(blk, psfgrp, device, ctx=None):
                 count[(gj, gi)], expo[(gj, gi)] = len(expos), expos
     circ, norm = bool(blk.cfg.psf_circ), bool(blk.cfg.psf_norm)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).pin_memory().to(device, non_blocking=True)  # noqa: E731
+    oversamp = float(psfgrp.oversamp)
+
+    def host_half(key):
+        """PSF images and sampling positions of one group: [(image, yxco)] per exposure of the group (host arrays)."""
+        gj, gi = key
+        p0 = np.array(blk.instamps[2 * gj][2 * gi].psf_compute_point_pix, dtype=np.float64)
+        world = blk.outwcs.all_pix2world(np.array([p0]), 0)[0]
+        out = []
+        for e in expo[key]:
+            im = blk.inimages[e]
+            img = np.asarray(im.get_psf_pos(world, use_shortrange=True), dtype=np.float64)
+            d = (np.asarray(im.outpix2world2inpix(xy + p0)) - np.asarray(im.outpix2world2inpix(p0[None]))) * oversamp
+            out.append((img, np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)])))
+        return out
+
+    ahead = _HostAhead(host_half, host_threads)
 
     def provider(keys):
         imgs, yxco = [], []
-        for gj, gi in keys:
-            p0 = np.array(blk.instamps[2 * gj][2 * gi].psf_compute_point_pix, dtype=np.float64)
-            world = blk.outwcs.all_pix2world(np.array([p0]), 0)[0]
-            for e in expo[(gj, gi)]:
-                im = blk.inimages[e]
-                imgs.append(np.asarray(im.get_psf_pos(world, use_shortrange=True), dtype=np.float64))
-                d = (np.asarray(im.outpix2world2inpix(xy + p0)) - np.asarray(im.outpix2world2inpix(p0[None]))) * float(psfgrp.oversamp)
-                yxco.append(np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)]))
+        for key in keys:
+            for img, yx in ahead.get(key):
+                imgs.append(img)
+                yxco.append(yx)
         out = torch.empty((len(imgs), ns, ns), dtype=torch.float64, device=device)
         shapes = {}
         for q, im in enumerate(imgs):  # PSF images of one size are sampled together (normally all of them)
@@ -114,7 +171,7 @@ def input_psf_groups(blk, psfgrp, device, ctx=None):
             out[torch.as_tensor(idx, device=device)] = got
         return out
 
-    return count, expo, provider
+    return count, expo, provider, ahead
 
 
 def target_psfs(cfg, psfgrp, device, ctx=None):
@@ -129,7 +186,8 @@ def target_psfs(cfg, psfgrp, device, ctx=None):
     return psfs.sample_psf(imgs, ns, None, bool(cfg.psf_circ), bool(cfg.psf_norm), ctx)
 
 
-def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None, ctx=None):
+def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None, ctx=None,
+                        host_threads=1):
     """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  The stamps are those of the
     reference's loop: the window ``blk.j_st_min .. j_st_max, i_st_min .. i_st_max`` of Block._handle_postage_pad (coadd.py:1808-1838;
     default: all n1P x n1P) in cells of 2 x 2, stopping after ``blk.nrun`` stamps when the block carries one (cfg.stoptile,
@@ -138,8 +196,10 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     ``finalize=False`` skips the boundary recovery of coadd.py:2163-2181.  ``batch``: stamps per pass (default: sized
     from the device memory and the table arena, blockrun.plan_block); ``table_capacity``: overlap tables kept resident
     (default: the whole block's, or a third of the free device memory); ``ctx``: the library context to run on (default: the
-    process-wide one of the device).  Returns the ``BlockMaps``."""
-    from .blockrun import coadd_block
+    process-wide one of the device).  The host half of the PSF groups (PSF images, WCS evaluation of the sampling positions) of
+    the coming batches is prepared on ``host_threads`` worker thread(s) while the GPU works on the current one (_HostAhead; one
+    thread unless the block's ``inimages`` may be entered from several).  Returns the ``BlockMaps``."""
+    from .blockrun import coadd_block, plan_block, stamp_groups
     from .select import InStampPool
     from .stamps import BlockTables
 
@@ -152,7 +212,7 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
         if hasattr(cfg, k):
             setattr(scfg, k, getattr(cfg, k))
     pool = InStampPool([(st.x_val, st.y_val, st.data, st.pix_cumsum) for row in blk.instamps for st in row], scfg.n_inframe, device=device)
-    count, expo, provider = input_psf_groups(blk, psfgrp, device, ctx)
+    count, expo, provider, ahead = input_psf_groups(blk, psfgrp, device, ctx, host_threads)
     target = target_psfs(cfg, psfgrp, device, ctx)
     amp = getattr(cfg, "amp_penalty", None)
     amp = None if amp is None or 0.0 in tuple(amp) else (float(amp[0]), float(amp[1]) * float(psfgrp.oversamp))  # psfutil.py:661-671
@@ -165,8 +225,15 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
         from .blockrun import reference_stamp_order
 
         stamps = reference_stamp_order(*window, nrun=getattr(blk, "nrun", None))
-    maps = coadd_block(scfg, pool, tables, n1P, int(blk.n_inimage), batch=batch, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
-                       postage_pad=int(getattr(cfg, "postage_pad", 0)), stamps=stamps, origin=(window[0], window[2]))
+    # the passes first: their order tells which groups' host halves to prepare ahead of the device
+    chunks = plan_block(scfg, pool, tables, n1P, batch, stamps=stamps)
+    nst = n1P + 2
+    ahead.schedule([g for c in chunks for j, i in c for g in stamp_groups(j, i, nst) if g in count])
+    try:
+        maps = coadd_block(scfg, pool, tables, n1P, int(blk.n_inimage), chunks=chunks, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
+                           postage_pad=int(getattr(cfg, "postage_pad", 0)), origin=(window[0], window[2]))
+    finally:
+        ahead.close()
     blk.out_map, blk.T_weightmap = maps.out_map.cpu().numpy(), maps.T_weightmap.cpu().numpy()
     outmaps = getattr(cfg, "outmaps", "USKTN")
     for c, name, key in (("U", "UC_map", "UC"), ("S", "Sigma_map", "Sigma"), ("K", "kappa_map", "kappa"), ("T", "Tsum_map", "Tsum"), ("N", "Neff_map", "Neff")):
