@@ -296,6 +296,18 @@ int imcom_coadd_epilogue(imcom_ctx *ctx, int batch, const int *n_host, int ldn, 
                          int n2f, int fade, int n2, float *Tt, const float *indata, int n_inframe,
                          const int *expo, int n_expo, float *outimage, double *Tsum_stamp,
                          double *Tsum_inpix, double *Neff);
+/* imcom_solve_chol_resident and imcom_coadd_epilogue in ONE call, for fade == 0 (with fade > 0 the map tapers of
+ * coadd.py:1118-1122 come in between: use the three calls): CholKernel (lakernel.py:281-394) on the device layouts, then
+ * OutStamp._perform_coaddition (coadd.py:1294-1363) for the same stamps.  With one kappa node the coaddition's sums -- per
+ * exposure sum_j T[a][j] and per input frame sum_j T[a][j] indata[j] -- are taken from the tiles of T while the backward
+ * launches of the solve still hold them, so T (20 MB per stamp) is not read again; with several nodes the stand-alone
+ * epilogue runs inside the call.  Arguments as in the two entries; all pointers DEVICE except n_host / C / kappaC / info. */
+int imcom_solve_chol_resident_coadd(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm,
+                                    const double *A, const double *Bt, const double *C, const double *kappaC, int nv,
+                                    double ucmin, double smax, float *Tt, float *UC, float *Sigma, float *kappa,
+                                    int *info, int n2f, int fade, int n2, const float *indata, int n_inframe,
+                                    const int *expo, int n_expo, float *outimage, double *Tsum_stamp,
+                                    double *Tsum_inpix, double *Neff);
 /* OutStamp.trapezoid (coadd.py:1222-1292) on [batch][n2f][n2f] float32 maps (kappa, Sigma, UC). */
 int imcom_trapezoid_f32(imcom_ctx *ctx, float *maps, long nmaps, int n2f, int fade);
 /* OutStamp._build_system_matrices, coadd.py:1104-1107: after the "Iterative" kernel (whose U/C and Sigma can come

@@ -85,6 +85,8 @@ SIGNATURES = {
     "imcom_build_B": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(TableGeom), _vp, _i, _vp, _vp, _i, _i, _vp],
     "imcom_solve_chol_resident": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp],
     "imcom_coadd_epilogue": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "imcom_solve_chol_resident_coadd": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp,
+                                        _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "imcom_trapezoid_f32": [_vp, _vp, _l, _i, _i],
     "imcom_clamp_min_f32": [_vp, _vp, _l, C.c_float],
     "imcom_sample_psf": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i],

@@ -186,10 +186,33 @@ static int lambda_min_group(imcom_ctx *ctx, const double *A, const int *n_host, 
 
 // before_solve (optional): called once, after the first factorisation's launches have been queued and before the first launch
 // that reads Bt -- the host-buffer entry uploads -B/2 there, behind the factorisation instead of in front of it.
+// what the coaddition needs besides T (coadd.py:1294-1363), for the entries that solve and coadd in one call
+struct CoaddArgs {
+    int n2f, fade, n2, n_inframe, n_expo;
+    const float *indata;
+    const int *expo;
+    float *outimage;
+    double *Tsum_stamp, *Tsum_inpix, *Neff;
+};
+
+static bool coadd_fusable(int nv, int fade)
+{
+    static const bool off = getenv("IMCOM_SOLVE_UNFUSED") != nullptr || getenv("IMCOM_EPILOGUE_UNFUSED") != nullptr;
+    return !off && nv == 1 && fade == 0;  // one kappa node: T is final in the backward launches; no taper to apply to it first
+}
+
+static size_t coadd_fuse_bytes(int batch, int Np, int m, int mp, int nv, const CoaddArgs *co)
+{
+    if (!co) return 0;
+    size_t t = (size_t)batch * m * co->n_expo * 8 + 512;  // Tsum_image
+    if (coadd_fusable(nv, co->fade)) t += (size_t)batch * 2 * (Np / NB) * (co->n_expo + co->n_inframe) * mp * 8 + 512;
+    return t;
+}
+
 static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m, int mp, const double *A,
                      const double *Bt, const double *C_host, const double *kappaC_host, int nv, double ucmin,
                      double smax, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host,
-                     const std::function<int()> &before_solve = nullptr)
+                     const std::function<int()> &before_solve = nullptr, const CoaddArgs *co = nullptr)
 {
     bool bt_ready = !before_solve;
     const int nbmax_all = Np / NB;
@@ -217,6 +240,17 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     static const bool unfused_solve = getenv("IMCOM_SOLVE_UNFUSED") != nullptr;
     double *colsums = (nv == 1 && !unfused_solve) ? (double *)ws_take(ctx, (size_t)batch * 2 * nbmax_all * mp * 8 * 2) : nullptr;
     double *Dpart = colsums, *Npart = colsums ? colsums + (size_t)batch * 2 * nbmax_all * mp : nullptr;
+    // the coaddition of the same call: its sums ride in the backward launches when T is final there (else the stand-alone epilogue)
+    CoaddFuse cfuse;
+    double *Tsum_image = nullptr;
+    if (co) {
+        Tsum_image = (double *)ws_take(ctx, (size_t)batch * m * co->n_expo * 8);
+        if (colsums && coadd_fusable(nv, co->fade)) {
+            cfuse.indata = co->indata; cfuse.expo = co->expo; cfuse.n_inframe = co->n_inframe; cfuse.n_expo = co->n_expo;
+            cfuse.Epart = (double *)ws_take(ctx, (size_t)batch * 2 * nbmax_all * (co->n_expo + co->n_inframe) * mp * 8);
+        }
+        if (!Tsum_image || (colsums && coadd_fusable(nv, co->fade) && !cfuse.Epart)) { set_error("internal: workspace plan too small (coaddition)"); return IMCOM_ERR_NOMEM; }
+    }
     if (!L || !Dinv || !Y || !dshift || !ints || !inc || !dbl || !kappaC_dev || (nv > 1 && (!Dp || !Npq || !W)) || (pbytes && !partial) || (nv == 1 && !unfused_solve && !colsums)) {
         set_error("internal: workspace plan too small");
         return IMCOM_ERR_NOMEM;
@@ -282,7 +316,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                 if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nblk_dev, false)); }
             }
             for (int k = nbmax - 1; k >= 0; k--) {
-                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, nbmax, eb, nblk_dev, n_dev, Dfused, partial, parts_solve, Npart, Tt)); }
+                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, nbmax, eb, nblk_dev, n_dev, Dfused, partial, parts_solve, Npart, Tt, cfuse.Epart ? &cfuse : nullptr)); }
                 if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nblk_dev, true)); }
             }
         }
@@ -331,6 +365,15 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             }
         if (!any) break;
         IMCOM_REQUIRE(attempt <= nv + 1, "repair loop did not terminate");
+    }
+    if (co) {
+        ProfScope ps(ctx, "epilogue");
+        if (cfuse.Epart)
+            IMCOM_TRY(launch_coadd_from_partials(ctx, batch, n_dev, nblk_dev, Np, m, mp, co->n2, cfuse, co->outimage, Tsum_image, co->Tsum_stamp, co->Tsum_inpix,
+                                                 co->Neff));
+        else
+            IMCOM_TRY(launch_epilogue(ctx, batch, n_dev, Np, m, mp, co->n2f, co->fade, co->n2, Tt, co->indata, co->n_inframe, co->expo, co->n_expo, co->outimage,
+                                      Tsum_image, co->Tsum_stamp, co->Tsum_inpix, co->Neff));
     }
     return IMCOM_OK;
 }
@@ -888,6 +931,27 @@ int imcom_solve_chol_resident(imcom_ctx *ctx, int batch, const int *n_host, int 
     IMCOM_REQUIRE(nv <= CHOL_MAXNV, "nv=%d kappa nodes: at most %d", nv, CHOL_MAXNV);
     IMCOM_TRY(ws_reserve(ctx, chol_core_bytes(batch, ldn, m, ldm, nv)));
     return chol_core(ctx, batch, n_host, ldn, m, ldm, A, Bt, C_host, kappaC_host, nv, ucmin, smax, Tt, UC, Sigma, kappa, info_host);
+}
+
+// CholKernel on the device layouts followed by the coaddition of the same stamps, in one call: with one kappa node and fade 0
+// the coaddition's sums are taken from the tiles of T while the backward launches still hold them (no pass over T afterwards);
+// otherwise the call is imcom_solve_chol_resident + the map tapers' caller + imcom_coadd_epilogue back to back.
+int imcom_solve_chol_resident_coadd(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm, const double *A, const double *Bt,
+                                    const double *C_host, const double *kappaC_host, int nv, double ucmin, double smax, float *Tt, float *UC,
+                                    float *Sigma, float *kappa, int *info_host, int n2f, int fade, int n2, const float *indata, int n_inframe,
+                                    const int *expo, int n_expo, float *outimage, double *Tsum_stamp, double *Tsum_inpix, double *Neff)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n_host && A && Bt && C_host && kappaC_host && Tt && UC && Sigma && kappa && info_host, "null pointer");
+    IMCOM_REQUIRE(indata && expo && outimage && Tsum_stamp && Tsum_inpix && Neff, "null pointer (coaddition)");
+    IMCOM_REQUIRE(ldn >= NB && ldn % NB == 0 && ldm % NB == 0 && m >= 1 && m <= ldm && nv >= 1, "ldn=%d / ldm=%d must be multiples of %d", ldn, ldm, NB);
+    IMCOM_REQUIRE(nv <= CHOL_MAXNV, "nv=%d kappa nodes: at most %d", nv, CHOL_MAXNV);
+    IMCOM_REQUIRE(m == n2f * n2f && n_inframe >= 1 && n_expo >= 1 && fade >= 0 && n2 >= 1, "bad sizes (coaddition)");
+    IMCOM_REQUIRE(fade == 0, "imcom_solve_chol_resident_coadd: fade = %d -- the map tapers of coadd.py:1118-1122 come between the solve and the coaddition: "
+                             "call imcom_solve_chol_resident, imcom_trapezoid_f32, imcom_coadd_epilogue", fade);
+    const CoaddArgs co{n2f, fade, n2, n_inframe, n_expo, indata, expo, outimage, Tsum_stamp, Tsum_inpix, Neff};
+    IMCOM_TRY(ws_reserve(ctx, chol_core_bytes(batch, ldn, m, ldm, nv) + coadd_fuse_bytes(batch, ldn, m, ldm, nv, &co)));
+    return chol_core(ctx, batch, n_host, ldn, m, ldm, A, Bt, C_host, kappaC_host, nv, ucmin, smax, Tt, UC, Sigma, kappa, info_host, nullptr, &co);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "launchers.h"
 #include "mma_dma.h"
 
 namespace imcom {
@@ -239,6 +240,74 @@ __device__ __forceinline__ void tile_col_sumsq(const f64x4 (&acc)[4][MMA_NJ], do
     }
 }
 
+// The coaddition's sums from the tile of T a workgroup has just finished (accumulators in the TRI row map): for every column a of
+// the tile, sum over the tile's rows j of float(T[j][a]) w_q[j] -- w_q the indicator of exposure q, then the pixel values of input
+// frame f -- per wave row, so that launch_coadd_from_partials can add the pieces in a fixed order and the pass of the stand-alone
+// epilogue over T (20 MB per stamp) is not needed.  T enters as the float32 the reference holds (lakernel.py:96).
+__device__ __forceinline__ void tile_coadd_partials(const f64x4 (&acc)[4][MMA_NJ], int s, int k, int c, int ldn, int ldm, int ns, const float *__restrict__ indata,
+                                                    const int *__restrict__ expo, int n_inframe, int n_expo, double *__restrict__ Epart)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / MMA_WN, wn = wave % MMA_WN;
+    const int nacc = n_expo + n_inframe;
+    double *out = Epart + (((long)s * 2 * (ldn / NB) + 2 * k + wm) * nacc) * ldm + c * NB + wn * (16 * MMA_NJ) + (lane & 15);
+    const int g0 = k * NB + wm * 16 + (lane >> 4);  // row of (i, r): g0 + 32 i + 4 r
+    const int *ex = expo + (long)s * ldn;
+    // (the engine keeps 64 accumulator registers per thread alive here and two workgroups per CU need the kernel below 128: the
+    // passes re-read the rows' exposure / pixel value instead of holding them, and the loops over passes are not unrolled)
+#pragma unroll 1
+    for (int e0 = 0; e0 < n_expo; e0 += 2) {  // two exposures per pass over the accumulators
+        double v0[MMA_NJ], v1[MMA_NJ];
+#pragma unroll
+        for (int j = 0; j < MMA_NJ; j++) v0[j] = v1[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int g = g0 + 32 * i + 4 * r;
+                const int d = (g < ns ? ex[g] : -1) - e0;  // rows beyond the stamp's pixels: no exposure
+#pragma unroll
+                for (int j = 0; j < MMA_NJ; j++) {
+                    const double t = (double)(float)acc[i][j][r];
+                    v0[j] += d == 0 ? t : 0.0;
+                    v1[j] += d == 1 ? t : 0.0;
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < MMA_NJ; j++) {
+            double t0 = v0[j], t1 = v1[j];
+            t0 += __shfl_xor(t0, 16, 64); t1 += __shfl_xor(t1, 16, 64);
+            t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64);
+            if (lane < 16) {
+                out[(long)e0 * ldm + j * 16] = t0;
+                if (e0 + 1 < n_expo) out[(long)(e0 + 1) * ldm + j * 16] = t1;
+            }
+        }
+    }
+#pragma unroll 1
+    for (int f = 0; f < n_inframe; f++) {
+        double v[MMA_NJ];
+#pragma unroll
+        for (int j = 0; j < MMA_NJ; j++) v[j] = 0.0;
+        const float *xin = indata + ((long)s * n_inframe + f) * ldn;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int g = g0 + 32 * i + 4 * r;
+                const double x = g < ns ? (double)xin[g] : 0.0;
+#pragma unroll
+                for (int j = 0; j < MMA_NJ; j++) v[j] += (double)(float)acc[i][j][r] * x;
+            }
+#pragma unroll
+        for (int j = 0; j < MMA_NJ; j++) {
+            double t = v[j];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (lane < 16) out[(long)(n_expo + f) * ldm + j * 16] = t;
+        }
+    }
+}
+
 __global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_fwd_kernel(const double *__restrict__ L,
                                                            const double *__restrict__ Bt,
                                                            double *__restrict__ Y, int ldn, int ldm,
@@ -270,12 +339,14 @@ __global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_fwd_kernel(co
     }
 }
 
-__global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_bwd_kernel(const double *__restrict__ L,
+__global__ __launch_bounds__(MMA_THREADS, MMA_WAVES == 8 ? 4 : MMA_MINWAVES) void solve_bwd_kernel(const double *__restrict__ L,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk,
                                                            const int *__restrict__ n, const double *__restrict__ Dinv,
                                                            const double *__restrict__ partial, int nparts,
-                                                           double *__restrict__ Npart, float *__restrict__ Tt)
+                                                           double *__restrict__ Npart, float *__restrict__ Tt,
+                                                           const float *__restrict__ co_indata, const int *__restrict__ co_expo,
+                                                           int co_n_inframe, int co_n_expo, double *__restrict__ co_Epart)
 {
     __shared__ __attribute__((aligned(16))) double smem[DMA_LDS_DOUBLES];
     int s, c;
@@ -300,6 +371,7 @@ __global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_bwd_kernel(co
             tile_col_sumsq(acc, Npart + ((long)s * 2 * (ldn / NB) + 2 * k) * ldm + c * NB, ldm);
             float *To = Tt + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
             IMCOM_FOR_ACC_TRI(row, col, v, { To[(long)row * ldm + col] = (float)v; })
+            if (co_Epart) tile_coadd_partials(acc, s, k, c, ldn, ldm, n[s], co_indata, co_expo, co_n_inframe, co_n_expo, co_Epart);
         }
     }
 }
@@ -510,15 +582,21 @@ int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *
 }
 
 int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int nbmax, int batch,
-                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts, double *Npart, float *Tt)
+                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts, double *Npart, float *Tt,
+                     const CoaddFuse *cf)
 {
     dim3 grid(ldm / NB, batch);
+    const bool co = cf && cf->Epart && Npart && Dinv;  // (the sums are taken where the tile of T is final: the fused launches)
+    const float *ci = co ? cf->indata : nullptr;
+    const int *ce = co ? cf->expo : nullptr;
+    const int cf_ = co ? cf->n_inframe : 0, cn = co ? cf->n_expo : 0;
+    double *cp = co ? cf->Epart : nullptr;
     if (nparts > 1 && nbmax - 1 - k >= nparts) {
         hipLaunchKernelGGL(solve_partial_kernel<true>, dim3(ldm / NB, nparts, batch), dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, nparts, partial);
         IMCOM_TRY(check_launch("solve_partial_kernel"));
-        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, Npart, Tt);
+        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, Npart, Tt, ci, ce, cf_, cn, cp);
     } else
-        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, Npart, Tt);
+        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, Npart, Tt, ci, ce, cf_, cn, cp);
     return check_launch("solve_bwd_kernel");
 }
 

@@ -6,6 +6,7 @@
 // (lakernel1, lsolve_sps, build_reduced_T_wrap), coadd.py:1222-1292 (trapezoid), 1320-1354
 // (_perform_coaddition).
 #include "common.h"
+#include "launchers.h"
 
 namespace imcom {
 
@@ -594,6 +595,36 @@ __global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__
     }
 }
 
+// The tail of coadd_epilogue_kernel (coadd.py:1329-1354) from the per-block-row sums the backward launches left (tile_coadd_partials,
+// gemm_f64.hip): pieces added in the order block row 0 .. nblk - 1, lower wave row first.  fade == 0 only (nothing to taper).
+__global__ __launch_bounds__(256) void coadd_from_partials_kernel(const double *__restrict__ Epart, int ldn, int ldm, int m, const int *__restrict__ n,
+                                                                  const int *__restrict__ nblk, int n_inframe, int n_expo,
+                                                                  float *__restrict__ outimage, double *__restrict__ Tsum_image_part,
+                                                                  double *__restrict__ Tsum_inpix, double *__restrict__ Neff)
+{
+    const int s = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= m) return;
+    const int nacc = n_expo + n_inframe, np = 2 * nblk[s];
+    const double *base = Epart + (long)s * 2 * (ldn / NB) * nacc * ldm + a;
+    auto total = [&](int q) {
+        double v = 0.0;
+        for (int kk = 0; kk < np; kk++) v += base[((long)kk * nacc + q) * ldm];
+        return v;
+    };
+    double tot = 0.0, sabs = 0.0, sq = 0.0;
+    double *ti = Tsum_image_part + ((long)s * m + a) * n_expo;
+    for (int e = 0; e < n_expo; e++) {
+        const double v = total(e);
+        ti[e] = v;
+        tot += v;
+        sabs += fabs(v);
+    }
+    for (int e = 0; e < n_expo; e++) { const double t = ti[e] / sabs; sq += t * t; }
+    Tsum_inpix[(long)s * m + a] = tot;
+    Neff[(long)s * m + a] = 1.0 / sq;
+    for (int f = 0; f < n_inframe; f++) outimage[((long)s * n_inframe + f) * m + a] = (float)total(n_expo + f);
+}
+
 __global__ __launch_bounds__(256) void tsum_stamp_kernel(const double *__restrict__ Tsum_image, int m, int n_expo,
                                                          int n2, double *__restrict__ Tsum_stamp)
 {
@@ -719,6 +750,16 @@ int launch_epilogue(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, int m,
     }
     IMCOM_TRY(check_launch("coadd_epilogue_kernel"));
     hipLaunchKernelGGL(tsum_stamp_kernel, dim3(n_expo, batch), dim3(256), 0, ctx->stream, Tsum_image, m, n_expo, n2, Tsum_stamp);
+    return check_launch("tsum_stamp_kernel");
+}
+
+int launch_coadd_from_partials(imcom_ctx *ctx, int batch, const int *n_dev, const int *nblk_dev, int ldn, int m, int ldm, int n2, const CoaddFuse &cf,
+                               float *outimage, double *Tsum_image, double *Tsum_stamp, double *Tsum_inpix, double *Neff)
+{
+    hipLaunchKernelGGL(coadd_from_partials_kernel, dim3((m + 255) / 256, batch), dim3(256), 0, ctx->stream, cf.Epart, ldn, ldm, m, n_dev, nblk_dev, cf.n_inframe,
+                       cf.n_expo, outimage, Tsum_image, Tsum_inpix, Neff);
+    IMCOM_TRY(check_launch("coadd_from_partials_kernel"));
+    hipLaunchKernelGGL(tsum_stamp_kernel, dim3(cf.n_expo, batch), dim3(256), 0, ctx->stream, Tsum_image, m, cf.n_expo, n2, Tsum_stamp);
     return check_launch("tsum_stamp_kernel");
 }
 

@@ -15,8 +15,20 @@ int launch_chol_trsm(imcom_ctx *ctx, double *L, const double *Dinv, int ldn, int
 int launch_solve_fwd(imcom_ctx *ctx, const double *L, const double *Bt, double *Y, int ldn, int ldm, int k,
                      int batch, int bbatch, const int *nblk, const int *n, const double *Dinv, double *partial, int nparts,
                      double *Dpart);  // Dinv != null: Linv[k] applied in the same launch; Dpart: column sums of Y^2 per block row
+// The coaddition sums (coadd.py:1320-1354) riding in the backward launches: per block row and wave row of a tile, the column sums
+// sum_j T[j][a] w_q[j] over the tile's rows with w_q = the indicator of exposure q (q < n_expo) or input frame q - n_expo --
+// Epart [batch][2 ldn / 128][n_expo + n_inframe][ldm]; launch_coadd_from_partials adds them up in a fixed order.
+struct CoaddFuse {
+    const float *indata = nullptr;  // [batch][n_inframe][ldn]
+    const int *expo = nullptr;      // [batch][ldn]
+    int n_inframe = 0, n_expo = 0;
+    double *Epart = nullptr;
+};
 int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ldm, int k, int nbmax, int batch,
-                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts, double *Npart, float *Tt);
+                     const int *nblk, const int *n, const double *Dinv, double *partial, int nparts, double *Npart, float *Tt,
+                     const CoaddFuse *cf = nullptr);
+int launch_coadd_from_partials(imcom_ctx *ctx, int batch, const int *n_dev, const int *nblk_dev, int ldn, int m, int ldm, int n2, const CoaddFuse &cf,
+                               float *outimage, double *Tsum_image, double *Tsum_stamp, double *Tsum_inpix, double *Neff);
 int launch_solve_dinv(imcom_ctx *ctx, const double *Dinv, double *Y, int ldn, int ldm, int k, int batch,
                       const int *nblk, bool trans);
 int launch_probe_fill(imcom_ctx *ctx, double *p, long count, unsigned seed);

@@ -679,12 +679,15 @@ class StampBatch:
                                     _dp(self.Bt_o[o])))
 
     def solve(self):
-        """lakernel.CholKernel (lakernel.py:281-394) + the map taper of coadd.py:1118-1122."""
+        """lakernel.CholKernel (lakernel.py:281-394) + the map taper of coadd.py:1118-1122.  Cholesky with fade 0: the coaddition
+        of the same stamps rides in the call (imcom_solve_chol_resident_coadd: with one kappa node its sums are taken from the
+        tiles of T inside the backward launches) and ``coadd()`` finds it done."""
         self._stream()
+        self._coadded = set()
         for o in range(self.n_out):
-            self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o])
+            self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o], o)
 
-    def _solve_target(self, Bt, Cs, Tt, UC, Sigma, kappa, info):
+    def _solve_target(self, Bt, Cs, Tt, UC, Sigma, kappa, info, o=0):
         cfg = self.cfg
         if cfg.kernel == "Eigen":
             # lakernel.EigenKernel (lakernel.py:141-223) on the resident layouts
@@ -715,6 +718,13 @@ class StampBatch:
             Tt[:, :, : self.m] = T.transpose(1, 2)
         elif cfg.kernel != "Cholesky":
             raise NotImplementedError(f"resident path: no {cfg.kernel} kernel")
+        elif cfg.fade == 0:
+            check(lib.imcom_solve_chol_resident_coadd(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm,
+                                                      _dp(self.A), _dp(Bt), _hp(Cs), _hp(self.kappaC), len(self.kappaC),
+                                                      float(cfg.uctarget), float(cfg.sigmamax), _dp(Tt), _dp(UC), _dp(Sigma), _dp(kappa), _hp(info),
+                                                      self.n2f, 0, cfg.n2, _dp(self.indata), cfg.n_inframe, _dp(self.expo), self.n_expo,
+                                                      _dp(self.outimage_o[o]), _dp(self.Tsum_stamp_o[o]), _dp(self.Tsum_inpix_o[o]), _dp(self.Neff_o[o])))
+            self._coadded.add(o)
         else:
             check(lib.imcom_solve_chol_resident(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm,
                                             _dp(self.A), _dp(Bt), _hp(Cs), _hp(self.kappaC), len(self.kappaC),
@@ -731,7 +741,10 @@ class StampBatch:
         """OutStamp._perform_coaddition (coadd.py:1294-1363)."""
         self._stream()
         cfg = self.cfg
+        done, self._coadded = getattr(self, "_coadded", set()), set()
         for o in range(self.n_out):
+            if o in done:  # coadded inside solve()
+                continue
             check(lib.imcom_coadd_epilogue(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, self.n2f,
                                            cfg.fade, cfg.n2, _dp(self.Tt_o[o]), _dp(self.indata), cfg.n_inframe, _dp(self.expo),
                                            self.n_expo, _dp(self.outimage_o[o]), _dp(self.Tsum_stamp_o[o]), _dp(self.Tsum_inpix_o[o]),

@@ -214,3 +214,37 @@ def test_unusual_configurations(name, kw, scale):
     from tests import parity as smoke
 
     smoke.check_batch(dataclasses.replace(synth.CONFIGS["tiny"], name=name, **kw), n_stamps=3, tolT_scale=scale)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(kappaC=(1e-5, 1e-4, 1e-3)), dict(n_out=2), dict(n_expo=9, n_inframe=3)])
+def test_coaddition_inside_the_solve_equals_the_stand_alone_epilogue(kw):
+    """With fade 0 the Cholesky solve and the coaddition are one call (imcom_solve_chol_resident_coadd): with one kappa node the
+    per-exposure sums and T . indata are taken from the tiles of T inside the backward launches.  The stand-alone epilogue
+    (imcom_coadd_epilogue), run afterwards on the T the solve left, must give the same coaddition -- float64 sums of the same
+    float32 T in another order: images to a float32 ulp, weight sums to 1e-12 -- for a ragged batch, several
+    kappa nodes (the epilogue then runs inside the call), two target PSFs, nine exposures / three input frames."""
+    import dataclasses
+
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    cfg = dataclasses.replace(synth.CONFIGS["smallm"], name="fusedco", kappaC=(6e-4,), **kw)
+    assert cfg.fade == 0
+    stamps = [synth.make_stamp(cfg, 300 + i) for i in range(5)]
+    psfs, target = synth.make_psfs(cfg, max(s.n_expo for s in stamps))
+    sb = StampBatch(cfg, stamps, PSFGroupTables(psfs, target, cfg.nfft))
+    assert sb.n_out == cfg.n_out
+    sb.run()
+    torch.cuda.synchronize()
+    names = ("outimage_o", "Tsum_stamp_o", "Tsum_inpix_o", "Neff_o")
+    fused = {k: getattr(sb, k).clone() for k in names}
+    assert sb._coadded == set()  # (coadd() found the targets done and reset the marks)
+    sb.coadd()  # nothing is marked now: the stand-alone epilogue on the same T
+    torch.cuda.synchronize()
+    for k in names:
+        a, b = fused[k].double(), getattr(sb, k).double()
+        tol = 2e-7 if k == "outimage_o" else 1e-12
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()), k
+    assert float(sb.outimage_o.abs().max()) > 0

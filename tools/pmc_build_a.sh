@@ -9,6 +9,6 @@ i=0
 for set in "$@"; do
   i=$((i+1))
   echo "pass $i: $set"
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d $O/p$i -o r -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-block > /dev/null 2> $O/p$i.err || { echo "pass $i failed"; grep -m2 -i "error\|exceeds\|invalid\|not found" $O/p$i.err | cut -c1-300; continue; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d $O/p$i -o r -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-block --no-configs > /dev/null 2> $O/p$i.err || { echo "pass $i failed"; grep -m2 -i "error\|exceeds\|invalid\|not found" $O/p$i.err | cut -c1-300; continue; }
   python3 $ROOT/tools/pmc_dump.py $(find $O/p$i -name "*.db" | head -1) build_ | cut -c1-600
 done
