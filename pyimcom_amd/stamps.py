@@ -7,6 +7,7 @@ stream; every number is produced by libimcom_hip kernels through the C-ABI (incl
 """
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -679,9 +680,10 @@ class StampBatch:
                                     _dp(self.Bt_o[o])))
 
     def solve(self):
-        """lakernel.CholKernel (lakernel.py:281-394) + the map taper of coadd.py:1118-1122.  Cholesky with fade 0: the coaddition
-        of the same stamps rides in the call (imcom_solve_chol_resident_coadd: with one kappa node its sums are taken from the
-        tiles of T inside the backward launches) and ``coadd()`` finds it done."""
+        """lakernel.CholKernel (lakernel.py:281-394) + the map taper of coadd.py:1118-1122.  With IMCOM_EPILOGUE_FUSED=1 (Cholesky,
+        fade 0) the coaddition of the same stamps rides in the call (imcom_solve_chol_resident_coadd: with one kappa node its sums
+        are taken from the tiles of T inside the backward launches) and ``coadd()`` finds it done -- measured: the 2.0 ms the pass
+        over T costs per 256 cfg-2 stamps come back as 2.0 ms more in the backward launches, so it is not the default."""
         self._stream()
         self._coadded = set()
         for o in range(self.n_out):
@@ -718,7 +720,7 @@ class StampBatch:
             Tt[:, :, : self.m] = T.transpose(1, 2)
         elif cfg.kernel != "Cholesky":
             raise NotImplementedError(f"resident path: no {cfg.kernel} kernel")
-        elif cfg.fade == 0:
+        elif cfg.fade == 0 and os.environ.get("IMCOM_EPILOGUE_FUSED") == "1":
             check(lib.imcom_solve_chol_resident_coadd(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm,
                                                       _dp(self.A), _dp(Bt), _hp(Cs), _hp(self.kappaC), len(self.kappaC),
                                                       float(cfg.uctarget), float(cfg.sigmamax), _dp(Tt), _dp(UC), _dp(Sigma), _dp(kappa), _hp(info),

@@ -217,8 +217,8 @@ def test_unusual_configurations(name, kw, scale):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(kappaC=(1e-5, 1e-4, 1e-3)), dict(n_out=2), dict(n_expo=9, n_inframe=3)])
-def test_coaddition_inside_the_solve_equals_the_stand_alone_epilogue(kw):
-    """With fade 0 the Cholesky solve and the coaddition are one call (imcom_solve_chol_resident_coadd): with one kappa node the
+def test_coaddition_inside_the_solve_equals_the_stand_alone_epilogue(kw, monkeypatch):
+    """With fade 0 the Cholesky solve and the coaddition can be one call (imcom_solve_chol_resident_coadd, IMCOM_EPILOGUE_FUSED=1): with one kappa node the
     per-exposure sums and T . indata are taken from the tiles of T inside the backward launches.  The stand-alone epilogue
     (imcom_coadd_epilogue), run afterwards on the T the solve left, must give the same coaddition -- float64 sums of the same
     float32 T in another order: images to a float32 ulp, weight sums to 1e-12 -- for a ragged batch, several
@@ -230,13 +230,17 @@ def test_coaddition_inside_the_solve_equals_the_stand_alone_epilogue(kw):
     from pyimcom_amd import synth
     from pyimcom_amd.stamps import PSFGroupTables, StampBatch
 
-    cfg = dataclasses.replace(synth.CONFIGS["smallm"], name="fusedco", kappaC=(6e-4,), **kw)
+    monkeypatch.setenv("IMCOM_EPILOGUE_FUSED", "1")
+    cfg = dataclasses.replace(synth.CONFIGS["smallm"], name="fusedco", **dict(dict(kappaC=(6e-4,)), **kw))
     assert cfg.fade == 0
     stamps = [synth.make_stamp(cfg, 300 + i) for i in range(5)]
     psfs, target = synth.make_psfs(cfg, max(s.n_expo for s in stamps))
     sb = StampBatch(cfg, stamps, PSFGroupTables(psfs, target, cfg.nfft))
     assert sb.n_out == cfg.n_out
-    sb.run()
+    sb.build()
+    sb.solve()
+    assert sb._coadded == set(range(cfg.n_out))  # the call coadded every target
+    sb.coadd()
     torch.cuda.synchronize()
     names = ("outimage_o", "Tsum_stamp_o", "Tsum_inpix_o", "Neff_o")
     fused = {k: getattr(sb, k).clone() for k in names}
