@@ -27,6 +27,7 @@
 // The bisection takes the same decisions as lakernel1 except where udc or sum2 sits within rounding of its bound.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 #include "launchers.h"
@@ -154,34 +155,39 @@ __global__ __launch_bounds__(64) void tri_solve_kernel(const double *__restrict_
 // LDL^T of B + kappa I, left-looking over the last BW columns kept in registers:
 //   d_i = B_ii + kappa - sum_q l_{i,j}^2 d_j,   l_{i+t,i} = (B_{i+t,i} - sum_q l_{i+t,j} l_{i,j} d_j) / d_i   (j = i-1-q, q < BW),
 //   z_i = c_i - sum_q l_{i,j} z_j,   D = sum z_i^2 / d_i,   S = -dD/dkappa with every quantity's kappa-derivative carried along.
-// History slot q holds column j = i-1-q: dh[q], lh[q][t] = l_{j+t,j} (t = 1..BW), zh[q], and their derivatives; slots of columns
-// before the first are zero, so the sums need no guards.
+// The last BW columns live in a ring of PHYSICAL slots: column j in slot j mod BW -- dh, lh[t] = l_{j+t,j} (t = 1..BW), zh, the
+// products xh[t] = l_{j+t,j} d_j that both sums need, and the kappa-derivatives of all of them.  The rows are processed BW at a
+// time with the row's phase i mod BW a template parameter, so every slot index is a compile-time constant: the ring never moves
+// (round 3 shifted it by one slot per row: 84 register moves next to ~120 arithmetic instructions; and formed l d three times).
+// Slots of columns before the first hold d = 1 and zeros, so the sums need no guards.
 template <int B_>
 struct BandState {
-    double dh[B_], dph[B_], zh[B_], zph[B_], lh[B_][B_ + 1], lph[B_][B_ + 1];
+    double dh[B_], dph[B_], zh[B_], zph[B_], lh[B_][B_ + 1], lph[B_][B_ + 1], xh[B_][B_ + 1], xph[B_][B_ + 1];
     __device__ __forceinline__ void clear()
     {
 #pragma unroll
         for (int q = 0; q < B_; q++) {
             dh[q] = 1.0; dph[q] = 0.0; zh[q] = 0.0; zph[q] = 0.0;
 #pragma unroll
-            for (int t = 0; t <= B_; t++) { lh[q][t] = 0.0; lph[q][t] = 0.0; }
+            for (int t = 0; t <= B_; t++) { lh[q][t] = 0.0; lph[q][t] = 0.0; xh[q][t] = 0.0; xph[q][t] = 0.0; }
         }
     }
 };
 
-// one row of the sweep with derivative; bd[t] = B[i+t][i] (zero beyond the matrix), ci = c_i; returns the contributions to D and S
-template <int B_, bool FAST>
+// Row i (i mod B_ == PHI) of the sweep with derivative; bd[t] = B[i+t][i] (zero beyond the matrix), ci = c_i; adds the row's
+// contributions to D and S; the row's own column (d_i, z_i, l_{i+t,i}) is left in slot PHI.
+template <int B_, bool FAST, int PHI>
 __device__ __forceinline__ void band_row(BandState<B_> &h, const double (&bd)[B_ + 1], double ci, double kap, double &D, double &S)
 {
     double d = bd[0] + kap, dp = 1.0, z = ci, zp = 0.0;
 #pragma unroll
     for (int q = 0; q < B_; q++) {
-        const double l = h.lh[q][q + 1], lp = h.lph[q][q + 1], ld_ = l * h.dh[q];
-        d -= l * ld_;
-        dp -= 2.0 * lp * ld_ + l * l * h.dph[q];
-        z -= l * h.zh[q];
-        zp -= lp * h.zh[q] + l * h.zph[q];
+        const int p = (PHI - 1 - q + 2 * B_) % B_;  // slot of column j = i - 1 - q
+        const double l = h.lh[p][q + 1], lp = h.lph[p][q + 1], x = h.xh[p][q + 1], xp = h.xph[p][q + 1];
+        d -= l * x;                  // l^2 d_j
+        dp -= lp * x + l * xp;       // d/dkappa (l^2 d_j) = 2 l l' d_j + l^2 d_j'
+        z -= l * h.zh[p];
+        zp -= lp * h.zh[p] + l * h.zph[p];
     }
     const double r = FAST ? fast_recip(d) : 1.0 / d, t = z * r;
     D += z * t;
@@ -194,22 +200,33 @@ __device__ __forceinline__ void band_row(BandState<B_> &h, const double (&bd)[B_
 #pragma unroll
         for (int q = 0; q < B_; q++)
             if (q + 1 + tt <= B_) {
-                const double a = h.lh[q][q + 1 + tt], ap = h.lph[q][q + 1 + tt], b = h.lh[q][q + 1], bp = h.lph[q][q + 1], dq = h.dh[q];
-                num -= a * b * dq;
-                nump -= (ap * b + a * bp) * dq + a * b * h.dph[q];
+                const int p = (PHI - 1 - q + 2 * B_) % B_;
+                const double a = h.lh[p][q + 1 + tt], ap = h.lph[p][q + 1 + tt], x = h.xh[p][q + 1], xp = h.xph[p][q + 1];
+                num -= a * x;              // l_{i+tt,j} l_{i,j} d_j
+                nump -= ap * x + a * xp;
             }
         ln[tt] = num * r;
         lpn[tt] = (nump - ln[tt] * dp) * r;
     }
+    h.dh[PHI] = d; h.dph[PHI] = dp; h.zh[PHI] = z; h.zph[PHI] = zp;
 #pragma unroll
-    for (int q = B_ - 1; q > 0; q--) {
-        h.dh[q] = h.dh[q - 1]; h.dph[q] = h.dph[q - 1]; h.zh[q] = h.zh[q - 1]; h.zph[q] = h.zph[q - 1];
-#pragma unroll
-        for (int tt = 0; tt <= B_; tt++) { h.lh[q][tt] = h.lh[q - 1][tt]; h.lph[q][tt] = h.lph[q - 1][tt]; }
+    for (int tt = 0; tt <= B_; tt++) {
+        h.lh[PHI][tt] = ln[tt];
+        h.lph[PHI][tt] = lpn[tt];
+        h.xh[PHI][tt] = ln[tt] * d;
+        h.xph[PHI][tt] = lpn[tt] * d + ln[tt] * dp;
     }
-    h.dh[0] = d; h.dph[0] = dp; h.zh[0] = z; h.zph[0] = zp;
-#pragma unroll
-    for (int tt = 0; tt <= B_; tt++) { h.lh[0][tt] = ln[tt]; h.lph[0][tt] = lpn[tt]; }
+}
+
+// rows i0 .. i0 + B_ - 1 (those below ns): f(phase as an integral constant, row) for every one of them, phases in order
+template <int B_, typename F>
+__device__ __forceinline__ void band_rows(int i0, int ns, F &&f)
+{
+    static_assert(B_ >= 1 && B_ <= 4, "band_rows unrolls up to four phases");
+    if (i0 < ns) f(std::integral_constant<int, 0>{}, i0);
+    if constexpr (B_ > 1) { if (i0 + 1 < ns) f(std::integral_constant<int, 1>{}, i0 + 1); }
+    if constexpr (B_ > 2) { if (i0 + 2 < ns) f(std::integral_constant<int, 2>{}, i0 + 2); }
+    if constexpr (B_ > 3) { if (i0 + 3 < ns) f(std::integral_constant<int, 3>{}, i0 + 3); }
 }
 
 template <int B_>
@@ -220,14 +237,22 @@ __device__ __forceinline__ void band_sweep(const double *__restrict__ band, int 
     h.clear();
     D = 0.0;
     S = 0.0;
-    double cn = c[0];
-    for (int i = 0; i < ns; i++) {
-        const double ci = cn;
-        cn = i + 1 < ns ? c[(long)(i + 1) * cstride] : 0.0;  // one row ahead of its use
-        double bd[B_ + 1];
+    double cv[B_];
 #pragma unroll
-        for (int t = 0; t <= B_; t++) bd[t] = band[(long)t * np + i];  // wave-uniform
-        band_row<B_, true>(h, bd, ci, kap, D, S);
+    for (int q = 0; q < B_; q++) cv[q] = q < ns ? c[(long)q * cstride] : 0.0;
+    for (int i0 = 0; i0 < ns; i0 += B_) {
+        double cn[B_];  // the next group's rows of c: in flight while this group is swept
+#pragma unroll
+        for (int q = 0; q < B_; q++) cn[q] = i0 + B_ + q < ns ? c[(long)(i0 + B_ + q) * cstride] : 0.0;
+        band_rows<B_>(i0, ns, [&](auto phi, int i) {
+            constexpr int PHI = decltype(phi)::value;
+            double bd[B_ + 1];
+#pragma unroll
+            for (int t = 0; t <= B_; t++) bd[t] = band[(long)t * np + i];  // wave-uniform
+            band_row<B_, true, PHI>(h, bd, cv[PHI], kap, D, S);
+        });
+#pragma unroll
+        for (int q = 0; q < B_; q++) cv[q] = cn[q];
     }
 }
 
@@ -272,16 +297,17 @@ __global__ __launch_bounds__(64) void band_solve_kernel(const double *__restrict
     BandState<B_> h;
     h.clear();
     double D = 0.0, Sd = 0.0;
-    for (int i = 0; i < ns; i++) {
-        double bd[B_ + 1];
+    for (int i0 = 0; i0 < ns; i0 += B_) {
+        band_rows<B_>(i0, ns, [&](auto phi, int i) {
+            constexpr int PHI = decltype(phi)::value;
+            double bd[B_ + 1];
 #pragma unroll
-        for (int t = 0; t <= B_; t++) bd[t] = bs[(long)t * np + i];
-        const double D0 = D;
-        band_row<B_, false>(h, bd, c[(long)i * mp], kap, D, Sd);
-        (void)D0;
-        c[(long)i * mp] = h.zh[0] / h.dh[0];  // w_i = z_i / d_i
+            for (int t = 0; t <= B_; t++) bd[t] = bs[(long)t * np + i];
+            band_row<B_, false, PHI>(h, bd, c[(long)i * mp], kap, D, Sd);
+            c[(long)i * mp] = h.zh[PHI] / h.dh[PHI];  // w_i = z_i / d_i
 #pragma unroll
-        for (int t = 1; t <= B_; t++) lb[((long)(t - 1) * np + i) * mp] = h.lh[0][t];
+            for (int t = 1; t <= B_; t++) lb[((long)(t - 1) * np + i) * mp] = h.lh[PHI][t];
+        });
     }
     double yh[B_];  // y_{i+1} .. y_{i+B_}
 #pragma unroll
@@ -317,13 +343,18 @@ __global__ __launch_bounds__(64) void band_pd_kernel(const double *__restrict__ 
     h.clear();
     double D = 0.0, S = 0.0, mn = 1.0 / 0.0;
     int bad = 0;
-    for (int i = 0; i < n[s]; i++) {
-        double bd[B_ + 1];
+    const int ns = n[s];
+    for (int i0 = 0; i0 < ns && !bad; i0 += B_) {
+        band_rows<B_>(i0, ns, [&](auto phi, int i) {
+            constexpr int PHI = decltype(phi)::value;
+            if (bad) return;
+            double bd[B_ + 1];
 #pragma unroll
-        for (int t = 0; t <= B_; t++) bd[t] = bs[(long)t * np + i];
-        band_row<B_, false>(h, bd, 0.0, kap, D, S);
-        mn = fmin(mn, h.dh[0]);
-        if (!(h.dh[0] > 0.0)) { bad = 1; mn = h.dh[0]; break; }
+            for (int t = 0; t <= B_; t++) bd[t] = bs[(long)t * np + i];
+            band_row<B_, false, PHI>(h, bd, 0.0, kap, D, S);
+            if (!(h.dh[PHI] > 0.0)) { bad = 1; mn = h.dh[PHI]; }
+            else mn = fmin(mn, h.dh[PHI]);
+        });
     }
     flag[s] = bad;
     minpiv[s] = mn;
