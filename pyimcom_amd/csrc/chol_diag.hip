@@ -230,6 +230,118 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *__restrict__ L, 
     }
 }
 
+// Triangular factor of a block reflector of 128 Householder reflectors, H_ps ... H_ps+127 = I - V T V^T (forward, column-wise):
+// T^-1 = diag(1 / tau) + striu(S) with S = V V^T (from a GEMM, symmetric), i.e. T = (Lm^-1)^T for the LOWER triangular
+// Lm = diag(1 / tau) + stril(S) -- inverted here exactly as chol_diag_kernel inverts L[k,k]: 16 x 16 diagonal inverses (a column per
+// thread), then recursive doubling with MFMA products, everything in LDS.  Only tau itself is ever used (as the reciprocal of Lm's
+// diagonal), never 1 / tau: a reflector with tau = 0 (H = I: padding columns) gives a zero row and column of T by itself.
+// (tridiag.hip's trd_larft_kernel builds the same T column by column, a row per thread: 128 dependent steps of scalar loads,
+// 0.44 - 1.25 ms per panel where this takes tens of microseconds; it stays as IMCOM_LARFT=serial for cross-checks.)
+__global__ __launch_bounds__(256) void larft_inv_kernel(const double *__restrict__ Sg, const double *__restrict__ tauvec, int ld, int ps,
+                                                        double *__restrict__ T)
+{
+    extern __shared__ double S[];            // [128][SLD]: strict lower part of S = V V^T, overwritten by the inverse's off-diagonal blocks
+    double *Xd = S + NB * SLD;               // [8][16][XLD] inverses of the diagonal sub-blocks
+    double *rdg = Xd + 8 * 16 * XLD;         // [128] reciprocal of Lm's diagonal = tau
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *Ss = Sg + (long)s * NB * NB;
+    {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+        for (int t0 = tid; t0 < NB * NB / 2; t0 += 8 * 256) {
+            f64x2 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = *(const f64x2 *)&Ss[2 * (t0 + 256 * q)];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int t = t0 + 256 * q;
+                *(f64x2 *)&S[(t >> 6) * SLD + 2 * (t & 63)] = v[q];
+            }
+        }
+    }
+    if (tid < NB) rdg[tid] = ps + tid < ld ? tauvec[(long)s * ld + ps + tid] : 0.0;
+    __syncthreads();
+    if (tid < 128) {
+        const int blk = tid >> 4, c = tid & 15, o = 16 * blk;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            double v = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; l++)
+                if (l < i && l >= c) v -= S[(o + i) * SLD + o + l] * x[l];
+            x[i] = (i >= c) ? v * rdg[o + i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) Xd[(blk * 16 + i) * XLD + c] = x[i];
+    }
+    __syncthreads();
+    auto Xinv = [&](int r, int c) -> double {
+        if ((r >> 4) == (c >> 4)) return Xd[r * XLD + (c & 15)];
+        return (r > c) ? S[r * SLD + c] : 0.0;
+    };
+    const int li = lane & 15, lk = lane >> 4;
+    for (int h = 16; h < NB; h *= 2) {
+        const int hb = h / 16, npair = NB / (2 * h);
+        for (int t = wave; t < npair * hb * hb; t += 4) {  // tmp = B A^-1 into the (unused) upper right of the pair
+            const int p = t / (hb * hb), q = t % (hb * hb), ti = q / hb, tj = q % hb;
+            const int base = 2 * h * p;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kb = tj; kb < hb; kb++)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    const int kk = base + 16 * kb + 4 * k4 + lk;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(base + h + 16 * ti + li) * SLD + kk], Xinv(kk, base + 16 * tj + li), acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[(base + 16 * ti + lk + 4 * r) * SLD + base + h + 16 * tj + li] = acc[r];
+        }
+        __syncthreads();
+        f64x4 res[4];
+        int cnt = 0;
+        for (int t = wave; t < npair * hb * hb; t += 4, cnt++) {  // X_BA = -C^-1 tmp
+            const int p = t / (hb * hb), q = t % (hb * hb), ti = q / hb, tj = q % hb;
+            const int base = 2 * h * p;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int kb = 0; kb <= ti; kb++)
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    const int kk = 16 * kb + 4 * k4 + lk;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xinv(base + h + 16 * ti + li, base + h + kk), S[(base + kk) * SLD + base + h + 16 * tj + li], acc, 0, 0, 0);
+                }
+            res[cnt & 3] = acc;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int t = wave; t < npair * hb * hb; t += 4, cnt++) {
+            const int p = t / (hb * hb), q = t % (hb * hb), ti = q / hb, tj = q % hb;
+            const int base = 2 * h * p;
+            const f64x4 acc = res[cnt & 3];
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[(base + h + 16 * ti + lk + 4 * r) * SLD + base + 16 * tj + li] = -acc[r];
+        }
+        __syncthreads();
+    }
+    // T = (Lm^-1)^T, upper triangular, row-major [128][128]
+    double *To = T + (long)s * NB * NB;
+    for (int t = tid; t < NB * NB; t += 256) {
+        const int r = t >> 7, c = t & 127;
+        To[t] = c >= r ? Xinv(c, r) : 0.0;
+    }
+}
+
+int launch_larft_inv(imcom_ctx *ctx, const double *S, const double *tauvec, int ld, int ps, double *T, int batch)
+{
+    static bool attr_set = false;
+    const size_t bytes = (size_t)(NB * SLD + 8 * 16 * XLD + NB) * sizeof(double);
+    if (!attr_set) {
+        IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)larft_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(larft_inv_kernel, dim3(batch), dim3(256), bytes, ctx->stream, S, tauvec, ld, ps, T);
+    return check_launch("larft_inv_kernel");
+}
+
 int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail)
 {
     static bool attr_set = false;

@@ -71,6 +71,8 @@ int trd_panel_step(imcom_ctx *ctx, const TrdBasis &b, int batch, int p, double *
 
 // la_kernels.hip
 int launch_chol_diag(imcom_ctx *ctx, double *L, double *Dinv, int ldn, int k, int batch, const int *nblk, int *fail);
+// chol_diag.hip: T [batch][128][128] of the block reflector of reflectors ps .. ps+127 from S = V V^T [batch][128][128] and tau [batch][ld]
+int launch_larft_inv(imcom_ctx *ctx, const double *S, const double *tauvec, int ld, int ps, double *T, int batch);
 int launch_diag_shift(imcom_ctx *ctx, const double *A, int ldn, const double *inc, const int *ninc, double *dshift,
                       int batch);
 int launch_pack_A(imcom_ctx *ctx, const double *A, long lda, const int *n, double *Ap, int ldp, int batch);

@@ -18,6 +18,7 @@
 // 8 n^2 bytes per column), and ragged n is handled by per-stamp guards.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "launchers.h"
@@ -331,6 +332,12 @@ __global__ __launch_bounds__(256) void trd_w_kernel(double *__restrict__ Vall, c
     if (threadIdx.x == 0) pdot[s * npart + blockIdx.x] = t;
 }
 
+static bool larft_serial()
+{
+    static const bool v = getenv("IMCOM_LARFT") && !strcmp(getenv("IMCOM_LARFT"), "serial");
+    return v;
+}
+
 // Triangular factor of a panel's block reflector H_ps ... H_pe-1 = I - V T V^T (forward, column-wise):
 // T[c][c] = tau_c, T[0:c, c] = -tau_c T[0:c, 0:c] (V^T v_c).  S = V^T V comes from a GEMM.  One block per stamp.
 __global__ __launch_bounds__(128) void trd_larft_kernel(const double *__restrict__ S, const double *__restrict__ tauvec, int ld,
@@ -355,6 +362,14 @@ __global__ __launch_bounds__(128) void trd_larft_kernel(const double *__restrict
     }
     __syncthreads();
     for (int q = 0; q < TP; q++) T[(long)s * TP * TP + (long)q * TP + r] = Ts[q * (TP + 1) + r];
+}
+
+// T of one panel: the MFMA triangular inverse (chol_diag.hip); IMCOM_LARFT=serial keeps the column-by-column kernel above
+static int launch_larft(imcom_ctx *ctx, const double *S, const double *tauvec, int ld, int ps, double *T, int batch)
+{
+    if (!larft_serial()) return launch_larft_inv(ctx, S, tauvec, ld, ps, T, batch);
+    hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), LARFT_LDS, ctx->stream, S, tauvec, ld, ps, T);
+    return check_launch("trd_larft_kernel");
 }
 
 // One Givens step of the implicit QR bulge chase at position k of the block [lo, hi].  Carried state: (x, z) the
@@ -777,15 +792,13 @@ int trd_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int m
 int trd_panel_factors(imcom_ctx *ctx, TrdBasis *out, int batch)
 {
     const int ld = out->ld;
-    hipStream_t st = ctx->stream;
     ProfScope ps_(ctx, "eigen_applyq");
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LARFT_LDS));
     for (int p = 0; p < out->npanels; p++) {
         const int ps = p * TP, rem = ld - ps;
         const double *Vp = out->Vall + (long)ps * ld + ps;
         IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, rem, batch, Vp, ld, (long)ld * ld, Vp, ld, (long)ld * ld, out->Sm, TP, (long)TP * TP, 1.0, 0.0));
-        hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), LARFT_LDS, st, out->Sm, out->tauvec, ld, ps, out->Tm + (size_t)p * batch * TP * TP);
-        IMCOM_TRY(check_launch("trd_larft_kernel"));
+        IMCOM_TRY(launch_larft(ctx, out->Sm, out->tauvec, ld, ps, out->Tm + (size_t)p * batch * TP * TP, batch));
     }
     return trd_pair_factors(ctx, out, batch);
 }
@@ -799,8 +812,7 @@ int trd_panel_step(imcom_ctx *ctx, const TrdBasis &b, int batch, int p, double *
     double *Tm = b.Tm + (size_t)p * batch * TP * TP;
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)trd_larft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LARFT_LDS));
     IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, rem, batch, Vp, ld, (long)ld * ld, Vp, ld, (long)ld * ld, b.Sm, TP, (long)TP * TP, 1.0, 0.0));
-    hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), LARFT_LDS, ctx->stream, b.Sm, b.tauvec, ld, ps, Tm);
-    IMCOM_TRY(check_launch("trd_larft_kernel"));
+    IMCOM_TRY(launch_larft(ctx, b.Sm, b.tauvec, ld, ps, Tm, batch));
     double *Cp = C + (long)ps * mp;
     IMCOM_TRY(launch_gemm(ctx, false, true, TP, mp, rem, batch, Vp, ld, (long)ld * ld, Cp, mp, (long)ld * mp, b.W1, mp, (long)TP * mp, 1.0, 0.0));
     IMCOM_TRY(launch_gemm(ctx, true, true, TP, mp, TP, batch, Tm, TP, (long)TP * TP, b.W1, mp, (long)TP * mp, b.W2, mp, (long)TP * mp, 1.0, 0.0));
@@ -934,8 +946,7 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
             const double *Vp = Vall + (long)ps * ld + ps;  // rows (reflectors) ps.., components ps..
             double *Xb = X + (long)ps * ld + ps;
             IMCOM_TRY(launch_gemm(ctx, false, false, TP, TP, rem, batch, Vp, ld, (long)ld * ld, Vp, ld, (long)ld * ld, Sm, TP, (long)TP * TP, 1.0, 0.0));
-            hipLaunchKernelGGL(trd_larft_kernel, dim3(batch), dim3(TP), LARFT_LDS, st, Sm, tauvec, ld, ps, Tm);
-            IMCOM_TRY(check_launch("trd_larft_kernel"));
+            IMCOM_TRY(launch_larft(ctx, Sm, tauvec, ld, ps, Tm, batch));
             IMCOM_TRY(launch_gemm(ctx, false, false, rem, TP, rem, batch, Xb, ld, (long)ld * ld, Vp, ld, (long)ld * ld, W1, TP, (long)ld * TP, 1.0, 0.0));
             IMCOM_TRY(launch_gemm(ctx, false, false, rem, TP, TP, batch, W1, TP, (long)ld * TP, Tm, TP, (long)TP * TP, W2, TP, (long)ld * TP, 1.0, 0.0));
             IMCOM_TRY(launch_gemm(ctx, false, true, rem, rem, TP, batch, W2, TP, (long)ld * TP, Vp, ld, (long)ld * ld, Xb, ld, (long)ld * ld, -1.0, 1.0));

@@ -184,6 +184,7 @@ def test_alternative_code_paths_in_subprocess():
     assert os.path.exists(dev_lib), f"{dev_lib} is missing: run `make -C pyimcom_amd/csrc DEV=1` (or __graft_entry__.build())"
     env.update(IMCOM_HIP_LIB=dev_lib, IMCOM_EIGH="jacobi", IMCOM_BUILD_A="window")
     env.update(IMCOM_EIGEN_SPLIT="2")  # the Eigen kernel's sub-batches on streams of their own (default from 192 stamps on)
+    env.update(IMCOM_LARFT="serial")   # the block reflectors' triangular factors column by column (default: MFMA triangular inverse)
     code = ("import dataclasses; from pyimcom_amd import synth; from tests import parity as smoke; "
             "smoke.check_batch(synth.CONFIGS['small'], 2); "
             "smoke.check_batch(dataclasses.replace(synth.CONFIGS['tiny'], kernel='Eigen'), 2); print('alt paths ok')")
