@@ -192,6 +192,23 @@ def pmc_traffic(batch, cfg_name):
     return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
 
 
+def pmc_band_traffic(kernel="symv4_kernel"):
+    """HBM bytes per launch AND matrix of one of the band reduction's kernels from the newest committed counter passes
+    (tools/pmc_band_reduce.sh: one reduction of 8 matrices of 2938 rows, FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
+    correction as for pmc_traffic) -- only when they were taken on the kernel sources this run was built from; else None."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_band_reduce.json")))
+    if not files:
+        return None, None
+    doc = json.load(open(files[-1]))
+    from pyimcom_amd._lib import source_sha16
+
+    if doc.get("csrc_sha16") != source_sha16() or kernel not in doc.get("kernels", {}):
+        return None, None
+    return doc["kernels"][kernel]["traffic_bytes_per_launch"] / float(doc["batch"]), os.path.join("profiles", os.path.basename(files[-1]))
+
+
 def block_workload(dev, n1P, identical=False, seed=5, config="cfg2"):
     """Synthetic block at cfg-2 geometry for the block leg (and for tests/test_gpu_bigblock.py's check of it): the InStamp
     pool of (n1P + 2)^2 InStamps, and per 2 x 2 group of InStamps PSF images [E, ns + 16, ns + 16] (a smooth modulation of the
@@ -370,9 +387,12 @@ def config_legs(ctx, dev, which=("cfg1", "cfg4", "cfg5", "cfg3")):
                 trd2 = ctx.profile_get("eigen_trd")[0]
                 if l4:
                     nbytes = float((n**3 / 3.0).sum())  # sum over the groups of four columns of the trailing lower triangle, 8 B per entry
+                    per_matrix, src = pmc_band_traffic("symv4_kernel")
                     leg["roofline_hbm"] = {"kernel": "symv4_kernel", "bound": "hbm", "achieved": nbytes / (ms4 * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                            "frac": nbytes / (ms4 * 1e-3) / 8e12, "bytes_per_launch": nbytes / l4, "avg_launch_ms": ms4 / l4, "launches": l4,
-                                           "ms_per_step": ms4, "reduction_ms_in_this_pass": trd2, "traffic": None,
+                                           "ms_per_step": ms4, "reduction_ms_in_this_pass": trd2,
+                                           "traffic": None if per_matrix is None else per_matrix * nb,  # counters: per launch and matrix at N = 2938, x this batch
+                                           "traffic_source": src,
                                            "note": "algorithmic bytes N^3/3 per stamp; HIP events around each launch, taken in a separate pass"}
             leg["job_roofline_frac"] = job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS
             ctx.profile_enable(False)

@@ -537,11 +537,15 @@ def _sweep_dead_launches(outdir, keep):
     import os
     import shutil
 
+    import time
+
     for d in os.listdir(outdir):
         path = os.path.join(outdir, d)
         if not d.startswith(".farm-") or path == keep or not os.path.isdir(path):
             continue
         try:
+            if time.time() - os.path.getmtime(path) < 60.0:  # (a launch that has only just made its directory has no claims yet)
+                continue
             names = [f for f in os.listdir(path) if f.endswith((".claim", ".merge"))]
             if not any(_claim_state(os.path.join(path, f)) for f in names):
                 shutil.rmtree(path, ignore_errors=True)
