@@ -29,7 +29,10 @@
 namespace imcom {
 
 constexpr int BW = BAND_BW;      // bandwidth = reflectors per group
-constexpr int BTPL = 64;         // reflectors per lazy super-panel (multiple of BW)
+#ifndef IMCOM_BTPL
+#define IMCOM_BTPL 64
+#endif
+constexpr int BTPL = IMCOM_BTPL; // reflectors per lazy super-panel (multiple of BW; build-time: make EXTRA=-DIMCOM_BTPL=128 for A/B runs)
 constexpr int BTHREADS = 1024;   // band_step_kernel: one workgroup per stamp
 constexpr int RTHREADS = 512;    // band_step_reg_kernel (256 registers per thread)
 constexpr int BSTRIP = 64;       // rows per strip of the symmetric product
