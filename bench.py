@@ -187,7 +187,7 @@ def pmc_traffic(batch, cfg_name):
 
     if doc.get("batch") != batch or doc.get("workload") != cfg_name or doc.get("csrc_sha16") != source_sha16():
         return None, None  # another workload, or counters taken on other kernel sources than the ones this run was built from
-    ks = [doc["kernels"][k] for k in ("solve_fwd_kernel", "solve_bwd_kernel") if k in doc["kernels"]]
+    ks = [v for k, v in doc["kernels"].items() if k.split("<")[0] in ("solve_fwd_kernel", "solve_bwd_kernel")]  # (solve_bwd_kernel<false>: a template since round 4)
     n = sum(k["launches"] for k in ks)
     return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
 

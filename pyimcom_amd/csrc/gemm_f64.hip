@@ -339,7 +339,10 @@ __global__ __launch_bounds__(MMA_THREADS, MMA_MINWAVES) void solve_fwd_kernel(co
     }
 }
 
-__global__ __launch_bounds__(MMA_THREADS, MMA_WAVES == 8 ? 4 : MMA_MINWAVES) void solve_bwd_kernel(const double *__restrict__ L,
+// CO: the coaddition's sums taken from the finished tile of T (tile_coadd_partials; opt-in, IMCOM_EPILOGUE_FUSED): an instantiation of
+// its own, bounded to four waves per SIMD, so that the default kernel's registers are exactly what they were without it
+template <bool CO>
+__global__ __launch_bounds__(MMA_THREADS, (CO && MMA_WAVES == 8) ? 4 : MMA_MINWAVES) void solve_bwd_kernel(const double *__restrict__ L,
                                                            double *__restrict__ Y, int ldn, int ldm,
                                                            int k, const int *__restrict__ nblk,
                                                            const int *__restrict__ n, const double *__restrict__ Dinv,
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(MMA_THREADS, MMA_WAVES == 8 ? 4 : MMA_MINWAVES) voi
             tile_col_sumsq(acc, Npart + ((long)s * 2 * (ldn / NB) + 2 * k) * ldm + c * NB, ldm);
             float *To = Tt + (long)s * ldn * ldm + (long)k * NB * ldm + c * NB;
             IMCOM_FOR_ACC_TRI(row, col, v, { To[(long)row * ldm + col] = (float)v; })
-            if (co_Epart) tile_coadd_partials(acc, s, k, c, ldn, ldm, n[s], co_indata, co_expo, co_n_inframe, co_n_expo, co_Epart);
+            if constexpr (CO) tile_coadd_partials(acc, s, k, c, ldn, ldm, n[s], co_indata, co_expo, co_n_inframe, co_n_expo, co_Epart);
         }
     }
 }
@@ -594,9 +597,12 @@ int launch_solve_bwd(imcom_ctx *ctx, const double *L, double *Y, int ldn, int ld
     if (nparts > 1 && nbmax - 1 - k >= nparts) {
         hipLaunchKernelGGL(solve_partial_kernel<true>, dim3(ldm / NB, nparts, batch), dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, nparts, partial);
         IMCOM_TRY(check_launch("solve_partial_kernel"));
-        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, Npart, Tt, ci, ce, cf_, cn, cp);
-    } else
-        hipLaunchKernelGGL(solve_bwd_kernel, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, Npart, Tt, ci, ce, cf_, cn, cp);
+        if (co) hipLaunchKernelGGL(solve_bwd_kernel<true>, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, Npart, Tt, ci, ce, cf_, cn, cp);
+        else hipLaunchKernelGGL(solve_bwd_kernel<false>, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, partial, nparts, Npart, Tt, ci, ce, cf_, cn, cp);
+    } else if (co)
+        hipLaunchKernelGGL(solve_bwd_kernel<true>, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, Npart, Tt, ci, ce, cf_, cn, cp);
+    else
+        hipLaunchKernelGGL(solve_bwd_kernel<false>, grid, dim3(MMA_THREADS), 0, ctx->stream, L, Y, ldn, ldm, k, nblk, n, Dinv, nullptr, 0, Npart, Tt, ci, ce, cf_, cn, cp);
     return check_launch("solve_bwd_kernel");
 }
 
