@@ -371,18 +371,27 @@ def config_legs(ctx, dev, which=("cfg1", "cfg4", "cfg5", "cfg3")):
                 job = float((n**3 / 3.0 + 2.0 * cfg.m * n**2 + 165.0 * n * (n + 1) + 220.0 * n * cfg.m).sum())
             else:
                 flops = float((4.0 * n**3 / 3.0 + 4.0 * n**2 * cfg.m).sum())
-                ms = sum(fams[k][0] for k in ("eigen_trd", "eigen_applyq", "lakernel1"))
+                # wall time of the solve: the step minus the builders and the epilogue (the stage events of reduction / reflector products /
+                # search overlap in time -- second queue, sub-batches on streams of their own -- so their sum is not a duration)
+                ms = dt * 1e3 * steps - sum(fams[k][0] for k in ("build_A", "build_B", "epilogue"))
                 ach = flops * steps / (ms * 1e-3) / 1e12
                 leg["roofline"] = {"kernel": "Eigen solve: band reduction (symv4 / band_step / band_apply / syr2k) + reflector GEMMs + kappa search", "bound": "mfma",
                                    "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                                   "flops_per_stamp": flops / nb, "count": "4 N^3 / 3 + 4 N^2 m (the path's own; SURVEY 8d's 9 N^3 + 4 N^2 m would read "
+                                   "flops_per_stamp": flops / nb, "solve_wall_ms_per_step": ms / steps, "count": "4 N^3 / 3 + 4 N^2 m (the path's own; SURVEY 8d's 9 N^3 + 4 N^2 m would read "
                                    f"{(9.0 * n**3 + 4.0 * n**2 * cfg.m).sum() * steps / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS:.2f})", "traffic": None}
                 job = flops + float((165.0 * n * (n + 1) + 220.0 * n * cfg.m).sum())
-                # second pass with HIP events around every symv4 launch (profile level 2)
+                # second pass with HIP events around every symv4 launch (profile level 2), the whole batch on ONE stream (with sub-batches
+                # on streams of their own the launches of two streams overlap and share the memory system: durations would not add)
+                split_was = os.environ.get("IMCOM_EIGEN_SPLIT")
+                os.environ["IMCOM_EIGEN_SPLIT"] = "1"
                 ctx.profile_enable(2)
                 ctx.profile_reset()
                 b.solve()
                 torch.cuda.synchronize()
+                if split_was is None:
+                    os.environ.pop("IMCOM_EIGEN_SPLIT", None)
+                else:
+                    os.environ["IMCOM_EIGEN_SPLIT"] = split_was
                 ms4, l4 = ctx.profile_get("symv4")
                 trd2 = ctx.profile_get("eigen_trd")[0]
                 if l4:

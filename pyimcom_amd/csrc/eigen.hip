@@ -787,7 +787,8 @@ static size_t solve_eigen_ws(int batch, int np, int mp, int m);
 // products beside the reduction; batch 256: 5.48 / 5.31 / 5.56.  Default: two sub-batches from 192 stamps on, else one.
 static int eigen_split(int batch, int np)
 {
-    static const int forced = getenv("IMCOM_EIGEN_SPLIT") ? atoi(getenv("IMCOM_EIGEN_SPLIT")) : 0;
+    const char *env = getenv("IMCOM_EIGEN_SPLIT");  // (read at every call: bench.py takes the per-launch timings of symv4 on one stream)
+    const int forced = env ? atoi(env) : 0;
     int k = forced > 0 ? forced : (batch >= 192 ? 2 : 1);
     if (!eigen_uses_band(np)) k = 1;
     return std::max(1, std::min(std::min(k, batch), 8));
