@@ -1,7 +1,10 @@
 """Host-side logic that needs no GPU: stamp neighbourhoods and pivots (coadd.py:853, 918-919), the visiting order of
 the pixel partition (coadd.py:329-336), the table sets a stamp needs, and the oracle's own selection / block helpers."""
 
+import os
+
 import numpy as np
+import pytest
 
 
 def test_stamp_neighbours_and_pivots():
@@ -162,3 +165,48 @@ def test_choose_batch_is_kernel_aware_and_never_zero():
     assert it < chol and it * stamp_bytes(2304, 2304, 1, "Iterative") <= 0.8 * free  # ~0.4 GB of patch matrices per stamp
     eig = choose_batch(2304, 2944, 2304, 1, free, kernel="Eigen")
     assert eig * stamp_bytes(2944, 2304, 1, "Eigen") <= 0.8 * free
+
+
+def test_reference_stamp_order_and_host_ahead():
+    """Host mirrors added in round 4: the visiting order of the reference's stamp loop (cells of 2 x 2 from the window's origin,
+    coadd.py:2056-2064) against the fixture made by executing that loop, and refblock's _HostAhead (groups' host halves prepared
+    on worker threads in the plan's order, on-demand requests served by the same workers, a bounded number held ready)."""
+    import threading
+    import time
+
+    from pyimcom_amd.blockrun import reference_stamp_order
+    from pyimcom_amd.refblock import _HostAhead
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "block_loop.npz"))
+    for case in ("whole", "inner", "stop"):
+        lo_j, hi_j, lo_i, hi_i = (int(v) for v in g[f"{case}_window"])
+        assert np.array_equal(np.array(reference_stamp_order(lo_j, hi_j, lo_i, hi_i, int(g[f"{case}_nrun"]))), g[f"{case}_visited"])
+    with pytest.raises(ValueError, match="Size must be even"):
+        reference_stamp_order(1, 3, 1, 4)
+    assert oracle_order(1, 4, 1, 2) == reference_stamp_order(1, 4, 1, 2)
+
+    seen, lock = [], threading.Lock()
+
+    def work(key):
+        with lock:
+            seen.append((key, threading.current_thread().name))
+        time.sleep(0.01)
+        return key * 2
+
+    for threads in (1, 4):
+        seen.clear()
+        ah = _HostAhead(work, threads=threads, ahead=3)
+        ah.schedule([1, 2, 3, 4, 5, 2])
+        time.sleep(0.1)
+        assert len(seen) == 3  # no more than `ahead` groups are prepared before anything is taken
+        assert [ah.get(k) for k in (1, 2, 3, 4, 5)] == [2, 4, 6, 8, 10]
+        assert ah.get(99) == 198 and ah.get(2) == 4  # not foreseen / asked for again: computed on demand
+        ah.close()
+        assert all(name.startswith("imcom-psf") for _, name in seen)  # every call into the block's objects is made on a worker thread
+        assert [k for k, _ in seen][:5] == [1, 2, 3, 4, 5] or threads > 1
+
+
+def oracle_order(*a):
+    from oracle import oracle as orc
+
+    return orc.stamp_loop_order(*a)
