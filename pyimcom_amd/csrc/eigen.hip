@@ -560,6 +560,7 @@ static int eigen_fallback(imcom_ctx *ctx, const std::vector<int> &idx, const int
     limit = std::min(limit, ctx->ws_bytes);  // the end of the caller's share of the workspace
     const size_t mark = ctx->ws_used, room = limit - std::min(limit, align_up(mark, 256));
     int cap = (int)idx.size();
+    if (const char *e = getenv("IMCOM_EIGEN_FALLBACK_CAP")) cap = std::max(1, std::min(cap, atoi(e)));  // (tests: several rounds of the loop below)
     while (cap > 1 && eigen_fallback_bytes(cap, np, mp, m) > room) cap = (cap + 1) / 2;
     if (eigen_fallback_bytes(cap, np, mp, m) > room) { set_error("internal: no workspace for the eigendecomposition of a stamp"); return IMCOM_ERR_NOMEM; }
     const size_t mat = (size_t)np * np, big = (size_t)np * mp;

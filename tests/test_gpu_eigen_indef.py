@@ -114,3 +114,52 @@ def test_eigen_resident_mixed_batch_with_indefinite_stamps_cfg3(kind):
         assert np.allclose(res.UC[b].cpu().numpy().ravel()[same], UC[same], rtol=1e-5 + tol, atol=1e-9)
         assert np.allclose(res.Sigma[b].cpu().numpy().ravel()[same], Sigma[same], rtol=1e-5 + tol, atol=1e-9)
     assert flips <= (6 if kind == "multi" else 0)
+
+
+@pytest.mark.parametrize("split", ["1", "2"])
+@pytest.mark.parametrize("tag", ["eig1", "eigm"])
+def test_eigen_batch_of_indefinite_stamps_in_rounds(golden, tag, split, monkeypatch):
+    """imcom_solve_eigen on a batch of five stamps -- three indefinite copies of the chain golden's system (N = 220), the
+    positive definite original, and an empty stamp -- with the eigenbasis route limited to two stamps at a time
+    (IMCOM_EIGEN_FALLBACK_CAP: the route normally takes as many as the workspace holds): info = [1, 0, 1, 0, 1], the indefinite ones
+    equal the reference's outputs, the others are untouched by their neighbours' fallback."""
+    import ctypes as C
+
+    from pyimcom_amd._lib import MEM_HOST, check, default_context, lib
+    from tests.test_oracle import indef_case
+
+    monkeypatch.setenv("IMCOM_EIGEN_FALLBACK_CAP", "2")
+    monkeypatch.setenv("IMCOM_EIGEN_SPLIT", split)  # "2": the batch as two sub-batches on streams of their own, each with indefinite stamps
+    g, A, mB, Cs, n2f = indef_case(golden, "chain")
+    ch = golden("stamp_chain_mid")
+    kC = np.ascontiguousarray(g[f"chain_{tag}_kappaC"], dtype=np.float64)
+    n, m, ldn = A.shape[0], mB.shape[1], 256
+    batch = 5
+    ns = np.array([n, n, n, 0, n], dtype=np.int32)
+    Ab = np.zeros((batch, ldn, ldn))
+    Bb = np.zeros((batch, m, ldn))
+    for s in (0, 2, 4):
+        Ab[s, :n, :n], Bb[s, :, :n] = A, mB[0]
+    Ab[1, :n, :n], Bb[1, :, :n] = ch["A"], mB[0]
+    Cv = np.full(batch, float(Cs[0]))
+    T = np.full((batch, m, ldn), np.nan, dtype=np.float32)
+    UC, Sg, kp = (np.zeros((batch, m), dtype=np.float32) for _ in range(3))
+    info = np.full(batch, -1, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    check(lib.imcom_solve_eigen(default_context().handle, batch, p(ns), ldn, m, p(Ab), p(Bb), p(Cv), p(kC), len(kC), float(g["chain_uctarget"]),
+                                float(g["chain_sigmamax"]), 13, p(T), p(UC), p(Sg), p(kp), p(info), MEM_HOST))
+    assert info.tolist() == [1, 0, 1, 0, 1]
+    ref = {q: g[f"chain_{tag}_{q}"] for q in ("T", "UC", "Sigma", "kappa")}
+    for s in (0, 2, 4):
+        assert np.abs(T[s, :, :n] - ref["T"][0]).max() <= 2e-6 * np.abs(ref["T"]).max(), s
+        assert np.all(T[s, :, n:] == 0)
+        assert np.allclose(UC[s], ref["UC"].ravel(), rtol=2e-5, atol=1e-9) and np.allclose(Sg[s], ref["Sigma"].ravel(), rtol=2e-5, atol=1e-9)
+        assert np.allclose(kp[s], ref["kappa"].ravel(), rtol=1e-6, atol=0)
+    # the positive definite stamp: the chain golden's own Eigen outputs for these nodes do not exist; compare with the oracle
+    from oracle import oracle as orc
+
+    To, Uo, So, ko, _ = orc.eigen_kernel(ch["A"], mB[0], float(Cs[0]), kC, float(g["chain_uctarget"]), float(g["chain_sigmamax"]))
+    same = np.abs(kp[1].astype(np.float64) / ko.astype(np.float64) - 1.0) <= 1e-6
+    assert same.sum() >= same.size - 2
+    assert np.abs(T[1, :, :n][same] - To[same]).max() <= 2e-6 * np.abs(To).max()
+    assert np.all(UC[3] == 1) and np.all(Sg[3] == 0) and np.all(kp[3] == 1)  # lakernel.py:110-119
