@@ -335,7 +335,7 @@ def config_legs(ctx, dev, which=("cfg1", "cfg4", "cfg5", "cfg3")):
     from pyimcom_amd import synth
     from pyimcom_amd.stamps import PSFGroupTables, StampBatch
 
-    plan = {"cfg1": [(256, 5)], "cfg4": [(256, 3)], "cfg5": [(170, 1)], "cfg3": [(32, 2), (256, 1)]}
+    plan = {"cfg1": [(256, 5)], "cfg4": [(256, 3)], "cfg5": [(170, 2)], "cfg3": [(32, 2), (256, 1)]}
     out = {}
     for name in which:
         cfg = synth.CONFIGS[name]
