@@ -319,6 +319,40 @@ def reference_stamp_order(j_st_min, j_st_max, i_st_min, i_st_max, nrun=None):
     return out
 
 
+def count_pixels(cfg, pool, n1P):
+    """Pixels every stamp of a block selects (coadd.py:886-977), [n1P, n1P] int, EXACT: the selection kernel itself run over the
+    whole block, a few hundred stamps per call, only its counts read back (a few milliseconds per block; cached on the pool).
+    With exact counts the passes are sized without the 10 % margin an estimate needs -- at cfg-3 size the margin alone turned
+    passes of 256 stamps into passes of 128 (ldn 3328 instead of 3072 in the memory model).  Pools that do not live on a GPU
+    (the planner's host tests) have no exact counts: returns None."""
+    if getattr(pool, "device", None) is None or getattr(pool.device, "type", "") != "cuda" or not hasattr(pool, "x"):
+        return None
+    key = (float(cfg.rho), int(cfg.n2), int(n1P))
+    cache = getattr(pool, "_pixel_counts", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    nst = n1P + 2
+    todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    per = np.diff(pool.inst_off)
+    out = np.zeros((n1P, n1P), np.int64)
+    step = 512
+    for c0 in range(0, len(todo), step):
+        nb = _neighbours_of(todo[c0 : c0 + step], cfg.n2, nst)
+        cap = max(int(per[t[0][t[0] >= 0]].sum()) for t in nb)
+        _, _, _, _, cumsum = select_pixels(pool, np.stack([t[0] for t in nb]), np.stack([t[1] for t in nb]), np.stack([t[2] for t in nb]), cfg.rho,
+                                           max(NB, (cap + NB - 1) // NB * NB))
+        for (j, i), n in zip(todo[c0 : c0 + step], cumsum[:, 9]):
+            out[j - 1, i - 1] = int(n)
+    pool._pixel_counts = (key, out)
+    return out
+
+
+def stamp_pixels(cfg, pool, n1P):
+    """(pixels per stamp [n1P, n1P], exact?): the selection's own counts when the pool is on a GPU, else the estimate."""
+    exact = count_pixels(cfg, pool, n1P)
+    return (exact.astype(np.float64), True) if exact is not None else (estimate_pixels(cfg, pool, n1P), False)
+
+
 def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     """The batches coadd_block runs: list of lists of (j_st, i_st).  ``batch=None``: sized from the block's largest stamp, the
     free device memory and -- with a BlockTables -- the table arena (``choose_batch`` / ``plan_batches``); an explicit ``batch``
@@ -328,8 +362,8 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     if not todo:
         return []
     grouped = isinstance(tables, BlockTables)
-    win = estimate_pixels(cfg, pool, n1P)
-    cap_pix = int(1.1 * max(win[j - 1, i - 1] for j, i in todo)) + 64
+    win, exact = stamp_pixels(cfg, pool, n1P)
+    cap_pix = int(max(win[j - 1, i - 1] for j, i in todo)) if exact else int(1.1 * max(win[j - 1, i - 1] for j, i in todo)) + 64
     ldn_max = ldn or max(NB, (cap_pix + NB - 1) // NB * NB)
     ldm = (cfg.m + NB - 1) // NB * NB
     if batch is None:
@@ -390,8 +424,9 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     if chunks and ldn is None:
         # sized once for the block's largest batch (estimated, as the plan's): a buffer that has to grow in the middle of the
         # block costs a device allocation of ~10 GB, 0.1 s with the GPU idle
-        win = estimate_pixels(cfg, pool, n1P)
-        ld_pre = (int(1.05 * max(win[j - 1, i - 1] for c in chunks for j, i in c)) + 32 + NB - 1) // NB * NB
+        win, exact = stamp_pixels(cfg, pool, n1P)
+        nmax_ = max(win[j - 1, i - 1] for c in chunks for j, i in c)
+        ld_pre = (int(nmax_ if exact else 1.05 * nmax_ + 32) + NB - 1) // NB * NB
         bmax, ldm, O = max(len(c) for c in chunks), (cfg.m + NB - 1) // NB * NB, int(getattr(tables, "n_out", 1))
         import torch
 

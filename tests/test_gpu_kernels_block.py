@@ -22,7 +22,7 @@ def test_eigen_kernel_block_at_full_stamp_size():
     from oracle import oracle as orc
     from pyimcom_amd import synth
     from pyimcom_amd.block import BlockMaps
-    from pyimcom_amd.blockrun import coadd_block, estimate_pixels, plan_block, prepare_batch, release_buffers, stamp_bytes
+    from pyimcom_amd.blockrun import coadd_block, count_pixels, estimate_pixels, plan_block, prepare_batch, release_buffers, stamp_bytes
     from pyimcom_amd.stamps import NB, BlockTables
     from tests.test_gpu_bigblock import _workload
 
@@ -43,7 +43,9 @@ def test_eigen_kernel_block_at_full_stamp_size():
     # memory: the estimate the planner sizes batches with must cover what the largest pass took
     bmax = max(len(c) for c in chunks)
     took = torch.cuda.max_memory_allocated() + tabs.ctx.workspace_bytes() - base
-    ldn = (int(1.1 * estimate_pixels(cfg, pool, n1P).max()) + 64 + NB - 1) // NB * NB  # the planner's own bound (plan_block)
+    exact = count_pixels(cfg, pool, n1P)  # the planner sizes passes from the selection's own counts
+    assert np.abs(estimate_pixels(cfg, pool, n1P) / exact - 1.0).max() < 0.1  # (what a pool without a GPU falls back to)
+    ldn = (int(exact.max()) + NB - 1) // NB * NB
     est = bmax * stamp_bytes(ldn, (cfg.m + NB - 1) // NB * NB, 1, "Eigen")
     print(f"[eigen block] largest pass {bmax} stamps: took {took / 2**30:.2f} GiB, stamp_bytes estimate {est / 2**30:.2f} GiB")
     assert took <= est, (took, est)
@@ -73,7 +75,7 @@ def test_eigen_kernel_block_at_full_stamp_size():
     # two stamps against the oracle's EigenKernel
     flips = 0
     for (j, i), (n, A, mB, res) in keep.items():
-        assert 2600 < n < 3200 and res.info[0] == 0
+        assert 2600 < n < 3200 and res.info[0] == 0 and exact[j - 1, i - 1] == n  # (the planner's counts are the selection's)
         T, UC, Sigma, kappa, _ = orc.eigen_kernel(A, mB, float(tabs.C), cfg.kappaC, cfg.uctarget, cfg.sigmamax)
         k_gpu, k_ref = res.kappa[0].cpu().numpy().ravel().astype(np.float64), kappa.astype(np.float64)
         same = np.abs(k_gpu / k_ref - 1.0) <= 1e-6
