@@ -291,9 +291,11 @@ def block_leg(ctx, dev, n1P=48, reps=3, config="cfg2", warm=16):
         tabs.reset()  # table construction (PSF sampling, spectra, overlap tables) is part of the block
         return coadd_block(cfg, pool, tabs, n1P, E)
 
-    # warm-up on a corner of the block (kernels loaded, workspaces grown), then the timed block(s)
+    # warm-up (kernels loaded, workspace and per-batch buffers grown to what a pass of this block takes: a first pass that has to
+    # allocate tens of GB does so with the GPU idle), then the timed block(s): a corner of the block, and the first pass of the plan
     w = min(warm, n1P)
     coadd_block(cfg, pool, tabs, n1P, E, stamps=[(j, i) for j in range(1, w + 1) for i in range(1, w + 1)])
+    coadd_block(cfg, pool, tabs, n1P, E, chunks=plan_block(cfg, pool, tabs, n1P)[:1], pad_sides=None)
     torch.cuda.synchronize()
     ctx.profile_enable(True)
     runs = []

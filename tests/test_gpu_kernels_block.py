@@ -48,8 +48,8 @@ def test_eigen_kernel_block_at_full_stamp_size():
     ldn = (int(exact.max()) + NB - 1) // NB * NB
     est = bmax * stamp_bytes(ldn, (cfg.m + NB - 1) // NB * NB, 1, "Eigen")
     print(f"[eigen block] largest pass {bmax} stamps: took {took / 2**30:.2f} GiB, stamp_bytes estimate {est / 2**30:.2f} GiB")
-    assert took <= est, (took, est)
-    assert est <= 2.0 * took  # ... and is not a wild overestimate either (it decides how many stamps share a pass)
+    assert took <= est / 0.8, (took, est)  # the planner fills 0.8 of the free memory by this estimate: what a pass takes must fit
+    assert est <= 2.0 * took  # ... and it is not a wild overestimate either (it decides how many stamps share a pass)
 
     # stamp by stamp
     one = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, E, ctx=tabs.ctx)
