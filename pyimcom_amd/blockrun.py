@@ -367,7 +367,15 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     ldn_max = ldn or max(NB, (cap_pix + NB - 1) // NB * NB)
     ldm = (cfg.m + NB - 1) // NB * NB
     if batch is None:
+        # what a pass can draw on: free memory, and what earlier passes / blocks left in the library workspace and in the per-batch
+        # buffers -- both are reused (counting them as taken made a second block of the same kind plan passes half the size)
         free = free_device_bytes(pool.device)
+        ctx_ = getattr(tables, "ctx", None)
+        if ctx_ is not None and hasattr(ctx_, "workspace_bytes"):
+            free += int(ctx_.workspace_bytes())
+        key_ = getattr(pool.device, "index", None) or 0
+        if key_ in _BUFS:
+            free += sum(b_.nbytes() for b_ in _BUFS[key_])
         n_out = int(getattr(tables, "n_out", 1))
         if grouped:  # tiles of 2 x 2-stamp cells, sized by memory and by the table arena (plan_batches)
             cap = max(1, min(256, int(0.8 * free) // stamp_bytes(ldn_max, ldm, n_out, cfg.kernel)))

@@ -537,6 +537,10 @@ class BatchBuffers:
     def __init__(self, device):
         self.dev, self._flat = torch.device(device), {}
 
+    def nbytes(self):
+        """Bytes this set holds (a later batch reuses them: a planner counts them as available)."""
+        return sum(f.numel() * f.element_size() for f in self._flat.values() if f is not None)
+
     def take(self, name, shape, dtype):
         n = int(np.prod(shape))
         f = self._flat.get(name)
