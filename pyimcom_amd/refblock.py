@@ -149,15 +149,32 @@ def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1):
             im = blk.inimages[e]
             img = np.asarray(im.get_psf_pos(world, use_shortrange=True), dtype=np.float64)
             d = (np.asarray(im.outpix2world2inpix(xy + p0)) - np.asarray(im.outpix2world2inpix(p0[None]))) * oversamp
-            out.append((img, np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)])))
-        return out
+            out.append((img, d))
+        # stacked into page-locked memory here, on the worker: the device loop's thread only queues the copies
+        if len({img.shape for img, _ in out}) == 1:
+            k = len(out)
+            imgs = torch.empty((k,) + out[0][0].shape, dtype=torch.float64, pin_memory=True)
+            yx = torch.empty((k, 2, ns, ns), dtype=torch.float64, pin_memory=True)
+            iv, yv = imgs.numpy(), yx.numpy()
+            for q, (img, d) in enumerate(out):
+                iv[q] = img
+                yv[q, 0], yv[q, 1] = d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)
+            return imgs, yx
+        return [(img, np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)])) for img, d in out]
 
     ahead = _HostAhead(host_half, host_threads)
 
     def provider(keys):
+        got = [ahead.get(key) for key in keys]
+        if all(isinstance(g, tuple) for g in got) and len({g[0].shape[1:] for g in got}) == 1:
+            # every group arrived as page-locked stacks of one image size: queue the copies, sample everything in one call
+            im = torch.cat([g[0].to(device, non_blocking=True) for g in got]) if len(got) > 1 else got[0][0].to(device, non_blocking=True)
+            yx = torch.cat([g[1].to(device, non_blocking=True) for g in got]) if len(got) > 1 else got[0][1].to(device, non_blocking=True)
+            return psfs.sample_psf(im, ns, yx, circ, norm, ctx)
         imgs, yxco = [], []
-        for key in keys:
-            for img, yx in ahead.get(key):
+        for g in got:
+            pairs = [(g[0][q].numpy(), g[1][q].numpy()) for q in range(g[0].shape[0])] if isinstance(g, tuple) else g
+            for img, yx in pairs:
                 imgs.append(img)
                 yxco.append(yx)
         out = torch.empty((len(imgs), ns, ns), dtype=torch.float64, device=device)
