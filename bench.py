@@ -479,7 +479,7 @@ def seam_legs(ctx, dev, cfg, batch):
     blk, psfgrp, _, _ = synth.duck_block(cfg, n1P, cfg.n_expo if isinstance(cfg.n_expo, int) else cfg.n_expo[1], seed=5)
     fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize", "epilogue", "block_acc")
     dctx = ctx
-    threads = max(1, min(8, (os.cpu_count() or 2) // 2))
+    threads = int(os.environ.get("IMCOM_BENCH_HOST_THREADS", max(1, min(16, (os.cpu_count() or 2) // 2))))
     coadd_output_stamps(blk, psfgrp, device=dev, ctx=ctx, host_threads=threads)
     torch.cuda.synchronize()
     res = {}
