@@ -4,7 +4,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=${1:-32}
 export PYTHONPATH=$ROOT IMCOM_EIGEN_SPLIT=1
-O=$ROOT/gpurun_out/pmc_sq_eigen; rm -rf $O; mkdir -p $O
+O=$ROOT/gpurun_out/pmc_sq_eigen; rm -rf $O/sq; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $O/sq -- python3 $ROOT/tools/bench_eigen.py cfg3 $B > $O/run.log 2>&1 || { echo "pass failed"; tail -3 $O/run.log; exit 1; }
 cd $ROOT
