@@ -442,7 +442,16 @@ int imcom_ctx_create(int device, imcom_ctx **out)
         // priority, so that a short kernel of the main stream's dependent chain does not queue behind its long tiles
         int least = 0, greatest = 0;
         IMCOM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        IMCOM_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, least));
+        // IMCOM_AUX_CUS = k: the second queue confined to k of the CUs (bit i of the mask = CU i / 8 of XCD i % 8), so that the
+        // main stream's one-workgroup-per-stamp kernels always find CUs without a product tile on them (A/B runs)
+        const char *cus = getenv("IMCOM_AUX_CUS");
+        const int k = cus ? atoi(cus) : 0;
+        if (k > 0 && k < ctx->cu_count) {
+            std::vector<uint32_t> mask((ctx->cu_count + 31) / 32, 0u);
+            for (int i = 0; i < k; i++) mask[i / 32] |= 1u << (i % 32);
+            IMCOM_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->aux_stream, (uint32_t)mask.size(), mask.data()));
+        } else
+            IMCOM_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, least));
     }
     ctx->stream = ctx->own_stream;
     *out = ctx;
@@ -462,6 +471,7 @@ int imcom_ctx_destroy(imcom_ctx *ctx)
     if (ctx->stream_event) hipEventDestroy(ctx->stream_event);
     if (ctx->aux_stream) hipStreamDestroy(ctx->aux_stream);
     for (auto s_ : ctx->sub_streams) hipStreamDestroy(s_);
+    for (auto s_ : ctx->part_streams) hipStreamDestroy(s_);
     if (ctx->flag_pin) hipHostFree(ctx->flag_pin);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -63,6 +63,7 @@ struct imcom_ctx {
     hipStream_t aux_stream = nullptr;  // second queue for work that overlaps the main stream (eigensolver rotations)
     std::vector<hipEvent_t> sync_events;  // plain (no timing) events for cross-stream ordering
     std::vector<hipStream_t> sub_streams;  // streams of the sub-batches of one call (eigen.hip)
+    std::vector<hipStream_t> part_streams; // the same with a share of the CUs each (IMCOM_SPLIT_CUS=1; eigen.hip)
     int *flag_pin = nullptr;               // page-locked read-back of per-stamp flags (an async copy into pageable memory would block the host)
     size_t flag_pin_count = 0;
     hipEvent_t stream_event = nullptr;    // orders a newly bound stream behind the previous one (imcom_ctx_set_stream)

@@ -782,15 +782,19 @@ static size_t solve_eigen_ws(int batch, int np, int mp, int m);
 
 // Sub-batches of one call on streams of their own (IMCOM_EIGEN_SPLIT = count).  The reduction alternates a bandwidth-bound pass
 // over the trailing matrix (symv4) with a latency chain that keeps ONE workgroup per stamp busy (band_step: a seventh of the
-// reduction at batch 32) and small launches around them; sub-batches in flight were meant to put one's latency chain beside
-// another's memory pass.  Measured (cfg-3, ms per stamp, one / two / four sub-batches): batch 32: 7.77 / 7.82 / 10.80 -- the queues
-// of the streams mostly take turns (two halves: 128 ms of reduction each where 85 were due), and the halves lose the reflector
-// products beside the reduction; batch 256: 5.48 / 5.31 / 5.56.  Default: two sub-batches from 192 stamps on, else one.
+// reduction at batch 32) and small launches around them; sub-batches in flight put one's latency chain and launch gaps beside
+// another's memory pass.  Measured on the final kernels (cfg-3, ms per stamp, one / two sub-batches; profiles/r04_negative_results.txt
+// item 5): batch 16: 9.79 / 9.80, 32: 7.40-7.50 / 7.14-7.15, 64: 6.29 / 5.97-6.01, 128: 5.82 / 5.63, 256: 5.48 / 5.32; three or four
+// are slower (7.30 at 32, 5.50 at 256).  Two halves beat one batch WITH its reflector products on the low-priority queue beside the
+// reduction (which the halves do not use).  Default: two sub-batches from 24 stamps on, else one.
+// IMCOM_SPLIT_CUS=1 confines each sub-batch's stream to a share of the CUs of its own (hipExtStreamCreateWithCUMask): four quarters
+// of 64 CUs reach 5.20-5.23 at batch 256 (-2 %), equal at 128, slower at 32 / 64 -- and any share that is not a whole number of
+// CUs per XCD (three, five, six parts) more than doubles the time.  Not the default.
 static int eigen_split(int batch, int np)
 {
     const char *env = getenv("IMCOM_EIGEN_SPLIT");  // (read at every call: bench.py takes the per-launch timings of symv4 on one stream)
     const int forced = env ? atoi(env) : 0;
-    int k = forced > 0 ? forced : (batch >= 192 ? 2 : 1);
+    int k = forced > 0 ? forced : (batch >= 24 ? 2 : 1);
     if (!eigen_uses_band(np)) k = 1;
     return std::max(1, std::min(std::min(k, batch), 8));
 }
@@ -838,11 +842,27 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         IMCOM_HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
         ctx->sub_streams.push_back(s_);
     }
-    while ((int)ctx->sync_events.size() < 2 + nsub) {
+    while ((int)ctx->sync_events.size() < 3 + nsub) {
         hipEvent_t e;
         IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->sync_events.push_back(e);
     }
+    // IMCOM_SPLIT_CUS=1 (A/B runs): every sub-batch on a stream confined to a share of the CUs of its own, so that one's
+    // one-workgroup-per-stamp step finds free CUs while another's memory pass runs
+    const char *pc = getenv("IMCOM_SPLIT_CUS");
+    const bool parted = pc && atoi(pc) != 0;
+    if (parted && (int)ctx->part_streams.size() != nsub) {
+        for (auto s_ : ctx->part_streams) { hipStreamSynchronize(s_); hipStreamDestroy(s_); }
+        ctx->part_streams.clear();
+        for (int q = 0; q < nsub; q++) {
+            std::vector<uint32_t> mask((ctx->cu_count + 31) / 32, 0u);
+            for (int i = ctx->cu_count * q / nsub; i < ctx->cu_count * (q + 1) / nsub; i++) mask[i / 32] |= 1u << (i % 32);
+            hipStream_t s_;
+            IMCOM_HIP_CHECK(hipExtStreamCreateWithCUMask(&s_, (uint32_t)mask.size(), mask.data()));
+            ctx->part_streams.push_back(s_);
+        }
+    }
+    auto stream_of = [&](int q) { return parted ? ctx->part_streams[q] : (q == 0 ? main : ctx->sub_streams[q - 1]); };
     // the small host arrays of all sub-batches go through the pinned ring: it must not wrap while copies queued on another stream
     // have not run yet
     IMCOM_HIP_CHECK(hipStreamSynchronize(main));
@@ -853,25 +873,30 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         imcom_ctx *c;
         hipStream_t m;
         int k;
-        ~Restore() { c->stream = m; for (int q = 0; q + 1 < k; q++) hipStreamSynchronize(c->sub_streams[q]); }
+        ~Restore()
+        {
+            c->stream = m;
+            for (int q = 0; q + 1 < k; q++) hipStreamSynchronize(c->sub_streams[q]);
+            for (auto s_ : c->part_streams) hipStreamSynchronize(s_);
+        }
     } restore{ctx, main, nsub};
     size_t at = base;
     int rc = IMCOM_OK;
     for (int q = 0; q < nsub && rc == IMCOM_OK; q++) {
         EigenJob &j = jobs[q];
-        ctx->stream = q == 0 ? main : ctx->sub_streams[q - 1];
-        if (q > 0) IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, fork, 0));
+        ctx->stream = stream_of(q);
+        if (ctx->stream != main) IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, fork, 0));
         ctx->ws_used = at;  // every sub-batch in a share of its own: nothing one hands back is reused by another while it runs
         at = align_up(at, 256) + solve_eigen_ws(j.batch, np, mp, m);
         j.limit = at;
         rc = eigen_enqueue(ctx, j, ldn, m, np, mp, kappaC, nv, ucmin, smax, nbis, false);
     }
     for (int q = 0; q < nsub && rc == IMCOM_OK; q++) {
-        ctx->stream = q == 0 ? main : ctx->sub_streams[q - 1];
+        ctx->stream = stream_of(q);
         rc = eigen_finish(ctx, jobs[q], ldn, m, np, mp, kappaC, nv, ucmin, smax, nbis);
-        if (rc == IMCOM_OK && q > 0) {  // join: the caller's stream goes on when the sub-batch's T has been stored
-            IMCOM_HIP_CHECK(hipEventRecord(ctx->sync_events[2 + q], ctx->stream));
-            IMCOM_HIP_CHECK(hipStreamWaitEvent(main, ctx->sync_events[2 + q], 0));
+        if (rc == IMCOM_OK && ctx->stream != main) {  // join: the caller's stream goes on when the sub-batch's T has been stored
+            IMCOM_HIP_CHECK(hipEventRecord(ctx->sync_events[3 + q], ctx->stream));
+            IMCOM_HIP_CHECK(hipStreamWaitEvent(main, ctx->sync_events[3 + q], 0));
         }
     }
     ctx->stream = main;
