@@ -116,7 +116,7 @@ def test_eigen_resident_mixed_batch_with_indefinite_stamps_cfg3(kind):
     assert flips <= (6 if kind == "multi" else 0)
 
 
-@pytest.mark.parametrize("split", ["1", "2"])
+@pytest.mark.parametrize("split", ["1", "2", "4cus"])
 @pytest.mark.parametrize("tag", ["eig1", "eigm"])
 def test_eigen_batch_of_indefinite_stamps_in_rounds(golden, tag, split, monkeypatch):
     """imcom_solve_eigen on a batch of five stamps -- three indefinite copies of the chain golden's system (N = 220), the
@@ -129,7 +129,11 @@ def test_eigen_batch_of_indefinite_stamps_in_rounds(golden, tag, split, monkeypa
     from tests.test_oracle import indef_case
 
     monkeypatch.setenv("IMCOM_EIGEN_FALLBACK_CAP", "2")
-    monkeypatch.setenv("IMCOM_EIGEN_SPLIT", split)  # "2": the batch as two sub-batches on streams of their own, each with indefinite stamps
+    # "2": the batch as two sub-batches on streams of their own, each with indefinite stamps; "4cus": four, every stream confined to a
+    # quarter of the CUs (IMCOM_SPLIT_CUS, hipExtStreamCreateWithCUMask: the opt-in of profiles/r04_negative_results.txt item 5)
+    monkeypatch.setenv("IMCOM_EIGEN_SPLIT", split.replace("cus", ""))
+    if split.endswith("cus"):
+        monkeypatch.setenv("IMCOM_SPLIT_CUS", "1")
     g, A, mB, Cs, n2f = indef_case(golden, "chain")
     ch = golden("stamp_chain_mid")
     kC = np.ascontiguousarray(g[f"chain_{tag}_kappaC"], dtype=np.float64)

@@ -183,7 +183,9 @@ def test_alternative_code_paths_in_subprocess():
     # __graft_entry__.build() makes the developer library: its absence is a broken build, not a reason to pass with half the test
     assert os.path.exists(dev_lib), f"{dev_lib} is missing: run `make -C pyimcom_amd/csrc DEV=1` (or __graft_entry__.build())"
     env.update(IMCOM_HIP_LIB=dev_lib, IMCOM_EIGH="jacobi", IMCOM_BUILD_A="window")
-    env.update(IMCOM_EIGEN_SPLIT="2")  # the Eigen kernel's sub-batches on streams of their own (default from 192 stamps on)
+    # one Eigen batch with its reflector products beside the reduction on the second queue (the default below 24 stamps), that queue
+    # confined to 192 CUs (IMCOM_AUX_CUS: read when the context is created); the sub-batch variants: tests/test_gpu_eigen_indef.py
+    env.update(IMCOM_EIGEN_SPLIT="1", IMCOM_EIGEN_OVERLAP="1", IMCOM_AUX_CUS="192")
     env.update(IMCOM_LARFT="serial")   # the block reflectors' triangular factors column by column (default: MFMA triangular inverse)
     code = ("import dataclasses; from pyimcom_amd import synth; from tests import parity as smoke; "
             "smoke.check_batch(synth.CONFIGS['small'], 2); "
