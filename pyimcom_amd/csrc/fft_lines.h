@@ -109,22 +109,28 @@ template <int R2> struct Wf16 {
 };
 __device__ __forceinline__ int wf_pad16(int i) { return i + (i >> 4); }
 
+#ifndef IMCOM_FFT_ABL
+#define IMCOM_FFT_ABL 0  // timing experiments (tools/ab_fft_abl.sh; results are then garbage): bit 0 no global loads, bit 1 no global stores,
+                         // bit 2 twiddles as constants (no LDS reads for them), bit 3 no LDS stores between the stages
+#endif
 template <int R2, bool INV, class Load0, class StoreN>
 __device__ __forceinline__ void wf16_line(cplx *line, const cplx *twl, Load0 load0, StoreN storeN)
 {
     constexpr int NB = Wf16<R2>::NB;
+    constexpr int ABL = IMCOM_FFT_ABL;
     const int lane = threadIdx.x & 63;
+    double sink = 0.0;
     if (lane < NB) {  // stage 0: butterfly `lane`, inputs lane + NB t, outputs 16 lane + u
         cplx v[16];
 #pragma unroll
         for (int t = 0; t < 16; t++) {
-            v[t] = load0(lane + NB * t);
+            v[t] = (ABL & 1) ? make_double2(1e-3 * lane + t, 0.5 * t - 1e-3 * lane) : load0(lane + NB * t);
             if (t == 7) __builtin_amdgcn_sched_barrier(0);  // two batches of loads: a loader may need two fetches per element
         }
         SmallDft<16, INV>::run(v);
         cplx *dst = line + 17 * lane;
 #pragma unroll
-        for (int u = 0; u < 16; u++) dst[u] = v[u];
+        for (int u = 0; u < 16; u++) { if (ABL & 8) sink += v[u].x + v[u].y; else dst[u] = v[u]; }
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < NB) {  // stage 1 (Ns = 16): k = lane & 15; inputs lane + NB t, outputs 256 (lane >> 4) + k + 16 u
@@ -135,14 +141,14 @@ __device__ __forceinline__ void wf16_line(cplx *line, const cplx *twl, Load0 loa
         for (int t = 0; t < 16; t++) v[t] = src[17 * R2 * t];
 #pragma unroll
         for (int t = 1; t < 16; t++) {
-            cplx w = tw[16 * (t - 1)];
+            cplx w = (ABL & 4) ? make_double2(0.6 + 0.01 * t, 0.8 - 0.01 * t) : tw[16 * (t - 1)];
             if (INV) w.y = -w.y;
             v[t] = cmulf(v[t], w);
         }
         SmallDft<16, INV>::run(v);
         cplx *dst = line + 272 * a + k;
 #pragma unroll
-        for (int u = 0; u < 16; u++) dst[17 * u] = v[u];
+        for (int u = 0; u < 16; u++) { if (ABL & 8) sink += v[u].x + v[u].y; else dst[17 * u] = v[u]; }
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -154,13 +160,16 @@ __device__ __forceinline__ void wf16_line(cplx *line, const cplx *twl, Load0 loa
         for (int t = 0; t < R2; t++) v[t] = src[272 * t];
 #pragma unroll
         for (int t = 1; t < R2; t++) {
-            cplx w = tw[256 * (t - 1)];
+            cplx w = (ABL & 4) ? make_double2(0.6 + 0.01 * t, 0.8 - 0.01 * t) : tw[256 * (t - 1)];
             if (INV) w.y = -w.y;
             v[t] = cmulf(v[t], w);
         }
         SmallDft<R2, INV>::run(v);
 #pragma unroll
-        for (int u = 0; u < R2; u++) storeN(j + 256 * u, v[u]);
+        for (int u = 0; u < R2; u++) {
+            if (ABL & 8) v[u].x += sink;
+            if (!(ABL & 2) || v[u].x == 1.2345e300) storeN(j + 256 * u, v[u]);
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }

@@ -415,7 +415,10 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const c
             const int llo = win ? win[4 * t] >> 1 : 0, lhi = win ? (win[4 * t + 1] + 1) >> 1 : rp;
             for (int l = 8 * (wave & 3) + (lane >> 3); l < rp; l += 32) {
                 const int i = 2 * l + h - nc + (2 * l + h < nc ? n : 0);
-                if (c2 < ncol && l >= llo && l < lhi) dst[(long)l * (2 * nhp)] = src[wf_pad16(i)];
+                if (c2 < ncol && l >= llo && l < lhi) {
+                    const cplx v = src[wf_pad16(i)];
+                    if (!(IMCOM_FFT_ABL & 2) || v.x == 1.2345e300) dst[(long)l * (2 * nhp)] = v;
+                }
             }
         }
         __syncthreads();
@@ -512,18 +515,24 @@ static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const in
                         double a0, double a1, const int *win_dev, const int *slot_dev, cplx *V, double *tables)
 {
     // the column kernel's waves write V in groups of four (four neighbouring columns = one 128-byte line per row pair)
-    const int W = wf16_waves<R2>(), Wc = W / 4 * 4, nh = Wf16<R2>::N / 2 + 1;
-    const size_t lds = wf16_lds<R2>(W);
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int W = wf16_waves<R2>(), nh = Wf16<R2>::N / 2 + 1;
+    // The column kernel's rounds -- transform, barrier, the groups' stores, barrier -- keep the waves of a workgroup in step.
+    // IMCOM_FFT_COLS_SPLIT=1: workgroups of ONE group of four waves, as many per CU as the LDS holds (two at n = 768), each in a phase
+    // of its own: 2.31 -> 2.22 us per table on a bare request of 3600 tables, nothing inside a block (1752 against 1754 ms per 48 x 48
+    // block; profiles/r04_negative_results.txt item 7) -- not the default.
+    static const bool split = getenv("IMCOM_FFT_COLS_SPLIT") && atoi(getenv("IMCOM_FFT_COLS_SPLIT")) > 0;
+    const int Wc = split ? 4 : W / 4 * 4, per_cu = split ? (int)std::max<size_t>(1, (160 * 1024) / wf16_lds<R2>(4)) : 1;
+    const size_t lds = wf16_lds<R2>(W), ldsc = wf16_lds<R2>(Wc);
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_rows_kernel<R2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long cols = (long)npairs * nh, rows = (long)npairs * ((nsamp + 1) / 2);
-    const int g1 = (int)std::max<long>(8, std::min<long>(ctx->cu_count, (cols + Wc - 1) / Wc) / 8 * 8);  // a multiple of the 8 XCDs
+    const int g1 = (int)std::max<long>(8, std::min<long>((long)per_cu * ctx->cu_count, (cols + Wc - 1) / Wc) / 8 * 8);  // a multiple of the 8 XCDs
     const int g2 = (int)std::min<long>(ctx->cu_count, (rows + W - 1) / W);
     if (a0 != 0.0)
-        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, true>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V);
+        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, true>), dim3(g1), dim3(64 * Wc), ldsc, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V);
     else
-        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, false>), dim3(g1), dim3(64 * Wc), lds, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V);
+        hipLaunchKernelGGL((wf16_inv_cols_kernel<R2, false>), dim3(g1), dim3(64 * Wc), ldsc, ctx->stream, Ra, Rb, pairs_dev, npairs, nsamp, tw, a0, a1, win_dev, V);
     hipLaunchKernelGGL(wf16_inv_rows_kernel<R2>, dim3(g2), dim3(64 * W), lds, ctx->stream, (const cplx *)V, npairs, nsamp, tw, win_dev, slot_dev, tables);
     return check_launch("psf_overlap (16 x 16 x r lines)");
 }
