@@ -113,8 +113,11 @@ __device__ __forceinline__ int wf_pad16(int i) { return i + (i >> 4); }
 #define IMCOM_FFT_ABL 0  // timing experiments (tools/ab_fft_abl.sh; results are then garbage): bit 0 no global loads, bit 1 no global stores,
                          // bit 2 twiddles as constants (no LDS reads for them), bit 3 no LDS stores between the stages
 #endif
-template <int R2, bool INV, class Load0, class StoreN>
-__device__ __forceinline__ void wf16_line(cplx *line, const cplx *twl, Load0 load0, StoreN storeN)
+// tw1(t), t = 1 .. 15: the lane's stage-1 twiddle exp(-2 pi i t k / 256), k = lane & 15; tw2(q, t), t = 1 .. R2 - 1: the stage-2 twiddle
+// exp(-2 pi i t j / n) of butterfly j = lane + 64 q -- from the tables in LDS (wf16_line) or from registers the caller filled once
+// (wf16_line_regs: a lane's twiddles are the same for every line)
+template <int R2, bool INV, class Load0, class StoreN, class Tw1, class Tw2>
+__device__ __forceinline__ void wf16_line_impl(cplx *line, Load0 load0, StoreN storeN, Tw1 tw1, Tw2 tw2)
 {
     constexpr int NB = Wf16<R2>::NB;
     constexpr int ABL = IMCOM_FFT_ABL;
@@ -135,13 +138,13 @@ __device__ __forceinline__ void wf16_line(cplx *line, const cplx *twl, Load0 loa
     __builtin_amdgcn_wave_barrier();
     if (lane < NB) {  // stage 1 (Ns = 16): k = lane & 15; inputs lane + NB t, outputs 256 (lane >> 4) + k + 16 u
         const int k = lane & 15, a = lane >> 4;
-        const cplx *src = line + lane + a, *tw = twl + k;
+        const cplx *src = line + lane + a;
         cplx v[16];
 #pragma unroll
         for (int t = 0; t < 16; t++) v[t] = src[17 * R2 * t];
 #pragma unroll
         for (int t = 1; t < 16; t++) {
-            cplx w = (ABL & 4) ? make_double2(0.6 + 0.01 * t, 0.8 - 0.01 * t) : tw[16 * (t - 1)];
+            cplx w = (ABL & 4) ? make_double2(0.6 + 0.01 * t, 0.8 - 0.01 * t) : tw1(t);
             if (INV) w.y = -w.y;
             v[t] = cmulf(v[t], w);
         }
@@ -154,13 +157,13 @@ __device__ __forceinline__ void wf16_line(cplx *line, const cplx *twl, Load0 loa
 #pragma unroll
     for (int q = 0; q < 4; q++) {  // stage 2 (Ns = 256): butterfly j = lane + 64 q, inputs j + 256 t, outputs j + 256 u
         const int j = lane + 64 * q;
-        const cplx *src = line + j + (j >> 4), *tw = twl + Wf16<R2>::TW2 + j;
+        const cplx *src = line + j + (j >> 4);
         cplx v[R2];
 #pragma unroll
         for (int t = 0; t < R2; t++) v[t] = src[272 * t];
 #pragma unroll
         for (int t = 1; t < R2; t++) {
-            cplx w = (ABL & 4) ? make_double2(0.6 + 0.01 * t, 0.8 - 0.01 * t) : tw[256 * (t - 1)];
+            cplx w = (ABL & 4) ? make_double2(0.6 + 0.01 * t, 0.8 - 0.01 * t) : tw2(q, t);
             if (INV) w.y = -w.y;
             v[t] = cmulf(v[t], w);
         }
@@ -172,6 +175,35 @@ __device__ __forceinline__ void wf16_line(cplx *line, const cplx *twl, Load0 loa
         }
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+template <int R2, bool INV, class Load0, class StoreN>
+__device__ __forceinline__ void wf16_line(cplx *line, const cplx *twl, Load0 load0, StoreN storeN)
+{
+    const int lane = threadIdx.x & 63;
+    const cplx *t1 = twl + (lane & 15), *t2 = twl + Wf16<R2>::TW2 + lane;
+    wf16_line_impl<R2, INV>(line, load0, storeN, [t1](int t) { return t1[16 * (t - 1)]; }, [t2](int q, int t) { return t2[64 * q + 256 * (t - 1)]; });
+}
+
+// a lane's twiddles in registers: 15 + 4 (R2 - 1) complex values (92 registers at n = 768), for kernels that run two waves per SIMD anyway
+template <int R2> struct WfTw {
+    cplx t1[15], t2[4][R2 - 1];
+};
+template <int R2>
+__device__ __forceinline__ void wf16_load_tw(WfTw<R2> &w, const cplx *tw)  // tw: the stage tables (global memory or LDS)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 1; t < 16; t++) w.t1[t - 1] = tw[(lane & 15) + 16 * (t - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int t = 1; t < R2; t++) w.t2[q][t - 1] = tw[Wf16<R2>::TW2 + lane + 64 * q + 256 * (t - 1)];
+}
+template <int R2, bool INV, class Load0, class StoreN>
+__device__ __forceinline__ void wf16_line_regs(cplx *line, const WfTw<R2> &w, Load0 load0, StoreN storeN)
+{
+    wf16_line_impl<R2, INV>(line, load0, storeN, [&w](int t) { return w.t1[t - 1]; }, [&w](int q, int t) { return w.t2[q][t - 1]; });
 }
 
 }  // namespace imcom

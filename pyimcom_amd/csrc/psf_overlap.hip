@@ -363,13 +363,21 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_fwd_cols_kernel(const c
     }
 }
 
+constexpr int WF_COLS_WAVES = 8;  // waves per workgroup of the column kernel: two per SIMD, 256 registers each
 template <int R2, bool AMP>
-__global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
+__global__ __launch_bounds__(WF_COLS_WAVES * 64) void wf16_inv_cols_kernel(const cplx *__restrict__ Ra, const cplx *__restrict__ Rb,
                                                                          const int *__restrict__ pairs, int npairs, int ns,
                                                                          const cplx *__restrict__ tw, double amp0, double amps,
                                                                          const int *__restrict__ win, cplx *__restrict__ V)
 {
-    IMCOM_WF16_PROLOGUE;
+    // (no copy of the stage tables in LDS: this kernel runs two waves per SIMD -- eight lines fill the LDS -- and a lane's twiddles, the
+    // same for every line, stay in 92 of its 256 registers: the tables' LDS reads were a tenth of the kernel, tools/ab_fft_abl.sh)
+    extern __shared__ cplx fbuf[];
+    constexpr int n = Wf16<R2>::N, nh = n / 2 + 1;
+    const int W = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    cplx *line = fbuf + wave * Wf16<R2>::LINE;
+    WfTw<R2> twr;
+    wf16_load_tw<R2>(twr, tw);
     const int nc = ns / 2, rp = (ns + 1) / 2;
     constexpr int nhp = v_stride(n);
     // Line order: four neighbouring columns of a pair, then the next pair, ...  Workgroups are dealt round-robin over the 8 XCDs
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(WF_MAXWAVES * 64) void wf16_inv_cols_kernel(const c
                 return z;
             };
             auto keep = [line](int i, cplx v) { line[wf_pad16(i)] = v; };
-            wf16_line<R2, true>(line, twl, load0, keep);
+            wf16_line_regs<R2, true>(line, twr, load0, keep);
         }
         __syncthreads();
         // group q = wave >> 2 holds columns 4g .. 4g+3 of pair t in lines 4q .. 4q+3; lane = (row pair within a block of 8, column,
@@ -521,8 +529,9 @@ static int wf16_inverse(imcom_ctx *ctx, const cplx *Ra, const cplx *Rb, const in
     // of its own: 2.31 -> 2.22 us per table on a bare request of 3600 tables, nothing inside a block (1752 against 1754 ms per 48 x 48
     // block; profiles/r04_negative_results.txt item 7) -- not the default.
     static const bool split = getenv("IMCOM_FFT_COLS_SPLIT") && atoi(getenv("IMCOM_FFT_COLS_SPLIT")) > 0;
-    const int Wc = split ? 4 : W / 4 * 4, per_cu = split ? (int)std::max<size_t>(1, (160 * 1024) / wf16_lds<R2>(4)) : 1;
-    const size_t lds = wf16_lds<R2>(W), ldsc = wf16_lds<R2>(Wc);
+    const int Wc = split ? 4 : std::min(WF_COLS_WAVES, W / 4 * 4);
+    const size_t lds = wf16_lds<R2>(W), ldsc = (size_t)Wc * Wf16<R2>::LINE * 16;  // (the column kernel keeps no stage tables in LDS)
+    const int per_cu = split ? (int)std::max<size_t>(1, std::min<size_t>(WF_COLS_WAVES / 4, (160 * 1024) / ldsc)) : 1;
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_cols_kernel<R2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
     IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)wf16_inv_rows_kernel<R2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
