@@ -285,7 +285,8 @@ def block_leg(ctx, dev, n1P=48, reps=3, config="cfg2", warm=16):
 
     fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize",
             "eigen_trd", "eigen_applyq", "lakernel1", "eigen_gemm", "epilogue", "block_acc")
-    tabs = BlockTables(groups, target, cfg.nfft, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True)
+    tabs = BlockTables(groups, target, cfg.nfft, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True,
+                       eager_groups=os.environ.get("BENCH_EAGER_GROUPS", "1") != "0")  # (A/B runs: BENCH_EAGER_GROUPS=0)
 
     def one():
         tabs.reset()  # table construction (PSF sampling, spectra, overlap tables) is part of the block

@@ -420,6 +420,17 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
                      n_out=int(getattr(tables, "n_out", 1)), origin=origin)
     if chunks is None:
+        if isinstance(tables, BlockTables) and claim is None and tables.eager_groups:
+            # every PSF group of the stamps to come is sampled / transformed sooner or later: queue as many as the spectra arena holds
+            # NOW, so that the device works while the host plans the passes (12 ms at n1P = 48) and prepares the first one
+            # (BlockTables(eager_groups=True): the provider only queues device work)
+            if stamps is None:
+                tables.prefetch(list(tables.psf))  # the whole block: every group
+            else:
+                # (a stamp's nine InStamps j-1 .. j+1 lie in the group rows (j-1) >> 1 and (j+1) >> 1, likewise the columns: stamp_groups)
+                ji = np.asarray(stamps).reshape(-1, 2)
+                gs = np.unique(np.concatenate([np.stack([(ji[:, 0] + a) >> 1, (ji[:, 1] + b) >> 1], axis=1) for a in (-1, 1) for b in (-1, 1)]), axis=0)
+                tables.prefetch([(int(a), int(b)) for a, b in gs])
         chunks = plan_block(cfg, pool, tables, n1P, batch, ldn, stamps)
     chunks = [[(int(j), int(i)) for j, i in c] for c in chunks]
     maps.chunks_done = []

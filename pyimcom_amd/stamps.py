@@ -203,7 +203,7 @@ class BlockTables:
     ValueError (``blockrun.plan_batches`` sizes a block's batches by ``demand``)."""
 
     def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=None, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict",
-                 group_count=None, bulk_provider=None, cells=False, spec_capacity=None):
+                 group_count=None, bulk_provider=None, cells=False, spec_capacity=None, eager_groups=False):
         assert on_full in ("evict", "raise")
         self.on_full, self.evictions, self.evicted_tables, self.computed_tables = on_full, 0, 0, 0
         self.ctx = ctx or default_context()
@@ -220,6 +220,11 @@ class BlockTables:
         # InStamps (coadd.py:207, 329-358).  The separations between two different groups' pixels then have one sign along
         # every axis in which the groups differ, and of their cross tables only that half (quarter) is computed.
         self.cells = bool(cells)
+        # ``eager_groups=True``: the caller states that materialising a group costs the HOST nothing but queueing device work (PSF images
+        # resident on the device, sampled there) -- coadd_block then asks for every group of a block at its start, so that the device
+        # samples and transforms while the host plans the passes.  Not for providers that wait for host work (refblock's worker threads
+        # deliver the groups in the order of the plan).
+        self.eager_groups = bool(eager_groups)
         self.psf = dict(group_psfs)
         self._order = {k: q for q, k in enumerate(self.psf)}
         self._bulk = bulk_provider
