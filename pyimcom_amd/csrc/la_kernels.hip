@@ -480,12 +480,11 @@ __global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__
 {
     // frames f0 .. f0+nf-1 of the n_inframe input layers; the call with f0 == 0 also tapers T in place and writes
     // the weight sums (later calls find T already tapered)
-    extern __shared__ double accs[];  // [n_expo + nf][256][CPT]
+    extern __shared__ double accs[];  // [max(n_expo, nf)][256][CPT]: the per-exposure sums; at the end, when those have been read, the frames' sums
     const bool first = f0 == 0;
     const int s = blockIdx.y, c = threadIdx.x & 63, a0 = (blockIdx.x * 64 + c) * CPT, rg = threadIdx.x >> 6;
     const int ns = n[s];
-    const int nacc = n_expo + nf;
-    for (int t = 0; t < nacc; t++)
+    for (int t = 0; t < n_expo; t++)
 #pragma unroll
         for (int q = 0; q < CPT; q++) accs[(t * 256 + threadIdx.x) * CPT + q] = 0.0;
     const long base = (long)s * ldn * ldm;
@@ -561,21 +560,16 @@ __global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__
         if (cur >= 0)
 #pragma unroll
             for (int q = 0; q < CPT; q++) accs[(cur * 256 + threadIdx.x) * CPT + q] += racc[q];
-#pragma unroll
-        for (int f = 0; f < EPI_MAXF; f++)
-            if (f < nf)
-#pragma unroll
-                for (int q = 0; q < CPT; q++) accs[((n_expo + f) * 256 + threadIdx.x) * CPT + q] = oacc[f][q];
     }
     __syncthreads();
-    if (rg == 0 && live) {
-        auto tot4 = [&](int t, int q) {
-            return accs[(t * 256 + c) * CPT + q] + accs[(t * 256 + 64 + c) * CPT + q] + accs[(t * 256 + 128 + c) * CPT + q] + accs[(t * 256 + 192 + c) * CPT + q];
-        };
+    auto tot4 = [&](int t, int q) {
+        return accs[(t * 256 + c) * CPT + q] + accs[(t * 256 + 64 + c) * CPT + q] + accs[(t * 256 + 128 + c) * CPT + q] + accs[(t * 256 + 192 + c) * CPT + q];
+    };
+    if (rg == 0 && live && first) {
         for (int q = 0; q < CPT; q++) {
             const int a = a0 + q;
             if (a >= m) break;
-            if (first) {
+            {
                 double tot = 0.0, sabs = 0.0, sq = 0.0;
                 for (int e = 0; e < n_expo; e++) {
                     const double v = tot4(e, q);
@@ -590,9 +584,24 @@ __global__ __launch_bounds__(256) void coadd_epilogue_kernel(float *__restrict__
                 Tsum_inpix[(long)s * m + a] = tot;
                 Neff[(long)s * m + a] = neff;
             }
-            for (int f = 0; f < nf; f++) outimage[((long)s * n_inframe + f0 + f) * m + a] = (float)tot4(n_expo + f, q);
         }
     }
+    // the frames' sums of the four row groups meet in the slots the exposures no longer need (the LDS request is what decides how
+    // many workgroups a CU holds -- three instead of two at six exposures -- and this kernel's rate follows them: tools/ab_epi_occ.sh)
+    __syncthreads();
+    if (live)
+#pragma unroll
+        for (int f = 0; f < EPI_MAXF; f++)
+            if (f < nf)
+#pragma unroll
+                for (int q = 0; q < CPT; q++) accs[(f * 256 + threadIdx.x) * CPT + q] = oacc[f][q];
+    __syncthreads();
+    if (rg == 0 && live)
+        for (int q = 0; q < CPT; q++) {
+            const int a = a0 + q;
+            if (a >= m) break;
+            for (int f = 0; f < nf; f++) outimage[((long)s * n_inframe + f0 + f) * m + a] = (float)tot4(f, q);
+        }
 }
 
 // The tail of coadd_epilogue_kernel (coadd.py:1329-1354) from the per-block-row sums the backward launches left (tile_coadd_partials,
@@ -735,9 +744,11 @@ int launch_epilogue(imcom_ctx *ctx, int batch, const int *n_dev, int ldn, int m,
 {
     for (int f0 = 0; f0 < n_inframe; f0 += EPI_MAXF) {  // EPI_MAXF input layers per pass over T
         const int nf = n_inframe - f0 < EPI_MAXF ? n_inframe - f0 : EPI_MAXF;
-        const int cpt = (size_t)(n_expo + nf) * 256 * 4 * sizeof(double) <= 64 * 1024 + 2048 ? 4 : 1;  // 2 blocks per CU with 4
-        const size_t bytes = (size_t)(n_expo + nf) * 256 * cpt * sizeof(double);
+        const int nslot = n_expo > nf ? n_expo : nf;
+        const int cpt = (size_t)nslot * 256 * 4 * sizeof(double) <= 64 * 1024 + 2048 ? 4 : 1;  // at least 2 blocks per CU with 4
+        size_t bytes = (size_t)nslot * 256 * cpt * sizeof(double);
         IMCOM_REQUIRE(bytes <= 128 * 1024, "epilogue: n_expo = %d too large", n_expo);
+        if (const char *e = getenv("IMCOM_EPI_LDS_PAD")) bytes += (size_t)atoi(e);  // occupancy experiment (tools/ab_epi_occ.sh)
         if (cpt == 4) {
             IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)coadd_epilogue_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
             hipLaunchKernelGGL(coadd_epilogue_kernel<4>, dim3((m + 255) / 256, batch), dim3(256), bytes, ctx->stream, Tt, ldn, ldm, m, n2f, fade,
