@@ -194,3 +194,49 @@ def test_bench_block_leg_workload_with_identical_groups_equals_one_group():
 
     var = coadd_block(cfg2, pool2, BlockTables(groups2, target2, cfg2.nfft, group_count=counts2, bulk_provider=sample2, cells=True), n1P, E)
     assert float((var.out_map - a).abs().max()) > 1e-3 * float(a.abs().max())
+
+
+def test_eager_groups_leave_no_trace():
+    """BlockTables(eager_groups=True): every PSF group of the block is sampled / transformed at the block's start instead of pass by pass
+    (and, with few spectra rows, only as many as the arena holds).  Spectra rows and table slots are then handed out in another order --
+    the block maps must be the same bits, for the whole block and for a window of stamps."""
+    import torch
+
+    import bench
+    from pyimcom_amd import psfs as psfmod
+    from pyimcom_amd.blockrun import coadd_block
+    from pyimcom_amd.stamps import BlockTables
+
+    dev = "cuda:0"
+    n1P = 8
+    torch.cuda.empty_cache()
+    cfg, inst, pool, psfs, target, groups, counts, img_all, yxco_all = bench.block_workload(dev, n1P)
+    E, ns = cfg.n_expo, psfs.shape[-1]
+    order = {k: q for q, k in enumerate(groups)}
+    calls = []
+
+    def sample_groups(keys):
+        calls.append(len(keys))
+        idx = torch.as_tensor([order[k] for k in keys], device=dev)
+        return psfmod.sample_psf(img_all[idx].reshape(-1, ns + 16, ns + 16), ns, yxco_all[idx].reshape(-1, 2, ns, ns), psf_norm=True)
+
+    def block(eager, stamps=None, spec_capacity=None):
+        calls.clear()
+        tabs = BlockTables(groups, target, cfg.nfft, group_count=counts, bulk_provider=sample_groups, cells=True, eager_groups=eager,
+                           spec_capacity=spec_capacity)
+        maps = coadd_block(cfg, pool, tabs, n1P, E, batch=16, stamps=stamps)
+        torch.cuda.synchronize()
+        return maps, list(calls)
+
+    ref, c0 = block(False)
+    eag, c1 = block(True)
+    assert c1[0] == len(groups) and len(c1) == 1 and len(c0) > 1  # one call for the whole block against one per pass
+    few, _ = block(True, spec_capacity=1 + 10 * E)  # the arena holds ten groups: the rest is materialised when first needed
+    win = [(j, i) for j in range(3, 7) for i in range(3, 7)]
+    ref_w, _ = block(False, stamps=win)
+    eag_w, c2 = block(True, stamps=win)
+    assert c2[0] == 9  # the window's stamps touch 3 x 3 groups
+    for a, b in ((ref, eag), (ref, few), (ref_w, eag_w)):
+        assert torch.equal(a.out_map, b.out_map) and torch.equal(a.T_weightmap, b.T_weightmap)
+        for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+            assert torch.equal(a.maps[k], b.maps[k]), k

@@ -97,6 +97,19 @@ def test_resident_path_many_input_layers():
     smoke.check_batch(cfg, n_stamps=2)
 
 
+def test_resident_path_more_layers_than_exposures():
+    """Two exposures, six input layers: the epilogue's LDS slots are sized by the LARGER of the two counts (the frames' sums of a pass
+    -- four layers -- meet in the slots the per-exposure sums have left), with and without the fade taper."""
+    import dataclasses
+
+    from pyimcom_amd import synth
+    from tests import parity as smoke
+
+    for fade in (0, 2):
+        cfg = dataclasses.replace(synth.CONFIGS["small"], name=f"small_l6e2f{fade}", n_inframe=6, n_expo=2, fade=fade)
+        smoke.check_batch(cfg, n_stamps=2)
+
+
 def test_two_target_psfs_vs_oracle():
     """n_out = 2 (OUTPSF plus one cfg.outpsf_extra entry): the reference solves every target on its own with
     kappa = kappaC * C of that target (lakernel.py:121-128); A is shared.  Every output of both targets against the
