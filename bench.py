@@ -504,6 +504,26 @@ def seam_legs(ctx, dev, cfg, batch):
                                  "PSF images + sampling positions per group from host objects (prepared on worker threads ahead of the device), everything "
                                  "else on the device, maps back to host",
                          "out_map_rms": float(np.sqrt(np.mean(np.square(blk.out_map))))}
+    # the same seam on a block of several passes (32 x 32 stamps, 289 PSF groups): the host half of pass k + 1 is prepared while pass k is on
+    # the device, which a one-pass block cannot show (its device waits for the host's whole share first)
+    del blk, psfgrp
+    n1P = int(os.environ.get("IMCOM_BENCH_SEAM_N1P", "32"))
+    if n1P > 16:
+        blk, psfgrp, _, _ = synth.duck_block(cfg, n1P, cfg.n_expo if isinstance(cfg.n_expo, int) else cfg.n_expo[1], seed=5)
+        coadd_output_stamps(blk, psfgrp, device=dev, ctx=ctx, host_threads=threads)  # (a first block of a size pays its allocations: 2.5 s against 1.1)
+        torch.cuda.synchronize()
+        dctx.profile_enable(True)
+        dctx.profile_reset()
+        t0 = time.perf_counter()
+        maps = coadd_output_stamps(blk, psfgrp, device=dev, ctx=ctx, host_threads=threads)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gpu_ms = sum(dctx.profile_get(f)[0] for f in fams)
+        dctx.profile_enable(False)
+        out["block_seam"]["several_passes"] = {"value": n1P * n1P / dt, "unit": "postage-stamps/s", "ms_per_block": dt * 1e3, "stamps_per_block": n1P * n1P,
+                                               "gpu_ms_per_block": gpu_ms, "host_share": 1.0 - gpu_ms * 1e-3 / dt, "host_threads": threads,
+                                               "what": f"the same call on a {n1P}x{n1P}-stamp Block ({(n1P // 2 + 1) ** 2} PSF groups; the second block of that size in the process)"}
+        del maps, blk, psfgrp
     return out
 
 

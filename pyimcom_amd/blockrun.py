@@ -435,8 +435,10 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     chunks = [[(int(j), int(i)) for j, i in c] for c in chunks]
     maps.chunks_done = []
     if isinstance(tables, BlockTables) and chunks and claim is None:
-        # the PSF groups of the first batches are sampled / transformed before the host turns to the per-stamp bookkeeping
-        tables.prefetch(dict.fromkeys(g for c in chunks[:2] for t in c for g in stamp_groups(t[0], t[1], nst)))
+        # the PSF groups of the first batches are sampled / transformed before the host turns to the per-stamp bookkeeping (a provider that
+        # waits for host work is only asked for the first pass: with two, the device idled until the second pass's groups were there)
+        first = chunks[:1] if tables.provider_waits else chunks[:2]
+        tables.prefetch(dict.fromkeys(g for c in first for t in c for g in stamp_groups(t[0], t[1], nst)))
     # two sets of the large per-batch arrays, used alternately (batch k + 1 is prepared while batch k is solved) and kept from
     # block to block
     bufs = _batch_buffers(pool.device)

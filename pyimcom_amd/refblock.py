@@ -235,7 +235,8 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     amp = None if amp is None or 0.0 in tuple(amp) else (float(amp[0]), float(amp[1]) * float(psfgrp.oversamp))  # psfutil.py:661-671
     tables = BlockTables({k: None for k in count}, target, int(psfgrp.nfft), group_expo=expo, group_count=count, bulk_provider=provider,
                          capacity=None if table_capacity is None else int(table_capacity), amp_penalty=amp, device=device, ctx=ctx,
-                         cells=True)  # groups of 2 x 2 InStamps: cells of the block's grid (coadd.py:207, 329-358)
+                         cells=True,  # groups of 2 x 2 InStamps: cells of the block's grid (coadd.py:207, 329-358)
+                         provider_waits=True)  # the provider hands over what the worker threads have prepared
     n1P = int(cfg.n1P)
     window = [int(getattr(blk, k, d)) for k, d in (("j_st_min", 1), ("j_st_max", n1P), ("i_st_min", 1), ("i_st_max", n1P))]
     if stamps is None and (window != [1, n1P, 1, n1P] or getattr(blk, "nrun", None) not in (None, n1P * n1P)):
@@ -245,7 +246,10 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     # the passes first: their order tells which groups' host halves to prepare ahead of the device
     chunks = plan_block(scfg, pool, tables, n1P, batch, stamps=stamps)
     nst = n1P + 2
-    ahead.schedule([g for c in chunks for j, i in c for g in stamp_groups(j, i, nst) if g in count])
+    per_pass = [list(dict.fromkeys(g for j, i in c for g in stamp_groups(j, i, nst) if g in count)) for c in chunks]
+    # the workers may run a whole pass ahead of the device (21 MB of page-locked memory per group at six exposures)
+    ahead.ahead = max(ahead.ahead, max((len(p) for p in per_pass), default=0))
+    ahead.schedule([g for p in per_pass for g in p])
     try:
         maps = coadd_block(scfg, pool, tables, n1P, int(blk.n_inimage), chunks=chunks, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
                            postage_pad=int(getattr(cfg, "postage_pad", 0)), origin=(window[0], window[2]))

@@ -203,7 +203,7 @@ class BlockTables:
     ValueError (``blockrun.plan_batches`` sizes a block's batches by ``demand``)."""
 
     def __init__(self, group_psfs, psf_out, nfft, group_expo=None, capacity=None, amp_penalty=None, ctx=None, device="cuda:0", on_full="evict",
-                 group_count=None, bulk_provider=None, cells=False, spec_capacity=None, eager_groups=False):
+                 group_count=None, bulk_provider=None, cells=False, spec_capacity=None, eager_groups=False, provider_waits=False):
         assert on_full in ("evict", "raise")
         self.on_full, self.evictions, self.evicted_tables, self.computed_tables = on_full, 0, 0, 0
         self.ctx = ctx or default_context()
@@ -225,6 +225,10 @@ class BlockTables:
         # samples and transforms while the host plans the passes.  Not for providers that wait for host work (refblock's worker threads
         # deliver the groups in the order of the plan).
         self.eager_groups = bool(eager_groups)
+        # ``provider_waits=True``: the opposite statement -- the provider may block on host work (refblock: PSF file broker and WCS on worker
+        # threads).  coadd_block then asks ahead of time only for the groups of the FIRST pass; the next pass's groups are asked for when
+        # that pass is prepared, i.e. while the device is busy with the current one.
+        self.provider_waits = bool(provider_waits)
         self.psf = dict(group_psfs)
         self._order = {k: q for q, k in enumerate(self.psf)}
         self._bulk = bulk_provider
