@@ -205,6 +205,12 @@ def test_alternative_code_paths_in_subprocess():
             "smoke.check_batch(dataclasses.replace(synth.CONFIGS['tiny'], kernel='Eigen'), 2); print('alt paths ok')")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "alt paths ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # IMCOM_FFT_COLS_SPLIT: the tables' column transform as independent workgroups of four waves (same arithmetic: the static sizes'
+    # tables against numpy, and the resident path on them); IMCOM_EPI_LDS_PAD: the epilogue at one workgroup per CU
+    env = dict(os.environ, IMCOM_FFT_COLS_SPLIT="1", IMCOM_EPI_LDS_PAD="45000", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_gpu_psfs.py", "tests/test_gpu_stamps.py", "-k",
+                          "(mixed_radix and (32-8 or 24-16 or 32-16)) or test_resident_path_vs_oracle or windows"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     # IMCOM_FFT_GENERIC: the general line-FFT kernels also at the sizes the static 16 x 16 x r kernels normally take
     env = dict(os.environ, IMCOM_FFT_GENERIC="1", PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_gpu_psfs.py", "-k", "mixed_radix and (32-8 or 24-16)"],
