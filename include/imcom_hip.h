@@ -284,6 +284,17 @@ int imcom_solve_chol_resident(imcom_ctx *ctx, int batch, const int *n_host, int 
                               const double *A, const double *Bt, const double *C_host,
                               const double *kappaC_host, int nv, double ucmin, double smax,
                               float *Tt, float *UC, float *Sigma, float *kappa, int *info_host);
+/* imcom_solve_chol_resident in two halves, for a caller with host work to do while the device factors and solves
+ * (the reference's loop is synchronous, lakernel.py:84-138; a block driver prepares its next pass in between).
+ * _begin queues the whole first attempt and returns.  _end waits for it: every A + kappa I positive definite (the
+ * normal case) -> info = 0, IMCOM_OK, outputs final; otherwise _end returns 1 and the caller runs
+ * imcom_solve_chol_resident on the same arguments (the eigh-shift repair of lakernel.py:262-279).  Work queued on the
+ * context between the two calls runs behind the solve; no second solve may begin before _end. */
+int imcom_solve_chol_resident_begin(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm,
+                                    const double *A, const double *Bt, const double *C_host,
+                                    const double *kappaC_host, int nv, double ucmin, double smax,
+                                    float *Tt, float *UC, float *Sigma, float *kappa);
+int imcom_solve_chol_resident_end(imcom_ctx *ctx, int batch, int *info_host);
 /* coadd.py:1320-1354: fade taper of T (trapezoid, 1222-1292), per-exposure weight sums, Neff and
  * outimage = T . indata.
  *   Tt           [batch][ldn][ldm] float32 (tapered in place when fade > 0)

@@ -84,6 +84,8 @@ SIGNATURES = {
     "imcom_build_A": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(TableGeom), _vp, _vp, _i, _vp],
     "imcom_build_B": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(TableGeom), _vp, _i, _vp, _vp, _i, _i, _vp],
     "imcom_solve_chol_resident": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp],
+    "imcom_solve_chol_resident_begin": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],
+    "imcom_solve_chol_resident_end": [_vp, _i, _vp],
     "imcom_coadd_epilogue": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "imcom_solve_chol_resident_coadd": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp,
                                         _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],

@@ -108,7 +108,12 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None, buffers=None)
         lgp = h2d(lg, x.device).gather(1, seg)  # group position of every pixel
         flat = lut.reshape(len(chunk), -1).gather(1, lgp * lut.shape[2] + expo[:, :keep].long())
         valid = torch.arange(keep, device=x.device)[None, :] < h2d(n, x.device, np.int64)[:, None]
-        bad = ((flat < 0) & valid).any()  # read by StampBatch.check() once the batch has been solved: no host wait here
+        bad = ((flat < 0) & valid).any()  # read by check_batch() once the batch has been solved: no host wait here
+        # (its way to the host starts now, into page-locked memory: a read-back after the solve would queue behind whatever the
+        # next pass's preparation has put on the stream by then)
+        bad_host = torch.empty((), dtype=torch.bool).pin_memory()
+        bad_host.copy_(bad, non_blocking=True)
+        bad = (bad_host, torch.cuda.current_stream(x.device).record_event())
         psf_slot = flat.clamp_(min=0).to(torch.int32)
     sb = StampBatch.from_device(cfg, tables, n, x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep],
                                 [(i - 1) * cfg.n2 - cfg.fade for _, i in chunk], [(j - 1) * cfg.n2 - cfg.fade for j, _ in chunk],
@@ -144,14 +149,20 @@ def _side_stream(device):
     dev = torch.device(device)
     key = dev.index or 0
     if key not in _SIDE:
-        _SIDE[key] = (torch.cuda.Stream(dev), Context(key))
+        # (highest priority: its few small kernels -- the host waits for their counts -- must not queue behind the thousands of workgroups
+        # of a solve that the main stream has in flight)
+        _SIDE[key] = (torch.cuda.Stream(dev, priority=-1), Context(key))
     return _SIDE[key]
 
 
 def check_batch(sb):
     """Raise if a pixel of the batch belongs to an exposure its PSF group holds no PSF for (call after the solve: the flag
     is read back from the device)."""
-    if getattr(sb, "bad_psf", None) is not None and bool(sb.bad_psf):
+    bad = getattr(sb, "bad_psf", None)
+    if isinstance(bad, tuple):  # (page-locked flag, event behind its copy)
+        bad[1].synchronize()
+        bad = bool(bad[0])
+    if bad is not None and bool(bad):
         raise ValueError("a pixel belongs to an exposure its PSF group holds no PSF for (BlockTables.group_expo)")
 
 
@@ -467,16 +478,19 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
                 return sb
         return None
 
-    # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after
-    # the current one's A and B builds have been queued, i.e. while the GPU is busy with them; only then does the host
-    # block in the solve's status read-back
+    # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after the current
+    # one's A and B builds AND its solve have been queued (solve_begin: the Cholesky kernel's launches without their read-back), i.e.
+    # while the GPU is busy with them; only then does the host block in the solve's status read-back (solve_end).  (Until round 4 the
+    # solve was queued after the next chunk's preparation: where that takes longer than the builds -- the Block seam, whose provider
+    # hands over host arrays -- the device idled for the difference in every pass.)
     nxt = next_batch()
     while nxt is not None:
         sb = nxt
         sb.build()
+        sb.solve_begin()
         if pipeline:
             nxt = next_batch()
-        sb.solve()
+        sb.solve_end()
         check_batch(sb)
         sb.coadd()
         if not pipeline:

@@ -212,7 +212,7 @@ static size_t coadd_fuse_bytes(int batch, int Np, int m, int mp, int nv, const C
 static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m, int mp, const double *A,
                      const double *Bt, const double *C_host, const double *kappaC_host, int nv, double ucmin,
                      double smax, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host,
-                     const std::function<int()> &before_solve = nullptr, const CoaddArgs *co = nullptr)
+                     const std::function<int()> &before_solve = nullptr, const CoaddArgs *co = nullptr, bool defer = false)
 {
     bool bt_ready = !before_solve;
     const int nbmax_all = Np / NB;
@@ -328,6 +328,25 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                 IMCOM_TRY(launch_finalize_single(ctx, Y, Bt, Np, mp, m, n_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch));
             else
                 IMCOM_TRY(launch_multi(ctx, Y, node_stride, Bt, Np, mp, m, n_dev, nv, kappaC_dev, C_dev, ucmin, smax, Dp, Npq, W, Tt, UC, Sigma, kappa, batch));
+        }
+        if (defer) {
+            // imcom_solve_chol_resident_begin: everything of the first attempt is queued; the failure flags travel to page-locked memory
+            // behind it (in stream order: before whatever the caller queues next may reuse the workspace) and ..._end reads them
+            const size_t cnt = (size_t)nv * batch;
+            if (ctx->flag_pin_count < cnt) {
+                if (ctx->flag_pin) { IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream)); IMCOM_HIP_CHECK(hipHostFree(ctx->flag_pin)); ctx->flag_pin = nullptr; ctx->flag_pin_count = 0; }
+                IMCOM_HIP_CHECK(hipHostMalloc((void **)&ctx->flag_pin, std::max<size_t>(cnt, 256) * 4, hipHostMallocDefault));
+                ctx->flag_pin_count = std::max<size_t>(cnt, 256);
+            }
+            IMCOM_HIP_CHECK(hipMemcpyAsync(ctx->flag_pin, fail_dev, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+            while (ctx->sync_events.size() < 3) {
+                hipEvent_t e;
+                IMCOM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->sync_events.push_back(e);
+            }
+            IMCOM_HIP_CHECK(hipEventRecord(ctx->sync_events[2], ctx->stream));
+            ctx->deferred_flags = (long)cnt;
+            return IMCOM_OK;
         }
         IMCOM_HIP_CHECK(hipMemcpyAsync(fail.data(), fail_dev, fail.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -941,6 +960,40 @@ int imcom_solve_chol_resident(imcom_ctx *ctx, int batch, const int *n_host, int 
     IMCOM_REQUIRE(nv <= CHOL_MAXNV, "nv=%d kappa nodes: at most %d", nv, CHOL_MAXNV);
     IMCOM_TRY(ws_reserve(ctx, chol_core_bytes(batch, ldn, m, ldm, nv)));
     return chol_core(ctx, batch, n_host, ldn, m, ldm, A, Bt, C_host, kappaC_host, nv, ucmin, smax, Tt, UC, Sigma, kappa, info_host);
+}
+
+// The same solve in two halves, for a caller that has host work to do while the device factors and solves (blockrun.coadd_block
+// prepares the next pass in between): _begin queues everything of the FIRST attempt and returns; _end waits for it and reads the
+// factorisations' failure flags.  All positive definite (the normal case): info = 0, IMCOM_OK, the outputs are final.  Otherwise _end
+// returns 1 and has written nothing: the caller runs imcom_solve_chol_resident on the same arguments, which repairs as the reference does
+// (lakernel.py:262-279).  Between the two calls the caller may queue other work on the context (it runs behind the solve and may reuse
+// the workspace), but no other solve.
+int imcom_solve_chol_resident_begin(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm, const double *A, const double *Bt,
+                                    const double *C_host, const double *kappaC_host, int nv, double ucmin, double smax, float *Tt, float *UC,
+                                    float *Sigma, float *kappa)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n_host && A && Bt && C_host && kappaC_host && Tt && UC && Sigma && kappa, "null pointer");
+    IMCOM_REQUIRE(ldn >= NB && ldn % NB == 0 && ldm % NB == 0 && m >= 1 && m <= ldm && nv >= 1, "ldn=%d / ldm=%d must be multiples of %d", ldn, ldm, NB);
+    IMCOM_REQUIRE(nv <= CHOL_MAXNV, "nv=%d kappa nodes: at most %d", nv, CHOL_MAXNV);
+    IMCOM_REQUIRE(ctx->deferred_flags == 0, "imcom_solve_chol_resident_begin: the previous begin has not been ended");
+    IMCOM_TRY(ws_reserve(ctx, chol_core_bytes(batch, ldn, m, ldm, nv)));
+    std::vector<int> info(batch, 0);
+    return chol_core(ctx, batch, n_host, ldn, m, ldm, A, Bt, C_host, kappaC_host, nv, ucmin, smax, Tt, UC, Sigma, kappa, info.data(), nullptr, nullptr, true);
+}
+
+int imcom_solve_chol_resident_end(imcom_ctx *ctx, int batch, int *info_host)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(info_host && batch >= 1, "null pointer");
+    IMCOM_REQUIRE(ctx->deferred_flags > 0 && ctx->deferred_flags % batch == 0, "imcom_solve_chol_resident_end without a matching begin");
+    const long cnt = ctx->deferred_flags;
+    ctx->deferred_flags = 0;
+    IMCOM_HIP_CHECK(hipEventSynchronize(ctx->sync_events[2]));
+    for (long q = 0; q < cnt; q++)
+        if (ctx->flag_pin[q] != 0) return 1;  // a factorisation failed: imcom_solve_chol_resident repairs it
+    for (int s = 0; s < batch; s++) info_host[s] = 0;
+    return IMCOM_OK;
 }
 
 // CholKernel on the device layouts followed by the coaddition of the same stamps, in one call: with one kappa node and fade 0

@@ -66,6 +66,7 @@ struct imcom_ctx {
     std::vector<hipStream_t> part_streams; // the same with a share of the CUs each (IMCOM_SPLIT_CUS=1; eigen.hip)
     int *flag_pin = nullptr;               // page-locked read-back of per-stamp flags (an async copy into pageable memory would block the host)
     size_t flag_pin_count = 0;
+    long deferred_flags = 0;               // imcom_solve_chol_resident_begin: flags on their way to flag_pin (0: no begin outstanding)
     hipEvent_t stream_event = nullptr;    // orders a newly bound stream behind the previous one (imcom_ctx_set_stream)
     // bump-allocated device workspace; reset at the start of every API call that uses it
     char *ws = nullptr;

@@ -167,9 +167,18 @@ def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1):
     def provider(keys):
         got = [ahead.get(key) for key in keys]
         if all(isinstance(g, tuple) for g in got) and len({g[0].shape[1:] for g in got}) == 1:
-            # every group arrived as page-locked stacks of one image size: queue the copies, sample everything in one call
-            im = torch.cat([g[0].to(device, non_blocking=True) for g in got]) if len(got) > 1 else got[0][0].to(device, non_blocking=True)
-            yx = torch.cat([g[1].to(device, non_blocking=True) for g in got]) if len(got) > 1 else got[0][1].to(device, non_blocking=True)
+            # every group arrived as page-locked stacks of one image size: queue the copies, sample everything in one call.  The copies
+            # (1.5 GB for the 72 new groups of a pass at six exposures) run on the upload stream, beside the solve the current stream is
+            # busy with; queued behind it they were 30 ms per pass with the device's compute units idle.
+            from .stamps import upload_stream
+
+            up, cur = upload_stream(device), torch.cuda.current_stream(device)
+            with torch.cuda.stream(up):
+                im = torch.cat([g[0].to(device, non_blocking=True) for g in got]) if len(got) > 1 else got[0][0].to(device, non_blocking=True)
+                yx = torch.cat([g[1].to(device, non_blocking=True) for g in got]) if len(got) > 1 else got[0][1].to(device, non_blocking=True)
+            cur.wait_stream(up)
+            im.record_stream(cur)
+            yx.record_stream(cur)
             return psfs.sample_psf(im, ns, yx, circ, norm, ctx)
         imgs, yxco = [], []
         for g in got:

@@ -33,11 +33,32 @@ def _hp(a):
 _GRIDS = {}
 
 
+_UPLOAD = {}
+
+
+def upload_stream(dev):
+    """The stream host-to-device copies run on (one per device, highest priority), beside whatever the current stream is busy with."""
+    dev = torch.device(dev)
+    key = dev.index or 0
+    if key not in _UPLOAD:
+        _UPLOAD[key] = torch.cuda.Stream(dev, priority=-1)
+    return _UPLOAD[key]
+
+
 def h2d(a, dev, dtype=None):
-    """Host array -> device tensor through pinned memory, queued on the current stream without a host wait (a plain
-    ``torch.as_tensor(a, device=dev)`` of pageable memory drains the stream first: 0.2-0.4 ms of idle GPU per call in a block)."""
-    t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype))
-    return t.pin_memory().to(dev, non_blocking=True)
+    """Host array -> device tensor through pinned memory without a host wait (a plain ``torch.as_tensor(a, device=dev)`` of pageable
+    memory drains the stream first: 0.2-0.4 ms of idle GPU per call in a block).  The copy runs on a stream of its own and the
+    current stream waits for it on the device: it does not queue behind the solve the current stream may be busy with, and its
+    page-locked staging block is free again as soon as the copy is done (behind a long solve torch's host allocator found every
+    block still in use and paid a fresh allocation, 2 ms, per call)."""
+    dev = torch.device(dev)
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).pin_memory()
+    up, cur = upload_stream(dev), torch.cuda.current_stream(dev)
+    with torch.cuda.stream(up):
+        out = t.to(dev, non_blocking=True)
+    cur.wait_stream(up)
+    out.record_stream(cur)
+    return out
 
 
 def free_device_bytes(dev):
@@ -701,6 +722,38 @@ class StampBatch:
         self._coadded = set()
         for o in range(self.n_out):
             self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o], o)
+
+    def solve_begin(self):
+        """The solve queued, not waited for (imcom_solve_chol_resident_begin; one target PSF, Cholesky kernel -- anything else runs
+        ``solve()`` here and ``solve_end()`` is a no-op): the caller prepares its next pass while the device factors and solves, then
+        calls ``solve_end()``."""
+        cfg = self.cfg
+        self._deferred = False
+        if cfg.kernel != "Cholesky" or self.n_out != 1 or (cfg.fade == 0 and os.environ.get("IMCOM_EPILOGUE_FUSED") == "1") \
+                or os.environ.get("IMCOM_SOLVE_DEFERRED", "1") == "0":
+            return self.solve()
+        self._stream()
+        self._coadded = set()
+        check(lib.imcom_solve_chol_resident_begin(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, _dp(self.A), _dp(self.Bt_o[0]),
+                                                  _hp(self.Cs_o[0]), _hp(self.kappaC), len(self.kappaC), float(cfg.uctarget), float(cfg.sigmamax),
+                                                  _dp(self.Tt_o[0]), _dp(self.UC_o[0]), _dp(self.Sigma_o[0]), _dp(self.kappa_o[0])))
+        if cfg.fade > 0:
+            for t in (self.kappa_o[0], self.Sigma_o[0], self.UC_o[0]):
+                check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))
+        self._deferred = True
+
+    def solve_end(self):
+        """Wait for ``solve_begin()``'s work; a batch with a factorisation that failed is solved again by the synchronous entry, which
+        repairs it as the reference does (lakernel.py:262-279)."""
+        if not getattr(self, "_deferred", False):
+            return
+        self._deferred = False
+        self._stream()
+        rc = lib.imcom_solve_chol_resident_end(self.ctx.handle, self.batch, _hp(self.info_o[0]))
+        if rc == 1:
+            self.solve()
+        else:
+            check(rc)
 
     def _solve_target(self, Bt, Cs, Tt, UC, Sigma, kappa, info, o=0):
         cfg = self.cfg
