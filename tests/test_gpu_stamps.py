@@ -274,3 +274,42 @@ def test_coaddition_inside_the_solve_equals_the_stand_alone_epilogue(kw, monkeyp
         tol = 2e-7 if k == "outimage_o" else 1e-12
         assert float((a - b).abs().max()) <= tol * float(b.abs().max()), k
     assert float(sb.outimage_o.abs().max()) > 0
+
+
+def test_solve_in_two_halves_equals_the_synchronous_solve():
+    """imcom_solve_chol_resident_begin / _end (StampBatch.solve_begin / solve_end: what blockrun.coadd_block runs, with the next pass
+    prepared in between): the same bits as the synchronous entry -- for a normal batch, with the fade taper, and for a batch in which
+    one stamp's A + kappa I is not positive definite: _end then reports the failure, the synchronous entry repairs it as the reference
+    does (lakernel.py:262-279) and info names the stamp."""
+    import dataclasses
+
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    for fade, breakit in ((0, False), (2, False), (0, True)):
+        cfg = dataclasses.replace(synth.CONFIGS["small"], name=f"small_halves_{fade}_{int(breakit)}", fade=fade)
+        stamps = [synth.make_stamp(cfg, i) for i in range(3)]
+        psfs, target = synth.make_psfs(cfg, max(s.n_expo for s in stamps))
+        tabs = PSFGroupTables(psfs, target, cfg.nfft)
+        out = []
+        for halves in (False, True):
+            sb = StampBatch(cfg, stamps, tabs)
+            sb.build()
+            if breakit:  # stamp 1: a diagonal entry far below zero -- the factorisation fails, the eigh-shift repair takes over
+                sb.A[1, 5, 5] -= 10.0 * float(sb.A[1].diagonal().abs().max())
+            if halves:
+                sb.solve_begin()
+                torch.zeros(1 << 20, device="cuda:0").sum()  # (other work queued between the halves)
+                sb.solve_end()
+            else:
+                sb.solve()
+            sb.coadd()
+            torch.cuda.synchronize()
+            r = sb.result()
+            out.append({k: getattr(r, k).clone() for k in ("Tt", "UC", "Sigma", "kappa", "outimage", "Neff")} | {"info": sb.info_o[0].copy()})
+        a, b = out
+        assert (a["info"] == b["info"]).all() and (int(a["info"][1]) != 0) == breakit and a["info"][0] == 0
+        for k in ("Tt", "UC", "Sigma", "kappa", "outimage", "Neff"):
+            assert torch.equal(a[k], b[k]), (fade, breakit, k)
