@@ -746,14 +746,15 @@ class StampBatch:
         """Wait for ``solve_begin()``'s work; a batch with a factorisation that failed is solved again by the synchronous entry, which
         repairs it as the reference does (lakernel.py:262-279)."""
         if not getattr(self, "_deferred", False):
-            return
+            return False
         self._deferred = False
         self._stream()
         rc = lib.imcom_solve_chol_resident_end(self.ctx.handle, self.batch, _hp(self.info_o[0]))
         if rc == 1:
             self.solve()
-        else:
-            check(rc)
+            return True  # (solved again: whatever the caller queued on the first attempt's outputs has to be queued again)
+        check(rc)
+        return False
 
     def _solve_target(self, Bt, Cs, Tt, UC, Sigma, kappa, info, o=0):
         cfg = self.cfg
@@ -820,8 +821,15 @@ class StampBatch:
 
     def run(self):
         self.build()
-        self.solve()
-        self.coadd()
+        self.solve_begin()
+        if getattr(self, "_deferred", False):
+            # the coaddition queued behind the solve's launches before the host waits for them (no gap between the two on the device);
+            # a batch whose factorisation failed has been solved again by solve_end(): coadd its repaired T
+            self.coadd()
+            if self.solve_end():
+                self.coadd()
+        else:
+            self.coadd()
         return self.result()
 
     def result(self, o=0):
