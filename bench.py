@@ -681,26 +681,46 @@ def main():
             },
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()},
         }
+        from pyimcom_amd.blockrun import release_buffers
+
+        def tidy():
+            torch.cuda.synchronize()
+            release_buffers()
+            ctx.release_workspace()
+            torch.cuda.empty_cache()
+
+        def leg(fn):
+            """An additional leg must never cost the headline its JSON line: a leg that fails reports the error instead of its numbers."""
+            import traceback
+
+            try:
+                return fn()
+            except Exception as e:  # noqa: BLE001
+                traceback.print_exc(file=sys.stderr)
+                try:
+                    tidy()
+                except Exception:  # noqa: BLE001
+                    pass
+                return {"error": f"{type(e).__name__}: {e}"[:400]}
+
         if not args.no_block and world == 1 and args.config == "cfg2":
-            out.update(seam_legs(ctx, dev, cfg, batch))
+            seams = leg(lambda: seam_legs(ctx, dev, cfg, batch))
+            out.update(seams if "error" not in seams else {"seams": seams})
             del batch
             torch.cuda.empty_cache()
-            out["block"] = block_leg(ctx, dev, reps=args.block_reps)
+            out["block"] = leg(lambda: block_leg(ctx, dev, reps=args.block_reps))
         if not args.no_configs and world == 1 and args.config == "cfg2":
             batch = None
             torch.cuda.empty_cache()
-            from pyimcom_amd.blockrun import release_buffers
-
             release_buffers()
-            out["configs"] = config_legs(ctx, dev)
+            out["configs"] = leg(lambda: config_legs(ctx, dev))
             out["configs"]["cfg2"] = {"config": "BASELINE configs[1]", "value": out["value"], "unit": out["unit"], "ms_per_stamp": out["ms_per_stamp"],
                                       "roofline": {k: out["roofline"][k] for k in ("kernel", "achieved", "peak", "frac")}, "see": "the top level of this line"}
             # BASELINE configs[2] "batched across one block": the Eigen kernel with its kappa sweep through coadd_block, PSF group per 2 x 2 InStamps
-            ctx.release_workspace()  # (the 256-stamp Eigen leg left 130 GB of workspace on the context: the block planner sizes passes by free memory)
-            torch.cuda.empty_cache()
-            out["eigen_block"] = block_leg(ctx, dev, n1P=16, reps=1, config="cfg3", warm=8)
+            tidy()  # (the 256-stamp Eigen leg left 130 GB of workspace on the context: the block planner sizes passes by free memory)
+            out["eigen_block"] = leg(lambda: block_leg(ctx, dev, n1P=16, reps=1, config="cfg3", warm=8))
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
-            out["cpu_baseline"] = cpu_baseline(cfg, cpu_sample, psfs, target, args.cpu_budget)
+            out["cpu_baseline"] = leg(lambda: cpu_baseline(cfg, cpu_sample, psfs, target, args.cpu_budget))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
-from ._lib import PAIR_SWAP,  PAIR_FLIP, TableGeom, check, default_context, lib
+from ._lib import PAIR_SWAP,  PAIR_FLIP, ImcomError, TableGeom, check, default_context, lib
 
 NB = 128
 
@@ -721,22 +721,34 @@ class StampBatch:
         self._stream()
         self._coadded = set()
         for o in range(self.n_out):
-            self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o], o)
+            try:
+                self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o], o)
+            except ImcomError as e:
+                if e.status != -3:  # IMCOM_ERR_NOMEM: the library's workspace is a device allocation of its own -- memory that torch's
+                    raise           # caching allocator holds without using it is not available to it until it is handed back
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o], o)
 
     def solve_begin(self):
-        """The solve queued, not waited for (imcom_solve_chol_resident_begin; one target PSF, Cholesky kernel -- anything else runs
-        ``solve()`` here and ``solve_end()`` is a no-op): the caller prepares its next pass while the device factors and solves, then
-        calls ``solve_end()``."""
+        """The solve queued, not waited for (imcom_solve_chol_resident_begin; one target PSF, Cholesky kernel -- for anything else nothing
+        happens here and ``solve_end()`` runs the synchronous ``solve()``): the caller prepares its next pass while the device factors and
+        solves, then calls ``solve_end()``."""
         cfg = self.cfg
-        self._deferred = False
+        self._deferred, self._unsolved = False, False
         if cfg.kernel != "Cholesky" or self.n_out != 1 or (cfg.fade == 0 and os.environ.get("IMCOM_EPILOGUE_FUSED") == "1") \
                 or os.environ.get("IMCOM_SOLVE_DEFERRED", "1") == "0":
-            return self.solve()
+            self._unsolved = True  # solve_end() runs the synchronous solve: the caller's work in between still overlaps the builds
+            return
         self._stream()
         self._coadded = set()
-        check(lib.imcom_solve_chol_resident_begin(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, _dp(self.A), _dp(self.Bt_o[0]),
-                                                  _hp(self.Cs_o[0]), _hp(self.kappaC), len(self.kappaC), float(cfg.uctarget), float(cfg.sigmamax),
-                                                  _dp(self.Tt_o[0]), _dp(self.UC_o[0]), _dp(self.Sigma_o[0]), _dp(self.kappa_o[0])))
+        rc = lib.imcom_solve_chol_resident_begin(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, _dp(self.A), _dp(self.Bt_o[0]),
+                                                 _hp(self.Cs_o[0]), _hp(self.kappaC), len(self.kappaC), float(cfg.uctarget), float(cfg.sigmamax),
+                                                 _dp(self.Tt_o[0]), _dp(self.UC_o[0]), _dp(self.Sigma_o[0]), _dp(self.kappa_o[0]))
+        if rc == -3:  # the workspace could not grow (nothing has been queued): the synchronous path hands torch's cached memory back and retries
+            self._unsolved = True
+            return
+        check(rc)
         if cfg.fade > 0:
             for t in (self.kappa_o[0], self.Sigma_o[0], self.UC_o[0]):
                 check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))
@@ -745,6 +757,10 @@ class StampBatch:
     def solve_end(self):
         """Wait for ``solve_begin()``'s work; a batch with a factorisation that failed is solved again by the synchronous entry, which
         repairs it as the reference does (lakernel.py:262-279)."""
+        if getattr(self, "_unsolved", False):
+            self._unsolved = False
+            self.solve()
+            return False
         if not getattr(self, "_deferred", False):
             return False
         self._deferred = False
@@ -829,6 +845,7 @@ class StampBatch:
             if self.solve_end():
                 self.coadd()
         else:
+            self.solve_end()  # (kernels without the two halves: the synchronous solve)
             self.coadd()
         return self.result()
 
