@@ -313,3 +313,39 @@ def test_solve_in_two_halves_equals_the_synchronous_solve():
         assert (a["info"] == b["info"]).all() and (int(a["info"][1]) != 0) == breakit and a["info"][0] == 0
         for k in ("Tt", "UC", "Sigma", "kappa", "outimage", "Neff"):
             assert torch.equal(a[k], b[k]), (fade, breakit, k)
+
+
+def test_solve_retries_when_the_workspace_cannot_grow(monkeypatch):
+    """The library's workspace is a device allocation of its own: memory torch's caching allocator holds unused is not available to
+    it.  IMCOM_ERR_NOMEM from the solve makes StampBatch hand that memory back and try once more; another status is raised."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd._lib import ImcomError
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    cfg = synth.CONFIGS["tiny"]
+    stamps = [synth.make_stamp(cfg, i) for i in range(2)]
+    psfs, target = synth.make_psfs(cfg, max(s.n_expo for s in stamps))
+    sb = StampBatch(cfg, stamps, PSFGroupTables(psfs, target, cfg.nfft))
+    ref = sb.run()
+    torch.cuda.synchronize()
+    T_ref = ref.Tt.clone()
+    real, calls = StampBatch._solve_target, []
+
+    def flaky(self, *a, **k):
+        calls.append(1)
+        if len(calls) == 1:
+            raise ImcomError(-3, "device workspace: out of memory (injected)")
+        return real(self, *a, **k)
+
+    monkeypatch.setattr(StampBatch, "_solve_target", flaky)
+    sb.build()
+    sb.solve()
+    sb.coadd()
+    torch.cuda.synchronize()
+    assert len(calls) == 2 and torch.equal(sb.result().Tt, T_ref)
+    calls.clear()
+    monkeypatch.setattr(StampBatch, "_solve_target", lambda self, *a, **k: (_ for _ in ()).throw(ImcomError(-5, "injected")))
+    with pytest.raises(ImcomError):
+        sb.solve()
