@@ -322,6 +322,7 @@ def block_leg(ctx, dev, n1P=48, reps=3, config="cfg2", warm=16):
         "stage_ms_per_block": stages, # (the Eigen kernel's sub-batches run on two streams: their stage times overlap and do not add up to the wall time)
         "host_and_gaps_ms_per_block": (dt * 1e3 - sum(stages.values())) if sum(stages.values()) <= dt * 1e3 else None,
         "out_map_rms": float(maps.out_map.square().mean().sqrt()),
+        "passes_halved": int(getattr(maps, "passes_halved", 0)),  # passes the device had no memory for after all, run again as two (last timed block)
     }
 
 

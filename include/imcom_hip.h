@@ -289,7 +289,7 @@ int imcom_solve_chol_resident(imcom_ctx *ctx, int batch, const int *n_host, int 
  * _begin queues the whole first attempt and returns.  _end waits for it: every A + kappa I positive definite (the
  * normal case) -> info = 0, IMCOM_OK, outputs final; otherwise _end returns 1 and the caller runs
  * imcom_solve_chol_resident on the same arguments (the eigh-shift repair of lakernel.py:262-279).  Work queued on the
- * context between the two calls runs behind the solve; no second solve may begin before _end. */
+ * context between the two calls runs behind the solve; a begin whose _end never came is waited for and forgotten by the next begin. */
 int imcom_solve_chol_resident_begin(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm,
                                     const double *A, const double *Bt, const double *C_host,
                                     const double *kappaC_host, int nv, double ucmin, double smax,

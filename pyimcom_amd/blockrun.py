@@ -15,6 +15,7 @@ import numpy as np
 
 from .block import BlockMaps
 from .select import select_pixels
+from ._lib import ImcomError
 from .stamps import NB, BatchBuffers, BlockTables, StampBatch, free_device_bytes, h2d
 
 
@@ -473,7 +474,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         for q in todo:  # the next pass this process may run
             if chunks[q] and (claim is None or claim(q)):
                 sb = prepare_batch(cfg, pool, tables, chunks[q], n1P, n_expo, ldn, buffers=bufs[count[0] & 1])
-                sb.chunk_index = q
+                sb.chunk_index, sb.buf_index = q, count[0] & 1
                 count[0] += 1
                 return sb
         return None
@@ -483,14 +484,50 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     # while the GPU is busy with them; only then does the host block in the solve's status read-back (solve_end).  (Until round 4 the
     # solve was queued after the next chunk's preparation: where that takes longer than the builds -- the Block seam, whose provider
     # hands over host arrays -- the device idled for the difference in every pass.)
+    def out_of_memory(e):
+        return e.status == -3 or (e.status == -2 and "out of memory" in str(e))  # IMCOM_ERR_NOMEM, or a launch / allocation HIP refused for lack of memory
+
+    def in_halves(sb):
+        """A pass the device has no memory for after all (the plan is an estimate: 0.8 of what is free divided by a model of a stamp's
+        needs) is run again as two passes of half the stamps, cut on a cell boundary, in the failed pass's buffers."""
+        import torch
+
+        torch.cuda.synchronize()
+        tables.ctx.release_workspace()
+        torch.cuda.empty_cache()
+        chunk, h = list(sb.chunk), max(4, len(sb.chunk) // 2 // 4 * 4)
+        done = []
+        for part in (chunk[:h], chunk[h:]):
+            if not part:
+                continue
+            sp = prepare_batch(cfg, pool, tables, part, n1P, n_expo, ldn, buffers=bufs[sb.buf_index])
+            sp.build()
+            sp.solve()
+            check_batch(sp)
+            sp.coadd()
+            maps.add(sp.results(), [j for j, _ in sp.chunk], [i for _, i in sp.chunk])
+            done.append(len(part))
+        return done
+
     nxt = next_batch()
+    maps.passes_halved = 0
     while nxt is not None:
         sb = nxt
         sb.build()
         sb.solve_begin()
         if pipeline:
             nxt = next_batch()
-        sb.solve_end()
+        try:
+            sb.solve_end()
+        except ImcomError as e:
+            if not out_of_memory(e) or len(sb.chunk) < 8:
+                raise
+            in_halves(sb)
+            maps.passes_halved += 1
+            maps.chunks_done.append(sb.chunk_index)
+            if not pipeline:
+                nxt = next_batch()
+            continue
         check_batch(sb)
         sb.coadd()
         if not pipeline:

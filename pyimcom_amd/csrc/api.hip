@@ -976,7 +976,10 @@ int imcom_solve_chol_resident_begin(imcom_ctx *ctx, int batch, const int *n_host
     IMCOM_REQUIRE(batch >= 1 && n_host && A && Bt && C_host && kappaC_host && Tt && UC && Sigma && kappa, "null pointer");
     IMCOM_REQUIRE(ldn >= NB && ldn % NB == 0 && ldm % NB == 0 && m >= 1 && m <= ldm && nv >= 1, "ldn=%d / ldm=%d must be multiples of %d", ldn, ldm, NB);
     IMCOM_REQUIRE(nv <= CHOL_MAXNV, "nv=%d kappa nodes: at most %d", nv, CHOL_MAXNV);
-    IMCOM_REQUIRE(ctx->deferred_flags == 0, "imcom_solve_chol_resident_begin: the previous begin has not been ended");
+    if (ctx->deferred_flags != 0) {  // a begin whose end never came (the caller failed in between): its work is waited for and forgotten
+        IMCOM_HIP_CHECK(hipEventSynchronize(ctx->sync_events[2]));
+        ctx->deferred_flags = 0;
+    }
     IMCOM_TRY(ws_reserve(ctx, chol_core_bytes(batch, ldn, m, ldm, nv)));
     std::vector<int> info(batch, 0);
     return chol_core(ctx, batch, n_host, ldn, m, ldm, A, Bt, C_host, kappaC_host, nv, ucmin, smax, Tt, UC, Sigma, kappa, info.data(), nullptr, nullptr, true);

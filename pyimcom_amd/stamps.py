@@ -576,6 +576,10 @@ class BatchBuffers:
         f = self._flat.get(name)
         if f is None or f.dtype != dtype or f.numel() < n:
             self._flat[name] = None  # drop the old block before the larger one is requested
+            if f is not None:
+                # ... and hand it back to the driver: torch's allocator would keep it cached, of no use to a larger request and out of
+                # reach for the library's own workspace allocation (a pass that then does not fit is halved, blockrun.coadd_block)
+                torch.cuda.empty_cache()
             f = self._flat[name] = torch.empty(n, dtype=dtype, device=self.dev)
         return f[:n].view(*shape)
 

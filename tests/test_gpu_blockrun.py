@@ -374,3 +374,50 @@ def test_ragged_batches_are_reordered_without_a_trace(monkeypatch):
     for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
         assert torch.equal(a.maps[k], b.maps[k]), k
     assert float(a.out_map.abs().max()) > 0
+
+
+def test_a_pass_that_runs_out_of_memory_is_run_in_halves(monkeypatch):
+    """The plan of a block is an estimate of what fits; a pass whose solve reports IMCOM_ERR_NOMEM (or a launch HIP refused for lack of
+    memory) is run again as two passes of half the stamps, cut on a cell boundary, and the block comes out as if those halves had been
+    planned: the same bits as the explicit plan.  Both kinds of solve: the two halves of the Cholesky kernel and the synchronous one."""
+    import dataclasses
+
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd._lib import ImcomError
+    from pyimcom_amd.blockrun import coadd_block
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    n1P, n_expo = 4, 3
+    for kernel in ("Cholesky", "Eigen"):
+        cfg = dataclasses.replace(synth.CONFIGS["tiny"], kernel=kernel)
+        inst = _instamps(cfg, n1P, n_expo, np.random.default_rng(5))
+        psfs, target = synth.make_psfs(cfg, n_expo)
+        tabs = PSFGroupTables(psfs, target, cfg.nfft)
+        pool = InStampPool(inst, cfg.n_inframe)
+        todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+        plan = [todo[:8], todo[8:]]
+        real = StampBatch.solve_end
+
+        def refuse(self):  # passes of more than four stamps do not "fit"
+            if self.batch > 4:
+                self._deferred = self._unsolved = False
+                if self.cfg.kernel == "Cholesky":
+                    self.ctx.release_workspace()  # (forget the begin that is outstanding)
+                raise ImcomError(-3, "device workspace: out of memory (injected)")
+            return real(self)
+
+        with monkeypatch.context() as mp:
+            mp.setenv("IMCOM_SOLVE_DEFERRED", "0")  # (the injected failure stands for both; an outstanding begin would have to be ended)
+            mp.setattr(StampBatch, "solve_end", refuse)
+            got = coadd_block(cfg, pool, tabs, n1P, n_expo, chunks=plan)
+            torch.cuda.synchronize()
+        assert got.passes_halved == 2
+        ref = coadd_block(cfg, pool, tabs, n1P, n_expo, chunks=[todo[:4], todo[4:8], todo[8:12], todo[12:]])
+        torch.cuda.synchronize()
+        assert ref.passes_halved == 0
+        assert torch.equal(got.out_map, ref.out_map) and torch.equal(got.T_weightmap, ref.T_weightmap), kernel
+        for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+            assert torch.equal(got.maps[k], ref.maps[k]), (kernel, k)
