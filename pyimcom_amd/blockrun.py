@@ -176,7 +176,7 @@ def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap
     the other kernels work on copies in the reference's layout (``stamp_bytes``)."""
     hi = min(int(n_stamps), int(cap))
     if free_bytes is not None:
-        hi = max(1, min(hi, int(0.8 * free_bytes) // stamp_bytes(ldn, ldm, n_out, kernel)))
+        hi = max(1, min(hi, int(fill_of(kernel) * free_bytes) // stamp_bytes(ldn, ldm, n_out, kernel)))
     if hi >= n_stamps:
         return max(int(n_stamps), 1)
     tiles, slots = max(ldm // NB, 1), 2 * cu_count
@@ -187,6 +187,13 @@ def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap
         if best_cost is None or cost < best_cost:
             best, best_cost = b, cost
     return best
+
+
+def fill_of(kernel):
+    """Share of the free device memory a plan may fill by the model of ``stamp_bytes``: 0.8; 0.7 for the Eigen kernel, whose workspace is
+    most of a pass -- at 0.8 a 16 x 16-stamp cfg-3 block sat on the border between one pass of 256 stamps and two of 128, and the one pass,
+    when the device had a few GB less to give than it reported, ran out of memory or (worse) at a sixth of its speed."""
+    return 0.7 if kernel == "Eigen" else 0.8
 
 
 def stamp_bytes(ldn, ldm, n_out=1, kernel="Cholesky", resident=2):
@@ -390,7 +397,7 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
             free += sum(b_.nbytes() for b_ in _BUFS[key_])
         n_out = int(getattr(tables, "n_out", 1))
         if grouped:  # tiles of 2 x 2-stamp cells, sized by memory and by the table arena (plan_batches)
-            cap = max(1, min(256, int(0.8 * free) // stamp_bytes(ldn_max, ldm, n_out, cfg.kernel)))
+            cap = max(1, min(256, int(fill_of(cfg.kernel) * free) // stamp_bytes(ldn_max, ldm, n_out, cfg.kernel)))
         else:
             cap = choose_batch(len(todo), ldn_max, ldm, n_out, free, kernel=cfg.kernel)
     else:
@@ -488,7 +495,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         return e.status == -3 or (e.status == -2 and "out of memory" in str(e))  # IMCOM_ERR_NOMEM, or a launch / allocation HIP refused for lack of memory
 
     def in_halves(sb):
-        """A pass the device has no memory for after all (the plan is an estimate: 0.8 of what is free divided by a model of a stamp's
+        """A pass the device has no memory for after all (the plan is an estimate: 0.7-0.8 of what is free divided by a model of a stamp's
         needs) is run again as two passes of half the stamps, cut on a cell boundary, in the failed pass's buffers."""
         import torch
 
