@@ -452,7 +452,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
                 tables.prefetch([(int(a), int(b)) for a, b in gs])
         chunks = plan_block(cfg, pool, tables, n1P, batch, ldn, stamps)
     chunks = [[(int(j), int(i)) for j, i in c] for c in chunks]
-    maps.chunks_done = []
+    maps.chunks_done, maps.chunk_sizes, maps.info_nonzero = [], [len(c) for c in chunks], 0
     if isinstance(tables, BlockTables) and chunks and claim is None:
         # the PSF groups of the first batches are sampled / transformed before the host turns to the per-stamp bookkeeping (a provider that
         # waits for host work is only asked for the first pass: with two, the device idled until the second pass's groups were there)
@@ -541,6 +541,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
             nxt = next_batch()
         maps.add(sb.results(), [j for j, _ in sb.chunk], [i for _, i in sb.chunk])
         maps.chunks_done.append(sb.chunk_index)
+        maps.info_nonzero += int(sum(int((np.asarray(i_) != 0).sum()) for i_ in sb.info_o))  # stamps repaired (Cholesky) / re-solved in the eigenbasis (Eigen)
     if pad_sides is not None:
         maps.finalize(pad_sides, postage_pad)
     return maps
