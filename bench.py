@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime initialises (pyimcom_amd/__init__.py has the reason)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -152,7 +152,7 @@ def _side_stream(device):
     if key not in _SIDE:
         # (highest priority: its few small kernels -- the host waits for their counts -- must not queue behind the thousands of workgroups
         # of a solve that the main stream has in flight)
-        _SIDE[key] = (torch.cuda.Stream(dev, priority=-1), Context(key))
+        _SIDE[key] = (torch.cuda.Stream(dev, priority=int(os.environ.get("IMCOM_STREAM_PRIORITY", "-1"))), Context(key))
     return _SIDE[key]
 
 

@@ -41,7 +41,7 @@ def upload_stream(dev):
     dev = torch.device(dev)
     key = dev.index or 0
     if key not in _UPLOAD:
-        _UPLOAD[key] = torch.cuda.Stream(dev, priority=-1)
+        _UPLOAD[key] = torch.cuda.Stream(dev, priority=int(os.environ.get("IMCOM_STREAM_PRIORITY", "-1")))
     return _UPLOAD[key]
 
 
