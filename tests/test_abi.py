@@ -48,3 +48,19 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "from oracle" not in src and "import oracle" not in src and "tests" not in [w for l in src.splitlines()
                         if l.startswith(("from ", "import ")) for w in l.replace(".", " ").split()[1:2]], f
+
+
+def test_package_import_asks_for_eight_hardware_queues():
+    """The HIP runtime reads GPU_MAX_HW_QUEUES at its first call; the package sets 8 on import unless the caller has chosen (on the default
+    of four, streams that share a queue wait for each other: profiles/r04_negative_results.txt item 18)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os; import pyimcom_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env["PYTHONPATH"] = root
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "6"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "6"
