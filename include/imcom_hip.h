@@ -287,14 +287,23 @@ int imcom_solve_chol_resident(imcom_ctx *ctx, int batch, const int *n_host, int 
 /* imcom_solve_chol_resident in two halves, for a caller with host work to do while the device factors and solves
  * (the reference's loop is synchronous, lakernel.py:84-138; a block driver prepares its next pass in between).
  * _begin queues the whole first attempt and returns.  _end waits for it: every A + kappa I positive definite (the
- * normal case) -> info = 0, IMCOM_OK, outputs final; otherwise _end returns 1 and the caller runs
- * imcom_solve_chol_resident on the same arguments (the eigh-shift repair of lakernel.py:262-279).  Work queued on the
+ * normal case) -> info = 0, IMCOM_OK, outputs final; otherwise _end returns 1 with info[s] != 0 for the stamps whose
+ * factorisation failed (the other stamps' outputs are final) and the caller runs imcom_solve_chol_resident_redo on those
+ * (one kappa node) or imcom_solve_chol_resident on the same arguments (the eigh-shift repair of lakernel.py:262-279).  Work queued on the
  * context between the two calls runs behind the solve; a begin whose _end never came is waited for and forgotten by the next begin. */
 int imcom_solve_chol_resident_begin(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm,
                                     const double *A, const double *Bt, const double *C_host,
                                     const double *kappaC_host, int nv, double ucmin, double smax,
                                     float *Tt, float *UC, float *Sigma, float *kappa);
 int imcom_solve_chol_resident_end(imcom_ctx *ctx, int batch, int *info_host);
+/* CholKernel._call_single_kappa (lakernel.py:281-323) for SOME stamps of a resident batch: redo_host[s] = 0 leaves stamp s and
+ * its outputs untouched, 1 solves it, 2 solves it knowing that the factorisation of A + kappa I fails (what _end reported), i.e.
+ * straight to _cholesky_wrapper's repair (lakernel.py:262-279: AA_ii += |w[0]| + 1e-16 with w[0] the smallest eigenvalue of A).
+ * nv must be 1.  info as imcom_solve_chol_resident, written for the stamps that were solved. */
+int imcom_solve_chol_resident_redo(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm,
+                                   const double *A, const double *Bt, const double *C_host,
+                                   const double *kappaC_host, int nv, double ucmin, double smax,
+                                   float *Tt, float *UC, float *Sigma, float *kappa, const int *redo_host, int *info_host);
 /* coadd.py:1320-1354: fade taper of T (trapezoid, 1222-1292), per-exposure weight sums, Neff and
  * outimage = T . indata.
  *   Tt           [batch][ldn][ldm] float32 (tapered in place when fade > 0)

@@ -86,6 +86,7 @@ SIGNATURES = {
     "imcom_solve_chol_resident": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp],
     "imcom_solve_chol_resident_begin": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],
     "imcom_solve_chol_resident_end": [_vp, _i, _vp],
+    "imcom_solve_chol_resident_redo": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp],
     "imcom_coadd_epilogue": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "imcom_solve_chol_resident_coadd": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp,
                                         _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],

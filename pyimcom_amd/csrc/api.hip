@@ -106,9 +106,11 @@ int pin_reserve(imcom_ctx *ctx, size_t bytes)
 //   A  [batch][Np][Np]   identity-padded, never modified
 //   Bt [batch][Np][mp]   input-pixel-major -B/2, zero padded
 // Produces Tt (float32 [batch][Np][mp]) and the per-pixel maps.
-constexpr int REPAIR_GROUP = 32;  // failed stamps whose smallest eigenvalues are computed in one batch of the eigensolver (repair path)
+constexpr int REPAIR_GROUP = 32;  // failed stamps whose smallest eigenvalues are computed in one batch of the eigensolver (repair path, small matrices / fallback)
 constexpr int CHOL_MAXNV = 8;  // kappa nodes of the multi-kappa Cholesky kernel (launch_multi's MAXNV; 3 nv diagonal increments <= MAX_INC)
 static_assert(3 * CHOL_MAXNV <= MAX_INC_HOST, "diagonal increments of the repair sequence");
+constexpr int LMIN_P = NB;        // vectors of the subspace iteration for the smallest eigenvalue (one tile column of the solves)
+constexpr int LMIN_MIN_N = 1024;  // smaller matrices go through the eigensolver itself (cheap there; the block needs n >> LMIN_P)
 
 // Split-K for small batches: with fewer than ~256 tiles per launch (the kernel-class seam hands over one stamp: 18) the K
 // loop of every tile is dealt to up to 8 workgroups, so that a launch has ~512 of them (gemm_f64.hip).
@@ -132,6 +134,27 @@ static int nodes_per_pass(int batch, int mp, int nv)
     return (nv > 1 && (long)batch * nv * (mp / NB) <= 1024) ? nv : 1;
 }
 
+static bool lmin_subspace_enabled()
+{
+    static const bool off = getenv("IMCOM_LMIN") && strcmp(getenv("IMCOM_LMIN"), "eigh") == 0;  // (cross-check: the eigensolver for every repair)
+    return !off;
+}
+
+// workspace of lambda_min_subspace on top of the factorisation's own L / Dinv / dshift
+static size_t lmin_ws_bytes(int batch, int Np)
+{
+    if (!lmin_subspace_enabled() || Np < LMIN_MIN_N) return 0;
+    WsPlan p;
+    for (int q = 0; q < 3; q++) p.add((size_t)batch * Np * LMIN_P * 8);      // X, Y, Z = A X
+    for (int q = 0; q < 3; q++) p.add((size_t)batch * LMIN_P * LMIN_P * 8);  // G, its inverse Cholesky factor, H = X^T A X
+    p.add((size_t)batch * LMIN_P * 8);                                       // eigenvalues of H
+    p.add((size_t)batch * 8 * NB * NB * 8);                                  // split-K partial products of the 128-column solves
+    p.add((size_t)batch * 8);                                                // largest diagonal entry
+    for (int q = 0; q < 4; q++) p.add((size_t)batch * 4);                    // want, ones, flags of the Gram factorisations, masked nblk
+    p.add(eigh_ws_bytes(batch, LMIN_P, false));
+    return p.total + 8192;
+}
+
 static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
 {
     WsPlan p;
@@ -141,6 +164,7 @@ static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
     p.add((size_t)nv * batch * Np * mp * 8);     // Y / X per node
     p.add(eb * Np * 8);                          // dshift
     p.add(eb * 4 * 3 + (size_t)batch * 4 * nv);  // n, nblk, ninc, fail[nv]
+    p.add((size_t)batch * 4 * 4);                // attempt masks: stamps to factor, their block counts, block counts of the solves, solved flags
     p.add(eb * MAX_INC_HOST * 8);                // inc
     p.add((size_t)batch * 8 * 2);                // kap, C
     p.add((size_t)nv * 8);                       // kappaC
@@ -149,9 +173,10 @@ static size_t chol_core_bytes(int batch, int Np, int m, int mp, int nv)
         p.add((size_t)batch * m * nv * nv * 8);  // Npq
         p.add((size_t)batch * m * nv * 8);       // W
     }
-    // repair path (lakernel.py:262-279): eigenvalues of up to REPAIR_GROUP failed stamps' A at a time
+    // repair path (lakernel.py:262-279): the smallest eigenvalue of every failed stamp's A -- the subspace iteration on the stamps in
+    // place (lambda_min_subspace), the eigensolver on up to REPAIR_GROUP gathered copies for small matrices and as its fallback
     const int rg = std::min(batch, REPAIR_GROUP);
-    p.add(eigh_ws_bytes(rg, Np, false) + (size_t)rg * Np * Np * 8 * (eigh_uses_jacobi() ? 2 : 1) + (size_t)rg * Np * 8 + 4096);
+    p.add(std::max(eigh_ws_bytes(rg, Np, false) + (size_t)rg * Np * Np * 8 * (eigh_uses_jacobi() ? 2 : 1) + (size_t)rg * Np * 8 + 4096, lmin_ws_bytes(batch, Np)));
     p.add(splitk_bytes((int)eb, Np, mp));
     if (nv == 1) p.add((size_t)batch * 2 * nb * mp * 8 * 2);  // per-block-row column sums of Y^2 and X^2
     return p.total + 4096;
@@ -184,6 +209,152 @@ static int lambda_min_group(imcom_ctx *ctx, const double *A, const int *n_host, 
     return rc;
 }
 
+// The smallest eigenvalue of the stamps `idx` WITHOUT an eigendecomposition (the reference's repair needs w[0] of eigh(A) and nothing
+// else, lakernel.py:266-268).  A production stamp (configs/paper4_configs/H158_Chol_benchmark.json: N ~ 6.2k pixels) has thousands of
+// eigenvalues within 1e-5 |A| of zero and a smallest one of either sign; the tridiagonalisation of a 6.2k matrix costs 4 N^3 / 3 flops at
+// memory speed (95 ms per stamp), the kernels this library is fast at are the blocked Cholesky and the triangular solves.  So:
+//   1. a shift sigma with A + sigma I positive definite (trial factorisations, sigma x 8 per failure; the first trial is 4 x the
+//      increment the failed factorisation had);
+//   2. subspace iteration with the inverse, X <- orth((A + sigma I)^-1 X), on a block of 128 vectors = one tile column of the solve
+//      kernels (CholQR twice per step: Gram matrix on the tile engine, its Cholesky factor and the factor's inverse from the diagonal-block
+//      kernel), then Rayleigh-Ritz with A ITSELF: theta = lambda_min(X^T A X) >= lambda_min(A), accurate to eps |A| once the block has
+//      converged -- the accuracy class of LAPACK's own w[0];
+//   3. re-factor at sigma' = |theta| (1 + eta) just above the estimate (eta from the change of theta; a sigma' that is not above
+//      |lambda_min| makes the factorisation fail: eta x 8), where the block converges by 1e-3 per step; stop when two successive
+//      Rayleigh-Ritz values agree to 1e-11.
+// Everything runs on the stamps in place (L, Dinv, dshift of the caller's factorisation; stamps that are not wanted have no blocks in
+// these launches).  factor(shift, mask, fail): L L^T = A + shift[s] I for the stamps of mask, fail[s] != 0 where that is not positive
+// definite; solve(mask, X, Y): Y = (L L^T)^-1 X on LMIN_P columns.  ok[s] = 0: no answer (the caller takes the eigensolver).
+static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, const int *n_dev, int Np, const double *A, const std::vector<int> &idx,
+                               const std::vector<double> &inc_failed,
+                               const std::function<int(const std::vector<double> &, const std::vector<char> &, std::vector<int> &)> &factor,
+                               const std::function<int(const std::vector<char> &, const double *, double *, double *, int)> &solve,
+                               std::vector<double> &w0, std::vector<char> &ok)
+{
+    const size_t mark = ctx->ws_used;
+    const int P = LMIN_P;
+    const size_t blk = (size_t)batch * Np * P * 8, sq = (size_t)batch * P * P * 8;
+    double *X = (double *)ws_take(ctx, blk), *Y = (double *)ws_take(ctx, blk), *Z = (double *)ws_take(ctx, blk);
+    double *G = (double *)ws_take(ctx, sq), *Gi = (double *)ws_take(ctx, sq), *H = (double *)ws_take(ctx, sq);
+    double *lam = (double *)ws_take(ctx, (size_t)batch * P * 8);
+    double *part = (double *)ws_take(ctx, (size_t)batch * 8 * NB * NB * 8);
+    double *dmax_d = (double *)ws_take(ctx, (size_t)batch * 8);
+    int *want_d = (int *)ws_take(ctx, (size_t)batch * 4), *ones_d = (int *)ws_take(ctx, (size_t)batch * 4), *gfail_d = (int *)ws_take(ctx, (size_t)batch * 4);
+    if (!X || !Y || !Z || !G || !Gi || !H || !lam || !part || !dmax_d || !want_d || !ones_d || !gfail_d) { set_error("internal: workspace (smallest eigenvalue)"); return IMCOM_ERR_NOMEM; }
+    const size_t mark_eig = ctx->ws_used;
+    hipStream_t st = ctx->stream;
+    std::vector<char> want(batch, 0);
+    std::vector<int> want_i(batch, 0), ones(batch, 1), nP(batch, P);
+    for (int s : idx) { want[s] = 1; want_i[s] = 1; }
+    IMCOM_TRY(upload(ctx, want_d, want_i.data(), (size_t)batch));
+    IMCOM_TRY(upload(ctx, ones_d, ones.data(), (size_t)batch));
+    IMCOM_HIP_CHECK(hipMemsetAsync(gfail_d, 0, (size_t)batch * 4, st));
+    IMCOM_HIP_CHECK(hipMemsetAsync(Y, 0, blk, st));
+    IMCOM_HIP_CHECK(hipMemsetAsync(Z, 0, blk, st));
+    IMCOM_HIP_CHECK(hipMemsetAsync(G, 0, sq, st));  // (stamps that are not wanted keep zero blocks: gram_guard_kernel puts ones on their diagonals)
+    IMCOM_HIP_CHECK(hipMemsetAsync(H, 0, sq, st));
+    IMCOM_TRY(launch_diag_max(ctx, A, Np, n_dev, dmax_d, batch));
+    std::vector<double> dmax(batch, 0.0);
+    IMCOM_HIP_CHECK(hipMemcpyAsync(dmax.data(), dmax_d, (size_t)batch * 8, hipMemcpyDeviceToHost, st));
+    IMCOM_HIP_CHECK(hipStreamSynchronize(st));
+    // 1. a positive definite shift
+    std::vector<double> sigma(batch, 0.0);
+    std::vector<char> todo = want, act = want;
+    std::vector<int> fail;
+    for (int s : idx) sigma[s] = std::max(std::max(4.0 * inc_failed[s], 1e-13 * dmax[s]), 1e-300);
+    for (int t = 0;; t++) {
+        IMCOM_TRY(factor(sigma, todo, fail));
+        bool any = false;
+        for (int s : idx) {
+            if (!todo[s]) continue;
+            if (fail[s] != 0 && std::isfinite(sigma[s] * 8.0)) { sigma[s] *= 8.0; any = true; }
+            else if (fail[s] != 0) { todo[s] = 0; act[s] = 0; }  // (not finite: not a matrix this iteration can help)
+            else todo[s] = 0;
+        }
+        if (!any) break;
+        if (t >= 24) {
+            for (int s : idx) if (todo[s]) { todo[s] = 0; act[s] = 0; }
+            break;
+        }
+    }
+    // 2. / 3. subspace iteration, Rayleigh-Ritz with A, closer shifts
+    IMCOM_TRY(launch_lmin_init(ctx, X, Np, P, n_dev, want_d, batch));
+    const long sX = (long)Np * P, sG = (long)P * P;
+    // a product per stamp of the batch, or -- when few stamps are wanted -- per wanted stamp (the others' operands are zero)
+    const bool few = (long)idx.size() * 4 <= (long)batch;
+    auto gemm = [&](bool akm, bool bkm, int M, int N, int K, const double *Ao, long lda, long sA, const double *Bo, long ldb, long sB, double *Co, long ldc, long sC) -> int {
+        if (!few) return launch_gemm(ctx, akm, bkm, M, N, K, batch, Ao, lda, sA, Bo, ldb, sB, Co, ldc, sC, 1.0, 0.0);
+        for (int s : idx) IMCOM_TRY(launch_gemm(ctx, akm, bkm, M, N, K, 1, Ao + s * sA, lda, sA, Bo + s * sB, ldb, sB, Co + s * sC, ldc, sC, 1.0, 0.0));
+        return IMCOM_OK;
+    };
+    auto orth = [&]() -> int {  // X <- orth(Y): CholQR twice (X = Y R^-1 with R^T R = Y^T Y; the second pass takes the loss of the first back)
+        for (int pass = 0; pass < 2; pass++) {
+            double *src = pass == 0 ? Y : X, *dst = pass == 0 ? X : Y;
+            IMCOM_TRY(gemm(true, true, P, P, Np, src, P, sX, src, P, sX, G, P, sG));
+            IMCOM_TRY(launch_gram_guard(ctx, G, P, want_d, batch));
+            IMCOM_TRY(launch_chol_diag(ctx, G, Gi, P, 0, batch, ones_d, gfail_d));
+            IMCOM_TRY(gemm(false, false, Np, P, P, src, P, sX, Gi, P, sG, dst, P, sX));  // dst[i][c] = sum_j src[i][j] Linv[c][j]
+        }
+        std::swap(X, Y);  // the orthonormal block is in the buffer pass 1 wrote
+        return IMCOM_OK;
+    };
+    std::vector<double> theta(batch, 0.0), prev(batch, 0.0), eta(batch, 1e-3), lam0(batch, 0.0);
+    std::vector<char> conv(batch, 0);
+    std::vector<int> gfail(batch, 0);
+    const int max_rounds = 8;
+    for (int round = 0; round < max_rounds; round++) {
+        std::vector<char> run(batch, 0);
+        bool any = false;
+        for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; }
+        if (!any) break;
+        const int iters = round == 0 ? 5 : 2;
+        for (int it = 0; it < iters; it++) {
+            IMCOM_TRY(solve(run, X, Y, part, splitk_parts(batch, 1)));
+            IMCOM_TRY(orth());
+        }
+        // Z = A X, H = X^T Z, theta = its smallest eigenvalue
+        IMCOM_TRY(gemm(false, true, Np, P, Np, A, Np, (long)Np * Np, X, P, sX, Z, P, sX));
+        IMCOM_TRY(gemm(true, true, P, P, Np, X, P, sX, Z, P, sX, H, P, sG));
+        ctx->ws_used = mark_eig;
+        IMCOM_TRY(eigh_device(ctx, batch, nP.data(), P, H, P, sG, lam, P, nullptr, 0, 0, nullptr));
+        ctx->ws_used = mark_eig;
+        IMCOM_HIP_CHECK(hipMemcpy2DAsync(lam0.data(), 8, lam, (size_t)P * 8, 8, batch, hipMemcpyDeviceToHost, st));
+        IMCOM_HIP_CHECK(hipMemcpyAsync(gfail.data(), gfail_d, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<char> refac(batch, 0);
+        bool any_refac = false;
+        for (int s : idx) {
+            if (!run[s]) continue;
+            if (gfail[s] != 0 || !std::isfinite(lam0[s])) { act[s] = 0; continue; }  // the block lost rank / not a number: the eigensolver's case
+            prev[s] = theta[s];
+            theta[s] = lam0[s];
+            const double rel = fabs(theta[s] - prev[s]) / std::max(fabs(theta[s]), 1e-300);
+            if (round >= 1 && rel <= 1e-11) { conv[s] = 1; continue; }
+            // the next shift: just above |theta| (theta >= lambda_min: the shift must exceed |theta| by more than theta's error)
+            const double want_eta = round == 0 ? 1e-3 : std::min(std::max(16.0 * rel, 1e-9), 1e-2);
+            if (theta[s] < 0.0 && (round == 0 || want_eta < 0.25 * eta[s])) { eta[s] = want_eta; refac[s] = 1; any_refac = true; }
+        }
+        for (int t = 0; any_refac; t++) {
+            std::vector<double> sg = sigma;
+            for (int s : idx) if (refac[s]) sg[s] = -theta[s] * (1.0 + eta[s]);
+            IMCOM_TRY(factor(sg, refac, fail));
+            any_refac = false;
+            for (int s : idx) {
+                if (!refac[s]) continue;
+                if (fail[s] == 0) { sigma[s] = sg[s]; refac[s] = 0; }
+                else if (t >= 10) { refac[s] = 0; act[s] = 0; }
+                else { eta[s] *= 8.0; any_refac = true; }
+            }
+        }
+    }
+    for (int s : idx) {
+        ok[s] = act[s] && conv[s];
+        if (ok[s]) w0[s] = theta[s];
+    }
+    ctx->ws_used = mark;
+    return IMCOM_OK;
+}
+
 // before_solve (optional): called once, after the first factorisation's launches have been queued and before the first launch
 // that reads Bt -- the host-buffer entry uploads -B/2 there, behind the factorisation instead of in front of it.
 // what the coaddition needs besides T (coadd.py:1294-1363), for the entries that solve and coadd in one call
@@ -209,20 +380,29 @@ static size_t coadd_fuse_bytes(int batch, int Np, int m, int mp, int nv, const C
     return t;
 }
 
+// redo_host (optional, one kappa node only): per stamp 0 = leave the stamp and its outputs alone, 1 = solve it, 2 = solve it knowing that
+// the factorisation of A + kappa I fails (imcom_solve_chol_resident_end said so: straight to the repair).
+// With ONE kappa node an attempt after the first works on the stamps whose factorisation failed and on nothing else: the launches
+// see the other stamps with no blocks at all, and their outputs stay what the first attempt wrote (a batch of 256 in which one
+// factorisation fails used to be factored and solved three times over).
 static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m, int mp, const double *A,
                      const double *Bt, const double *C_host, const double *kappaC_host, int nv, double ucmin,
                      double smax, float *Tt, float *UC, float *Sigma, float *kappa, int *info_host,
-                     const std::function<int()> &before_solve = nullptr, const CoaddArgs *co = nullptr, bool defer = false)
+                     const std::function<int()> &before_solve = nullptr, const CoaddArgs *co = nullptr, bool defer = false,
+                     const int *redo_host = nullptr)
 {
     bool bt_ready = !before_solve;
     const int nbmax_all = Np / NB;
     const int pb = nodes_per_pass(batch, mp, nv), eb = batch * pb;  // nodes per pass, stamps x nodes of a pass
+    const bool masked = nv == 1;  // (pb == 1 then)
+    IMCOM_REQUIRE(!redo_host || masked, "a redo mask needs a single kappa node");
     double *L = (double *)ws_take(ctx, (size_t)eb * Np * Np * 8);
     double *Dinv = (double *)ws_take(ctx, (size_t)eb * nbmax_all * NB * NB * 8);
     const long node_stride = (long)batch * Np * mp;
     double *Y = (double *)ws_take(ctx, (size_t)nv * node_stride * 8);
     double *dshift = (double *)ws_take(ctx, (size_t)eb * Np * 8);
     int *ints = (int *)ws_take(ctx, (size_t)eb * 4 * 3 + (size_t)batch * 4 * nv);
+    int *mints = (int *)ws_take(ctx, (size_t)batch * 4 * 4);
     double *inc = (double *)ws_take(ctx, (size_t)eb * MAX_INC_HOST * 8);
     double *dbl = (double *)ws_take(ctx, (size_t)batch * 8 * 2);
     double *kappaC_dev = (double *)ws_take(ctx, (size_t)nv * 8);
@@ -251,22 +431,26 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         }
         if (!Tsum_image || (colsums && coadd_fusable(nv, co->fade) && !cfuse.Epart)) { set_error("internal: workspace plan too small (coaddition)"); return IMCOM_ERR_NOMEM; }
     }
-    if (!L || !Dinv || !Y || !dshift || !ints || !inc || !dbl || !kappaC_dev || (nv > 1 && (!Dp || !Npq || !W)) || (pbytes && !partial) || (nv == 1 && !unfused_solve && !colsums)) {
+    if (!L || !Dinv || !Y || !dshift || !ints || !mints || !inc || !dbl || !kappaC_dev || (nv > 1 && (!Dp || !Npq || !W)) || (pbytes && !partial) || (nv == 1 && !unfused_solve && !colsums)) {
         set_error("internal: workspace plan too small");
         return IMCOM_ERR_NOMEM;
     }
+    const size_t ws_after_plan = ctx->ws_used;  // (the repair's own scratch is taken from here on and handed back)
     int *n_dev = ints, *nblk_dev = ints + eb, *ninc_dev = ints + 2 * eb, *fail_dev = ints + 3 * eb;  // n, nblk, ninc [eb]; fail[nv][batch]
+    int *fac_dev = mints, *nblk_fac = mints + batch, *nblk_sol = mints + 2 * batch, *act_dev = mints + 3 * batch;  // one kappa node: this attempt's stamps
     double *kap_dev = dbl, *C_dev = dbl + batch;
 
     std::vector<int> nblk(batch), ninc(batch, 0), fail((size_t)nv * batch);
     std::vector<double> inc_h((size_t)batch * MAX_INC_HOST, 0.0), kap_h(batch), rep(batch, 0.0);
     std::vector<char> repaired((size_t)nv * batch, 0), have_w0(batch, 0);
+    std::vector<char> active(batch, 1), known(batch, 0);  // the stamps of the coming attempt; stamps whose first factorisation is known to fail
     int nbmax = 0;
     for (int s = 0; s < batch; s++) {
         IMCOM_REQUIRE(n_host[s] >= 0 && n_host[s] <= Np, "n[%d]=%d outside [0,%d]", s, n_host[s], Np);
         nblk[s] = (n_host[s] + NB - 1) / NB;
         if (nblk[s] > nbmax) nbmax = nblk[s];
-        info_host[s] = 0;
+        if (redo_host) { active[s] = redo_host[s] != 0; known[s] = redo_host[s] == 2; }
+        if (active[s]) info_host[s] = 0;
     }
     for (int q = 0; q < pb; q++) {  // the stamps of a pass: node-major copies
         IMCOM_TRY(upload(ctx, n_dev + q * batch, n_host, batch));
@@ -275,8 +459,58 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     IMCOM_TRY(upload(ctx, C_dev, C_host, batch));
     IMCOM_TRY(upload(ctx, kappaC_dev, kappaC_host, nv));
 
+    // one factorisation over the stamps of `mask` with the diagonal A_ii + shift[s] (the smallest-eigenvalue iteration's trial
+    // factorisations: lambda_min_subspace), flags read back
+    auto factor_masked = [&](const std::vector<double> &shift, const std::vector<char> &mask, std::vector<int> &fail_h) -> int {
+        std::vector<int> nb(batch), one(batch, 1);
+        std::vector<double> ih((size_t)batch * MAX_INC_HOST, 0.0);
+        int nbm = 0;
+        for (int s = 0; s < batch; s++) {
+            nb[s] = mask[s] ? nblk[s] : 0;
+            nbm = std::max(nbm, nb[s]);
+            ih[(size_t)s * MAX_INC_HOST] = shift[s];
+        }
+        IMCOM_TRY(upload(ctx, nblk_fac, nb.data(), (size_t)batch));
+        IMCOM_TRY(upload(ctx, inc, ih.data(), ih.size()));
+        IMCOM_TRY(upload(ctx, ninc_dev, one.data(), (size_t)batch));
+        IMCOM_TRY(launch_diag_shift(ctx, A, Np, inc, ninc_dev, dshift, batch));
+        IMCOM_HIP_CHECK(hipMemsetAsync(fail_dev, 0, (size_t)batch * 4, ctx->stream));
+        for (int k = 0; k < nbm; k++) {
+            IMCOM_TRY(launch_chol_update(ctx, A, L, Np, k, nbm, batch, batch, nblk_fac, dshift, partial, partial ? splitk_parts(batch, nbm - k) : 1));
+            IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, batch, nblk_fac, fail_dev));
+            IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbm, batch, nblk_fac));
+        }
+        fail_h.assign(batch, 0);
+        IMCOM_HIP_CHECK(hipMemcpyAsync(fail_h.data(), fail_dev, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return IMCOM_OK;
+    };
+    // Yv = (L L^T)^-1 Xv on LMIN_P columns for the stamps of `mask`
+    auto solve_block = [&](const std::vector<char> &mask, const double *Xv, double *Yv, double *part, int parts) -> int {
+        std::vector<int> nb(batch);
+        int nbm = 0;
+        for (int s = 0; s < batch; s++) { nb[s] = mask[s] ? nblk[s] : 0; nbm = std::max(nbm, nb[s]); }
+        IMCOM_TRY(upload(ctx, nblk_sol, nb.data(), (size_t)batch));
+        for (int k = 0; k < nbm; k++) IMCOM_TRY(launch_solve_fwd(ctx, L, Xv, Yv, Np, LMIN_P, k, batch, batch, nblk_sol, n_dev, Dinv, part, parts, nullptr));
+        for (int k = nbm - 1; k >= 0; k--) IMCOM_TRY(launch_solve_bwd(ctx, L, Yv, Np, LMIN_P, k, nbm, batch, nblk_sol, n_dev, Dinv, part, parts, nullptr, nullptr));
+        return IMCOM_OK;
+    };
+
     for (int attempt = 0;; attempt++) {
         IMCOM_HIP_CHECK(hipMemsetAsync(fail_dev, 0, (size_t)nv * batch * 4, ctx->stream));
+        const int *nb_fac = nblk_dev, *nb_sol = nblk_dev, *act_fin = nullptr;
+        std::vector<char> fac(batch, 1);  // the stamps this attempt factors
+        if (masked) {
+            std::vector<int> f_i(batch), nb_i(batch);
+            for (int s = 0; s < batch; s++) {
+                fac[s] = active[s] && !(attempt == 0 && known[s]);
+                f_i[s] = fac[s];
+                nb_i[s] = fac[s] ? nblk[s] : 0;
+            }
+            IMCOM_TRY(upload(ctx, fac_dev, f_i.data(), (size_t)batch));
+            IMCOM_TRY(upload(ctx, nblk_fac, nb_i.data(), (size_t)batch));
+            nb_fac = nblk_fac; nb_sol = nblk_sol; act_fin = act_dev;
+        }
         for (int p0 = 0; p0 < nv; p0 += pb) {
             for (int q = 0; q < pb; q++) {
                 const int p = p0 + q;
@@ -302,30 +536,32 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             }
             int *failp = fail_dev + (size_t)p0 * batch;
             for (int k = 0; k < nbmax; k++) {
-                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_update(ctx, A, L, Np, k, nbmax, eb, batch, nblk_dev, dshift, partial, partial ? splitk_parts(eb, nbmax - k) : 1)); }
-                { ProfScope ps(ctx, "chol_diag"); IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, eb, nblk_dev, failp)); }
-                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, eb, nblk_dev)); }
+                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_update(ctx, A, L, Np, k, nbmax, eb, batch, nb_fac, dshift, partial, partial ? splitk_parts(eb, nbmax - k) : 1)); }
+                { ProfScope ps(ctx, "chol_diag"); IMCOM_TRY(launch_chol_diag(ctx, L, Dinv, Np, k, eb, nb_fac, failp)); }
+                { ProfScope ps(ctx, "chol_gemm"); IMCOM_TRY(launch_chol_trsm(ctx, L, Dinv, Np, k, nbmax, eb, nb_fac)); }
             }
+            // one kappa node: a stamp whose factorisation has just failed is left out of the solves (its tiles return at once)
+            if (masked) IMCOM_TRY(launch_solve_mask(ctx, nblk_dev, fac_dev, failp, nblk_sol, act_dev, batch));
             if (!bt_ready) { IMCOM_TRY(before_solve()); bt_ready = true; }
             double *Yp = Y + p0 * node_stride;
             // the diagonal blocks are applied inside the update launches; IMCOM_SOLVE_UNFUSED=1 keeps them apart (A/B runs)
             static const bool unfused = getenv("IMCOM_SOLVE_UNFUSED") != nullptr;
             const double *Dfused = unfused ? nullptr : Dinv;
             for (int k = 0; k < nbmax; k++) {
-                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, eb, batch, nblk_dev, n_dev, Dfused, partial, parts_solve, Dpart)); }
-                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nblk_dev, false)); }
+                { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_fwd(ctx, L, Bt, Yp, Np, mp, k, eb, batch, nb_sol, n_dev, Dfused, partial, parts_solve, Dpart)); }
+                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nb_sol, false)); }
             }
             for (int k = nbmax - 1; k >= 0; k--) {
-                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, nbmax, eb, nblk_dev, n_dev, Dfused, partial, parts_solve, Npart, Tt, cfuse.Epart ? &cfuse : nullptr)); }
-                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nblk_dev, true)); }
+                if (k < nbmax - 1 || !unfused) { ProfScope ps(ctx, "solve_gemm"); IMCOM_TRY(launch_solve_bwd(ctx, L, Yp, Np, mp, k, nbmax, eb, nb_sol, n_dev, Dfused, partial, parts_solve, Npart, Tt, cfuse.Epart ? &cfuse : nullptr)); }
+                if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nb_sol, true)); }
             }
         }
         {
             ProfScope ps(ctx, "finalize");
             if (nv == 1 && colsums)
-                IMCOM_TRY(launch_finalize_fused(ctx, Dpart, Npart, Np, mp, m, n_dev, nblk_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch));
+                IMCOM_TRY(launch_finalize_fused(ctx, Dpart, Npart, Np, mp, m, n_dev, nblk_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch, act_fin));
             else if (nv == 1)
-                IMCOM_TRY(launch_finalize_single(ctx, Y, Bt, Np, mp, m, n_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch));
+                IMCOM_TRY(launch_finalize_single(ctx, Y, Bt, Np, mp, m, n_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch, act_fin));
             else
                 IMCOM_TRY(launch_multi(ctx, Y, node_stride, Bt, Np, mp, m, n_dev, nv, kappaC_dev, C_dev, ucmin, smax, Dp, Npq, W, Tt, UC, Sigma, kappa, batch));
         }
@@ -350,6 +586,9 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         }
         IMCOM_HIP_CHECK(hipMemcpyAsync(fail.data(), fail_dev, fail.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (masked && attempt == 0)
+            for (int s = 0; s < batch; s++)
+                if (active[s] && known[s]) fail[s] = 1;  // (the caller's knowledge stands for the factorisation that was not repeated)
         bool any = false;
         std::vector<int> need;  // stamps whose smallest eigenvalue is wanted: w, v = eigh(A); shift by |w[0]| + 1e-16
         for (int s = 0; s < batch; s++) {
@@ -365,24 +604,49 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             }
             if (f && !have_w0[s]) need.push_back(s);
         }
-        for (size_t g0 = 0; g0 < need.size(); g0 += REPAIR_GROUP) {
-            const int cnt = (int)std::min<size_t>(REPAIR_GROUP, need.size() - g0);
-            std::vector<double> w0(cnt, 0.0);
+        if (!need.empty()) {
             ProfScope ps(ctx, "eigen_repair");
-            IMCOM_TRY(lambda_min_group(ctx, A, n_host, Np, need.data() + g0, cnt, w0.data()));
-            for (int q = 0; q < cnt; q++) {
-                rep[need[g0 + q]] = fabs(w0[q]) + 1e-16;
-                have_w0[need[g0 + q]] = 1;
+            std::vector<double> w0v(batch, 0.0);
+            std::vector<char> got(batch, 0);
+            std::vector<int> big;
+            if (lmin_subspace_enabled())
+                for (int s : need)
+                    if (n_host[s] >= LMIN_MIN_N) big.push_back(s);
+            if (!big.empty()) {
+                // the largest diagonal increment whose factorisation failed: the first trial shift is four times that
+                std::vector<double> incf(batch, 0.0);
+                for (int s : big)
+                    for (int p = 0; p < nv; p++)
+                        if (fail[(size_t)p * batch + s] != 0) incf[s] = std::max(incf[s], kappaC_host[p] * C_host[s]);
+                ctx->ws_used = ws_after_plan;
+                IMCOM_TRY(lambda_min_subspace(ctx, batch, n_host, n_dev, Np, A, big, incf, factor_masked, solve_block, w0v, got));
+                ctx->ws_used = ws_after_plan;
+            }
+            std::vector<int> rest;
+            for (int s : need)
+                if (!got[s]) rest.push_back(s);
+            for (size_t g0 = 0; g0 < rest.size(); g0 += REPAIR_GROUP) {
+                const int cnt = (int)std::min<size_t>(REPAIR_GROUP, rest.size() - g0);
+                std::vector<double> w0(cnt, 0.0);
+                IMCOM_TRY(lambda_min_group(ctx, A, n_host, Np, rest.data() + g0, cnt, w0.data()));
+                for (int q = 0; q < cnt; q++) { w0v[rest[g0 + q]] = w0[q]; got[rest[g0 + q]] = 1; }
+            }
+            for (int s : need) {
+                rep[s] = fabs(w0v[s]) + 1e-16;
+                have_w0[s] = 1;
             }
         }
+        std::vector<char> next(batch, 0);
         for (int p = 0; p < nv; p++)
             for (int s = 0; s < batch; s++) {
                 if (fail[(size_t)p * batch + s] == 0) continue;
                 repaired[(size_t)p * batch + s] = 1;
                 if (info_host[s] == 0) info_host[s] = p + 1;
+                next[s] = 1;
                 any = true;
             }
         if (!any) break;
+        if (masked) active = next;  // the next attempt: the stamps that failed, nothing else
         IMCOM_REQUIRE(attempt <= nv + 1, "repair loop did not terminate");
     }
     if (co) {
@@ -993,10 +1257,36 @@ int imcom_solve_chol_resident_end(imcom_ctx *ctx, int batch, int *info_host)
     const long cnt = ctx->deferred_flags;
     ctx->deferred_flags = 0;
     IMCOM_HIP_CHECK(hipEventSynchronize(ctx->sync_events[2]));
-    for (long q = 0; q < cnt; q++)
-        if (ctx->flag_pin[q] != 0) return 1;  // a factorisation failed: imcom_solve_chol_resident repairs it
+    // a factorisation failed: info says whose (info[s] = 1 + the first kappa node that failed), and imcom_solve_chol_resident_redo (one kappa
+    // node) or imcom_solve_chol_resident (all stamps again) repairs as the reference does
+    bool any = false;
     for (int s = 0; s < batch; s++) info_host[s] = 0;
-    return IMCOM_OK;
+    for (long q = 0; q < cnt; q++)
+        if (ctx->flag_pin[q] != 0) {
+            any = true;
+            const int s = (int)(q % batch), p = (int)(q / batch);
+            if (info_host[s] == 0) info_host[s] = p + 1;
+        }
+    return any ? 1 : IMCOM_OK;
+}
+
+// The solve for SOME stamps of a resident batch (one kappa node): redo_host[s] = 0 leaves stamp s and all its outputs alone, 1 solves
+// it, 2 solves it knowing that the plain factorisation fails -- what imcom_solve_chol_resident_end has just reported -- so that the repair
+// of lakernel.py:262-279 starts at once.  A batch in which a few factorisations fail costs those stamps again, not the batch.
+int imcom_solve_chol_resident_redo(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm, const double *A, const double *Bt,
+                                   const double *C_host, const double *kappaC_host, int nv, double ucmin, double smax, float *Tt, float *UC,
+                                   float *Sigma, float *kappa, const int *redo_host, int *info_host)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(batch >= 1 && n_host && A && Bt && C_host && kappaC_host && Tt && UC && Sigma && kappa && redo_host && info_host, "null pointer");
+    IMCOM_REQUIRE(ldn >= NB && ldn % NB == 0 && ldm % NB == 0 && m >= 1 && m <= ldm, "ldn=%d / ldm=%d must be multiples of %d", ldn, ldm, NB);
+    IMCOM_REQUIRE(nv == 1, "imcom_solve_chol_resident_redo: one kappa node (nv=%d: call imcom_solve_chol_resident)", nv);
+    if (ctx->deferred_flags != 0) {
+        IMCOM_HIP_CHECK(hipEventSynchronize(ctx->sync_events[2]));
+        ctx->deferred_flags = 0;
+    }
+    IMCOM_TRY(ws_reserve(ctx, chol_core_bytes(batch, ldn, m, ldm, nv)));
+    return chol_core(ctx, batch, n_host, ldn, m, ldm, A, Bt, C_host, kappaC_host, nv, ucmin, smax, Tt, UC, Sigma, kappa, info_host, nullptr, nullptr, false, redo_host);
 }
 
 // CholKernel on the device layouts followed by the coaddition of the same stamps, in one call: with one kappa node and fade 0

@@ -94,10 +94,11 @@ __global__ __launch_bounds__(256) void finalize_single_kernel(const double *__re
                                                               const double *__restrict__ Cs,
                                                               float *__restrict__ Tt, float *__restrict__ UC,
                                                               float *__restrict__ Sigma,
-                                                              float *__restrict__ kappa)
+                                                              float *__restrict__ kappa, const int *__restrict__ act)
 {
     __shared__ double red[2][4][64];
     const int s = blockIdx.y, a = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    if (act && act[s] == 0) return;  // (uniform over the workgroup) not a stamp of this attempt
     const int ns = n[s];
     const long base = (long)s * ldn * ldm;
     double D = 0.0, N = 0.0;
@@ -138,10 +139,10 @@ __global__ __launch_bounds__(256) void finalize_fused_kernel(const double *__res
                                                              const int *__restrict__ nblk, const double *__restrict__ kap,
                                                              const double *__restrict__ Cs, float *__restrict__ Tt,
                                                              float *__restrict__ UC, float *__restrict__ Sigma,
-                                                             float *__restrict__ kappa)
+                                                             float *__restrict__ kappa, const int *__restrict__ act)
 {
     const int s = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= ldm) return;
+    if (a >= ldm || (act && act[s] == 0)) return;  // act: the stamps this attempt has solved (the others keep what they have)
     const int ns = n[s], nb = nblk[s], np = 2 * (ldn / NB);
     for (long i = (long)nb * NB; i < ldn; i++) Tt[((long)s * ldn + i) * ldm + a] = 0.0f;
     if (a >= m) return;
@@ -678,18 +679,95 @@ int launch_unpack_T(imcom_ctx *ctx, const float *Tt, int ldp, int ldm, const int
 }
 
 int launch_finalize_single(imcom_ctx *ctx, const double *X, const double *Bt, int ldn, int ldm, int m, const int *n,
-                           const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa, int batch)
+                           const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa, int batch, const int *act)
 {
-    hipLaunchKernelGGL(finalize_single_kernel, dim3(ldm / 64, batch), dim3(256), 0, ctx->stream, X, Bt, ldn, ldm, m, n, kap, Cs, Tt, UC, Sigma, kappa);
+    hipLaunchKernelGGL(finalize_single_kernel, dim3(ldm / 64, batch), dim3(256), 0, ctx->stream, X, Bt, ldn, ldm, m, n, kap, Cs, Tt, UC, Sigma, kappa, act);
     return check_launch("finalize_single_kernel");
 }
 
 int launch_finalize_fused(imcom_ctx *ctx, const double *Dpart, const double *Npart, int ldn, int ldm, int m, const int *n,
-                          const int *nblk, const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa, int batch)
+                          const int *nblk, const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa, int batch, const int *act)
 {
     hipLaunchKernelGGL(finalize_fused_kernel, dim3((ldm + 255) / 256, batch), dim3(256), 0, ctx->stream, Dpart, Npart, ldn, ldm, m, n, nblk, kap, Cs,
-                       Tt, UC, Sigma, kappa);
+                       Tt, UC, Sigma, kappa, act);
     return check_launch("finalize_fused_kernel");
+}
+
+// Which stamps of an attempt go on to the solves: act[s] = fac[s] && the factorisation just queued did not fail; nblk_sol[s] = nblk[s]
+// for those, 0 for the rest (a launch's tiles of a stamp with nblk = 0 return at once: the stamp keeps what an earlier attempt wrote).
+__global__ void solve_mask_kernel(const int *__restrict__ nblk, const int *__restrict__ fac, const int *__restrict__ fail, int *__restrict__ nblk_sol,
+                                  int *__restrict__ act, int batch)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    const int a = fac[s] != 0 && fail[s] == 0;
+    act[s] = a;
+    nblk_sol[s] = a ? nblk[s] : 0;
+}
+
+int launch_solve_mask(imcom_ctx *ctx, const int *nblk, const int *fac, const int *fail, int *nblk_sol, int *act, int batch)
+{
+    hipLaunchKernelGGL(solve_mask_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream, nblk, fac, fail, nblk_sol, act, batch);
+    return check_launch("solve_mask_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small kernels of the smallest-eigenvalue iteration (api.hip: lambda_min_subspace)
+// X [batch][ldn][P]: pseudo-random start block, zero on the rows beyond n[s] and for stamps that are not wanted
+__global__ void lmin_init_kernel(double *__restrict__ X, int ldn, int P, const int *__restrict__ n, const int *__restrict__ want)
+{
+    const int s = blockIdx.y;
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= (long)ldn * P) return;
+    const int i = (int)(e / P);
+    double v = 0.0;
+    if (want[s] != 0 && i < n[s]) {
+        unsigned long long x = ((unsigned long long)s * ldn * P + (unsigned long long)e) * 6364136223846793005ULL + 1442695040888963407ULL;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32; x *= 0x94D049BB133111EBULL; x ^= x >> 29;
+        v = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+    X[(long)s * ldn * P + e] = v;
+}
+
+// dmax[s] = max_i |A_ii| over the stamp's own rows (the scale of the first trial shift when kappa = 0)
+__global__ __launch_bounds__(256) void diag_max_kernel(const double *__restrict__ A, int ldn, const int *__restrict__ n, double *__restrict__ dmax)
+{
+    __shared__ double red[256];
+    const int s = blockIdx.x;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n[s]; i += 256) v = fmax(v, fabs(A[(long)s * ldn * ldn + (long)i * ldn + i]));
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dmax[s] = red[0];
+}
+
+// G[s] += I on the stamps that are not wanted (their Gram matrix is zero: the Cholesky of the block orthogonalisation must not fail on them)
+__global__ void gram_guard_kernel(double *__restrict__ G, int P, const int *__restrict__ want)
+{
+    const int s = blockIdx.x, c = threadIdx.x;
+    if (c < P && want[s] == 0) G[(long)s * P * P + (long)c * P + c] = 1.0;
+}
+
+int launch_lmin_init(imcom_ctx *ctx, double *X, int ldn, int P, const int *n, const int *want, int batch)
+{
+    hipLaunchKernelGGL(lmin_init_kernel, dim3((unsigned)(((long)ldn * P + 255) / 256), batch), dim3(256), 0, ctx->stream, X, ldn, P, n, want);
+    return check_launch("lmin_init_kernel");
+}
+
+int launch_diag_max(imcom_ctx *ctx, const double *A, int ldn, const int *n, double *dmax, int batch)
+{
+    hipLaunchKernelGGL(diag_max_kernel, dim3(batch), dim3(256), 0, ctx->stream, A, ldn, n, dmax);
+    return check_launch("diag_max_kernel");
+}
+
+int launch_gram_guard(imcom_ctx *ctx, double *G, int P, const int *want, int batch)
+{
+    hipLaunchKernelGGL(gram_guard_kernel, dim3(batch), dim3(P), 0, ctx->stream, G, P, want);
+    return check_launch("gram_guard_kernel");
 }
 
 int launch_multi(imcom_ctx *ctx, const double *Xs, long node_stride, const double *Bt, int ldn, int ldm, int m, const int *n,

@@ -82,10 +82,14 @@ int launch_unpack_T(imcom_ctx *ctx, const float *Tt, int ldp, int ldm, const int
                     int batch);
 int launch_finalize_fused(imcom_ctx *ctx, const double *Dpart, const double *Npart, int ldn, int ldm, int m, const int *n,
                           const int *nblk, const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa,
-                          int batch);
+                          int batch, const int *act = nullptr);  // act != null: only the stamps with act[s] != 0
+int launch_solve_mask(imcom_ctx *ctx, const int *nblk, const int *fac, const int *fail, int *nblk_sol, int *act, int batch);
+int launch_lmin_init(imcom_ctx *ctx, double *X, int ldn, int P, const int *n, const int *want, int batch);
+int launch_diag_max(imcom_ctx *ctx, const double *A, int ldn, const int *n, double *dmax, int batch);
+int launch_gram_guard(imcom_ctx *ctx, double *G, int P, const int *want, int batch);
 int launch_finalize_single(imcom_ctx *ctx, const double *X, const double *Bt, int ldn, int ldm, int m, const int *n,
                            const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa,
-                           int batch);
+                           int batch, const int *act = nullptr);
 int launch_multi(imcom_ctx *ctx, const double *Xs, long node_stride, const double *Bt, int ldn, int ldm, int m,
                  const int *n, int nv, const double *kappaC_dev, const double *Cs, double ucmin, double smax,
                  double *Dp, double *Npq, double *W, float *Tt, float *UC, float *Sigma, float *kappa, int batch);

@@ -30,6 +30,13 @@ def _hp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _runs(mask):
+    """Runs [s0, s1) of consecutive true entries of a boolean mask."""
+    m = np.concatenate([[False], np.asarray(mask, dtype=bool), [False]])
+    d = np.flatnonzero(m[1:] != m[:-1])
+    return [(int(a), int(b)) for a, b in zip(d[0::2], d[1::2])]
+
+
 _GRIDS = {}
 
 
@@ -759,8 +766,10 @@ class StampBatch:
         self._deferred = True
 
     def solve_end(self):
-        """Wait for ``solve_begin()``'s work; a batch with a factorisation that failed is solved again by the synchronous entry, which
-        repairs it as the reference does (lakernel.py:262-279)."""
+        """Wait for ``solve_begin()``'s work.  Stamps whose factorisation failed are solved again with the reference's repair
+        (lakernel.py:262-279) -- those stamps only (imcom_solve_chol_resident_redo; the others' outputs are final).  Returns False, or
+        the boolean mask [batch] of the stamps that were solved again: whatever the caller queued on the first attempt's outputs of
+        THOSE stamps (the coaddition) has to be queued again for them (``coadd(only=mask)``)."""
         if getattr(self, "_unsolved", False):
             self._unsolved = False
             self.solve()
@@ -769,10 +778,22 @@ class StampBatch:
             return False
         self._deferred = False
         self._stream()
-        rc = lib.imcom_solve_chol_resident_end(self.ctx.handle, self.batch, _hp(self.info_o[0]))
+        cfg, info = self.cfg, self.info_o[0]
+        rc = lib.imcom_solve_chol_resident_end(self.ctx.handle, self.batch, _hp(info))
         if rc == 1:
-            self.solve()
-            return True  # (solved again: whatever the caller queued on the first attempt's outputs has to be queued again)
+            again = info != 0
+            if len(self.kappaC) != 1 or os.environ.get("IMCOM_REDO_ALL") == "1":  # several kappa nodes: every stamp again (the synchronous entry)
+                self.solve()
+                return np.ones(self.batch, dtype=bool)
+            redo = np.where(again, 2, 0).astype(np.int32)
+            check(lib.imcom_solve_chol_resident_redo(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, _dp(self.A), _dp(self.Bt_o[0]),
+                                                     _hp(self.Cs_o[0]), _hp(self.kappaC), 1, float(cfg.uctarget), float(cfg.sigmamax),
+                                                     _dp(self.Tt_o[0]), _dp(self.UC_o[0]), _dp(self.Sigma_o[0]), _dp(self.kappa_o[0]), _hp(redo), _hp(info)))
+            if cfg.fade > 0:  # the map tapers of coadd.py:1118-1122 on the stamps that were solved again (the others have theirs)
+                for s0, s1 in _runs(again):
+                    for t in (self.kappa_o[0], self.Sigma_o[0], self.UC_o[0]):
+                        check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t[s0:]), s1 - s0, self.n2f, cfg.fade))
+            return again
         check(rc)
         return False
 
@@ -826,18 +847,21 @@ class StampBatch:
             for t in (kappa, Sigma, UC):
                 check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))
 
-    def coadd(self):
-        """OutStamp._perform_coaddition (coadd.py:1294-1363)."""
+    def coadd(self, only=None):
+        """OutStamp._perform_coaddition (coadd.py:1294-1363).  ``only``: boolean mask [batch] -- the stamps to coadd (the call tapers T in
+        place when fade > 0, so a stamp must be coadded once per solve: ``solve_end()`` says which stamps it solved again)."""
         self._stream()
         cfg = self.cfg
         done, self._coadded = getattr(self, "_coadded", set()), set()
+        spans = [(0, self.batch)] if only is None else _runs(only)
         for o in range(self.n_out):
             if o in done:  # coadded inside solve()
                 continue
-            check(lib.imcom_coadd_epilogue(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, self.n2f,
-                                           cfg.fade, cfg.n2, _dp(self.Tt_o[o]), _dp(self.indata), cfg.n_inframe, _dp(self.expo),
-                                           self.n_expo, _dp(self.outimage_o[o]), _dp(self.Tsum_stamp_o[o]), _dp(self.Tsum_inpix_o[o]),
-                                           _dp(self.Neff_o[o])))
+            for s0, s1 in spans:
+                check(lib.imcom_coadd_epilogue(self.ctx.handle, s1 - s0, _hp(self.n[s0:s1]), self.ldn, self.m, self.ldm, self.n2f,
+                                               cfg.fade, cfg.n2, _dp(self.Tt_o[o][s0:]), _dp(self.indata[s0:]), cfg.n_inframe, _dp(self.expo[s0:]),
+                                               self.n_expo, _dp(self.outimage_o[o][s0:]), _dp(self.Tsum_stamp_o[o][s0:]), _dp(self.Tsum_inpix_o[o][s0:]),
+                                               _dp(self.Neff_o[o][s0:])))
 
     def run(self):
         self.build()
@@ -846,8 +870,9 @@ class StampBatch:
             # the coaddition queued behind the solve's launches before the host waits for them (no gap between the two on the device);
             # a batch whose factorisation failed has been solved again by solve_end(): coadd its repaired T
             self.coadd()
-            if self.solve_end():
-                self.coadd()
+            again = self.solve_end()
+            if again is not False:
+                self.coadd(only=again)
         else:
             self.solve_end()  # (kernels without the two halves: the synchronous solve)
             self.coadd()

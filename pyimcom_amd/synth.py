@@ -76,6 +76,12 @@ CONFIGS = {
     "cfg3": WorkloadConfig("cfg3", 48, 0, 1.25 / 48, 8, 0.45, "Eigen", (1e-5, 1e-4, 1e-3)),
     "cfg4": WorkloadConfig("cfg4", 48, 0, 1.25 / 48, (6, 10), 0.45, "Cholesky", (6e-4,)),
     "cfg5": WorkloadConfig("cfg5", 48, 0, 1.25 / 48, 16, 0.45, "Cholesky", (6e-4,)),
+    # the reference's own benchmark shape (configs/paper4_configs/H158_Chol_benchmark.json: OUTSIZE [80, 32, 0.0390625], FADE 3, PAD 2 ->
+    # n1P = 84, INPAD 1.24 -> rho = 31.7 output pixels against n2 = 32 (the guard of coadd.py:1915), NPIXPSF 48, oversamp 8, GAUSSIAN target
+    # with that EXTRASMOOTH, KAPPAC [6e-4], FLATPEN 0, five EXTRAINPUT layers + the science layer = 6 input layers) at six exposures:
+    # N ~ 6.2k input pixels against m = 38^2 = 1444 outputs, i.e. N / m = 4.3 -- the factorisation is 42 % of the matrix flops
+    "paper4": WorkloadConfig("paper4", 32, 3, 0.0390625, 6, 1.24, "Cholesky", (6e-4,), n_inframe=6, extrasmooth=0.934253980316821,
+                             flat_penalty=0.0),
     # small cases for parity tests (oracle finishes in seconds)
     "tiny": WorkloadConfig("tiny", 8, 1, 0.11 / 2.5, 3, 0.12, "Cholesky", (6e-4,), psf="gauss", npixpsf=8, oversamp=4,
                            psf_sigma=0.45, extrasmooth=0.6),

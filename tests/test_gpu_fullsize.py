@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,nst", [("cfg1", 1), ("cfg2", 2), ("cfg2f", 1), ("cfg4", 3), ("cfg5", 1)])
+@pytest.mark.parametrize("name,nst", [("cfg1", 1), ("cfg2", 2), ("cfg2f", 1), ("cfg4", 3), ("cfg5", 1), ("paper4", 1)])
 def test_baseline_config_vs_oracle(name, nst):
     """Every Cholesky configuration of BASELINE.json at its full stamp size -- cfg-5 included: ONE deep-field stamp, 16 exposures,
     N ~ 5.9k (lakernel.py:281-323 on a 5.9k system: the oracle needs about half a minute on the box's host cores) -- A, B, T,

@@ -349,3 +349,69 @@ def test_solve_retries_when_the_workspace_cannot_grow(monkeypatch):
     monkeypatch.setattr(StampBatch, "_solve_target", lambda self, *a, **k: (_ for _ in ()).throw(ImcomError(-5, "injected")))
     with pytest.raises(ImcomError):
         sb.solve()
+
+
+def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle():
+    """The Cholesky repair (lakernel.py:262-279: AA_ii += |w[0]| + 1e-16, w[0] the smallest eigenvalue of A) at a size where the library
+    finds w[0] WITHOUT an eigendecomposition (api.hip lambda_min_subspace: trial factorisations, subspace iteration with the inverse
+    on 128 vectors, Rayleigh-Ritz with A; matrices of 1024 rows and more).  cfg-2 stamps (N ~ 2.2k), a batch of four of which three
+    are made indefinite by different amounts -- A - c I with c a multiple of kappa, so that w[0] = lambda_min(A) - c sits in the dense
+    lower end of a real PSF-overlap spectrum -- and one stays as it is.  T, the maps and info against the oracle's CholKernel (numpy eigh
+    + scipy cholesky), through the synchronous entry and through begin / end / redo (only the failed stamps are solved again: the healthy
+    stamp's outputs must come out bit for bit as a batch without failures gives them)."""
+    import torch
+
+    from oracle import oracle as orc
+    from pyimcom_amd import synth
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    cfg = synth.CONFIGS["cfg2"]
+    stamps = [synth.make_stamp(cfg, 40 + i) for i in range(4)]
+    psfs, target = synth.make_psfs(cfg, cfg.n_expo)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    kap = cfg.kappaC[0] * tabs.C
+    shifts = [3.0 * kap, 0.0, 40.0 * kap, 1.5 * kap]
+    ref = StampBatch(cfg, stamps, tabs)
+    ref.run()
+    torch.cuda.synchronize()
+    healthy = {k: getattr(ref, k)[1].clone() for k in ("Tt", "UC", "Sigma", "kappa", "outimage")}
+    assert not ref.info.any()
+    want = None
+    for mode in ("synchronous", "halves"):
+        sb = StampBatch(cfg, stamps, tabs)
+        sb.build()
+        for s, c in enumerate(shifts):
+            if c:
+                n = int(sb.n[s])
+                sb.A[s, :n, :n].diagonal().sub_(c)
+        if want is None:
+            want = []
+            for s, st in enumerate(stamps):
+                n, m = st.n, cfg.m
+                A = sb.A[s, :n, :n].cpu().numpy()
+                mB = np.ascontiguousarray(sb.Bt[s, :n, :m].cpu().numpy().T)
+                want.append(orc.chol_kernel(A, mB, tabs.C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax) + (np.linalg.eigvalsh(A),))
+        if mode == "synchronous":
+            sb.solve()
+            sb.coadd()
+        else:
+            sb.solve_begin()
+            sb.coadd()
+            again = sb.solve_end()
+            assert again is not False and list(again) == [True, False, True, True]
+            sb.coadd(only=again)
+        torch.cuda.synchronize()
+        r = sb.result()
+        assert list(r.info) == [1, 0, 1, 1], (mode, r.info)
+        for s, st in enumerate(stamps):
+            To, Uo, So, ko, info_o, lam = want[s]
+            assert int(r.info[s]) == info_o
+            # after the repair the smallest eigenvalue of the factored matrix is kappa + 1e-16: cond = (lam_max + kappa + |w0|) / kappa
+            cond = (lam[-1] + kap + abs(min(lam[0], 0.0))) / kap
+            T = r.T(s).cpu().numpy()
+            assert np.abs(T - To).max() <= (1e-6 + 50 * cond * 2.2e-16) * np.abs(To).max(), (mode, s)
+            s2 = (cfg.n2f, cfg.n2f)
+            assert np.allclose(r.UC[s].cpu().numpy(), Uo.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9), (mode, s)
+            assert np.allclose(r.Sigma[s].cpu().numpy(), So.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9), (mode, s)
+        for k, v in healthy.items():  # the stamp without a failure: what a batch without failures gives, bit for bit
+            assert torch.equal(getattr(sb, k)[1], v), (mode, k)
