@@ -616,7 +616,7 @@ def main():
         batch.run()
     barrier()
     elapsed = time.perf_counter() - t0
-    fams = {f: ctx.profile_get(f) for f in ("solve_gemm", "solve_dinv", "chol_gemm", "chol_diag", "build_A", "build_B",
+    fams = {f: ctx.profile_get(f) for f in ("solve_gemm", "solve_dinv", "chol_gemm", "chol_diag", "eigen_repair", "build_A", "build_B",
                                             "finalize", "epilogue")}
     ctx.profile_enable(False)
     ranks_seen, per_rank = 1, [args.batch * args.steps / elapsed]

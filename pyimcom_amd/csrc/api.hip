@@ -257,6 +257,8 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     std::vector<double> dmax(batch, 0.0);
     IMCOM_HIP_CHECK(hipMemcpyAsync(dmax.data(), dmax_d, (size_t)batch * 8, hipMemcpyDeviceToHost, st));
     IMCOM_HIP_CHECK(hipStreamSynchronize(st));
+    static const bool dbg = getenv("IMCOM_LMIN_DEBUG") != nullptr;
+    int nfac = 0, nfac_failed = 0, rounds_run = 0;
     // 1. a positive definite shift
     std::vector<double> sigma(batch, 0.0);
     std::vector<char> todo = want, act = want;
@@ -264,6 +266,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     for (int s : idx) sigma[s] = std::max(std::max(4.0 * inc_failed[s], 1e-13 * dmax[s]), 1e-300);
     for (int t = 0;; t++) {
         IMCOM_TRY(factor(sigma, todo, fail));
+        nfac++;
         bool any = false;
         for (int s : idx) {
             if (!todo[s]) continue;
@@ -271,6 +274,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
             else if (fail[s] != 0) { todo[s] = 0; act[s] = 0; }  // (not finite: not a matrix this iteration can help)
             else todo[s] = 0;
         }
+        if (any) nfac_failed++;
         if (!any) break;
         if (t >= 24) {
             for (int s : idx) if (todo[s]) { todo[s] = 0; act[s] = 0; }
@@ -301,13 +305,20 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     std::vector<double> theta(batch, 0.0), prev(batch, 0.0), eta(batch, 1e-3), lam0(batch, 0.0);
     std::vector<char> conv(batch, 0);
     std::vector<int> gfail(batch, 0);
-    const int max_rounds = 8;
+    // Per stamp two phases.  Coarse (at the first shift): rounds of three steps until two successive Rayleigh-Ritz values agree to
+    // 2 % -- a closer shift chosen earlier than that tends to land below |lambda_min| (a random block needs a few steps before the
+    // asymptotic rate holds), and every trial that fails costs a factorisation = eight steps.  Then ONE factorisation at
+    // |theta| (1 + eta), eta = 8 x that change, and fine rounds of two steps there until two values agree to 1e-11; another
+    // factorisation only when a round has gained less than a factor 20.
+    const int max_rounds = 14;
+    std::vector<char> fine(batch, 0);
+    std::vector<double> lastrel(batch, 1.0);
     for (int round = 0; round < max_rounds; round++) {
         std::vector<char> run(batch, 0);
-        bool any = false;
-        for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; }
+        bool any = false, coarse = false;
+        for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; coarse |= !fine[s]; }
         if (!any) break;
-        const int iters = round == 0 ? 5 : 2;
+        const int iters = coarse ? 3 : 2;
         for (int it = 0; it < iters; it++) {
             IMCOM_TRY(solve(run, X, Y, part, splitk_parts(batch, 1)));
             IMCOM_TRY(orth());
@@ -328,16 +339,26 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
             if (gfail[s] != 0 || !std::isfinite(lam0[s])) { act[s] = 0; continue; }  // the block lost rank / not a number: the eigensolver's case
             prev[s] = theta[s];
             theta[s] = lam0[s];
-            const double rel = fabs(theta[s] - prev[s]) / std::max(fabs(theta[s]), 1e-300);
+            const double rel = round == 0 ? 1.0 : fabs(theta[s] - prev[s]) / std::max(fabs(theta[s]), 1e-300);
             if (round >= 1 && rel <= 1e-11) { conv[s] = 1; continue; }
-            // the next shift: just above |theta| (theta >= lambda_min: the shift must exceed |theta| by more than theta's error)
-            const double want_eta = round == 0 ? 1e-3 : std::min(std::max(16.0 * rel, 1e-9), 1e-2);
-            if (theta[s] < 0.0 && (round == 0 || want_eta < 0.25 * eta[s])) { eta[s] = want_eta; refac[s] = 1; any_refac = true; }
+            // a shift just above |theta| (theta >= lambda_min: it must exceed |theta| by more than theta's error)
+            if (!fine[s]) {
+                if (round >= 1 && rel <= 2e-2 && theta[s] < 0.0) {
+                    fine[s] = 1;
+                    eta[s] = std::min(std::max(8.0 * rel, 1e-3), 0.25);
+                    refac[s] = 1; any_refac = true;
+                }
+            } else if (rel > 0.05 * lastrel[s] && 16.0 * rel < 0.25 * eta[s] && theta[s] < 0.0) {
+                eta[s] = std::max(16.0 * rel, 1e-9);
+                refac[s] = 1; any_refac = true;
+            }
+            lastrel[s] = rel;
         }
         for (int t = 0; any_refac; t++) {
             std::vector<double> sg = sigma;
             for (int s : idx) if (refac[s]) sg[s] = -theta[s] * (1.0 + eta[s]);
             IMCOM_TRY(factor(sg, refac, fail));
+            nfac++;
             any_refac = false;
             for (int s : idx) {
                 if (!refac[s]) continue;
@@ -345,12 +366,20 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
                 else if (t >= 10) { refac[s] = 0; act[s] = 0; }
                 else { eta[s] *= 8.0; any_refac = true; }
             }
+            if (any_refac) nfac_failed++;
+        }
+        rounds_run = round + 1;
+        if (dbg) {
+            const int s = idx[0];
+            fprintf(stderr, "[lmin] round %d (%d steps): stamp %d theta %.15e (prev %.15e) sigma %.6e eta %.3e fine %d conv %d\n", round, iters, s, theta[s], prev[s],
+                    sigma[s], eta[s], (int)fine[s], (int)conv[s]);
         }
     }
     for (int s : idx) {
         ok[s] = act[s] && conv[s];
         if (ok[s]) w0[s] = theta[s];
     }
+    if (dbg) fprintf(stderr, "[lmin] %zu stamps: %d factorisations (%d of them failed for some stamp), %d rounds\n", idx.size(), nfac, nfac_failed, rounds_run);
     ctx->ws_used = mark;
     return IMCOM_OK;
 }

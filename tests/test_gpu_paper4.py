@@ -1,0 +1,127 @@
+"""GPU parity at the reference's own benchmark shape (configs/paper4_configs/H158_Chol_benchmark.json -> synth.CONFIGS["paper4"]):
+32 x 32-output stamps with FADE 3 (m = 38^2 = 1444), INPAD 1.24" = 31.7 output pixels against n2 = 32 -- one pixel inside the guard of
+coadd.py:1915 --, six exposures, six input layers, N ~ 6.2k input pixels per stamp (N / m = 4.3: the factorisation is 42 % of the matrix
+flops), kappa / C = 6e-4.  With PSFs of 48 native pixels the overlap tables end at separations of 24 native pixels while the pixels of a
+stamp lie up to 34 apart: 11 % of A is cut to zero (psfutil.py:1691-1702 leaves off-table samples untouched), A + kappa I is not
+positive definite and EVERY stamp goes through _cholesky_wrapper's repair (lakernel.py:262-279).  The one-stamp A / B / T / maps /
+six-layer image test is tests/test_gpu_fullsize.py::test_baseline_config_vs_oracle[paper4-1]."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _corner(n1P, seed=17):
+    from pyimcom_amd import synth
+    from pyimcom_amd.select import InStampPool
+
+    cfg = synth.CONFIGS["paper4"]
+    inst = synth.make_instamps(cfg, n1P, cfg.n_expo, np.random.default_rng(seed))
+    return cfg, inst, InStampPool(inst, cfg.n_inframe)
+
+
+def test_paper4_selection_vs_oracle():
+    """ST-1 at rho = 31.744 of n2 = 32 (coadd.py:716-749, 886-977, 923): the edge strips are nearly whole InStamps, the corner quarter
+    discs three quarters of one.  Every stamp of a 4 x 4 block -- corners and edges of the block included, where neighbours are
+    missing -- bit for bit against the oracle: pixel order, positions, the six layers, exposure indices, segment boundaries."""
+    from oracle import oracle as orc
+    from pyimcom_amd.blockrun import _neighbours_of
+    from pyimcom_amd.select import select_pixels
+
+    n1P = 4
+    cfg, inst, pool = _corner(n1P)
+    assert 31.7 < cfg.rho < cfg.n2
+    nst = n1P + 2
+    todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    nb = _neighbours_of(todo, cfg.n2, nst)
+    ids, pvx, pvy = (np.stack([t[q] for t in nb]) for q in range(3))
+    cap = max(int(sum(inst[k][0].size for k in row if k >= 0)) for row in ids)
+    ld = (cap + 127) // 128 * 128
+    x, y, indata, expo, cumsum = select_pixels(pool, ids, pvx, pvy, cfg.rho, ld)
+    x, y, indata, expo = x.cpu().numpy(), y.cpu().numpy(), indata.cpu().numpy(), expo.cpu().numpy()
+    for s, (j, i) in enumerate(todo):
+        piv = [(None if np.isnan(a) else a, None if np.isnan(b) else b) for a, b in zip(pvx[s], pvy[s])]
+        rx, ry, rd, re, rc = orc.process_input_stamps([inst[k] if k >= 0 else None for k in ids[s]], piv, cfg.rho)
+        n = rx.size
+        assert 6000 < n < 6500, n  # every stamp of this block has its nine neighbours (the InStamp array has a guard ring, coadd.py:207)
+        assert np.array_equal(cumsum[s], rc), (s, cumsum[s], rc)
+        assert np.array_equal(x[s, :n], rx) and np.array_equal(y[s, :n], ry)
+        assert np.array_equal(indata[s, :, :n], rd) and np.array_equal(expo[s, :n], re)
+        assert not x[s, n:].any() and not indata[s, :, n:].any()
+        # an edge strip holds rho / n2 = 99.2 % of its InStamp, a corner pi/4 (rho / n2)^2 = 77 %
+        cell = lambda k: inst[ids[s][k]][0].size  # noqa: E731
+        seg = np.diff(rc)
+        for k in (1, 3, 5, 7):
+            assert 0.975 * cell(k) <= seg[k] <= cell(k)
+        for k in (0, 2, 6, 8):
+            assert 0.72 * cell(k) <= seg[k] <= 0.82 * cell(k)
+        assert seg[4] == cell(4)
+
+
+def test_paper4_block_corner_fade3_six_layers_vs_oracle():
+    """A 4 x 4-stamp corner of the production block through ``coadd_block`` (selection, A, B, Cholesky with the repair on every stamp,
+    coaddition of six layers, the fade-3 tapers of the maps and of T, overlapping stamps added in the reference's order, boundary
+    recovery), planned by the block planner at this stamp size.  The oracle restates the reference's loop for the 2 x 2 stamps at the
+    block's corner (four stamps of N ~ 6.2k with an eigendecomposition each: about a minute of host time); the block pixels that only
+    those four reach -- the first 64 rows and columns, tapered edges and the recovered boundary included -- are compared with it, the
+    rest of the corner through properties."""
+    import torch
+
+    from oracle import oracle as orc
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import coadd_block, plan_block, stamp_neighbours
+    from pyimcom_amd.stamps import PSFGroupTables
+    from tests import parity
+
+    n1P = 4
+    cfg, inst, pool = _corner(n1P)
+    E, nst = cfg.n_expo, n1P + 2
+    psfs, target = synth.make_psfs(cfg, E)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    chunks = plan_block(cfg, pool, tabs, n1P)
+    assert sorted(t for c in chunks for t in c) == [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    maps = coadd_block(cfg, pool, tabs, n1P, E, chunks=chunks, pad_sides="all")
+    torch.cuda.synchronize()
+    assert maps.info_nonzero == n1P * n1P, "every stamp of this shape needs the repair"
+    got = maps.out_map.cpu().numpy()
+    assert got.shape == (1, cfg.n_inframe, maps.nside, maps.nside) and np.isfinite(got).all()
+
+    g, _, _ = parity.oracle_tables(cfg, psfs, target)
+    t_gpu = tabs.tables.cpu().numpy()
+    pair_tab, pair_pen, _ = tabs.pair_maps(cfg.flat_penalty)
+    ns = maps.nside
+    names = (("UC", "UC"), ("Sigma", "Sigma"), ("kappa", "kappa"), ("Tsum", "Tsum_inpix"), ("Neff", "Neff"))
+    ref = {k: np.zeros((1, ns, ns), np.float32) for k, _ in names}
+    ref_out = np.zeros((1, cfg.n_inframe, ns, ns), np.float32)
+    for j, i in orc.stamp_loop_order(1, 2, 1, 2):
+        ids, pvx, pvy = stamp_neighbours(j, i, cfg.n2, nst)
+        piv = [(None if np.isnan(a) else a, None if np.isnan(b) else b) for a, b in zip(pvx, pvy)]
+        x, y, indata, expo, cum = orc.process_input_stamps([inst[k] if k >= 0 else None for k in ids], piv, cfg.rho)
+        st = synth.Stamp(x=x, y=y, expo=expo.astype(np.int32), seg=None, indata=indata, out_x0=(i - 1) * cfg.n2 - cfg.fade,
+                         out_y0=(j - 1) * cfg.n2 - cfg.fade, n_expo=E, inpix_cumsum=cum)
+        r = parity.oracle_stamp(cfg, g, t_gpu, float(tabs.Cs[0]), st, pair_tab, pair_pen, tabs.io_map(0))
+        orc.block_accumulate(ref_out, r["outimage"][None], j, i, cfg.n2, cfg.fade)
+        for name, key in names:
+            orc.block_accumulate(ref[name], np.asarray(r[key], dtype=np.float32)[None], j, i, cfg.n2, cfg.fade)
+    orc.trapezoid_recover(ref_out, cfg.fade)
+    for name in ref:
+        orc.trapezoid_recover(ref[name], cfg.fade)
+    lim = 2 * cfg.n2  # stamp 3 starts at block pixel 2 n2 (its taper's first pixel)
+    a, b = got[..., :lim, :lim], ref_out[..., :lim, :lim]
+    assert np.abs(b).max() > 0
+    # cond ~ 1e5 after the repair: T carries cond x eps ~ 1e-11; the image tolerance of tests/parity.py, summed over <= 4 stamps
+    for f in range(cfg.n_inframe):
+        assert np.abs(a[0, f] - b[0, f]).max() <= 5e-5 * np.abs(b[0, f]).max(), f
+    for name in ref:
+        x_, y_ = maps.maps[name].cpu().numpy()[..., :lim, :lim], ref[name][..., :lim, :lim]
+        assert np.allclose(x_, y_, rtol=3e-5, atol=1e-6 * np.abs(y_).max()), (name, np.abs(x_ - y_).max(), np.abs(y_).max())
+    # the rest of the corner: every layer finite, the white-noise layers of comparable power over the block, kappa = kappaC C + the
+    # repair everywhere after the recovery (single kappa node: the map is flat per stamp, its taper sums to one across the overlaps)
+    kap = maps.maps["kappa"].cpu().numpy()[0]
+    assert np.isfinite(kap).all() and kap.min() > 0
+    inner = kap[cfg.fade : ns - cfg.fade, cfg.fade : ns - cfg.fade]
+    assert inner.max() / inner.min() < 1.001  # one PSF group: the same kappa C in every stamp, the tapers add up to one
+    p_in = np.square(got[0, 1:, :lim, :lim]).mean()
+    p_all = np.square(got[0, 1:]).mean()
+    assert 0.5 < p_in / p_all < 2.0

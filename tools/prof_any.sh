@@ -11,6 +11,6 @@ F=$(find gpurun_out/anyprof/$L -name '*kernel_stats.csv' | head -1)
 python3 - "$F" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:14]:
+for r in rows[:30]:
     print(f"{r['Name'][:70]:70s} n={int(r['Calls']):5d} avg={float(r['AverageNs'])/1e3:9.1f} us  tot={float(r['TotalDurationNs'])/1e6:8.2f} ms")
 PY
