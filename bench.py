@@ -29,7 +29,132 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (spec); 77.2 measu
 CONFIG_INDEX = {"cfg1": 0, "cfg2": 1, "cfg2f": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}  # BASELINE.json configs[] of each workload
 
 
-def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
+class Telemetry:
+    """Shader / memory clock, board power and temperatures of the GPU this rank runs on, sampled from sysfs (amdgpu hwmon: freq1 = sclk,
+    freq2 = mclk, power1_input, temp2 = junction, temp3 = memory) by a thread while a timed region runs -- what tells a reader of the
+    line why this box is faster or slower than another one (boxes of the pool differ by ~6 % on the same kernel).  The card is found by
+    the PCI address torch reports for the device; anything that cannot be read is left out (never an error)."""
+
+    def __init__(self, device_index=0, period_s=0.05):
+        import glob
+
+        self.dir, self.period, self.rows, self._stop, self._thr = None, period_s, [], None, None
+        try:
+            import torch
+
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for c in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(c).endswith(addr):
+                    h = glob.glob(os.path.join(c, "hwmon", "hwmon*"))
+                    if h:
+                        self.dir, self.addr = h[0], addr
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _read(self, name, scale):
+        try:
+            return float(open(os.path.join(self.dir, name)).read()) * scale
+        except Exception:  # noqa: BLE001
+            return None
+
+    def sample(self):
+        return (self._read("freq1_input", 1e-6), self._read("freq2_input", 1e-6), self._read("power1_input", 1e-6),
+                self._read("temp2_input", 1e-3), self._read("temp3_input", 1e-3))
+
+    def start(self):
+        import threading
+
+        if self.dir is None:
+            return self
+        self.rows, self._stop = [], threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.rows.append(self.sample())
+                self._stop.wait(self.period)
+
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        if self._thr is None:
+            return {"source": None}
+        self._stop.set()
+        self._thr.join()
+        out = {"source": f"sysfs hwmon of {self.addr}, every {self.period * 1e3:.0f} ms", "samples": len(self.rows)}
+        for k, name in enumerate(("sclk_mhz", "mclk_mhz", "power_w", "temp_junction_c", "temp_mem_c")):
+            v = sorted(r[k] for r in self.rows if r[k] is not None)
+            if v:
+                out[name] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+        cap = self._read("power1_cap", 1e-6)
+        if cap is not None:
+            out["power_cap_w"] = cap
+        return out
+
+
+def spread(ms):
+    """min / median / max of a list of per-step milliseconds."""
+    v = sorted(ms)
+    return {"min": v[0], "median": v[len(v) // 2], "max": v[-1]} if v else None
+
+
+# LDS-DMA gathers of table rows served by the XCDs' L2s: 16.8-18.8 TB/s chip-wide (MI355X_MICROARCH.md, "Indexed rows: gather into LDS")
+L2_GATHER_PEAK_GBS = 18800.0
+
+
+def roofline_build_A(n_arr, ms_per_step, traffic_bytes=None, traffic_src=None):
+    """The A builder against the roofs that bound it ("a table-gather + FMA kernel -> LDS / L2 gather bandwidth and vector
+    fp64; report HBM GB/s").  Per sample of the symmetric half (N (N + 1) / 2 per stamp) the kernel stages the ten stencil rows of the
+    sample's overlap table as 5 x 16-byte LDS-DMA pieces each = 800 B from L1 / L2 into LDS, computes 330 flops and writes 8 B (16 with the
+    mirrored entry): the staged bytes per second against the guide's rate for LDS-DMA row gathers out of L2 is the roofline line; the
+    HBM side (A written once: 8 N^2 per stamp) and the vector-fp64 side are reported next to it."""
+    import numpy as np
+
+    n = np.asarray(n_arr, dtype=np.float64)
+    samples = float((n * (n + 1) / 2).sum())
+    t = ms_per_step * 1e-3
+    staged = samples * 800.0 / t / 1e9
+    return {"kernel": "build_A_kernel", "bound": "l2-gather", "achieved": staged, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": staged / L2_GATHER_PEAK_GBS,
+            "samples_per_s": samples / t, "staged_bytes_per_sample": 800, "avg_launch_ms": ms_per_step,
+            "hbm_write_GBs": float((8.0 * n * n).sum()) / t / 1e9, "hbm_frac": float((8.0 * n * n).sum()) / t / 8e12,
+            "valu_TFLOPs": 330.0 * samples / t / 1e12, "valu_frac": 330.0 * samples / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": traffic_bytes, "traffic_source": traffic_src,
+            "note": "achieved = 800 B staged per sample of the symmetric half over the launch time; peak = the guide's LDS-DMA row-gather rate out of L2"}
+
+
+def roofline_chol(n_arr, factorisations, ms_gemm, ms_diag, launches):
+    """The blocked Cholesky (chol_update + chol_trsm + chol_diag launches) against the fp64 matrix peak: N^3 / 3 per factorisation."""
+    import numpy as np
+
+    n = np.asarray(n_arr, dtype=np.float64)
+    flops = float((n**3 / 3.0).sum()) * factorisations
+    t = (ms_gemm + ms_diag) * 1e-3
+    ach = flops / t / 1e12 if t > 0 else 0.0
+    return {"kernel": "chol_update_kernel+chol_trsm_kernel+chol_diag_kernel", "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / FP64_MFMA_PEAK_TFLOPS, "factorisations_per_step": factorisations, "ms_per_step": ms_gemm + ms_diag, "ms_diag_blocks": ms_diag,
+            "launches": launches, "traffic": None, "note": "algorithmic N^3/3 per factorisation; the update launches execute the diagonal tiles in full (+13 % at N = 2.2k)"}
+
+
+def pmc_kernel_traffic(kernel, batch, cfg_name):
+    """HBM bytes per launch of `kernel` from the newest committed counter passes of the headline command (as pmc_traffic)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    doc = json.load(open(files[-1]))
+    from pyimcom_amd._lib import source_sha16
+
+    if doc.get("batch") != batch or doc.get("workload") != cfg_name or doc.get("csrc_sha16") != source_sha16():
+        return None, None
+    ks = [v for k, v in doc["kernels"].items() if k.split("<")[0].split("(")[0] == kernel]
+    n = sum(k["launches"] for k in ks)
+    return (sum(k["traffic_bytes_per_launch"] * k["launches"] for k in ks) / n if n else None), os.path.join("profiles", os.path.basename(files[-1]))
+
+
+def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0, modes=("all", "one", "processes")):
     """The oracle (CPU restatement of the reference path, oracle/) timed on this box's host cores on a bounded sample of
     the same workload: whole stamps -- A and B build (C interpolators, OpenMP over the samples), LAPACK potrf / potrs (numpy
     / scipy BLAS threads), maps, coaddition -- first on all cores, then on ONE thread (threadpoolctl + orc.set_threads),
@@ -78,8 +203,8 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
     # the C interpolators are called once per exposure pair (~80k samples): more than ~32 OpenMP threads only add
     # start-up and spinning next to the BLAS threads (measured: 256 threads 5.7 s per stamp, 1 thread 0.3 s)
     omp = min(cores, 32)
-    done, dt, stages = sample(budget_s * 0.5, omp)
-    if threadpool_limits is not None:
+    done, dt, stages = sample(budget_s * (0.5 if "one" in modes else 1.0), omp)
+    if threadpool_limits is not None and "one" in modes:
         with threadpool_limits(limits=1):
             done1, dt1, stages1 = sample(budget_s * 0.5, 1)
     else:
@@ -91,13 +216,14 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0):
         "cores": cores,
         "kind": "port",
         "sample": f"{done} whole {cfg.name} stamps (N~{stamps[0].n}, m={cfg.m}) through oracle/ on {cores} cores ({dt:.1f} s): C interpolators "
-                  f"with {omp} OpenMP threads, scipy potrf/potrs on {blas}; then {done1} stamps on 1 thread ({dt1:.1f} s)",
+                  f"with {omp} OpenMP threads, scipy potrf/potrs on {blas}" + (f"; then {done1} stamps on 1 thread ({dt1:.1f} s)" if done1 else ""),
         "blas": blas,
         "stage_ms_per_stamp": stages,
     }
     if done1:
         out["one_thread"] = {"value": done1 / dt1, "unit": "postage-stamps/s", "cores": 1, "stage_ms_per_stamp": stages1}
-    out["processes"] = cpu_processes(cfg.name, cores, budget_s * 0.5)
+    if "processes" in modes:
+        out["processes"] = cpu_processes(cfg.name, cores, budget_s * 0.5)
     return out
 
 
@@ -432,6 +558,206 @@ def config_legs(ctx, dev, which=("cfg1", "cfg4", "cfg5", "cfg3")):
     return out
 
 
+def paper4_leg(ctx, dev, batch=128, steps=2, cpu_budget=25.0, block_passes=2):
+    """The reference's OWN benchmark shape (configs/paper4_configs/H158_Chol_benchmark.json; synth.CONFIGS["paper4"]): 32 x 32 outputs with
+    fade 3 (m = 1444), INPAD 1.24" (rho = 31.7 of n2 = 32), six exposures, six input layers, N ~ 6.2k, kappa / C = 6e-4 -- the regime a
+    pyimcom user runs, N / m = 4.3: the factorisation (N^3 / 3 = 81 GFlop) is nearly as large as the solves (2 N^2 m = 112).  With 48-pixel
+    PSFs 11 % of A is beyond the overlap tables' reach (psfutil.py:1691-1702 leaves those samples zero): A + kappa I is indefinite and EVERY
+    stamp takes _cholesky_wrapper's repair (lakernel.py:262-279), so a step is: A, B, one failed factorisation, the smallest eigenvalue
+    (api.hip lambda_min_subspace: trial factorisations + 128-column solves), the repaired factorisation, the solve, coaddition of six layers.
+    Three figures: (1) resident batches as the headline is measured; (2) the first passes of the production block -- n1P = 84, a PSF group
+    per 2 x 2 InStamps, 1849 groups -- through coadd_block with the block planner's own plan, and the seconds per block that rate gives;
+    (3) the oracle on the same stamps on the host's cores."""
+    import numpy as np
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import coadd_block, plan_block, release_buffers
+    from pyimcom_amd.stamps import BlockTables, PSFGroupTables, StampBatch
+
+    cfg = synth.CONFIGS["paper4"]
+    stamps = [synth.make_stamp(cfg, i) for i in range(batch)]
+    psfs, target = synth.make_psfs(cfg, cfg.n_expo)
+    tables = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=dev)
+    b = StampBatch(cfg, stamps, tables, ctx=ctx, device=dev)
+    b.run()
+    torch.cuda.synchronize()
+    fam_names = ("solve_gemm", "chol_gemm", "chol_diag", "eigen_repair", "build_A", "build_B", "finalize", "epilogue")
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    tel = Telemetry(torch.device(dev).index or 0).start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    telemetry = tel.stop()
+    fams = {f: ctx.profile_get(f) for f in fam_names}
+    ctx.profile_enable(False)
+    n = b.n.astype(np.float64)
+    m = cfg.m
+    repaired = int((b.info != 0).sum())
+    fs_flops = float((n**3 / 3.0 + 2.0 * m * n**2).sum())  # factorisation + solves, what a stamp needs (SURVEY 8d)
+    fs_ms = sum(fams[k][0] for k in ("solve_gemm", "chol_gemm", "chol_diag", "eigen_repair")) / steps
+    ach = fs_flops / (fs_ms * 1e-3) / 1e12
+    # the kernels themselves: the two factorisations of a step (the failed one and the repaired one) and the one solve, without the
+    # eigenvalue iteration -- the rate the same launches have when no repair is needed
+    facts = 2 if repaired else 1
+    k_ms = (fams["solve_gemm"][0] + (fams["chol_gemm"][0] + fams["chol_diag"][0]) / facts) / steps
+    ach_k = fs_flops / (k_ms * 1e-3) / 1e12
+    job = fs_flops + float((165.0 * n * (n + 1) + 220.0 * n * m).sum())
+    out = {"value": batch / dt, "unit": "postage-stamps/s", "ms_per_stamp": dt / batch * 1e3, "ms_per_step": dt * 1e3, "batch": batch, "steps": steps,
+           "N_mean": float(n.mean()), "N_max": int(n.max()), "m": m, "n_inframe": cfg.n_inframe, "n_expo": cfg.n_expo, "fade": cfg.fade, "kappaC": list(cfg.kappaC),
+           "stamps_repaired": repaired, "stage_ms_per_step": {k: v[0] / steps for k, v in fams.items() if v[0] > 0},
+           "config": "configs/paper4_configs/H158_Chol_benchmark.json of the reference (OUTSIZE [80, 32, 0.0390625], FADE 3, PAD 2, INPAD 1.24, KAPPAC [6e-4], "
+                     "NPIXPSF 48, GAUSSIAN target, five EXTRAINPUT layers) at six exposures, analytic Roman-like PSFs",
+           "roofline": {"kernel": "factorisation + triangular solves as the path runs them (failed factorisation, smallest-eigenvalue iteration, repaired factorisation, solve)",
+                        "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                        "flops_per_stamp": fs_flops / batch, "count": "N^3/3 + 2 N^2 m per stamp (what a stamp needs; the repair's extra factorisations and block solves are "
+                        "time, not credit)", "ms_per_step": fs_ms, "traffic": None},
+           "roofline_kernels": {"kernel": "chol_update + chol_trsm + chol_diag (one factorisation) + solve_fwd + solve_bwd", "bound": "mfma", "achieved": ach_k,
+                                "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_k / FP64_MFMA_PEAK_TFLOPS, "ms_per_step": k_ms,
+                                "note": "the same launches without the eigenvalue iteration: the rate of a stamp whose A + kappa I is positive definite"},
+           "roofline_chol": roofline_chol(n, facts, fams["chol_gemm"][0] / steps, fams["chol_diag"][0] / steps, fams["chol_gemm"][1] // steps),
+           "roofline_build_A": roofline_build_A(n, fams["build_A"][0] / steps),
+           "job_roofline_frac": job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "telemetry": telemetry}
+    cpu_sample = stamps[:4]
+    del b, tables
+    torch.cuda.synchronize()
+    release_buffers()
+    ctx.release_workspace()
+    torch.cuda.empty_cache()
+
+    # (2) the production block: n1P = 84, a PSF group per 2 x 2 InStamps; the first passes of the planner's plan, timed
+    def block():
+        n1P = 84
+        cfgb, inst, pool, psfs_b, target_b, groups, counts, img_all, yxco_all = block_workload(dev, n1P, config="paper4")
+        from pyimcom_amd import psfs as psfmod
+
+        ns, order = psfs_b.shape[-1], {k: q for q, k in enumerate(groups)}
+
+        def sample_groups(keys):
+            idx = torch.tensor([order[k] for k in keys]).pin_memory().to(dev, non_blocking=True)
+            return psfmod.sample_psf(img_all[idx].reshape(-1, ns + 16, ns + 16), ns, yxco_all[idx].reshape(-1, 2, ns, ns), psf_norm=True, ctx=ctx)
+
+        tabs = BlockTables(groups, target_b, cfgb.nfft, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True)
+        plan = plan_block(cfgb, pool, tabs, n1P)
+        first = plan[:block_passes]
+        coadd_block(cfgb, pool, tabs, n1P, cfgb.n_expo, chunks=first[:1], pad_sides=None)  # warm-up: buffers, workspace, kernels
+        torch.cuda.synchronize()
+        tabs.reset()
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        maps = coadd_block(cfgb, pool, tabs, n1P, cfgb.n_expo, chunks=first, pad_sides=None)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        fam_b = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "eigen_repair", "solve_gemm", "finalize", "epilogue", "block_acc")
+        st = {f: ctx.profile_get(f)[0] for f in fam_b}
+        ctx.profile_enable(False)
+        done = sum(len(c) for c in first)
+        return {"n1P": n1P, "stamps_per_block": n1P * n1P, "psf_groups": len(groups), "passes_in_plan": len(plan), "pass_sizes": sorted({len(c) for c in plan}),
+                "passes_timed": len(first), "stamps_timed": done, "ms_timed": dtb * 1e3, "ms_per_stamp": dtb * 1e3 / done, "value": done / dtb, "unit": "postage-stamps/s",
+                "seconds_per_block": dtb / done * n1P * n1P, "stamps_repaired": int(getattr(maps, "info_nonzero", 0)),
+                "tables": {"computed": int(tabs.computed_tables), "block_total": int(tabs.block_demand()), "arena": int(tabs.capacity)},
+                "stage_ms": {k: v for k, v in st.items() if v > 0}, "input_pixels": int(pool.npool),
+                "what": "the first passes of the 84 x 84-stamp production block through coadd_block (plan, PSF sampling, spectra, overlap tables of the passes' "
+                        "groups, selection, pair maps, A, B, Cholesky with the repair, coaddition, block maps); seconds_per_block = this rate x 7056 stamps"}
+
+    try:
+        out["block"] = block()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        traceback.print_exc(file=sys.stderr)
+        out["block"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    torch.cuda.synchronize()
+    release_buffers()
+    ctx.release_workspace()
+    torch.cuda.empty_cache()
+    if cpu_budget and cpu_budget > 0:
+        try:
+            cb = cpu_baseline(cfg, cpu_sample, psfs, target, cpu_budget, modes=("all",))
+            out["cpu_baseline"] = cb
+            out["vs_cpu"] = out["value"] / cb["value"]
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def summary_of(out):
+    """Every leg of the line in a few numbers -- value and roofline fraction -- short enough to survive in the last ~1.5 k characters of
+    the line (a driver that keeps a tail of stdout sees all legs, not only the last ones).  v = stamps/s, ms = ms per stamp, f = roofline
+    fraction of the leg's dominant kernel family, job = all algorithmic flops of the stamps over the wall time / fp64 matrix peak."""
+    r3 = lambda x: None if x is None else float(f"{x:.4g}")  # noqa: E731
+
+    def leg(d, extra=()):
+        if not isinstance(d, dict):
+            return None
+        if "error" in d:
+            return {"error": d["error"][:60]}
+        o = {"v": r3(d.get("value")), "ms": r3(d.get("ms_per_stamp"))}
+        if isinstance(d.get("roofline"), dict):
+            o["f"] = r3(d["roofline"].get("frac"))
+        if d.get("job_roofline_frac") is not None:
+            o["job"] = r3(d["job_roofline_frac"])
+        for k in extra:
+            if d.get(k) is not None:
+                o[k] = r3(d[k]) if isinstance(d[k], float) else d[k]
+        return o
+
+    sm = {"headline": {"v": r3(out["value"]), "ms_step": r3(out["ms_per_step"]), "f": r3(out["roofline"]["frac"]), "launch_ms": r3(out["roofline"]["avg_launch_ms"]),
+                       "step_ms": [r3(out["step_ms"][k]) for k in ("min", "median", "max")] if out.get("step_ms", {}).get("min") is not None else None,
+                       "probe": [r3(out["roofline"].get("mfma_probe_tflops")), r3(out["roofline"].get("mfma_probe_sustained_tflops"))],
+                       "n_gpus": out["n_gpus"]}}
+    tel = out.get("telemetry") or {}
+    if tel.get("sclk_mhz"):
+        sm["headline"]["sclk"] = [r3(tel["sclk_mhz"][k]) for k in ("min", "median", "max")]
+        sm["headline"]["W"] = r3(tel.get("power_w", {}).get("median"))
+        sm["headline"]["Tj"] = r3(tel.get("temp_junction_c", {}).get("max"))
+    for k in ("roofline_chol", "roofline_build_A"):
+        if isinstance(out.get(k), dict):
+            sm["headline"][k[9:]] = r3(out[k]["frac"])
+    if "block" in out:
+        sm["block"] = leg(out["block"])
+    if "eigen_block" in out:
+        sm["eigen_block"] = leg(out["eigen_block"], ("batches_run",))
+    if "block_seam" in out:
+        bs = out["block_seam"]
+        sm["block_seam"] = {"v": r3(bs.get("value")), "threads": bs.get("host_threads"), "v1": r3(bs.get("one_host_thread", {}).get("value")),
+                            "v_passes": r3(bs.get("several_passes", {}).get("value"))}
+    if "kernel_seam" in out:
+        ks = out["kernel_seam"]
+        sm["kernel_seam"] = {"ms": r3(ks.get("ms_per_stamp")), "ms4": r3(ks.get("ms_per_stamp_group4"))}
+    cf = out.get("configs")
+    if isinstance(cf, dict):
+        if "error" in cf:
+            sm["configs"] = {"error": cf["error"][:60]}
+        for name in ("cfg1", "cfg4", "cfg5"):
+            if name in cf:
+                sm[name] = leg(cf[name])
+        if "cfg3" in cf:
+            c3 = cf["cfg3"]
+            sm["cfg3"] = {k: {"ms": r3(v.get("ms_per_stamp")), "f": r3(v.get("roofline", {}).get("frac")), "symv4_f": r3(v.get("roofline_hbm", {}).get("frac"))}
+                          for k, v in c3.items() if isinstance(v, dict) and k.startswith("b")} if isinstance(c3, dict) and "error" not in c3 else leg(c3)
+        if "paper4" in cf:
+            p4 = cf["paper4"]
+            sm["paper4"] = leg(p4, ("stamps_repaired", "batch"))
+            if isinstance(p4, dict) and "error" not in p4:
+                sm["paper4"]["f_kernels"] = r3(p4.get("roofline_kernels", {}).get("frac"))
+                blk = p4.get("block", {})
+                sm["paper4"]["block"] = {"error": blk["error"][:60]} if "error" in blk else {"v": r3(blk.get("value")), "s_per_block": r3(blk.get("seconds_per_block"))}
+                if isinstance(p4.get("cpu_baseline"), dict) and "value" in p4["cpu_baseline"]:
+                    sm["paper4"]["cpu"] = r3(p4["cpu_baseline"]["value"])
+    if "farm" in out:
+        sm["farm"] = leg(out["farm"], ("makespan_s", "blocks", "ranks_seen"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict) and "value" in cb:
+        sm["cpu"] = {"v": r3(cb["value"]), "cores": cb.get("cores"), "v1": r3(cb.get("one_thread", {}).get("value")), "vP": r3(cb.get("processes", {}).get("value")),
+                     "P": cb.get("processes", {}).get("processes")}
+    return sm
+
+
 def seam_legs(ctx, dev, cfg, batch):
     """The two seams a pyimcom user reaches the library through, timed the way they are used (never the headline):
     ``kernel_seam`` -- the drop-in LA kernel class (OutStamp.LAKERNEL, coadd.py:839-844, 1091-1093): ONE stamp per call, A and -B/2
@@ -611,11 +937,17 @@ def main():
     barrier()
     ctx.profile_enable(True)
     ctx.profile_reset()
+    tel = Telemetry(local_rank).start()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # per-step times: events on the stream the steps run on
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         batch.run()
+        marks[k + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    telemetry = tel.stop()
+    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
     fams = {f: ctx.profile_get(f) for f in ("solve_gemm", "solve_dinv", "chol_gemm", "chol_diag", "eigen_repair", "build_A", "build_B",
                                             "finalize", "epilogue")}
     ctx.profile_enable(False)
@@ -651,7 +983,12 @@ def main():
         ms, launches = fams["solve_gemm"]
         traffic, traffic_src = pmc_traffic(args.batch, cfg.name)
         achieved = solve_flops_step * args.steps / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        probe = ctx.mfma_probe(50.0)  # a pure fp64 MFMA loop on every SIMD, measured now: what the pipe gives with no operand traffic
+        # a pure fp64 MFMA loop on every SIMD, measured now: what the pipe gives with no operand traffic -- for 50 ms (the clock of a
+        # cold chip) and sustained for more than a second (the clock the chip holds once it is warm and at its power limit)
+        probe = ctx.mfma_probe(50.0)
+        tel_p = Telemetry(local_rank).start()
+        probe_sustained = ctx.mfma_probe(1200.0)
+        probe_tel = tel_p.stop()
         out = {
             "metric": "postage-stamps/sec (and ms/stamp) for N~2k A-solve",
             "value": world * args.batch * args.steps / elapsed,
@@ -690,9 +1027,18 @@ def main():
                 "avg_launch_ms": ms / max(launches, 1),
                 "launches": launches,
                 "mfma_probe_tflops": probe,  # informative: frac above is against the guide's 78.6
+                "mfma_probe_sustained_tflops": probe_sustained,  # the same loop for 1.2 s
+                "mfma_probe_sustained_telemetry": probe_tel,
             },
             "stage_ms_per_step": {k: v[0] / args.steps for k, v in fams.items()},
+            "step_ms": {"all": step_ms, **(spread(step_ms) or {})},  # HIP events between the steps, on the steps' stream
+            "telemetry": telemetry,  # clocks / power / temperatures sampled while the timed steps ran
         }
+        if cfg.kernel == "Cholesky":
+            facts = 1 + (1 if int((batch.info != 0).sum()) else 0)
+            out["roofline_chol"] = roofline_chol(n_arr, facts, fams["chol_gemm"][0] / args.steps, fams["chol_diag"][0] / args.steps, fams["chol_gemm"][1] // max(args.steps, 1))
+        tr_a, tr_src = pmc_kernel_traffic("build_A_kernel", args.batch, cfg.name)
+        out["roofline_build_A"] = roofline_build_A(n_arr, fams["build_A"][0] / args.steps, tr_a, tr_src)
         from pyimcom_amd.blockrun import release_buffers
 
         def tidy():
@@ -731,8 +1077,12 @@ def main():
             # BASELINE configs[2] "batched across one block": the Eigen kernel with its kappa sweep through coadd_block, PSF group per 2 x 2 InStamps
             tidy()  # (the 256-stamp Eigen leg left 130 GB of workspace on the context: the block planner sizes passes by free memory)
             out["eigen_block"] = leg(lambda: block_leg(ctx, dev, n1P=16, reps=1, config="cfg3", warm=8))
+            tidy()
+            # the reference's own benchmark shape (not a BASELINE config: the shape its users run)
+            out["configs"]["paper4"] = leg(lambda: paper4_leg(ctx, dev, cpu_budget=0.0 if args.no_cpu_baseline else min(args.cpu_budget, 25.0)))
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = leg(lambda: cpu_baseline(cfg, cpu_sample, psfs, target, args.cpu_budget))
+        out["summary"] = summary_of(out)  # LAST: the compact form of every leg, inside the tail a driver keeps of a long line
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -862,7 +862,7 @@ int imcom_ctx_profile_get(imcom_ctx *ctx, const char *family, double *ms, long *
 int imcom_ctx_mfma_probe(imcom_ctx *ctx, double millis, double *tflops)
 {
     IMCOM_TRY(check_ctx(ctx));
-    IMCOM_REQUIRE(tflops && millis > 0.0 && millis <= 1000.0, "bad arguments");
+    IMCOM_REQUIRE(tflops && millis > 0.0 && millis <= 5000.0, "bad arguments (millis in (0, 5000])");
     const int nwg = 2 * ctx->cu_count;  // two 8-wave workgroups per CU: four waves per SIMD, all resident at once
     IMCOM_TRY(ws_reserve(ctx, 4096));
     double *sink = (double *)ws_take(ctx, 8);
@@ -880,7 +880,7 @@ int imcom_ctx_mfma_probe(imcom_ctx *ctx, double millis, double *tflops)
         float f = 0.f;
         IMCOM_HIP_CHECK(hipEventElapsedTime(&f, e0, e1));
         ms = f;
-        if (pass == 0) iters = (int)std::max(200.0, std::min(2.0e6, iters * millis / std::max(ms, 1e-3)));
+        if (pass == 0) iters = (int)std::max(200.0, std::min(2.0e7, iters * millis / std::max(ms, 1e-3)));
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
