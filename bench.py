@@ -413,7 +413,11 @@ def block_leg(ctx, dev, n1P=48, reps=3, config="cfg2", warm=16):
 
     fams = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B", "chol_gemm", "chol_diag", "solve_gemm", "finalize",
             "eigen_trd", "eigen_applyq", "lakernel1", "eigen_gemm", "epilogue", "block_acc")
+    from pyimcom_amd.blockrun import memory_plan
+
+    mplan = memory_plan(cfg, pool, n1P, E, ctx=ctx)  # stamps first, the arenas get the rest (up to every table of the block)
     tabs = BlockTables(groups, target, cfg.nfft, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True,
+                       capacity=mplan["capacity"], spec_capacity=mplan["spec_capacity"],
                        eager_groups=os.environ.get("BENCH_EAGER_GROUPS", "1") != "0")  # (A/B runs: BENCH_EAGER_GROUPS=0)
 
     def one():
@@ -422,17 +426,14 @@ def block_leg(ctx, dev, n1P=48, reps=3, config="cfg2", warm=16):
 
     # warm-up (kernels loaded, workspace and per-batch buffers grown to what a pass of this block takes: a first pass that has to
     # allocate tens of GB does so with the GPU idle), then the timed block(s): a corner of the block, and the first pass of the plan
-    w = min(warm, n1P)
-    coadd_block(cfg, pool, tabs, n1P, E, stamps=[(j, i) for j in range(1, w + 1) for i in range(1, w + 1)])
-    # (the planner counts the workspace and the buffers earlier passes left as available: the plan may grow once they exist -- repeat until
-    # the plan the timed block will make is the one that has been warmed up; a 256-stamp Eigen pass that first has to grow a 125 GB
-    # workspace and its buffers inside the timed region took 7.9 s instead of 1.4)
-    for _ in range(3):
-        first = plan_block(cfg, pool, tabs, n1P)
-        coadd_block(cfg, pool, tabs, n1P, E, chunks=first[:1], pad_sides=None)
-        torch.cuda.synchronize()
-        if [len(c) for c in plan_block(cfg, pool, tabs, n1P)] == [len(c) for c in first]:
-            break
+    # ONE warm-up pass: the first pass of the plan (kernels loaded, the workspace tensor and the per-batch buffers at the size the block's
+    # passes take).  The plan is made from torch's allocator alone and counts what the warm-up leaves behind as available: it is the same
+    # plan before and after (asserted below; until round 5 the library's own hipMalloc beside torch's cache made it depend on history).
+    first = plan_block(cfg, pool, tabs, n1P)
+    coadd_block(cfg, pool, tabs, n1P, E, chunks=first[:1], pad_sides=None)
+    torch.cuda.synchronize()
+    again = plan_block(cfg, pool, tabs, n1P)
+    plan_stable = [len(c) for c in again] == [len(c) for c in first]
     ctx.profile_enable(True)
     runs = []
     for _ in range(reps):
@@ -460,6 +461,7 @@ def block_leg(ctx, dev, n1P=48, reps=3, config="cfg2", warm=16):
         "batches_run": list(getattr(maps, "chunk_sizes", [])), "info_nonzero": int(getattr(maps, "info_nonzero", 0)),  # the plan of the last timed block itself
         "free_gb_at_end": round(torch.cuda.mem_get_info(dev)[0] / 1e9, 1), "torch_reserved_gb": round(torch.cuda.memory_reserved(dev) / 1e9, 1),
         "passes_halved": int(getattr(maps, "passes_halved", 0)),  # passes the device had no memory for after all, run again as two (last timed block)
+        "plan_stable": bool(plan_stable), "memory_plan": {k: mplan[k] for k in ("capacity", "spec_capacity", "stamps", "bytes_per_stamp", "available")},
     }
 
 
@@ -640,7 +642,11 @@ def paper4_leg(ctx, dev, batch=128, steps=2, cpu_budget=25.0, block_passes=2):
             idx = torch.tensor([order[k] for k in keys]).pin_memory().to(dev, non_blocking=True)
             return psfmod.sample_psf(img_all[idx].reshape(-1, ns + 16, ns + 16), ns, yxco_all[idx].reshape(-1, 2, ns, ns), psf_norm=True, ctx=ctx)
 
-        tabs = BlockTables(groups, target_b, cfgb.nfft, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True)
+        from pyimcom_amd.blockrun import memory_plan
+
+        mplan = memory_plan(cfgb, pool, n1P, cfgb.n_expo, ctx=ctx)
+        tabs = BlockTables(groups, target_b, cfgb.nfft, ctx=ctx, device=dev, group_count=counts, bulk_provider=sample_groups, cells=True,
+                           capacity=mplan["capacity"], spec_capacity=mplan["spec_capacity"])
         plan = plan_block(cfgb, pool, tabs, n1P)
         first = plan[:block_passes]
         coadd_block(cfgb, pool, tabs, n1P, cfgb.n_expo, chunks=first[:1], pad_sides=None)  # warm-up: buffers, workspace, kernels
@@ -660,6 +666,7 @@ def paper4_leg(ctx, dev, batch=128, steps=2, cpu_budget=25.0, block_passes=2):
                 "passes_timed": len(first), "stamps_timed": done, "ms_timed": dtb * 1e3, "ms_per_stamp": dtb * 1e3 / done, "value": done / dtb, "unit": "postage-stamps/s",
                 "seconds_per_block": dtb / done * n1P * n1P, "stamps_repaired": int(getattr(maps, "info_nonzero", 0)),
                 "tables": {"computed": int(tabs.computed_tables), "block_total": int(tabs.block_demand()), "arena": int(tabs.capacity)},
+                "memory_plan": {k: mplan[k] for k in ("capacity", "spec_capacity", "stamps", "bytes_per_stamp", "available")},
                 "stage_ms": {k: v for k, v in st.items() if v > 0}, "input_pixels": int(pool.npool),
                 "what": "the first passes of the 84 x 84-stamp production block through coadd_block (plan, PSF sampling, spectra, overlap tables of the passes' "
                         "groups, selection, pair maps, A, B, Cholesky with the repair, coaddition, block maps); seconds_per_block = this rate x 7056 stamps"}

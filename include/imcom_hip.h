@@ -65,6 +65,16 @@ int imcom_ctx_workspace_bytes(imcom_ctx *ctx, size_t *bytes);
 /* Give the workspace back to the device (after draining the context's streams); the next call allocates what it needs.
  * For drivers that change kernel or batch size between blocks: the workspace otherwise keeps the size of the largest call. */
 int imcom_ctx_workspace_release(imcom_ctx *ctx);
+/* ONE OWNER for device memory.  By default a context allocates its workspace itself (hipMalloc, growing on demand).  After this
+ * call it works in the caller's buffer `ptr` of `bytes` bytes (256-byte aligned; NULL, 0 = "none yet") and never allocates device
+ * memory again: a call that needs more returns IMCOM_ERR_NOMEM without having queued anything, imcom_ctx_workspace_needed says how
+ * much it asked for, and the caller -- who knows what else lives on the device -- provides it or plans smaller.  The buffer must
+ * stay valid until the next imcom_ctx_set_workspace / imcom_ctx_destroy; imcom_ctx_workspace_release only forgets it.  The
+ * reference's analogue is TEMPFILE, its "virtual memory" for A sub-blocks (psfutil.py:2056-2085): where they live is the user's call.
+ * pyimcom_amd.Context takes the buffer from torch's allocator, so that torch is the only allocator on the device. */
+int imcom_ctx_set_workspace(imcom_ctx *ctx, void *ptr, size_t bytes);
+/* Workspace bytes the most recent call on this context asked for (whether or not it got them). */
+int imcom_ctx_workspace_needed(imcom_ctx *ctx, size_t *bytes);
 /* Elapsed device milliseconds spent in the named kernel family since the last reset, measured with
  * HIP events on the context's stream when profiling is enabled (bench.py's roofline leg).
  * family: "solve_gemm", "chol_gemm", "chol_diag", "build_A", "build_B", "finalize", "epilogue",
@@ -156,6 +166,8 @@ int imcom_solve_eigen(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, c
 /* Bytes of device workspace imcom_solve_eigen_resident takes for `batch` stamps of these leading dimensions (a planner adds
  * them to its own buffers: pyimcom_amd.blockrun.stamp_bytes).  Pure arithmetic: no context, no device call. */
 int imcom_solve_eigen_workspace(int batch, int ldn, int ldm, int m, size_t *bytes);
+/* The same for imcom_solve_chol_resident / _begin / _redo (nv kappa nodes; the repair path's scratch included). */
+int imcom_solve_chol_workspace(int batch, int ldn, int m, int ldm, int nv, size_t *bytes);
 /* Householder reduction of symmetric matrices to band form, the basis the Eigen kernel's kappa search works in
  * (numpy.linalg.eigh at lakernel.py:162, 201 is not needed for it: DESIGN.md "Eigen path"): A = Q B Q^T, B[i][j] = 0 for
  * |i - j| > 4, Q = H_0 H_1 ... with H_r = I - tau_r v_r v_r^T, v_r zero above its pivot row r + 4 (v_r[r+4] = 1).

@@ -61,6 +61,8 @@ SIGNATURES = {
     "imcom_ctx_sync": [_vp],
     "imcom_ctx_workspace_bytes": [_vp, C.POINTER(C.c_size_t)],
     "imcom_ctx_workspace_release": [_vp],
+    "imcom_ctx_set_workspace": [_vp, _vp, C.c_size_t],
+    "imcom_ctx_workspace_needed": [_vp, C.POINTER(C.c_size_t)],
     "imcom_ctx_profile_enable": [_vp, _i],
     "imcom_ctx_profile_reset": [_vp],
     "imcom_ctx_profile_get": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_l)],
@@ -103,25 +105,68 @@ SIGNATURES = {
     "imcom_psf_overlap_spectra_slots": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "imcom_block_accumulate": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
     "imcom_solve_eigen_workspace": [_i, _i, _i, _i, _vp],
+    "imcom_solve_chol_workspace": [_i, _i, _i, _i, _i, _vp],
     "imcom_block_place": [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
     "imcom_block_combine": [_vp, _i, _i, _i, _l, _vp, _i, _vp, _i, _i, _i, _i],
     "imcom_compress_map_f32": [_vp, _vp, _l, _i, _i, _vp],
     "imcom_trapezoid_recover_f32": [_vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i],
 }
+_cdll = lib
 for _name, _args in SIGNATURES.items():
-    _f = getattr(lib, _name)
+    _f = getattr(_cdll, _name)
     _f.argtypes = _args
     _f.restype = C.c_int
-lib.imcom_version.argtypes = []
-lib.imcom_version.restype = C.c_int
-lib.imcom_dev_build.argtypes = []
-lib.imcom_dev_build.restype = C.c_int
-lib.imcom_psf_spectra_size.argtypes = [_i, _i]
-lib.imcom_psf_spectra_size.restype = C.c_long
-lib.imcom_smooth_pad_width.argtypes = [_d, _d]
-lib.imcom_smooth_pad_width.restype = C.c_int
-lib.imcom_last_error.argtypes = []
-lib.imcom_last_error.restype = C.c_char_p
+
+IMCOM_ERR_NOMEM = -3
+_CONTEXTS = {}  # handle value -> Context (weak): the contexts whose workspace this module provides from torch's allocator
+
+
+def _with_workspace(name, fn):
+    """A library call on a context whose device workspace this module owns (Context, below): when the call reports that the
+    workspace it was given is too small (IMCOM_ERR_NOMEM before anything was queued), the context's buffer is replaced by one of
+    the size the call asked for -- taken from torch's allocator, the only allocator on the device -- and the call is made again."""
+
+    def call(*args):
+        rc = fn(*args)
+        if rc != IMCOM_ERR_NOMEM or not args:
+            return rc
+        h = args[0]
+        ref = _CONTEXTS.get(h.value if isinstance(h, C.c_void_p) else h)
+        ctx = ref() if ref is not None else None
+        if ctx is None or not ctx._grow_to_needed():
+            return rc
+        return fn(*args)
+
+    call.__name__ = name
+    return call
+
+
+class _Lib:
+    """The shared library with every context-taking entry wrapped by ``_with_workspace``; everything else passes through."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name, args in SIGNATURES.items():
+            f = getattr(cdll, name)
+            takes_ctx = bool(args) and args[0] is _vp and name not in ("imcom_ctx_destroy", "imcom_ctx_set_workspace", "imcom_ctx_workspace_needed",
+                                                                       "imcom_ctx_workspace_bytes", "imcom_ctx_workspace_release")
+            setattr(self, name, _with_workspace(name, f) if takes_ctx else f)
+
+    def __getattr__(self, name):  # (only what __init__ did not set)
+        return getattr(self._cdll, name)
+
+
+lib = _Lib(_cdll)
+_cdll.imcom_version.argtypes = []
+_cdll.imcom_version.restype = C.c_int
+_cdll.imcom_dev_build.argtypes = []
+_cdll.imcom_dev_build.restype = C.c_int
+_cdll.imcom_psf_spectra_size.argtypes = [_i, _i]
+_cdll.imcom_psf_spectra_size.restype = C.c_long
+_cdll.imcom_smooth_pad_width.argtypes = [_d, _d]
+_cdll.imcom_smooth_pad_width.restype = C.c_int
+_cdll.imcom_last_error.argtypes = []
+_cdll.imcom_last_error.restype = C.c_char_p
 
 EXPORTED = sorted(list(SIGNATURES) + ["imcom_version", "imcom_dev_build", "imcom_last_error", "imcom_psf_spectra_size", "imcom_smooth_pad_width"])
 
@@ -153,12 +198,60 @@ def device_count():
 
 
 class Context:
-    """One libimcom context = one GPU + one stream + one workspace (not thread-safe)."""
+    """One libimcom context = one GPU + one stream + one workspace (not thread-safe).
 
-    def __init__(self, device=0):
+    Device memory has ONE owner: torch's caching allocator.  The context's workspace is a torch tensor handed to the library
+    (imcom_ctx_set_workspace): the library never allocates device memory itself; a call that needs a larger workspace says so,
+    the tensor is replaced by one of exactly that size (``_grow_to_needed``; the old one goes back to torch first) and the call is
+    made again.  ``torch.cuda.memory_allocated`` therefore accounts for everything on the device, and a planner that reads torch's
+    numbers (pyimcom_amd.blockrun) plans with exact figures.  ``own_workspace=False`` (or no torch): the library's own hipMalloc."""
+
+    def __init__(self, device=0, own_workspace=True):
         self._h = _vp()
         check(lib.imcom_ctx_create(int(device), C.byref(self._h)))
         self.device = int(device)
+        self._ws = None
+        self._owns_ws = False
+        if own_workspace:
+            try:
+                import torch  # noqa: F401
+
+                check(lib.imcom_ctx_set_workspace(self._h, None, 0))
+                self._owns_ws = True
+                import weakref
+
+                _CONTEXTS[self._h.value] = weakref.ref(self)
+            except ImportError:  # pragma: no cover
+                pass
+
+    def _grow_to_needed(self):
+        """Replace the workspace tensor by one of the size the last call asked for.  False: nothing to do (the call's failure was
+        not about this workspace)."""
+        if not self._owns_ws or not self._h:
+            return False
+        import torch
+
+        need = self.workspace_needed()
+        have = 0 if self._ws is None else self._ws.numel()
+        if need <= have:
+            return False
+        dev = torch.device("cuda", self.device)
+        torch.cuda.synchronize(dev)  # whatever still runs in the old buffer
+        check(lib.imcom_ctx_set_workspace(self._h, None, 0))
+        self._ws = None
+        torch.cuda.empty_cache()  # the old buffer goes back to the driver: a larger one cannot be carved out of it
+        size = (need + (1 << 21) - 1) >> 21 << 21
+        try:
+            self._ws = torch.empty(size, dtype=torch.uint8, device=dev)
+        except torch.OutOfMemoryError as e:
+            raise ImcomError(IMCOM_ERR_NOMEM, f"device workspace of {size} bytes: {e}") from None
+        check(lib.imcom_ctx_set_workspace(self._h, _vp(self._ws.data_ptr()), size))
+        return True
+
+    def workspace_needed(self):
+        b = C.c_size_t(0)
+        check(lib.imcom_ctx_workspace_needed(self.handle, C.byref(b)))
+        return b.value
 
     @property
     def handle(self):
@@ -180,6 +273,8 @@ class Context:
     def release_workspace(self):
         """Hand the device workspace back (it otherwise keeps the size of the largest call made on this context)."""
         check(lib.imcom_ctx_workspace_release(self.handle))
+        if self._owns_ws:
+            self._ws = None  # (imcom_ctx_workspace_release has drained the context's streams)
 
     def profile_enable(self, on=True):
         """on = 2: also the per-launch scopes inside long stages (the band reduction's "symv4")."""
@@ -207,8 +302,10 @@ class Context:
 
     def close(self):
         if self._h:
+            _CONTEXTS.pop(self._h.value, None)
             lib.imcom_ctx_destroy(self._h)
             self._h = _vp()
+            self._ws = None
 
     def __del__(self):
         try:

@@ -168,7 +168,7 @@ def check_batch(sb):
 
 
 
-def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap=256, kernel="Cholesky"):
+def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap=256, kernel="Cholesky", nv=1, n_inframe=2):
     """Stamps per batch for a block: as many as memory holds (at most ``cap``), and among those the count for which the block's
     passes -- the short last one included -- take the fewest rounds of workgroups.  A solve launch has batch x ldm/128 workgroups for 2 x ``cu_count`` resident ones: 256 cfg-2 stamps
     are exactly 9 rounds, 128 are 4.5 (every launch ends with a half-empty round: cfg-4 ran 694 stamps/s at 128, 793 at 256),
@@ -176,7 +176,7 @@ def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap
     the other kernels work on copies in the reference's layout (``stamp_bytes``)."""
     hi = min(int(n_stamps), int(cap))
     if free_bytes is not None:
-        hi = max(1, min(hi, int(fill_of(kernel) * free_bytes) // stamp_bytes(ldn, ldm, n_out, kernel)))
+        hi = max_stamps(int(fill_of(kernel) * free_bytes), ldn, ldm, n_out, kernel, nv, n_inframe, cap=hi)
     if hi >= n_stamps:
         return max(int(n_stamps), 1)
     tiles, slots = max(ldm // NB, 1), 2 * cu_count
@@ -189,31 +189,144 @@ def choose_batch(n_stamps, ldn, ldm, n_out=1, free_bytes=None, cu_count=256, cap
     return best
 
 
-def fill_of(kernel):
-    """Share of the free device memory a plan may fill by the model of ``stamp_bytes``: 0.8; 0.7 for the Eigen kernel, whose workspace is
-    most of a pass -- at 0.8 a 16 x 16-stamp cfg-3 block sat on the border between one pass of 256 stamps and two of 128, and the one pass,
-    when the device had a few GB less to give than it reported, ran out of memory or (worse) at a sixth of its speed."""
-    return 0.7 if kernel == "Eigen" else 0.8
+def fill_of(kernel=None):
+    """Share of the available device memory a plan may fill.  Every byte of a pass is accounted for -- the per-batch arrays, the
+    library workspace by the library's own arithmetic (``stamp_bytes``), the selection's outputs, the block maps -- and all of it comes
+    from ONE allocator (torch's: the library works in a torch tensor, ``_lib.Context``), so what is left out is only that allocator's
+    rounding of large blocks to 2 MB and the kernels' code objects: 3 %.  (Until round 5 the library allocated its workspace beside
+    torch's allocator and the plan kept 20-30 % back for what the two withheld from each other.)"""
+    return 0.97
 
 
-def stamp_bytes(ldn, ldm, n_out=1, kernel="Cholesky", resident=2):
-    """Device bytes per stamp of a block's batches while an LA kernel runs: the StampBatch buffers of ``resident`` batches
-    (coadd_block prepares batch k + 1 while batch k is solved) + the library workspace of the one being solved."""
-    base = 8 * (ldn * ldn + n_out * ldn * ldm) + 4 * n_out * ldn * ldm + 64 * ldm * n_out  # A, -B/2, T (f32), maps
+PLAN_HYSTERESIS = 256 << 20  # bytes the available memory may drift before a block is planned anew (a quarter of FIXED_RESERVE)
+FIXED_RESERVE = 1 << 30  # bytes a plan leaves alone whatever the block: small per-call buffers, pinned staging's device mirrors, code objects
+
+
+# The workspace is ONE buffer that the calls of a pass use one after the other: it has the size of the largest of them.  Beside the LA
+# kernel that is the overlap tables' inverse transform (chunked to 4 GiB of intermediates, csrc/psf_overlap.hip; the forward spectra are
+# asked for in chunks of SPECTRA_CHUNK PSFs, 2.4 MB of workspace each: stamps.BlockTables._ensure_spectra).
+TABLE_WS_BYTES = (4 << 30) + (16 << 20)
+
+
+def pass_bytes(nb, ldn, ldm, n_out=1, kernel="Cholesky", resident=2, nv=1, n_inframe=2, table_ws=0):
+    """Device bytes of a pass of ``nb`` stamps while an LA kernel runs: the StampBatch buffers of ``resident`` batches (coadd_block
+    prepares batch k + 1 while batch k is solved), the selection's outputs and their trimmed copies, and the library workspace of the
+    batch being solved -- for the Cholesky and Eigen kernels by the library's own count (imcom_solve_chol_workspace /
+    imcom_solve_eigen_workspace for exactly ``nb`` stamps and ``nv`` kappa nodes)."""
+    import ctypes
+
+    from ._lib import check, lib
+
+    nb = max(int(nb), 1)
+    base = 8 * (ldn * ldn + n_out * ldn * ldm) + 4 * n_out * ldn * ldm + 64 * ldm * n_out * (2 + n_inframe)  # A, -B/2, T (f32), maps and images
+    small = 3 * int(1.15 * ldn) * (20 + 4 * n_inframe) + 16 * ldn  # selection outputs (x, y, expo, indata at the nine InStamps' capacity), copies, PSF slots
+    ws = ctypes.c_size_t(0)
     if kernel == "Cholesky":
-        return resident * base + 8 * (ldn * ldn + n_out * ldn * ldm + ldn * NB)  # L, Y, inverted diagonal blocks
+        check(lib.imcom_solve_chol_workspace(nb, int(ldn), int(ldm), int(ldm), int(nv), ctypes.byref(ws)))
+        return nb * resident * (base + small) + max(ws.value, table_ws) + (2 << 20)
     extra = 12 * ldm * ldn  # -B/2 (f64) and T (f32) in the reference's [m][N] layout
-    if kernel == "Eigen":  # the resident entry works on the StampBatch layouts themselves: no copies; its workspace by the library's own count
-        import ctypes
-
-        from ._lib import check, lib
-
-        nb, ws = 32, ctypes.c_size_t(0)
+    if kernel == "Eigen":  # the resident entry works on the StampBatch layouts themselves: no copies
         check(lib.imcom_solve_eigen_workspace(nb, int(ldn), int(ldm), int(ldm), ctypes.byref(ws)))
-        return resident * base + ws.value // nb + (1 << 20)
+        return nb * resident * (base + small) + max(ws.value, table_ws) + (2 << 20)
     if kernel == "Iterative":
-        return resident * base + extra + (ldm // 16 + 1) * ITER_PATCH_BYTES  # one dense union sub-matrix per 4 x 4 patch (csrc/iter_empir.hip)
-    return resident * base + extra + 8 * ldn * ldn
+        return nb * (resident * (base + small) + extra) + max(nb * (ldm // 16 + 1) * ITER_PATCH_BYTES, table_ws)  # one dense union sub-matrix per 4 x 4 patch (csrc/iter_empir.hip)
+    return nb * (resident * (base + small) + extra) + max(nb * 8 * ldn * ldn, table_ws)
+
+
+def stamp_bytes(ldn, ldm, n_out=1, kernel="Cholesky", resident=2, nv=1, n_inframe=2, nb=256):
+    """``pass_bytes`` per stamp at a pass of ``nb`` stamps (a planner's first estimate; ``max_stamps`` is exact)."""
+    return -(-pass_bytes(nb, ldn, ldm, n_out, kernel, resident, nv, n_inframe) // nb)
+
+
+def max_stamps(avail, ldn, ldm, n_out=1, kernel="Cholesky", nv=1, n_inframe=2, cap=256, table_ws=0):
+    """The largest pass (at most ``cap`` stamps, at least one) whose ``pass_bytes`` fit ``avail`` bytes."""
+    lo, hi = 1, max(int(cap), 1)
+    if pass_bytes(hi, ldn, ldm, n_out, kernel, 2, nv, n_inframe, table_ws) <= avail:
+        return hi
+    while lo < hi:  # pass_bytes grows with nb: bisection for the last nb that fits
+        mid = (lo + hi + 1) // 2
+        if pass_bytes(mid, ldn, ldm, n_out, kernel, 2, nv, n_inframe, table_ws) <= avail:
+            lo = mid
+        else:
+            hi = mid - 1
+    return lo
+
+
+def block_maps_bytes(n1P, n2, fade, n_inframe, n_out=1, n_expo=1):
+    """Device bytes of a block's BlockMaps (block.py): the maps themselves and, with fade > 0, the four parity layers the stamps'
+    tiles are kept in (allocated when the first tiles arrive: after the plan was made)."""
+    ns = n1P * n2 + 2 * fade
+    maps = n_out * ns * ns * 4 * (n_inframe + 5) + n_out * n_expo * n1P * n1P * 4
+    layers = n_out * 4 * ns * ns * (4 * n_inframe + 4 * 3 + 8 * 2) if fade > 0 else 0  # out_map / UC, Sigma, kappa (f32); Tsum, Neff (f64)
+    return maps + layers
+
+
+def available_bytes(device, ctx=None):
+    """Device memory a pass can draw on: what the driver reports free, what torch's allocator holds without using it, and what earlier
+    passes left in the context's workspace and in the per-batch buffers (both are torch tensors that the next pass reuses or replaces)."""
+    import torch
+
+    free = free_device_bytes(device)
+    if ctx is not None and getattr(ctx, "_ws", None) is not None:
+        free += int(ctx._ws.numel())
+    elif ctx is not None and hasattr(ctx, "workspace_bytes") and not getattr(ctx, "_owns_ws", False):
+        free += int(ctx.workspace_bytes())
+    key_ = torch.device(device).index or 0
+    if key_ in _BUFS:
+        free += sum(b_.nbytes() for b_ in _BUFS[key_])
+    return free
+
+
+def tile_tables(h, w, n, n_out):
+    """Overlap tables a tile of h x w cells of 2 x 2 stamps needs resident (the cost model of plan_batches): self + input-output sets of its
+    (h + 1)(w + 1) groups, cross sets of the neighbouring pairs."""
+    S = n * (n + 1) // 2 + n_out * n
+    return (h + 1) * (w + 1) * S + ((h + 1) * w + h * (w + 1) + 2 * h * w) * n * n
+
+
+def memory_plan(cfg, pool, n1P, n_psf, n_out=1, nfft=None, ctx=None, cap=256, kernel=None, nv=None):
+    """How a block's device memory is divided BEFORE its table arenas exist: {"capacity": overlap tables, "spec_capacity": spectra rows,
+    "stamps": stamps per pass the rest holds}, to be handed to ``BlockTables(capacity=..., spec_capacity=...)``.  Stamps first: a pass is
+    as large as memory allows up to ``cap`` provided the arenas still hold two passes' worth of tables and spectra (the pass on the device
+    and the one being prepared); what is left beyond that goes to the arenas, up to the whole block (nothing is then computed twice).
+    At cfg-2 size (0.15 GB per stamp) that is passes of 256 and every table of a 48 x 48 block resident; at the reference's production
+    shape (1.2 GB per stamp: paper4) it is passes of ~160 and arenas of two passes -- where the fixed thirds of BlockTables' defaults
+    left the stamps passes of 32-40."""
+    import ctypes
+
+    import torch
+
+    from ._lib import lib
+
+    kernel = kernel or cfg.kernel
+    nv = nv or len(cfg.kappaC)
+    nfft = nfft or cfg.nfft
+    win, exact = stamp_pixels(cfg, pool, n1P)
+    nmax = int(win.max()) if exact else int(1.1 * win.max()) + 64
+    ldn = max(NB, (nmax + NB - 1) // NB * NB)
+    ldm = (cfg.m + NB - 1) // NB * NB
+    avail = int(fill_of(kernel) * available_bytes(pool.device, ctx)) - FIXED_RESERVE - block_maps_bytes(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_out, n_psf)
+    tb = 8 * (cfg.nsamp + 12) ** 2
+    sb = 8 * int(lib.imcom_psf_spectra_size(cfg.nsamp, nfft)) or 1
+    ng = (n1P + 3) // 2
+    S = n_psf * (n_psf + 1) // 2 + n_out * n_psf
+    block_tables = ng * ng * S + (2 * ng * (ng - 1) + 2 * (ng - 1) ** 2) * n_psf * n_psf
+    block_rows = n_out + ng * ng * n_psf
+    pb = lambda k: pass_bytes(k, ldn, ldm, n_out, kernel, 2, nv, cfg.n_inframe, TABLE_WS_BYTES)  # noqa: E731
+    c = min(cap, n1P * n1P)
+    while True:
+        side = max(1, int(np.ceil(np.sqrt(max(c, 4) / 4.0))))
+        need_t = min(block_tables, 2 * tile_tables(side, side, n_psf, n_out))
+        need_r = min(block_rows, n_out + 2 * (side + 1) ** 2 * n_psf)
+        if pb(c) + need_t * tb + need_r * sb <= avail or c <= 4:
+            break
+        c = max(4, c - 4)
+    per = pb(c) // c
+    rest = max(avail - pb(c), need_t * tb + need_r * sb)
+    cap_t = int(min(block_tables, max(need_t, (rest - need_r * sb) * 0.85 // tb)))
+    cap_r = int(min(block_rows, max(need_r, (rest - cap_t * tb) // sb)))
+    return {"capacity": max(cap_t, 1), "spec_capacity": max(cap_r, n_out + 4 * n_psf), "stamps": int(c), "ldn": ldn, "bytes_per_stamp": int(per),
+            "available": int(avail), "block_tables": int(block_tables)}
 
 
 ITER_PATCH_BYTES = 512 * 512 * 8 + 512 * 16 * 8 + 512 * 8  # iter_block_ws_bytes (csrc/iter_block.hip), per 4 x 4 patch
@@ -388,18 +501,24 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     if batch is None:
         # what a pass can draw on: free memory, and what earlier passes / blocks left in the library workspace and in the per-batch
         # buffers -- both are reused (counting them as taken made a second block of the same kind plan passes half the size)
-        free = free_device_bytes(pool.device)
-        ctx_ = getattr(tables, "ctx", None)
-        if ctx_ is not None and hasattr(ctx_, "workspace_bytes"):
-            free += int(ctx_.workspace_bytes())
-        key_ = getattr(pool.device, "index", None) or 0
-        if key_ in _BUFS:
-            free += sum(b_.nbytes() for b_ in _BUFS[key_])
         n_out = int(getattr(tables, "n_out", 1))
-        if grouped:  # tiles of 2 x 2-stamp cells, sized by memory and by the table arena (plan_batches)
-            cap = max(1, min(256, int(fill_of(cfg.kernel) * free) // stamp_bytes(ldn_max, ldm, n_out, cfg.kernel)))
+        nv_, nf_ = len(cfg.kappaC), cfg.n_inframe
+        free = available_bytes(pool.device, getattr(tables, "ctx", None)) - int((FIXED_RESERVE + block_maps_bytes(n1P, cfg.n2, cfg.fade, nf_, n_out, getattr(tables, "n_psf", 1)))
+                                                                                   / fill_of(cfg.kernel))
+        free = max(free, 0)
+        # A plan is kept while the memory it was made for has not moved by more than PLAN_HYSTERESIS: small buffers come and go between
+        # two plans of the same block (selection outputs, a finished block's maps, the allocator's rounding -- tens of MB), and a plan that
+        # sits on the border between k and k + 1 stamps per pass must not flip with them
+        key_ = (cfg.name, cfg.kernel, nv_, nf_, n_out, n1P, len(todo), ldn_max, ldm, grouped)
+        memo = getattr(tables, "_plan_memo", None)
+        if memo is not None and memo[0] == key_ and abs(memo[1] - free) <= PLAN_HYSTERESIS:
+            free = memo[1]
         else:
-            cap = choose_batch(len(todo), ldn_max, ldm, n_out, free, kernel=cfg.kernel)
+            tables._plan_memo = (key_, free)
+        if grouped:  # tiles of 2 x 2-stamp cells, sized by memory and by the table arena (plan_batches)
+            cap = max_stamps(int(fill_of(cfg.kernel) * free), ldn_max, ldm, n_out, cfg.kernel, nv_, nf_, cap=256, table_ws=TABLE_WS_BYTES)
+        else:
+            cap = choose_batch(len(todo), ldn_max, ldm, n_out, free, kernel=cfg.kernel, nv=nv_, n_inframe=nf_)
     else:
         cap = max(1, int(batch))
     if not grouped:
@@ -521,18 +640,27 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     while nxt is not None:
         sb = nxt
         sb.build()
-        sb.solve_begin()
-        if pipeline:
-            nxt = next_batch()
         try:
+            sb.solve_begin()
+            if pipeline:
+                nxt = next_batch()
             sb.solve_end()
-        except ImcomError as e:
-            if not out_of_memory(e) or len(sb.chunk) < 8:
+        except (ImcomError, RuntimeError) as e:
+            # the emergency route (a plan is exact about this process's memory, not about what else shares the device): the pass again as two
+            oom = out_of_memory(e) if isinstance(e, ImcomError) else "out of memory" in str(e).lower()
+            if not oom or len(sb.chunk) < 8:
                 raise
+            prepared = nxt if (pipeline and nxt is not sb) else None
             in_halves(sb)
             maps.passes_halved += 1
             maps.chunks_done.append(sb.chunk_index)
-            if not pipeline:
+            if prepared is not None:
+                # the halves' table sets may have replaced the ones the already prepared next pass was given (its slots and maps were fixed
+                # when it was prepared): prepare it again
+                q_, b_ = prepared.chunk_index, prepared.buf_index
+                nxt = prepare_batch(cfg, pool, tables, chunks[q_], n1P, n_expo, ldn, buffers=bufs[b_])
+                nxt.chunk_index, nxt.buf_index = q_, b_
+            elif not pipeline or nxt is sb:
                 nxt = next_batch()
             continue
         check_batch(sb)

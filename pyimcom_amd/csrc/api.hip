@@ -23,7 +23,13 @@ void set_error(const char *fmt, ...)
 int ws_reserve(imcom_ctx *ctx, size_t bytes)
 {
     ctx->ws_used = 0;
+    ctx->ws_limit = 0;
+    ctx->ws_need = bytes;
     if (bytes <= ctx->ws_bytes) return IMCOM_OK;
+    if (ctx->ws_external) {  // the caller owns device memory: say what is needed (imcom_ctx_workspace_needed) and let it decide
+        set_error("caller-provided workspace of %zu bytes: this call needs %zu (imcom_ctx_set_workspace)", ctx->ws_bytes, bytes);
+        return IMCOM_ERR_NOMEM;
+    }
     if (ctx->ws) {
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         IMCOM_HIP_CHECK(hipFree(ctx->ws));
@@ -43,7 +49,8 @@ int ws_reserve(imcom_ctx *ctx, size_t bytes)
 void *ws_take(imcom_ctx *ctx, size_t bytes)
 {
     const size_t off = align_up(ctx->ws_used, 256);
-    if (off + bytes > ctx->ws_bytes) return nullptr;  // callers reserve the exact total first
+    const size_t end = ctx->ws_limit ? std::min(ctx->ws_limit, ctx->ws_bytes) : ctx->ws_bytes;
+    if (off + bytes > end) return nullptr;  // callers reserve the exact total first
     ctx->ws_used = off + bytes;
     return ctx->ws + off;
 }
@@ -777,7 +784,7 @@ int imcom_ctx_destroy(imcom_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     for (auto &p : ctx->pending) { hipEventDestroy(p.start); hipEventDestroy(p.stop); }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->ws && !ctx->ws_external) hipFree(ctx->ws);
     if (ctx->pin) hipHostFree(ctx->pin);
     for (auto e : ctx->sync_events) hipEventDestroy(e);
     if (ctx->stream_event) hipEventDestroy(ctx->stream_event);
@@ -825,9 +832,45 @@ int imcom_ctx_workspace_release(imcom_ctx *ctx)
     IMCOM_TRY(check_ctx(ctx));
     IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->aux_stream) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
-    if (ctx->ws) IMCOM_HIP_CHECK(hipFree(ctx->ws));
+    if (ctx->ws && !ctx->ws_external) IMCOM_HIP_CHECK(hipFree(ctx->ws));
     ctx->ws = nullptr;
     ctx->ws_bytes = ctx->ws_used = 0;
+    return IMCOM_OK;
+}
+
+// One owner for device memory: from this call on the context works in the caller's buffer and never allocates device memory itself
+// (a call that needs more returns IMCOM_ERR_NOMEM, imcom_ctx_workspace_needed says how much).  The analogue in the reference is its
+// TEMPFILE "virtual memory" knob (psfutil.py:2056-2085): the user decides where the sub-blocks live, not luck.
+int imcom_ctx_set_workspace(imcom_ctx *ctx, void *ptr, size_t bytes)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE((ptr != nullptr) == (bytes > 0), "workspace pointer and size must come together (NULL, 0: none yet)");
+    IMCOM_REQUIRE(((uintptr_t)ptr & 255) == 0, "the workspace must be aligned to 256 bytes");
+    IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
+    for (auto s_ : ctx->sub_streams) IMCOM_HIP_CHECK(hipStreamSynchronize(s_));
+    if (ctx->ws && !ctx->ws_external) IMCOM_HIP_CHECK(hipFree(ctx->ws));
+    ctx->ws = (char *)ptr;
+    ctx->ws_bytes = bytes;
+    ctx->ws_used = 0;
+    ctx->ws_external = true;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_workspace_needed(imcom_ctx *ctx, size_t *bytes)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(bytes, "null bytes");
+    *bytes = ctx->ws_need;
+    return IMCOM_OK;
+}
+
+// Bytes of workspace imcom_solve_chol_resident (and _begin / _redo) takes: pure arithmetic, for a planner
+int imcom_solve_chol_workspace(int batch, int ldn, int m, int ldm, int nv, size_t *bytes)
+{
+    IMCOM_REQUIRE(batch >= 1 && ldn >= NB && ldn % NB == 0 && ldm >= NB && ldm % NB == 0 && m >= 1 && m <= ldm && nv >= 1 && nv <= CHOL_MAXNV && bytes,
+                  "bad sizes (ldn, ldm multiples of 128)");
+    *bytes = chol_core_bytes(batch, ldn, m, ldm, nv);
     return IMCOM_OK;
 }
 

@@ -642,6 +642,23 @@ __global__ void band_init_kernel(const double *__restrict__ A, long lda, long st
 
 bool band_basis_fits(int ld) { return ((size_t)BW * ld + 2 * BTPL * BW + 16 * 4 + BW * BW) * 8 <= 160 * 1024; }
 
+// what band_basis_device leaves behind for trd_apply_q (the rest of band_basis_ws_bytes is scratch, free again when it returns)
+size_t band_basis_keep_bytes(int batch, int ld, int mp)
+{
+    const int npanels = (ld + NB - 1) / NB;
+    size_t t = 0;
+    auto add = [&](size_t b) { t = align_up(t, 256) + b; };
+    add((size_t)batch * ld * ld * 8);                       // Vall
+    add((size_t)batch * ld * 8);                            // tau
+    add((size_t)batch * (BW + 1) * ld * 8);                 // band
+    add((size_t)batch * 4);                                 // n
+    add((size_t)batch * npanels * NB * NB * 8);             // T factors of all panels
+    add((size_t)batch * NB * NB * 8);                       // S = V V^T of one panel
+    add((size_t)batch * 2 * NB * mp * 8 * 2);               // W1, W2 (256 rows: pairs of panels)
+    add((size_t)batch * (npanels / 2) * 4 * NB * NB * 8);   // factors of the pairs
+    return align_up(t, 256);
+}
+
 size_t band_basis_ws_bytes(int batch, int ld, int mp)
 {
     const int npanels = (ld + NB - 1) / NB;

@@ -72,6 +72,9 @@ struct imcom_ctx {
     char *ws = nullptr;
     size_t ws_bytes = 0;
     size_t ws_used = 0;
+    size_t ws_limit = 0;       // != 0: ws_take hands out nothing beyond this offset (a sub-batch's share of the workspace, eigen.hip)
+    bool ws_external = false;  // imcom_ctx_set_workspace: the caller owns the workspace memory, the library never allocates device memory
+    size_t ws_need = 0;        // what the last ws_reserve asked for (imcom_ctx_workspace_needed)
     // pinned host staging for small per-stamp arrays
     char *pin = nullptr;
     size_t pin_bytes = 0;
@@ -110,7 +113,13 @@ inline int upload(imcom_ctx *ctx, T *dst, const T *src_host, size_t count)
     }
     size_t off = align_up(ctx->pin_used, 64);
     if (off + bytes > ctx->pin_bytes) {
+        // the ring wraps: every copy queued out of it must have run -- on the current stream and on the streams the context's
+        // sub-batches run on (eigen.hip: their copies out of the ring may still be pending)
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->own_stream && ctx->own_stream != ctx->stream) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->own_stream));
+        if (ctx->aux_stream) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
+        for (auto s_ : ctx->sub_streams) IMCOM_HIP_CHECK(hipStreamSynchronize(s_));
+        for (auto s_ : ctx->part_streams) IMCOM_HIP_CHECK(hipStreamSynchronize(s_));
         off = 0;
     }
     memcpy(ctx->pin + off, src_host, bytes);

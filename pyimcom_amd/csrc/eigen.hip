@@ -280,19 +280,22 @@ __global__ __launch_bounds__(64) void band_search_kernel(const double *__restric
 
 // y = (B + kappa I)^-1 c per output pixel, in place, with the maps (tri_solve_kernel's contract).  Lb [B_][np][mp]: l_{i+t,i} of
 // every pixel's factorisation between the forward and the backward pass.
+// A launch takes the output pixels a0 .. a0 + mc - 1 (a chunk of columns; Lb [B_][np][mc] then holds the factors of that chunk only:
+// the launches of a call reuse it one after the other -- four chunks: a quarter of the 4 [np][mp] arrays that used to be the largest
+// item of the Eigen path's workspace).
 template <int B_>
 __global__ __launch_bounds__(64) void band_solve_kernel(const double *__restrict__ band, double *__restrict__ Cb, double *__restrict__ Lb, int np,
                                                         int mp, int m, const int *__restrict__ n, const double *__restrict__ Cs,
                                                         const double *__restrict__ kap_stamp, const double *__restrict__ kap_pix,
-                                                        float *__restrict__ UC, float *__restrict__ Sigma, float *__restrict__ kappa)
+                                                        float *__restrict__ UC, float *__restrict__ Sigma, float *__restrict__ kappa, int a0, int mc)
 {
-    const int s = blockIdx.y, a = blockIdx.x * 64 + threadIdx.x;
+    const int s = blockIdx.y, al = blockIdx.x * 64 + threadIdx.x, a = a0 + al;
     const int ns = n[s];
-    if (a >= m) return;
+    if (al >= mc || a >= m) return;
     const long pa = (long)s * m + a;
     if (ns == 0) { UC[pa] = 1.0f; Sigma[pa] = 0.0f; kappa[pa] = 1.0f; return; }  // lakernel.py:110-119
     const double *bs = band + (long)s * (B_ + 1) * np;
-    double *c = Cb + (long)s * np * mp + a, *lb = Lb + (long)s * B_ * np * mp + a;
+    double *c = Cb + (long)s * np * mp + a, *lb = Lb + (long)s * B_ * np * mc + al;
     const double C = Cs[s], kap = kap_pix ? kap_pix[pa] : kap_stamp[s];
     BandState<B_> h;
     h.clear();
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(64) void band_solve_kernel(const double *__restrict
             band_row<B_, false, PHI>(h, bd, c[(long)i * mp], kap, D, Sd);
             c[(long)i * mp] = h.zh[PHI] / h.dh[PHI];  // w_i = z_i / d_i
 #pragma unroll
-            for (int t = 1; t <= B_; t++) lb[((long)(t - 1) * np + i) * mp] = h.lh[PHI][t];
+            for (int t = 1; t <= B_; t++) lb[((long)(t - 1) * np + i) * mc] = h.lh[PHI][t];
         });
     }
     double yh[B_];  // y_{i+1} .. y_{i+B_}
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(64) void band_solve_kernel(const double *__restrict
     for (int i = ns - 1; i >= 0; i--) {
         double y = c[(long)i * mp];
 #pragma unroll
-        for (int t = 1; t <= B_; t++) y -= lb[((long)(t - 1) * np + i) * mp] * yh[t - 1];  // l_{i+t,i} is zero beyond the matrix
+        for (int t = 1; t <= B_; t++) y -= lb[((long)(t - 1) * np + i) * mc] * yh[t - 1];  // l_{i+t,i} is zero beyond the matrix
         c[(long)i * mp] = y;
         S += y * y;
 #pragma unroll
@@ -643,6 +646,9 @@ struct EigenJob {
     int *flag_h = nullptr;  // page-locked, in ctx->flag_pin
 };
 
+// columns per launch of band_solve_kernel: a quarter of the padded output pixels, in whole wavefronts
+static int band_solve_chunk(int mp) { return std::max(64, ((mp + BAND_BW - 1) / BAND_BW + 63) / 64 * 64); }
+
 static int eigen_enqueue(imcom_ctx *ctx, EigenJob &j, int ldn, int m, int np, int mp, const double *kappaC, int nv, double ucmin, double smax, int nbis,
                          bool allow_overlap)
 {
@@ -657,8 +663,10 @@ static int eigen_enqueue(imcom_ctx *ctx, EigenJob &j, int ldn, int m, int np, in
     double *kpix = (double *)ws_take(ctx, szM * 8), *par = j.par = (double *)ws_take(ctx, (size_t)batch * 8 * 5);
     int *n_early = j.n_early = (int *)ws_take(ctx, (size_t)batch * 4), *flag = j.flag = (int *)ws_take(ctx, (size_t)batch * 4);
     j.keep = ctx->ws_used;
-    double *Lb = (double *)ws_take(ctx, banded ? big * BAND_BW : big);
-    if (!Cb || !Lb || !kpix || !par || !n_early || !flag) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    // the factors between the two sweeps of the final solve: [np][mp] in the tridiagonal basis; in the band basis BAND_BW of them per
+    // CHUNK of mp / BAND_BW columns (the same bytes), taken once the reduction has handed its scratch back -- over it, not beside it
+    double *Lb = banded ? nullptr : (double *)ws_take(ctx, big);
+    if (!Cb || (!banded && !Lb) || !kpix || !par || !n_early || !flag) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
     std::vector<double> ph(4 * (size_t)batch);
     for (int s = 0; s < batch; s++) {
         ph[s] = j.C[s];
@@ -731,9 +739,15 @@ static int eigen_enqueue(imcom_ctx *ctx, EigenJob &j, int ldn, int m, int np, in
                                    par + 2 * batch, ucmin, smax, nbis, kpix);
                 IMCOM_TRY(check_launch("band_search_kernel"));
             }
-            hipLaunchKernelGGL(band_solve_kernel<BAND_BW>, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.band, Cb, Lb, np, mp, m, n_early, par, par + batch,
-                               nv > 1 ? kpix : nullptr, j.UC_d, j.Sig_d, j.kap_d);
+            const int mc = band_solve_chunk(mp);
+            const size_t mark_l = ctx->ws_used;
+            Lb = (double *)ws_take(ctx, (size_t)batch * BAND_BW * np * mc * 8);
+            if (!Lb) { set_error("internal: workspace (band factors)"); return IMCOM_ERR_NOMEM; }
+            for (int a0 = 0; a0 < m; a0 += mc)
+                hipLaunchKernelGGL(band_solve_kernel<BAND_BW>, dim3((mc + 63) / 64, batch), dim3(64), 0, st, tb.band, Cb, Lb, np, mp, m, n_early, par, par + batch,
+                                   nv > 1 ? kpix : nullptr, j.UC_d, j.Sig_d, j.kap_d, a0, mc);
             IMCOM_TRY(check_launch("band_solve_kernel"));
+            ctx->ws_used = mark_l;  // (same stream: whatever takes this memory next runs behind the launches)
         } else {
             if (nv > 1) {
                 hipLaunchKernelGGL(tri_search_kernel, dim3((m + 63) / 64, batch), dim3(64), 0, st, tb.dvec, tb.evec, Cb, np, mp, m, n_early, par,
@@ -876,6 +890,7 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         ~Restore()
         {
             c->stream = m;
+            c->ws_limit = 0;
             for (int q = 0; q + 1 < k; q++) hipStreamSynchronize(c->sub_streams[q]);
             for (auto s_ : c->part_streams) hipStreamSynchronize(s_);
         }
@@ -889,10 +904,12 @@ static int solve_eigen_core(imcom_ctx *ctx, int batch, const int *n, int ldn, in
         ctx->ws_used = at;  // every sub-batch in a share of its own: nothing one hands back is reused by another while it runs
         at = align_up(at, 256) + solve_eigen_ws(j.batch, np, mp, m);
         j.limit = at;
+        ctx->ws_limit = j.limit;  // a sub-batch that needs more than its share fails (IMCOM_ERR_NOMEM) instead of writing into the next one's
         rc = eigen_enqueue(ctx, j, ldn, m, np, mp, kappaC, nv, ucmin, smax, nbis, false);
     }
     for (int q = 0; q < nsub && rc == IMCOM_OK; q++) {
         ctx->stream = stream_of(q);
+        ctx->ws_limit = jobs[q].limit;
         rc = eigen_finish(ctx, jobs[q], ldn, m, np, mp, kappaC, nv, ucmin, smax, nbis);
         if (rc == IMCOM_OK && ctx->stream != main) {  // join: the caller's stream goes on when the sub-batch's T has been stored
             IMCOM_HIP_CHECK(hipEventRecord(ctx->sync_events[3 + q], ctx->stream));
@@ -908,7 +925,10 @@ static size_t solve_eigen_ws(int batch, int np, int mp, int m)
 {
     const bool banded = eigen_uses_band(np);
     const size_t big = (size_t)batch * np * mp * 8;
-    const size_t basis = (banded ? band_basis_ws_bytes(batch, np, mp) : trd_basis_ws_bytes(batch, np, mp)) + (size_t)(banded ? BAND_BW : 1) * big;
+    // band basis: what the reduction keeps + the larger of its scratch and the chunk of band factors that later lies over it
+    const size_t keep_b = banded ? band_basis_keep_bytes(batch, np, mp) : 0;
+    const size_t basis = banded ? keep_b + std::max(band_basis_ws_bytes(batch, np, mp) - keep_b, (size_t)batch * BAND_BW * np * band_solve_chunk(mp) * 8 + 512)
+                                : trd_basis_ws_bytes(batch, np, mp) + big;
     // what stays (c -> y -> x, kappa per pixel, parameters) + the larger of the basis route and ONE stamp's eigendecomposition
     return big + (size_t)batch * m * 8 + (size_t)batch * 64 + std::max(basis, eigen_fallback_bytes(1, np, mp, m)) + 65536;
 }

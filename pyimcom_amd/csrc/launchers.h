@@ -63,6 +63,7 @@ int trd_pair_factors(imcom_ctx *ctx, TrdBasis *out, int batch);  // T2 from Tm (
 // band.hip: the same with A = Q B Q^T, B of bandwidth BAND_BW (a quarter of the passes over the matrix); ld up to what the panel's LDS holds
 bool band_basis_fits(int ld);
 size_t band_basis_ws_bytes(int batch, int ld, int mp);
+size_t band_basis_keep_bytes(int batch, int ld, int mp);  // the part of it that outlives band_basis_device (reflectors, factors, W1 / W2)
 // on_panel(p) (optional) is called on the host as soon as the launches that complete the 128 reflectors of panel p have been queued:
 // the caller may start applying them on another stream; the panels' T factors are then the caller's job (trd_panel_step)
 int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int mp, const double *A, long lda, long strideA, TrdBasis *out,

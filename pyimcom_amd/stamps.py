@@ -16,6 +16,7 @@ import torch
 from ._lib import PAIR_SWAP,  PAIR_FLIP, ImcomError, TableGeom, check, default_context, lib
 
 NB = 128
+SPECTRA_CHUNK = 1024  # PSFs sampled and transformed per call (BlockTables._ensure_spectra)
 
 
 def _roundup(v, a):
@@ -375,13 +376,23 @@ class BlockTables:
             if self._spec_next + sum(self._count_of[g] for g in miss) > self._spec_cap:
                 raise ValueError(f"spectra arena of {self._spec_cap} rows cannot hold the PSF groups of one batch")
         miss.sort(key=self._order.__getitem__)
-        p = self._sampled(miss)
-        r0 = self._spec_next
-        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        check(lib.imcom_psf_spectra(self.ctx.handle, _dp(p), p.shape[0], self.nsamp, self.nfft, _dp(self._spec_all[r0 : r0 + p.shape[0]])))
-        for g in miss:
-            self._spec_row[g] = self._spec_next
-            self._spec_next += self._count_of[g]
+        # in runs of at most SPECTRA_CHUNK PSFs: the sampled images are a transient of 1.2 MB per PSF and the transform takes 2.4 MB of
+        # workspace per PSF (a block's 11 k PSFs in one call would be 13 + 26 GB that no plan accounts for)
+        q0 = 0
+        while q0 < len(miss):
+            q1, cnt = q0, 0
+            while q1 < len(miss) and (q1 == q0 or cnt + self._count_of[miss[q1]] <= SPECTRA_CHUNK):
+                cnt += self._count_of[miss[q1]]
+                q1 += 1
+            part = miss[q0:q1]
+            p = self._sampled(part)
+            r0 = self._spec_next
+            self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            check(lib.imcom_psf_spectra(self.ctx.handle, _dp(p), p.shape[0], self.nsamp, self.nfft, _dp(self._spec_all[r0 : r0 + p.shape[0]])))
+            for g in part:
+                self._spec_row[g] = self._spec_next
+                self._spec_next += self._count_of[g]
+            q0 = q1
 
     def prefetch(self, groups):
         """Queue the sampling / spectra of `groups` now (as far as the spectra arena holds them; otherwise groups are

@@ -109,13 +109,13 @@ def test_gloo_world2_farm_driver(tmp_path):
 def test_choose_batch_fills_the_last_round():
     """blockrun.choose_batch: everything in one pass when it fits; else the count below the memory cap that wastes least of the
     last round of workgroups (18 column tiles per cfg-2 stamp, 512 resident workgroups)."""
-    from pyimcom_amd.blockrun import choose_batch, stamp_bytes
+    from pyimcom_amd.blockrun import choose_batch, fill_of, pass_bytes
 
     assert choose_batch(200, 2304, 2304) == 200                      # the whole block in one pass
     assert choose_batch(1024, 2304, 2304) == 256                     # 256 x 18 = 9 full rounds
     assert choose_batch(576, 2304, 2304) == 256                      # 9 + 9 + 3 rounds; 3 x 192 would be 3 x 7: a tie goes to fewer passes
-    per = stamp_bytes(2304, 2304)  # two resident batches' A, -B/2, T + the solve's workspace
-    b = choose_batch(1024, 2304, 2304, free_bytes=int(100 * per / 0.8) + 1)  # memory for 100 stamps
+    need = pass_bytes(100, 2304, 2304)  # two resident batches' A, -B/2, T + the solve's workspace, for exactly 100 stamps
+    b = choose_batch(1024, 2304, 2304, free_bytes=int(need / fill_of()) + 1)  # memory for 100 stamps
     assert b == 85 and (85 * 18) % 512 > 500                         # 1530 of 1536 slots, not 100 x 18 = 3.5 rounds
     assert choose_batch(1024, 6016, 2304, free_bytes=8 * 10**9) >= 1  # never zero
 

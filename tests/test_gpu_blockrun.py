@@ -421,3 +421,58 @@ def test_a_pass_that_runs_out_of_memory_is_run_in_halves(monkeypatch):
         assert torch.equal(got.out_map, ref.out_map) and torch.equal(got.T_weightmap, ref.T_weightmap), kernel
         for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
             assert torch.equal(got.maps[k], ref.maps[k]), (kernel, k)
+
+
+def test_plan_is_exact_and_reproducible_under_a_memory_cap():
+    """ONE owner for device memory: the library works in a torch tensor (imcom_ctx_set_workspace; _lib.Context), so
+    torch's allocator accounts for every byte and ``plan_block`` sizes passes from it alone.  With the free memory capped by a hog
+    tensor: (1) the plan made on a fresh process state and the plan made after a block has run (workspace tensor and per-batch buffers
+    now exist and count as available) are the SAME plan; (2) the passes are smaller than without the cap; (3) the block runs through
+    without a pass being halved and its peak stays inside the cap; (4) the library itself allocated nothing: torch's peak IS the
+    device's."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import available_bytes, coadd_block, pass_bytes, plan_block, release_buffers
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import NB, PSFGroupTables
+
+    cfg = synth.CONFIGS["cfg2"]
+    n1P, E = 8, cfg.n_expo
+    inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng(8))
+    pool = InStampPool(inst, cfg.n_inframe)
+    psfs, target = synth.make_psfs(cfg, E)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    ctx = tabs.ctx
+    release_buffers()
+    ctx.release_workspace()
+    torch.cuda.empty_cache()
+    free_plan = [len(c) for c in plan_block(cfg, pool, tabs, n1P)]
+    assert free_plan == [64]  # nothing in the way: the whole block in one pass
+    # cap: room for ~24 stamps
+    ldm = (cfg.m + NB - 1) // NB * NB
+    room = pass_bytes(24, 2304, ldm, 1, "Cholesky", nv=1, n_inframe=cfg.n_inframe) + (3 << 30)
+    spare = available_bytes(pool.device, ctx) - room
+    hog = torch.empty(spare, dtype=torch.uint8, device=pool.device)
+    first = [len(c) for c in plan_block(cfg, pool, tabs, n1P)]
+    assert sum(first) == 64 and 8 <= max(first) < 40, first
+    free0 = torch.cuda.mem_get_info()[0]
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    maps = coadd_block(cfg, pool, tabs, n1P, E)
+    torch.cuda.synchronize()
+    assert maps.passes_halved == 0 and maps.chunk_sizes == first
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak <= room, (peak, room)
+    # (4): what left the driver's free pool is what torch reserved -- no allocation beside torch's
+    taken = free0 - torch.cuda.mem_get_info()[0]
+    assert taken <= torch.cuda.memory_reserved() - 0 and ctx._ws is not None and ctx.workspace_bytes() == ctx._ws.numel()
+    again = [len(c) for c in plan_block(cfg, pool, tabs, n1P)]
+    assert again == first, (first, again)
+    maps2 = coadd_block(cfg, pool, tabs, n1P, E)
+    torch.cuda.synchronize()
+    assert maps2.passes_halved == 0 and torch.equal(maps2.out_map, maps.out_map)
+    del hog
+    release_buffers()
+    ctx.release_workspace()
+    torch.cuda.empty_cache()

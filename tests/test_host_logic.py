@@ -155,16 +155,22 @@ def test_plan_batches_tiles_cover_the_block_and_fit_the_arena():
 
 
 def test_choose_batch_is_kernel_aware_and_never_zero():
-    from pyimcom_amd.blockrun import choose_batch, stamp_bytes
+    from pyimcom_amd.blockrun import choose_batch, fill_of, max_stamps, pass_bytes
 
     assert choose_batch(0, 2304, 2304) == 1  # an empty block must not produce a zero step (coadd_block returns before using it)
     free = 100 << 30
     chol = choose_batch(2304, 2304, 2304, 1, free)
     assert chol == 256
     it = choose_batch(2304, 2304, 2304, 1, free, kernel="Iterative")
-    assert it < chol and it * stamp_bytes(2304, 2304, 1, "Iterative") <= 0.8 * free  # ~0.4 GB of patch matrices per stamp
+    assert it < chol and pass_bytes(it, 2304, 2304, 1, "Iterative") <= fill_of() * free  # ~0.4 GB of patch matrices per stamp
     eig = choose_batch(2304, 2944, 2304, 1, free, kernel="Eigen")
-    assert eig * stamp_bytes(2944, 2304, 1, "Eigen") <= 0.8 * free
+    assert pass_bytes(eig, 2944, 2304, 1, "Eigen") <= fill_of() * free
+    # the exact bound: the largest pass that fits, by the library's own workspace arithmetic; one more stamp does not fit
+    for kernel, ldn, avail in (("Cholesky", 6272, 120 << 30), ("Eigen", 3072, 60 << 30), ("Cholesky", 2304, 20 << 30)):
+        k = max_stamps(avail, ldn, 1536, 1, kernel, nv=1, n_inframe=6)
+        assert 1 <= k < 256 and pass_bytes(k, ldn, 1536, 1, kernel, 2, 1, 6) <= avail < pass_bytes(k + 1, ldn, 1536, 1, kernel, 2, 1, 6), (kernel, k)
+    # three kappa nodes take a Y per node: fewer stamps fit
+    assert max_stamps(60 << 30, 2304, 2304, 1, "Cholesky", nv=3) < max_stamps(60 << 30, 2304, 2304, 1, "Cholesky", nv=1)
 
 
 def test_reference_stamp_order_and_host_ahead():
