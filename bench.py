@@ -1049,9 +1049,12 @@ def main():
         from pyimcom_amd.blockrun import release_buffers
 
         def tidy():
+            import gc
+
             torch.cuda.synchronize()
             release_buffers()
             ctx.release_workspace()
+            gc.collect()  # (objects in reference cycles hold their tensors until the collector runs)
             torch.cuda.empty_cache()
 
         def leg(fn):
@@ -1072,12 +1075,11 @@ def main():
             seams = leg(lambda: seam_legs(ctx, dev, cfg, batch))
             out.update(seams if "error" not in seams else {"seams": seams})
             del batch
-            torch.cuda.empty_cache()
+            tidy()
             out["block"] = leg(lambda: block_leg(ctx, dev, reps=args.block_reps))
         if not args.no_configs and world == 1 and args.config == "cfg2":
             batch = None
-            torch.cuda.empty_cache()
-            release_buffers()
+            tidy()
             out["configs"] = leg(lambda: config_legs(ctx, dev))
             out["configs"]["cfg2"] = {"config": "BASELINE configs[1]", "value": out["value"], "unit": out["unit"], "ms_per_stamp": out["ms_per_stamp"],
                                       "roofline": {k: out["roofline"][k] for k in ("kernel", "achieved", "peak", "frac")}, "see": "the top level of this line"}

@@ -395,25 +395,30 @@ def plan_batches(todo, nst, cap, tables=None, tiles_per_stamp=18, stamp_cost=0.6
 
     cell_of = lambda t: ((t[0] + 1) >> 1, (t[1] + 1) >> 1)  # noqa: E731
 
-    def emit(chunk):
-        # cells stay together and in order (the stamps of a cell share their pair maps and their tables in cache)
-        chunk.sort(key=lambda t: (cell_of(t), t))
-        if len(chunk) > cap or (len(chunk) > 1 and tables.demand(chunk_keys(chunk, nst)) > tables.capacity):
-            cells = list(dict.fromkeys(cell_of(t) for t in chunk))
-            if len(cells) > 1:  # halve along the longer side of the tile, on a cell boundary
-                js, is_ = sorted({c[0] for c in cells}), sorted({c[1] for c in cells})
-                if len(js) >= len(is_):
-                    first = set(js[: len(js) // 2])
-                    parts = [t for t in chunk if cell_of(t)[0] in first], [t for t in chunk if cell_of(t)[0] not in first]
+    def emit(first):
+        # cells stay together and in order (the stamps of a cell share their pair maps and their tables in cache).  (A loop with its own
+        # stack, not a recursive closure: a function that refers to itself is a reference cycle, and this one holds ``tables`` -- a
+        # block's table arena, tens of GB, stayed alive until the next pass of the garbage collector.)
+        stack = [first]
+        while stack:
+            chunk = stack.pop()
+            chunk.sort(key=lambda t: (cell_of(t), t))
+            if len(chunk) > cap or (len(chunk) > 1 and tables.demand(chunk_keys(chunk, nst)) > tables.capacity):
+                cells = list(dict.fromkeys(cell_of(t) for t in chunk))
+                if len(cells) > 1:  # halve along the longer side of the tile, on a cell boundary
+                    js, is_ = sorted({c[0] for c in cells}), sorted({c[1] for c in cells})
+                    if len(js) >= len(is_):
+                        head = set(js[: len(js) // 2])
+                        parts = [t for t in chunk if cell_of(t)[0] in head], [t for t in chunk if cell_of(t)[0] not in head]
+                    else:
+                        head = set(is_[: len(is_) // 2])
+                        parts = [t for t in chunk if cell_of(t)[1] in head], [t for t in chunk if cell_of(t)[1] not in head]
                 else:
-                    first = set(is_[: len(is_) // 2])
-                    parts = [t for t in chunk if cell_of(t)[1] in first], [t for t in chunk if cell_of(t)[1] not in first]
+                    parts = chunk[: len(chunk) // 2], chunk[len(chunk) // 2 :]
+                stack.append(list(parts[1]))  # (the first half is taken off the stack first: the order of the recursive form)
+                stack.append(list(parts[0]))
             else:
-                parts = chunk[: len(chunk) // 2], chunk[len(chunk) // 2 :]
-            emit(list(parts[0]))
-            emit(list(parts[1]))
-        else:
-            out.append(chunk)
+                out.append(chunk)
 
     for a in range(nr):
         for b in (range(nc) if a % 2 == 0 else range(nc - 1, -1, -1)):
