@@ -151,8 +151,12 @@ def _side_stream(device):
     key = dev.index or 0
     if key not in _SIDE:
         # (highest priority: its few small kernels -- the host waits for their counts -- must not queue behind the thousands of workgroups
-        # of a solve that the main stream has in flight)
-        _SIDE[key] = (torch.cuda.Stream(dev, priority=int(os.environ.get("IMCOM_STREAM_PRIORITY", "-1"))), Context(key))
+        # of a solve that the main stream has in flight.  It IS the upload stream of stamps.h2d: the path keeps to two streams beside the
+        # caller's own -- the HIP runtime deals a process's streams onto four hardware queues by default, and streams that share a queue
+        # wait for each other; with one stream more than queues the Eigen path lost 30 %.)
+        from .stamps import upload_stream
+
+        _SIDE[key] = (upload_stream(dev), Context(key))
     return _SIDE[key]
 
 

@@ -697,6 +697,28 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     return IMCOM_OK;
 }
 
+// The context's second queue, created when a call first needs one (most never do: a stream that exists takes a share of the HIP
+// runtime's hardware queues whether or not it carries work).  It carries work that FILLS gaps of the main stream (copies, the Eigen
+// path's reflector products): lowest priority, so that a short kernel of the main stream's dependent chain does not queue behind its
+// long tiles.
+int ensure_aux(imcom_ctx *ctx)
+{
+    if (ctx->aux_stream) return IMCOM_OK;
+    int least = 0, greatest = 0;
+    IMCOM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // IMCOM_AUX_CUS = k: the second queue confined to k of the CUs (bit i of the mask = CU i / 8 of XCD i % 8), so that the
+    // main stream's one-workgroup-per-stamp kernels always find CUs without a product tile on them (A/B runs)
+    const char *cus = getenv("IMCOM_AUX_CUS");
+    const int k = cus ? atoi(cus) : 0;
+    if (k > 0 && k < ctx->cu_count) {
+        std::vector<uint32_t> mask((ctx->cu_count + 31) / 32, 0u);
+        for (int i = 0; i < k; i++) mask[i / 32] |= 1u << (i % 32);
+        IMCOM_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->aux_stream, (uint32_t)mask.size(), mask.data()));
+    } else
+        IMCOM_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, least));
+    return IMCOM_OK;
+}
+
 static int check_ctx(imcom_ctx *ctx)
 {
     if (!ctx) { set_error("null context"); return IMCOM_ERR_ARG; }
@@ -756,22 +778,6 @@ int imcom_ctx_create(int device, imcom_ctx **out)
     ctx->device = device;
     ctx->cu_count = prop.multiProcessorCount;
     IMCOM_HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
-    {
-        // the second queue carries work that FILLS gaps of the main stream (copies, the Eigen path's reflector products): lowest
-        // priority, so that a short kernel of the main stream's dependent chain does not queue behind its long tiles
-        int least = 0, greatest = 0;
-        IMCOM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // IMCOM_AUX_CUS = k: the second queue confined to k of the CUs (bit i of the mask = CU i / 8 of XCD i % 8), so that the
-        // main stream's one-workgroup-per-stamp kernels always find CUs without a product tile on them (A/B runs)
-        const char *cus = getenv("IMCOM_AUX_CUS");
-        const int k = cus ? atoi(cus) : 0;
-        if (k > 0 && k < ctx->cu_count) {
-            std::vector<uint32_t> mask((ctx->cu_count + 31) / 32, 0u);
-            for (int i = 0; i < k; i++) mask[i / 32] |= 1u << (i % 32);
-            IMCOM_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->aux_stream, (uint32_t)mask.size(), mask.data()));
-        } else
-            IMCOM_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, least));
-    }
     ctx->stream = ctx->own_stream;
     *out = ctx;
     return IMCOM_OK;
@@ -1165,6 +1171,7 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
             // the copy lands in workspace that kernels of an EARLIER, un-synchronised device-mode call on this context may still be
             // using: it waits for the point the main stream had reached when this call began (ev_entry) -- not for this call's own
             // factorisation, behind which it is meant to hide
+            IMCOM_TRY(ensure_aux(ctx));
             IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ev_entry, 0));
             IMCOM_HIP_CHECK(hipMemcpyAsync(B_d, mBhalf, szB * 8, hipMemcpyHostToDevice, ctx->aux_stream));
             IMCOM_HIP_CHECK(hipEventRecord(ev, ctx->aux_stream));
@@ -1175,7 +1182,7 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
     };
     const int rc_core = chol_core(ctx, batch, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info, stage_B);
     if (rc_core != IMCOM_OK) {
-        if (host) hipStreamSynchronize(ctx->aux_stream);  // nothing of this call may still be copying into the workspace
+        if (host && ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);  // nothing of this call may still be copying into the workspace
         return rc_core;
     }
     if (ldn > 0) { ProfScope ps(ctx, "pack"); IMCOM_TRY(launch_unpack_T(ctx, Tt, Np, mp, n_dev, m, T_d, ldn, batch)); }
@@ -1252,6 +1259,7 @@ int imcom_solve_chol_stamps(imcom_ctx *ctx, int nst, const int *n, int m, const 
     auto stage_B = [&]() -> int {
         hipEvent_t ev = ctx->sync_events[0];
         tB0 = now();
+        IMCOM_TRY(ensure_aux(ctx));
         IMCOM_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ev_entry, 0));
         for (int s = 0; s < nst; s++)
             if (n[s] > 0) IMCOM_HIP_CHECK(hipMemcpyAsync(rawB + offB[s], mBhalf[s], (size_t)m * n[s] * 8, hipMemcpyHostToDevice, ctx->aux_stream));
@@ -1267,7 +1275,7 @@ int imcom_solve_chol_stamps(imcom_ctx *ctx, int nst, const int *n, int m, const 
     tcore = now();
     if (timing) { hipStreamSynchronize(ctx->stream); tsync = now(); }
     if (rc_core != IMCOM_OK) {
-        hipStreamSynchronize(ctx->aux_stream);  // nothing of this call may still be copying into the workspace
+        if (ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);  // nothing of this call may still be copying into the workspace
         return rc_core;
     }
     for (int s = 0; s < nst; s++) {

@@ -139,6 +139,7 @@ struct ProfScope {
 };
 
 int profile_collect(imcom_ctx *ctx);
+int ensure_aux(imcom_ctx *ctx);  // creates ctx->aux_stream on first need (api.hip)
 
 inline int check_launch(const char *what)
 {

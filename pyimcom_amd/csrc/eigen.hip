@@ -690,11 +690,14 @@ static int eigen_enqueue(imcom_ctx *ctx, EigenJob &j, int ldn, int m, int np, in
             ctx->sync_events.push_back(e);
         }
         hipEvent_t ev_main = ctx->sync_events[0], ev_aux = ctx->sync_events[1];
+        // (the second queue only where the overlap below will use it: see `overlap`)
+        const char *ov_ = getenv("IMCOM_EIGEN_OVERLAP");
+        if (allow_overlap && nmax > 0 && (ov_ ? atoi(ov_) != 0 : batch <= 128)) IMCOM_TRY(ensure_aux(ctx));
         hipStream_t aux = ctx->aux_stream;
         struct AuxDrain {  // whatever path leaves this scope, nothing may still run on the second stream (the workspace is reused)
             hipStream_t s;
             bool armed = true;
-            ~AuxDrain() { if (armed) hipStreamSynchronize(s); }
+            ~AuxDrain() { if (armed && s) hipStreamSynchronize(s); }
         } drain{aux};
         // Worth it while the reduction's one-workgroup-per-stamp step leaves most CUs idle: the products' tiles monopolise a CU
         // (registers, LDS) and the reduction's dependent chain queues behind them.  cfg-3, with / without: batch 32 251 / 265 ms,

@@ -970,6 +970,7 @@ int tridiag_eigh_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, co
         ctx->sync_events.push_back(e);
     }
     hipEvent_t *ev_qr = ctx->sync_events.data(), *ev_ap = ev_qr + QR_RING, ev_x = ctx->sync_events[2 * QR_RING];
+    IMCOM_TRY(ensure_aux(ctx));
     hipStream_t sb = ctx->aux_stream;
     // whatever path leaves this function (an IMCOM_TRY / IMCOM_HIP_CHECK early return included), nothing may still be
     // running on the second stream: the next API call hands the same workspace out again

@@ -139,16 +139,52 @@ def _proc_start(pid):
         return None
 
 
+def _ids():
+    """What tells two processes on machines of the same name apart: the boot id of the kernel and the PID namespace (containers with host
+    networking share a hostname but not their process tables)."""
+    import os
+
+    def rd(fn, f):
+        try:
+            return fn(f).strip() if fn is not os.readlink else fn(f)
+        except OSError:
+            return None
+
+    return rd(lambda f: open(f).read(), "/proc/sys/kernel/random/boot_id"), rd(os.readlink, "/proc/self/ns/pid")
+
+
 def _owner(rank):
     import json
     import os
     import socket
 
-    return json.dumps({"rank": int(rank), "pid": os.getpid(), "start": _proc_start(os.getpid()), "host": socket.gethostname()})
+    boot, pidns = _ids()
+    return json.dumps({"rank": int(rank), "pid": os.getpid(), "start": _proc_start(os.getpid()), "host": socket.gethostname(), "boot": boot, "pidns": pidns})
 
 
-def _claim_state(path, grace=10.0):
-    """None: no such claim; True: its owner is (or may be) alive; False: the owner is gone -- the claim is stale."""
+STALE_AFTER = 1800.0  # seconds without a heartbeat after which a claim whose owner cannot be checked from here counts as abandoned (IMCOM_FARM_STALE_S)
+
+
+def _gen_path(path, g):
+    """Generation g of a claim: `path` itself, then path.t1, path.t2, ... -- a claim is never renamed or removed; taking over from a
+    dead owner is the (atomic, exclusive) creation of the NEXT generation, so two takers cannot both win and nobody's fresh claim can
+    be swept away by a taker that judged its predecessor (the rename-based takeover had a check-then-rename race)."""
+    return path if g == 0 else f"{path}.t{g}"
+
+
+def _latest_gen(path):
+    import os
+
+    if not os.path.exists(path):
+        return -1
+    g = 0
+    while os.path.exists(_gen_path(path, g + 1)):
+        g += 1
+    return g
+
+
+def _one_claim_state(path, grace=10.0):
+    """State of ONE generation file.  None: no such file; True: its owner is (or may be) alive; False: the owner is gone."""
     import json
     import os
     import socket
@@ -168,21 +204,59 @@ def _claim_state(path, grace=10.0):
             return time.time() - os.path.getmtime(path) < grace
         except OSError:
             return None
-    if rec.get("host") != socket.gethostname() or rec.get("start") is None or _proc_start(os.getpid()) is None:
-        return True  # cannot tell from here
+    boot, pidns = _ids()
+    same_table = (rec.get("host") == socket.gethostname() and rec.get("start") is not None and _proc_start(os.getpid()) is not None
+                  and rec.get("boot", boot) == boot and rec.get("pidns", pidns) == pidns)
+    if not same_table:
+        # another machine, another boot, another PID namespace: the owner's process cannot be looked up from here.  It is taken to be
+        # alive while it keeps touching its claim (owners do, at every pass: _heartbeat) and abandoned after STALE_AFTER seconds of silence
+        try:
+            return time.time() - os.path.getmtime(path) < float(os.environ.get("IMCOM_FARM_STALE_S", STALE_AFTER))
+        except OSError:
+            return None
     return _proc_start(rec["pid"]) == rec["start"]
 
 
-def _take_stale(path):
-    """Remove a stale claim; True for the one process that did it."""
+def _claim_state(path, grace=10.0):
+    """None: no such claim; True: the owner of its latest generation is (or may be) alive; False: that owner is gone -- the claim is stale."""
+    g = _latest_gen(path)
+    return None if g < 0 else _one_claim_state(_gen_path(path, g), grace)
+
+
+def _claim(path, me):
+    """Claim `path` for the owner record `me`: create it, or -- when the owner of its latest generation no longer exists -- create
+    the next generation.  Exactly one of any number of concurrent callers gets True."""
     import os
 
-    try:
-        os.rename(path, f"{path}.stale{os.getpid()}")
-    except OSError:
+    g = 0
+    while True:
+        if _try_create(_gen_path(path, g), me):
+            return True
+        if os.path.exists(_gen_path(path, g + 1)):
+            g += 1  # somebody has taken this generation over already: judge the next one
+            continue
+        if _one_claim_state(_gen_path(path, g)) is False:
+            g += 1  # a dead owner: try to be the one who creates the next generation
+            continue
         return False
-    os.remove(f"{path}.stale{os.getpid()}")
-    return True
+
+
+def _heartbeat(path):
+    """Touch the latest generation of a claim this process holds (for readers that cannot look its process up)."""
+    import os
+
+    g = _latest_gen(path)
+    if g >= 0:
+        try:
+            os.utime(_gen_path(path, g))
+        except OSError:
+            pass
+
+
+def _is_claim_file(name):
+    import re
+
+    return re.search(r"\.(claim|merge)(\.t\d+)?$", name) is not None
 
 
 def launch_token(world, token=None):
@@ -292,7 +366,7 @@ class _Prefetch:
 
 
 def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=None, restart=True, log=print, coadd=None,
-        schedule="dynamic", token=None, backend=None, prefetch=True, poll=0.05):
+        schedule="dynamic", token=None, backend=None, prefetch=True, poll=0.05, max_wait=None):
     """Coadd this rank's share of `blocks` (ids) and write block_<id>.npz files into `outdir`.
 
     costs[k]: relative cost of blocks[k] (estimate_cost summed over its stamps);
@@ -302,7 +376,10 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
     schedule "dynamic" (default): blocks are claimed on start in order of decreasing cost and the passes of the last blocks
     are shared (see above); "static": the longest-processing-time partition of `costs`, computed identically by every rank
     -- no files besides the outputs.  `coadd` (static) / `backend` (dynamic) replace the device calls (the host-logic tests run
-    the driver without a GPU that way).  Returns the list of block ids whose output file this rank wrote."""
+    the driver without a GPU that way).  ``max_wait`` (seconds, optional): a rank with nothing left to take raises when the blocks it
+    waits for -- in the hands of ranks it cannot look up -- make no progress for that long, instead of waiting for ever (a claim whose
+    owner cannot be checked counts as abandoned after IMCOM_FARM_STALE_S = 1800 s without a heartbeat and is then taken over).
+    Returns the list of block ids whose output file this rank wrote."""
     import json
     import os
     import time
@@ -359,9 +436,7 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
 
     def take(path):
         """Claim `path`: create it, or take it over from an owner that no longer exists."""
-        if _try_create(path, me):
-            return True
-        return _claim_state(path) is False and _take_stale(path) and _try_create(path, me)
+        return _claim(path, me)
 
     def claimable(path):
         return _claim_state(path) in (None, False)
@@ -369,23 +444,37 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
     def free_blocks():
         return [b for b in order if not finished(b) and claimable(cp(b, "claim"))]
 
-    def parts_of(b):
-        """The readable part files of block b: [(name, passes, arrays)] in the order of their first pass."""
+    passes_memo = {}  # part file name -> its passes (a part file is complete and immutable once its name exists: written under another name, renamed)
+
+    def part_passes(b):
+        """[(name, passes)] of the readable part files of block b, in the order of their first pass.  Only the small `passes` member of a
+        file is read, once (np.load is lazy per member): ranks that wait for the last shared block poll this 20 times a second, and a part
+        holds the block's maps in four parity layers -- hundreds of MB at production size."""
         pat = re.compile(rf"^b{int(b):04d}\.part\.\d+\.\d+\.npz$")
         out = []
         for f in sorted(os.listdir(cdir)):
             if not pat.match(f):
                 continue
-            try:
-                with np.load(os.path.join(cdir, f)) as z:
-                    out.append((f, [int(q) for q in z["passes"]], {k: z[k] for k in z.files if k != "passes"}))
-            except (OSError, ValueError, EOFError, KeyError, zipfile.BadZipFile):
-                continue  # not a complete file (yet): its passes do not count
+            if f not in passes_memo:
+                try:
+                    with np.load(os.path.join(cdir, f)) as z:
+                        passes_memo[f] = [int(q) for q in z["passes"]]
+                except (OSError, ValueError, EOFError, KeyError, zipfile.BadZipFile):
+                    continue  # not a complete file (yet): its passes do not count
+            out.append((f, passes_memo[f]))
         out.sort(key=lambda t: min(t[1]))
         return out
 
+    def parts_of(b):
+        """The same with the arrays loaded: [(name, passes, arrays)] (the merge, once the pass list is complete and the merge claim taken)."""
+        out = []
+        for f, ps in part_passes(b):
+            with np.load(os.path.join(cdir, f)) as z:
+                out.append((f, ps, {k: z[k] for k in z.files if k != "passes"}))
+        return out
+
     def covered(b):
-        return sorted(q for _, ps, _ in parts_of(b) for q in ps)
+        return sorted(q for _, ps in part_passes(b) for q in ps)
 
     def write_out(b, spec, total, ranks):
         out = be.finalize(spec, total)
@@ -407,10 +496,11 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
 
         def claim(k):
             path = cp(b, f"c{idx[k]:04d}.claim")
+            _heartbeat(cp(b, "claim"))  # (for ranks that cannot look this process up: the block's owner is at work)
             if _try_create(path, me):
                 return True
             # the pass of a rank that died before it wrote its part
-            return _claim_state(path) is False and idx[k] not in covered(b) and _take_stale(path) and _try_create(path, me)
+            return _claim_state(path) is False and idx[k] not in covered(b) and _claim(path, me)
 
         arrays, ran = be.coadd(spec, view, claim)
         ran = [idx[k] for k in ran]
@@ -426,13 +516,13 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
 
     def try_merge(b, spec, nchunks):
         nonlocal busy
-        parts = parts_of(b)
-        have = sorted(q for _, ps, _ in parts for q in ps)
+        have = covered(b)
         if len(set(have)) != len(have):
             raise RuntimeError(f"block {b}: passes {have} were coadded more than once")
         if have != list(range(nchunks)) or finished(b) or not take(cp(b, "merge")):
             return False
         t0 = time.perf_counter()
+        parts = parts_of(b)  # the arrays are read here, by the one rank that merges
         total = {k: v.copy() for k, v in parts[0][2].items()}
         for _, _, arrays in parts[1:]:  # in the order of the parts' first passes
             for k in total:
@@ -503,7 +593,7 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
     for b in order:
         if restart and os.path.exists(block_path(outdir, b)):
             log(f"[farm rank {rank}] block {b}: {block_path(outdir, b)} exists, skipped")
-    waiting = None
+    waiting, waiting_since = None, time.perf_counter()
     while True:
         did = phase1()
         did = phase2() or did
@@ -515,15 +605,17 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
         # nothing this rank could take: either other ranks are at work on the rest (stay: if one of them dies its claims go
         # stale and are taken over above), or the rest is lost
         def live(b):
-            names = [f for f in os.listdir(cdir) if f.startswith(f"b{int(b):04d}.") and f.endswith((".claim", ".merge"))]
-            return any(_claim_state(os.path.join(cdir, f)) for f in names)
+            names = [f for f in os.listdir(cdir) if f.startswith(f"b{int(b):04d}.") and _is_claim_file(f)]
+            return any(_one_claim_state(os.path.join(cdir, f)) for f in names)
 
         lost = [b for b in pending if not live(b)]
         if lost and lost == [b for b in lost if not finished(b) and not live(b)]:  # (looked twice: a merge may have ended in between)
             raise RuntimeError(f"[farm rank {rank}] blocks {lost} have no output file and nobody works on them")
         if waiting != pending:
             log(f"[farm rank {rank}] nothing left to take; blocks {pending} are in other ranks' hands")
-            waiting = pending
+            waiting, waiting_since = pending, time.perf_counter()
+        if max_wait is not None and time.perf_counter() - waiting_since > max_wait:
+            raise RuntimeError(f"[farm rank {rank}] waited {max_wait:.0f} s for blocks {pending} in other ranks' hands without any of them finishing (max_wait)")
         time.sleep(poll)
     pre.join()
     wall = time.perf_counter() - t_start
@@ -546,8 +638,8 @@ def _sweep_dead_launches(outdir, keep):
         try:
             if time.time() - os.path.getmtime(path) < 60.0:  # (a launch that has only just made its directory has no claims yet)
                 continue
-            names = [f for f in os.listdir(path) if f.endswith((".claim", ".merge"))]
-            if not any(_claim_state(os.path.join(path, f)) for f in names):
+            names = [f for f in os.listdir(path) if _is_claim_file(f)]
+            if not any(_one_claim_state(os.path.join(path, f)) for f in names):
                 shutil.rmtree(path, ignore_errors=True)
         except OSError:
             pass

@@ -48,9 +48,6 @@ def check_supported(cfg):
         raise ImcomError(IMCOM_ERR_UNSUPPORTED, f"LAKERNEL = {kernel!r}")
     if int(getattr(cfg, "n1P", 0)) % 2:  # the reference asserts n1 % 2 == 0 (config.py:503): the PSF groups are pairs of InStamp rows / columns
         raise ImcomError(IMCOM_ERR_UNSUPPORTED, f"n1P = {cfg.n1P} is odd: PSF groups are 2 x 2 InStamps (psfutil.py:1803-1824)")
-    if kernel == "Empirical" and getattr(cfg, "no_qlt_ctrl", False):
-        raise ImcomError(IMCOM_ERR_UNSUPPORTED, "Empirical kernel without quality control on the block seam "
-                         "(use the kernel-class seam, pyimcom_amd.lakernel.HipEmpirKernel)")
 
 
 def stamp_config(cfg, psfgrp, n_inimage, flat_penalty, name="block"):
@@ -59,7 +56,8 @@ def stamp_config(cfg, psfgrp, n_inimage, flat_penalty, name="block"):
     return WorkloadConfig(name, int(cfg.n2), int(cfg.fade_kernel), float(cfg.dtheta) * 3600.0, int(n_inimage),
                           float(cfg.instamp_pad) / ARCSEC, str(cfg.linear_algebra), tuple(float(k) for k in np.atleast_1d(cfg.kappaC_arr)),
                           npixpsf=int(psfgrp.npixpsf), oversamp=int(psfgrp.oversamp), uctarget=float(cfg.uctarget),
-                          sigmamax=float(cfg.sigmamax), flat_penalty=float(flat_penalty), n_inframe=int(cfg.n_inframe), n_out=targets)
+                          sigmamax=float(cfg.sigmamax), flat_penalty=float(flat_penalty), n_inframe=int(cfg.n_inframe), n_out=targets,
+                          no_qlt_ctrl=str(cfg.linear_algebra) == "Empirical" and bool(getattr(cfg, "no_qlt_ctrl", False)))  # coadd.py:856-858
 
 
 class _HostAhead:

@@ -724,6 +724,8 @@ class StampBatch:
 
     def build(self):
         """A (psfutil.py:1401-1495, 1597-1732 + coadd.py:1027-1068) and B (1497-1595 + coadd.py:1075-1082)."""
+        if self._no_qlt_ctrl():
+            return  # coadd.py:1020-1025: the Empirical kernel without quality control never builds the system matrices
         self._stream()
         h = self.ctx.handle
         check(lib.imcom_build_A(h, self.batch, _hp(self.n), self.ldn, _dp(self.x), _dp(self.y), _dp(self.psf),
@@ -734,6 +736,9 @@ class StampBatch:
                                     _dp(self.tables.tables), self.tables.tables.shape[0], C.byref(self.geom),
                                     _dp(self.io_tab_o[o]), self.npsf, _dp(self.out_x0), _dp(self.out_y0), self.n2f, self.ldm,
                                     _dp(self.Bt_o[o])))
+
+    def _no_qlt_ctrl(self):
+        return self.cfg.kernel == "Empirical" and bool(getattr(self.cfg, "no_qlt_ctrl", False))
 
     def solve(self):
         """lakernel.CholKernel (lakernel.py:281-394) + the map taper of coadd.py:1118-1122.  With IMCOM_EPILOGUE_FUSED=1 (Cholesky,
@@ -818,7 +823,8 @@ class StampBatch:
         elif cfg.kernel in ("Iterative", "Empirical"):
             # lakernel.IterKernel / EmpirKernel (lakernel.py:533-805) on device pointers; the output pixel centres
             # are the integer grid starting at (out_y0, out_x0), the acceptance radius is INPAD in output pixels
-            mB = Bt[:, :, : self.m].transpose(1, 2).contiguous()
+            nqc = self._no_qlt_ctrl()
+            mB = None if nqc else Bt[:, :, : self.m].transpose(1, 2).contiguous()
             T = torch.empty((self.batch, self.m, self.ldn), dtype=torch.float32, device=self.dev)
             g = torch.arange(self.n2f, dtype=torch.float64, device=self.dev)
             oy = (self.out_y0[:, None, None] + g[None, :, None]).expand(self.batch, self.n2f, self.n2f)
@@ -832,9 +838,10 @@ class StampBatch:
                                            int(getattr(cfg, "iter_max", 30)), int(nv > 1), _dp(T), _dp(UC), _dp(Sigma),
                                            _dp(kappa), 1))
             else:
-                check(lib.imcom_solve_empir(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, _dp(self.A), _dp(mB),
+                # (no quality control, lakernel.py:774-777: T alone, the maps stay zero, A and -B/2 are never read)
+                check(lib.imcom_solve_empir(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, None if nqc else _dp(self.A), None if nqc else _dp(mB),
                                             _hp(Cs), float(self.kappaC[0]), _dp(yx), _dp(self.y), _dp(self.x), float(cfg.rho),
-                                            0, _dp(T), _dp(UC), _dp(Sigma), _dp(kappa), 1))
+                                            1 if nqc else 0, _dp(T), _dp(UC), _dp(Sigma), _dp(kappa), 1))
             Tt.zero_()
             Tt[:, :, : self.m] = T.transpose(1, 2)
         elif cfg.kernel != "Cholesky":
@@ -854,7 +861,7 @@ class StampBatch:
         if cfg.kernel == "Iterative":  # coadd.py:1104-1107: "these could be negative as the iterative kernel is not exact"
             for t in (UC, Sigma):
                 check(lib.imcom_clamp_min_f32(self.ctx.handle, _dp(t), t.numel(), 1e-32))
-        if cfg.fade > 0:
+        if cfg.fade > 0 and not self._no_qlt_ctrl():  # (without quality control _build_system_matrices returns before the map tapers, coadd.py:1020-1025)
             for t in (kappa, Sigma, UC):
                 check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))
 

@@ -37,6 +37,7 @@ class WorkloadConfig:
     mask_frac: float = 1e-3
     psf_sigma: float = 0.9      # Gaussian input PSF width, native pixels (cfg-1: 0.9 + 0.05 e)
     n_out: int = 1              # target PSFs (OUTPSF + cfg.outpsf_extra); target k is a Gaussian of width extrasmooth * (1 + k/4)
+    no_qlt_ctrl: bool = False   # EMPIRNQC (config.py:573): the Empirical kernel without its quality maps -- no A, no B (coadd.py:1020-1025)
 
     @property
     def n2f(self):

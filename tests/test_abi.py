@@ -64,3 +64,21 @@ def test_package_import_asks_for_eight_hardware_queues():
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "8"
     env["GPU_MAX_HW_QUEUES"] = "6"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip() == "6"
+
+
+@pytest.mark.gpu
+def test_import_after_the_runtime_is_up_warns_and_changes_nothing():
+    """A plug-in does not reconfigure its host's HIP runtime behind its back: when the device has been touched before the import
+    (GPU_MAX_HW_QUEUES can no longer take effect) the package leaves the environment alone and says so once."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, warnings, torch; torch.zeros(1, device='cuda:0'); warnings.simplefilter('always');\n"
+            "with warnings.catch_warnings(record=True) as w:\n    import pyimcom_amd\n"
+            "print('GPU_MAX_HW_QUEUES' in os.environ, sum('GPU_MAX_HW_QUEUES' in str(x.message) for x in w))")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    env["PYTHONPATH"] = root
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.split() == ["False", "1"], (out.stdout, out.stderr[-500:])

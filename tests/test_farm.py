@@ -326,11 +326,37 @@ def test_launch_token_and_claim_liveness(tmp_path):
     rec = json.loads(farm._owner(0))
     rec["start"] = "1"  # this pid, but not this process: the number has been reused
     gone.write_text(json.dumps(rec))
-    assert farm._claim_state(str(gone)) is False and farm._take_stale(str(gone)) and not gone.exists()
+    assert farm._claim_state(str(gone)) is False
+    # takeover = the next GENERATION of the claim, created exclusively (nothing is renamed or removed: two takers cannot both win,
+    # and a taker cannot sweep away the fresh claim of the one who was faster)
+    me, you = farm._owner(1), farm._owner(2)
+    assert farm._claim(str(gone), me) and (tmp_path / "b.claim.t1").read_text() == me and gone.exists()
+    assert farm._claim_state(str(gone)) is True and not farm._claim(str(gone), you)  # the new owner is alive: respected
+    # two takers interleaved by hand, the way the advisor's example goes: both have judged generation 0 stale; the slower one's attempt
+    # to create generation 1 fails, it looks at generation 1, finds a live owner and gives up -- nobody's claim is lost
+    race = tmp_path / "r.claim"
+    race.write_text(json.dumps(rec))
+    assert farm._one_claim_state(str(race)) is False
+    assert farm._try_create(farm._gen_path(str(race), 1), you)           # the faster taker
+    assert not farm._claim(str(race), me)                                  # the slower one
+    assert (tmp_path / "r.claim.t1").read_text() == you and farm._latest_gen(str(race)) == 1
+    # ... and when the faster taker dies too, the next generation is free for the taking
+    dead = dict(json.loads(you), start="1")
+    (tmp_path / "r.claim.t1").write_text(json.dumps(dead))
+    assert farm._claim(str(race), me) and farm._latest_gen(str(race)) == 2
     other = tmp_path / "c.claim"
     rec["host"] = "elsewhere"
     other.write_text(json.dumps(rec))
-    assert farm._claim_state(str(other)) is True  # cannot be checked from here: respected
+    assert farm._claim_state(str(other)) is True  # cannot be checked from here: respected while its heartbeat is fresh ...
+    import os
+
+    os.utime(other, (0, 0))
+    assert farm._claim_state(str(other)) is False  # ... abandoned after IMCOM_FARM_STALE_S of silence (no rank waits for ever)
+    samehost = tmp_path / "e.claim"
+    rec2 = dict(json.loads(farm._owner(0)), pidns="pid:[1]", start="1")  # same hostname, another PID namespace: not this process table
+    samehost.write_text(json.dumps(rec2))
+    assert farm._claim_state(str(samehost)) is True
+    assert farm._is_claim_file("b0001.claim") and farm._is_claim_file("b0001.c0003.claim.t2") and farm._is_claim_file("b0001.merge") and not farm._is_claim_file("b0001.plan.json")
     assert farm._claim_state(str(tmp_path / "none.claim")) is None
     empty = tmp_path / "d.claim"
     empty.write_text("")

@@ -106,7 +106,7 @@ def test_block_seam_vs_reference_golden(golden, name):
     assert np.all(blk.UC_map[0][mask] == 0) and np.all(blk.out_map[0, 0][mask] == 0)
 
 
-def oracle_block(g, kernel, kC, flat_penalty):
+def oracle_block(g, kernel, kC, flat_penalty, no_qlt_ctrl=False):
     """The reference's stamp loop over the WHOLE block of tests/golden/stamp_chain*.npz with the oracle (coadd.py:2003-2084:
     per stamp _process_input_stamps -> system matrices from the PSFOvl of its groups -> LA kernel -> map tapers ->
     _perform_coaddition -> _output_stamp_wrapper accumulation; then the boundary recovery of 2163-2181), from the raw inputs:
@@ -138,7 +138,10 @@ def oracle_block(g, kernel, kC, flat_penalty):
             groups = [None if k < 0 else (int(k) // nst >> 1, int(k) % nst >> 1) for k in ids]
             x, y, indata, expo, cum = orc.process_input_stamps(nine, piv, rho)
             ox, oy = (i - 1) * n2 - fade + g1, (j - 1) * n2 - fade + g1
-            A, mB = orc.stamp_system_groups(nine, sels, groups, rft_in, rft_out, geo, ox, oy, group_expo)
+            if no_qlt_ctrl:  # coadd.py:1020-1025: no system matrices at all
+                A, mB = None, np.zeros((n2f * n2f, x.size))
+            else:
+                A, mB = orc.stamp_system_groups(nine, sels, groups, rft_in, rft_out, geo, ox, oy, group_expo)
             oyy, oxx = np.meshgrid(oy, ox, indexing="ij")
             if kernel == "Cholesky":
                 T, UC, Sg, kp, _ = orc.chol_kernel(A, mB, C, kC, 1e-6, 0.5)
@@ -148,11 +151,12 @@ def oracle_block(g, kernel, kC, flat_penalty):
                 T, UC, Sg, kp, _ = orc.iter_kernel(A, mB, C, kC, 1e-6, 0.5, oyy.ravel(), oxx.ravel(), y, x, rho)
                 UC, Sg = orc.iterative_clamp(UC, Sg)  # coadd.py:1104-1107
             else:
-                T, UC, Sg, kp, _ = orc.empir_kernel(A, mB, C, kC, oyy.ravel(), oxx.ravel(), y, x, rho)
+                T, UC, Sg, kp, _ = orc.empir_kernel(A, mB, C, kC, oyy.ravel(), oxx.ravel(), y, x, rho, no_qlt_ctrl=no_qlt_ctrl)
             s2 = (n2f, n2f)
             UC, Sg, kp = (np.array(v, dtype=np.float32).reshape(s2).copy() for v in (UC, Sg, kp))
-            for a in (kp, Sg, UC):  # coadd.py:1118-1122
-                orc.trapezoid(a, fade)
+            if not no_qlt_ctrl:  # (_build_system_matrices returns before the tapers in that mode)
+                for a in (kp, Sg, UC):  # coadd.py:1118-1122
+                    orc.trapezoid(a, fade)
             outimage, Tst, Tin, Neff = orc.perform_coaddition(T[None].copy(), indata, expo, n_inimage, n2f, n2, fade, cum)
             orc.block_accumulate(out_map, outimage, j, i, n2, fade)
             for name, v in (("UC", UC), ("Sigma", Sg), ("kappa", kp), ("Tsum", Tin[0]), ("Neff", Neff[0])):
@@ -168,7 +172,7 @@ def oracle_block(g, kernel, kC, flat_penalty):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["stamp_chain", "stamp_chain_mid"])
 @pytest.mark.parametrize("kernel,kC", [("Cholesky", [2e-3]), ("Cholesky", [1e-4, 1e-2, 1e-1]), ("Eigen", [2e-3]), ("Eigen", [1e-4, 1e-1]),
-                                       ("Iterative", [3e-2]), ("Empirical", [2e-3])])
+                                       ("Iterative", [3e-2]), ("Empirical", [2e-3]), ("Empirical-nqc", [2e-3])])
 def test_block_seam_whole_block_vs_oracle(golden, name, kernel, kC):
     """All n1P x n1P stamps of the reference chain's block, boundary recovery included, through ``coadd_output_stamps`` with
     each of the four LA kernels (Cholesky and Eigen with one and with several kappa nodes), against the oracle's restatement
@@ -178,9 +182,14 @@ def test_block_seam_whole_block_vs_oracle(golden, name, kernel, kC):
 
     g = golden(name)
     fp = float(g["flat_penalty"])
+    nqc = kernel.endswith("-nqc")  # EMPIRNQC: the Empirical kernel without quality control (coadd.py:856-858, 1020-1025; lakernel.py:774-777)
+    kernel = kernel.split("-")[0]
     blk, psfgrp = reference_block(g, kernel, kC)
+    blk.cfg.no_qlt_ctrl = nqc
     maps = coadd_output_stamps(blk, psfgrp, flat_penalty=fp, batch=3)
-    ref = oracle_block(g, kernel, kC, fp)
+    ref = oracle_block(g, kernel, kC, fp, nqc)
+    if nqc:
+        assert not blk.UC_map.any() and not blk.Sigma_map.any() and not blk.kappa_map.any() and np.abs(blk.out_map).max() > 0
     assert blk.out_map.shape == (1, blk.cfg.n_inframe, maps.nside, maps.nside) and blk.T_weightmap.shape == (1, blk.n_inimage, blk.cfg.n1P, blk.cfg.n1P)
     cg = kernel == "Iterative"  # CG at rtol 1.5e-3: the iterate the loop stops at carries the rounding of its dot products
     rt = 2e-3 if cg else 5e-5
