@@ -4,6 +4,8 @@ include/imcom_hip.h declares; no compute calls here (no GPU in the build contain
 import os
 import re
 
+import pytest
+
 from tests.conftest import ROOT
 
 
