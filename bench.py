@@ -765,6 +765,78 @@ def summary_of(out):
     return sm
 
 
+def farm_leg(rank, world, dev, dist, cdev, mosaic=4, n1P=32, config="cfg4", seed=4):
+    """BASELINE configs[3] on the multi-GPU clock: a mosaic of ``mosaic`` x ``mosaic`` blocks (every block its own exposure depth in 6-10,
+    its own lattices, data and PSFs) farmed over the ranks by ``pyimcom_amd.farm.run`` with the dynamic schedule -- blocks claimed on
+    start, largest first; the passes of the last blocks shared; no data-path collective, coordination through files of the output
+    directory, as the reference's own one-process-per-block runs coordinate through output files (docs/run_README.rst:81-100,
+    examples/multiblock_norep.pl:25-27, 42-66).  Inside the clock (barrier to barrier): every block's inputs (make_block: InStamps, sampled
+    PSFs, overlap tables), the plan, the passes, the merges of shared blocks, the block files.  Collectives are used for the clock and the
+    accounting only.  Every rank calls this; rank 0 gets the dict."""
+    import shutil
+    import tempfile
+
+    import numpy as np
+    import torch
+
+    from pyimcom_amd import farm
+
+    blocks, costs, make_block = farm.synthetic_mosaic(config, mosaic, n1P, seed)
+    box = [tempfile.mkdtemp(prefix="imcom_farm_") if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    outdir = box[0]
+    mk = lambda b: make_block(b, dev)  # noqa: E731
+    mk.host, mk.device = make_block.host, (lambda b, h: make_block.device(b, h, dev))
+    stats, err = {}, None
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    try:
+        farm.run(blocks, costs, mk, outdir, rank, world, device=dev, restart=False, log=lambda *_: None, stats=stats, max_wait=600.0)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001  (a rank that fails still meets the others in the collectives below, then exits non-zero)
+        import traceback
+
+        traceback.print_exc(file=sys.stderr)
+        err = f"{type(e).__name__}: {e}"[:300]
+    mine = time.perf_counter() - t0
+    vec = torch.zeros(4 * world + 2, dtype=torch.float64, device=cdev)
+    vec[rank], vec[world + rank], vec[2 * world + rank], vec[3 * world + rank] = mine, stats.get("busy_s", 0.0), stats.get("blocks_written", 0), stats.get("passes_run") or 0
+    vec[4 * world], vec[4 * world + 1] = (1.0 if err else 0.0), 1.0
+    if dist is not None:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    vec = vec.cpu().numpy()
+    failed, ranks_seen = int(round(vec[4 * world])), int(round(vec[4 * world + 1]))
+    out = None
+    if rank == 0:
+        wall = vec[:world]
+        stamps = len(blocks) * n1P * n1P
+        missing = [b for b in blocks if not os.path.exists(farm.block_path(outdir, b))]
+        ok = not failed and not missing
+        if ok:
+            z = np.load(farm.block_path(outdir, blocks[0]))
+            ok = bool(np.isfinite(z["out_map"]).all() and np.abs(z["out_map"]).max() > 0)
+        out = {"value": stamps / float(wall.max()) if ok else None, "unit": "postage-stamps/s", "makespan_s": float(wall.max()), "blocks": len(blocks),
+               "stamps": stamps, "stamps_per_block": n1P * n1P, "ranks_seen": ranks_seen, "n_gpus": world,
+               "per_rank_wall_s": [float(v) for v in wall], "per_rank_busy_s": [float(v) for v in vec[world : 2 * world]],
+               "per_rank_blocks_written": [int(round(v)) for v in vec[2 * world : 3 * world]], "per_rank_passes": [int(round(v)) for v in vec[3 * world : 4 * world]],
+               "ms_per_stamp": float(wall.max()) / stamps * 1e3 * world if ok else None,  # GPU-milliseconds per stamp
+               "schedule": "dynamic (blocks claimed largest first, tail passes shared)", "config": f"BASELINE configs[3]: {mosaic}x{mosaic} blocks of {n1P}x{n1P} "
+               f"{config} stamps, 6-10 exposures per block; make_block + plan + passes + merges + block files inside the clock",
+               "ranks_failed": failed, "blocks_missing": missing}
+        if not ok:
+            out["error"] = err or f"{failed} rank(s) failed, blocks missing: {missing}"
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        shutil.rmtree(outdir, ignore_errors=True)
+    if err:
+        raise SystemExit(f"[bench rank {rank}] farm leg failed: {err}")
+    return out
+
+
 def seam_legs(ctx, dev, cfg, batch):
     """The two seams a pyimcom user reaches the library through, timed the way they are used (never the headline):
     ``kernel_seam`` -- the drop-in LA kernel class (OutStamp.LAKERNEL, coadd.py:839-844, 1091-1093): ONE stamp per call, A and -B/2
@@ -886,6 +958,10 @@ def main():
     ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)  # one single-threaded oracle process (cpu_baseline's P-process figure)
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--ldn", type=int, default=None, help="leading dimension of A / L / -B/2 (experiments; default: N rounded up to 128)")
+    ap.add_argument("--farm", action="store_true", help="run the mosaic farm leg (BASELINE configs[3]) also at --gpus 1; at --gpus N > 1 it always runs")
+    ap.add_argument("--no-farm", action="store_true", help="skip the farm leg at --gpus N > 1")
+    ap.add_argument("--farm-mosaic", type=int, default=4, help="blocks per side of the farm leg's mosaic")
+    ap.add_argument("--farm-n1P", type=int, default=32, help="output stamps per block side in the farm leg")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal of the multi-rank path on a box with ONE GPU: every rank uses cuda:0 and the ranks "
                          "rendezvous over gloo (not a measurement)")
@@ -958,6 +1034,7 @@ def main():
     fams = {f: ctx.profile_get(f) for f in ("solve_gemm", "solve_dinv", "chol_gemm", "chol_diag", "eigen_repair", "build_A", "build_B",
                                             "finalize", "epilogue")}
     ctx.profile_enable(False)
+    n_keep, info_keep = batch.n.copy(), batch.info.copy()
     ranks_seen, per_rank = 1, [args.batch * args.steps / elapsed]
     if dist is not None:
         cdev = "cpu" if args.rehearse_shared_gpu else dev
@@ -977,14 +1054,29 @@ def main():
         if ranks_seen != world:
             raise SystemExit(f"the all-reduce saw {ranks_seen} ranks, WORLD_SIZE says {world}")
 
+    farm_out = None
+    if world > 1 and not args.no_farm:
+        # every rank: the mosaic of BASELINE configs[3] farmed over the ranks (the headline above is N copies of one batch; this is the
+        # configuration BASELINE names for N GPUs)
+        from pyimcom_amd.blockrun import release_buffers as _rb
+
+        del batch
+        batch_n, batch_info = None, None
+        torch.cuda.synchronize()
+        ctx.release_workspace()
+        torch.cuda.empty_cache()
+        cdev_ = "cpu" if (args.rehearse_shared_gpu or dist is None) else dev
+        farm_out = farm_leg(rank, world, dev, dist, cdev_, mosaic=args.farm_mosaic, n1P=args.farm_n1P)
+        _rb()
+        batch = None
     if rank == 0:
-        n_arr = batch.n.astype(np.float64)
+        n_arr = n_keep.astype(np.float64)
         # Algorithmic flops of the launches being timed.  SURVEY 8d counts 2 N^2 m per stamp for the two triangular
         # solves, and the solve_fwd / solve_bwd launches carry all of it: the updates below the 128-row diagonal
         # blocks and the diagonal blocks themselves (priced as the triangular solves they are, m rows_k^2 each,
         # although the kernel multiplies by the dense inverse).  With IMCOM_SOLVE_UNFUSED=1 the diagonal blocks are
         # separate solve_dinv launches, timed apart, and only 2 m (N^2 - sum_k rows_k^2) is attributed here.
-        rows_sq = np.array([(np.minimum(128, np.maximum(n - 128 * np.arange((n + 127) // 128), 0)) ** 2).sum() for n in batch.n], dtype=np.float64)
+        rows_sq = np.array([(np.minimum(128, np.maximum(n - 128 * np.arange((n + 127) // 128), 0)) ** 2).sum() for n in n_keep], dtype=np.float64)
         fused = fams["solve_dinv"][1] == 0
         solve_flops_step = float((2.0 * cfg.m * (n_arr**2 - (0.0 if fused else 1.0) * rows_sq)).sum())
         ms, launches = fams["solve_gemm"]
@@ -1042,10 +1134,12 @@ def main():
             "telemetry": telemetry,  # clocks / power / temperatures sampled while the timed steps ran
         }
         if cfg.kernel == "Cholesky":
-            facts = 1 + (1 if int((batch.info != 0).sum()) else 0)
+            facts = 1 + (1 if int((info_keep != 0).sum()) else 0)
             out["roofline_chol"] = roofline_chol(n_arr, facts, fams["chol_gemm"][0] / args.steps, fams["chol_diag"][0] / args.steps, fams["chol_gemm"][1] // max(args.steps, 1))
         tr_a, tr_src = pmc_kernel_traffic("build_A_kernel", args.batch, cfg.name)
         out["roofline_build_A"] = roofline_build_A(n_arr, fams["build_A"][0] / args.steps, tr_a, tr_src)
+        if farm_out is not None:
+            out["farm"] = farm_out
         from pyimcom_amd.blockrun import release_buffers
 
         def tidy():
@@ -1089,6 +1183,10 @@ def main():
             tidy()
             # the reference's own benchmark shape (not a BASELINE config: the shape its users run)
             out["configs"]["paper4"] = leg(lambda: paper4_leg(ctx, dev, cpu_budget=0.0 if args.no_cpu_baseline else min(args.cpu_budget, 25.0)))
+        if world == 1 and args.farm:  # (N = 1: the same mosaic on one GPU, for the scaling curve's first point; opt-in)
+            batch = None
+            tidy()
+            out["farm"] = leg(lambda: farm_leg(0, 1, dev, None, "cpu", mosaic=args.farm_mosaic, n1P=args.farm_n1P))
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = leg(lambda: cpu_baseline(cfg, cpu_sample, psfs, target, args.cpu_budget))
         out["summary"] = summary_of(out)  # LAST: the compact form of every leg, inside the tail a driver keeps of a long line

@@ -366,7 +366,7 @@ class _Prefetch:
 
 
 def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=None, restart=True, log=print, coadd=None,
-        schedule="dynamic", token=None, backend=None, prefetch=True, poll=0.05, max_wait=None):
+        schedule="dynamic", token=None, backend=None, prefetch=True, poll=0.05, max_wait=None, stats=None):
     """Coadd this rank's share of `blocks` (ids) and write block_<id>.npz files into `outdir`.
 
     costs[k]: relative cost of blocks[k] (estimate_cost summed over its stamps);
@@ -379,6 +379,7 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
     the driver without a GPU that way).  ``max_wait`` (seconds, optional): a rank with nothing left to take raises when the blocks it
     waits for -- in the hands of ranks it cannot look up -- make no progress for that long, instead of waiting for ever (a claim whose
     owner cannot be checked counts as abandoned after IMCOM_FARM_STALE_S = 1800 s without a heartbeat and is then taken over).
+    ``stats`` (optional dict): filled with this rank's busy_s / wall_s / blocks_written / passes_run.
     Returns the list of block ids whose output file this rank wrote."""
     import json
     import os
@@ -415,6 +416,8 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
             busy += time.perf_counter() - t0
             log(f"[farm rank {rank}] block {b}: {spec['n1P'] ** 2} stamps, {spec['n_expo']} exposures, {time.perf_counter() - t0:.2f} s -> {path}")
         log(f"[farm rank {rank}] busy {busy:.2f} s of {time.perf_counter() - t_start:.2f} s (static schedule)")
+        if stats is not None:
+            stats.update(busy_s=busy, wall_s=time.perf_counter() - t_start, blocks_written=len(done), passes_run=None)
         return done
     assert schedule == "dynamic"
     import re
@@ -429,7 +432,7 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
     order = [blocks[k] for k in sorted(range(len(blocks)), key=lambda k: (-costs[k], k))]
     cost_of = dict(zip(blocks, costs))
     pre = _Prefetch(make_block, prefetch)
-    nparts = [0]
+    nparts, passes_run = [0], [0]
 
     def finished(b):  # by this launch, or (restart) by an earlier one
         return os.path.exists(block_path(outdir, b)) and (restart or os.path.exists(cp(b, "done")))
@@ -504,6 +507,7 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
 
         arrays, ran = be.coadd(spec, view, claim)
         ran = [idx[k] for k in ran]
+        passes_run[0] += len(ran)
         wrote = False
         if len(ran) == len(chunks) and take(cp(b, "merge")):
             write_out(b, spec, arrays, [rank])
@@ -620,6 +624,8 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
     pre.join()
     wall = time.perf_counter() - t_start
     log(f"[farm rank {rank}] busy {busy:.2f} s of {wall:.2f} s ({100.0 * busy / max(wall, 1e-9):.0f} %), wrote {len(done)} block files")
+    if stats is not None:
+        stats.update(busy_s=busy, wall_s=wall, blocks_written=len(done), passes_run=passes_run[0])
     return done
 
 

@@ -150,7 +150,7 @@ def test_bench_multi_rank_rehearsal():
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8",
-           "--rehearse-shared-gpu"]
+           "--rehearse-shared-gpu", "--farm-mosaic", "2", "--farm-n1P", "4"]
     out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -159,3 +159,9 @@ def test_bench_multi_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "postage-stamps/s"
     assert d["config"]["stamps_per_step_per_gpu"] == 8 and d["value"] > 0 and "cpu_baseline" not in d and "block" not in d
     assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # whole-job aggregate over both ranks
+    # BASELINE configs[3] on the multi-rank clock: a 2 x 2 mosaic of small cfg-4 blocks farmed over the two ranks (dynamic schedule)
+    f = d["farm"]
+    assert "error" not in f and f["blocks"] == 4 and f["ranks_seen"] == 2 and f["n_gpus"] == 2 and f["stamps"] == 4 * 16
+    assert sum(f["per_rank_blocks_written"]) == 4 and f["value"] > 0 and abs(f["value"] - f["stamps"] / f["makespan_s"]) < 1e-9 * f["value"]
+    assert len(f["per_rank_busy_s"]) == 2 and all(0 < b_ <= f["makespan_s"] + 1e-6 for b_ in f["per_rank_busy_s"]) and f["blocks_missing"] == []
+    assert d["summary"]["farm"]["v"] > 0 and d["summary"]["farm"]["blocks"] == 4
