@@ -116,9 +116,28 @@ def prepare_batch(cfg, pool, tables, chunk, n1P, n_expo, ldn=None, buffers=None)
         bad_host.copy_(bad, non_blocking=True)
         bad = (bad_host, torch.cuda.current_stream(x.device).record_event())
         psf_slot = flat.clamp_(min=0).to(torch.int32)
-    sb = StampBatch.from_device(cfg, tables, n, x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep],
+    x, y, expo, indata = x[:, :keep], y[:, :keep], expo[:, :keep], indata[:, :, :keep]
+    perm = None
+    if os.environ.get("IMCOM_PIXEL_ORDER", "psf") != "segments":
+        # A stamp's pixels by PSF (group by group, exposure by exposure) instead of the reference's nine InStamp segments with the
+        # exposures inside each (coadd.py:937, 688-707): a run of one PSF is then ~N / (groups x exposures) pixels long instead of a
+        # segment's share of it, and a 16-row tile of the A builder reads ONE overlap table where it used to straddle two or three
+        # (inside a block: 152 -> 114 us per cfg-2 stamp, profiles/r04_negative_results.txt items 3, 10, 14).  A, -B/2, T and indata all
+        # live in this order; nothing the block hands out depends on it (the maps and images are sums over the pixels), and
+        # ``StampBatchResult.T`` gives T back in the reference's order.  IMCOM_PIXEL_ORDER=segments keeps the reference's order (A/B runs).
+        import torch
+
+        key = (psf_slot if grouped else expo).long()
+        valid = torch.arange(keep, device=x.device)[None, :] < h2d(n, x.device, np.int64)[:, None]
+        perm = torch.where(valid, key, torch.full_like(key, 1 << 30)).sort(dim=1, stable=True).indices
+        x, y, expo = x.gather(1, perm), y.gather(1, perm), expo.gather(1, perm)
+        indata = indata.gather(2, perm[:, None, :].expand(-1, indata.shape[1], -1))
+        if grouped:
+            psf_slot = psf_slot.gather(1, perm)
+    sb = StampBatch.from_device(cfg, tables, n, x, y, expo, indata,
                                 [(i - 1) * cfg.n2 - cfg.fade for _, i in chunk], [(j - 1) * cfg.n2 - cfg.fade for j, _ in chunk],
                                 n_expo, ctx=tables.ctx, psf_slot=psf_slot, maps=maps_, buffers=buffers)
+    sb.perm = perm  # [B, keep]: position k of a stamp holds the pixel that the reference's order has at perm[k] (None: the reference's order)
     sb.chunk = chunk  # the batch's stamps in the order of its rows (a ragged batch is reordered above)
     sb.bad_psf = bad if grouped else None
     return sb

@@ -413,6 +413,186 @@ __global__ __launch_bounds__(RTHREADS) void band_step_reg_kernel(const double *_
 }
 #undef VS_
 
+// dot blocks of the symmetric-product launches, one wave per task: (V_k . v_c, W_k . v_c) for the super-panel's earlier reflectors k
+// (coefG[s][0 / 1][k][c]), then the group's own v_c' . v_c (gramG[s][c'][c])
+__device__ __forceinline__ void symv4_dot_blocks(const double *__restrict__ Vall, const double *__restrict__ Wp, long so, int s, int ns, int ld, int r0, int ps,
+                                                 int task, int lane, double *__restrict__ coefG, double *__restrict__ gramG)
+{
+    const int kc = r0 - ps;
+    const double *v0 = Vall + so + (long)r0 * ld;
+    if (task < kc) {
+        const double *vk = Vall + so + (long)(ps + task) * ld, *wk = Wp + ((long)s * BTPL + task) * ld;
+        double dv[BW], dw[BW];
+#pragma unroll
+        for (int c = 0; c < BW; c++) dv[c] = dw[c] = 0.0;
+        for (int i = r0 + BW + lane; i < ns; i += 64) {
+            const double a = vk[i], b = wk[i];
+#pragma unroll
+            for (int c = 0; c < BW; c++) { const double x = v0[(long)c * ld + i]; dv[c] += a * x; dw[c] += b * x; }
+        }
+#pragma unroll
+        for (int c = 0; c < BW; c++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { dv[c] += __shfl_xor(dv[c], off, 64); dw[c] += __shfl_xor(dw[c], off, 64); }
+        }
+        if (lane == 0)
+#pragma unroll
+            for (int c = 0; c < BW; c++) {
+                coefG[(((long)s * 2 + 0) * BTPL + task) * BW + c] = dv[c];
+                coefG[(((long)s * 2 + 1) * BTPL + task) * BW + c] = dw[c];
+            }
+    } else if (task - kc < BW * (BW - 1) / 2) {
+        int c1 = 0, q = task - kc;
+        while (q >= BW - 1 - c1) { q -= BW - 1 - c1; c1++; }
+        const int c2 = c1 + 1 + q;
+        double d = 0.0;
+        for (int i = r0 + BW + lane; i < ns; i += 64) d += v0[(long)c1 * ld + i] * v0[(long)c2 * ld + i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+        if (lane == 0) gramG[(long)s * BW * BW + c1 * BW + c2] = d;
+    }
+}
+
+// The same pass with BOTH products on the fp64 matrix pipe (v_mfma_f64_16x16x4), which the path's one bandwidth-bound kernel left
+// idle (SQ_VALU_MFMA_BUSY 0.000 while the waves waited on memory a third of their time and on their own arithmetic -- 16 flops per
+// 8-byte element, three cross-lane steps per chunk for the transposed sums -- for the rest).  A wave takes a 64-row x 16-column slab
+// of the strip per chunk as four 16 x 16 tiles.  A tile is loaded ONCE, in the layout of the MFMA's B operand (lane = (row 4 kk + lane / 16,
+// column lane % 16): 4 rows x 128 contiguous bytes per instruction), and serves
+//   the transposed product  Zt[c][j] += sum_i V[i][c] T[i][j]  as that B operand (A = V^T at the strip's rows, padded from 4 to 16
+//                           reflectors: the pipe is idle, the padding costs nothing that was in use) -- the sum over the rows is the
+//                           instruction's own k sum: no cross-lane step, one coalesced 8-byte store per lane and chunk;
+//   the row product         Z[i][c]  += sum_j T[i][j] V[j][c]  as the A operand of a second MFMA, for which the k index has to be the
+//                           COLUMN: the tile goes through 2.3 KB of the wave's own LDS (written row-major, read transposed, stride 18:
+//                           conflict-free both ways; no barrier -- a wave's LDS instructions execute in order).
+// Per tile: 4 global loads, 4 + 4 LDS instructions, 8 MFMAs, where the VALU form issued 44 instructions; the 32 MFMAs of a chunk take
+// 2048 cycles of a SIMD's pipe per 8 KB = 9.4 TB/s chip-wide, twice the rate HBM delivers.
+typedef double sv_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int SV_TLD = 18;
+template <int ABL>  // ablation (timing runs only, results are then garbage): 1 = loads alone, 2 = + transposed product and its stores, 3 = + LDS round trip without the row MFMAs
+__global__ __launch_bounds__(256) void symv4_mfma_kernel(const double *__restrict__ At, const double *__restrict__ Vall, const double *__restrict__ Wp,
+                                                         const int *__restrict__ n, int ld, int r0, int ps, int nrowtiles, double *__restrict__ Z4,
+                                                         double *__restrict__ part4, double *__restrict__ coefG, double *__restrict__ gramG)
+{
+    static_assert(BSTRIP == 64 && BW == 4, "four 16-row tiles per slab, four reflectors");
+    __shared__ __attribute__((aligned(16))) double tl[4][16 * SV_TLD];
+    __shared__ double racc[4][BSTRIP][BW];
+    const int s = blockIdx.y, ns = n[s];
+    if (r0 + BW + 1 >= ns) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long so = (long)s * ld * ld;
+    if ((int)blockIdx.x >= nrowtiles) {
+        symv4_dot_blocks(Vall, Wp, so, s, ns, ld, r0, ps, ((int)blockIdx.x - nrowtiles) * 4 + wave, lane, coefG, gramG);
+        return;
+    }
+    const int strip = ((r0 + 1) / BSTRIP) + (nrowtiles - 1 - (int)blockIdx.x), rb = strip * BSTRIP;  // longest strips first
+    if (rb >= ns) return;
+    const int lr = lane >> 4, lc = lane & 15;
+    double *part_s = part4 + (((long)s * (ld / BSTRIP) + strip) * BW) * ld;
+    double *tile = tl[wave];
+    // one buffer descriptor per operand; a lane that has nothing to load (reflector index >= BW) points beyond the buffer and gets 0.0
+    const int nrec = (int)((long)ld * ld * 8);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(At + so), 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(Vall + so), 0, nrec, 0x00020000);
+    auto ld1 = [&](const __amdgpu_buffer_rsrc_t &r, int voff, int soff) {
+        typedef int v2i_ __attribute__((ext_vector_type(2)));
+        const v2i_ q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        return __builtin_bit_cast(double, q);
+    };
+    const int oob = 0x7ffffff0;
+    const int voff_a = (lr * ld + wave * 16 + lc) * 8;                           // tile element (row 4 kk + lr, column lc) of the wave's slab
+    const int voff_vc = lc < BW ? ((r0 + lc) * ld + wave * 16 + lr) * 8 : oob;  // B operand of the row product: V[column 4 kk + lr][reflector lc]
+    const int voff_vt = lc < BW ? ((r0 + lc) * ld + lr) * 8 : oob;              // A operand of the transposed product: V[row 4 kk + lr][reflector lc]
+    // V^T at the strip's rows (rows beyond the stamp: the reflectors are zero there)
+    double vt[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) vt[q] = ld1(rv, voff_vt, (rb + 4 * q) * 8);
+    sv_f64x4 drow[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) drow[t] = sv_f64x4{0.0, 0.0, 0.0, 0.0};
+    const int cend = rb + BSTRIP, cfirst = (r0 + 1) & ~(SCHUNK - 1), clast = cend - SCHUNK;
+    // The slab of a chunk is fetched and worked on in two HALVES of 32 rows, TWO halves ahead of the one being worked on.  Loads and
+    // stores leave a wave's vmcnt counter in order: with one chunk in flight (the first version, and the VALU form) the wait for the
+    // next chunk's loads also waited for the previous chunk's store of the transposed sums to be acknowledged -- 100 of 590 ms at batch
+    // 256, the whole gap to the loads-only ablation.  With two halves in flight the store of chunk k is younger than the loads the next
+    // two halves wait for, and long done when a wait first reaches it.  (Always the same loads in flight, past the strip's end the last
+    // chunk once more -- a fetch under a branch loses the prefetch in the machine code, see symv4_kernel --, nothing consumes a loaded
+    // value inside fetch.)
+    auto fetch = [&](auto half_c, double (&rn)[8], double (&vn)[4], int c0) {
+        constexpr int H = decltype(half_c)::value;
+        const int cc = min(c0, clast);
+        if (H == 0)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) vn[kk] = ld1(rv, voff_vc, (cc + 4 * kk) * 8);
+#pragma unroll
+        for (int q = 0; q < 8; q++) rn[q] = ld1(ra, voff_a, ((rb + 32 * H + 4 * q) * ld + cc) * 8);
+    };
+    sv_f64x4 dt = {0.0, 0.0, 0.0, 0.0};
+    auto process = [&](auto half_c, const double (&r)[8], const double (&vc)[4], int c0) {
+        constexpr int H = decltype(half_c)::value;
+        const int cw = c0 + wave * 16;
+        if (ABL == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) drow[q & 3][0] += r[q] + vc[q & 3];
+            return;
+        }
+        if (cw < rb) {  // (wave-uniform) columns left of the diagonal block receive the transposed contributions
+            if (H == 0) dt = sv_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 8; q++) dt = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[8 * H + q], r[q], dt, 0, 0, 0);
+            if (H == 1) part_s[(long)lr * ld + cw + lc] = dt[0];  // D[reflector lr + 4 reg][column lc]: register 0 holds the four reflectors
+        }
+        if (ABL == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) drow[q][0] += vc[q];
+            return;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) tile[(4 * kk + lr) * SV_TLD + lc] = r[4 * tt + kk];
+            __builtin_amdgcn_wave_barrier();
+            double rt[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) rt[kk] = tile[lc * SV_TLD + 4 * kk + lr];
+            if (ABL == 3) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) drow[2 * H + tt][kk] += rt[kk] * vc[kk];
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) drow[2 * H + tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(rt[kk], vc[kk], drow[2 * H + tt], 0, 0, 0);
+            }
+        }
+    };
+    const std::integral_constant<int, 0> h0c;
+    const std::integral_constant<int, 1> h1c;
+    double a0[8], a1[8], b0[8], b1[8], u0[4], u1[4];
+    fetch(h0c, a0, u0, cfirst);
+    fetch(h1c, a1, u0, cfirst);
+    for (int c0 = cfirst; c0 < cend; c0 += 2 * SCHUNK) {
+        fetch(h0c, b0, u1, c0 + SCHUNK);
+        process(h0c, a0, u0, c0);
+        fetch(h1c, b1, u1, c0 + SCHUNK);
+        process(h1c, a1, u0, c0);
+        if (c0 + SCHUNK >= cend) break;
+        fetch(h0c, a0, u0, c0 + 2 * SCHUNK);
+        process(h0c, b0, u1, c0 + SCHUNK);
+        fetch(h1c, a1, u0, c0 + 2 * SCHUNK);
+        process(h1c, b1, u1, c0 + SCHUNK);
+    }
+    // row sums of the four waves (each has walked its own columns): D[row lr + 4 reg][reflector lc] of tile t
+    if (lc < BW)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) racc[wave][16 * t + lr + 4 * rg][lc] = drow[t][rg];
+    __syncthreads();
+    if (threadIdx.x < BSTRIP * BW) {
+        const int i = threadIdx.x / BW, c = threadIdx.x % BW;
+        if (rb + i < ns) Z4[((long)s * BW + c) * ld + rb + i] = (racc[0][i][c] + racc[1][i][c]) + (racc[2][i][c] + racc[3][i][c]);
+    }
+}
+
 // Z[c][i] = (At v_c)[i] for the BW reflectors of columns r0 .. r0+BW-1, rows i > r0: one pass over the trailing lower triangle.
 // A workgroup takes a strip of 32 rows, walks its columns in chunks of 128 (32 per wave, a double2 per lane and row) and
 // leaves (a) the row sums over the columns up to the strip's diagonal block and (b), from the same loads, the strip's
@@ -428,41 +608,7 @@ __global__ __launch_bounds__(256) void symv4_kernel(const double *__restrict__ A
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long so = (long)s * ld * ld;
     if ((int)blockIdx.x >= nrowtiles) {
-        // dot blocks, one wave per task: (V_k . v_c, W_k . v_c) for the super-panel's earlier reflectors k (coefG[s][0 / 1][k][c]),
-        // then the group's own v_c' . v_c (gramG[s][c'][c])
-        const int task = ((int)blockIdx.x - nrowtiles) * 4 + wave, kc = r0 - ps;
-        const double *v0 = Vall + so + (long)r0 * ld;
-        if (task < kc) {
-            const double *vk = Vall + so + (long)(ps + task) * ld, *wk = Wp + ((long)s * BTPL + task) * ld;
-            double dv[BW], dw[BW];
-#pragma unroll
-            for (int c = 0; c < BW; c++) dv[c] = dw[c] = 0.0;
-            for (int i = r0 + BW + lane; i < ns; i += 64) {
-                const double a = vk[i], b = wk[i];
-#pragma unroll
-                for (int c = 0; c < BW; c++) { const double x = v0[(long)c * ld + i]; dv[c] += a * x; dw[c] += b * x; }
-            }
-#pragma unroll
-            for (int c = 0; c < BW; c++) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { dv[c] += __shfl_xor(dv[c], off, 64); dw[c] += __shfl_xor(dw[c], off, 64); }
-            }
-            if (lane == 0)
-#pragma unroll
-                for (int c = 0; c < BW; c++) {
-                    coefG[(((long)s * 2 + 0) * BTPL + task) * BW + c] = dv[c];
-                    coefG[(((long)s * 2 + 1) * BTPL + task) * BW + c] = dw[c];
-                }
-        } else if (task - kc < BW * (BW - 1) / 2) {
-            int c1 = 0, q = task - kc;
-            while (q >= BW - 1 - c1) { q -= BW - 1 - c1; c1++; }
-            const int c2 = c1 + 1 + q;
-            double d = 0.0;
-            for (int i = r0 + BW + lane; i < ns; i += 64) d += v0[(long)c1 * ld + i] * v0[(long)c2 * ld + i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-            if (lane == 0) gramG[(long)s * BW * BW + c1 * BW + c2] = d;
-        }
+        symv4_dot_blocks(Vall, Wp, so, s, ns, ld, r0, ps, ((int)blockIdx.x - nrowtiles) * 4 + wave, lane, coefG, gramG);
         return;
     }
     // longest strips (bottom of the matrix) first: they bound the launch's critical path
@@ -769,8 +915,17 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
             if (r0 + BW + 1 < nmax) {
                 const int nrowtiles = (nmax - 1) / BSTRIP - (r0 + 1) / BSTRIP + 1, ndot = (r0 - ps + BW * (BW - 1) / 2 + 3) / 4;
                 ProfScope pf(ctx, "symv4", 1, true);  // (profile level 2: HIP events around this launch alone, for the HBM roofline of the pass)
-                hipLaunchKernelGGL(symv4_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, out->Vall, Wp, out->n_dev, ld, r0, ps, nrowtiles, Z4,
-                                   part4, coefG, gramG);
+                static const bool use_mfma = !(getenv("IMCOM_SYMV4") && strcmp(getenv("IMCOM_SYMV4"), "valu") == 0);  // (A/B runs: the VALU form)
+                static const int abl = getenv("IMCOM_SYMV4_ABL") ? atoi(getenv("IMCOM_SYMV4_ABL")) : 0;  // (timing runs: parts of the kernel taken out)
+#define IMCOM_SYMV4_LAUNCH(A_) hipLaunchKernelGGL(symv4_mfma_kernel<A_>, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, out->Vall, Wp, out->n_dev, ld, r0, ps, nrowtiles, Z4, part4, coefG, gramG)
+                if (use_mfma && abl == 1) IMCOM_SYMV4_LAUNCH(1);
+                else if (use_mfma && abl == 2) IMCOM_SYMV4_LAUNCH(2);
+                else if (use_mfma && abl == 3) IMCOM_SYMV4_LAUNCH(3);
+                else if (use_mfma) IMCOM_SYMV4_LAUNCH(0);
+#undef IMCOM_SYMV4_LAUNCH
+                else
+                    hipLaunchKernelGGL(symv4_kernel, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, out->Vall, Wp, out->n_dev, ld, r0, ps, nrowtiles, Z4,
+                                       part4, coefG, gramG);
             }
             IMCOM_TRY(check_launch("band step"));
             // the reflectors of columns < r0 + BW are final (phase P of this group has been queued): a whole panel of 128?

@@ -615,11 +615,30 @@ class StampBatchResult:
     Neff: torch.Tensor
     info: np.ndarray
     n: np.ndarray
+    perm: torch.Tensor = None  # [batch, ldn] or None: the batch's pixel order (blockrun.prepare_batch orders a stamp's pixels by PSF)
 
-    def T(self, s):
-        """T of stamp s in the reference layout [m, N] (lakernel.py:96)."""
+    def T(self, s, order="reference"):
+        """T of stamp s in the reference layout [m, N] (lakernel.py:96), input pixels in the reference's order (coadd.py:937);
+        ``order="batch"``: in the order the batch holds them (the order of its x, y, A, -B/2)."""
         m = self.UC.shape[-1] * self.UC.shape[-2]
-        return self.Tt[s, : int(self.n[s]), :m].T.contiguous()
+        n = int(self.n[s])
+        Tm = self.Tt[s, :n, :m].T.contiguous()
+        if self.perm is None or order == "batch":
+            return Tm
+        out = torch.empty_like(Tm)
+        out[:, self.perm[s, :n]] = Tm
+        return out
+
+    def to_reference_order(self, s, a, axes=(0,)):
+        """An array of stamp s whose `axes` run over the batch's input pixels (rows / columns of A, rows of -B/2 ...), in the reference's order."""
+        n = int(self.n[s])
+        if self.perm is None:
+            return a
+        inv = torch.empty(n, dtype=torch.long, device=self.perm.device)
+        inv[self.perm[s, :n]] = torch.arange(n, device=self.perm.device)
+        for ax in axes:
+            a = a.index_select(ax, inv)
+        return a
 
 
 class StampBatch:
@@ -901,7 +920,7 @@ class StampBatch:
         s2 = (self.batch, self.n2f, self.n2f)
         return StampBatchResult(self.Tt_o[o], self.UC_o[o].view(s2), self.Sigma_o[o].view(s2), self.kappa_o[o].view(s2),
                                 self.outimage_o[o].view(self.batch, self.cfg.n_inframe, self.n2f, self.n2f), self.Tsum_stamp_o[o],
-                                self.Tsum_inpix_o[o].view(s2), self.Neff_o[o].view(s2), self.info_o[o].copy(), self.n.copy())
+                                self.Tsum_inpix_o[o].view(s2), self.Neff_o[o].view(s2), self.info_o[o].copy(), self.n.copy(), getattr(self, "perm", None))
 
     def results(self):
         return [self.result(o) for o in range(self.n_out)]

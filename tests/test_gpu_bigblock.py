@@ -136,7 +136,7 @@ def test_block_of_reference_size(name, n1P, E):
         cond = (lam[-1] + kap) / (max(lam[0], 0.0) + kap)
         f2, s2 = 2 * cfg.fade, (cfg.n2f, cfg.n2f)
         inner = (slice(f2, cfg.n2f - f2),) * 2  # the tapers of coadd.py:1118-1122, 1320-1327 leave these output pixels untouched
-        T = res.T(q).cpu().numpy().reshape(cfg.n2f, cfg.n2f, n)[inner]
+        T = res.T(q, order="batch").cpu().numpy().reshape(cfg.n2f, cfg.n2f, n)[inner]  # (A, -B/2 above are in the batch's pixel order)
         assert np.abs(T - To.reshape(cfg.n2f, cfg.n2f, n)[inner]).max() <= (1e-6 + 50 * cond * 2.2e-16) * np.abs(To).max(), (j, i)
         assert np.allclose(res.kappa[q].cpu().numpy()[inner], ko.reshape(s2)[inner], rtol=1e-5, atol=0)
         assert np.allclose(res.UC[q].cpu().numpy()[inner], Uo.reshape(s2)[inner], rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)

@@ -209,7 +209,10 @@ def test_full_chain_vs_reference_golden(golden, name):
     torch.cuda.synchronize()
     N, m = g["A"].shape[0], cfg.m
     assert int(sb.n[0]) == N
-    A, Bt = sb.A[0, :N, :N].cpu().numpy(), sb.Bt[0, :N, :m].cpu().numpy()
+    # (the batch orders a stamp's pixels by PSF, blockrun.prepare_batch: back to the reference's order of coadd.py:937 for the comparison)
+    assert sb.perm is not None and sorted(sb.perm[0, :N].tolist()) == list(range(N))
+    A = res.to_reference_order(0, sb.A[0, :N, :N], axes=(0, 1)).cpu().numpy()
+    Bt = res.to_reference_order(0, sb.Bt[0, :N, :m], axes=(0,)).cpu().numpy()
     assert np.abs(A - g["A"]).max() <= 1e-11 * np.abs(g["A"]).max()
     assert np.abs(Bt.T - g["mBhalf"][0]).max() <= 1e-11 * np.abs(g["mBhalf"]).max()
     lam = np.linalg.eigvalsh(g["A"])
@@ -476,3 +479,51 @@ def test_plan_is_exact_and_reproducible_under_a_memory_cap():
     release_buffers()
     ctx.release_workspace()
     torch.cuda.empty_cache()
+
+
+def test_pixels_ordered_by_psf_give_the_same_block(monkeypatch):
+    """prepare_batch orders a stamp's input pixels by PSF (PSF group, then exposure) instead of the reference's nine InStamp segments
+    (coadd.py:937), so that a tile of the A builder stays on one overlap table.  Everything a block hands out is a sum over the input
+    pixels: the maps of the two orders agree to the rounding of those sums (NOT bit for bit: the order of A's rows is the order of the
+    factorisation's operations), T comes back in the reference's order, and the permutation is one (a stable sort by PSF index)."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import coadd_block, prepare_batch
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import BlockTables
+
+    cfg = synth.CONFIGS["small"]
+    n1P, E = 4, 4
+    inst = synth.make_instamps(cfg, n1P, E, np.random.default_rng(5))
+    pool = InStampPool(inst, cfg.n_inframe)
+    psfs, target = synth.make_psfs(cfg, E)
+    ng = (n1P + 3) // 2
+    tabs = BlockTables({(gj, gi): synth.group_psfs(psfs, gj, gi) for gj in range(ng) for gi in range(ng)}, target, cfg.nfft, capacity=2000)
+    chunk = [(2, 2), (2, 3), (3, 2)]
+    sb = prepare_batch(cfg, pool, tabs, chunk, n1P, E)
+    assert sb.perm is not None
+    for q in range(len(chunk)):
+        n = int(sb.n[q])
+        slot = sb.psf[q, :n].cpu().numpy()
+        assert np.all(np.diff(slot) >= 0) and len(set(slot.tolist())) > E  # runs of one PSF, several groups
+        p = sb.perm[q, :n].cpu().numpy()
+        assert sorted(p.tolist()) == list(range(n))
+        for s_ in set(slot.tolist()):
+            assert np.all(np.diff(p[slot == s_]) > 0)  # stable: inside a PSF the reference's order
+    sb.run()
+    a = coadd_block(cfg, pool, tabs, n1P, E, batch=5)
+    Ta = sb.result().T(1).clone()
+    monkeypatch.setenv("IMCOM_PIXEL_ORDER", "segments")
+    sb2 = prepare_batch(cfg, pool, tabs, chunk, n1P, E)
+    assert sb2.perm is None
+    sb2.run()
+    b = coadd_block(cfg, pool, tabs, n1P, E, batch=5)
+    torch.cuda.synchronize()
+    Tb = sb2.result().T(1)
+    assert float((Ta - Tb).abs().max()) <= 2e-6 * float(Tb.abs().max())  # the same T, pixel for pixel, in the reference's order
+    assert float((a.out_map - b.out_map).abs().max()) <= 1e-5 * float(b.out_map.abs().max())
+    for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+        x, y = a.maps[k], b.maps[k]
+        assert torch.allclose(x, y, rtol=2e-5, atol=1e-7 * float(y.abs().max())), k
+    assert torch.allclose(a.T_weightmap, b.T_weightmap, rtol=1e-5, atol=1e-8)

@@ -87,7 +87,7 @@ def test_eigen_kernel_block_at_full_stamp_size():
         lam = np.linalg.eigvalsh(A)
         kap = cfg.kappaC[0] * float(tabs.C)
         cond = (lam[-1] + kap) / (max(lam[0], 0.0) + kap)
-        Tg = res.T(0).cpu().numpy()
+        Tg = res.T(0, order="batch").cpu().numpy()  # (A and -B/2 were taken in the batch's pixel order)
         assert np.abs(Tg[same] - T[same]).max() <= (1e-6 + 50 * cond * 2.2e-16) * np.abs(T).max(), (j, i)
         assert np.allclose(res.UC[0].cpu().numpy().ravel()[same], UC[same], rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)
         assert np.allclose(res.Sigma[0].cpu().numpy().ravel()[same], Sigma[same], rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)
@@ -153,7 +153,7 @@ def test_iterative_kernel_block_one_pass_of_256_stamps():
         T, UC, Sigma, kappa, _ = orc.iter_kernel(A, mB, float(tabs.C), cfg.kappaC, cfg.uctarget, cfg.sigmamax, oy, ox, sb.y[q, :n].cpu().numpy(),
                                                  sb.x[q, :n].cpu().numpy(), float(cfg.rho))
         UC, Sigma = orc.iterative_clamp(UC, Sigma)
-        Tg = res.T(q).cpu().numpy()
+        Tg = res.T(q, order="batch").cpu().numpy()
         assert np.array_equal(Tg == 0, T == 0), (j, i)  # the same acceptance discs
         assert np.abs(Tg - T).max() <= TOL_ITER["T"] * np.abs(T).max(), (j, i)
         assert np.allclose(res.Sigma[q].cpu().numpy().ravel(), Sigma, rtol=TOL_ITER["map_rtol"], atol=TOL_ITER["map_atol"])
