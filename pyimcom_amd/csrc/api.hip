@@ -325,7 +325,9 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         bool any = false, coarse = false;
         for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; coarse |= !fine[s]; }
         if (!any) break;
-        const int iters = coarse ? 3 : 2;
+        // (a Rayleigh-Ritz step costs two steps' time -- A X on the tile engine and a batch of 128 x 128 eigenvalue problems: the first one
+        // comes after six steps, when it has something to say)
+        const int iters = round == 0 ? 6 : 3;
         for (int it = 0; it < iters; it++) {
             IMCOM_TRY(solve(run, X, Y, part, splitk_parts(batch, 1)));
             IMCOM_TRY(orth());
