@@ -646,8 +646,14 @@ struct EigenJob {
     int *flag_h = nullptr;  // page-locked, in ctx->flag_pin
 };
 
-// columns per launch of band_solve_kernel: a quarter of the padded output pixels, in whole wavefronts
-static int band_solve_chunk(int mp) { return std::max(64, ((mp + BAND_BW - 1) / BAND_BW + 63) / 64 * 64); }
+// columns per launch of band_solve_kernel: a quarter of the padded output pixels, in whole wavefronts -- for the batches whose
+// workspace matters; a small batch takes all columns at once (four launches of a few hundred one-wave workgroups each are latency,
+// 6 -> 13 ms per 32 cfg-3 stamps, and 64 stamps' factors are 14 GB)
+static int band_solve_chunk(int mp, int batch)
+{
+    const int parts = batch <= 64 ? 1 : BAND_BW;
+    return std::max(64, ((mp + parts - 1) / parts + 63) / 64 * 64);
+}
 
 static int eigen_enqueue(imcom_ctx *ctx, EigenJob &j, int ldn, int m, int np, int mp, const double *kappaC, int nv, double ucmin, double smax, int nbis,
                          bool allow_overlap)
@@ -742,7 +748,7 @@ static int eigen_enqueue(imcom_ctx *ctx, EigenJob &j, int ldn, int m, int np, in
                                    par + 2 * batch, ucmin, smax, nbis, kpix);
                 IMCOM_TRY(check_launch("band_search_kernel"));
             }
-            const int mc = band_solve_chunk(mp);
+            const int mc = band_solve_chunk(mp, batch);
             const size_t mark_l = ctx->ws_used;
             Lb = (double *)ws_take(ctx, (size_t)batch * BAND_BW * np * mc * 8);
             if (!Lb) { set_error("internal: workspace (band factors)"); return IMCOM_ERR_NOMEM; }
@@ -930,7 +936,7 @@ static size_t solve_eigen_ws(int batch, int np, int mp, int m)
     const size_t big = (size_t)batch * np * mp * 8;
     // band basis: what the reduction keeps + the larger of its scratch and the chunk of band factors that later lies over it
     const size_t keep_b = banded ? band_basis_keep_bytes(batch, np, mp) : 0;
-    const size_t basis = banded ? keep_b + std::max(band_basis_ws_bytes(batch, np, mp) - keep_b, (size_t)batch * BAND_BW * np * band_solve_chunk(mp) * 8 + 512)
+    const size_t basis = banded ? keep_b + std::max(band_basis_ws_bytes(batch, np, mp) - keep_b, (size_t)batch * BAND_BW * np * band_solve_chunk(mp, batch) * 8 + 512)
                                 : trd_basis_ws_bytes(batch, np, mp) + big;
     // what stays (c -> y -> x, kappa per pixel, parameters) + the larger of the basis route and ONE stamp's eigendecomposition
     return big + (size_t)batch * m * 8 + (size_t)batch * 64 + std::max(basis, eigen_fallback_bytes(1, np, mp, m)) + 65536;
