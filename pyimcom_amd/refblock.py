@@ -240,8 +240,15 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     target = target_psfs(cfg, psfgrp, device, ctx)
     amp = getattr(cfg, "amp_penalty", None)
     amp = None if amp is None or 0.0 in tuple(amp) else (float(amp[0]), float(amp[1]) * float(psfgrp.oversamp))  # psfutil.py:661-671
+    # the device's memory divided before the arenas exist: stamps first, the table and spectra arenas get the rest (blockrun.memory_plan)
+    spec_cap = None
+    if table_capacity is None and count:
+        from .blockrun import memory_plan
+
+        mp_ = memory_plan(scfg, pool, int(cfg.n1P), max(count.values()), n_out=int(target.shape[0]), nfft=int(psfgrp.nfft), ctx=ctx)
+        table_capacity, spec_cap = mp_["capacity"], mp_["spec_capacity"]
     tables = BlockTables({k: None for k in count}, target, int(psfgrp.nfft), group_expo=expo, group_count=count, bulk_provider=provider,
-                         capacity=None if table_capacity is None else int(table_capacity), amp_penalty=amp, device=device, ctx=ctx,
+                         capacity=None if table_capacity is None else int(table_capacity), spec_capacity=spec_cap, amp_penalty=amp, device=device, ctx=ctx,
                          cells=True,  # groups of 2 x 2 InStamps: cells of the block's grid (coadd.py:207, 329-358)
                          provider_waits=True)  # the provider hands over what the worker threads have prepared
     n1P = int(cfg.n1P)
