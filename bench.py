@@ -604,7 +604,10 @@ def paper4_leg(ctx, dev, batch=128, steps=2, cpu_budget=25.0, block_passes=2):
     ach = fs_flops / (fs_ms * 1e-3) / 1e12
     # the kernels themselves: the two factorisations of a step (the failed one and the repaired one) and the one solve, without the
     # eigenvalue iteration -- the rate the same launches have when no repair is needed
-    facts = 2 if repaired else 1
+    # factorisations the Cholesky stages timed per step (two launch groups -- update, panel solve -- per block column each): ONE since the
+    # steps after the first skip the factorisation that is known to fail (StampBatch.solve_begin(expect_repair=True))
+    nbk = (int(n.max()) + 127) // 128
+    facts = max(1, int(round(fams["chol_gemm"][1] / steps / (2.0 * nbk))))
     k_ms = (fams["solve_gemm"][0] + (fams["chol_gemm"][0] + fams["chol_diag"][0]) / facts) / steps
     ach_k = fs_flops / (k_ms * 1e-3) / 1e12
     job = fs_flops + float((165.0 * n * (n + 1) + 220.0 * n * m).sum())

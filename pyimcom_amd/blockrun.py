@@ -665,11 +665,13 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
 
     nxt = next_batch()
     maps.passes_halved = 0
+    share = 0.0  # of the previous pass's stamps that took the Cholesky repair: at the reference's production shape it is every stamp, and a
+                 # pass that follows such a pass does not attempt the factorisation that fails (StampBatch.solve_begin)
     while nxt is not None:
         sb = nxt
         sb.build()
         try:
-            sb.solve_begin()
+            sb.solve_begin(expect_repair=share >= StampBatch.EXPECT_REPAIR)
             if pipeline:
                 nxt = next_batch()
             sb.solve_end()
@@ -691,6 +693,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
             elif not pipeline or nxt is sb:
                 nxt = next_batch()
             continue
+        share = float(getattr(sb, "repair_share", 0.0))
         check_batch(sb)
         sb.coadd()
         if not pipeline:

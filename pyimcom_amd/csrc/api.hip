@@ -482,6 +482,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     std::vector<double> inc_h((size_t)batch * MAX_INC_HOST, 0.0), kap_h(batch), rep(batch, 0.0);
     std::vector<char> repaired((size_t)nv * batch, 0), have_w0(batch, 0);
     std::vector<char> active(batch, 1), known(batch, 0);  // the stamps of the coming attempt; stamps whose first factorisation is known to fail
+    std::vector<char> expected_only(batch, 0);            // ... of which the eigenvalue says that they do not fail after all
     int nbmax = 0;
     for (int s = 0; s < batch; s++) {
         IMCOM_REQUIRE(n_host[s] >= 0 && n_host[s] <= Np, "n[%d]=%d outside [0,%d]", s, n_host[s], Np);
@@ -549,7 +550,9 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             IMCOM_TRY(upload(ctx, nblk_fac, nb_i.data(), (size_t)batch));
             nb_fac = nblk_fac; nb_sol = nblk_sol; act_fin = act_dev;
         }
-        for (int p0 = 0; p0 < nv; p0 += pb) {
+        bool any_fac = false;
+        for (int s = 0; s < batch; s++) any_fac |= fac[s] != 0;
+        for (int p0 = 0; any_fac && p0 < nv; p0 += pb) {
             for (int q = 0; q < pb; q++) {
                 const int p = p0 + q;
                 // the diagonal of AA at node p as the reference builds it: a sequence of in-place adds
@@ -594,7 +597,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                 if (unfused) { ProfScope ps(ctx, "solve_dinv"); IMCOM_TRY(launch_solve_dinv(ctx, Dinv, Yp, Np, mp, k, eb, nb_sol, true)); }
             }
         }
-        {
+        if (any_fac) {
             ProfScope ps(ctx, "finalize");
             if (nv == 1 && colsums)
                 IMCOM_TRY(launch_finalize_fused(ctx, Dpart, Npart, Np, mp, m, n_dev, nblk_dev, kap_dev, C_dev, Tt, UC, Sigma, kappa, batch, act_fin));
@@ -672,16 +675,23 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             for (int s : need) {
                 rep[s] = fabs(w0v[s]) + 1e-16;
                 have_w0[s] = 1;
+                // A stamp whose failure was the CALLER's expectation (redo = 2 without a factorisation having failed here): the smallest
+                // eigenvalue says whether A + kappa I is positive definite after all.  If it clearly is (w0 + kappa above 1e-6 kappa: the
+                // eigenvalue is good to 1e-11) the reference's cholesky() succeeds and nothing is repaired: the stamp is factored plainly in
+                // the next attempt -- and repaired then, should that factorisation fail in spite of the eigenvalue.
+                const double kap_s = kappaC_host[0] * C_host[s];
+                if (masked && attempt == 0 && known[s] && w0v[s] + kap_s > 1e-6 * fabs(kap_s)) expected_only[s] = 1;
             }
         }
         std::vector<char> next(batch, 0);
         for (int p = 0; p < nv; p++)
             for (int s = 0; s < batch; s++) {
                 if (fail[(size_t)p * batch + s] == 0) continue;
-                repaired[(size_t)p * batch + s] = 1;
-                if (info_host[s] == 0) info_host[s] = p + 1;
                 next[s] = 1;
                 any = true;
+                if (masked && attempt == 0 && expected_only[s]) continue;  // (solved in the next attempt, without the repair)
+                repaired[(size_t)p * batch + s] = 1;
+                if (info_host[s] == 0) info_host[s] = p + 1;
             }
         if (!any) break;
         if (masked) active = next;  // the next attempt: the stamps that failed, nothing else

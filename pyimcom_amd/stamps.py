@@ -776,12 +776,18 @@ class StampBatch:
                 torch.cuda.empty_cache()
                 self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o], o)
 
-    def solve_begin(self):
+    def solve_begin(self, expect_repair=False):
         """The solve queued, not waited for (imcom_solve_chol_resident_begin; one target PSF, Cholesky kernel -- for anything else nothing
         happens here and ``solve_end()`` runs the synchronous ``solve()``): the caller prepares its next pass while the device factors and
-        solves, then calls ``solve_end()``."""
+        solves, then calls ``solve_end()``.  ``expect_repair``: the caller has seen (nearly) every stamp of the previous pass take
+        _cholesky_wrapper's repair (lakernel.py:262-279; the reference's production shape: DESIGN.md section 4): the factorisation that
+        would fail is not attempted -- ``solve_end()`` goes straight to the smallest eigenvalues, which also say for every stamp whether
+        A + kappa I is positive definite after all (such a stamp is then factored plainly, as the reference would have)."""
         cfg = self.cfg
-        self._deferred, self._unsolved = False, False
+        self._deferred, self._unsolved, self._expected = False, False, False
+        if expect_repair and cfg.kernel == "Cholesky" and self.n_out == 1 and len(self.kappaC) == 1 and os.environ.get("IMCOM_REDO_ALL") != "1":
+            self._expected = True
+            return
         if cfg.kernel != "Cholesky" or self.n_out != 1 or (cfg.fade == 0 and os.environ.get("IMCOM_EPILOGUE_FUSED") == "1") \
                 or os.environ.get("IMCOM_SOLVE_DEFERRED", "1") == "0":
             self._unsolved = True  # solve_end() runs the synchronous solve: the caller's work in between still overlaps the builds
@@ -809,6 +815,20 @@ class StampBatch:
             self._unsolved = False
             self.solve()
             return False
+        if getattr(self, "_expected", False):
+            self._expected = False
+            self._stream()
+            self._coadded = set()
+            cfg, info = self.cfg, self.info_o[0]
+            redo = np.full(self.batch, 2, dtype=np.int32)
+            check(lib.imcom_solve_chol_resident_redo(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, _dp(self.A), _dp(self.Bt_o[0]),
+                                                     _hp(self.Cs_o[0]), _hp(self.kappaC), 1, float(cfg.uctarget), float(cfg.sigmamax),
+                                                     _dp(self.Tt_o[0]), _dp(self.UC_o[0]), _dp(self.Sigma_o[0]), _dp(self.kappa_o[0]), _hp(redo), _hp(info)))
+            if cfg.fade > 0:
+                for t in (self.kappa_o[0], self.Sigma_o[0], self.UC_o[0]):
+                    check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))
+            self.repair_share = float((info != 0).mean())
+            return False
         if not getattr(self, "_deferred", False):
             return False
         self._deferred = False
@@ -828,8 +848,10 @@ class StampBatch:
                 for s0, s1 in _runs(again):
                     for t in (self.kappa_o[0], self.Sigma_o[0], self.UC_o[0]):
                         check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t[s0:]), s1 - s0, self.n2f, cfg.fade))
+            self.repair_share = float(again.mean())
             return again
         check(rc)
+        self.repair_share = 0.0
         return False
 
     def _solve_target(self, Bt, Cs, Tt, UC, Sigma, kappa, info, o=0):
@@ -900,9 +922,12 @@ class StampBatch:
                                                self.n_expo, _dp(self.outimage_o[o][s0:]), _dp(self.Tsum_stamp_o[o][s0:]), _dp(self.Tsum_inpix_o[o][s0:]),
                                                _dp(self.Neff_o[o][s0:])))
 
+    repair_share = 0.0   # share of the batch's stamps that took the Cholesky repair in its last solve (solve_begin / solve_end)
+    EXPECT_REPAIR = 0.75  # a driver skips the doomed first factorisation of a pass when the pass before it was above this
+
     def run(self):
         self.build()
-        self.solve_begin()
+        self.solve_begin(expect_repair=self.repair_share >= self.EXPECT_REPAIR)
         if getattr(self, "_deferred", False):
             # the coaddition queued behind the solve's launches before the host waits for them (no gap between the two on the device);
             # a batch whose factorisation failed has been solved again by solve_end(): coadd its repaired T

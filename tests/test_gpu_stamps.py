@@ -379,7 +379,7 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
     healthy = {k: getattr(ref, k)[1].clone() for k in ("Tt", "UC", "Sigma", "kappa", "outimage")}
     assert not ref.info.any()
     want = None
-    for mode in ("synchronous", "halves"):
+    for mode in ("synchronous", "halves", "expected"):
         sb = StampBatch(cfg, stamps, tabs)
         sb.build()
         for s, c in enumerate(shifts):
@@ -395,6 +395,13 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
                 want.append(orc.chol_kernel(A, mB, tabs.C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax) + (np.linalg.eigvalsh(A),))
         if mode == "synchronous":
             sb.solve()
+            sb.coadd()
+        elif mode == "expected":
+            # a driver that has seen the previous pass repaired throughout skips the factorisation that fails: every stamp is handed over
+            # as "known to fail", and the smallest eigenvalue itself says which stamps are positive definite after all (the healthy ones
+            # here): those are factored plainly, info = 0, as the reference's cholesky() would have succeeded
+            sb.solve_begin(expect_repair=True)
+            assert sb.solve_end() is False and abs(sb.repair_share - np.mean(failed)) < 1e-12
             sb.coadd()
         else:
             sb.solve_begin()
@@ -416,4 +423,4 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
             assert np.allclose(r.UC[s].cpu().numpy(), Uo.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9), (mode, s)
             assert np.allclose(r.Sigma[s].cpu().numpy(), So.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9), (mode, s)
         for k, v in healthy.items():  # the stamp without a failure: what a batch without failures gives, bit for bit
-            assert torch.equal(getattr(sb, k)[1], v), (mode, k)
+            assert torch.equal(getattr(sb, k)[1], v), (mode, k)  # (also in the "expected" mode: its plain factorisation is the same launches on the same data)
