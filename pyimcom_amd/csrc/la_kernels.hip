@@ -722,7 +722,8 @@ __global__ void lmin_init_kernel(double *__restrict__ X, int ldn, int P, const i
     const int i = (int)(e / P);
     double v = 0.0;
     if (want[s] != 0 && i < n[s]) {
-        unsigned long long x = ((unsigned long long)s * ldn * P + (unsigned long long)e) * 6364136223846793005ULL + 1442695040888963407ULL;
+        // (the same start block for every stamp: what a stamp's iteration does must not depend on its place in the batch)
+        unsigned long long x = (unsigned long long)e * 6364136223846793005ULL + 1442695040888963407ULL;
         x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32; x *= 0x94D049BB133111EBULL; x ^= x >> 29;
         v = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
     }

@@ -125,3 +125,85 @@ def test_paper4_block_corner_fade3_six_layers_vs_oracle():
     p_in = np.square(got[0, 1:, :lim, :lim]).mean()
     p_all = np.square(got[0, 1:]).mean()
     assert 0.5 < p_in / p_all < 2.0
+
+
+def test_paper4_kernel_class_seam_vs_oracle():
+    """The drop-in LA kernel class (OutStamp.LAKERNEL["Cholesky"], coadd.py:839-844, 1091-1093) on ONE production-shape stamp handed over as
+    host arrays: N = 6.2k, A + kappa I indefinite -- `_cholesky_wrapper`'s repair (lakernel.py:262-279) through the library's small-batch
+    path (split-K launches, the smallest eigenvalue by the subspace iteration with one wanted stamp) -- against the oracle's CholKernel
+    (scipy cholesky -> LinAlgError -> numpy eigh -> shifted cholesky) on the same A, -B/2, C."""
+    import torch
+
+    from oracle import oracle as orc
+    from pyimcom_amd import synth
+    from pyimcom_amd.lakernel import HipCholKernel
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+    from tests.golden.make_golden import make_outst
+
+    cfg = synth.CONFIGS["paper4"]
+    st = synth.make_stamp(cfg, 3)
+    psfs, target = synth.make_psfs(cfg, st.n_expo)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    sb = StampBatch(cfg, [st], tabs)
+    sb.build()
+    torch.cuda.synchronize()
+    n, m = st.n, cfg.m
+    A = sb.A[0, :n, :n].cpu().numpy().copy()
+    mB = np.ascontiguousarray(sb.Bt[0, :n, :m].cpu().numpy().T)[None]
+    del sb
+    torch.cuda.empty_cache()
+    C = np.array([tabs.C])
+    kC = np.array(cfg.kappaC)
+    o = make_outst(A.copy(), mB.copy(), C, cfg.n2f, kC, cfg.uctarget, cfg.sigmamax)
+    K = HipCholKernel(o)
+    K()
+    assert np.array_equal(o.sysmata, A) and int(K.info[0]) == 1  # A untouched (lakernel.py:277 restores AA, never A); repaired
+    To, Uo, So, ko, info_o = orc.chol_kernel(A, mB[0], float(C[0]), kC, cfg.uctarget, cfg.sigmamax)
+    assert info_o == 1
+    lam_max = float(np.abs(A).sum(axis=1).max())  # (a bound is enough for the tolerance: no second eigendecomposition of a 6.2k matrix)
+    kap = kC[0] * C[0]
+    cond = (lam_max + kap) / kap  # after the repair the smallest eigenvalue of the factored matrix is kappa + 1e-16
+    assert np.abs(o.T[0] - To).max() <= (1e-6 + 50 * cond * 2.2e-16) * np.abs(To).max()
+    s2 = (cfg.n2f, cfg.n2f)
+    assert np.allclose(o.UC[0], Uo.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)
+    assert np.allclose(o.Sigma[0], So.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)
+    assert np.allclose(o.kappa[0], ko.reshape(s2), rtol=1e-5, atol=0)
+
+
+def test_paper4_block_in_several_passes_expects_the_repair():
+    """``coadd_block`` over a 4 x 4 corner in passes of four stamps: the first pass finds every factorisation failing, the following ones
+    are told to expect that (StampBatch.solve_begin(expect_repair=True)) and go straight to the smallest eigenvalues -- the maps must be
+    those of the single-pass block to the rounding of the solves (not bit for bit: launches of different batch sizes deal their tiles
+    differently), every stamp repaired."""
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import coadd_block
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    n1P = 4
+    cfg, inst, pool = _corner(n1P)
+    psfs, target = synth.make_psfs(cfg, cfg.n_expo)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    calls = []
+    real = StampBatch.solve_begin
+
+    def spy(self, expect_repair=False):
+        calls.append(bool(expect_repair))
+        return real(self, expect_repair)
+
+    StampBatch.solve_begin = spy
+    try:
+        one = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=16)
+        assert calls == [False]
+        calls.clear()
+        four = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=4)
+    finally:
+        StampBatch.solve_begin = real
+    torch.cuda.synchronize()
+    assert calls == [False, True, True, True] and one.info_nonzero == four.info_nonzero == 16
+    a, b = one.out_map, four.out_map
+    assert float((a - b).abs().max()) <= 5e-6 * float(a.abs().max())
+    for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+        x, y = one.maps[k], four.maps[k]
+        assert torch.allclose(x, y, rtol=2e-5, atol=1e-7 * float(x.abs().max())), k
