@@ -322,8 +322,8 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     std::vector<double> lastrel(batch, 1.0);
     for (int round = 0; round < max_rounds; round++) {
         std::vector<char> run(batch, 0);
-        bool any = false, coarse = false;
-        for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; coarse |= !fine[s]; }
+        bool any = false;
+        for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; }
         if (!any) break;
         // (a Rayleigh-Ritz step costs two steps' time -- A X on the tile engine and a batch of 128 x 128 eigenvalue problems: the first one
         // comes after six steps, when it has something to say)
@@ -382,6 +382,14 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
             const int s = idx[0];
             fprintf(stderr, "[lmin] round %d (%d steps): stamp %d theta %.15e (prev %.15e) sigma %.6e eta %.3e fine %d conv %d\n", round, iters, s, theta[s], prev[s],
                     sigma[s], eta[s], (int)fine[s], (int)conv[s]);
+            double rmin = 1e300, rmax = 0.0;
+            int nfine = 0, nconv = 0, nrun = 0;
+            for (int q : idx) {
+                if (!run[q]) continue;
+                nrun++; nfine += fine[q]; nconv += conv[q];
+                rmin = std::min(rmin, lastrel[q]); rmax = std::max(rmax, lastrel[q]);
+            }
+            fprintf(stderr, "[lmin]   %d stamps ran: change of theta %.2e .. %.2e, %d fine, %d converged\n", nrun, rmin, rmax, nfine, nconv);
         }
     }
     for (int s : idx) {

@@ -915,8 +915,14 @@ int band_basis_device(imcom_ctx *ctx, int batch, const int *n_host, int ld, int 
             if (r0 + BW + 1 < nmax) {
                 const int nrowtiles = (nmax - 1) / BSTRIP - (r0 + 1) / BSTRIP + 1, ndot = (r0 - ps + BW * (BW - 1) / 2 + 3) / 4;
                 ProfScope pf(ctx, "symv4", 1, true);  // (profile level 2: HIP events around this launch alone, for the HBM roofline of the pass)
-                static const bool use_mfma = !(getenv("IMCOM_SYMV4") && strcmp(getenv("IMCOM_SYMV4"), "valu") == 0);  // (A/B runs: the VALU form)
-                static const int abl = getenv("IMCOM_SYMV4_ABL") ? atoi(getenv("IMCOM_SYMV4_ABL")) : 0;  // (timing runs: parts of the kernel taken out)
+                // IMCOM_SYMV4=mfma: both products on the matrix pipe (symv4_mfma_kernel).  Built in round 5 and measured: alone on one stream
+                // as fast as the VALU form (537-552 against 527-555 ms per 256 cfg-3 stamps), 1.5 % slower beside a second sub-batch's
+                // stream (5.39-5.44 against 5.31-5.34 ms per stamp at batch 256, 7.15-7.28 against 7.13-7.17 at 32) -- the pass is bounded by
+                // its access pattern and its partial stores, not by arithmetic (profiles/r05_negative_results.txt item 1).  Not the default.
+                // (read per call -- a test runs both forms in one process; two getenv beside a launch are nothing)
+                const char *form = getenv("IMCOM_SYMV4"), *ablv = getenv("IMCOM_SYMV4_ABL");
+                const bool use_mfma = form && strcmp(form, "mfma") == 0;
+                const int abl = ablv ? atoi(ablv) : 0;  // (timing runs: parts of the kernel taken out)
 #define IMCOM_SYMV4_LAUNCH(A_) hipLaunchKernelGGL(symv4_mfma_kernel<A_>, dim3(nrowtiles + ndot, batch), dim3(256), 0, st, At, out->Vall, Wp, out->n_dev, ld, r0, ps, nrowtiles, Z4, part4, coefG, gramG)
                 if (use_mfma && abl == 1) IMCOM_SYMV4_LAUNCH(1);
                 else if (use_mfma && abl == 2) IMCOM_SYMV4_LAUNCH(2);

@@ -55,6 +55,33 @@ def test_band_reduce_vs_numpy_ragged_batch():
         assert np.all(band[s][:, n:] == 0)
 
 
+def test_symv4_forms_agree(monkeypatch):
+    """The strip pass on the vector unit (the default) and on the matrix pipe (IMCOM_SYMV4=mfma, profiles/r05_negative_results.txt
+    item 1): same band to rounding, each against LAPACK's eigenvalues, on a ragged batch that has full 64-row strips, strips cut by
+    the matrix end and a matrix below one strip."""
+    from pyimcom_amd.linalg import band_reduce
+
+    rng = np.random.default_rng(41)
+    ld = 640
+    ns = [640, 577, 333, 64, 37]
+    A = np.zeros((len(ns), ld, ld))
+    for s, n in enumerate(ns):
+        X = rng.standard_normal((n, n))
+        A[s, :n, :n] = X @ X.T / n + 0.01 * np.eye(n)
+    A[:, np.arange(ld), np.arange(ld)] += (np.arange(ld)[None, :] >= np.array(ns)[:, None]) * 1.0
+    out = {}
+    for form in ("valu", "mfma"):
+        monkeypatch.setenv("IMCOM_SYMV4", form)
+        out[form] = band_reduce(A.copy(), ns)[0]
+    for s, n in enumerate(ns):
+        scale = np.abs(A[s]).max()
+        ev = np.linalg.eigvalsh(A[s, :n, :n])
+        for form in out:
+            assert np.abs(np.linalg.eigvalsh(_dense_band(out[form][s][:, :n], n)) - ev).max() < 1e-13 * scale, (form, s)
+        # (different summation orders: the reflectors differ in rounding, and so do the bands -- signs included only through v's rounding)
+        assert np.abs(np.abs(out["valu"][s]) - np.abs(out["mfma"][s])).max() < 1e-11 * scale, s
+
+
 def test_band_reduce_on_cfg3_matrix():
     """The A of a cfg-3 stamp (N ~ 2.9k, ld = 2944) built on the device: the band's eigenvalues against LAPACK's of A, 2e-14 |A|."""
     import ctypes as C
