@@ -151,7 +151,12 @@ def _batch_buffers(device):
 
     key = torch.device(device).index or 0
     if key not in _BUFS:
-        _BUFS[key] = (BatchBuffers(device), BatchBuffers(device))
+        # ONE set of A, -B/2, T for the pass on the device and the one being prepared: coadd_block builds a pass's A and B only after the
+        # pass before it has been solved, coadded and added to the block's maps (all on one stream), and preparing a pass (selection, pair
+        # maps) writes none of the three.  (Two sets until round 5: at the reference's production shape -- 0.43 GB of A, -B/2, T per
+        # stamp -- the idle set was a third of a pass's memory and held the passes at 84 stamps of a possible 168+.)
+        b = BatchBuffers(device)
+        _BUFS[key] = (b, b)
     return _BUFS[key]
 
 
@@ -232,10 +237,11 @@ TABLE_WS_BYTES = (4 << 30) + (16 << 20)
 
 
 def pass_bytes(nb, ldn, ldm, n_out=1, kernel="Cholesky", resident=2, nv=1, n_inframe=2, table_ws=0):
-    """Device bytes of a pass of ``nb`` stamps while an LA kernel runs: the StampBatch buffers of ``resident`` batches (coadd_block
-    prepares batch k + 1 while batch k is solved), the selection's outputs and their trimmed copies, and the library workspace of the
-    batch being solved -- for the Cholesky and Eigen kernels by the library's own count (imcom_solve_chol_workspace /
-    imcom_solve_eigen_workspace for exactly ``nb`` stamps and ``nv`` kappa nodes)."""
+    """Device bytes of a pass of ``nb`` stamps while an LA kernel runs: one set of the large StampBatch buffers (A, -B/2, T: shared by
+    the pass on the device and the one being prepared, ``_batch_buffers``), the selection's outputs and their trimmed copies for
+    ``resident`` batches (coadd_block prepares batch k + 1 while batch k is solved), and the library workspace of the batch being
+    solved -- for the Cholesky and Eigen kernels by the library's own count (imcom_solve_chol_workspace / imcom_solve_eigen_workspace
+    for exactly ``nb`` stamps and ``nv`` kappa nodes)."""
     import ctypes
 
     from ._lib import check, lib
@@ -246,14 +252,14 @@ def pass_bytes(nb, ldn, ldm, n_out=1, kernel="Cholesky", resident=2, nv=1, n_inf
     ws = ctypes.c_size_t(0)
     if kernel == "Cholesky":
         check(lib.imcom_solve_chol_workspace(nb, int(ldn), int(ldm), int(ldm), int(nv), ctypes.byref(ws)))
-        return nb * resident * (base + small) + max(ws.value, table_ws) + (2 << 20)
+        return nb * (base + resident * small) + max(ws.value, table_ws) + (2 << 20)
     extra = 12 * ldm * ldn  # -B/2 (f64) and T (f32) in the reference's [m][N] layout
     if kernel == "Eigen":  # the resident entry works on the StampBatch layouts themselves: no copies
         check(lib.imcom_solve_eigen_workspace(nb, int(ldn), int(ldm), int(ldm), ctypes.byref(ws)))
-        return nb * resident * (base + small) + max(ws.value, table_ws) + (2 << 20)
+        return nb * (base + resident * small) + max(ws.value, table_ws) + (2 << 20)
     if kernel == "Iterative":
-        return nb * (resident * (base + small) + extra) + max(nb * (ldm // 16 + 1) * ITER_PATCH_BYTES, table_ws)  # one dense union sub-matrix per 4 x 4 patch (csrc/iter_empir.hip)
-    return nb * (resident * (base + small) + extra) + max(nb * 8 * ldn * ldn, table_ws)
+        return nb * (base + resident * small + extra) + max(nb * (ldm // 16 + 1) * ITER_PATCH_BYTES, table_ws)  # one dense union sub-matrix per 4 x 4 patch (csrc/iter_empir.hip)
+    return nb * (base + resident * small + extra) + max(nb * 8 * ldn * ldn, table_ws)
 
 
 def stamp_bytes(ldn, ldm, n_out=1, kernel="Cholesky", resident=2, nv=1, n_inframe=2, nb=256):
@@ -296,7 +302,7 @@ def available_bytes(device, ctx=None):
         free += int(ctx.workspace_bytes())
     key_ = torch.device(device).index or 0
     if key_ in _BUFS:
-        free += sum(b_.nbytes() for b_ in _BUFS[key_])
+        free += _BUFS[key_][0].nbytes()
     return free
 
 
@@ -605,8 +611,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         # waits for host work is only asked for the first pass: with two, the device idled until the second pass's groups were there)
         first = chunks[:1] if tables.provider_waits else chunks[:2]
         tables.prefetch(dict.fromkeys(g for c in first for t in c for g in stamp_groups(t[0], t[1], nst)))
-    # two sets of the large per-batch arrays, used alternately (batch k + 1 is prepared while batch k is solved) and kept from
-    # block to block
+    # the large per-batch arrays (one set: see _batch_buffers), kept from block to block
     bufs = _batch_buffers(pool.device)
     if chunks and ldn is None:
         # sized once for the block's largest batch (estimated, as the plan's): a buffer that has to grow in the middle of the
@@ -617,10 +622,9 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         bmax, ldm, O = max(len(c) for c in chunks), (cfg.m + NB - 1) // NB * NB, int(getattr(tables, "n_out", 1))
         import torch
 
-        for b_ in bufs:
-            b_.take("A", (bmax, ld_pre, ld_pre), torch.float64)
-            b_.take("Bt", (O, bmax, ld_pre, ldm), torch.float64)
-            b_.take("Tt", (O, bmax, ld_pre, ldm), torch.float32)
+        bufs[0].take("A", (bmax, ld_pre, ld_pre), torch.float64)
+        bufs[0].take("Bt", (O, bmax, ld_pre, ldm), torch.float64)
+        bufs[0].take("Tt", (O, bmax, ld_pre, ldm), torch.float32)
     todo = iter(range(len(chunks)))
     count = [0]
 

@@ -153,12 +153,13 @@ static size_t lmin_ws_bytes(int batch, int Np)
     if (!lmin_subspace_enabled() || Np < LMIN_MIN_N) return 0;
     WsPlan p;
     for (int q = 0; q < 3; q++) p.add((size_t)batch * Np * LMIN_P * 8);      // X, Y, Z = A X
-    for (int q = 0; q < 3; q++) p.add((size_t)batch * LMIN_P * LMIN_P * 8);  // G, its inverse Cholesky factor, H = X^T A X
+    for (int q = 0; q < 4; q++) p.add((size_t)batch * LMIN_P * LMIN_P * 8);  // G, its inverse Cholesky factor, H = X^T A X, H's eigenvectors
     p.add((size_t)batch * LMIN_P * 8);                                       // eigenvalues of H
+    p.add((size_t)batch * LMIN_RESID_GROUPS * 2 * 8);                        // residuals of the two lowest Ritz pairs, by row group
     p.add((size_t)batch * 8 * NB * NB * 8);                                  // split-K partial products of the 128-column solves
     p.add((size_t)batch * 8);                                                // largest diagonal entry
     for (int q = 0; q < 4; q++) p.add((size_t)batch * 4);                    // want, ones, flags of the Gram factorisations, masked nblk
-    p.add(eigh_ws_bytes(batch, LMIN_P, false));
+    p.add(eigh_ws_bytes(batch, LMIN_P, true));
     return p.total + 8192;
 }
 
@@ -225,10 +226,11 @@ static int lambda_min_group(imcom_ctx *ctx, const double *A, const int *n_host, 
 //   2. subspace iteration with the inverse, X <- orth((A + sigma I)^-1 X), on a block of 128 vectors = one tile column of the solve
 //      kernels (CholQR twice per step: Gram matrix on the tile engine, its Cholesky factor and the factor's inverse from the diagonal-block
 //      kernel), then Rayleigh-Ritz with A ITSELF: theta = lambda_min(X^T A X) >= lambda_min(A), accurate to eps |A| once the block has
-//      converged -- the accuracy class of LAPACK's own w[0];
-//   3. re-factor at sigma' = |theta| (1 + eta) just above the estimate (eta from the change of theta; a sigma' that is not above
-//      |lambda_min| makes the factorisation fail: eta x 8), where the block converges by 1e-3 per step; stop when two successive
-//      Rayleigh-Ritz values agree to 1e-11.
+//      converged -- the accuracy class of LAPACK's own w[0] -- with the residuals of the two lowest Ritz pairs as the error bound;
+//   3. re-factor at sigma' = |theta| (1 + eta) just above the estimate (eta from that bound; a sigma' that is not above
+//      |lambda_min| makes the factorisation fail: eta x 8), where the block converges by 1e-3 and more per step; stop when the bound is
+//      below 1e-11 |theta| (or two successive Rayleigh-Ritz values agree to that).
+// On a paper4 stamp: 2 factorisations, 6 + 3 steps, 2 Rayleigh-Ritz steps = 5.4 ms, theta within 2e-13 of LAPACK's w[0].
 // Everything runs on the stamps in place (L, Dinv, dshift of the caller's factorisation; stamps that are not wanted have no blocks in
 // these launches).  factor(shift, mask, fail): L L^T = A + shift[s] I for the stamps of mask, fail[s] != 0 where that is not positive
 // definite; solve(mask, X, Y): Y = (L L^T)^-1 X on LMIN_P columns.  ok[s] = 0: no answer (the caller takes the eigensolver).
@@ -242,12 +244,13 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     const int P = LMIN_P;
     const size_t blk = (size_t)batch * Np * P * 8, sq = (size_t)batch * P * P * 8;
     double *X = (double *)ws_take(ctx, blk), *Y = (double *)ws_take(ctx, blk), *Z = (double *)ws_take(ctx, blk);
-    double *G = (double *)ws_take(ctx, sq), *Gi = (double *)ws_take(ctx, sq), *H = (double *)ws_take(ctx, sq);
+    double *G = (double *)ws_take(ctx, sq), *Gi = (double *)ws_take(ctx, sq), *H = (double *)ws_take(ctx, sq), *Qh = (double *)ws_take(ctx, sq);
     double *lam = (double *)ws_take(ctx, (size_t)batch * P * 8);
+    double *rpart = (double *)ws_take(ctx, (size_t)batch * LMIN_RESID_GROUPS * 2 * 8);
     double *part = (double *)ws_take(ctx, (size_t)batch * 8 * NB * NB * 8);
     double *dmax_d = (double *)ws_take(ctx, (size_t)batch * 8);
     int *want_d = (int *)ws_take(ctx, (size_t)batch * 4), *ones_d = (int *)ws_take(ctx, (size_t)batch * 4), *gfail_d = (int *)ws_take(ctx, (size_t)batch * 4);
-    if (!X || !Y || !Z || !G || !Gi || !H || !lam || !part || !dmax_d || !want_d || !ones_d || !gfail_d) { set_error("internal: workspace (smallest eigenvalue)"); return IMCOM_ERR_NOMEM; }
+    if (!X || !Y || !Z || !G || !Gi || !H || !Qh || !lam || !rpart || !part || !dmax_d || !want_d || !ones_d || !gfail_d) { set_error("internal: workspace (smallest eigenvalue)"); return IMCOM_ERR_NOMEM; }
     const size_t mark_eig = ctx->ws_used;
     hipStream_t st = ctx->stream;
     std::vector<char> want(batch, 0);
@@ -260,6 +263,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     IMCOM_HIP_CHECK(hipMemsetAsync(Z, 0, blk, st));
     IMCOM_HIP_CHECK(hipMemsetAsync(G, 0, sq, st));  // (stamps that are not wanted keep zero blocks: gram_guard_kernel puts ones on their diagonals)
     IMCOM_HIP_CHECK(hipMemsetAsync(H, 0, sq, st));
+    IMCOM_HIP_CHECK(hipMemsetAsync(Qh, 0, sq, st));
     IMCOM_TRY(launch_diag_max(ctx, A, Np, n_dev, dmax_d, batch));
     std::vector<double> dmax(batch, 0.0);
     IMCOM_HIP_CHECK(hipMemcpyAsync(dmax.data(), dmax_d, (size_t)batch * 8, hipMemcpyDeviceToHost, st));
@@ -309,14 +313,22 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         std::swap(X, Y);  // the orthonormal block is in the buffer pass 1 wrote
         return IMCOM_OK;
     };
-    std::vector<double> theta(batch, 0.0), prev(batch, 0.0), eta(batch, 1e-3), lam0(batch, 0.0);
+    std::vector<double> theta(batch, 0.0), prev(batch, 0.0), eta(batch, 1e-3), lam01((size_t)batch * 2, 0.0), rp((size_t)batch * LMIN_RESID_GROUPS * 2, 0.0);
+    std::vector<double> est(batch, 0.0), est_simple(batch, 0.0), dbg_th(batch, 0.0), dbg_r1(batch, 0.0), dbg_r2(batch, 0.0), dbg_g2(batch, 0.0), dbg_gP(batch, 0.0), lamP(batch, 0.0);
     std::vector<char> conv(batch, 0);
     std::vector<int> gfail(batch, 0);
-    // Per stamp two phases.  Coarse (at the first shift): rounds of three steps until two successive Rayleigh-Ritz values agree to
-    // 2 % -- a closer shift chosen earlier than that tends to land below |lambda_min| (a random block needs a few steps before the
-    // asymptotic rate holds), and every trial that fails costs a factorisation = eight steps.  Then ONE factorisation at
-    // |theta| (1 + eta), eta = 8 x that change, and fine rounds of two steps there until two values agree to 1e-11; another
-    // factorisation only when a round has gained less than a factor 20.
+    // Per stamp two phases.  Coarse, at the first shift: six steps, then a Rayleigh-Ritz step that also yields the residuals r1, r2 of the
+    // two lowest Ritz pairs (theta1, y1), (theta2, y2) -- there is an eigenvalue within |r1| of theta1, and once theta1 is separated from
+    // the rest, (theta2 - |r2|) - theta1 = gap > 4 |r1|, theta1 - lambda_min <= |r1|^2 / gap (Kato-Temple).  With that bound below 5 % the
+    // stamp gets ONE factorisation at |theta1| (1 + eta), eta = twice the bound (a shift that is not above |lambda_min| makes the
+    // factorisation fail: eta x 8 -- every such trial costs eight steps' time), where the block converges by 1e-3 and more per step:
+    // fine rounds of three steps until the bound is below 1e-11 |theta1|, which the first one reaches on a production stamp
+    // (configs/paper4: six coarse steps leave 2e-3, three fine ones 1e-13).  The change between two successive values of theta1 -- the
+    // criterion of the first version, which cost a round of three steps and a Rayleigh-Ritz step in each phase only to confirm -- still
+    // ends either phase when the residuals cannot (theta1 inside a cluster closer than its residual).
+    static const int coarse_steps = getenv("IMCOM_LMIN_COARSE") ? std::max(1, atoi(getenv("IMCOM_LMIN_COARSE"))) : 6;
+    static const int round_steps = getenv("IMCOM_LMIN_FINE") ? std::max(1, atoi(getenv("IMCOM_LMIN_FINE"))) : 3;
+    static const bool by_change = getenv("IMCOM_LMIN_BOUND") && strcmp(getenv("IMCOM_LMIN_BOUND"), "change") == 0;  // (A/B: the first version's criteria alone)
     const int max_rounds = 14;
     std::vector<char> fine(batch, 0);
     std::vector<double> lastrel(batch, 1.0);
@@ -325,36 +337,53 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         bool any = false;
         for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; }
         if (!any) break;
-        // (a Rayleigh-Ritz step costs two steps' time -- A X on the tile engine and a batch of 128 x 128 eigenvalue problems: the first one
-        // comes after six steps, when it has something to say)
-        const int iters = round == 0 ? 6 : 3;
+        const int iters = round == 0 ? coarse_steps : round_steps;
         for (int it = 0; it < iters; it++) {
             IMCOM_TRY(solve(run, X, Y, part, splitk_parts(batch, 1)));
             IMCOM_TRY(orth());
         }
-        // Z = A X, H = X^T Z, theta = its smallest eigenvalue
+        // Z = A X, H = X^T Z, its eigenvalues and eigenvectors, the residuals of the two lowest pairs
         IMCOM_TRY(gemm(false, true, Np, P, Np, A, Np, (long)Np * Np, X, P, sX, Z, P, sX));
         IMCOM_TRY(gemm(true, true, P, P, Np, X, P, sX, Z, P, sX, H, P, sG));
         ctx->ws_used = mark_eig;
-        IMCOM_TRY(eigh_device(ctx, batch, nP.data(), P, H, P, sG, lam, P, nullptr, 0, 0, nullptr));
+        IMCOM_TRY(eigh_device(ctx, batch, nP.data(), P, H, P, sG, lam, P, Qh, P, sG, nullptr));
         ctx->ws_used = mark_eig;
-        IMCOM_HIP_CHECK(hipMemcpy2DAsync(lam0.data(), 8, lam, (size_t)P * 8, 8, batch, hipMemcpyDeviceToHost, st));
+        IMCOM_TRY(launch_ritz_residual(ctx, X, Z, Qh, lam, Np, P, n_dev, want_d, rpart, batch));
+        IMCOM_HIP_CHECK(hipMemcpy2DAsync(lam01.data(), 16, lam, (size_t)P * 8, 16, batch, hipMemcpyDeviceToHost, st));
+        IMCOM_HIP_CHECK(hipMemcpyAsync(rp.data(), rpart, rp.size() * 8, hipMemcpyDeviceToHost, st));
+        IMCOM_HIP_CHECK(hipMemcpy2DAsync(lamP.data(), 8, lam + P - 1, (size_t)P * 8, 8, batch, hipMemcpyDeviceToHost, st));
         IMCOM_HIP_CHECK(hipMemcpyAsync(gfail.data(), gfail_d, (size_t)batch * 4, hipMemcpyDeviceToHost, st));
         IMCOM_HIP_CHECK(hipStreamSynchronize(st));
         std::vector<char> refac(batch, 0);
         bool any_refac = false;
         for (int s : idx) {
             if (!run[s]) continue;
-            if (gfail[s] != 0 || !std::isfinite(lam0[s])) { act[s] = 0; continue; }  // the block lost rank / not a number: the eigensolver's case
+            const double th1 = lam01[2 * (size_t)s], th2 = lam01[2 * (size_t)s + 1];
+            double q1 = 0.0, q2 = 0.0;
+            for (int g = 0; g < LMIN_RESID_GROUPS; g++) { q1 += rp[((size_t)s * LMIN_RESID_GROUPS + g) * 2]; q2 += rp[((size_t)s * LMIN_RESID_GROUPS + g) * 2 + 1]; }
+            if (gfail[s] != 0 || !std::isfinite(th1) || !std::isfinite(q1) || !std::isfinite(q2)) { act[s] = 0; continue; }  // the block lost rank / not a number: the eigensolver's case
+            const double r1 = sqrt(q1), r2 = sqrt(q2), gap = (th2 - r2) - th1, mag = std::max(fabs(th1), 1e-300);
+            est_simple[s] = r1;
+            if (dbg && round == 0) { dbg_th[s] = th1; dbg_r1[s] = r1; dbg_r2[s] = r2; dbg_g2[s] = th2 - th1; dbg_gP[s] = lamP[s] - th1; }
+            // theta1 - lambda_min >= 0: at most |r1|, at most |r1|^2 / gap once theta1 is separated (both rigorous) -- and in fact close to
+            // |r1|^2 / (theta_P - theta1), the distance to the part of the spectrum the block has NOT captured (the lowest eigenvalues of a
+            // stamp's A come in near-degenerate pairs, so the rigorous gap is tiny while theta1's error is governed by the bulk near zero:
+            // on 128 paper4 stamps the error was 1.03 ... 1.28 x that quotient after six coarse steps and after three fine ones)
+            const double span = lamP[s] - th1;
+            est[s] = gap > 4.0 * r1 ? r1 * r1 / gap : r1;
+            if (span > 4.0 * r1) est[s] = std::min(est[s], 3.0 * r1 * r1 / span);
             prev[s] = theta[s];
-            theta[s] = lam0[s];
-            const double rel = round == 0 ? 1.0 : fabs(theta[s] - prev[s]) / std::max(fabs(theta[s]), 1e-300);
-            if (round >= 1 && rel <= 1e-11) { conv[s] = 1; continue; }
+            theta[s] = th1;
+            const double rel = round == 0 ? 1.0 : fabs(theta[s] - prev[s]) / mag;
+            const double bound = by_change ? 1.0 : est[s] / mag;
+            // (the quotient with theta_P is an estimate, not a bound: it ends the iteration only together with the rigorous |r1| <= 1e-6 |theta1|,
+            // which keeps the worst case -- theta1 inside a cluster the block has not separated -- at the rounding level of the float32 T)
+            if ((bound <= 1e-11 && r1 <= 1e-6 * mag) || (round >= 1 && rel <= 1e-11)) { conv[s] = 1; lastrel[s] = rel; continue; }
             // a shift just above |theta| (theta >= lambda_min: it must exceed |theta| by more than theta's error)
             if (!fine[s]) {
-                if (round >= 1 && rel <= 2e-2 && theta[s] < 0.0) {
+                if (theta[s] < 0.0 && (bound <= 5e-2 || (round >= 1 && rel <= 2e-2))) {
                     fine[s] = 1;
-                    eta[s] = std::min(std::max(8.0 * rel, 1e-3), 0.25);
+                    eta[s] = std::min(std::max(bound <= 5e-2 ? 1.5 * bound : 8.0 * rel, 1e-3), 0.25);
                     refac[s] = 1; any_refac = true;
                 }
             } else if (rel > 0.05 * lastrel[s] && 16.0 * rel < 0.25 * eta[s] && theta[s] < 0.0) {
@@ -380,17 +409,26 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         rounds_run = round + 1;
         if (dbg) {
             const int s = idx[0];
-            fprintf(stderr, "[lmin] round %d (%d steps): stamp %d theta %.15e (prev %.15e) sigma %.6e eta %.3e fine %d conv %d\n", round, iters, s, theta[s], prev[s],
-                    sigma[s], eta[s], (int)fine[s], (int)conv[s]);
-            double rmin = 1e300, rmax = 0.0;
+            fprintf(stderr, "[lmin] round %d (%d steps): stamp %d theta %.15e (prev %.15e) sigma %.6e eta %.3e fine %d conv %d   |r1| %.3e  bound %.3e (of |theta|)\n", round,
+                    iters, s, theta[s], prev[s], sigma[s], eta[s], (int)fine[s], (int)conv[s], est_simple[s], est[s] / std::max(fabs(theta[s]), 1e-300));
+            double rmin = 1e300, rmax = 0.0, bmin = 1e300, bmax = 0.0, smin = 1e300, smax_ = 0.0;
             int nfine = 0, nconv = 0, nrun = 0;
             for (int q : idx) {
                 if (!run[q]) continue;
+                const double mag = std::max(fabs(theta[q]), 1e-300);
                 nrun++; nfine += fine[q]; nconv += conv[q];
                 rmin = std::min(rmin, lastrel[q]); rmax = std::max(rmax, lastrel[q]);
+                bmin = std::min(bmin, est[q] / mag); bmax = std::max(bmax, est[q] / mag);
+                smin = std::min(smin, est_simple[q] / mag); smax_ = std::max(smax_, est_simple[q] / mag);
             }
-            fprintf(stderr, "[lmin]   %d stamps ran: change of theta %.2e .. %.2e, %d fine, %d converged\n", nrun, rmin, rmax, nfine, nconv);
+            fprintf(stderr, "[lmin]   %d stamps ran: change of theta %.2e .. %.2e, bound %.2e .. %.2e, |r1| / |theta| %.2e .. %.2e, %d fine, %d converged\n", nrun, rmin, rmax, bmin,
+                    bmax, smin, smax_, nfine, nconv);
         }
+    }
+    if (dbg) for (int s : idx) if (conv[s] && dbg_r1[s] > 0.0) {
+        const double d = dbg_th[s] - theta[s];
+        fprintf(stderr, "[lmin0] stamp %d theta0 %.9e final %.15e err %.3e r1 %.3e r1^2/err %.3e th2-th1 %.3e thP-th1 %.3e r2 %.3e\n", s, dbg_th[s], theta[s], d / fabs(theta[s]), dbg_r1[s],
+                dbg_r1[s] * dbg_r1[s] / std::max(d, 1e-300), dbg_g2[s], dbg_gP[s], dbg_r2[s]);
     }
     for (int s : idx) {
         ok[s] = act[s] && conv[s];

@@ -753,6 +753,47 @@ __global__ void gram_guard_kernel(double *__restrict__ G, int P, const int *__re
     if (c < P && want[s] == 0) G[(long)s * P * P + (long)c * P + c] = 1.0;
 }
 
+// Residuals of the two lowest Ritz pairs of the iteration's Rayleigh-Ritz step: with y_k = X q_k (X orthonormal [ldn][128], q_k the k-th
+// eigenvector of H = X^T A X, eigenvectors in the COLUMNS of Qh) and Z = A X, r_k = Z q_k - theta_k y_k.  part[s][g][k] = the share of
+// |r_k|^2 of the rows workgroup g took (added up by the host in the order of g: the same sums on every run).
+constexpr int LMIN_RG = LMIN_RESID_GROUPS;
+__global__ __launch_bounds__(256) void ritz_residual_kernel(const double *__restrict__ X, const double *__restrict__ Z, const double *__restrict__ Qh,
+                                                            const double *__restrict__ lam, int ldn, const int *__restrict__ n, const int *__restrict__ want,
+                                                            double *__restrict__ part)
+{
+    constexpr int P = 128;
+    __shared__ double red[4][2];
+    const int s = blockIdx.y, g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (want[s] != 0) {
+        const double *q = Qh + (long)s * P * P;
+        const double q0a = q[(long)lane * P], q0b = q[(long)(lane + 64) * P], q1a = q[(long)lane * P + 1], q1b = q[(long)(lane + 64) * P + 1];
+        const double th0 = lam[(long)s * P], th1 = lam[(long)s * P + 1];
+        const double *Xs = X + (long)s * ldn * P, *Zs = Z + (long)s * ldn * P;
+        for (int i = g * 4 + wave; i < n[s]; i += LMIN_RG * 4) {
+            const double xa = Xs[(long)i * P + lane], xb = Xs[(long)i * P + lane + 64], za = Zs[(long)i * P + lane], zb = Zs[(long)i * P + lane + 64];
+            double d0 = (za - th0 * xa) * q0a + (zb - th0 * xb) * q0b, d1 = (za - th1 * xa) * q1a + (zb - th1 * xb) * q1b;
+            for (int o = 32; o > 0; o >>= 1) {
+                d0 += __shfl_xor(d0, o);
+                d1 += __shfl_xor(d1, o);
+            }
+            acc0 += d0 * d0;
+            acc1 += d1 * d1;
+        }
+    }
+    if (lane == 0) { red[wave][0] = acc0; red[wave][1] = acc1; }
+    __syncthreads();
+    if (threadIdx.x < 2) part[((long)s * LMIN_RG + g) * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int launch_ritz_residual(imcom_ctx *ctx, const double *X, const double *Z, const double *Qh, const double *lam, int ldn, int P, const int *n,
+                         const int *want, double *part, int batch)
+{
+    IMCOM_REQUIRE(P == 128, "ritz_residual: blocks of 128 vectors");
+    hipLaunchKernelGGL(ritz_residual_kernel, dim3(LMIN_RG, batch), dim3(256), 0, ctx->stream, X, Z, Qh, lam, ldn, n, want, part);
+    return check_launch("ritz_residual_kernel");
+}
+
 int launch_lmin_init(imcom_ctx *ctx, double *X, int ldn, int P, const int *n, const int *want, int batch)
 {
     hipLaunchKernelGGL(lmin_init_kernel, dim3((unsigned)(((long)ldn * P + 255) / 256), batch), dim3(256), 0, ctx->stream, X, ldn, P, n, want);

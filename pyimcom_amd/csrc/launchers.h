@@ -85,6 +85,9 @@ int launch_finalize_fused(imcom_ctx *ctx, const double *Dpart, const double *Npa
                           const int *nblk, const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa,
                           int batch, const int *act = nullptr);  // act != null: only the stamps with act[s] != 0
 int launch_solve_mask(imcom_ctx *ctx, const int *nblk, const int *fac, const int *fail, int *nblk_sol, int *act, int batch);
+constexpr int LMIN_RESID_GROUPS = 32;  // row groups of launch_ritz_residual: part is [batch][32][2]
+int launch_ritz_residual(imcom_ctx *ctx, const double *X, const double *Z, const double *Qh, const double *lam, int ldn, int P, const int *n,
+                         const int *want, double *part, int batch);
 int launch_lmin_init(imcom_ctx *ctx, double *X, int ldn, int P, const int *n, const int *want, int batch);
 int launch_diag_max(imcom_ctx *ctx, const double *A, int ldn, const int *n, double *dmax, int batch);
 int launch_gram_guard(imcom_ctx *ctx, double *G, int P, const int *want, int batch);
