@@ -669,6 +669,10 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
 
     nxt = next_batch()
     maps.passes_halved = 0
+    maps.pass_seconds = []  # host clock per pass (a pass ends with the solve's status read-back: what is still queued behind it belongs to the next)
+    import time
+
+    t_pass = time.perf_counter()
     share = 0.0  # of the previous pass's stamps that took the Cholesky repair: at the reference's production shape it is every stamp, and a
                  # pass that follows such a pass does not attempt the factorisation that fails (StampBatch.solve_begin)
     while nxt is not None:
@@ -705,6 +709,8 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         maps.add(sb.results(), [j for j, _ in sb.chunk], [i for _, i in sb.chunk])
         maps.chunks_done.append(sb.chunk_index)
         maps.info_nonzero += int(sum(int((np.asarray(i_) != 0).sum()) for i_ in sb.info_o))  # stamps repaired (Cholesky) / re-solved in the eigenbasis (Eigen)
+        maps.pass_seconds.append(time.perf_counter() - t_pass)
+        t_pass = time.perf_counter()
     if pad_sides is not None:
         maps.finalize(pad_sides, postage_pad)
     return maps

@@ -319,8 +319,8 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     std::vector<int> gfail(batch, 0);
     // Per stamp two phases.  Coarse, at the first shift: six steps, then a Rayleigh-Ritz step that also yields the residuals r1, r2 of the
     // two lowest Ritz pairs (theta1, y1), (theta2, y2) -- there is an eigenvalue within |r1| of theta1, and once theta1 is separated from
-    // the rest, (theta2 - |r2|) - theta1 = gap > 4 |r1|, theta1 - lambda_min <= |r1|^2 / gap (Kato-Temple).  With that bound below 5 % the
-    // stamp gets ONE factorisation at |theta1| (1 + eta), eta = twice the bound (a shift that is not above |lambda_min| makes the
+    // the rest, (theta2 - |r2|) - theta1 = gap > 4 |r1|, theta1 - lambda_min <= |r1|^2 / gap (Kato-Temple).  With that bound below 15 % the
+    // stamp gets ONE factorisation at |theta1| (1 + eta), eta = 1.5 x the bound (a shift that is not above |lambda_min| makes the
     // factorisation fail: eta x 8 -- every such trial costs eight steps' time), where the block converges by 1e-3 and more per step:
     // fine rounds of three steps until the bound is below 1e-11 |theta1|, which the first one reaches on a production stamp
     // (configs/paper4: six coarse steps leave 2e-3, three fine ones 1e-13).  The change between two successive values of theta1 -- the
@@ -331,13 +331,16 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     static const bool by_change = getenv("IMCOM_LMIN_BOUND") && strcmp(getenv("IMCOM_LMIN_BOUND"), "change") == 0;  // (A/B: the first version's criteria alone)
     const int max_rounds = 14;
     std::vector<char> fine(batch, 0);
+    std::vector<int> steps_wanted(batch, 0);
     std::vector<double> lastrel(batch, 1.0);
     for (int round = 0; round < max_rounds; round++) {
         std::vector<char> run(batch, 0);
         bool any = false;
         for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; }
         if (!any) break;
-        const int iters = round == 0 ? coarse_steps : round_steps;
+        int iters = round == 0 ? coarse_steps : round_steps;
+        for (int s : idx) if (run[s]) iters = std::max(iters, steps_wanted[s]);  // (a stamp's first round at its closer shift: see below)
+        std::fill(steps_wanted.begin(), steps_wanted.end(), 0);
         for (int it = 0; it < iters; it++) {
             IMCOM_TRY(solve(run, X, Y, part, splitk_parts(batch, 1)));
             IMCOM_TRY(orth());
@@ -381,10 +384,13 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
             if ((bound <= 1e-11 && r1 <= 1e-6 * mag) || (round >= 1 && rel <= 1e-11)) { conv[s] = 1; lastrel[s] = rel; continue; }
             // a shift just above |theta| (theta >= lambda_min: it must exceed |theta| by more than theta's error)
             if (!fine[s]) {
-                if (theta[s] < 0.0 && (bound <= 5e-2 || (round >= 1 && rel <= 2e-2))) {
+                if (theta[s] < 0.0 && (bound <= 0.15 || (round >= 1 && rel <= 2e-2))) {
                     fine[s] = 1;
-                    eta[s] = std::min(std::max(bound <= 5e-2 ? 1.5 * bound : 8.0 * rel, 1e-3), 0.25);
+                    eta[s] = std::min(std::max(bound <= 0.15 ? 1.5 * bound : 8.0 * rel, 1e-3), 0.25);
                     refac[s] = 1; any_refac = true;
+                    // steps of the first fine round: with e = bound / 3 the error of theta1 and the bulk of the spectrum |theta1| away, the shift
+                    // leaves lambda_min + sigma' = 3.5 e |theta1| and a step multiplies the error by (3.5 e)^2: e (12 e^2)^j <= 3e-12
+                    steps_wanted[s] = bound <= 1.5e-2 ? 3 : bound <= 4e-2 ? 4 : bound <= 7e-2 ? 5 : 6;
                 }
             } else if (rel > 0.05 * lastrel[s] && 16.0 * rel < 0.25 * eta[s] && theta[s] < 0.0) {
                 eta[s] = std::max(16.0 * rel, 1e-9);
