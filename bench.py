@@ -565,8 +565,9 @@ def paper4_leg(ctx, dev, batch=128, steps=2, cpu_budget=25.0, block_passes=3):
     fade 3 (m = 1444), INPAD 1.24" (rho = 31.7 of n2 = 32), six exposures, six input layers, N ~ 6.2k, kappa / C = 6e-4 -- the regime a
     pyimcom user runs, N / m = 4.3: the factorisation (N^3 / 3 = 81 GFlop) is nearly as large as the solves (2 N^2 m = 112).  With 48-pixel
     PSFs 11 % of A is beyond the overlap tables' reach (psfutil.py:1691-1702 leaves those samples zero): A + kappa I is indefinite and EVERY
-    stamp takes _cholesky_wrapper's repair (lakernel.py:262-279), so a step is: A, B, one failed factorisation, the smallest eigenvalue
-    (api.hip lambda_min_subspace: trial factorisations + 128-column solves), the repaired factorisation, the solve, coaddition of six layers.
+    stamp takes _cholesky_wrapper's repair (lakernel.py:262-279), so a step is: A, B, the smallest eigenvalue (api.hip lambda_min_subspace:
+    two factorisations at shifts of its own + 128-column solves), the repaired factorisation, the solve, coaddition of six layers -- the
+    factorisation of A + kappa I itself, which fails, is attempted by a batch's first step only (StampBatch.run: expect_repair).
     Three figures: (1) resident batches as the headline is measured; (2) the first passes of the production block -- n1P = 84, a PSF group
     per 2 x 2 InStamps, 1849 groups -- through coadd_block with the block planner's own plan, and the seconds per block that rate gives;
     (3) the oracle on the same stamps on the host's cores."""
