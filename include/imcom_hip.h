@@ -316,6 +316,15 @@ int imcom_solve_chol_resident_redo(imcom_ctx *ctx, int batch, const int *n_host,
                                    const double *A, const double *Bt, const double *C_host,
                                    const double *kappaC_host, int nv, double ucmin, double smax,
                                    float *Tt, float *UC, float *Sigma, float *kappa, const int *redo_host, int *info_host);
+/* _cholesky_wrapper's repair (lakernel.py:262-279) needs w[0], the smallest eigenvalue of a failed stamp's A; the library finds it by
+ * inverse subspace iteration, which starts from a shift sigma with A + sigma I positive definite.  A driver that
+ * has just repaired neighbouring stamps knows where w[0] lies: imcom_ctx_set_repair_hint(ctx, h) with h ~ max |w[0]| of those stamps
+ * makes the following Cholesky calls on this context start at h (1 + 5 %) -- one factorisation inside the iteration instead of two.  The
+ * hint changes the iteration's path, not what it converges to (w[0] to 1e-11 either way; a hint that is too small for a stamp costs that
+ * stamp one failed factorisation).  0 clears it.  imcom_ctx_last_repair: how many stamps the last Cholesky call repaired and the range
+ * of their w[0] (count = 0: none, the range is then 0). */
+int imcom_ctx_set_repair_hint(imcom_ctx *ctx, double lmin_abs);
+int imcom_ctx_last_repair(imcom_ctx *ctx, int *count, double *w0_min, double *w0_max);
 /* coadd.py:1320-1354: fade taper of T (trapezoid, 1222-1292), per-exposure weight sums, Neff and
  * outimage = T . indata.
  *   Tt           [batch][ldn][ldm] float32 (tapered in place when fade > 0)

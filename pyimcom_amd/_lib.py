@@ -63,6 +63,8 @@ SIGNATURES = {
     "imcom_ctx_workspace_release": [_vp],
     "imcom_ctx_set_workspace": [_vp, _vp, C.c_size_t],
     "imcom_ctx_workspace_needed": [_vp, C.POINTER(C.c_size_t)],
+    "imcom_ctx_set_repair_hint": [_vp, _d],
+    "imcom_ctx_last_repair": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "imcom_ctx_profile_enable": [_vp, _i],
     "imcom_ctx_profile_reset": [_vp],
     "imcom_ctx_profile_get": [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(_l)],
@@ -149,7 +151,7 @@ class _Lib:
         for name, args in SIGNATURES.items():
             f = getattr(cdll, name)
             takes_ctx = bool(args) and args[0] is _vp and name not in ("imcom_ctx_destroy", "imcom_ctx_set_workspace", "imcom_ctx_workspace_needed",
-                                                                       "imcom_ctx_workspace_bytes", "imcom_ctx_workspace_release")
+                                                                       "imcom_ctx_workspace_bytes", "imcom_ctx_workspace_release", "imcom_ctx_set_repair_hint", "imcom_ctx_last_repair")
             setattr(self, name, _with_workspace(name, f) if takes_ctx else f)
 
     def __getattr__(self, name):  # (only what __init__ did not set)
@@ -247,6 +249,17 @@ class Context:
             raise ImcomError(IMCOM_ERR_NOMEM, f"device workspace of {size} bytes: {e}") from None
         check(lib.imcom_ctx_set_workspace(self._h, _vp(self._ws.data_ptr()), size))
         return True
+
+    def set_repair_hint(self, lmin_abs):
+        """An estimate of max |w[0]| for the stamps the next Cholesky calls repair (lakernel.py:262-279); 0 / None clears it
+        (imcom_ctx_set_repair_hint: the smallest-eigenvalue iteration then starts close to its answer)."""
+        check(lib.imcom_ctx_set_repair_hint(self.handle, float(lmin_abs or 0.0)))
+
+    def last_repair(self):
+        """(stamps the last Cholesky call repaired, smallest and largest w[0] among them)."""
+        c, a, b = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+        check(lib.imcom_ctx_last_repair(self.handle, C.byref(c), C.byref(a), C.byref(b)))
+        return c.value, a.value, b.value
 
     def workspace_needed(self):
         b = C.c_size_t(0)

@@ -675,11 +675,13 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     t_pass = time.perf_counter()
     share = 0.0  # of the previous pass's stamps that took the Cholesky repair: at the reference's production shape it is every stamp, and a
                  # pass that follows such a pass does not attempt the factorisation that fails (StampBatch.solve_begin)
+    hint = None  # max |w[0]| of the last pass that repaired stamps: where the next pass's smallest-eigenvalue iterations start (over a production
+                 # block it stays within 1 % from pass to pass: profiles/r05_negative_results.txt item 7)
     while nxt is not None:
         sb = nxt
         sb.build()
         try:
-            sb.solve_begin(expect_repair=share >= StampBatch.EXPECT_REPAIR)
+            sb.solve_begin(expect_repair=share >= StampBatch.EXPECT_REPAIR, repair_hint=hint)
             if pipeline:
                 nxt = next_batch()
             sb.solve_end()
@@ -702,6 +704,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
                 nxt = next_batch()
             continue
         share = float(getattr(sb, "repair_share", 0.0))
+        hint = getattr(sb, "repair_absmax", None) or hint
         check_batch(sb)
         sb.coadd()
         if not pipeline:

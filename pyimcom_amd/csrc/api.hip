@@ -235,7 +235,7 @@ static int lambda_min_group(imcom_ctx *ctx, const double *A, const int *n_host, 
 // these launches).  factor(shift, mask, fail): L L^T = A + shift[s] I for the stamps of mask, fail[s] != 0 where that is not positive
 // definite; solve(mask, X, Y): Y = (L L^T)^-1 X on LMIN_P columns.  ok[s] = 0: no answer (the caller takes the eigensolver).
 static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, const int *n_dev, int Np, const double *A, const std::vector<int> &idx,
-                               const std::vector<double> &inc_failed,
+                               const std::vector<double> &inc_failed, double hint,
                                const std::function<int(const std::vector<double> &, const std::vector<char> &, std::vector<int> &)> &factor,
                                const std::function<int(const std::vector<char> &, const double *, double *, double *, int)> &solve,
                                std::vector<double> &w0, std::vector<char> &ok)
@@ -274,14 +274,28 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     std::vector<double> sigma(batch, 0.0);
     std::vector<char> todo = want, act = want;
     std::vector<int> fail;
-    for (int s : idx) sigma[s] = std::max(std::max(4.0 * inc_failed[s], 1e-13 * dmax[s]), 1e-300);
+    // The caller's estimate of max |lambda_min| (imcom_ctx_set_repair_hint: what the pass before this one found -- over a production
+    // block the largest |lambda_min| of a pass of 168 stamps stays within 1 % from pass to pass, the stamps of a pass within 6 % of
+    // each other): the first shift is that estimate plus a margin instead of four times the failed increment, i.e. already as close as the
+    // SECOND shift of a stamp that starts without one, and the iteration needs one factorisation instead of two.  An estimate that is too
+    // small for a stamp costs that stamp one failed factorisation (then the shift it would have started with).
+    static const bool hint_off = getenv("IMCOM_LMIN_HINT") && strcmp(getenv("IMCOM_LMIN_HINT"), "0") == 0;
+    static const double hint_margin = getenv("IMCOM_LMIN_MARGIN") ? std::max(0.0, atof(getenv("IMCOM_LMIN_MARGIN"))) : 0.05;
+    std::vector<char> hinted(batch, 0);
+    std::vector<double> base(batch, 0.0);
+    bool any_hinted = false;
+    for (int s : idx) {
+        base[s] = sigma[s] = std::max(std::max(4.0 * inc_failed[s], 1e-13 * dmax[s]), 1e-300);
+        if (!hint_off && hint > 0.0 && std::isfinite(hint)) { sigma[s] = hint * (1.0 + hint_margin); hinted[s] = 1; any_hinted = true; }
+    }
     for (int t = 0;; t++) {
         IMCOM_TRY(factor(sigma, todo, fail));
         nfac++;
         bool any = false;
         for (int s : idx) {
             if (!todo[s]) continue;
-            if (fail[s] != 0 && std::isfinite(sigma[s] * 8.0)) { sigma[s] *= 8.0; any = true; }
+            if (fail[s] != 0 && hinted[s]) { sigma[s] = std::max(base[s], 2.0 * sigma[s]); hinted[s] = 0; any = true; }
+            else if (fail[s] != 0 && std::isfinite(sigma[s] * 8.0)) { sigma[s] *= 8.0; any = true; }
             else if (fail[s] != 0) { todo[s] = 0; act[s] = 0; }  // (not finite: not a matrix this iteration can help)
             else todo[s] = 0;
         }
@@ -327,6 +341,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     // criterion of the first version, which cost a round of three steps and a Rayleigh-Ritz step in each phase only to confirm -- still
     // ends either phase when the residuals cannot (theta1 inside a cluster closer than its residual).
     static const int coarse_steps = getenv("IMCOM_LMIN_COARSE") ? std::max(1, atoi(getenv("IMCOM_LMIN_COARSE"))) : 6;
+    static const int hinted_steps = getenv("IMCOM_LMIN_HINTED") ? std::max(1, atoi(getenv("IMCOM_LMIN_HINTED"))) : 7;  // (34 x (7.6e-3)^7: see the hint above)
     static const int round_steps = getenv("IMCOM_LMIN_FINE") ? std::max(1, atoi(getenv("IMCOM_LMIN_FINE"))) : 3;
     static const bool by_change = getenv("IMCOM_LMIN_BOUND") && strcmp(getenv("IMCOM_LMIN_BOUND"), "change") == 0;  // (A/B: the first version's criteria alone)
     const int max_rounds = 14;
@@ -338,7 +353,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         bool any = false;
         for (int s : idx) if (act[s] && !conv[s]) { run[s] = 1; any = true; }
         if (!any) break;
-        int iters = round == 0 ? coarse_steps : round_steps;
+        int iters = round == 0 ? (any_hinted ? hinted_steps : coarse_steps) : round_steps;
         for (int s : idx) if (run[s]) iters = std::max(iters, steps_wanted[s]);  // (a stamp's first round at its closer shift: see below)
         std::fill(steps_wanted.begin(), steps_wanted.end(), 0);
         for (int it = 0; it < iters; it++) {
@@ -383,7 +398,21 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
             // which keeps the worst case -- theta1 inside a cluster the block has not separated -- at the rounding level of the float32 T)
             if ((bound <= 1e-11 && r1 <= 1e-6 * mag) || (round >= 1 && rel <= 1e-11)) { conv[s] = 1; lastrel[s] = rel; continue; }
             // a shift just above |theta| (theta >= lambda_min: it must exceed |theta| by more than theta's error)
-            if (!fine[s]) {
+            // a first shift that is already close (a good hint): no second factorisation, the rounds go on where they are; a step multiplies
+            // the error by ((lambda_min + sigma) / (|lambda_min| + lambda_min + sigma))^2 (the bulk of the spectrum is |lambda_min| away)
+            const double close = theta[s] < 0.0 ? (sigma[s] + theta[s]) / mag : 1e300;
+            if (!fine[s] && close > 0.0 && close <= 0.25) {
+                fine[s] = 1;
+                eta[s] = close;
+                const double c = (close / (1.0 + close)) * (close / (1.0 + close));
+                steps_wanted[s] = (int)std::min(6.0, std::max(1.0, ceil(log(std::max(1e-11 / std::max(bound, 1e-300), 1e-300)) / log(c))));
+            }
+            if (!fine[s] && theta[s] < 0.0 && sigma[s] > 4.0 * (mag + r1) && !(bound <= 0.15)) {
+                // a first shift far above what is needed (the x 8 ladder overshot, or a hint from another regime): the block converges by
+                // (1 - |lambda_min| / sigma)^2 per step there.  lambda_min >= theta1 - |r1| (rigorous): one factorisation at twice that, still coarse
+                eta[s] = 1.0 + 2.0 * r1 / mag;
+                refac[s] = 1; any_refac = true;
+            } else if (!fine[s]) {
                 if (theta[s] < 0.0 && (bound <= 0.15 || (round >= 1 && rel <= 2e-2))) {
                     fine[s] = 1;
                     eta[s] = std::min(std::max(bound <= 0.15 ? 1.5 * bound : 8.0 * rel, 1e-3), 0.25);
@@ -440,7 +469,11 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         ok[s] = act[s] && conv[s];
         if (ok[s]) w0[s] = theta[s];
     }
-    if (dbg) fprintf(stderr, "[lmin] %zu stamps: %d factorisations (%d of them failed for some stamp), %d rounds\n", idx.size(), nfac, nfac_failed, rounds_run);
+    if (dbg) {
+        double tmin = 1e300, tmax = -1e300;
+        for (int s : idx) if (ok[s]) { tmin = std::min(tmin, w0[s]); tmax = std::max(tmax, w0[s]); }
+        fprintf(stderr, "[lmin] %zu stamps: %d factorisations (%d of them failed for some stamp), %d rounds; lambda_min %.6e .. %.6e\n", idx.size(), nfac, nfac_failed, rounds_run, tmin, tmax);
+    }
     ctx->ws_used = mark;
     return IMCOM_OK;
 }
@@ -482,6 +515,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                      const int *redo_host = nullptr)
 {
     bool bt_ready = !before_solve;
+    ctx->last_repair_count = 0;
     const int nbmax_all = Np / NB;
     const int pb = nodes_per_pass(batch, mp, nv), eb = batch * pb;  // nodes per pass, stamps x nodes of a pass
     const bool masked = nv == 1;  // (pb == 1 then)
@@ -712,7 +746,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                     for (int p = 0; p < nv; p++)
                         if (fail[(size_t)p * batch + s] != 0) incf[s] = std::max(incf[s], kappaC_host[p] * C_host[s]);
                 ctx->ws_used = ws_after_plan;
-                IMCOM_TRY(lambda_min_subspace(ctx, batch, n_host, n_dev, Np, A, big, incf, factor_masked, solve_block, w0v, got));
+                IMCOM_TRY(lambda_min_subspace(ctx, batch, n_host, n_dev, Np, A, big, incf, ctx->repair_hint, factor_masked, solve_block, w0v, got));
                 ctx->ws_used = ws_after_plan;
             }
             std::vector<int> rest;
@@ -727,6 +761,9 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             for (int s : need) {
                 rep[s] = fabs(w0v[s]) + 1e-16;
                 have_w0[s] = 1;
+                ctx->last_w0_min = ctx->last_repair_count ? std::min(ctx->last_w0_min, w0v[s]) : w0v[s];
+                ctx->last_w0_max = ctx->last_repair_count ? std::max(ctx->last_w0_max, w0v[s]) : w0v[s];
+                ctx->last_repair_count++;
                 // A stamp whose failure was the CALLER's expectation (redo = 2 without a factorisation having failed here): the smallest
                 // eigenvalue says whether A + kappa I is positive definite after all.  If it clearly is (w0 + kappa above 1e-6 kappa: the
                 // eigenvalue is good to 1e-11) the reference's cholesky() succeeds and nothing is repaired: the stamp is factored plainly in
@@ -932,6 +969,24 @@ int imcom_ctx_workspace_needed(imcom_ctx *ctx, size_t *bytes)
     IMCOM_TRY(check_ctx(ctx));
     IMCOM_REQUIRE(bytes, "null bytes");
     *bytes = ctx->ws_need;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_set_repair_hint(imcom_ctx *ctx, double lmin_abs)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(lmin_abs >= 0.0 && std::isfinite(lmin_abs), "repair hint: a finite |lambda_min| >= 0 (0 clears it)");
+    ctx->repair_hint = lmin_abs;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_last_repair(imcom_ctx *ctx, int *count, double *w0_min, double *w0_max)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    IMCOM_REQUIRE(count && w0_min && w0_max, "null output");
+    *count = ctx->last_repair_count;
+    *w0_min = ctx->last_repair_count ? ctx->last_w0_min : 0.0;
+    *w0_max = ctx->last_repair_count ? ctx->last_w0_max : 0.0;
     return IMCOM_OK;
 }
 

@@ -75,6 +75,11 @@ struct imcom_ctx {
     size_t ws_limit = 0;       // != 0: ws_take hands out nothing beyond this offset (a sub-batch's share of the workspace, eigen.hip)
     bool ws_external = false;  // imcom_ctx_set_workspace: the caller owns the workspace memory, the library never allocates device memory
     size_t ws_need = 0;        // what the last ws_reserve asked for (imcom_ctx_workspace_needed)
+    // Cholesky repair (lakernel.py:262-279): the caller's estimate of max |w[0]| over the stamps of the next calls (0: none;
+    // imcom_ctx_set_repair_hint) and what the last call's repaired stamps had (imcom_ctx_last_repair)
+    double repair_hint = 0.0;
+    int last_repair_count = 0;
+    double last_w0_min = 0.0, last_w0_max = 0.0;
     // pinned host staging for small per-stamp arrays
     char *pin = nullptr;
     size_t pin_bytes = 0;

@@ -776,15 +776,28 @@ class StampBatch:
                 torch.cuda.empty_cache()
                 self._solve_target(self.Bt_o[o], self.Cs_o[o], self.Tt_o[o], self.UC_o[o], self.Sigma_o[o], self.kappa_o[o], self.info_o[o], o)
 
-    def solve_begin(self, expect_repair=False):
+    def _repair_hint(self, hint):
+        """Hand the driver's estimate of max |w[0]| to the context for the calls of this solve (None / 0: none)."""
+        self.ctx.set_repair_hint(hint if hint and np.isfinite(hint) and hint > 0 else 0.0)
+
+    def _note_repair(self):
+        """What the solve's repaired stamps had: ``repair_absmax`` = max |w[0]| (None when nothing was repaired), the next pass's hint."""
+        cnt, lo, hi = self.ctx.last_repair()
+        self.repair_absmax = max(abs(lo), abs(hi)) if cnt else None
+
+    def solve_begin(self, expect_repair=False, repair_hint=None):
         """The solve queued, not waited for (imcom_solve_chol_resident_begin; one target PSF, Cholesky kernel -- for anything else nothing
         happens here and ``solve_end()`` runs the synchronous ``solve()``): the caller prepares its next pass while the device factors and
         solves, then calls ``solve_end()``.  ``expect_repair``: the caller has seen (nearly) every stamp of the previous pass take
         _cholesky_wrapper's repair (lakernel.py:262-279; the reference's production shape: DESIGN.md section 4): the factorisation that
         would fail is not attempted -- ``solve_end()`` goes straight to the smallest eigenvalues, which also say for every stamp whether
-        A + kappa I is positive definite after all (such a stamp is then factored plainly, as the reference would have)."""
+        A + kappa I is positive definite after all (such a stamp is then factored plainly, as the reference would have).
+        ``repair_hint``: max |w[0]| of the stamps the previous pass repaired (``repair_absmax`` of that pass): the smallest-eigenvalue
+        iteration of this pass's repairs starts there (imcom_ctx_set_repair_hint) -- its path changes, not what it converges to."""
         cfg = self.cfg
         self._deferred, self._unsolved, self._expected = False, False, False
+        self.repair_absmax = None
+        self._repair_hint(repair_hint)
         if expect_repair and cfg.kernel == "Cholesky" and self.n_out == 1 and len(self.kappaC) == 1 and os.environ.get("IMCOM_REDO_ALL") != "1":
             self._expected = True
             return
@@ -807,6 +820,13 @@ class StampBatch:
         self._deferred = True
 
     def solve_end(self):
+        try:
+            return self._solve_end()
+        finally:
+            if self.ctx._h:
+                self.ctx.set_repair_hint(0.0)  # (the hint was for this solve: a later call on the context starts without one)
+
+    def _solve_end(self):
         """Wait for ``solve_begin()``'s work.  Stamps whose factorisation failed are solved again with the reference's repair
         (lakernel.py:262-279) -- those stamps only (imcom_solve_chol_resident_redo; the others' outputs are final).  Returns False, or
         the boolean mask [batch] of the stamps that were solved again: whatever the caller queued on the first attempt's outputs of
@@ -814,6 +834,7 @@ class StampBatch:
         if getattr(self, "_unsolved", False):
             self._unsolved = False
             self.solve()
+            self._note_repair()
             return False
         if getattr(self, "_expected", False):
             self._expected = False
@@ -828,6 +849,7 @@ class StampBatch:
                 for t in (self.kappa_o[0], self.Sigma_o[0], self.UC_o[0]):
                     check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t), self.batch, self.n2f, cfg.fade))
             self.repair_share = float((info != 0).mean())
+            self._note_repair()
             return False
         if not getattr(self, "_deferred", False):
             return False
@@ -849,6 +871,7 @@ class StampBatch:
                     for t in (self.kappa_o[0], self.Sigma_o[0], self.UC_o[0]):
                         check(lib.imcom_trapezoid_f32(self.ctx.handle, _dp(t[s0:]), s1 - s0, self.n2f, cfg.fade))
             self.repair_share = float(again.mean())
+            self._note_repair()
             return again
         check(rc)
         self.repair_share = 0.0
@@ -927,7 +950,7 @@ class StampBatch:
 
     def run(self):
         self.build()
-        self.solve_begin(expect_repair=self.repair_share >= self.EXPECT_REPAIR)
+        self.solve_begin(expect_repair=self.repair_share >= self.EXPECT_REPAIR, repair_hint=getattr(self, "repair_absmax", None))
         if getattr(self, "_deferred", False):
             # the coaddition queued behind the solve's launches before the host waits for them (no gap between the two on the device);
             # a batch whose factorisation failed has been solved again by solve_end(): coadd its repaired T

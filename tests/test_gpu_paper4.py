@@ -172,7 +172,7 @@ def test_paper4_kernel_class_seam_vs_oracle():
 
 def test_paper4_block_in_several_passes_expects_the_repair():
     """``coadd_block`` over a 4 x 4 corner in passes of four stamps: the first pass finds every factorisation failing, the following ones
-    are told to expect that (StampBatch.solve_begin(expect_repair=True)) and go straight to the smallest eigenvalues -- the maps must be
+    are told to expect that (StampBatch.solve_begin(expect_repair=True, repair_hint=...)) and go straight to the smallest eigenvalues -- the maps must be
     those of the single-pass block to the rounding of the solves (not bit for bit: launches of different batch sizes deal their tiles
     differently), every stamp repaired."""
     import torch
@@ -188,20 +188,26 @@ def test_paper4_block_in_several_passes_expects_the_repair():
     calls = []
     real = StampBatch.solve_begin
 
-    def spy(self, expect_repair=False):
+    hints = []
+
+    def spy(self, expect_repair=False, repair_hint=None):
         calls.append(bool(expect_repair))
-        return real(self, expect_repair)
+        hints.append(repair_hint)
+        return real(self, expect_repair, repair_hint)
 
     StampBatch.solve_begin = spy
     try:
         one = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=16)
-        assert calls == [False]
+        assert calls == [False] and hints == [None]
         calls.clear()
+        hints.clear()
         four = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=4)
     finally:
         StampBatch.solve_begin = real
     torch.cuda.synchronize()
     assert calls == [False, True, True, True] and one.info_nonzero == four.info_nonzero == 16
+    # ... and where the smallest eigenvalues lie (max |w[0]| of the pass before: the iteration starts at that shift, one factorisation instead of two)
+    assert hints[0] is None and all(h is not None and 1e-6 < h < 3e-6 for h in hints[1:]), hints
     a, b = one.out_map, four.out_map
     assert float((a - b).abs().max()) <= 5e-6 * float(a.abs().max())
     for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):

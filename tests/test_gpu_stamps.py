@@ -379,7 +379,8 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
     healthy = {k: getattr(ref, k)[1].clone() for k in ("Tt", "UC", "Sigma", "kappa", "outimage")}
     assert not ref.info.any()
     want = None
-    for mode in ("synchronous", "halves", "expected"):
+    w0_abs = None
+    for mode in ("synchronous", "halves", "expected", "hint", "hint_small", "hint_large"):
         sb = StampBatch(cfg, stamps, tabs)
         sb.build()
         for s, c in enumerate(shifts):
@@ -396,6 +397,15 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
         if mode == "synchronous":
             sb.solve()
             sb.coadd()
+        elif mode.startswith("hint"):
+            # the driver's estimate of max |w[0]| (what the pass before found: StampBatch.repair_absmax): the iteration starts there.  A good one,
+            # one that is too small for every failed stamp (their first factorisation fails: back to the shift they would have started with)
+            # and one that is three times too large (a slow first shift: a second factorisation, as without a hint) -- the same answers
+            f = {"hint": 1.0, "hint_small": 0.5, "hint_large": 3.0}[mode]
+            sb.solve_begin(expect_repair=True, repair_hint=f * w0_abs)
+            assert sb.solve_end() is False and abs(sb.repair_share - np.mean(failed)) < 1e-12
+            assert sb.ctx.last_repair()[0] == len(stamps)  # (every stamp was handed over as "known to fail": its w[0] was computed)
+            sb.coadd()
         elif mode == "expected":
             # a driver that has seen the previous pass repaired throughout skips the factorisation that fails: every stamp is handed over
             # as "known to fail", and the smallest eigenvalue itself says which stamps are positive definite after all (the healthy ones
@@ -410,6 +420,12 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
             assert again is not False and list(again) == failed
             sb.coadd(only=again)
         torch.cuda.synchronize()
+        if mode == "expected":
+            cnt, lo, hi = sb.ctx.last_repair()
+            # (all stamps went through the iteration; the most negative of their smallest eigenvalues is LAPACK's)
+            assert cnt == len(stamps) and abs(lo - min(w[5][0] for w in want)) <= 1e-9 * abs(lo)
+            w0_abs = sb.repair_absmax
+            assert w0_abs == max(abs(lo), abs(hi))
         r = sb.result()
         assert list(r.info) == [int(f) for f in failed], (mode, r.info)
         for s, st in enumerate(stamps):
