@@ -235,7 +235,7 @@ static int lambda_min_group(imcom_ctx *ctx, const double *A, const int *n_host, 
 // these launches).  factor(shift, mask, fail): L L^T = A + shift[s] I for the stamps of mask, fail[s] != 0 where that is not positive
 // definite; solve(mask, X, Y): Y = (L L^T)^-1 X on LMIN_P columns.  ok[s] = 0: no answer (the caller takes the eigensolver).
 static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, const int *n_dev, int Np, const double *A, const std::vector<int> &idx,
-                               const std::vector<double> &inc_failed, double hint,
+                               const std::vector<double> &inc_failed, double hint, const std::vector<char> &may_decide, std::vector<char> &decided,
                                const std::function<int(const std::vector<double> &, const std::vector<char> &, std::vector<int> &)> &factor,
                                const std::function<int(const std::vector<char> &, const double *, double *, double *, int)> &solve,
                                std::vector<double> &w0, std::vector<char> &ok)
@@ -394,6 +394,15 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
             theta[s] = th1;
             const double rel = round == 0 ? 1.0 : fabs(theta[s] - prev[s]) / mag;
             const double bound = by_change ? 1.0 : est[s] / mag;
+            // A stamp whose failure is the CALLER's expectation, not an observed one (may_decide): all that is wanted first is whether
+            // A + inc I is positive definite after all, and lambda_min >= theta1 - |r1| decides that long before theta1 has converged --
+            // lambda_min of a healthy PSF-overlap matrix is rounding noise around zero inside a dense cluster, which this iteration would
+            // chase for all its rounds and then hand to the eigensolver.  (From the second Rayleigh-Ritz step on: ten steps bring a
+            // lambda_min of the size of -inc out of a random block beyond doubt.)  theta1 is then no eigenvalue: `decided` says so.
+            if (may_decide[s] && round >= 1 && inc_failed[s] > 0.0 && (th1 - r1) + inc_failed[s] > 1e-3 * inc_failed[s]) {
+                conv[s] = 1; decided[s] = 1; lastrel[s] = rel;
+                continue;
+            }
             // (the quotient with theta_P is an estimate, not a bound: it ends the iteration only together with the rigorous |r1| <= 1e-6 |theta1|,
             // which keeps the worst case -- theta1 inside a cluster the block has not separated -- at the rounding level of the float32 T)
             if ((bound <= 1e-11 && r1 <= 1e-6 * mag) || (round >= 1 && rel <= 1e-11)) { conv[s] = 1; lastrel[s] = rel; continue; }
@@ -472,7 +481,10 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     if (dbg) {
         double tmin = 1e300, tmax = -1e300;
         for (int s : idx) if (ok[s]) { tmin = std::min(tmin, w0[s]); tmax = std::max(tmax, w0[s]); }
-        fprintf(stderr, "[lmin] %zu stamps: %d factorisations (%d of them failed for some stamp), %d rounds; lambda_min %.6e .. %.6e\n", idx.size(), nfac, nfac_failed, rounds_run, tmin, tmax);
+        int nok = 0;
+        for (int s : idx) nok += ok[s] ? 1 : 0;
+        fprintf(stderr, "[lmin] %zu stamps: %d factorisations (%d of them failed for some stamp), %d rounds; lambda_min %.6e .. %.6e; %d without an answer (the eigensolver's)\n", idx.size(), nfac,
+                nfac_failed, rounds_run, tmin, tmax, (int)idx.size() - nok);
     }
     ctx->ws_used = mark;
     return IMCOM_OK;
@@ -736,6 +748,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             std::vector<double> w0v(batch, 0.0);
             std::vector<char> got(batch, 0);
             std::vector<int> big;
+            std::vector<char> may_decide(batch, 0), decided(batch, 0);
             if (lmin_subspace_enabled())
                 for (int s : need)
                     if (n_host[s] >= LMIN_MIN_N) big.push_back(s);
@@ -746,7 +759,8 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                     for (int p = 0; p < nv; p++)
                         if (fail[(size_t)p * batch + s] != 0) incf[s] = std::max(incf[s], kappaC_host[p] * C_host[s]);
                 ctx->ws_used = ws_after_plan;
-                IMCOM_TRY(lambda_min_subspace(ctx, batch, n_host, n_dev, Np, A, big, incf, ctx->repair_hint, factor_masked, solve_block, w0v, got));
+                for (int s : big) may_decide[s] = masked && attempt == 0 && known[s];
+                IMCOM_TRY(lambda_min_subspace(ctx, batch, n_host, n_dev, Np, A, big, incf, ctx->repair_hint, may_decide, decided, factor_masked, solve_block, w0v, got));
                 ctx->ws_used = ws_after_plan;
             }
             std::vector<int> rest;
@@ -760,10 +774,12 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
             }
             for (int s : need) {
                 rep[s] = fabs(w0v[s]) + 1e-16;
-                have_w0[s] = 1;
-                ctx->last_w0_min = ctx->last_repair_count ? std::min(ctx->last_w0_min, w0v[s]) : w0v[s];
-                ctx->last_w0_max = ctx->last_repair_count ? std::max(ctx->last_w0_max, w0v[s]) : w0v[s];
-                ctx->last_repair_count++;
+                have_w0[s] = decided[s] ? 0 : 1;  // (decided: w0v is a lower bound's witness, not the eigenvalue -- should the plain factorisation fail after all, the iteration runs again)
+                if (!decided[s]) {
+                    ctx->last_w0_min = ctx->last_repair_count ? std::min(ctx->last_w0_min, w0v[s]) : w0v[s];
+                    ctx->last_w0_max = ctx->last_repair_count ? std::max(ctx->last_w0_max, w0v[s]) : w0v[s];
+                    ctx->last_repair_count++;
+                }
                 // A stamp whose failure was the CALLER's expectation (redo = 2 without a factorisation having failed here): the smallest
                 // eigenvalue says whether A + kappa I is positive definite after all.  If it clearly is (w0 + kappa above 1e-6 kappa: the
                 // eigenvalue is good to 1e-11) the reference's cholesky() succeeds and nothing is repaired: the stamp is factored plainly in

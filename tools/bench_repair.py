@@ -15,7 +15,7 @@ stamps = [synth.make_stamp(cfg, i) for i in range(nb)]
 psfs, target = synth.make_psfs(cfg, cfg.n_expo)
 b = StampBatch(cfg, stamps, PSFGroupTables(psfs, target, cfg.nfft))
 b.run(); torch.cuda.synchronize()
-b.ctx.profile_enable(True); b.ctx.profile_reset()
+b.ctx.profile_enable(os.environ.get('BENCH_NOPROF') != '1'); b.ctx.profile_reset()
 t0 = time.perf_counter()
 for _ in range(reps):
     res = b.run()
