@@ -341,6 +341,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     // criterion of the first version, which cost a round of three steps and a Rayleigh-Ritz step in each phase only to confirm -- still
     // ends either phase when the residuals cannot (theta1 inside a cluster closer than its residual).
     static const int coarse_steps = getenv("IMCOM_LMIN_COARSE") ? std::max(1, atoi(getenv("IMCOM_LMIN_COARSE"))) : 6;
+    static const int lmin_parts = getenv("IMCOM_LMIN_PARTS") ? std::min(8, std::max(1, atoi(getenv("IMCOM_LMIN_PARTS")))) : 0;  // (A/B: split-K parts of the 128-column solves)
     static const int hinted_steps = getenv("IMCOM_LMIN_HINTED") ? std::max(1, atoi(getenv("IMCOM_LMIN_HINTED"))) : 7;  // (34 x (7.6e-3)^7: see the hint above)
     static const int round_steps = getenv("IMCOM_LMIN_FINE") ? std::max(1, atoi(getenv("IMCOM_LMIN_FINE"))) : 3;
     static const bool by_change = getenv("IMCOM_LMIN_BOUND") && strcmp(getenv("IMCOM_LMIN_BOUND"), "change") == 0;  // (A/B: the first version's criteria alone)
@@ -357,7 +358,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         for (int s : idx) if (run[s]) iters = std::max(iters, steps_wanted[s]);  // (a stamp's first round at its closer shift: see below)
         std::fill(steps_wanted.begin(), steps_wanted.end(), 0);
         for (int it = 0; it < iters; it++) {
-            IMCOM_TRY(solve(run, X, Y, part, splitk_parts(batch, 1)));
+            IMCOM_TRY(solve(run, X, Y, part, lmin_parts > 0 ? lmin_parts : splitk_parts(batch, 1)));
             IMCOM_TRY(orth());
         }
         // Z = A X, H = X^T Z, its eigenvalues and eigenvectors, the residuals of the two lowest pairs

@@ -380,7 +380,7 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
     assert not ref.info.any()
     want = None
     w0_abs = None
-    for mode in ("synchronous", "halves", "expected", "hint", "hint_small", "hint_large"):
+    for mode in ("synchronous", "halves", "expected", "hint", "hint_small", "hint_large", "hint_far"):
         sb = StampBatch(cfg, stamps, tabs)
         sb.build()
         for s, c in enumerate(shifts):
@@ -400,8 +400,9 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
         elif mode.startswith("hint"):
             # the driver's estimate of max |w[0]| (what the pass before found: StampBatch.repair_absmax): the iteration starts there.  A good one,
             # one that is too small for every failed stamp (their first factorisation fails: back to the shift they would have started with)
-            # and one that is three times too large (a slow first shift: a second factorisation, as without a hint) -- the same answers
-            f = {"hint": 1.0, "hint_small": 0.5, "hint_large": 3.0}[mode]
+            # one that is three times too large (a slow first shift: a second factorisation, as without a hint) and one from another regime
+            # (twenty times: the shift is replaced after the first Rayleigh-Ritz step by 2 (|theta| + |r|)) -- the same answers
+            f = {"hint": 1.0, "hint_small": 0.5, "hint_large": 3.0, "hint_far": 20.0}[mode]
             sb.solve_begin(expect_repair=True, repair_hint=f * w0_abs)
             assert sb.solve_end() is False and abs(sb.repair_share - np.mean(failed)) < 1e-12
             assert sum(failed) <= sb.ctx.last_repair()[0] <= len(stamps)  # (the repaired stamps' w[0]; a healthy one is only DECIDED to be positive definite)
