@@ -484,6 +484,11 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         for (int s : idx) if (ok[s]) { tmin = std::min(tmin, w0[s]); tmax = std::max(tmax, w0[s]); }
         int nok = 0;
         for (int s : idx) nok += ok[s] ? 1 : 0;
+        if (getenv("IMCOM_LMIN_DUMP")) {  // every stamp's value, in batch order
+            fprintf(stderr, "[lmin-w0]");
+            for (int s : idx) fprintf(stderr, " %.9e", ok[s] ? w0[s] : 0.0);
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[lmin] %zu stamps: %d factorisations (%d of them failed for some stamp), %d rounds; lambda_min %.6e .. %.6e; %d without an answer (the eigensolver's)\n", idx.size(), nfac,
                 nfac_failed, rounds_run, tmin, tmax, (int)idx.size() - nok);
     }

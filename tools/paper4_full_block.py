@@ -38,6 +38,8 @@ fam = ("psf_sample", "psf_spectra", "psf_overlap", "select", "build_A", "build_B
 st = {f: round(ctx.profile_get(f)[0], 1) for f in fam}
 out_map = maps.out_map.float().cpu().numpy()
 ps = [float(t) for t in maps.pass_seconds]
+if len(sys.argv) > 1:  # the plan's passes (for IMCOM_LMIN_DUMP=1 runs: which stamp each dumped eigenvalue belongs to)
+    json.dump([[list(map(int, t)) for t in c] for c in plan], open(sys.argv[1], "w"))
 print(json.dumps({"workload": "paper4 production block: 84 x 84 output stamps, n2 = 32, fade 3, INPAD 1.24, 6 exposures, 6 layers, a PSF group per 2 x 2 InStamps",
                   "stamps": n1P * n1P, "seconds": dt, "stamps_per_s": n1P * n1P / dt, "ms_per_stamp": dt * 1e3 / (n1P * n1P), "passes": len(plan),
                   "pass_sizes": sorted({len(c) for c in plan}), "pass_seconds": {"first": ps[0], "median": float(np.median(ps)), "max": max(ps), "last": ps[-1]},
