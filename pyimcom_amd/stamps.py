@@ -820,6 +820,11 @@ class StampBatch:
         self._deferred = True
 
     def solve_end(self):
+        """Wait for ``solve_begin()``'s work.  Stamps whose factorisation failed are solved again with the reference's repair
+        (lakernel.py:262-279) -- those stamps only (imcom_solve_chol_resident_redo; the others' outputs are final).  Returns False, or
+        the boolean mask [batch] of the stamps that were solved again: whatever the caller queued on the first attempt's outputs of
+        THOSE stamps (the coaddition) has to be queued again for them (``coadd(only=mask)``).  ``repair_share`` and ``repair_absmax``
+        then say what the next pass may expect."""
         try:
             return self._solve_end()
         finally:
@@ -827,10 +832,6 @@ class StampBatch:
                 self.ctx.set_repair_hint(0.0)  # (the hint was for this solve: a later call on the context starts without one)
 
     def _solve_end(self):
-        """Wait for ``solve_begin()``'s work.  Stamps whose factorisation failed are solved again with the reference's repair
-        (lakernel.py:262-279) -- those stamps only (imcom_solve_chol_resident_redo; the others' outputs are final).  Returns False, or
-        the boolean mask [batch] of the stamps that were solved again: whatever the caller queued on the first attempt's outputs of
-        THOSE stamps (the coaddition) has to be queued again for them (``coadd(only=mask)``)."""
         if getattr(self, "_unsolved", False):
             self._unsolved = False
             self.solve()
