@@ -168,6 +168,18 @@ def test_paper4_kernel_class_seam_vs_oracle():
     assert np.allclose(o.UC[0], Uo.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)
     assert np.allclose(o.Sigma[0], So.reshape(s2), rtol=1e-5 + 50 * cond * 2.2e-16, atol=1e-9)
     assert np.allclose(o.kappa[0], ko.reshape(s2), rtol=1e-5, atol=0)
+    # The reference's stamp loop calls the class stamp after stamp: the second call starts its smallest-eigenvalue iteration where the
+    # first one's ended (lakernel._repair_memory -> imcom_ctx_set_repair_hint).  Same stamp again: the same answer by the other path.
+    from pyimcom_amd.lakernel import _repair_memory
+
+    mem = _repair_memory._recent.get(id(K.ctx))
+    assert mem and 1e-6 < mem[-1] < 3e-6
+    o2 = make_outst(A.copy(), mB.copy(), C, cfg.n2f, kC, cfg.uctarget, cfg.sigmamax)
+    K2 = HipCholKernel(o2)
+    K2()
+    assert int(K2.info[0]) == 1 and len(mem) >= 2 and abs(mem[-1] - mem[-2]) <= 1e-9 * mem[-1]
+    assert np.abs(o2.T[0] - o.T[0]).max() <= 1e-6 * np.abs(o.T[0]).max()
+    assert K.ctx.last_repair()[0] == 1 and np.allclose(o2.UC[0], o.UC[0], rtol=1e-5, atol=1e-9)
 
 
 def test_paper4_block_in_several_passes_expects_the_repair():
