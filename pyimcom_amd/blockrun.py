@@ -578,7 +578,7 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
 
 
 def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None, chunks=None,
-                claim=None, origin=(1, 1)):
+                claim=None, origin=(1, 1), repair_state=None):
     """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
     order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables or BlockTables.  ``stamps``: the (j_st, i_st) to
     coadd (default all n1P x n1P); ``pad_sides=None`` leaves the boundary recovery of coadd.py:2163-2181 out.  ``batch``:
@@ -586,7 +586,9 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     right before pass q is prepared; a pass it refuses is left out (another process coadds it: pyimcom_amd.farm shares a block's
     passes between the GPUs of a node) -- the passes that were run are listed in ``maps.chunks_done``.  ``origin``: (j_st_min,
     i_st_min) of the reference's loop (coadd.py:1808-1838): with fade > 0 overlapping stamps are summed in the order of that loop
-    whatever the batches are (block.py).  Returns the BlockMaps."""
+    whatever the batches are (block.py).  ``repair_state``: a dict a driver keeps from block to block ({"share", "hint"}: what the last
+    pass saw of _cholesky_wrapper's repair) -- a block's first pass then starts where the previous block's last one ended instead of
+    blind.  Returns the BlockMaps."""
     nst = n1P + 2
     assert pool.n_inst == nst * nst
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
@@ -677,6 +679,8 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
                  # pass that follows such a pass does not attempt the factorisation that fails (StampBatch.solve_begin)
     hint = None  # max |w[0]| of the last pass that repaired stamps: where the next pass's smallest-eigenvalue iterations start (over a production
                  # block it stays within 1 % from pass to pass: profiles/r05_negative_results.txt item 7)
+    if repair_state:
+        share, hint = float(repair_state.get("share", 0.0)), repair_state.get("hint")
     while nxt is not None:
         sb = nxt
         sb.build()
@@ -714,6 +718,8 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         maps.info_nonzero += int(sum(int((np.asarray(i_) != 0).sum()) for i_ in sb.info_o))  # stamps repaired (Cholesky) / re-solved in the eigenbasis (Eigen)
         maps.pass_seconds.append(time.perf_counter() - t_pass)
         t_pass = time.perf_counter()
+    if repair_state is not None:
+        repair_state.update(share=share, hint=hint)
     if pad_sides is not None:
         maps.finalize(pad_sides, postage_pad)
     return maps

@@ -301,7 +301,10 @@ class _GpuBackend:
 
         from .blockrun import coadd_block
 
-        maps = coadd_block(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], spec["n_expo"], chunks=chunks, claim=claim, pad_sides=None)
+        # (what the last pass saw of the Cholesky repair travels from block to block: a block's first pass does not start blind)
+        self._repair_state = getattr(self, "_repair_state", {})
+        maps = coadd_block(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], spec["n_expo"], chunks=chunks, claim=claim, pad_sides=None,
+                           repair_state=self._repair_state)
         torch.cuda.synchronize()
         return maps.state(), list(maps.chunks_done)
 

@@ -210,6 +210,8 @@ def target_psfs(cfg, psfgrp, device, ctx=None):
     return psfs.sample_psf(imgs, ns, None, bool(cfg.psf_circ), bool(cfg.psf_norm), ctx)
 
 
+_REPAIR_STATE = {}  # per context: what the last pass of the last block saw of _cholesky_wrapper's repair (blockrun.coadd_block)
+
 def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None, ctx=None,
                         host_threads=1):
     """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  The stamps are those of the
@@ -266,7 +268,8 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     ahead.schedule([g for p in per_pass for g in p])
     try:
         maps = coadd_block(scfg, pool, tables, n1P, int(blk.n_inimage), chunks=chunks, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
-                           postage_pad=int(getattr(cfg, "postage_pad", 0)), origin=(window[0], window[2]))
+                           postage_pad=int(getattr(cfg, "postage_pad", 0)), origin=(window[0], window[2]),
+                           repair_state=_REPAIR_STATE.setdefault(id(tables.ctx), {}))  # (block after block of one run: the first pass does not start blind)
     finally:
         ahead.close()
     blk.out_map, blk.T_weightmap = maps.out_map.cpu().numpy(), maps.T_weightmap.cpu().numpy()
