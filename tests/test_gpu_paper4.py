@@ -213,7 +213,15 @@ def test_paper4_block_in_several_passes_expects_the_repair():
         assert calls == [False] and hints == [None]
         calls.clear()
         hints.clear()
-        four = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=4)
+        state = {}
+        four = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=4, repair_state=state)
+        # ... and a driver that keeps the state hands it to its next block: that block's FIRST pass already expects the repair and knows where
+        assert state["share"] == 1.0 and 1e-6 < state["hint"] < 3e-6
+        n_before, state_hint_before = len(calls), state["hint"]
+        again = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=8, repair_state=state)
+        assert calls[n_before:] == [True, True] and hints[n_before] == state_hint_before
+        assert float((again.out_map - four.out_map).abs().max()) <= 5e-6 * float(four.out_map.abs().max())
+        del calls[n_before:], hints[n_before:]
     finally:
         StampBatch.solve_begin = real
     torch.cuda.synchronize()
