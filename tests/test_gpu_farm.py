@@ -51,6 +51,35 @@ def test_farm_two_processes_equal_one(tmp_path):
     assert np.array_equal(np.load(farm.block_path(one, 2))["out_map"], keep)
 
 
+def test_farm_blocks_of_repaired_stamps_with_and_without_hints(tmp_path):
+    """The reference's production shape through the farm driver (four blocks of 2 x 2 paper4 stamps in passes of two: every stamp takes
+    _cholesky_wrapper's repair, lakernel.py:262-279): what a pass learns about the repair travels to the next pass AND to the next block
+    (blockrun.coadd_block repair_state: expectation and the smallest eigenvalues' whereabouts).  Against the same run with
+    IMCOM_LMIN_HINT=0, in which every smallest-eigenvalue iteration starts blind: the same maps to the rounding of the float32 T."""
+    from pyimcom_amd import farm
+
+    def run(out, env_extra):
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", PYTHONPATH=ROOT, **env_extra)
+        cmd = [sys.executable, "-m", "pyimcom_amd.farm", "--out", out, "--config", "paper4", "--mosaic", "2", "--n1P", "2", "--batch", "2", "--schedule", "static"]
+        p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:]
+        return p.stdout
+
+    hinted, blind = str(tmp_path / "hinted"), str(tmp_path / "blind")
+    o1 = run(hinted, {"IMCOM_LMIN_DEBUG": "1"})
+    run(blind, {"IMCOM_LMIN_HINT": "0"})
+    # the iterations of the hinted run: a pass that starts blind needs two factorisations inside its iteration, the second pass of every block
+    # -- neighbours of the first pass's stamps -- one.  (The blocks of this mosaic have PSFs and lattices of their own: their smallest
+    # eigenvalues differ by more than the hint's reach, so a block's first pass, handed the previous block's value, still takes two.)
+    facs = [int(l.split(" stamps: ")[1].split()[0]) for l in o1.splitlines() if l.startswith("[lmin]") and " stamps: " in l]
+    assert len(facs) == 8 and facs[0] == 2 and all(f == 1 for f in facs[1::2]) and all(f <= 2 for f in facs), facs
+    for b in range(4):
+        a, c = np.load(farm.block_path(hinted, b)), np.load(farm.block_path(blind, b))
+        assert np.isfinite(a["out_map"]).all() and np.abs(a["out_map"]).max() > 0
+        for k in ("out_map", "UC", "Sigma", "kappa"):
+            assert np.allclose(a[k], c[k], rtol=2e-5, atol=5e-6 * np.abs(c[k]).max()), (b, k)
+
+
 def test_farm_dynamic_schedule_shares_a_block(tmp_path):
     """The dynamic schedule with more ranks than blocks left: ONE block of 6 x 6 stamps in passes of 5 stamps, two processes on
     cuda:0.  The first rank to claim the block plans it; the other joins and takes passes from the end of the plan; the rank that
