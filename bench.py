@@ -104,24 +104,53 @@ def spread(ms):
 L2_GATHER_PEAK_GBS = 18800.0
 
 
-def roofline_build_A(n_arr, ms_per_step, traffic_bytes=None, traffic_src=None):
+def on_table_samples(batch, cfg):
+    """Samples (i <= j) of every stamp's symmetric half whose stencil lies ON the pair's overlap table -- the ones build_A_kernel stages and
+    interpolates; the others are left zero by the reference (psfutil.py:1691-1702: xi < 4 or xi >= ng - 5 ...) and by the kernel, and
+    are no work.  Counted on the device from the batch's own pixel lists with the kernel's test (csrc/build_a.hip: dx / dscale + nc + 6
+    truncated to a cell); at cfg-2 every sample is on its table, at the reference's benchmark shape 11 % are not."""
+    import numpy as np
+    import torch
+
+    ng, nc, ds = cfg.nsamp + 12, float(cfg.nc), float(cfg.dscale)
+    out = np.zeros(batch.batch, dtype=np.float64)
+    for s in range(batch.batch):
+        n = int(batch.n[s])
+        x, y = batch.x[s, :n], batch.y[s, :n]
+        tot = 0
+        step = max(1, (1 << 24) // max(n, 1))
+        for r0 in range(0, n, step):
+            r1 = min(n, r0 + step)
+            cx = torch.floor((x[r0:r1, None] - x[None, :]) / ds + nc + 6.0)
+            cy = torch.floor((y[r0:r1, None] - y[None, :]) / ds + nc + 6.0)
+            on = (cx >= 4) & (cx < ng - 5) & (cy >= 4) & (cy < ng - 5)
+            on &= torch.arange(n, device=x.device)[None, :] >= torch.arange(r0, r1, device=x.device)[:, None]
+            tot += int(on.sum())
+        out[s] = tot
+    return out
+
+
+def roofline_build_A(n_arr, ms_per_step, traffic_bytes=None, traffic_src=None, samples_on_table=None):
     """The A builder against the roofs that bound it ("a table-gather + FMA kernel -> LDS / L2 gather bandwidth and vector
-    fp64; report HBM GB/s").  Per sample of the symmetric half (N (N + 1) / 2 per stamp) the kernel stages the ten stencil rows of the
-    sample's overlap table as 5 x 16-byte LDS-DMA pieces each = 800 B from L1 / L2 into LDS, computes 330 flops and writes 8 B (16 with the
-    mirrored entry): the staged bytes per second against the guide's rate for LDS-DMA row gathers out of L2 is the roofline line; the
-    HBM side (A written once: 8 N^2 per stamp) and the vector-fp64 side are reported next to it."""
+    fp64; report HBM GB/s").  Per sample of the symmetric half that lies ON its overlap table (``samples_on_table`` per stamp, from
+    on_table_samples; default: all N (N + 1) / 2) the kernel stages the ten stencil rows as 5 x 16-byte LDS-DMA pieces each = 800 B from
+    L1 / L2 into LDS and computes 330 flops; every entry of A is written once (8 N^2 bytes per stamp).  SURVEY 8(d)'s own roofs are
+    ``hbm_frac`` (bytes written over 8 TB/s) and ``valu_frac`` (flops over the vector fp64 peak); ``frac`` is the staged bytes per second
+    over the guide's MEASURED rate for LDS-DMA row gathers out of L2 -- an empirical gather rate, not a bound, named so in the line."""
     import numpy as np
 
     n = np.asarray(n_arr, dtype=np.float64)
-    samples = float((n * (n + 1) / 2).sum())
+    half = float((n * (n + 1) / 2).sum())
+    samples = half if samples_on_table is None else float(np.asarray(samples_on_table, dtype=np.float64).sum())
     t = ms_per_step * 1e-3
     staged = samples * 800.0 / t / 1e9
     return {"kernel": "build_A_kernel", "bound": "l2-gather", "achieved": staged, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": staged / L2_GATHER_PEAK_GBS,
-            "samples_per_s": samples / t, "staged_bytes_per_sample": 800, "avg_launch_ms": ms_per_step,
+            "peak_is": "empirical gather rate (guide: LDS-DMA row gathers out of L2, measured), not a bound",
+            "samples_per_s": samples / t, "samples_on_table_share": samples / half if half else None, "staged_bytes_per_sample": 800, "avg_launch_ms": ms_per_step,
             "hbm_write_GBs": float((8.0 * n * n).sum()) / t / 1e9, "hbm_frac": float((8.0 * n * n).sum()) / t / 8e12,
             "valu_TFLOPs": 330.0 * samples / t / 1e12, "valu_frac": 330.0 * samples / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "traffic": traffic_bytes, "traffic_source": traffic_src,
-            "note": "achieved = 800 B staged per sample of the symmetric half over the launch time; peak = the guide's LDS-DMA row-gather rate out of L2"}
+            "note": "achieved = 800 B staged per on-table sample of the symmetric half over the launch time; SURVEY 8(d)'s roofs are hbm_frac and valu_frac"}
 
 
 def roofline_chol(n_arr, factorisations, ms_gemm, ms_diag, launches):
@@ -216,7 +245,8 @@ def cpu_baseline(cfg, stamps, psfs, target, budget_s=20.0, modes=("all", "one", 
         "cores": cores,
         "kind": "port",
         "sample": f"{done} whole {cfg.name} stamps (N~{stamps[0].n}, m={cfg.m}) through oracle/ on {cores} cores ({dt:.1f} s): C interpolators "
-                  f"with {omp} OpenMP threads, scipy potrf/potrs on {blas}" + (f"; then {done1} stamps on 1 thread ({dt1:.1f} s)" if done1 else ""),
+                  f"with {omp} OpenMP threads, " + ("numpy conjugate gradients per output pixel" if cfg.kernel == "Iterative" else "scipy potrf/potrs") + f" on {blas}"
+                  + (f"; then {done1} stamps on 1 thread ({dt1:.1f} s)" if done1 else ""),
         "blas": blas,
         "stage_ms_per_stamp": stages,
     }
@@ -625,7 +655,7 @@ def paper4_leg(ctx, dev, batch=128, steps=2, cpu_budget=25.0, block_passes=3):
                                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_k / FP64_MFMA_PEAK_TFLOPS, "ms_per_step": k_ms,
                                 "note": "the same launches without the eigenvalue iteration: the rate of a stamp whose A + kappa I is positive definite"},
            "roofline_chol": roofline_chol(n, facts, fams["chol_gemm"][0] / steps, fams["chol_diag"][0] / steps, fams["chol_gemm"][1] // steps),
-           "roofline_build_A": roofline_build_A(n, fams["build_A"][0] / steps),
+           "roofline_build_A": roofline_build_A(n, fams["build_A"][0] / steps, samples_on_table=on_table_samples(b, cfg)),
            "job_roofline_frac": job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "telemetry": telemetry}
     cpu_sample = stamps[:4]
     del b, tables
@@ -686,6 +716,142 @@ def paper4_leg(ctx, dev, batch=128, steps=2, cpu_budget=25.0, block_passes=3):
 
     try:
         out["block"] = block()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        traceback.print_exc(file=sys.stderr)
+        out["block"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    torch.cuda.synchronize()
+    release_buffers()
+    ctx.release_workspace()
+    torch.cuda.empty_cache()
+    if cpu_budget and cpu_budget > 0:
+        try:
+            cb = cpu_baseline(cfg, cpu_sample, psfs, target, cpu_budget, modes=("all",))
+            out["cpu_baseline"] = cb
+            out["vs_cpu"] = out["value"] / cb["value"]
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+def iter_default_leg(ctx, dev, batch=128, steps=2, cpu_budget=20.0, block_n1P=16):
+    """The Iterative kernel at the reference's DEFAULT configuration (configs/default_config.json and 70 more of its 152 configs;
+    synth.CONFIGS["iter_default"]): 32 x 32 outputs, INPAD 0.6" (rho = 15.36 output pixels), six exposures, six input layers, N ~ 2.8k,
+    KAPPAC [0.0], ITERRTOL 1.5e-3, ITERMAX 30 -- lakernel.IterKernel (lakernel.py:533-654) with conjugate_gradient (397-442) per output pixel
+    on the ~560 input pixels of its acceptance disc.  A step = A, B, the blocked conjugate gradients (csrc/iter_block.hip: 4 x 4 patches of
+    output pixels share the dense sub-matrix of the union of their discs, 16 recurrences per MFMA product), the maps, the clamp of
+    coadd.py:1104-1107, the coaddition of six layers.  Three figures: (1) resident batches; (2) a block of ``block_n1P``^2 stamps through
+    coadd_block, and next to it the SAME block by the Cholesky kernel at kappa/C = 5e-4 with the rms difference of the coadded science layer
+    (the reference's own criterion, tests/pyimcom/test_pyimcom.py:971-978: < 2.5e-3); (3) the oracle on the same stamps on the host.
+    Roofline of the CG launches: they stream every patch's sub-matrix once per step -- algorithmic bytes 8 up^2 per patch and step, flops
+    2 up^2 x 16 -- 0.4 flop per byte-time of the matrix pipe: HBM-bound."""
+    import dataclasses
+
+    import numpy as np
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd.blockrun import coadd_block, release_buffers
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    cfg = synth.CONFIGS["iter_default"]
+    stamps = [synth.make_stamp(cfg, i) for i in range(batch)]
+    psfs, target = synth.make_psfs(cfg, cfg.n_expo)
+    tables = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=dev)
+    b = StampBatch(cfg, stamps, tables, ctx=ctx, device=dev)
+    b.run()
+    torch.cuda.synchronize()
+    fam_names = ("build_A", "build_B", "iter_gather", "iter_cg", "finalize", "epilogue")
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fams = {f: ctx.profile_get(f) for f in fam_names}
+    ctx.profile_enable(False)
+    its, steps_px = ctx.iter_stats(batch * cfg.m)
+    n = b.n.astype(np.float64)
+    cg_ms, cg_launches = fams["iter_cg"]
+    cg_s = cg_ms * 1e-3 / steps
+    out = {"value": batch / dt, "unit": "postage-stamps/s", "ms_per_stamp": dt / batch * 1e3, "ms_per_step": dt * 1e3, "batch": batch, "steps": steps,
+           "N_mean": float(n.mean()), "N_max": int(n.max()), "m": cfg.m, "n_inframe": cfg.n_inframe, "n_expo": cfg.n_expo, "kappaC": list(cfg.kappaC),
+           "iter_rtol": cfg.iter_rtol, "iter_max": cfg.iter_max, "rho_acc": cfg.rho, "kernel": cfg.kernel,
+           "stage_ms_per_step": {k: v[0] / steps for k, v in fams.items() if v[0] > 0},
+           "patches": its["patches"], "max_union": its["max_union"], "blocked_solver": its["blocked"],
+           "cg_steps_mean": float(steps_px.mean()), "cg_steps_max": int(steps_px.max()), "cg_pixels_at_itermax": float((steps_px >= cfg.iter_max).mean()),
+           "cg_steps_per_patch": its["patch_steps"] / max(its["patches"], 1),
+           "config": "configs/default_config.json of the reference (LAKERNEL Iterative, KAPPAC [0.0], OUTSIZE [80, 32, 0.0390625], INPAD 0.6, ITERRTOL 1.5e-3, "
+                     "ITERMAX 30, NPIXPSF 48, GAUSSIAN target, five EXTRAINPUT layers) at six exposures, analytic Roman-like PSFs",
+           "roofline": {"kernel": "iter_block_cg_kernel (16 conjugate-gradient recurrences per 4 x 4 patch, one MFMA product per step)", "bound": "hbm",
+                        "achieved": its["bytes"] / cg_s / 1e9 if cg_s else None, "peak": 8000.0, "unit": "GB/s", "frac": its["bytes"] / cg_s / 8e12 if cg_s else None,
+                        "bytes_per_launch": its["bytes"] * steps / max(cg_launches, 1), "avg_launch_ms": cg_ms / max(cg_launches, 1), "launches": cg_launches // max(steps, 1),
+                        "mfma_TFLOPs": its["flops"] / cg_s / 1e12 if cg_s else None, "mfma_frac": its["flops"] / cg_s / 1e12 / FP64_MFMA_PEAK_TFLOPS if cg_s else None,
+                        "count": "8 up^2 bytes and 32 up^2 flops per patch and CG step, up = the patch's union selection rounded up to 16 (the sub-matrix is "
+                                 "stored and read in full, both triangles)", "traffic": None}}
+    job = its["flops"] + float((165.0 * n * (n + 1) + 220.0 * n * cfg.m).sum())
+    out["job_roofline_frac"] = job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS
+    cpu_sample = stamps[:8]
+    del b, tables
+    torch.cuda.synchronize()
+    release_buffers()
+    ctx.release_workspace()
+    torch.cuda.empty_cache()
+
+    def block():
+        n1P, E = block_n1P, cfg.n_expo
+        rng = np.random.default_rng(11)
+        inst = synth.make_instamps(cfg, n1P, E, rng)
+        # the science layer: a field of unit-flux stars seen through a Gaussian of 0.9 native pixels (smooth, like the reference test's image)
+        p = synth.NATIVE_ARCSEC / cfg.dtheta_as
+        span = n1P * cfg.n2
+        sx, sy = rng.uniform(0, span, 24), rng.uniform(0, span, 24)
+        sig = 0.9 * p
+        inst2 = []
+        for (px, py, data, cum) in inst:
+            d = data.copy()
+            d[0] = (np.exp(-0.5 * ((px[:, None] - sx[None]) ** 2 + (py[:, None] - sy[None]) ** 2) / sig**2).sum(axis=1) / (2 * np.pi * 0.9**2)).astype(np.float32)
+            inst2.append((px, py, d, cum))
+        pool = InStampPool(inst2, cfg.n_inframe, device=dev)
+        tabs = PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx, device=dev)
+        coadd_block(cfg, pool, tabs, n1P, E, pad_sides=None)  # warm-up (buffers, workspace)
+        torch.cuda.synchronize()
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        maps = coadd_block(cfg, pool, tabs, n1P, E, pad_sides=None)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        st = {f: ctx.profile_get(f)[0] for f in ("select",) + fam_names}
+        ctx.profile_enable(False)
+        img_it = maps.out_map[0, 0].cpu().numpy().copy()
+        passes = list(getattr(maps, "chunk_sizes", []))
+        del maps
+        release_buffers()
+        ctx.release_workspace()
+        torch.cuda.empty_cache()
+        # the same block by the Cholesky kernel at the kappa the reference's own end-to-end test uses for this comparison (5e-4 C)
+        chol = dataclasses.replace(cfg, kernel="Cholesky", kappaC=(5e-4,))
+        t0 = time.perf_counter()
+        mc = coadd_block(chol, pool, tabs, n1P, E, pad_sides=None)
+        torch.cuda.synchronize()
+        dtc = time.perf_counter() - t0
+        img_ch = mc.out_map[0, 0].cpu().numpy().copy()
+        lo, hi = cfg.n2 // 2, n1P * cfg.n2 - cfg.n2 // 2  # (the block's inner part: the boundary recovery is left out on both sides)
+        d = (img_it - img_ch)[lo:hi, lo:hi]
+        return {"n1P": n1P, "stamps_per_block": n1P * n1P, "value": n1P * n1P / dtb, "unit": "postage-stamps/s", "ms_per_stamp": dtb * 1e3 / (n1P * n1P), "ms_per_block": dtb * 1e3,
+                "passes": passes, "stage_ms": {k: v for k, v in st.items() if v > 0}, "cholesky_block_ms": dtc * 1e3,
+                "image_rms_vs_cholesky": float(d.std()), "image_mean_vs_cholesky": float(d.mean()), "image_std": float(img_ch[lo:hi, lo:hi].std()),
+                "image_peak": float(np.abs(img_ch).max()), "criterion": "std < 2.5e-3 and |mean| < 2e-4 (tests/pyimcom/test_pyimcom.py:971-978)",
+                "what": "a block of n1P^2 stamps through coadd_block (ONE PSF group; selection, A, B, CG, coaddition, block maps), then the same block "
+                        "by the Cholesky kernel at kappa/C = 5e-4; rms of the science layer's difference"}
+
+    try:
+        out["block"] = block()
+        out["image_rms_vs_cholesky"] = out["block"]["image_rms_vs_cholesky"]
     except Exception as e:  # noqa: BLE001
         import traceback
 
@@ -769,6 +935,16 @@ def summary_of(out):
                 sm["paper4"]["block"] = {"error": blk["error"][:60]} if "error" in blk else {"v": r3(blk.get("value")), "s_per_block": r3(blk.get("seconds_per_block"))}
                 if isinstance(p4.get("cpu_baseline"), dict) and "value" in p4["cpu_baseline"]:
                     sm["paper4"]["cpu"] = r3(p4["cpu_baseline"]["value"])
+        if "iter_default" in cf:
+            it_ = cf["iter_default"]
+            sm["iter_default"] = leg(it_, ("cg_steps_mean", "image_rms_vs_cholesky"))
+            if isinstance(it_, dict) and "error" not in it_:
+                if isinstance(it_.get("roofline"), dict):
+                    sm["iter_default"]["bound"] = it_["roofline"].get("bound")
+                if isinstance(it_.get("block"), dict):
+                    sm["iter_default"]["block_v"] = {"error": it_["block"]["error"][:60]} if "error" in it_["block"] else r3(it_["block"].get("value"))
+                if isinstance(it_.get("cpu_baseline"), dict) and "value" in it_["cpu_baseline"]:
+                    sm["iter_default"]["cpu"] = r3(it_["cpu_baseline"]["value"])
     if "farm" in out:
         sm["farm"] = leg(out["farm"], ("makespan_s", "blocks", "ranks_seen"))
     cb = out.get("cpu_baseline")
@@ -776,6 +952,89 @@ def summary_of(out):
         sm["cpu"] = {"v": r3(cb["value"]), "cores": cb.get("cores"), "v1": r3(cb.get("one_thread", {}).get("value")), "vP": r3(cb.get("processes", {}).get("value")),
                      "P": cb.get("processes", {}).get("processes")}
     return sm
+
+
+def _sig(x, digits=5):
+    """Floats of the compact line carry `digits` significant digits (the detail file keeps everything)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+COMPACT_LIMIT = 4000  # bytes of the line a driver parses (VERDICT r05: a 22 KB line came back as parsed = null)
+
+
+def compact_line(out, detail_path=None, limit=COMPACT_LIMIT):
+    """The ONE line bench.py prints on stdout, last: the contract's keys, the dominant kernel's roofline, the CPU baseline and the
+    summary of every leg, below ``limit`` bytes whatever the legs reported (every verbose object -- configs, block, eigen_block,
+    telemetry, per-step times, stage splits, the legs' own rooflines -- is in the detail file and on stderr).  Should the line still
+    exceed the limit (it never has: ~2.6 KB with every leg), summary entries are dropped from the end until it fits; the contract's
+    keys, ``roofline`` and ``cpu_baseline`` are never dropped."""
+    keep = ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "ms_per_stamp", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: out[k] for k in keep if k in out}
+    cf = out.get("config", {})
+    line["config"] = {k: (cf[k][:200] if isinstance(cf[k], str) else cf[k]) for k in ("workload", "stamps_per_step_per_gpu", "N_mean", "m", "parallelism") if k in cf}
+    rf = out.get("roofline", {})
+    line["roofline"] = {k: (rf[k][:120] if isinstance(rf[k], str) else rf[k]) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                                                                         "avg_launch_ms", "launches", "flops_per_launch") if k in rf}
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        if "error" in cb:
+            line["cpu_baseline"] = {"error": cb["error"][:120]}
+        else:
+            c = {k: (cb[k][:160] if isinstance(cb[k], str) else cb[k]) for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+            if isinstance(cb.get("one_thread"), dict):
+                c["one_thread"] = cb["one_thread"].get("value")
+            if isinstance(cb.get("processes"), dict) and "value" in cb["processes"]:
+                c["processes"] = {"value": cb["processes"]["value"], "processes": cb["processes"].get("processes")}
+            line["cpu_baseline"] = c
+    if out.get("farm") is not None and isinstance(out["farm"], dict):
+        line["farm"] = {k: out["farm"].get(k) for k in ("value", "makespan_s", "blocks", "ranks_seen", "host_build_s", "per_rank_busy_s", "error") if out["farm"].get(k) is not None}
+        if isinstance(line["farm"].get("error"), str):
+            line["farm"]["error"] = line["farm"]["error"][:120]
+    if out.get("per_rank_value") and out.get("n_gpus", 1) > 1:
+        line["per_rank_value"] = out["per_rank_value"]
+    line["summary"] = dict(out.get("summary") or {})
+    line["detail"] = detail_path
+    line = _sig(line)
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text) > limit and line["summary"]:
+        line["summary"].pop(next(reversed(line["summary"])))
+        line["summary_truncated"] = True
+        text = json.dumps(line, separators=(",", ":"))
+    for k in ("farm", "per_rank_value"):  # (an 8-rank farm leg's lists: still not at the price of the contract's keys)
+        if len(text) > limit and k in line:
+            line.pop(k)
+            text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def write_detail(out):
+    """Everything the legs reported, as JSON, beside bench.py (``bench_detail.json``; also under gpurun_out/ when that directory exists,
+    so that a gpurun call brings it back) -- and on stderr, one "[bench detail] key: value" line per top-level key."""
+    text = json.dumps(out)
+    paths = [os.environ.get("IMCOM_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and not os.environ.get("IMCOM_BENCH_DETAIL"):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for p_ in paths:
+        try:
+            with open(p_, "w") as f:
+                f.write(text + "\n")
+            written = written or os.path.relpath(p_, ROOT)
+        except OSError:
+            pass
+    for k, v in out.items():  # stderr: one prefixed line per top-level key (never a bare JSON line: stdout's last line is the only one of those)
+        print(f"[bench detail] {k}: {json.dumps(v)}", file=sys.stderr)
+    sys.stderr.flush()
+    return written
 
 
 def farm_leg(rank, world, dev, dist, cdev, mosaic=4, n1P=32, config="cfg4", seed=4):
@@ -1073,8 +1332,7 @@ def main():
         # configuration BASELINE names for N GPUs)
         from pyimcom_amd.blockrun import release_buffers as _rb
 
-        del batch
-        batch_n, batch_info = None, None
+        batch = None
         torch.cuda.synchronize()
         ctx.release_workspace()
         torch.cuda.empty_cache()
@@ -1150,7 +1408,8 @@ def main():
             facts = 1 + (1 if int((info_keep != 0).sum()) else 0)
             out["roofline_chol"] = roofline_chol(n_arr, facts, fams["chol_gemm"][0] / args.steps, fams["chol_diag"][0] / args.steps, fams["chol_gemm"][1] // max(args.steps, 1))
         tr_a, tr_src = pmc_kernel_traffic("build_A_kernel", args.batch, cfg.name)
-        out["roofline_build_A"] = roofline_build_A(n_arr, fams["build_A"][0] / args.steps, tr_a, tr_src)
+        out["roofline_build_A"] = roofline_build_A(n_arr, fams["build_A"][0] / args.steps, tr_a, tr_src,
+                                                   samples_on_table=on_table_samples(batch, cfg) if batch is not None else None)
         if farm_out is not None:
             out["farm"] = farm_out
         from pyimcom_amd.blockrun import release_buffers
@@ -1196,14 +1455,19 @@ def main():
             tidy()
             # the reference's own benchmark shape (not a BASELINE config: the shape its users run)
             out["configs"]["paper4"] = leg(lambda: paper4_leg(ctx, dev, cpu_budget=0.0 if args.no_cpu_baseline else min(args.cpu_budget, 25.0)))
+            tidy()
+            # the reference's DEFAULT configuration: the Iterative kernel at kappa = 0 (71 of its 152 configs)
+            out["configs"]["iter_default"] = leg(lambda: iter_default_leg(ctx, dev, cpu_budget=0.0 if args.no_cpu_baseline else min(args.cpu_budget, 20.0)))
         if world == 1 and args.farm:  # (N = 1: the same mosaic on one GPU, for the scaling curve's first point; opt-in)
             batch = None
             tidy()
             out["farm"] = leg(lambda: farm_leg(0, 1, dev, None, "cpu", mosaic=args.farm_mosaic, n1P=args.farm_n1P))
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = leg(lambda: cpu_baseline(cfg, cpu_sample, psfs, target, args.cpu_budget))
-        out["summary"] = summary_of(out)  # LAST: the compact form of every leg, inside the tail a driver keeps of a long line
-        print(json.dumps(out))
+        out["summary"] = summary_of(out)
+        # verbose objects: the detail file and stderr; stdout's LAST line: the compact object a driver parses (< 4 KB)
+        sys.stdout.flush()
+        print(compact_line(out, write_detail(out)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

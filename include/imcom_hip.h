@@ -199,6 +199,14 @@ int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
                      double smax, const double *out_yx, const double *in_y, const double *in_x,
                      double rho_acc, double rtol, int maxiter, int exact_UC, float *T, float *UC,
                      float *Sigma, float *kappa, int memspace);
+/* What the last imcom_solve_iter call on this context did at its LAST kappa node (the reference has no counterpart: its
+ * conjugate_gradient, lakernel.py:397-442, returns x only; a parity test of recurrences that stop at maxiter needs the step
+ * counts, and the bench its roofline).  stats[8] (host): [0] 4 x 4 patches solved by the blocked solver, [1] sum over the
+ * patches of (union size rounded up to 16)^2 x steps the patch ran (x 2 x 16 = its flops, x 8 = the bytes of sub-matrix it
+ * streamed), [2] sum of steps, [3] sum of (union size)^2, [4] largest union of a patch, [5] 1 = blocked solver, 0 = the
+ * per-pixel kernel (a union above 1024), [6..7] reserved.  steps (host, optional): CG steps used per output pixel
+ * [batch][m], nsteps = batch * m of that call. */
+int imcom_solve_iter_stats(imcom_ctx *ctx, double *stats, int *steps, long nsteps);
 /* imcom_solve_empir: T_ai = max(rho_acc - dist_ai, 0) / sum_i max(rho_acc - dist_ai, 0) (a pixel with no input
  * pixel in range gets NaN, as in the reference); kappa = kappaC0 * C, Sigma = sum T^2, UC = 1 + (T A T^T - 2 D)/C.
  * no_qlt_ctrl != 0 (cfg.no_qlt_ctrl, coadd.py:856-858): only T is produced, A / mBhalf / C may be NULL and the

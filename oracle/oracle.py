@@ -211,13 +211,15 @@ def eigen_kernel(A, mBhalf, C_, kappaC, ucmin, smax, nbis=13):
     return T, UC, Sigma, kappa, 0
 
 
-def conjugate_gradient(A, b, rtol=1.5e-3, maxiter=30):
-    """lakernel.conjugate_gradient (lakernel.py:397-442): plain CG from x = 0, stop when |r| < rtol |b|."""
+def conjugate_gradient(A, b, rtol=1.5e-3, maxiter=30, info=None):
+    """lakernel.conjugate_gradient (lakernel.py:397-442): plain CG from x = 0, stop when |r| < rtol |b|.  ``info`` (a list, test
+    instrumentation the reference does not have): receives the number of steps taken."""
     atol = np.linalg.norm(b) * rtol
     x = np.zeros_like(b)
     r = b.copy()
     rho_prev = 0.0
     p = r.copy()
+    steps = 0
     for iteration in range(maxiter):
         rho_cur = np.dot(r, r)
         if rho_cur**0.5 < atol:
@@ -230,6 +232,9 @@ def conjugate_gradient(A, b, rtol=1.5e-3, maxiter=30):
         x += alpha * p
         r -= alpha * q
         rho_prev = rho_cur
+        steps += 1
+    if info is not None:
+        info.append(steps)
     return x
 
 
@@ -238,18 +243,19 @@ def _relevant(out_y, out_x, in_y, in_x, rho_acc):
     return np.hypot(out_y[:, None] - in_y[None, :], out_x[:, None] - in_x[None, :]) < rho_acc
 
 
-def _iterative_wrapper(AA, mBhalf, relevant, rtol, maxiter):
-    """lakernel.IterKernel._iterative_wrapper (545-586): one restricted CG solve per output pixel, float32 T."""
+def _iterative_wrapper(AA, mBhalf, relevant, rtol, maxiter, steps=None):
+    """lakernel.IterKernel._iterative_wrapper (545-586): one restricted CG solve per output pixel, float32 T.  ``steps`` (a list,
+    test instrumentation): receives the CG steps of every output pixel."""
     m, n = mBhalf.shape
     Ti = np.zeros((m, n), dtype=np.float32)
     for a in range(m):
         sel = np.nonzero(relevant[a])[0]
-        Ti[a, sel] = conjugate_gradient(AA[np.ix_(sel, sel)], mBhalf[a, sel], rtol, maxiter)
+        Ti[a, sel] = conjugate_gradient(AA[np.ix_(sel, sel)], mBhalf[a, sel], rtol, maxiter, info=steps)
     return Ti
 
 
 def iter_kernel(A, mBhalf, C_, kappaC, ucmin, smax, out_y, out_x, in_y, in_x, rho_acc, rtol=1.5e-3, maxiter=30,
-                exact_UC=None):
+                exact_UC=None, steps=None):
     """lakernel.IterKernel for ONE target PSF (single kappa 588-654, multi kappa 656-744).  exact_UC None takes the
     reference defaults (False for one node, True for several)."""
     kappaC = np.atleast_1d(np.asarray(kappaC, dtype=np.float64))
@@ -265,7 +271,7 @@ def iter_kernel(A, mBhalf, C_, kappaC, ucmin, smax, out_y, out_x, in_y, in_x, rh
         my_kappa = kappaC[0] * C_
         if my_kappa:
             AA[di] += my_kappa
-        Ti = _iterative_wrapper(AA, mBhalf, relevant, rtol, maxiter)
+        Ti = _iterative_wrapper(AA, mBhalf, relevant, rtol, maxiter, steps=steps)
         D = np.einsum("ai,ai->a", mBhalf, Ti)
         N = np.einsum("ai,ai->a", Ti, Ti)
         kappa[:] = my_kappa
@@ -881,7 +887,7 @@ def stamp_full(cfg, g, tables_pad, C, stamp, pair_tab, pair_pen, io_tab, timings
         oy, ox = np.repeat(stamp.out_y0 + g1, cfg.n2f), np.tile(stamp.out_x0 + g1, cfg.n2f)
         if cfg.kernel == "Iterative":
             T, UC, Sigma, kappa, info = iter_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax, oy, ox,
-                                                    stamp.y, stamp.x, cfg.rho)
+                                                    stamp.y, stamp.x, cfg.rho, getattr(cfg, "iter_rtol", 1.5e-3), getattr(cfg, "iter_max", 30))
             UC, Sigma = iterative_clamp(UC, Sigma)
         else:
             T, UC, Sigma, kappa, info = empir_kernel(A, mB, C, np.array(cfg.kappaC), oy, ox, stamp.y, stamp.x, cfg.rho)

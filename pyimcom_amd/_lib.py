@@ -80,6 +80,7 @@ SIGNATURES = {
     "imcom_solve_eigen": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _i],
     "imcom_solve_eigen_resident": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _i, _vp, _vp, _vp, _vp, _vp],
     "imcom_solve_iter": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _d, _d, _i, _i, _vp, _vp, _vp, _vp, _i],
+    "imcom_solve_iter_stats": [_vp, _vp, _vp, _l],
     "imcom_solve_empir": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _i],
     "imcom_eigh": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i],
     "imcom_band_reduce": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i],
@@ -300,6 +301,19 @@ class Context:
         ms, n = _d(0.0), _l(0)
         check(lib.imcom_ctx_profile_get(self.handle, family.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def iter_stats(self, nsteps=None):
+        """What the last imcom_solve_iter call on this context did at its last kappa node (imcom_solve_iter_stats): a dict -- patches of
+        4 x 4 output pixels, flops / bytes of their conjugate-gradient steps, the largest union selection, whether the blocked solver ran
+        -- and, with ``nsteps`` = batch * m of that call, the CG steps used per output pixel (int32 [nsteps])."""
+        import numpy as np
+
+        st = (_d * 8)()
+        steps = None if nsteps is None else np.zeros(int(nsteps), dtype=np.int32)
+        check(lib.imcom_solve_iter_stats(self.handle, st, None if steps is None else _vp(steps.ctypes.data), 0 if steps is None else int(nsteps)))
+        out = {"patches": int(st[0]), "up2_steps": float(st[1]), "patch_steps": float(st[2]), "up2": float(st[3]), "max_union": int(st[4]),
+               "blocked": bool(st[5]), "flops": 32.0 * float(st[1]), "bytes": 8.0 * float(st[1])}
+        return (out, steps) if nsteps is not None else out
 
     def mfma_probe(self, millis=50.0):
         """Rate [TFLOP/s] of a pure fp64 MFMA loop on every SIMD (imcom_ctx_mfma_probe): the chip's ceiling under matrix load."""

@@ -258,7 +258,10 @@ def pass_bytes(nb, ldn, ldm, n_out=1, kernel="Cholesky", resident=2, nv=1, n_inf
         check(lib.imcom_solve_eigen_workspace(nb, int(ldn), int(ldm), int(ldm), ctypes.byref(ws)))
         return nb * (base + resident * small) + max(ws.value, table_ws) + (2 << 20)
     if kernel == "Iterative":
-        return nb * (base + resident * small + extra) + max(nb * (ldm // 16 + 1) * ITER_PATCH_BYTES, table_ws)  # one dense union sub-matrix per 4 x 4 patch (csrc/iter_empir.hip)
+        # the blocked CG (csrc/iter_block.hip): every 4 x 4 patch's selection (6 KB), and the dense union sub-matrices of as many patches
+        # at a time as fit a fixed share of 8 GiB (imcom_solve_iter)
+        patches = nb * (ldm // 16 + 1)
+        return nb * (base + resident * small + extra) + max(min(8 << 30, patches * ITER_PATCH_BYTES) + patches * 6200 + nb * ldm * 256 + (64 << 20), table_ws)
     return nb * (base + resident * small + extra) + max(nb * 8 * ldn * ldn, table_ws)
 
 
@@ -358,7 +361,7 @@ def memory_plan(cfg, pool, n1P, n_psf, n_out=1, nfft=None, ctx=None, cap=256, ke
             "available": int(avail), "block_tables": int(block_tables)}
 
 
-ITER_PATCH_BYTES = 512 * 512 * 8 + 512 * 16 * 8 + 512 * 8  # iter_block_ws_bytes (csrc/iter_block.hip), per 4 x 4 patch
+ITER_PATCH_BYTES = 1024 * 1024 * 8 + 3 * 1024 * 16 * 8  # iter_block_patch_bytes(1024) (csrc/iter_block.hip): sub-matrix, right-hand sides, x, q of a 4 x 4 patch
 
 
 def stamp_groups(j_st, i_st, nst):
@@ -629,15 +632,28 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         bufs[0].take("Tt", (O, bmax, ld_pre, ldm), torch.float32)
     todo = iter(range(len(chunks)))
     count = [0]
+    claimed = []      # the passes this process took (claim(q) said yes): every one of them must end up in maps.chunks_done
+    pending = [None]  # a pass that was taken but whose preparation failed: the next call prepares THAT pass again, never a new one
 
     def next_batch():
-        for q in todo:  # the next pass this process may run
-            if chunks[q] and (claim is None or claim(q)):
-                sb = prepare_batch(cfg, pool, tables, chunks[q], n1P, n_expo, ldn, buffers=bufs[count[0] & 1])
-                sb.chunk_index, sb.buf_index = q, count[0] & 1
-                count[0] += 1
-                return sb
-        return None
+        """The next pass this process may run, prepared.  Taking a pass (the claim, under the farm a file other ranks see) and preparing it
+        are separate: when the preparation raises -- out of memory in its gathers, IMCOM_ERR_NOMEM of a table call -- the pass stays
+        ``pending`` and the next call prepares it again, so a pass that was claimed is never skipped."""
+        q = pending[0]
+        if q is None:
+            for q_ in todo:
+                if chunks[q_] and (claim is None or claim(q_)):
+                    q = q_
+                    claimed.append(q)
+                    break
+        if q is None:
+            return None
+        pending[0] = q
+        sb = prepare_batch(cfg, pool, tables, chunks[q], n1P, n_expo, ldn, buffers=bufs[count[0] & 1])
+        pending[0] = None
+        sb.chunk_index, sb.buf_index = q, count[0] & 1
+        count[0] += 1
+        return sb
 
     # software pipeline: the next chunk is prepared on the host (and its selection / table kernels queued) right after the current
     # one's A and B builds AND its solve have been queued (solve_begin: the Cholesky kernel's launches without their read-back), i.e.
@@ -648,8 +664,12 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         return e.status == -3 or (e.status == -2 and "out of memory" in str(e))  # IMCOM_ERR_NOMEM, or a launch / allocation HIP refused for lack of memory
 
     def in_halves(sb):
-        """A pass the device has no memory for after all (the plan is an estimate: 0.7-0.8 of what is free divided by a model of a stamp's
-        needs) is run again as two passes of half the stamps, cut on a cell boundary, in the failed pass's buffers."""
+        """The emergency route.  A plan fills 0.97 of what torch's allocator reports as available with exact figures for this process
+        (plan_block), but not for what else shares the device: a pass the device has no memory for after all is run again as two passes
+        of half the stamps, cut on a cell boundary, in the failed pass's buffers.  The failure may have come from solve_begin, from the
+        preparation of the NEXT pass or from solve_end, so launches of the failed pass (its builds, a deferred solve) may still be queued
+        on the ONE set of A / -B/2 / T arrays the halves are about to overwrite: the synchronize below is what makes that safe -- nothing
+        of the failed pass is read after it, its results are discarded."""
         import torch
 
         torch.cuda.synchronize()
@@ -705,7 +725,7 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
                 nxt = prepare_batch(cfg, pool, tables, chunks[q_], n1P, n_expo, ldn, buffers=bufs[b_])
                 nxt.chunk_index, nxt.buf_index = q_, b_
             elif not pipeline or nxt is sb:
-                nxt = next_batch()
+                nxt = next_batch()  # (a pass whose preparation failed above is still pending: it is prepared again, not skipped)
             continue
         share = float(getattr(sb, "repair_share", 0.0))
         hint = getattr(sb, "repair_absmax", None) or hint
@@ -720,6 +740,8 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         t_pass = time.perf_counter()
     if repair_state is not None:
         repair_state.update(share=share, hint=hint)
+    if sorted(claimed) != sorted(maps.chunks_done):  # (never seen; a pass that was taken and not coadded would be a silent hole in the maps)
+        raise RuntimeError(f"coadd_block: passes taken {sorted(claimed)} but coadded {sorted(maps.chunks_done)}")
     if pad_sides is not None:
         maps.finalize(pad_sides, postage_pad)
     return maps

@@ -90,6 +90,9 @@ struct imcom_ctx {
     std::vector<imcom::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
     int cu_count = 256;
+    // imcom_solve_iter_stats: what the last imcom_solve_iter call did at its last kappa node
+    double iter_stats[6] = {0, 0, 0, 0, 0, 0};  // patches, sum up^2 steps, sum steps, sum up^2, largest union, 1 = blocked solver
+    std::vector<int> iter_steps;                // CG steps per output pixel [batch][m]
 };
 
 namespace imcom {

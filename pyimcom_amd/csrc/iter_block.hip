@@ -3,8 +3,10 @@
 //
 // The reference solves, per output pixel a, the sub-system of the input pixels within rho_acc of a by conjugate gradients.
 // Neighbouring output pixels select almost the same input pixels, so one workgroup takes a 4 x 4 patch of output pixels:
-//   * the union U of their selections (ascending, <= BCG_UMAX), a 16-bit mask per member (which of the 16 pixels select it);
-//   * the dense sub-matrix AU = AA[U][U] once, in workspace (iter_block_setup_kernel);
+//   * the union U of their selections (ascending, <= BCG_UMAX), a 16-bit mask per member (which of the 16 pixels select it)
+//     (iter_block_select_kernel);
+//   * the dense sub-matrix AU = AA[U][U] once, in workspace, as 16 x 16 tiles of 2 KB each, tile-row major
+//     (iter_block_gather_kernel): the solver streams a tile row as one contiguous run;
 //   * 16 conjugate-gradient recurrences in step (iter_block_cg_kernel): vectors outside a pixel's own selection are kept at zero
 //     (masked p, r, q), which makes each recurrence exactly the CG on its own sub-matrix; the products q = AU p for all 16
 //     pixels are ONE 16-column matrix product per step on the fp64 MFMA (v_mfma_f64_16x16x4_f64), so the sub-matrix is read once
@@ -12,8 +14,15 @@
 //     pixel and step and runs at the rate of those gathers;
 //   * every recurrence stops on its own test (|r| < rtol |b|, checked at the top of a step as the reference does) and is frozen
 //     from then on.
+// At the reference's default configuration (configs/default_config.json: OUTSIZE [., 32, 0.0390625], INPAD 0.6 -> rho = 15.36
+// output pixels, six exposures, KAPPAC [0.0]) a pixel selects ~560 input pixels and a patch's union ~700: the sub-matrix is 4 MB,
+// no recurrence converges in 30 steps, and a step is bound by reading those 4 MB out of HBM (2 x 700^2 x 16 flops against them is
+// 0.4 of that time on the matrix pipe).  Round 6: unions up to 1024 (until then 512: the default configuration fell back to the
+// per-pixel kernel), tile-major storage, loads that run ahead across the tile rows, per-pixel step counts.
 // Sums run in another order than numpy's; what that means for a recurrence that does not converge is described in DESIGN.md
 // ("Iterative kernel and rounding") and is the same statement as for the per-pixel kernel.
+#include <algorithm>
+
 #include "common.h"
 #include "launchers.h"
 
@@ -22,11 +31,12 @@ namespace imcom {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BCG_R = 16;                  // output pixels (right-hand sides) per block
-constexpr int BCG_UMAX = 512;              // members of a block's union selection (multiple of 16)
-constexpr int BCG_TILES = BCG_UMAX / 16;   // 16-row tiles of the union
-constexpr int BCG_TPW = BCG_TILES / 4;     // tiles per wave (4 waves)
-constexpr int BCG_CH = 4;                  // k-tiles of a row strip fetched ahead
+constexpr int BCG_R = 16;       // output pixels (right-hand sides) per block
+constexpr int BCG_UMAX = 1024;  // members of a block's union selection (multiple of 16)
+#ifndef IMCOM_BCG_CH
+#define IMCOM_BCG_CH 8
+#endif
+constexpr int BCG_CH = IMCOM_BCG_CH;  // k-tiles fetched ahead: 16 KB per wave in flight (with 4 the stream ran at 3.5 TB/s, bound by the round trip)
 
 // block b of stamp s covers output pixels (4 by + dy) W + 4 bx + dx; pix[r] = its index or -1
 __device__ __forceinline__ int bcg_pixel(int b, int r, int W, int H, int m)
@@ -38,19 +48,13 @@ __device__ __forceinline__ int bcg_pixel(int b, int r, int W, int H, int m)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Union selection, masks, dense AU (diagonal from `diag`: the reference's in-place kappa adds), masked right-hand sides.
-//   usel [blocks][UMAX] int, umask [blocks][UMAX] ushort, nu [blocks] int, AU [blocks][UMAX][UMAX], BU [blocks][UMAX][16]
-__global__ __launch_bounds__(256) void iter_block_setup_kernel(const double *__restrict__ A, long lda, long strideA,
-                                                               const double *__restrict__ diag, long ldd,
-                                                               const double *__restrict__ B, long ldb,
-                                                               const double *__restrict__ oyx, const double *__restrict__ iy,
-                                                               const double *__restrict__ ix, long ldxy, const int *__restrict__ n,
-                                                               int m, int W, int H, double rho, int *__restrict__ usel,
-                                                               unsigned short *__restrict__ umask, int *__restrict__ nu,
-                                                               double *__restrict__ AU, double *__restrict__ BU)
+// Union selection and masks of every patch: usel [blocks][UMAX] int, umask [blocks][UMAX] ushort, nu [blocks] int (the true
+// count, also when it exceeds UMAX: the host then takes the per-pixel kernel).
+__global__ __launch_bounds__(256) void iter_block_select_kernel(const double *__restrict__ oyx, const double *__restrict__ iy,
+                                                                const double *__restrict__ ix, long ldxy, const int *__restrict__ n,
+                                                                int m, int W, int H, double rho, int *__restrict__ usel,
+                                                                unsigned short *__restrict__ umask, int *__restrict__ nu)
 {
-    __shared__ int sel[BCG_UMAX];
-    __shared__ unsigned short msk[BCG_UMAX];
     __shared__ double oys[BCG_R], oxs[BCG_R];
     __shared__ int pix[BCG_R];
     __shared__ int wcnt[4], total;
@@ -66,6 +70,8 @@ __global__ __launch_bounds__(256) void iter_block_setup_kernel(const double *__r
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     const double *py = iy + s * ldxy, *px = ix + s * ldxy;
+    int *sel = usel + blk * BCG_UMAX;
+    unsigned short *msk = umask + blk * BCG_UMAX;
     // ordered compaction of the input pixels that at least one of the 16 output pixels accepts
     for (int c0 = 0; c0 < ns; c0 += 256) {
         const int i = c0 + threadIdx.x;
@@ -90,28 +96,46 @@ __global__ __launch_bounds__(256) void iter_block_setup_kernel(const double *__r
     }
     const int nsel = total;
     if (threadIdx.x == 0) nu[blk] = nsel;
-    if (nsel > BCG_UMAX || nsel == 0) return;  // too large: the host falls back to the per-pixel kernel; empty: nothing to solve
-    const int up = (nsel + 15) / 16 * 16;
-    for (int j = threadIdx.x; j < up; j += 256) {
-        usel[blk * BCG_UMAX + j] = j < nsel ? sel[j] : 0;
-        umask[blk * BCG_UMAX + j] = j < nsel ? msk[j] : 0;
-    }
+    if (nsel > BCG_UMAX) return;
+    for (int j = nsel + threadIdx.x; j < (nsel + 15) / 16 * 16; j += 256) { sel[j] = 0; msk[j] = 0; }  // padding rows of the last tile
+}
+
+// Dense AU of the patches [blk0, blk0 + gridDim.x) (diagonal from `diag`: the reference's in-place kappa adds), zero padded to the
+// patch's own `up`, as tiles: element (j, i) at ((j >> 4) * nts + (i >> 4)) * 256 + (j & 15) * 16 + (i & 15), nts = ups / 16; and
+// the masked right-hand sides BU[j][r] = -B/2 [pixel r][U[j]] where pixel r selects U[j], else zero.
+__global__ __launch_bounds__(256) void iter_block_gather_kernel(const double *__restrict__ A, long lda, long strideA,
+                                                                const double *__restrict__ diag, long ldd,
+                                                                const double *__restrict__ B, long ldb, int m, int W, int H,
+                                                                int nblocks, long blk0, int ups, const int *__restrict__ usel,
+                                                                const unsigned short *__restrict__ umask, const int *__restrict__ nu,
+                                                                double *__restrict__ AU, double *__restrict__ BU)
+{
+    __shared__ int sel[BCG_UMAX];
+    __shared__ int pix[BCG_R];
+    const long blk = blk0 + blockIdx.x;
+    const int s = (int)(blk / nblocks), b = (int)(blk - (long)s * nblocks);
+    const int nsel = nu[blk];
+    if (nsel == 0) return;
+    const int up = (nsel + 15) / 16 * 16, nts = ups / 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = threadIdx.x; j < up; j += 256) sel[j] = j < nsel ? usel[blk * BCG_UMAX + j] : -1;
+    if (threadIdx.x < BCG_R) pix[threadIdx.x] = bcg_pixel(b, threadIdx.x, W, H, m);
+    __syncthreads();
     const double *As = A + s * strideA, *dg = diag + s * ldd;
-    double *AUb = AU + blk * (long)BCG_UMAX * BCG_UMAX, *BUb = BU + blk * (long)BCG_UMAX * BCG_R;
-    // dense AU, zero padded to `up`: a wave per row, lanes over the columns
+    double *AUb = AU + (long)blockIdx.x * ups * ups, *BUb = BU + (long)blockIdx.x * ups * BCG_R;
+    const unsigned short *msk = umask + blk * BCG_UMAX;
+    // a wave per row, lanes over the columns: 16 consecutive lanes write the 128 bytes of a tile row
     for (int j = wave; j < up; j += 4) {
-        const int gj = j < nsel ? sel[j] : -1;
+        const int gj = sel[j];
         const double *row = As + (long)(gj < 0 ? 0 : gj) * lda;
+        double *out = AUb + (long)(j >> 4) * nts * 256 + (j & 15) * 16;
         for (int i = lane; i < up; i += 64) {
             double v = 0.0;
-            if (gj >= 0 && i < nsel) {
-                const int gi = sel[i];
-                v = gi == gj ? dg[gj] : row[gi];
-            }
-            AUb[(long)j * BCG_UMAX + i] = v;
+            const int gi = sel[i];
+            if (gj >= 0 && gi >= 0) v = gi == gj ? dg[gj] : row[gi];
+            out[(long)(i >> 4) * 256 + (i & 15)] = v;
         }
     }
-    // right-hand sides: BU[j][r] = -B/2 [pixel r][U[j]] where pixel r selects U[j], else zero
     for (int t = threadIdx.x; t < up * BCG_R; t += 256) {
         const int j = t >> 4, r = t & 15;
         double v = 0.0;
@@ -121,25 +145,38 @@ __global__ __launch_bounds__(256) void iter_block_setup_kernel(const double *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// 16 conjugate-gradient recurrences in step.  Four waves; wave w owns the 16-row tiles w, w + 4, ...; in a tile, lane
-// (li = lane & 15, lk = lane >> 4) owns rows lk + 4 r' (r' < 4) of right-hand side li -- the C/D layout of the MFMA, so that the
-// products land where the vectors live.  p is shared through LDS ([row][16]) as the B operand of the next product.
+// 16 conjugate-gradient recurrences in step.  Four waves; wave w owns the 16-row tiles w, w + 4, ... (TPW of them at most); in a
+// tile, lane (li = lane & 15, lk = lane >> 4) owns rows lk + 4 r' (r' < 4) of right-hand side li -- the C/D layout of the MFMA, so
+// that the products land where the vectors live.  Where the vectors live: the residual r in registers; the search direction p in
+// LDS ([row][16], fp64: it is the B operand of the product, and its owner lane reads its own entries back from there); the iterate
+// x and the step's product q in workspace (touched once per step: 4 % of the step's traffic, out of L2).  With x, r, p AND q in
+// registers a union of 700 rows needed 548 registers per lane and spilled; this way 1024 rows fit.
+// stats: [0] patches, [1] sum up^2 steps, [2] sum steps, [3] sum up^2 (unsigned long long, atomics); steps: per output pixel.
+template <int TPW>
 __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__restrict__ AU, const double *__restrict__ BU,
                                                                const int *__restrict__ usel, const unsigned short *__restrict__ umask,
-                                                               const int *__restrict__ nu, int m, int W, int H, double rtol,
-                                                               int maxiter, float *__restrict__ T, long ldt)
+                                                               const int *__restrict__ nu, int m, int W, int H, int nblocks, long blk0,
+                                                               int ups, double rtol, int maxiter, float *__restrict__ T, long ldt,
+                                                               double *__restrict__ XW, int *__restrict__ steps,
+                                                               unsigned long long *__restrict__ stats)
 {
     extern __shared__ double lds[];  // P [up][16], then red [4][16] doubles
-    const int s = blockIdx.y, b = blockIdx.x;
-    const long blk = (long)s * gridDim.x + b;
+    const long blk = blk0 + blockIdx.x;
+    const int s = (int)(blk / nblocks), b = (int)(blk - (long)s * nblocks);
     const int nsel = nu[blk];
-    if (nsel > BCG_UMAX || nsel == 0) return;
-    const int up = (nsel + 15) / 16 * 16, ntile = up / 16;
-    double *P = lds, *red = lds + (long)up * BCG_R;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-    const double *AUb = AU + blk * (long)BCG_UMAX * BCG_UMAX, *BUb = BU + blk * (long)BCG_UMAX * BCG_R;
+    const int a = bcg_pixel(b, li, W, H, m);
+    if (nsel == 0) {
+        if (steps && threadIdx.x < BCG_R && a >= 0) steps[(long)s * m + a] = 0;
+        return;
+    }
+    const int up = (nsel + 15) / 16 * 16, ntile = up / 16, nts = ups / 16;
+    double *P = lds, *red = lds + (long)up * BCG_R;
+    const double *AUb = AU + (long)blockIdx.x * ups * ups, *BUb = BU + (long)blockIdx.x * ups * BCG_R;
+    double *Xb = XW + (long)blockIdx.x * 2 * ups * BCG_R, *Qb = Xb + (long)ups * BCG_R;  // iterate x; the step's product q
     const unsigned short *mk = umask + blk * BCG_UMAX;
-    const bool valid = bcg_pixel(b, li, W, H, m) >= 0;
+    const bool valid = a >= 0;
+    const int own0 = (16 * wave + lk) * BCG_R + li;  // this lane's entry (q, e) of a [row][16] vector: own0 + (64 q + 4 e) * 16
 
     // block sum per right-hand side over all rows: lanes with the same li, then the four waves (fixed order)
     auto rhs_sum = [&](double v) {
@@ -151,146 +188,167 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
         return (red[li] + red[BCG_R + li]) + (red[2 * BCG_R + li] + red[3 * BCG_R + li]);
     };
 
-    double x[BCG_TPW][4], r[BCG_TPW][4], p[BCG_TPW][4];
-    unsigned own = 0;  // bit 4 q + e: this right-hand side selects the row
+    double r[TPW][4];
+    unsigned long long own = 0;  // bit 4 q + e: this right-hand side selects the row
     double bb = 0.0;
 #pragma unroll
-    for (int q = 0; q < BCG_TPW; q++) {
+    for (int q = 0; q < TPW; q++) {
         const int tt = wave + 4 * q;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int j = 16 * tt + lk + 4 * e;
             const bool in = tt < ntile;
-            if (in && (mk[j] >> li & 1)) own |= 1u << (4 * q + e);
-            x[q][e] = 0.0;
+            if (in && (mk[j] >> li & 1)) own |= 1ull << (4 * q + e);
             r[q][e] = in ? BUb[(long)j * BCG_R + li] : 0.0;  // already masked
-            p[q][e] = r[q][e];
+            if (in) Xb[own0 + (64 * q + 4 * e) * BCG_R] = 0.0;
             bb += r[q][e] * r[q][e];
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     const double atol = sqrt(rhs_sum(bb)) * rtol;
     double rho_prev = 0.0;
     bool done = !valid;
+    int used = 0, block_steps = 0;
+    // a wave's tile rows as runs of ntile tiles of 256 doubles; lane (li, lk) reads columns 4 lk .. 4 lk + 3 of row li of a tile
+    const double *strip0 = AUb + (long)wave * nts * 256 + li * 16 + 4 * lk;
+    const long strip_step = 4L * nts * 256;
     for (int it = 0; it < maxiter; it++) {
         double rr = 0.0;
 #pragma unroll
-        for (int q = 0; q < BCG_TPW; q++)
+        for (int q = 0; q < TPW; q++)
 #pragma unroll
             for (int e = 0; e < 4; e++) rr += r[q][e] * r[q][e];
         const double rho_cur = rhs_sum(rr);
         if (!done && sqrt(rho_cur) < atol) done = true;  // "Are we done?" at the top of the step, as the reference
         if (__syncthreads_and(done)) break;
         const bool act = !done;
-        if (it > 0 && act) {
-            const double beta = rho_cur / rho_prev;
+        used += act ? 1 : 0;
+        block_steps++;
+        // (opaque to the optimiser: it otherwise hoists the 64-bit addresses of every own entry of x, q and p out of this loop and keeps
+        // them in registers -- 6 registers per entry, which is what made unions above 700 rows spill)
+        int ob = own0;
+        asm volatile("" : "+v"(ob));
+        // p = r (first step), p = p beta + r (later); a recurrence that has stopped multiplies zeros from now on
+        const double beta = (it > 0 && act) ? rho_cur / rho_prev : 0.0;
 #pragma unroll
-            for (int q = 0; q < BCG_TPW; q++)
+        for (int q = 0; q < TPW; q++) {
+            if (wave + 4 * q < ntile)
 #pragma unroll
-                for (int e = 0; e < 4; e++) p[q][e] = p[q][e] * beta + r[q][e];
-        }
-#pragma unroll
-        for (int q = 0; q < BCG_TPW; q++) {
-            const int tt = wave + 4 * q;
-            if (tt < ntile)
-#pragma unroll
-                for (int e = 0; e < 4; e++) P[(long)(16 * tt + lk + 4 * e) * BCG_R + li] = act ? p[q][e] : 0.0;
+                for (int e = 0; e < 4; e++) {
+                    double *pp = P + ob + (64 * q + 4 * e) * BCG_R;
+                    const double pold = it > 0 ? *pp : 0.0;
+                    *pp = act ? pold * beta + r[q][e] : 0.0;
+                }
+            __builtin_amdgcn_sched_barrier(0);  // (one tile at a time: with every tile's loads issued up front the unrolled loop took 16 TPW registers)
         }
         __syncthreads();
-        // q = AU P, tile by tile: A operand lane (row li of the tile, k = 4 lk + kk of a 16-wide k block), B operand P[k][li]
+        // q = AU P, tile row by tile row: A operand lane (row li of the tile, k = 4 lk + kk of a 16-wide k block), B operand P[k][li].
+        // The tiles of this wave's rows stream through registers BCG_CH at a time; the next chunk's loads -- the first chunk of the
+        // NEXT tile row at the end of a row -- are in flight while this one is multiplied.
         double pq = 0.0;
-        double qv[BCG_TPW][4];
+        f64x2 nx[BCG_CH][2];
+        auto fetch = [&](const double *strip, int kt0) {
 #pragma unroll
-        for (int q = 0; q < BCG_TPW; q++) {
-            const int tt = wave + 4 * q;
+            for (int u = 0; u < BCG_CH; u++) {
+                const int kt = min(kt0 + u, ntile - 1);  // the tail re-reads the last tile (unused)
+                nx[u][0] = *(const f64x2 *)(strip + (long)kt * 256);
+                nx[u][1] = *(const f64x2 *)(strip + (long)kt * 256 + 2);
+            }
+        };
+        if (wave < ntile) fetch(strip0, 0);
+#pragma unroll 1
+        for (int q = 0; wave + 4 * q < ntile; q++) {
+            const double *strip = strip0 + q * strip_step;
+            const bool more = wave + 4 * (q + 1) < ntile;
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            if (tt < ntile) {
-                // the row strip of AU streams through registers in chunks of BCG_CH k-tiles, the next chunk's loads in flight
-                // while this one is multiplied (one workgroup per CU: the wave has 512 registers, and two loads in flight per lane
-                // left every k-tile waiting on a memory round trip)
-                const double *arow = AUb + (long)(16 * tt + li) * BCG_UMAX + 4 * lk;
-                f64x2 nx[BCG_CH][2];
-                auto fetch = [&](int kt0) {
+            for (int kt0 = 0; kt0 < ntile; kt0 += BCG_CH) {
+                f64x2 cu[BCG_CH][2];
 #pragma unroll
-                    for (int u = 0; u < BCG_CH; u++) {
-                        const int kt = min(kt0 + u, ntile - 1);  // the tail re-reads the last tile (unused)
-                        nx[u][0] = *(const f64x2 *)(arow + 16 * kt);
-                        nx[u][1] = *(const f64x2 *)(arow + 16 * kt + 2);
-                    }
-                };
-                fetch(0);
-                for (int kt0 = 0; kt0 < ntile; kt0 += BCG_CH) {
-                    f64x2 cu[BCG_CH][2];
+                for (int u = 0; u < BCG_CH; u++) { cu[u][0] = nx[u][0]; cu[u][1] = nx[u][1]; }
+                if (kt0 + BCG_CH < ntile) fetch(strip, kt0 + BCG_CH);
+                else if (more) fetch(strip + strip_step, 0);
 #pragma unroll
-                    for (int u = 0; u < BCG_CH; u++) { cu[u][0] = nx[u][0]; cu[u][1] = nx[u][1]; }
-                    if (kt0 + BCG_CH < ntile) fetch(kt0 + BCG_CH);
-#pragma unroll
-                    for (int u = 0; u < BCG_CH; u++) {
-                        if (kt0 + u < ntile) {
-                            const double *pk = P + (long)(16 * (kt0 + u) + 4 * lk) * BCG_R + li;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[u][0].x, pk[0], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[u][0].y, pk[BCG_R], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[u][1].x, pk[2 * BCG_R], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[u][1].y, pk[3 * BCG_R], acc, 0, 0, 0);
-                        }
+                for (int u = 0; u < BCG_CH; u++) {
+                    if (kt0 + u < ntile) {
+                        const double *pk = P + (long)(16 * (kt0 + u) + 4 * lk) * BCG_R + li;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[u][0].x, pk[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[u][0].y, pk[BCG_R], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[u][1].x, pk[2 * BCG_R], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[u][1].y, pk[3 * BCG_R], acc, 0, 0, 0);
                     }
                 }
             }
+            // the product's rows of this tile: kept in workspace until alpha is known (q in registers next to r cost the spills)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                qv[q][e] = (own >> (4 * q + e) & 1) ? acc[e] : 0.0;
-                pq += p[q][e] * qv[q][e];
+                const int o = ob + (64 * q + 4 * e) * BCG_R;
+                const double v = (own >> (4 * q + e) & 1) ? acc[e] : 0.0;
+                Qb[o] = v;
+                pq += P[o] * v;
             }
         }
         const double pqs = rhs_sum(pq);
         if (act) {
             const double alpha = rho_cur / pqs;
 #pragma unroll
-            for (int q = 0; q < BCG_TPW; q++)
+            for (int q = 0; q < TPW; q++) {
+                if (wave + 4 * q < ntile)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    x[q][e] += alpha * p[q][e];
-                    r[q][e] -= alpha * qv[q][e];
-                }
+                    for (int e = 0; e < 4; e++) {
+                        const int o = ob + (64 * q + 4 * e) * BCG_R;
+                        Xb[o] += alpha * P[o];
+                        r[q][e] -= alpha * Qb[o];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             rho_prev = rho_cur;
         }
     }
-    const int a = bcg_pixel(b, li, W, H, m);
     if (a >= 0) {
         float *Trow = T + ((long)s * m + a) * ldt;
         const int *us = usel + blk * BCG_UMAX;
-#pragma unroll
-        for (int q = 0; q < BCG_TPW; q++)
+#pragma unroll 1
+        for (int q = 0; wave + 4 * q < ntile; q++)
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                if (own >> (4 * q + e) & 1) Trow[us[16 * (wave + 4 * q) + lk + 4 * e]] = (float)x[q][e];
+                if (own >> (4 * q + e) & 1) Trow[us[16 * (wave + 4 * q) + lk + 4 * e]] = (float)Xb[own0 + (64 * q + 4 * e) * BCG_R];
+        if (steps && wave == 0 && lk == 0) steps[(long)s * m + a] = used;
+    }
+    if (stats && threadIdx.x == 0) {
+        atomicAdd(stats + 0, 1ull);
+        atomicAdd(stats + 1, (unsigned long long)up * up * block_steps);
+        atomicAdd(stats + 2, (unsigned long long)block_steps);
+        atomicAdd(stats + 3, (unsigned long long)up * up);
     }
 }
 
-size_t iter_block_ws_bytes(int batch, int nblocks)
-{
-    const size_t nb = (size_t)batch * nblocks;
-    return nb * ((size_t)BCG_UMAX * BCG_UMAX * 8 + (size_t)BCG_UMAX * BCG_R * 8 + (size_t)BCG_UMAX * 6 + 4) + 4096;
-}
-
 int iter_block_count(int m, int W) { const int H = (m + W - 1) / W; return ((W + 3) / 4) * ((H + 3) / 4); }
+int iter_block_umax() { return BCG_UMAX; }
 
-// One kappa node.  Returns in *max_union the largest union selection (callers fall back to the per-pixel kernel when it
-// exceeds iter_block_umax()); T must have been zeroed.
+// workspace of a call: the selection of every patch of the batch + `budget` bytes for the dense sub-matrices of a sub-batch
+size_t iter_block_select_bytes(int batch, int nblocks) { return (size_t)batch * nblocks * ((size_t)BCG_UMAX * 6 + 4) + 4096; }
+size_t iter_block_patch_bytes(int ups) { return (size_t)ups * ups * 8 + 3 * (size_t)ups * BCG_R * 8; }  // AU + BU + x + q
+
+// One kappa node for the whole batch.  *max_union = the largest union selection: above iter_block_umax() nothing was solved and
+// the caller takes the per-pixel kernel.  T must have been zeroed.  `ws` holds iter_block_select_bytes() + `budget` bytes: the
+// patches go through the solver in groups whose sub-matrices fit the budget.  stats (device, 4 x u64) and steps (device,
+// [batch][m]) are optional.
 int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, const double *diag, long ldd, const double *B, long ldb,
                       const double *oyx, const double *iy, const double *ix, long ldxy, const int *n, int m, int W, int batch,
-                      double rho, double rtol, int maxiter, float *T, long ldt, void *ws, int *max_union)
+                      double rho, double rtol, int maxiter, float *T, long ldt, void *ws, size_t budget, int *max_union, int *steps,
+                      unsigned long long *stats)
 {
     const int H = (m + W - 1) / W, nblocks = iter_block_count(m, W);
     const size_t nb = (size_t)batch * nblocks;
     char *w = (char *)ws;
-    double *AU = (double *)w; w += nb * (size_t)BCG_UMAX * BCG_UMAX * 8;
-    double *BU = (double *)w; w += nb * (size_t)BCG_UMAX * BCG_R * 8;
     int *usel = (int *)w; w += nb * (size_t)BCG_UMAX * 4;
     unsigned short *umask = (unsigned short *)w; w += nb * (size_t)BCG_UMAX * 2;
-    int *nu = (int *)w;
-    hipLaunchKernelGGL(iter_block_setup_kernel, dim3(nblocks, batch), dim3(256), 0, ctx->stream, A, lda, strideA, diag, ldd, B, ldb, oyx, iy, ix,
-                       ldxy, n, m, W, H, rho, usel, umask, nu, AU, BU);
-    IMCOM_TRY(check_launch("iter_block_setup_kernel"));
+    int *nu = (int *)w; w += (nb * 4 + 4095) / 4096 * 4096;
+    {
+        ProfScope ps(ctx, "iter_gather");
+        hipLaunchKernelGGL(iter_block_select_kernel, dim3(nblocks, batch), dim3(256), 0, ctx->stream, oyx, iy, ix, ldxy, n, m, W, H, rho, usel, umask, nu);
+        IMCOM_TRY(check_launch("iter_block_select_kernel"));
+    }
     std::vector<int> nu_h(nb);
     IMCOM_HIP_CHECK(hipMemcpyAsync(nu_h.data(), nu, nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -298,13 +356,33 @@ int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, c
     for (size_t i = 0; i < nb; i++) mx = std::max(mx, nu_h[i]);
     *max_union = mx;
     if (mx > BCG_UMAX) return IMCOM_OK;  // nothing solved: the caller uses the per-pixel kernel
-    const size_t lds = ((size_t)((mx + 15) / 16 * 16) * BCG_R + 4 * BCG_R) * 8;
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)iter_block_cg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(iter_block_cg_kernel, dim3(nblocks, batch), dim3(256), lds, ctx->stream, (const double *)AU, (const double *)BU,
-                       (const int *)usel, (const unsigned short *)umask, (const int *)nu, m, W, H, rtol, maxiter, T, ldt);
-    return check_launch("iter_block_cg_kernel");
+    if (mx == 0) {
+        if (steps) IMCOM_HIP_CHECK(hipMemsetAsync(steps, 0, (size_t)batch * m * 4, ctx->stream));
+        return IMCOM_OK;
+    }
+    const int ups = (mx + 15) / 16 * 16, ntile = ups / 16;
+    const size_t per = iter_block_patch_bytes(ups);
+    const size_t group = std::max<size_t>(1, std::min<size_t>(nb, budget / per));
+    IMCOM_REQUIRE(per <= budget, "iterative kernel: a patch's sub-matrix (%zu bytes) exceeds the workspace share of %zu", per, budget);
+    double *AU = (double *)w, *BU = AU + group * (size_t)ups * ups, *XW = BU + group * (size_t)ups * BCG_R;
+    const size_t lds = ((size_t)ups * BCG_R + 4 * BCG_R) * 8;
+    const int tpw = (ntile + 3) / 4;
+    auto cg = tpw <= 8 ? iter_block_cg_kernel<8> : tpw <= 12 ? iter_block_cg_kernel<12> : iter_block_cg_kernel<16>;
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (size_t b0 = 0; b0 < nb; b0 += group) {
+        const unsigned g = (unsigned)std::min(group, nb - b0);
+        {
+        ProfScope ps(ctx, "iter_gather");
+        hipLaunchKernelGGL(iter_block_gather_kernel, dim3(g), dim3(256), 0, ctx->stream, A, lda, strideA, diag, ldd, B, ldb, m, W, H, nblocks, (long)b0,
+                           ups, (const int *)usel, (const unsigned short *)umask, (const int *)nu, AU, BU);
+        IMCOM_TRY(check_launch("iter_block_gather_kernel"));
+        }
+        ProfScope ps(ctx, "iter_cg");
+        hipLaunchKernelGGL(cg, dim3(g), dim3(256), lds, ctx->stream, (const double *)AU, (const double *)BU, (const int *)usel,
+                           (const unsigned short *)umask, (const int *)nu, m, W, H, nblocks, (long)b0, ups, rtol, maxiter, T, ldt, XW, steps, stats);
+        IMCOM_TRY(check_launch("iter_block_cg_kernel"));
+    }
+    return IMCOM_OK;
 }
-
-int iter_block_umax() { return BCG_UMAX; }
 
 }  // namespace imcom

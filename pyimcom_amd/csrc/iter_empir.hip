@@ -11,12 +11,14 @@
 namespace imcom {
 
 // iter_block.hip: the same solve for 4 x 4 patches of output pixels at a time (one MFMA product per CG step and patch)
-size_t iter_block_ws_bytes(int batch, int nblocks);
+size_t iter_block_select_bytes(int batch, int nblocks);
+size_t iter_block_patch_bytes(int ups);
 int iter_block_count(int m, int W);
 int iter_block_umax();
 int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, const double *diag, long ldd, const double *B, long ldb,
                       const double *oyx, const double *iy, const double *ix, long ldxy, const int *n, int m, int W, int batch,
-                      double rho, double rtol, int maxiter, float *T, long ldt, void *ws, int *max_union);
+                      double rho, double rtol, int maxiter, float *T, long ldt, void *ws, size_t budget, int *max_union, int *steps,
+                      unsigned long long *stats);
 
 constexpr int CG_MAXSEL = 4096;            // input pixels inside one acceptance disc (LDS: 16 KB indices + 32 KB p)
 constexpr int CG_SLOTS = CG_MAXSEL / 256;  // rows of the sub-system owned by one thread
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void iter_cg_kernel(const double *__restrict__
                                                       const double *__restrict__ oyx, const double *__restrict__ iy,
                                                       const double *__restrict__ ix, long ldxy, const int *__restrict__ n, int m,
                                                       double rho, double rtol, int maxiter, float *__restrict__ T, long ldt,
-                                                      int *__restrict__ status)
+                                                      int *__restrict__ status, int *__restrict__ steps)
 {
     __shared__ int sel[CG_MAXSEL];
     __shared__ double pv[CG_MAXSEL];
@@ -133,7 +135,10 @@ __global__ __launch_bounds__(256) void iter_cg_kernel(const double *__restrict__
         if (threadIdx.x == 0) atomicMax(status, nsel);
         return;
     }
-    if (nsel == 0) return;
+    if (nsel == 0) {
+        if (steps && threadIdx.x == 0) steps[(long)s * m + a] = 0;
+        return;
+    }
     const double *As = A + s * strideA, *dg = diag + s * ldd, *b = B + ((long)s * m + a) * ldb;
     double x[CG_SLOTS], r[CG_SLOTS], p[CG_SLOTS], q[CG_SLOTS];
     double bb = 0.0;
@@ -150,12 +155,14 @@ __global__ __launch_bounds__(256) void iter_cg_kernel(const double *__restrict__
     const double atol = sqrt(block_sum4(bb, red)) * rtol;
     double rho_prev = 0.0;
     const int nrows_w = (nsel - wave + 3) / 4;  // rows of this wave: j = wave + 4k, k < nrows_w
+    int used = 0;
     for (int it = 0; it < maxiter; it++) {
         double rr = 0.0;
 #pragma unroll
         for (int sl = 0; sl < CG_SLOTS; sl++) rr += r[sl] * r[sl];
         const double rho_cur = block_sum4(rr, red);
         if (sqrt(rho_cur) < atol) break;
+        used++;
         if (it > 0) {
             const double beta = rho_cur / rho_prev;
 #pragma unroll
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(256) void iter_cg_kernel(const double *__restrict__
         const int j = 4 * (lane + 64 * sl) + wave;
         if (j < nsel) Trow[sel[j]] = (float)x[sl];
     }
+    if (steps && threadIdx.x == 0) steps[(long)s * m + a] = used;
 }
 
 // float32 node solution -> padded float64 GEMM operand [mp][np]
@@ -484,11 +492,11 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
     size_t total = 65536 + (size_t)nv * szB * 4 + (size_t)batch * ldn * 8 + (size_t)batch * (MAX_INC + 4) * 8 + szM * 8 * (4 + nv + 2 * nv * nv);
     if (exact) total += big * (1 + nv) + (size_t)batch * np * np * 8;
     if (host) total += (szA + szB) * 8 + szB * 4 + szM * 12 + szM * 16 + (size_t)batch * ldn * 16 + 4096;
-    // The blocked solver keeps one dense sub-matrix per 4 x 4 patch (2.2 MB; 144 patches per cfg-2 stamp): the stamps of a call go
-    // through it in sub-batches that fit a fixed share of workspace instead of batch x 0.3 GB (80 GB for 256 cfg-2 stamps).
-    const size_t blk_budget = (size_t)8 << 30;
-    const int sub = per_pixel ? batch : (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, blk_budget / std::max<size_t>(iter_block_ws_bytes(1, nblocks), 1)));
-    if (!per_pixel) total += iter_block_ws_bytes(sub, nblocks) + 4096;
+    // The blocked solver keeps one dense sub-matrix per 4 x 4 patch (4 MB at the reference's default configuration, 64 patches per
+    // stamp): the patches of a call go through it in groups that fit a fixed share of workspace instead of batch x 0.3 GB.
+    const size_t blk_budget = per_pixel ? 0 : std::min<size_t>((size_t)8 << 30, (size_t)batch * nblocks * iter_block_patch_bytes(iter_block_umax()));
+    if (!per_pixel) total += iter_block_select_bytes(batch, nblocks) + blk_budget + 8192;
+    total += szM * 4 + 64;  // per-pixel step counts, statistics
     IMCOM_TRY(ws_reserve(ctx, total));
     Stage st{ctx, host};
     const double *A_d, *B_d, *yx_d, *iy_d, *ix_d;
@@ -508,8 +516,14 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
     int *ints = (int *)ws_take(ctx, (size_t)batch * 8 + 8);
     double *kc = (double *)ws_take(ctx, (size_t)(batch + nv) * 8);
     double *flat = (double *)ws_take(ctx, szM * 8 * (4 + nv + 2 * nv * nv));
-    void *blkws = per_pixel ? nullptr : ws_take(ctx, iter_block_ws_bytes(sub, nblocks));
-    if (!Tn || !dsh || !inc || !ints || !kc || !flat || (!per_pixel && !blkws)) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    void *blkws = per_pixel ? nullptr : ws_take(ctx, iter_block_select_bytes(batch, nblocks) + blk_budget + 4096);
+    int *steps_d = (int *)ws_take(ctx, szM * 4);
+    unsigned long long *stats_d = (unsigned long long *)ws_take(ctx, 64);
+    if (!Tn || !dsh || !inc || !ints || !kc || !flat || (!per_pixel && !blkws) || !steps_d || !stats_d) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    IMCOM_HIP_CHECK(hipMemsetAsync(stats_d, 0, 64, ctx->stream));
+    IMCOM_HIP_CHECK(hipMemsetAsync(steps_d, 0, szM * 4, ctx->stream));
+    ctx->iter_steps.clear();
+    for (double &v : ctx->iter_stats) v = 0.0;
     int *n_dev = ints, *ninc = ints + batch, *status = ints + 2 * batch;
     double *Cs_d = kc, *kappaC_d = kc + batch;
     double *Nf = flat, *Df = Nf + szM * nv * nv, *Ef = Df + szM * nv, *ok = Ef + szM * nv * nv, *oS = ok + szM, *oU = oS + szM, *ow = oU + szM;
@@ -539,31 +553,32 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
             IMCOM_HIP_CHECK(hipMemcpyAsync(ninc, ninc_h.data(), (size_t)batch * 4, hipMemcpyHostToDevice, ctx->stream));
             IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
             IMCOM_TRY(launch_diag_shift(ctx, A_d, ldn, inc, ninc, dsh, batch));
-            ProfScope ps(ctx, "iter_cg");
             bool blocked = false;
             if (!per_pixel) {  // 4 x 4 patches of output pixels per workgroup (iter_block.hip), unless a patch selects too many input pixels
                 int mx = 0;
                 IMCOM_HIP_CHECK(hipMemsetAsync(Tn + (size_t)p * szB, 0, szB * 4, ctx->stream));
-                for (int s0 = 0; s0 < batch && mx <= iter_block_umax(); s0 += sub) {
-                    const int sb = std::min(sub, batch - s0);
-                    int mxs = 0;
-                    IMCOM_TRY(launch_iter_block(ctx, A_d + (size_t)s0 * ldn * ldn, (long)ldn, (long)ldn * ldn, dsh + (size_t)s0 * ldn, (long)ldn,
-                                                B_d + (size_t)s0 * m * ldn, (long)ldn, yx_d + (size_t)s0 * 2 * m, iy_d + (size_t)s0 * ldn, ix_d + (size_t)s0 * ldn,
-                                                (long)ldn, n_dev + s0, m, gridW, sb, rho_acc, rtol, maxiter, Tn + (size_t)p * szB + (size_t)s0 * m * ldn, (long)ldn,
-                                                blkws, &mxs));
-                    mx = std::max(mx, mxs);
-                }
+                IMCOM_HIP_CHECK(hipMemsetAsync(stats_d, 0, 64, ctx->stream));  // (statistics and step counts: of the LAST node)
+                IMCOM_TRY(launch_iter_block(ctx, A_d, (long)ldn, (long)ldn * ldn, dsh, (long)ldn, B_d, (long)ldn, yx_d, iy_d, ix_d, (long)ldn, n_dev, m, gridW,
+                                            batch, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, blkws, blk_budget, &mx, steps_d, stats_d));
                 blocked = mx <= iter_block_umax();  // else: some patch selects more input pixels than the blocked solver holds -- the per-pixel kernel redoes the node
+                ctx->iter_stats[4] = (double)mx;
             }
             if (!blocked) {
+                ProfScope ps(ctx, "iter_cg");
                 hipLaunchKernelGGL(iter_cg_kernel, dim3(m, batch), dim3(256), 0, ctx->stream, A_d, (long)ldn, (long)ldn * ldn, dsh, (long)ldn, B_d,
-                                   (long)ldn, yx_d, iy_d, ix_d, (long)ldn, n_dev, m, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, status);
+                                   (long)ldn, yx_d, iy_d, ix_d, (long)ldn, n_dev, m, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, status, steps_d);
                 IMCOM_TRY(check_launch("iter_cg_kernel"));
             }
+            ctx->iter_stats[5] = blocked ? 1.0 : 0.0;
         }
         int st_h = 0;
+        unsigned long long stats_h[4] = {0, 0, 0, 0};
+        ctx->iter_steps.resize(szM);
         IMCOM_HIP_CHECK(hipMemcpyAsync(&st_h, status, 4, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipMemcpyAsync(stats_h, stats_d, 32, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipMemcpyAsync(ctx->iter_steps.data(), steps_d, szM * 4, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 4; k++) ctx->iter_stats[k] = (double)stats_h[k];
         IMCOM_REQUIRE(st_h == 0, "iterative kernel: %d input pixels inside one acceptance disc exceed the limit of %d", st_h, CG_MAXSEL);
         double *G = nullptr;
         if (exact) {
@@ -578,6 +593,7 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
                                       (long)mp * np, 1.0, 0.0));
             }
         }
+        ProfScope ps_red(ctx, "finalize");
         hipLaunchKernelGGL(iter_reduce_kernel, dim3(m, batch), dim3(256), 0, ctx->stream, Tn, (long)szB, (long)ldn, G, (long)batch * mp * np, mp, np, B_d,
                            (long)ldn, n_dev, m, nv, kappaC_d, Cs_d, exact ? 1 : 0, Nf, Df, Ef, UC_d, Sig_d, kap_d);
         IMCOM_TRY(check_launch("iter_reduce_kernel"));
@@ -593,5 +609,18 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
     IMCOM_TRY(st.back(Sigma, Sig_d, szM));
     IMCOM_TRY(st.back(kappa, kap_d, szM));
     if (host) IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return IMCOM_OK;
+}
+
+
+extern "C" int imcom_solve_iter_stats(imcom_ctx *ctx, double *stats, int *steps, long nsteps)
+{
+    IMCOM_TRY(ctx_ok2(ctx));
+    IMCOM_REQUIRE(stats, "null pointer");
+    for (int k = 0; k < 8; k++) stats[k] = k < 6 ? ctx->iter_stats[k] : 0.0;
+    if (steps) {
+        IMCOM_REQUIRE(nsteps == (long)ctx->iter_steps.size(), "step counts of the last imcom_solve_iter call: %zu pixels, caller asks for %ld", ctx->iter_steps.size(), nsteps);
+        std::copy(ctx->iter_steps.begin(), ctx->iter_steps.end(), steps);
+    }
     return IMCOM_OK;
 }

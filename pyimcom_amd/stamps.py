@@ -902,6 +902,7 @@ class StampBatch:
                                            _dp(self.y), _dp(self.x), float(cfg.rho), float(getattr(cfg, "iter_rtol", 1.5e-3)),
                                            int(getattr(cfg, "iter_max", 30)), int(nv > 1), _dp(T), _dp(UC), _dp(Sigma),
                                            _dp(kappa), 1))
+                self.iter_stats = self.ctx.iter_stats()  # patches, flops and bytes of the CG steps, largest union (bench.py's roofline)
             else:
                 # (no quality control, lakernel.py:774-777: T alone, the maps stay zero, A and -B/2 are never read)
                 check(lib.imcom_solve_empir(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, None if nqc else _dp(self.A), None if nqc else _dp(mB),

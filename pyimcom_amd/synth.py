@@ -38,6 +38,8 @@ class WorkloadConfig:
     psf_sigma: float = 0.9      # Gaussian input PSF width, native pixels (cfg-1: 0.9 + 0.05 e)
     n_out: int = 1              # target PSFs (OUTPSF + cfg.outpsf_extra); target k is a Gaussian of width extrasmooth * (1 + k/4)
     no_qlt_ctrl: bool = False   # EMPIRNQC (config.py:573): the Empirical kernel without its quality maps -- no A, no B (coadd.py:1020-1025)
+    iter_rtol: float = 1.5e-3   # ITERRTOL / ITERMAX (config.py; lakernel.py:397-442), the Iterative kernel's stopping rule
+    iter_max: int = 30
 
     @property
     def n2f(self):
@@ -83,6 +85,12 @@ CONFIGS = {
     # N ~ 6.2k input pixels against m = 38^2 = 1444 outputs, i.e. N / m = 4.3 -- the factorisation is 42 % of the matrix flops
     "paper4": WorkloadConfig("paper4", 32, 3, 0.0390625, 6, 1.24, "Cholesky", (6e-4,), n_inframe=6, extrasmooth=0.934253980316821,
                              flat_penalty=0.0),
+    # the reference's DEFAULT configuration (configs/default_config.json, and 70 more of its 152 configs): LAKERNEL Iterative, KAPPAC [0.0],
+    # OUTSIZE [80, 32, 0.0390625], FADE 0, INPAD 0.6 -> rho = 15.36 output pixels, ITERRTOL 1.5e-3, ITERMAX 30, NPIXPSF 48, GAUSSIAN target
+    # with that EXTRASMOOTH, FLATPEN 0, the science layer + five EXTRAINPUT layers, at six exposures: N ~ 2.8k, m = 1024, ~560 input pixels
+    # inside an output pixel's acceptance disc; with kappa = 0 no conjugate-gradient recurrence reaches the tolerance in 30 steps
+    "iter_default": WorkloadConfig("iter_default", 32, 0, 0.0390625, 6, 0.6, "Iterative", (0.0,), n_inframe=6, extrasmooth=0.8493218002880191,
+                                   flat_penalty=0.0),
     # small cases for parity tests (oracle finishes in seconds)
     "tiny": WorkloadConfig("tiny", 8, 1, 0.11 / 2.5, 3, 0.12, "Cholesky", (6e-4,), psf="gauss", npixpsf=8, oversamp=4,
                            psf_sigma=0.45, extrasmooth=0.6),

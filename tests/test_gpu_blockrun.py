@@ -426,6 +426,72 @@ def test_a_pass_that_runs_out_of_memory_is_run_in_halves(monkeypatch):
             assert torch.equal(got.maps[k], ref.maps[k]), (kernel, k)
 
 
+@pytest.mark.parametrize("with_claim", [False, True])
+@pytest.mark.parametrize("site", ["solve_begin", "next_batch", "solve_end"])
+def test_out_of_memory_at_any_point_of_a_pass_loses_no_pass(monkeypatch, site, with_claim):
+    """ADVICE r05 (high / medium): the out-of-memory handler of coadd_block covers solve_begin, the preparation of the NEXT pass and
+    solve_end.  Wherever the failure comes from, every pass this process took ends up in the maps -- a pass whose preparation failed is
+    prepared again, not skipped (it was already claimed: under the farm nobody else would ever coadd it) -- and the block has the bits
+    of a clean run.  Standalone and with a claim callback (the farm's)."""
+    import torch
+
+    from pyimcom_amd import blockrun, synth
+    from pyimcom_amd._lib import ImcomError
+    from pyimcom_amd.blockrun import coadd_block
+    from pyimcom_amd.select import InStampPool
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    n1P, n_expo = 4, 3
+    cfg = synth.CONFIGS["tiny"]
+    inst = _instamps(cfg, n1P, n_expo, np.random.default_rng(5))
+    psfs, target = synth.make_psfs(cfg, n_expo)
+    tabs = PSFGroupTables(psfs, target, cfg.nfft)
+    pool = InStampPool(inst, cfg.n_inframe)
+    todo = [(j, i) for j in range(1, n1P + 1) for i in range(1, n1P + 1)]
+    plan = [todo[:8], todo[8:]]
+    asked = []
+
+    def claim(q):
+        asked.append(q)
+        return True
+
+    fired = []
+    real_begin, real_end, real_prepare = StampBatch.solve_begin, StampBatch.solve_end, blockrun.prepare_batch
+
+    def begin(self, *a, **k):
+        if site == "solve_begin" and self.batch > 4 and not fired:
+            fired.append("begin")
+            raise ImcomError(-3, "device workspace: out of memory (injected)")
+        return real_begin(self, *a, **k)
+
+    def end(self):
+        if site == "solve_end" and self.batch > 4 and not fired:
+            fired.append("end")
+            real_end(self)  # (the outstanding begin is ended; its results are discarded by the halves)
+            raise ImcomError(-3, "device workspace: out of memory (injected)")
+        return real_end(self)
+
+    def prepare(cfg_, pool_, tables_, chunk, *a, **k):
+        if site == "next_batch" and list(chunk) == plan[1] and not fired:
+            fired.append("prepare")  # the second pass, prepared while the first pass's solve is queued
+            raise RuntimeError("HIP out of memory (injected)")
+        return real_prepare(cfg_, pool_, tables_, chunk, *a, **k)
+
+    with monkeypatch.context() as mp:
+        mp.setattr(StampBatch, "solve_begin", begin)
+        mp.setattr(StampBatch, "solve_end", end)
+        mp.setattr(blockrun, "prepare_batch", prepare)
+        got = coadd_block(cfg, pool, tabs, n1P, n_expo, chunks=plan, claim=claim if with_claim else None)
+        torch.cuda.synchronize()
+    assert fired and got.passes_halved == 1 and sorted(got.chunks_done) == [0, 1]
+    assert not with_claim or asked == [0, 1]  # every pass asked for once: the failed preparation did not draw a third
+    ref = coadd_block(cfg, pool, tabs, n1P, n_expo, chunks=[todo[:4], todo[4:8], todo[8:]])
+    torch.cuda.synchronize()
+    assert torch.equal(got.out_map, ref.out_map) and torch.equal(got.T_weightmap, ref.T_weightmap)
+    for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):
+        assert torch.equal(got.maps[k], ref.maps[k]), k
+
+
 def test_plan_is_exact_and_reproducible_under_a_memory_cap():
     """ONE owner for device memory: the library works in a torch tensor (imcom_ctx_set_workspace; _lib.Context), so
     torch's allocator accounts for every byte and ``plan_block`` sizes passes from it alone.  With the free memory capped by a hog
