@@ -130,3 +130,47 @@ def run(verbose=False):
     if verbose:
         print("[smoke] tables rel err", rep["tables"], "C rel err", rep["C"], "-> OK")
     return rep
+
+
+def iter_residuals(A, mB, T, relevant):
+    """|A_s T_a - b_a| / |b_a| per output pixel, in float64 from the float32 T (the stopping quantity of lakernel.py:397-442)."""
+    out = np.zeros(T.shape[0])
+    for a in range(T.shape[0]):
+        sel = np.nonzero(relevant[a])[0]
+        b = mB[a, sel]
+        out[a] = np.linalg.norm(A[np.ix_(sel, sel)] @ T[a, sel].astype(np.float64) - b) / np.linalg.norm(b)
+    return out
+
+
+def iter_parity(A, mB, C, relevant, rtol, maxiter, one, two, min_same=0.95):
+    """Parity of two runs of IterKernel (lakernel.py:533-654) on ONE system in the regime where its recurrences are not converged to
+    rounding (kappa = 0: sub-systems singular to 1e-11, 13-30 steps): ``one`` / ``two`` = (T float32 [m, n], steps [m], UC [m], Sigma [m]).
+    A recurrence's iterate carries the rounding of every inner product amplified along the run, so two orders of the sums -- numpy
+    against the device, or numpy against numpy on permuted pixels -- agree as follows, and this is what is asserted:
+      1. the acceptance discs exactly (T zero outside; lakernel.py:617-622);
+      2. the same number of steps for >= ``min_same`` of the pixels; where they agree, T within 2e-3 of its largest entry (median < 1e-6:
+         float32's own rounding); nowhere more than 4 steps apart;
+      3. BOTH sides meet the reference's stopping rule at every pixel: residual < rtol |b|, or maxiter steps used;
+      4. the maps follow T: |d U/C| <= (sum_i |b_i|) max_i |dT_ai| / C, |d Sigma| <= (sum_i |T_ai| + |T'_ai|) max_i |dT_ai| (+ the float32
+         the reference accumulates Sigma in), at every pixel.
+    Returns a report dict."""
+    (T1, s1, U1, S1), (T2, s2, U2, S2) = one, two
+    assert not T1[~relevant].any() and not T2[~relevant].any()
+    assert ((T1 != 0) & relevant).sum() >= 0.999 * relevant.sum() and ((T2 != 0) & relevant).sum() >= 0.999 * relevant.sum()
+    same = s1 == s2
+    scale = np.abs(T2).max(axis=1)
+    dTabs = np.abs(T1.astype(np.float64) - T2).max(axis=1)
+    dT = dTabs / scale
+    rep = {"same_steps": float(same.mean()), "dT_same_max": float(dT[same].max()), "dT_same_median": float(np.median(dT[same])),
+           "dT_other_max": float(dT[~same].max()) if (~same).any() else 0.0, "step_diff_max": int(np.abs(s1 - s2).max())}
+    assert rep["same_steps"] >= min_same and rep["dT_same_max"] < 2e-3 and rep["dT_same_median"] < 1e-6 and rep["step_diff_max"] <= 4, rep
+    assert rep["dT_other_max"] < 0.1, rep
+    for T_, st_ in ((T1, s1), (T2, s2)):
+        r = iter_residuals(A, mB, T_, relevant)
+        ok = (r < rtol * (1 + 1e-3)) | (st_ >= maxiter)
+        assert ok.all(), (r[~ok], st_[~ok])
+    bU = np.abs(mB).sum(axis=1) * dTabs / C * 1.01 + 2e-6
+    bS = 1.001 * (np.abs(T1).astype(np.float64).sum(axis=1) + np.abs(T2).astype(np.float64).sum(axis=1)) * dTabs + 2e-6 * np.abs(S2)
+    assert (np.abs(U1.astype(np.float64) - U2) <= bU).all(), np.abs(U1 - U2).max()
+    assert (np.abs(S1.astype(np.float64) - S2) <= bS).all(), np.abs(S1 - S2).max()
+    return rep

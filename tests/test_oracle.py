@@ -462,3 +462,36 @@ def test_block_loop_order_golden(golden, case):
     for j, i in sorted(ids):
         orc.block_accumulate(rows, g[f"st{j}{i}_outimage"], j, i, n2, fk)
     assert case != "whole" or not np.array_equal(rows, out_map)  # row by row is another sum
+
+
+def test_iter_default_oracle_against_itself():
+    """The parity statement for the Iterative kernel at the reference's default configuration (kappa = 0: tests/parity.py iter_parity,
+    used by tests/test_gpu_iter_default.py for device against oracle) holds for the oracle against ITSELF with every selection in reverse
+    pixel order -- the same conjugate-gradient recurrences (lakernel.py:397-442) with their sums in another order -- and is not
+    tighter than that: ~2 % of the output pixels stop a step apart, where the steps agree T differs by up to 5e-4 of its largest entry."""
+    from pyimcom_amd import synth
+    from tests.parity import iter_parity
+
+    cfg = synth.CONFIGS["iter_default"]
+    psfs, target = synth.make_psfs(cfg, cfg.n_expo)
+    g, tabs_ref, C_ref = orc.stamp_tables(cfg, psfs, target)
+    E, C = cfg.n_expo, float(C_ref[0])
+    tri = lambda i, j: (2 * E - i + 1) * i // 2 + j - i  # noqa: E731
+    tab = np.array([[tri(a, b) if a <= b else (tri(b, a) | (1 << 30)) for b in range(E)] for a in range(E)], dtype=np.int32)
+    st = synth.make_stamp(cfg, 0)
+    A, Bt = orc.stamp_system(g, st.x, st.y, st.expo, tabs_ref, tab, np.zeros((E, E)), np.arange(E) + E * (E + 1) // 2, st.out_x0, st.out_y0, cfg.n2f)
+    mB = np.ascontiguousarray(Bt.T)
+    g1 = np.arange(cfg.n2f, dtype=np.float64)
+    oy, ox = np.repeat(st.out_y0 + g1, cfg.n2f), np.tile(st.out_x0 + g1, cfg.n2f)
+    args = (C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax, oy, ox)
+    s1, s2 = [], []
+    T1, U1, S1, k1, _ = orc.iter_kernel(A, mB, *args, st.y, st.x, cfg.rho, cfg.iter_rtol, cfg.iter_max, steps=s1)
+    perm = np.arange(st.n)[::-1]
+    Tp, U2, S2, k2, _ = orc.iter_kernel(A[np.ix_(perm, perm)], mB[:, perm], *args, st.y[perm], st.x[perm], cfg.rho, cfg.iter_rtol, cfg.iter_max, steps=s2)
+    T2 = np.empty_like(Tp)
+    T2[:, perm] = Tp
+    relevant = orc._relevant(oy, ox, st.y, st.x, cfg.rho)
+    rep = iter_parity(A, mB, C, relevant, cfg.iter_rtol, cfg.iter_max, (T2, np.array(s2), U2, S2), (T1, np.array(s1), U1, S1))
+    assert 0.9 < rep["same_steps"] < 1.0 and rep["dT_same_max"] > 1e-5, rep  # (the statement is not vacuous: the two runs do differ)
+    assert np.array_equal(k1, k2) and not k1.any()  # kappa = 0
+    assert np.linalg.eigvalsh(A)[0] < 1e-10 * np.abs(A).max()  # the system the recurrences run on is singular to rounding
