@@ -403,6 +403,16 @@ int imcom_compress_map_f32(imcom_ctx *ctx, const float *map, long count, int coe
  * as the reference does at 786-793).  psf_arr [n_psf][nsamp][nsamp] out; samples off the image stay zero. */
 int imcom_sample_psf(imcom_ctx *ctx, int n_psf, const double *psf, int ny, int nx, const double *yxco,
                      int nsamp, int psf_circ, int psf_norm, double *psf_arr, int memspace);
+/* The sampling positions yxco of imcom_sample_psf from a coarse lattice: the reference evaluates outpix2world2inpix at all
+ * nsamp^2 positions of a PSF group and exposure (psfutil.py:751-771: 146 689 WCS evaluations, the host half of the Block seam);
+ * over the ~5" they span that map is smooth, so a caller may evaluate it on an L x L lattice of Chebyshev-Lobatto nodes
+ * u_a = u_mid + u_half cos(pi a / (L - 1)) of the sample coordinate and hand over
+ *   lattice [count][2][L][L]  the offsets (y plane then x plane, as yxco) at lattice point (node a along y, node b along x)
+ *   W       [nsamp][L] (HOST) W[i][a] = Lagrange basis polynomial a of the nodes at sample coordinate i
+ * yxco[c][k][iy][ix] = sum_a sum_b W[iy][a] W[ix][b] lattice[c][k][a][b] -- exact for maps of degree < L per axis (an affine WCS,
+ * SIP distortion up to order L - 1), 2 <= L <= 33.  lattice / yxco follow `memspace`. */
+int imcom_lattice_positions(imcom_ctx *ctx, int count, int L, const double *W, const double *lattice, int nsamp,
+                            double *yxco, int memspace);
 /* OutPSF.psf_gaussian psfutil.py:117-146 and OutPSF.psf_simple_airy 148-223 (n x n, row-major) */
 int imcom_psf_gaussian(imcom_ctx *ctx, int n, double sigmax, double sigmay, double *out, int memspace);
 int imcom_psf_simple_airy(imcom_ctx *ctx, int n, double ldp, double obsc, double tophat_conv, double sigma,

@@ -98,6 +98,7 @@ SIGNATURES = {
     "imcom_trapezoid_f32": [_vp, _vp, _l, _i, _i],
     "imcom_clamp_min_f32": [_vp, _vp, _l, C.c_float],
     "imcom_sample_psf": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _i],
+    "imcom_lattice_positions": [_vp, _i, _i, _vp, _vp, _i, _vp, _i],
     "imcom_psf_gaussian": [_vp, _i, _d, _d, _vp, _i],
     "imcom_psf_simple_airy": [_vp, _i, _d, _d, _d, _d, _vp, _i],
     "imcom_smooth_and_pad": [_vp, _i, _vp, _i, _i, _d, _d, _vp, _i],

@@ -580,8 +580,27 @@ def plan_block(cfg, pool, tables, n1P, batch=None, ldn=None, stamps=None):
     return chunks
 
 
+class RepairRecord:
+    """What a block's FIRST pass saw of _cholesky_wrapper's repair (lakernel.py:262-279) -- the share of its stamps that took it and the
+    largest |w[0]| among them -- kept for the block's other passes: each of them tells the library to expect the repair and where the
+    smallest-eigenvalue iterations start (imcom_ctx_set_repair_hint) from THIS record, whoever runs the pass and whatever ran before it
+    in the process.  The first pass itself starts blind.  So the inputs of every pass are a function of the block alone, and a block
+    whose passes are shared between processes (pyimcom_amd.farm keeps the record in a file beside the block's claims) has the bits of
+    the single process's block -- until round 6 a pass started from the pass before it, and a repaired stamp's w[0] depended on the
+    partition at the 1e-13 level.  In memory here; ``get`` waits for ``put`` only in the file-backed form."""
+
+    def __init__(self):
+        self.value = None
+
+    def put(self, share, hint):
+        self.value = {"share": float(share), "hint": None if hint is None else float(hint)}
+
+    def get(self):
+        return self.value
+
+
 def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postage_pad=0, ldn=None, pipeline=True, stamps=None, chunks=None,
-                claim=None, origin=(1, 1), repair_state=None):
+                claim=None, origin=(1, 1), repair_state=None, repair_record=None, first_chunk=0):
     """Coadd the n1P x n1P output stamps of a block.  ``pool``: InStampPool of the (n1P+2)^2 InStamps in row-major
     order (index j * nst + i, coadd.py:207); ``tables``: PSFGroupTables or BlockTables.  ``stamps``: the (j_st, i_st) to
     coadd (default all n1P x n1P); ``pad_sides=None`` leaves the boundary recovery of coadd.py:2163-2181 out.  ``batch``:
@@ -589,9 +608,11 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     right before pass q is prepared; a pass it refuses is left out (another process coadds it: pyimcom_amd.farm shares a block's
     passes between the GPUs of a node) -- the passes that were run are listed in ``maps.chunks_done``.  ``origin``: (j_st_min,
     i_st_min) of the reference's loop (coadd.py:1808-1838): with fade > 0 overlapping stamps are summed in the order of that loop
-    whatever the batches are (block.py).  ``repair_state``: a dict a driver keeps from block to block ({"share", "hint"}: what the last
-    pass saw of _cholesky_wrapper's repair) -- a block's first pass then starts where the previous block's last one ended instead of
-    blind.  Returns the BlockMaps."""
+    whatever the batches are (block.py).  ``repair_record`` (a RepairRecord; default: one of this call's own) and ``first_chunk`` (the
+    index in ``chunks`` of the block's first pass): the Cholesky repair's expectation and starting shift of every pass but the first come
+    from the block's first pass (RepairRecord).  ``repair_state``: a dict that receives {"share", "hint"} of that record (for a driver's
+    log; until round 6 it carried them from block to block -- a block's result then depended on the blocks before it).  Returns the
+    BlockMaps."""
     nst = n1P + 2
     assert pool.n_inst == nst * nst
     maps = BlockMaps(n1P, cfg.n2, cfg.fade, cfg.n_inframe, n_expo, ctx=tables.ctx, device=str(pool.device),
@@ -695,17 +716,23 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
     import time
 
     t_pass = time.perf_counter()
-    share = 0.0  # of the previous pass's stamps that took the Cholesky repair: at the reference's production shape it is every stamp, and a
-                 # pass that follows such a pass does not attempt the factorisation that fails (StampBatch.solve_begin)
-    hint = None  # max |w[0]| of the last pass that repaired stamps: where the next pass's smallest-eigenvalue iterations start (over a production
-                 # block it stays within 1 % from pass to pass: profiles/r05_negative_results.txt item 7)
-    if repair_state:
-        share, hint = float(repair_state.get("share", 0.0)), repair_state.get("hint")
+    record = repair_record if repair_record is not None else RepairRecord()
+
+    def pass_inputs(q):
+        """(expect the repair, where its iterations start) for pass q: nothing for the block's first pass, the first pass's record for the others"""
+        if q == first_chunk:
+            return False, None
+        rec = record.get()  # (file-backed: waits until the process that runs the first pass has written it)
+        if rec is None:  # no first pass in this call's plan (a driver that runs a block's later passes alone): blind
+            return False, None
+        return rec["share"] >= StampBatch.EXPECT_REPAIR, rec["hint"]
+
     while nxt is not None:
         sb = nxt
         sb.build()
         try:
-            sb.solve_begin(expect_repair=share >= StampBatch.EXPECT_REPAIR, repair_hint=hint)
+            expect, hint = pass_inputs(sb.chunk_index)
+            sb.solve_begin(expect_repair=expect, repair_hint=hint)
             if pipeline:
                 nxt = next_batch()
             sb.solve_end()
@@ -718,6 +745,8 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
             in_halves(sb)
             maps.passes_halved += 1
             maps.chunks_done.append(sb.chunk_index)
+            if sb.chunk_index == first_chunk:  # (its halves were solved blind by the synchronous entry: the record says "no expectation, no hint")
+                record.put(0.0, None)
             if prepared is not None:
                 # the halves' table sets may have replaced the ones the already prepared next pass was given (its slots and maps were fixed
                 # when it was prepared): prepare it again
@@ -727,8 +756,8 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
             elif not pipeline or nxt is sb:
                 nxt = next_batch()  # (a pass whose preparation failed above is still pending: it is prepared again, not skipped)
             continue
-        share = float(getattr(sb, "repair_share", 0.0))
-        hint = getattr(sb, "repair_absmax", None) or hint
+        if sb.chunk_index == first_chunk:
+            record.put(float(getattr(sb, "repair_share", 0.0)), getattr(sb, "repair_absmax", None))
         check_batch(sb)
         sb.coadd()
         if not pipeline:
@@ -738,8 +767,8 @@ def coadd_block(cfg, pool, tables, n1P, n_expo, batch=None, pad_sides="", postag
         maps.info_nonzero += int(sum(int((np.asarray(i_) != 0).sum()) for i_ in sb.info_o))  # stamps repaired (Cholesky) / re-solved in the eigenbasis (Eigen)
         maps.pass_seconds.append(time.perf_counter() - t_pass)
         t_pass = time.perf_counter()
-    if repair_state is not None:
-        repair_state.update(share=share, hint=hint)
+    if repair_state is not None and record.value is not None:
+        repair_state.update(record.value)
     if sorted(claimed) != sorted(maps.chunks_done):  # (never seen; a pass that was taken and not coadded would be a silent hole in the maps)
         raise RuntimeError(f"coadd_block: passes taken {sorted(claimed)} but coadded {sorted(maps.chunks_done)}")
     if pad_sides is not None:

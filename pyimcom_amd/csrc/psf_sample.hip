@@ -176,6 +176,39 @@ __global__ void crop_rect_kernel(const double *__restrict__ Z, int Py, int Px, i
     out[((long)p * nyy + r) * nxx + c] = Z[((long)p * Py + r) * Px + c];
 }
 
+// Sampling positions from a coarse lattice (round 6).  The reference evaluates the WCS chain outpix2world2inpix at all nsamp^2 =
+// 146 689 sampling positions of a PSF group and exposure (psfutil.py:751-771); over the 5" the samples span that map is smooth to
+// rounding at polynomial degree 16, so the host evaluates it on an L x L lattice of Chebyshev-Lobatto nodes and this kernel forms
+// yxco[c][k][iy][ix] = sum_a sum_b W[iy][a] W[ix][b] lat[c][k][a][b], W[i][a] = the a-th Lagrange basis polynomial of the nodes at
+// sample i (host, barycentric form).  One workgroup per (ROWS sample rows, coordinate plane): T[a][ix] = sum_b lat[a][b] W[ix][b] in
+// LDS, then out[iy][ix] = sum_a W[iy][a] T[a][ix].
+constexpr int LAT_ROWS = 32;
+__global__ __launch_bounds__(256) void lattice_positions_kernel(const double *__restrict__ W, const double *__restrict__ lat, int L, int ns,
+                                                                double *__restrict__ out)
+{
+    extern __shared__ double Tl[];  // [L][ns]
+    const int plane = blockIdx.y, r0 = blockIdx.x * LAT_ROWS;
+    const double *F = lat + (long)plane * L * L;
+    for (int ix = threadIdx.x; ix < ns; ix += 256) {
+        const double *w = W + (long)ix * L;
+        for (int a = 0; a < L; a++) {
+            double t = 0.0;
+            for (int b = 0; b < L; b++) t += F[a * L + b] * w[b];
+            Tl[a * ns + ix] = t;
+        }
+    }
+    __syncthreads();
+    double *o = out + (long)plane * ns * ns;
+    for (int iy = r0; iy < min(r0 + LAT_ROWS, ns); iy++) {
+        const double *w = W + (long)iy * L;
+        for (int ix = threadIdx.x; ix < ns; ix += 256) {
+            double v = 0.0;
+            for (int a = 0; a < L; a++) v += w[a] * Tl[a * ns + ix];
+            o[(long)iy * ns + ix] = v;
+        }
+    }
+}
+
 }  // namespace imcom
 
 using namespace imcom;
@@ -243,6 +276,41 @@ extern "C" int imcom_sample_psf(imcom_ctx *ctx, int n_psf, const double *psf, in
     }
     if (host) {
         IMCOM_HIP_CHECK(hipMemcpyAsync(psf_arr, out_d, szout, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return IMCOM_OK;
+}
+
+extern "C" int imcom_lattice_positions(imcom_ctx *ctx, int count, int L, const double *W, const double *lattice, int nsamp, double *yxco,
+                                       int memspace)
+{
+    IMCOM_TRY(ctx_ok3(ctx));
+    IMCOM_REQUIRE(count >= 1 && L >= 2 && L <= 33 && W && lattice && yxco && nsamp >= 1 && nsamp <= 600, "bad arguments (2 <= L <= 33, nsamp <= 600)");
+    const bool host = memspace == IMCOM_MEM_HOST;
+    const size_t szW = (size_t)nsamp * L * 8, szL = (size_t)count * 2 * L * L * 8, szO = (size_t)count * 2 * nsamp * nsamp * 8;
+    IMCOM_TRY(ws_reserve(ctx, szW + (host ? szL + szO : 0) + 8192));
+    double *W_d = (double *)ws_take(ctx, szW);
+    const double *lat_d = lattice;
+    double *out_d = yxco;
+    if (!W_d) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+    IMCOM_TRY(upload(ctx, W_d, W, (size_t)nsamp * L));
+    if (host) {
+        double *l = (double *)ws_take(ctx, szL);
+        out_d = (double *)ws_take(ctx, szO);
+        if (!l || !out_d) { set_error("internal: workspace"); return IMCOM_ERR_NOMEM; }
+        IMCOM_HIP_CHECK(hipMemcpyAsync(l, lattice, szL, hipMemcpyHostToDevice, ctx->stream));
+        lat_d = l;
+    }
+    const size_t lds = (size_t)L * nsamp * 8;
+    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)lattice_positions_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        ProfScope ps(ctx, "psf_sample");
+        hipLaunchKernelGGL(lattice_positions_kernel, dim3((nsamp + LAT_ROWS - 1) / LAT_ROWS, 2 * count), dim3(256), lds, ctx->stream, (const double *)W_d, lat_d,
+                           L, nsamp, out_d);
+        IMCOM_TRY(check_launch("lattice_positions_kernel"));
+    }
+    if (host) {
+        IMCOM_HIP_CHECK(hipMemcpyAsync(yxco, out_d, szO, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     return IMCOM_OK;

@@ -241,16 +241,30 @@ def _claim(path, me):
         return False
 
 
-def _heartbeat(path):
-    """Touch the latest generation of a claim this process holds (for readers that cannot look its process up)."""
+def _heartbeat(path, me=None):
+    """Touch the latest generation of a claim (for readers that cannot look its owner's process up) -- only when that generation's
+    record is this process's own (``me``: its owner record): a helper that shares a block's tail passes must not keep a dead
+    cross-host owner's block claim looking alive."""
+    import json
     import os
 
     g = _latest_gen(path)
-    if g >= 0:
+    if g < 0:
+        return False
+    p = _gen_path(path, g)
+    if me is not None:
         try:
-            os.utime(_gen_path(path, g))
-        except OSError:
-            pass
+            with open(p) as f:
+                rec, mine = json.loads(f.read() or "null"), json.loads(me)
+            if not isinstance(rec, dict) or any(rec.get(k) != mine.get(k) for k in ("rank", "pid", "start", "host")):
+                return False
+        except (OSError, ValueError):
+            return False
+    try:
+        os.utime(p)
+        return True
+    except OSError:
+        return False
 
 
 def _is_claim_file(name):
@@ -301,10 +315,10 @@ class _GpuBackend:
 
         from .blockrun import coadd_block
 
-        # (what the last pass saw of the Cholesky repair travels from block to block: a block's first pass does not start blind)
-        self._repair_state = getattr(self, "_repair_state", {})
+        # what the block's FIRST pass saw of the Cholesky repair serves its other passes, whoever runs them (blockrun.RepairRecord; the
+        # driver keeps it in a file beside the block's claims): a shared block has the single process's bits
         maps = coadd_block(spec["cfg"], spec["pool"], spec["tables"], spec["n1P"], spec["n_expo"], chunks=chunks, claim=claim, pad_sides=None,
-                           repair_state=self._repair_state)
+                           repair_record=spec.get("_repair_record"), first_chunk=spec.get("_first_chunk", 0))
         torch.cuda.synchronize()
         return maps.state(), list(maps.chunks_done)
 
@@ -322,6 +336,46 @@ class _GpuBackend:
         maps.finalize(spec.get("pad_sides", ""), spec.get("postage_pad", 0))
         torch.cuda.synchronize()
         return maps.arrays()
+
+
+class _FileRepairRecord:
+    """blockrun.RepairRecord in a file of the launch's claim directory (b<id>.repair.json): written once, atomically, by the process that
+    ran the block's first pass; the other processes' passes wait for it (they join a block from the end of its plan, normally long after
+    its first pass is through).  ``max_wait`` seconds without the file: the first pass's owner is taken to be gone -- an error, as a
+    pass would otherwise start from something else than what the single process's pass starts from."""
+
+    def __init__(self, path, poll=0.05, max_wait=None):
+        self.path, self.poll, self.max_wait, self.value = path, poll, max_wait, None
+
+    def put(self, share, hint):
+        import json
+
+        self.value = {"share": float(share), "hint": None if hint is None else float(hint)}
+        text = json.dumps(self.value)
+
+        def wr(tmp):
+            with open(tmp, "w") as f:
+                f.write(text)
+
+        _atomic_write(self.path, wr)
+
+    def get(self):
+        import json
+        import time
+
+        if self.value is not None:
+            return self.value
+        t0 = time.monotonic()
+        while True:
+            try:
+                with open(self.path) as f:
+                    self.value = json.load(f)
+                return self.value
+            except (OSError, ValueError):
+                pass
+            if self.max_wait is not None and time.monotonic() - t0 > self.max_wait:
+                raise RuntimeError(f"{self.path}: the block's first pass left no repair record within {self.max_wait:.0f} s")
+            time.sleep(self.poll)
 
 
 class _Prefetch:
@@ -500,14 +554,21 @@ def run(blocks, costs, make_block, outdir, rank=0, world=1, batch=None, device=N
         view = [chunks[q] for q in idx]
         t0 = time.perf_counter()
 
+        held = [None]  # the pass claim this process took last
+
         def claim(k):
             path = cp(b, f"c{idx[k]:04d}.claim")
-            _heartbeat(cp(b, "claim"))  # (for ranks that cannot look this process up: the block's owner is at work)
+            _heartbeat(cp(b, "claim"), me)  # (for ranks that cannot look this process up: the block's owner -- if that is this process -- is at work)
+            if held[0] is not None:
+                _heartbeat(held[0], me)  # and the pass claim this process holds
             if _try_create(path, me):
+                held[0] = path
                 return True
             # the pass of a rank that died before it wrote its part
             return _claim_state(path) is False and idx[k] not in covered(b) and _claim(path, me)
 
+        spec["_repair_record"] = _FileRepairRecord(cp(b, "repair.json"), poll, max_wait if max_wait is not None else 1800.0)
+        spec["_first_chunk"] = idx.index(0)  # where the block's first pass sits in this view of its plan
         arrays, ran = be.coadd(spec, view, claim)
         ran = [idx[k] for k in ran]
         passes_run[0] += len(ran)

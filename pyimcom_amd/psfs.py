@@ -115,3 +115,44 @@ def sample_psf(psf, nsamp, yxco=None, psf_circ=False, psf_norm=False, ctx=None):
     check(lib.imcom_sample_psf(ctx.handle, n_psf, _p(psf), ny, nx, _p(yxco), int(nsamp), int(bool(psf_circ)), int(bool(psf_norm)),
                                _p(out), MEM_DEVICE if tor else MEM_HOST))
     return out
+
+
+def lattice_nodes_and_weights(grid, L=17):
+    """Chebyshev-Lobatto nodes u_a over [grid[0], grid[-1]] and W [len(grid), L], W[i][a] = the a-th Lagrange basis polynomial of the
+    nodes at grid[i] (barycentric form, weights (-1)^a, halved at the ends) -- the host inputs of ``lattice_positions``."""
+    grid = np.asarray(grid, dtype=np.float64)
+    mid, half = 0.5 * (grid[0] + grid[-1]), 0.5 * (grid[-1] - grid[0])
+    a = np.arange(L)
+    nodes = mid + half * np.cos(np.pi * a / (L - 1))
+    w = (-1.0) ** a
+    w[0] *= 0.5
+    w[-1] *= 0.5
+    d = grid[:, None] - nodes[None, :]
+    hit = d == 0.0
+    d[hit] = 1.0
+    W = w[None, :] / d
+    W /= W.sum(axis=1, keepdims=True)
+    rows = hit.any(axis=1)
+    W[rows] = hit[rows].astype(np.float64)
+    return nodes, np.ascontiguousarray(W)
+
+
+def lattice_positions(lattice, W, nsamp, ctx=None):
+    """The sampling positions yxco [count, 2, nsamp, nsamp] of ``sample_psf`` from their values on an L x L lattice of Chebyshev-Lobatto
+    nodes (imcom_lattice_positions): ``lattice`` [count, 2, L, L] (numpy -> numpy out, torch device tensor -> device out), ``W`` from
+    ``lattice_nodes_and_weights``.  Replaces the nsamp^2 WCS evaluations per PSF group and exposure of psfutil.py:751-771."""
+    ctx = ctx or default_context()
+    tor = _is_torch(lattice)
+    count, two, L, L2 = lattice.shape
+    assert two == 2 and L == L2 and W.shape == (nsamp, L)
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    if tor:
+        import torch
+
+        lattice = lattice.contiguous()
+        ctx.set_stream(torch.cuda.current_stream(lattice.device).cuda_stream)
+    else:
+        lattice = np.ascontiguousarray(lattice, dtype=np.float64)
+    out = _out((count, 2, nsamp, nsamp), "torch" if tor else "numpy", lattice.device if tor else None)
+    check(lib.imcom_lattice_positions(ctx.handle, int(count), int(L), _p(W), _p(lattice), int(nsamp), _p(out), MEM_DEVICE if tor else MEM_HOST))
+    return out

@@ -104,14 +104,22 @@ class _HostAhead:
         self.futures, self.queue = {}, []
 
 
-def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1):
+LATTICE = 17  # nodes per axis of the lattice the sampling positions are evaluated on (positions="lattice")
+
+
+def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1, positions="lattice"):
     """PSFGrp._build_inpsfgrp for the 2x2 groups of InStamps (psfutil.py:797-851), on demand: returns (count, expo, provider,
     ahead) with count[(gj, gi)] = number of exposures with pixels in the group, expo[(gj, gi)] = their block indices,
     ``provider(keys)`` -> device tensor [sum of the keys' counts, nsamp, nsamp] of sampled PSFs, and ``ahead`` the _HostAhead that
     prepares the host half of coming groups (``ahead.schedule(keys in the order they will be needed)``): the host fetches the
     groups' PSF images at their computation points and evaluates the sampling positions (file broker, WCS: InImage.get_psf_pos,
     outpix2world2inpix), the provider uploads both, and the sampling + cut-out + normalisation (psfutil.py:709-795, 650-656) run
-    on the device in one call.  Nothing is read back; a group is fetched when a batch of stamps first needs it (BlockTables)."""
+    on the device in one call.  Nothing is read back; a group is fetched when a batch of stamps first needs it (BlockTables).
+    ``positions``: "exact" -- the host evaluates ``outpix2world2inpix`` at all nsamp^2 = 146 689 sampling positions per group and
+    exposure, as psfutil.py:751-771 does (2.3 MB uploaded each); "lattice" (default) -- at the 17 x 17 Chebyshev-Lobatto nodes spanning
+    the same window, and the device forms the positions from them (psfs.lattice_positions: exact for maps of degree < 17 per axis; the
+    real chain's deviation from that over the 5" window is below rounding -- tests/test_gpu_refblock.py bounds it at 1e-10 samples on
+    affine + distorted maps)."""
     import torch
 
     from . import psfs
@@ -121,6 +129,14 @@ def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1):
     lin = np.arange(ns) - (ns - 1) / 2.0
     gx, gy = np.meshgrid(lin, lin)
     xy = np.stack([gx.ravel(), gy.ravel()], axis=1) * float(psfgrp.dscale)  # psfutil.py:751-771
+    lattice = positions == "lattice"
+    if positions not in ("lattice", "exact"):
+        raise ValueError(f"positions = {positions!r}")
+    if lattice:
+        nodes, W_lat = psfs.lattice_nodes_and_weights(lin * float(psfgrp.dscale), LATTICE)
+        lx, ly = np.meshgrid(nodes, nodes)  # [a][b]: node a along y, node b along x
+        xy = np.stack([lx.ravel(), ly.ravel()], axis=1)
+    npos = LATTICE if lattice else ns  # positions per axis the host evaluates
     count, expo = {}, {}
     for gj in range(nst // 2):
         for gi in range(nst // 2):
@@ -152,13 +168,17 @@ def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1):
         if len({img.shape for img, _ in out}) == 1:
             k = len(out)
             imgs = torch.empty((k,) + out[0][0].shape, dtype=torch.float64, pin_memory=True)
-            yx = torch.empty((k, 2, ns, ns), dtype=torch.float64, pin_memory=True)
+            yx = torch.empty((k, 2, npos, npos), dtype=torch.float64, pin_memory=True)
             iv, yv = imgs.numpy(), yx.numpy()
             for q, (img, d) in enumerate(out):
                 iv[q] = img
-                yv[q, 0], yv[q, 1] = d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)
+                yv[q, 0], yv[q, 1] = d[:, 1].reshape(npos, npos), d[:, 0].reshape(npos, npos)
             return imgs, yx
-        return [(img, np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)])) for img, d in out]
+        return [(img, np.stack([d[:, 1].reshape(npos, npos), d[:, 0].reshape(npos, npos)])) for img, d in out]
+
+    def full(yx):
+        """device positions [k, 2, ns, ns] of what the host evaluated"""
+        return psfs.lattice_positions(yx, W_lat, ns, ctx) if lattice else yx
 
     ahead = _HostAhead(host_half, host_threads)
 
@@ -177,7 +197,7 @@ def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1):
             cur.wait_stream(up)
             im.record_stream(cur)
             yx.record_stream(cur)
-            return psfs.sample_psf(im, ns, yx, circ, norm, ctx)
+            return psfs.sample_psf(im, ns, full(yx), circ, norm, ctx)
         imgs, yxco = [], []
         for g in got:
             pairs = [(g[0][q].numpy(), g[1][q].numpy()) for q in range(g[0].shape[0])] if isinstance(g, tuple) else g
@@ -189,7 +209,7 @@ def input_psf_groups(blk, psfgrp, device, ctx=None, host_threads=1):
         for q, im in enumerate(imgs):  # PSF images of one size are sampled together (normally all of them)
             shapes.setdefault(im.shape, []).append(q)
         for idx in shapes.values():
-            got = psfs.sample_psf(up(np.stack([imgs[q] for q in idx])), ns, up(np.stack([yxco[q] for q in idx])), circ, norm, ctx)
+            got = psfs.sample_psf(up(np.stack([imgs[q] for q in idx])), ns, full(up(np.stack([yxco[q] for q in idx]))), circ, norm, ctx)
             if len(shapes) == 1:
                 return got
             out[torch.as_tensor(idx, device=device)] = got
@@ -213,7 +233,7 @@ def target_psfs(cfg, psfgrp, device, ctx=None):
 _REPAIR_STATE = {}  # per context: what the last pass of the last block saw of _cholesky_wrapper's repair (blockrun.coadd_block)
 
 def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None, ctx=None,
-                        host_threads=1):
+                        host_threads=1, positions="lattice"):
     """Run the stamp loop of ``blk`` on the GPU and fill its block maps (module docstring).  The stamps are those of the
     reference's loop: the window ``blk.j_st_min .. j_st_max, i_st_min .. i_st_max`` of Block._handle_postage_pad (coadd.py:1808-1838;
     default: all n1P x n1P) in cells of 2 x 2, stopping after ``blk.nrun`` stamps when the block carries one (cfg.stoptile,
@@ -224,7 +244,9 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     (default: the whole block's, or a third of the free device memory); ``ctx``: the library context to run on (default: the
     process-wide one of the device).  The host half of the PSF groups (PSF images, WCS evaluation of the sampling positions) of
     the coming batches is prepared on ``host_threads`` worker thread(s) while the GPU works on the current one (_HostAhead; one
-    thread unless the block's ``inimages`` may be entered from several).  Returns the ``BlockMaps``."""
+    thread unless the block's ``inimages`` may be entered from several).  ``positions``: "lattice" (default) -- the WCS chain is evaluated
+    at 17 x 17 nodes per PSF group and exposure and the device forms the nsamp^2 sampling positions from them; "exact" -- at all nsamp^2,
+    as the reference does (input_psf_groups).  Returns the ``BlockMaps``."""
     from .blockrun import coadd_block, plan_block, stamp_groups
     from .select import InStampPool
     from .stamps import BlockTables
@@ -238,7 +260,7 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
         if hasattr(cfg, k):
             setattr(scfg, k, getattr(cfg, k))
     pool = InStampPool([(st.x_val, st.y_val, st.data, st.pix_cumsum) for row in blk.instamps for st in row], scfg.n_inframe, device=device)
-    count, expo, provider, ahead = input_psf_groups(blk, psfgrp, device, ctx, host_threads)
+    count, expo, provider, ahead = input_psf_groups(blk, psfgrp, device, ctx, host_threads, positions)
     target = target_psfs(cfg, psfgrp, device, ctx)
     amp = getattr(cfg, "amp_penalty", None)
     amp = None if amp is None or 0.0 in tuple(amp) else (float(amp[0]), float(amp[1]) * float(psfgrp.oversamp))  # psfutil.py:661-671

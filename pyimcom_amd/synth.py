@@ -300,12 +300,13 @@ def group_psfs(psfs, gj, gi):
     return p / p.sum(axis=(1, 2), keepdims=True)
 
 
-def duck_block(wl, n1P, E, seed=3, kernel="Cholesky", pad_sides="all"):
+def duck_block(wl, n1P, E, seed=3, kernel="Cholesky", pad_sides="all", distortion=0.0):
     """A duck-typed ``pyimcom.coadd.Block`` + ``PSFGrp`` class attributes for ``refblock.coadd_output_stamps`` without FITS /
     WCS machinery: synthetic InStamps (``make_instamps``), per exposure an affine output-pixel -> input-pixel map (a small
     rotation) and a PSF image that varies smoothly with the position it is asked for, an identity output WCS.  What the
     reference's Block constructor would leave behind (coadd.py:1560-1937), as far as the stamp loop reads it.
-    Returns (blk, psfgrp, inst, image_at)."""
+    ``distortion`` > 0 adds quadratic and cubic terms to the maps (an optical distortion: ``distortion`` per output pixel^2, and
+    1e-4 of that per pixel^3, different per exposure).  Returns (blk, psfgrp, inst, image_at)."""
     ARCSEC = np.pi / 180.0 / 3600.0
     inst = make_instamps(wl, n1P, E, np.random.default_rng(seed))
     base, _ = make_psfs(wl, E)
@@ -339,7 +340,16 @@ def duck_block(wl, n1P, E, seed=3, kernel="Cholesky", pad_sides="all"):
         th = 0.004 * (e - E / 2)
         M = scale * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
         im.get_psf_pos = (lambda e_: (lambda point, use_shortrange=True: image_at(e_, point)))(e)
-        im.outpix2world2inpix = (lambda M_: (lambda xy: np.asarray(xy) @ M_.T))(M)
+        if distortion:
+            def warp(xy, M_=M, q_=distortion * (1.0 + 0.1 * e), c_=1e-4 * distortion):
+                xy = np.asarray(xy, dtype=np.float64)
+                x, y = xy[:, 0], xy[:, 1]
+                lin_ = xy @ M_.T
+                return lin_ + scale * np.stack([q_ * (x * x - 0.5 * x * y + 0.3 * y * y) + c_ * x * x * y, q_ * (0.7 * x * y - 0.2 * y * y) + c_ * (y**3 - x * y * y)], axis=1)
+
+            im.outpix2world2inpix = warp
+        else:
+            im.outpix2world2inpix = (lambda M_: (lambda xy: np.asarray(xy) @ M_.T))(M)
         blk.inimages.append(im)
     blk.instamps = [[None] * nst for _ in range(nst)]
     for j in range(nst):

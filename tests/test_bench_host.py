@@ -99,7 +99,7 @@ def test_the_stdout_line_is_compact_and_parses():
         assert line["cpu_baseline"]["value"] == 3.2123 and line["cpu_baseline"]["cores"] == 256 and line["cpu_baseline"]["kind"] == "port"
         assert line["cpu_baseline"]["one_thread"] == 1.5882 and line["cpu_baseline"]["processes"]["processes"] == 64
         assert line["config"]["workload"].startswith("BASELINE configs[1]") and len(line["config"]["workload"]) <= 200
-        assert line["n_gpus"] == n_gpus and line["value"] == 1662.1 and line["detail"] == "bench_detail.json"
+        assert line["n_gpus"] == n_gpus and line["value"] == 1662.123456 and line["detail"] == "bench_detail.json"
         for verbose in ("configs", "block", "eigen_block", "telemetry", "step_ms", "stage_ms_per_step"):
             assert verbose not in line
         assert "summary_truncated" not in line and line["summary"]["iter_default"]["v"] == 612.3

@@ -361,3 +361,38 @@ def test_launch_token_and_claim_liveness(tmp_path):
     empty = tmp_path / "d.claim"
     empty.write_text("")
     assert farm._claim_state(str(empty)) is True and farm._claim_state(str(empty), grace=0.0) is False
+
+
+def test_heartbeat_touches_only_own_claims_and_repair_record_file(tmp_path):
+    """a heartbeat touches a claim only when its latest generation is this process's own (a helper must not keep a dead
+    cross-host owner's claim looking alive); and the block's repair record (blockrun.RepairRecord kept in a file by the farm) is written
+    once, atomically, and read by the other processes."""
+    import json
+    import os
+    import time
+
+    from pyimcom_amd import farm
+
+    me, other = farm._owner(0), json.dumps(dict(json.loads(farm._owner(1)), pid=1, start=12345, host="elsewhere"))
+    mine, theirs = str(tmp_path / "b0000.claim"), str(tmp_path / "b0001.claim")
+    assert farm._try_create(mine, me) and farm._try_create(theirs, other)
+    old = time.time() - 1000
+    os.utime(mine, (old, old))
+    os.utime(theirs, (old, old))
+    assert farm._heartbeat(mine, me) and not farm._heartbeat(theirs, me)
+    assert os.path.getmtime(mine) > old + 500 and abs(os.path.getmtime(theirs) - old) < 1
+    assert not farm._heartbeat(str(tmp_path / "none.claim"), me)
+    # a later generation that is somebody else's: not touched either
+    assert farm._try_create(farm._gen_path(mine, 1), other)
+    assert not farm._heartbeat(mine, me)
+
+    rec = farm._FileRepairRecord(str(tmp_path / "b0000.repair.json"), poll=0.01, max_wait=0.2)
+    try:
+        rec.get()
+        raise AssertionError("no record yet: get() must give up after max_wait")
+    except RuntimeError as e:
+        assert "repair record" in str(e)
+    farm._FileRepairRecord(str(tmp_path / "b0000.repair.json")).put(1.0, 1.63e-6)
+    assert rec.get() == {"share": 1.0, "hint": 1.63e-6} and not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+    farm._FileRepairRecord(str(tmp_path / "b0002.repair.json")).put(0.0, None)
+    assert farm._FileRepairRecord(str(tmp_path / "b0002.repair.json")).get() == {"share": 0.0, "hint": None}

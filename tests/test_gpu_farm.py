@@ -53,9 +53,10 @@ def test_farm_two_processes_equal_one(tmp_path):
 
 def test_farm_blocks_of_repaired_stamps_with_and_without_hints(tmp_path):
     """The reference's production shape through the farm driver (four blocks of 2 x 2 paper4 stamps in passes of two: every stamp takes
-    _cholesky_wrapper's repair, lakernel.py:262-279): what a pass learns about the repair travels to the next pass AND to the next block
-    (blockrun.coadd_block repair_state: expectation and the smallest eigenvalues' whereabouts).  Against the same run with
-    IMCOM_LMIN_HINT=0, in which every smallest-eigenvalue iteration starts blind: the same maps to the rounding of the float32 T."""
+    _cholesky_wrapper's repair, lakernel.py:262-279): what a block's FIRST pass learns about the repair serves the block's other passes
+    (blockrun.RepairRecord: expectation and the smallest eigenvalues' whereabouts); every block's first pass starts blind, so a block's
+    result does not depend on the blocks before it.  Against the same run with IMCOM_LMIN_HINT=0, in which every smallest-eigenvalue
+    iteration starts blind: the same maps to the rounding of the float32 T."""
     from pyimcom_amd import farm
 
     def run(out, env_extra):
@@ -68,16 +69,46 @@ def test_farm_blocks_of_repaired_stamps_with_and_without_hints(tmp_path):
     hinted, blind = str(tmp_path / "hinted"), str(tmp_path / "blind")
     o1 = run(hinted, {"IMCOM_LMIN_DEBUG": "1"})
     run(blind, {"IMCOM_LMIN_HINT": "0"})
-    # the iterations of the hinted run: a pass that starts blind needs two factorisations inside its iteration, the second pass of every block
-    # -- neighbours of the first pass's stamps -- one.  (The blocks of this mosaic have PSFs and lattices of their own: their smallest
-    # eigenvalues differ by more than the hint's reach, so a block's first pass, handed the previous block's value, still takes two.)
+    # the iterations of the hinted run: a pass that starts blind -- every block's first -- needs two factorisations inside its iteration, the
+    # second pass of every block -- neighbours of the first pass's stamps, started from its record -- one
     facs = [int(l.split(" stamps: ")[1].split()[0]) for l in o1.splitlines() if l.startswith("[lmin]") and " stamps: " in l]
-    assert len(facs) == 8 and facs[0] == 2 and all(f == 1 for f in facs[1::2]) and all(f <= 2 for f in facs), facs
+    assert len(facs) == 8 and all(f == 2 for f in facs[0::2]) and all(f == 1 for f in facs[1::2]), facs
     for b in range(4):
         a, c = np.load(farm.block_path(hinted, b)), np.load(farm.block_path(blind, b))
         assert np.isfinite(a["out_map"]).all() and np.abs(a["out_map"]).max() > 0
         for k in ("out_map", "UC", "Sigma", "kappa"):
             assert np.allclose(a[k], c[k], rtol=2e-5, atol=5e-6 * np.abs(c[k]).max()), (b, k)
+
+
+def test_farm_shared_block_of_repaired_stamps_is_bit_identical(tmp_path):
+    """a block whose stamps all take the Cholesky repair (the reference's production shape), shared between two
+    processes WITH hints on, is the single process's block bit for bit: every pass but the block's first starts from the first pass's
+    record (a file beside the block's claims), whoever runs it."""
+    from pyimcom_amd import farm
+
+    def go(out, rank, world, token):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", PYTHONPATH=ROOT, IMCOM_LMIN_DEBUG="1")
+        env.pop("IMCOM_LMIN_HINT", None)
+        cmd = [sys.executable, "-m", "pyimcom_amd.farm", "--out", out, "--config", "paper4", "--mosaic", "1", "--n1P", "4", "--batch", "4",
+               "--shared-gpu", "--token", token]
+        return subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+    two, one = str(tmp_path / "two"), str(tmp_path / "one")
+    procs = [go(two, r, 2, "t2") for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    p1 = go(one, 0, 1, "t1")
+    o1 = p1.communicate(timeout=900)[0]
+    assert p1.returncode == 0, o1
+    a, c = np.load(farm.block_path(two, 0)), np.load(farm.block_path(one, 0))
+    for k in c.files:
+        if not k.startswith("meta_"):
+            assert np.array_equal(a[k], c[k]), k
+    assert np.isfinite(c["out_map"]).all() and np.abs(c["out_map"]).max() > 0
+    # hints were on: in the single process's run the first pass took two factorisations inside its iteration, the three others one
+    facs = [int(l.split(" stamps: ")[1].split()[0]) for l in o1.splitlines() if l.startswith("[lmin]") and " stamps: " in l]
+    assert facs == [2, 1, 1, 1], facs
+    assert os.path.exists(os.path.join(two, ".farm-t2", "b0000.repair.json"))
 
 
 def test_farm_dynamic_schedule_shares_a_block(tmp_path):
@@ -170,7 +201,7 @@ def test_farm_cfg4_block_with_psf_groups_vs_oracle(tmp_path):
     assert np.allclose(blk["kappa"][0, ys, xs], kp.reshape(s2), rtol=1e-6) and np.allclose(blk["T_weightmap"][0, :, j - 1, i - 1], Tst[0], rtol=2e-5, atol=2e-5 * np.abs(Tst).max())
 
 
-def test_bench_multi_rank_rehearsal():
+def test_bench_multi_rank_rehearsal(tmp_path):
     """bench.py's N > 1 path (torch.distributed.run, one rank per GPU, barrier + max-over-ranks timing, rank 0 prints
     the one JSON line) rehearsed on this one-GPU box: two ranks share cuda:0 and rendezvous over gloo.  Not a
     measurement -- it keeps the launch contract of the scaling run from rotting."""
@@ -180,17 +211,25 @@ def test_bench_multi_rank_rehearsal():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8",
            "--rehearse-shared-gpu", "--farm-mosaic", "2", "--farm-n1P", "4"]
-    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    detail = str(tmp_path / "detail.json")
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, IMCOM_BENCH_DETAIL=detail), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
+    assert len(lines) == 1 and out.stdout.rstrip().endswith(lines[0]) and len(lines[0]) < 4096, out.stdout  # ONE compact line, last on stdout
+    assert not [l for l in out.stderr.splitlines() if l.startswith("{")]  # (stderr carries the detail as prefixed lines, never a bare JSON line)
     d = json.loads(lines[0])
+    full = json.load(open(detail))  # everything verbose: the detail file
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "postage-stamps/s"
     assert d["config"]["stamps_per_step_per_gpu"] == 8 and d["value"] > 0 and "cpu_baseline" not in d and "block" not in d
     assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # whole-job aggregate over both ranks
     # BASELINE configs[3] on the multi-rank clock: a 2 x 2 mosaic of small cfg-4 blocks farmed over the two ranks (dynamic schedule)
-    f = d["farm"]
+    assert d["farm"]["blocks"] == 4 and d["farm"]["ranks_seen"] == 2 and d["farm"]["value"] > 0 and len(d["per_rank_value"]) == 2
+    f = full["farm"]
     assert "error" not in f and f["blocks"] == 4 and f["ranks_seen"] == 2 and f["n_gpus"] == 2 and f["stamps"] == 4 * 16
     assert sum(f["per_rank_blocks_written"]) == 4 and f["value"] > 0 and abs(f["value"] - f["stamps"] / f["makespan_s"]) < 1e-9 * f["value"]
     assert len(f["per_rank_busy_s"]) == 2 and all(0 < b_ <= f["makespan_s"] + 1e-6 for b_ in f["per_rank_busy_s"]) and f["blocks_missing"] == []
     assert d["summary"]["farm"]["v"] > 0 and d["summary"]["farm"]["blocks"] == 4
+    # the leg times GPUs: the blocks' host inputs are synthesised before the clock
+    # (this rehearsal's mosaic is tiny -- a 0.3 s makespan of which the claim files and polls are a visible part; at the driver's sizes the share
+    # is in profiles/r06_*: >= 0.9)
+    assert f["host_build_s"] > 0 and f["busy_share"] >= 0.6, (f["busy_share"], f["per_rank_busy_s"], f["makespan_s"])

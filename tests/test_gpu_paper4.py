@@ -184,9 +184,10 @@ def test_paper4_kernel_class_seam_vs_oracle():
 
 def test_paper4_block_in_several_passes_expects_the_repair():
     """``coadd_block`` over a 4 x 4 corner in passes of four stamps: the first pass finds every factorisation failing, the following ones
-    are told to expect that (StampBatch.solve_begin(expect_repair=True, repair_hint=...)) and go straight to the smallest eigenvalues -- the maps must be
+    are told to expect that (StampBatch.solve_begin(expect_repair=True, repair_hint=...)) and go straight to the smallest eigenvalues, all of
+    them from the FIRST pass's record (blockrun.RepairRecord: a pass's inputs are a function of the block alone) -- the maps must be
     those of the single-pass block to the rounding of the solves (not bit for bit: launches of different batch sizes deal their tiles
-    differently), every stamp repaired."""
+    differently), every stamp repaired.  A block's first pass starts blind whatever ran before it."""
     import torch
 
     from pyimcom_amd import synth
@@ -215,19 +216,20 @@ def test_paper4_block_in_several_passes_expects_the_repair():
         hints.clear()
         state = {}
         four = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=4, repair_state=state)
-        # ... and a driver that keeps the state hands it to its next block: that block's FIRST pass already expects the repair and knows where
-        assert state["share"] == 1.0 and 1e-6 < state["hint"] < 3e-6
-        n_before, state_hint_before = len(calls), state["hint"]
+        # the record of the block's first pass is handed out (a driver's log) ...
+        assert state["share"] == 1.0 and 1e-6 < state["hint"] < 3e-6 and state["hint"] == hints[1]
+        n_before = len(calls)
+        # ... but not read: the next block's first pass starts blind again, its second pass from ITS first pass's record
         again = coadd_block(cfg, pool, tabs, n1P, cfg.n_expo, batch=8, repair_state=state)
-        assert calls[n_before:] == [True, True] and hints[n_before] == state_hint_before
+        assert calls[n_before:] == [False, True] and hints[n_before] is None and 1e-6 < hints[n_before + 1] < 3e-6
         assert float((again.out_map - four.out_map).abs().max()) <= 5e-6 * float(four.out_map.abs().max())
         del calls[n_before:], hints[n_before:]
     finally:
         StampBatch.solve_begin = real
     torch.cuda.synchronize()
     assert calls == [False, True, True, True] and one.info_nonzero == four.info_nonzero == 16
-    # ... and where the smallest eigenvalues lie (max |w[0]| of the pass before: the iteration starts at that shift, one factorisation instead of two)
-    assert hints[0] is None and all(h is not None and 1e-6 < h < 3e-6 for h in hints[1:]), hints
+    # ... and where the smallest eigenvalues lie (max |w[0]| of the block's first pass: the iteration starts at that shift, one factorisation instead of two)
+    assert hints[0] is None and all(h is not None and 1e-6 < h < 3e-6 for h in hints[1:]) and len(set(hints[1:])) == 1, hints
     a, b = one.out_map, four.out_map
     assert float((a - b).abs().max()) <= 5e-6 * float(a.abs().max())
     for k in ("UC", "Sigma", "kappa", "Tsum", "Neff"):

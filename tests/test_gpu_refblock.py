@@ -233,7 +233,7 @@ def test_block_seam_at_reference_block_size():
     blk, psfgrp, inst, image_at = synth.duck_block(wl, n1P, E, seed=3)
     cfg, ns, nst = blk.cfg, wl.nsamp, n1P + 2
     torch.cuda.empty_cache()
-    maps = coadd_output_stamps(blk, psfgrp, flat_penalty=wl.flat_penalty)
+    maps = coadd_output_stamps(blk, psfgrp, flat_penalty=wl.flat_penalty, positions="exact")  # (bit for bit against a provider that evaluates every position)
     assert np.isfinite(blk.out_map).all() and np.abs(blk.out_map).max() > 0 and blk.out_map.shape == (1, 2, maps.nside, maps.nside)
     assert (blk.T_weightmap != 0).all() and blk.kappa_map.min() > 0
     del maps
@@ -307,3 +307,54 @@ def test_block_seam_honours_the_stamp_window_nrun_and_outmaps():
     blk.j_st_max = n1P  # 2 .. 6: five rows
     with pytest.raises(ValueError, match="Size must be even"):
         coadd_output_stamps(blk, psfgrp, flat_penalty=wl.flat_penalty)
+
+
+def test_sampling_positions_from_a_lattice():
+    """the host evaluates the WCS chain on a 17 x 17 lattice per PSF group and exposure instead of at all
+    nsamp^2 = 146 689 sampling positions (psfutil.py:751-771); the device forms the positions (imcom_lattice_positions).  On affine maps
+    and on maps with quadratic + cubic distortion the positions agree with the direct evaluation to 1e-10 samples (host and device
+    memory), and the Block seam's maps with ``positions="lattice"`` (the default) agree with ``positions="exact"`` to the level the
+    overlap tables are good to."""
+    import torch
+
+    from pyimcom_amd import psfs, synth
+    from pyimcom_amd.refblock import LATTICE, coadd_output_stamps
+
+    wl = synth.CONFIGS["cfg2"]
+    ns = wl.nsamp
+    lin = (np.arange(ns) - (ns - 1) / 2.0) * wl.dscale
+    nodes, W = psfs.lattice_nodes_and_weights(lin, LATTICE)
+    assert W.shape == (ns, LATTICE) and np.abs(W.sum(axis=1) - 1).max() < 1e-14
+    worst = 0.0
+    for distortion in (0.0, 1e-7, 1e-5):
+        blk, psfgrp, _, _ = synth.duck_block(wl, 4, 3, seed=3, distortion=distortion)
+        p0 = np.array([3 * wl.n2 - 0.5, 1 * wl.n2 - 0.5])
+        gx, gy = np.meshgrid(lin, lin)
+        lx, ly = np.meshgrid(nodes, nodes)
+        exact, lat = [], []
+        for im in blk.inimages:
+            f = lambda pts: (im.outpix2world2inpix(pts + p0) - im.outpix2world2inpix(p0[None])) * wl.oversamp  # noqa: E731
+            d = f(np.stack([gx.ravel(), gy.ravel()], axis=1))
+            exact.append(np.stack([d[:, 1].reshape(ns, ns), d[:, 0].reshape(ns, ns)]))
+            d = f(np.stack([lx.ravel(), ly.ravel()], axis=1))
+            lat.append(np.stack([d[:, 1].reshape(LATTICE, LATTICE), d[:, 0].reshape(LATTICE, LATTICE)]))
+        exact, lat = np.stack(exact), np.stack(lat)
+        got_h = psfs.lattice_positions(lat, W, ns)
+        got_d = psfs.lattice_positions(torch.as_tensor(lat, device="cuda:0"), W, ns).cpu().numpy()
+        assert np.array_equal(got_h, got_d)
+        worst = max(worst, float(np.abs(got_h - exact).max()))
+        assert np.abs(got_h - exact).max() < 1e-10, (distortion, np.abs(got_h - exact).max())  # in samples (1/8 native pixel), of offsets up to 200
+        if distortion == 1e-5:  # (the distorted map really is not affine over the window: 0.02 samples)
+            mid = exact[:, :, ns // 2, :]
+            bend = np.abs(mid - (mid[:, :, :1] + (mid[:, :, -1:] - mid[:, :, :1]) * np.linspace(0, 1, ns)[None, None, :])).max()
+            assert bend > 1e-3, bend
+    # the seam: lattice (default) against exact positions on a distorted block
+    wl_s = synth.CONFIGS["small"]
+    outs = {}
+    for mode in ("lattice", "exact"):
+        blk, psfgrp, _, _ = synth.duck_block(wl_s, 4, wl_s.n_expo, seed=5, distortion=1e-6)
+        coadd_output_stamps(blk, psfgrp, flat_penalty=wl_s.flat_penalty, positions=mode)
+        outs[mode] = (blk.out_map.copy(), blk.UC_map.copy(), blk.Sigma_map.copy(), blk.T_weightmap.copy())
+    for a, b in zip(outs["lattice"], outs["exact"]):
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max() + 1e-9, np.abs(a - b).max()  # float32 maps: a few ulp
+    assert np.abs(outs["exact"][0]).max() > 0
