@@ -318,8 +318,9 @@ int imcom_solve_chol_resident_begin(imcom_ctx *ctx, int batch, const int *n_host
 int imcom_solve_chol_resident_end(imcom_ctx *ctx, int batch, int *info_host);
 /* CholKernel._call_single_kappa (lakernel.py:281-323) for SOME stamps of a resident batch: redo_host[s] = 0 leaves stamp s and
  * its outputs untouched, 1 solves it, 2 solves it knowing that the factorisation of A + kappa I fails (what _end reported), i.e.
- * straight to _cholesky_wrapper's repair (lakernel.py:262-279: AA_ii += |w[0]| + 1e-16 with w[0] the smallest eigenvalue of A).
- * nv must be 1.  info as imcom_solve_chol_resident, written for the stamps that were solved. */
+ * straight to _cholesky_wrapper's repair (lakernel.py:262-279: AA_ii += |w[0]| + 1e-16 with w[0] the smallest eigenvalue of A),
+ * 3 the same on the caller's EXPECTATION (the stamps before it failed; a stamp whose A + kappa I is positive definite after all is
+ * recognised and solved without the repair).  nv must be 1.  info as imcom_solve_chol_resident, written for the stamps that were solved. */
 int imcom_solve_chol_resident_redo(imcom_ctx *ctx, int batch, const int *n_host, int ldn, int m, int ldm,
                                    const double *A, const double *Bt, const double *C_host,
                                    const double *kappaC_host, int nv, double ucmin, double smax,
@@ -332,6 +333,12 @@ int imcom_solve_chol_resident_redo(imcom_ctx *ctx, int batch, const int *n_host,
  * stamp one failed factorisation).  0 clears it.  imcom_ctx_last_repair: how many stamps the last Cholesky call repaired and the range
  * of their w[0] (count = 0: none, the range is then 0). */
 int imcom_ctx_set_repair_hint(imcom_ctx *ctx, double lmin_abs);
+/* The same knowledge for the host-array entries (imcom_solve_chol, imcom_solve_chol_stamps; one kappa node): expect != 0 makes the
+ * following calls on this context skip the factorisation of A + kappa I that a driver has just seen fail on the neighbouring stamps and
+ * go straight to the repair (lakernel.py:262-279) -- the resident path's redo code 2.  A stamp whose A + kappa I is positive definite
+ * after all is recognised by the smallest-eigenvalue iteration and solved without the repair (same outputs, one wasted iteration).
+ * 0 clears it. */
+int imcom_ctx_set_repair_expect(imcom_ctx *ctx, int expect);
 int imcom_ctx_last_repair(imcom_ctx *ctx, int *count, double *w0_min, double *w0_max);
 /* coadd.py:1320-1354: fade taper of T (trapezoid, 1222-1292), per-exposure weight sums, Neff and
  * outimage = T . indata.

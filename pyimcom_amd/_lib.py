@@ -64,6 +64,7 @@ SIGNATURES = {
     "imcom_ctx_set_workspace": [_vp, _vp, C.c_size_t],
     "imcom_ctx_workspace_needed": [_vp, C.POINTER(C.c_size_t)],
     "imcom_ctx_set_repair_hint": [_vp, _d],
+    "imcom_ctx_set_repair_expect": [_vp, _i],
     "imcom_ctx_last_repair": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "imcom_ctx_profile_enable": [_vp, _i],
     "imcom_ctx_profile_reset": [_vp],
@@ -256,6 +257,10 @@ class Context:
         """An estimate of max |w[0]| for the stamps the next Cholesky calls repair (lakernel.py:262-279); 0 / None clears it
         (imcom_ctx_set_repair_hint: the smallest-eigenvalue iteration then starts close to its answer)."""
         check(lib.imcom_ctx_set_repair_hint(self.handle, float(lmin_abs or 0.0)))
+
+    def set_repair_expect(self, expect):
+        """The host-array Cholesky entries go straight to the repair on the next calls (imcom_ctx_set_repair_expect)."""
+        check(lib.imcom_ctx_set_repair_expect(self.handle, int(bool(expect))))
 
     def last_repair(self):
         """(stamps the last Cholesky call repaired, smallest and largest w[0] among them)."""

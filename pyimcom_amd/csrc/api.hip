@@ -396,7 +396,10 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
             const double rel = round == 0 ? 1.0 : fabs(theta[s] - prev[s]) / mag;
             const double bound = by_change ? 1.0 : est[s] / mag;
             // A stamp whose failure is the CALLER's expectation, not an observed one (may_decide): all that is wanted first is whether
-            // A + inc I is positive definite after all, and lambda_min >= theta1 - |r1| decides that long before theta1 has converged --
+            // A + inc I is positive definite after all, and theta1 - |r1| decides that long before theta1 has converged (NOT a rigorous bound:
+            // the residual only says that SOME eigenvalue lies within |r1| of theta1; lambda_min can lie below if the block has not captured
+            // it.  A stamp decided this way is factored plainly next, and should that fail the iteration runs again: a misjudgement costs
+            // time, never a wrong shift -- and only stamps whose failure was EXPECTED, not observed, come here) --
             // lambda_min of a healthy PSF-overlap matrix is rounding noise around zero inside a dense cluster, which this iteration would
             // chase for all its rounds and then hand to the eigensolver.  (From the second Rayleigh-Ritz step on: ten steps bring a
             // lambda_min of the size of -inc out of a random block beyond doubt.)  theta1 is then no eigenvalue: `decided` says so.
@@ -522,7 +525,10 @@ static size_t coadd_fuse_bytes(int batch, int Np, int m, int mp, int nv, const C
 }
 
 // redo_host (optional, one kappa node only): per stamp 0 = leave the stamp and its outputs alone, 1 = solve it, 2 = solve it knowing that
-// the factorisation of A + kappa I fails (imcom_solve_chol_resident_end said so: straight to the repair).
+// the factorisation of A + kappa I fails (imcom_solve_chol_resident_end OBSERVED it: straight to the repair), 3 = the same as the caller's
+// EXPECTATION (the stamps before it failed): straight to the repair, but the smallest-eigenvalue iteration may find that A + kappa I is
+// positive definite after all and end early (may_decide), the stamp is then factored plainly.  An observed failure never takes that
+// shortcut (the bound it rests on is not rigorous, and for an observed failure it could only cost a second iteration).
 // With ONE kappa node an attempt after the first works on the stamps whose factorisation failed and on nothing else: the launches
 // see the other stamps with no blocks at all, and their outputs stay what the first attempt wrote (a batch of 256 in which one
 // factorisation fails used to be factored and solved three times over).
@@ -585,14 +591,15 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     std::vector<int> nblk(batch), ninc(batch, 0), fail((size_t)nv * batch);
     std::vector<double> inc_h((size_t)batch * MAX_INC_HOST, 0.0), kap_h(batch), rep(batch, 0.0);
     std::vector<char> repaired((size_t)nv * batch, 0), have_w0(batch, 0);
-    std::vector<char> active(batch, 1), known(batch, 0);  // the stamps of the coming attempt; stamps whose first factorisation is known to fail
+    std::vector<char> active(batch, 1), known(batch, 0), expected(batch, 0);  // the stamps of the coming attempt; stamps whose first factorisation is known
+                                                                            // to fail; ... of which by the caller's expectation only (redo code 3)
     std::vector<char> expected_only(batch, 0);            // ... of which the eigenvalue says that they do not fail after all
     int nbmax = 0;
     for (int s = 0; s < batch; s++) {
         IMCOM_REQUIRE(n_host[s] >= 0 && n_host[s] <= Np, "n[%d]=%d outside [0,%d]", s, n_host[s], Np);
         nblk[s] = (n_host[s] + NB - 1) / NB;
         if (nblk[s] > nbmax) nbmax = nblk[s];
-        if (redo_host) { active[s] = redo_host[s] != 0; known[s] = redo_host[s] == 2; }
+        if (redo_host) { active[s] = redo_host[s] != 0; known[s] = redo_host[s] >= 2; expected[s] = redo_host[s] == 3; }
         if (active[s]) info_host[s] = 0;
     }
     for (int q = 0; q < pb; q++) {  // the stamps of a pass: node-major copies
@@ -765,7 +772,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                     for (int p = 0; p < nv; p++)
                         if (fail[(size_t)p * batch + s] != 0) incf[s] = std::max(incf[s], kappaC_host[p] * C_host[s]);
                 ctx->ws_used = ws_after_plan;
-                for (int s : big) may_decide[s] = masked && attempt == 0 && known[s];
+                for (int s : big) may_decide[s] = masked && attempt == 0 && expected[s];
                 IMCOM_TRY(lambda_min_subspace(ctx, batch, n_host, n_dev, Np, A, big, incf, ctx->repair_hint, may_decide, decided, factor_masked, solve_block, w0v, got));
                 ctx->ws_used = ws_after_plan;
             }
@@ -791,7 +798,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
                 // eigenvalue is good to 1e-11) the reference's cholesky() succeeds and nothing is repaired: the stamp is factored plainly in
                 // the next attempt -- and repaired then, should that factorisation fail in spite of the eigenvalue.
                 const double kap_s = kappaC_host[0] * C_host[s];
-                if (masked && attempt == 0 && known[s] && w0v[s] + kap_s > 1e-6 * fabs(kap_s)) expected_only[s] = 1;
+                if (masked && attempt == 0 && expected[s] && w0v[s] + kap_s > 1e-6 * fabs(kap_s)) expected_only[s] = 1;
             }
         }
         std::vector<char> next(batch, 0);
@@ -999,6 +1006,13 @@ int imcom_ctx_set_repair_hint(imcom_ctx *ctx, double lmin_abs)
     IMCOM_TRY(check_ctx(ctx));
     IMCOM_REQUIRE(lmin_abs >= 0.0 && std::isfinite(lmin_abs), "repair hint: a finite |lambda_min| >= 0 (0 clears it)");
     ctx->repair_hint = lmin_abs;
+    return IMCOM_OK;
+}
+
+int imcom_ctx_set_repair_expect(imcom_ctx *ctx, int expect)
+{
+    IMCOM_TRY(check_ctx(ctx));
+    ctx->repair_expect = expect != 0;
     return IMCOM_OK;
 }
 
@@ -1321,7 +1335,11 @@ int imcom_solve_chol(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
         ProfScope ps(ctx, "pack");
         return launch_pack_Bt(ctx, B_d, ldn, m, n_dev, Bt, Np, mp, batch);
     };
-    const int rc_core = chol_core(ctx, batch, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info, stage_B);
+    // imcom_ctx_set_repair_expect: the caller has seen the factorisation of A + kappa I fail on the stamps before these (the reference's
+    // production shape: every stamp) -- straight to _cholesky_wrapper's repair, as the resident path's redo code 2
+    const std::vector<int> expect_all(batch, 3);
+    const int rc_core = chol_core(ctx, batch, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info, stage_B, nullptr, false,
+                                  (ctx->repair_expect && nv == 1) ? expect_all.data() : nullptr);
     if (rc_core != IMCOM_OK) {
         if (host && ctx->aux_stream) hipStreamSynchronize(ctx->aux_stream);  // nothing of this call may still be copying into the workspace
         return rc_core;
@@ -1412,7 +1430,9 @@ int imcom_solve_chol_stamps(imcom_ctx *ctx, int nst, const int *n, int m, const 
             IMCOM_TRY(launch_pack_Bt(ctx, rawB + offB[s], n[s], m, n_dev + s, Bt + (size_t)s * Np * mp, Np, mp, 1));
         return IMCOM_OK;
     };
-    const int rc_core = chol_core(ctx, nst, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info, stage_B);
+    const std::vector<int> expect_all(nst, 3);  // (imcom_ctx_set_repair_expect: see imcom_solve_chol)
+    const int rc_core = chol_core(ctx, nst, n, Np, m, mp, Ap, Bt, C, kappaC, nv, ucmin, smax, Tt, UC_d, Sig_d, kap_d, info, stage_B, nullptr, false,
+                                  (ctx->repair_expect && nv == 1) ? expect_all.data() : nullptr);
     tcore = now();
     if (timing) { hipStreamSynchronize(ctx->stream); tsync = now(); }
     if (rc_core != IMCOM_OK) {

@@ -78,6 +78,7 @@ struct imcom_ctx {
     // Cholesky repair (lakernel.py:262-279): the caller's estimate of max |w[0]| over the stamps of the next calls (0: none;
     // imcom_ctx_set_repair_hint) and what the last call's repaired stamps had (imcom_ctx_last_repair)
     double repair_hint = 0.0;
+    bool repair_expect = false;  // imcom_ctx_set_repair_expect: the host-entry Cholesky calls go straight to the repair
     int last_repair_count = 0;
     double last_w0_min = 0.0, last_w0_max = 0.0;
     // pinned host staging for small per-stamp arrays

@@ -45,9 +45,13 @@ class _repair_memory:
     _cholesky_wrapper's repair is the rule (lakernel.py:262-279; the reference's production configuration: DESIGN.md section 4) a stamp's
     smallest eigenvalue lies within a few per cent of its neighbours': the largest |w[0]| of the context's last sixteen repaired stamps is
     handed to the library as the next call's starting point (imcom_ctx_set_repair_hint: one factorisation inside the smallest-eigenvalue
-    iteration instead of two; what the iteration converges to does not change) and the call's own repairs are remembered."""
+    iteration instead of two; what the iteration converges to does not change) and the call's own repairs are remembered.  When the last
+    two calls both ended in the repair, the next one is told to EXPECT it (imcom_ctx_set_repair_expect): it does not attempt the
+    factorisation of A + kappa I that is known to fail (10 % of a production stamp's call); a stamp that needs no repair after all is
+    recognised and solved plainly."""
 
     _recent = {}  # context handle -> deque of max |w[0]| per call
+    _streak = {}  # context handle -> calls in a row that ended in the repair
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -57,6 +61,7 @@ class _repair_memory:
 
         self.q = self._recent.setdefault(id(self.ctx), collections.deque(maxlen=16))
         self.ctx.set_repair_hint(max(self.q) if self.q else 0.0)
+        self.ctx.set_repair_expect(self._streak.get(id(self.ctx), 0) >= 2)
         return self
 
     def __exit__(self, exc_type, exc, tb):
@@ -65,9 +70,11 @@ class _repair_memory:
                 cnt, lo, hi = self.ctx.last_repair()
                 if cnt:
                     self.q.append(max(abs(lo), abs(hi)))
+                self._streak[id(self.ctx)] = self._streak.get(id(self.ctx), 0) + 1 if cnt else 0
         finally:
             if self.ctx._h:
                 self.ctx.set_repair_hint(0.0)
+                self.ctx.set_repair_expect(False)
         return False
 
 

@@ -842,7 +842,7 @@ class StampBatch:
             self._stream()
             self._coadded = set()
             cfg, info = self.cfg, self.info_o[0]
-            redo = np.full(self.batch, 2, dtype=np.int32)
+            redo = np.full(self.batch, 3, dtype=np.int32)  # 3: the failure is this driver's EXPECTATION (2: observed by solve_end, below)
             check(lib.imcom_solve_chol_resident_redo(self.ctx.handle, self.batch, _hp(self.n), self.ldn, self.m, self.ldm, _dp(self.A), _dp(self.Bt_o[0]),
                                                      _hp(self.Cs_o[0]), _hp(self.kappaC), 1, float(cfg.uctarget), float(cfg.sigmamax),
                                                      _dp(self.Tt_o[0]), _dp(self.UC_o[0]), _dp(self.Sigma_o[0]), _dp(self.kappa_o[0]), _hp(redo), _hp(info)))
