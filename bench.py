@@ -663,6 +663,52 @@ def paper4_leg(ctx, dev, batch=128, steps=2, cpu_budget=25.0, block_passes=3):
            "roofline_build_A": roofline_build_A(n, fams["build_A"][0] / steps, samples_on_table=on_table_samples(b, cfg)),
            "job_roofline_frac": job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS, "telemetry": telemetry}
     cpu_sample = stamps[:4]
+
+    # the kernel-class seam on production stamps (OutStamp.LAKERNEL, coadd.py:839-844): HipCholKernel(outst)() one stamp per call on host
+    # arrays (380 MB up, 36 MB down), as the reference's stamp loop calls it -- neighbours one after the other, so the calls after the second
+    # expect the repair and start from their predecessors' smallest eigenvalues (lakernel._repair_memory) -- and the four OutStamps of a
+    # 2 x 2 group in one call (solve_chol_stamps)
+    def kernel_seam():
+        from pyimcom_amd.lakernel import HipCholKernel, solve_chol_stamps
+
+        class O:
+            pass
+
+        def outst(s):
+            n_ = int(b.n[s])
+            o, o.blk = O(), O()
+            o.blk.cfg = O()
+            c = o.blk.cfg
+            c.n_out, c.n2f, c.kappaC_arr, c.uctarget, c.sigmamax = 1, cfg.n2f, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax
+            o.sysmata = b.A[s, :n_, :n_].cpu().numpy().copy()
+            o.mhalfb = np.ascontiguousarray(b.Bt[s, :n_, :m].cpu().numpy().T)[None]
+            o.outovlc, o.inpix_cumsum = np.array([tables.C]), np.array([n_])
+            return o
+
+        b.build()
+        torch.cuda.synchronize()
+        outs = [outst(s) for s in range(4)]
+        per_call = []
+        for o in outs:
+            t0 = time.perf_counter()
+            HipCholKernel(o, ctx=ctx)()
+            per_call.append((time.perf_counter() - t0) * 1e3)
+        ref_T = outs[3].T
+        group = [outst(s) for s in range(4)]
+        t0 = time.perf_counter()
+        solve_chol_stamps(group, ctx=ctx)
+        t4 = (time.perf_counter() - t0) * 1e3
+        return {"ms_per_call": per_call, "ms_per_stamp": per_call[-1], "ms_per_stamp_group4": t4 / 4, "group4_vs_single_T": float(np.abs(group[3].T - ref_T).max() / np.abs(ref_T).max()),
+                "what": "HipCholKernel(outst)() on host arrays, one production stamp per call (four neighbours in a row: the last call expects the repair and has "
+                        "its predecessors' hint), then lakernel.solve_chol_stamps([four OutStamps]); PCIe-inclusive"}
+
+    try:
+        out["kernel_seam"] = kernel_seam()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        traceback.print_exc(file=sys.stderr)
+        out["kernel_seam"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     del b, tables
     torch.cuda.synchronize()
     release_buffers()
@@ -940,6 +986,8 @@ def summary_of(out):
                 sm["paper4"]["block"] = {"error": blk["error"][:60]} if "error" in blk else {"v": r3(blk.get("value")), "s_per_block": r3(blk.get("seconds_per_block"))}
                 if isinstance(p4.get("cpu_baseline"), dict) and "value" in p4["cpu_baseline"]:
                     sm["paper4"]["cpu"] = r3(p4["cpu_baseline"]["value"])
+                ks4 = p4.get("kernel_seam", {})
+                sm["paper4"]["seam_ms"] = {"error": ks4["error"][:60]} if "error" in ks4 else [r3(ks4.get("ms_per_stamp")), r3(ks4.get("ms_per_stamp_group4"))]
         if "iter_default" in cf:
             it_ = cf["iter_default"]
             sm["iter_default"] = leg(it_, ("cg_steps_mean", "image_rms_vs_cholesky"))

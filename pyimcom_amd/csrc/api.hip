@@ -237,7 +237,7 @@ static int lambda_min_group(imcom_ctx *ctx, const double *A, const int *n_host, 
 static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, const int *n_dev, int Np, const double *A, const std::vector<int> &idx,
                                const std::vector<double> &inc_failed, double hint, const std::vector<char> &may_decide, std::vector<char> &decided,
                                const std::function<int(const std::vector<double> &, const std::vector<char> &, std::vector<int> &)> &factor,
-                               const std::function<int(const std::vector<char> &, const double *, double *, double *, int)> &solve,
+                               const std::function<int(const std::vector<char> &, const double *, double *, double *, double *, int)> &solve,
                                std::vector<double> &w0, std::vector<char> &ok)
 {
     const size_t mark = ctx->ws_used;
@@ -358,7 +358,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         for (int s : idx) if (run[s]) iters = std::max(iters, steps_wanted[s]);  // (a stamp's first round at its closer shift: see below)
         std::fill(steps_wanted.begin(), steps_wanted.end(), 0);
         for (int it = 0; it < iters; it++) {
-            IMCOM_TRY(solve(run, X, Y, part, lmin_parts > 0 ? lmin_parts : splitk_parts(batch, 1)));
+            IMCOM_TRY(solve(run, X, Y, Z, part, lmin_parts > 0 ? lmin_parts : splitk_parts(batch, 1)));  // (Z: scratch here, the Rayleigh-Ritz step below fills it anew)
             IMCOM_TRY(orth());
         }
         // Z = A X, H = X^T Z, its eigenvalues and eigenvectors, the residuals of the two lowest pairs
@@ -635,11 +635,45 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         return IMCOM_OK;
     };
-    // Yv = (L L^T)^-1 Xv on LMIN_P columns for the stamps of `mask`
-    auto solve_block = [&](const std::vector<char> &mask, const double *Xv, double *Yv, double *part, int parts) -> int {
+    // Yv = (L L^T)^-1 Xv on LMIN_P columns for the stamps of `mask`; Wv: scratch of the same size (may be null).
+    // Two forms.  Many stamps: the left-looking block rows of the solve kernels (a launch per block row, one 128-column tile per stamp,
+    // the K loop dealt to up to 8 workgroups).  FEW stamps (the kernel-class seam hands over one, a 2 x 2 group four): that form keeps 9
+    // workgroups per stamp busy and a 128-column solve of a production stamp (N = 6.2k) takes 10.8 ms -- 97 of the 135 ms of a seam call
+    // (profiles/r06_seam_paper4_kernel_stats.csv).  There the solve runs RIGHT-looking on the generic product kernel: block k is finished by
+    // its inverted diagonal block, then ALL block rows below it are updated at once, Y_i -= L_ik Y_k: nb - k - 1 workgroups per stamp
+    // and launch instead of 9, the same flops.
+    static const bool right_off = getenv("IMCOM_LMIN_RIGHT") && strcmp(getenv("IMCOM_LMIN_RIGHT"), "0") == 0;
+    auto solve_block = [&](const std::vector<char> &mask, const double *Xv, double *Yv, double *Wv, double *part, int parts) -> int {
         std::vector<int> nb(batch);
-        int nbm = 0;
-        for (int s = 0; s < batch; s++) { nb[s] = mask[s] ? nblk[s] : 0; nbm = std::max(nbm, nb[s]); }
+        int nbm = 0, cnt = 0;
+        for (int s = 0; s < batch; s++) { nb[s] = mask[s] ? nblk[s] : 0; nbm = std::max(nbm, nb[s]); cnt += mask[s] ? 1 : 0; }
+        if (Wv && !right_off && cnt > 0 && cnt <= 8) {
+            const int P = LMIN_P;
+            const long sL = (long)Np * Np, sY = (long)Np * P, sD = (long)(Np / NB) * NB * NB;
+            for (int s0 = 0; s0 < batch;) {  // runs of consecutive wanted stamps with the same number of blocks: one batched launch each
+                if (!mask[s0] || nblk[s0] == 0) { s0++; continue; }
+                int s1 = s0 + 1;
+                while (s1 < batch && mask[s1] && nblk[s1] == nblk[s0]) s1++;
+                const int bc = s1 - s0, nbs = nblk[s0];
+                const double *L0 = L + s0 * sL, *D0 = Dinv + s0 * sD, *X0 = Xv + s0 * sY;
+                double *Y0 = Yv + s0 * sY, *W0 = Wv + s0 * sY;
+                IMCOM_HIP_CHECK(hipMemcpyAsync(W0, X0, (size_t)bc * sY * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                for (int k = 0; k < nbs; k++) {  // L Y = X
+                    IMCOM_TRY(launch_gemm(ctx, false, true, NB, P, NB, bc, D0 + (long)k * NB * NB, NB, sD, W0 + (long)k * NB * P, P, sY, Y0 + (long)k * NB * P, P, sY, 1.0, 0.0));
+                    if (k + 1 < nbs)
+                        IMCOM_TRY(launch_gemm(ctx, false, true, (nbs - k - 1) * NB, P, NB, bc, L0 + (long)(k + 1) * NB * Np + (long)k * NB, Np, sL, Y0 + (long)k * NB * P, P, sY,
+                                              W0 + (long)(k + 1) * NB * P, P, sY, -1.0, 1.0));
+                }
+                IMCOM_HIP_CHECK(hipMemcpyAsync(W0, Y0, (size_t)bc * sY * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                for (int k = nbs - 1; k >= 0; k--) {  // L^T Z = Y
+                    IMCOM_TRY(launch_gemm(ctx, true, true, NB, P, NB, bc, D0 + (long)k * NB * NB, NB, sD, W0 + (long)k * NB * P, P, sY, Y0 + (long)k * NB * P, P, sY, 1.0, 0.0));
+                    if (k > 0)
+                        IMCOM_TRY(launch_gemm(ctx, true, true, k * NB, P, NB, bc, L0 + (long)k * NB * Np, Np, sL, Y0 + (long)k * NB * P, P, sY, W0, P, sY, -1.0, 1.0));
+                }
+                s0 = s1;
+            }
+            return IMCOM_OK;
+        }
         IMCOM_TRY(upload(ctx, nblk_sol, nb.data(), (size_t)batch));
         for (int k = 0; k < nbm; k++) IMCOM_TRY(launch_solve_fwd(ctx, L, Xv, Yv, Np, LMIN_P, k, batch, batch, nblk_sol, n_dev, Dinv, part, parts, nullptr));
         for (int k = nbm - 1; k >= 0; k--) IMCOM_TRY(launch_solve_bwd(ctx, L, Yv, Np, LMIN_P, k, nbm, batch, nblk_sol, n_dev, Dinv, part, parts, nullptr, nullptr));

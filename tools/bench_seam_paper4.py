@@ -34,10 +34,23 @@ def outst(s):
 
 
 os_ = [outst(s) for s in range(calls)]
-ms = []
+ms, stages = [], []
+fams = ("pack", "chol_gemm", "chol_diag", "eigen_repair", "solve_gemm", "finalize")
 for o in os_:
+    b.ctx.profile_enable(True)
+    b.ctx.profile_reset()
     t0 = time.perf_counter()
     k = HipCholKernel(o, ctx=b.ctx)
     k()
     ms.append(round((time.perf_counter() - t0) * 1e3, 1))
-print(json.dumps({"ms_per_call": ms, "info": [int(k.info[0])], "N": int(b.n[0]), "m": cfg.m}))
+    stages.append({f: round(b.ctx.profile_get(f)[0], 1) for f in fams})
+    b.ctx.profile_enable(False)
+print(json.dumps({"ms_per_call": ms, "info": [int(k.info[0])], "N": int(b.n[0]), "m": cfg.m, "stages_last": stages[-1], "stages_first": stages[0]}))
+# the raw transfers of one call: A and -B/2 up from pageable numpy arrays, T down into a pinned array
+A_h, B_h = os_[0].sysmata, os_[0].mhalfb
+d = torch.empty(A_h.size, dtype=torch.float64, device="cuda:0")
+torch.cuda.synchronize()
+t0 = time.perf_counter(); d.copy_(torch.from_numpy(A_h).reshape(-1)); torch.cuda.synchronize(); tA = time.perf_counter() - t0
+Ap = torch.from_numpy(A_h).pin_memory()
+t0 = time.perf_counter(); d.copy_(Ap.reshape(-1), non_blocking=True); torch.cuda.synchronize(); tAp = time.perf_counter() - t0
+print(json.dumps({"A_MB": A_h.nbytes / 1e6, "A_up_pageable_ms": tA * 1e3, "A_up_pinned_ms": tAp * 1e3, "B_MB": B_h.nbytes / 1e6}))
