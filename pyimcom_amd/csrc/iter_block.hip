@@ -147,10 +147,11 @@ __global__ __launch_bounds__(256) void iter_block_gather_kernel(const double *__
 // ------------------------------------------------------------------------------------------------
 // 16 conjugate-gradient recurrences in step.  Four waves; wave w owns the 16-row tiles w, w + 4, ... (TPW of them at most); in a
 // tile, lane (li = lane & 15, lk = lane >> 4) owns rows lk + 4 r' (r' < 4) of right-hand side li -- the C/D layout of the MFMA, so
-// that the products land where the vectors live.  Where the vectors live: the residual r in registers; the search direction p in
-// LDS ([row][16], fp64: it is the B operand of the product, and its owner lane reads its own entries back from there); the iterate
-// x and the step's product q in workspace (touched once per step: 4 % of the step's traffic, out of L2).  With x, r, p AND q in
-// registers a union of 700 rows needed 548 registers per lane and spilled; this way 1024 rows fit.
+// that the products land where the vectors live.  Where the vectors live: the residual r and the step's product q in registers; the
+// search direction p in LDS ([row][16], fp64: it is the B operand of the product, and its owner lane reads its own entries back
+// from there); the iterate x in workspace, updated by atomic adds without return (one lane per entry: a fixed order, no waiting).
+// (What made the first version spill at 700 rows was not the vectors: the optimiser hoisted the 64-bit addresses of every own entry
+// out of the step loop, 6 registers per entry -- the opaque offset `ob` below stops that -- and overlapped the unrolled tile rows.)
 // stats: [0] patches, [1] sum up^2 steps, [2] sum steps, [3] sum up^2 (unsigned long long, atomics); steps: per output pixel.
 template <int TPW>
 __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__restrict__ AU, const double *__restrict__ BU,
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
     const int up = (nsel + 15) / 16 * 16, ntile = up / 16, nts = ups / 16;
     double *P = lds, *red = lds + (long)up * BCG_R;
     const double *AUb = AU + (long)blockIdx.x * ups * ups, *BUb = BU + (long)blockIdx.x * ups * BCG_R;
-    double *Xb = XW + (long)blockIdx.x * 2 * ups * BCG_R, *Qb = Xb + (long)ups * BCG_R;  // iterate x; the step's product q
+    double *Xb = XW + (long)blockIdx.x * ups * BCG_R;  // the iterate x
     const unsigned short *mk = umask + blk * BCG_UMAX;
     const bool valid = a >= 0;
     const int own0 = (16 * wave + lk) * BCG_R + li;  // this lane's entry (q, e) of a [row][16] vector: own0 + (64 q + 4 e) * 16
@@ -246,6 +247,9 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
         // The tiles of this wave's rows stream through registers BCG_CH at a time; the next chunk's loads -- the first chunk of the
         // NEXT tile row at the end of a row -- are in flight while this one is multiplied.
         double pq = 0.0;
+        double qv[TPW][4];
+#pragma unroll
+        for (int q = 0; q < TPW; q++) qv[q][0] = qv[q][1] = qv[q][2] = qv[q][3] = 0.0;
         f64x2 nx[BCG_CH][2];
         auto fetch = [&](const double *strip, int kt0) {
 #pragma unroll
@@ -256,6 +260,8 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
             }
         };
         if (wave < ntile) fetch(strip0, 0);
+        // (the loop over this wave's tile rows is NOT unrolled: unrolled, the compiler overlaps the rows' address arithmetic and loads and
+        // spills 300 registers; the row's four results reach the register array qv through a switch on the row number)
 #pragma unroll 1
         for (int q = 0; wave + 4 * q < ntile; q++) {
             const double *strip = strip0 + q * strip_step;
@@ -278,14 +284,19 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
                     }
                 }
             }
-            // the product's rows of this tile: kept in workspace until alpha is known (q in registers next to r cost the spills)
+            double v[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int o = ob + (64 * q + 4 * e) * BCG_R;
-                const double v = (own >> (4 * q + e) & 1) ? acc[e] : 0.0;
-                Qb[o] = v;
-                pq += P[o] * v;
+                v[e] = (own >> (4 * q + e) & 1) ? acc[e] : 0.0;
+                pq += P[ob + (64 * q + 4 * e) * BCG_R] * v[e];
             }
+#define BCG_PUT(Q) case Q: if (Q < TPW) { qv[Q < TPW ? Q : 0][0] = v[0]; qv[Q < TPW ? Q : 0][1] = v[1]; qv[Q < TPW ? Q : 0][2] = v[2]; qv[Q < TPW ? Q : 0][3] = v[3]; } break;
+            switch (q) {
+                BCG_PUT(0) BCG_PUT(1) BCG_PUT(2) BCG_PUT(3) BCG_PUT(4) BCG_PUT(5) BCG_PUT(6) BCG_PUT(7)
+                BCG_PUT(8) BCG_PUT(9) BCG_PUT(10) BCG_PUT(11) BCG_PUT(12) BCG_PUT(13) BCG_PUT(14) BCG_PUT(15)
+                default: break;
+            }
+#undef BCG_PUT
         }
         const double pqs = rhs_sum(pq);
         if (act) {
@@ -296,22 +307,27 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int o = ob + (64 * q + 4 * e) * BCG_R;
-                        Xb[o] += alpha * P[o];
-                        r[q][e] -= alpha * Qb[o];
+                        // x lives in workspace: an atomic add without return -- only this lane ever touches the entry, so the order of the
+                        // sums is fixed, and nothing waits for a load (a read-modify-write cost a memory round trip per tile and step)
+                        unsafeAtomicAdd(Xb + o, alpha * P[o]);
+                        r[q][e] -= alpha * qv[q][e];
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
             rho_prev = rho_cur;
         }
     }
+    __threadfence();  // this lane's atomic adds to x have reached L2 (the loads below bypass L1: device-scope atomic loads)
     if (a >= 0) {
         float *Trow = T + ((long)s * m + a) * ldt;
         const int *us = usel + blk * BCG_UMAX;
-#pragma unroll 1
-        for (int q = 0; wave + 4 * q < ntile; q++)
+#pragma unroll
+        for (int q = 0; q < TPW; q++) {
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                if (own >> (4 * q + e) & 1) Trow[us[16 * (wave + 4 * q) + lk + 4 * e]] = (float)Xb[own0 + (64 * q + 4 * e) * BCG_R];
+                if (own >> (4 * q + e) & 1) Trow[us[16 * (wave + 4 * q) + lk + 4 * e]] = (float)__hip_atomic_load(Xb + own0 + (64 * q + 4 * e) * BCG_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (steps && wave == 0 && lk == 0) steps[(long)s * m + a] = used;
     }
     if (stats && threadIdx.x == 0) {
@@ -327,7 +343,7 @@ int iter_block_umax() { return BCG_UMAX; }
 
 // workspace of a call: the selection of every patch of the batch + `budget` bytes for the dense sub-matrices of a sub-batch
 size_t iter_block_select_bytes(int batch, int nblocks) { return (size_t)batch * nblocks * ((size_t)BCG_UMAX * 6 + 4) + 4096; }
-size_t iter_block_patch_bytes(int ups) { return (size_t)ups * ups * 8 + 3 * (size_t)ups * BCG_R * 8; }  // AU + BU + x + q
+size_t iter_block_patch_bytes(int ups) { return (size_t)ups * ups * 8 + 2 * (size_t)ups * BCG_R * 8; }  // AU + BU + x
 
 // One kappa node for the whole batch.  *max_union = the largest union selection: above iter_block_umax() nothing was solved and
 // the caller takes the per-pixel kernel.  T must have been zeroed.  `ws` holds iter_block_select_bytes() + `budget` bytes: the
