@@ -92,7 +92,7 @@ struct imcom_ctx {
     std::vector<hipEvent_t> event_pool;
     int cu_count = 256;
     // imcom_solve_iter_stats: what the last imcom_solve_iter call did at its last kappa node
-    double iter_stats[6] = {0, 0, 0, 0, 0, 0};  // patches, sum up^2 steps, sum steps, sum up^2, largest union, 1 = blocked solver
+    double iter_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // patches, sum up^2 steps, sum steps, sum up^2, largest union, 1 = blocked solver, bytes streamed, 1 = half storage
     std::vector<int> iter_steps;                // CG steps per output pixel [batch][m]
 };
 

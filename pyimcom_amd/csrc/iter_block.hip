@@ -103,10 +103,13 @@ __global__ __launch_bounds__(256) void iter_block_select_kernel(const double *__
 // Dense AU of the patches [blk0, blk0 + gridDim.x) (diagonal from `diag`: the reference's in-place kappa adds), zero padded to the
 // patch's own `up`, as tiles: element (j, i) at ((j >> 4) * nts + (i >> 4)) * 256 + (j & 15) * 16 + (i & 15), nts = ups / 16; and
 // the masked right-hand sides BU[j][r] = -B/2 [pixel r][U[j]] where pixel r selects U[j], else zero.
+// SYM: only the tiles on and below the diagonal, packed column panel by column panel -- tile (I, K), I >= K, at
+// (K ntile - K (K - 1) / 2 + I - K) * 256 with ntile the patch's own tile count (iter_block_cg_sym_kernel).
+template <bool SYM>
 __global__ __launch_bounds__(256) void iter_block_gather_kernel(const double *__restrict__ A, long lda, long strideA,
                                                                 const double *__restrict__ diag, long ldd,
                                                                 const double *__restrict__ B, long ldb, int m, int W, int H,
-                                                                int nblocks, long blk0, int ups, const int *__restrict__ usel,
+                                                                int nblocks, long blk0, int ups, long au_stride, const int *__restrict__ usel,
                                                                 const unsigned short *__restrict__ umask, const int *__restrict__ nu,
                                                                 double *__restrict__ AU, double *__restrict__ BU)
 {
@@ -122,18 +125,23 @@ __global__ __launch_bounds__(256) void iter_block_gather_kernel(const double *__
     if (threadIdx.x < BCG_R) pix[threadIdx.x] = bcg_pixel(b, threadIdx.x, W, H, m);
     __syncthreads();
     const double *As = A + s * strideA, *dg = diag + s * ldd;
-    double *AUb = AU + (long)blockIdx.x * ups * ups, *BUb = BU + (long)blockIdx.x * ups * BCG_R;
+    double *AUb = AU + (long)blockIdx.x * au_stride, *BUb = BU + (long)blockIdx.x * ups * BCG_R;
     const unsigned short *msk = umask + blk * BCG_UMAX;
+    const int ntile = up / 16;
     // a wave per row, lanes over the columns: 16 consecutive lanes write the 128 bytes of a tile row
     for (int j = wave; j < up; j += 4) {
         const int gj = sel[j];
         const double *row = As + (long)(gj < 0 ? 0 : gj) * lda;
-        double *out = AUb + (long)(j >> 4) * nts * 256 + (j & 15) * 16;
-        for (int i = lane; i < up; i += 64) {
+        const int J = j >> 4;
+        double *out = AUb + (SYM ? 0 : (long)J * nts * 256) + (j & 15) * 16;
+        const int iend = SYM ? 16 * (J + 1) : up;  // (SYM: the tiles up to the diagonal one)
+        for (int i = lane; i < iend; i += 64) {
             double v = 0.0;
             const int gi = sel[i];
             if (gj >= 0 && gi >= 0) v = gi == gj ? dg[gj] : row[gi];
-            out[(long)(i >> 4) * 256 + (i & 15)] = v;
+            const int K = i >> 4;
+            const long tile = SYM ? (long)K * ntile - (long)K * (K - 1) / 2 + (J - K) : K;
+            out[tile * 256 + (i & 15)] = v;
         }
     }
     for (int t = threadIdx.x; t < up * BCG_R; t += 256) {
@@ -338,6 +346,256 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same recurrences on HALF the sub-matrix (round 6).  AU is symmetric; a step of the kernel above streams both triangles -- 4 MB
+// per patch at the default configuration against 2 x 700^2 x 16 flops: 2.5 x the matrix pipe's time at the HBM peak.  Here only the
+// tiles on and below the diagonal are stored and read, and every tile T = (I, K), I > K, is used twice while it is in registers:
+// q_I += T P_K and q_K += T^T P_I (the transposed operand is the same 2 KB read again, through L1, with the lanes' roles swapped).
+// The first product lands where its vector lives (wave I mod 4 owns tile row I).  The second belongs to another wave's tile row K:
+// the tiles are visited column panel by column panel (K outer), a wave keeps ONE accumulator for its share of panel K's transposed
+// products, leaves it in an LDS ring when the panel is done, and after a barrier per `ring` panels the owner of tile row K adds the four
+// waves' pieces in wave order -- a fixed order of sums: results are reproducible.  LDS: P [ups][16], the ring 2 x ring x 4 x 2 KB.
+// MEASURED: correct on the first run, HBM bytes halved -- and slower than the full-storage kernel (issue-bound, see launch_iter_block):
+// kept as IMCOM_ITER_SYM=1, not the default.
+#ifndef IMCOM_BCG_SCH
+#define IMCOM_BCG_SCH 4
+#endif
+constexpr int BCG_SCH = IMCOM_BCG_SCH;  // tiles fetched ahead by the symmetric kernel
+
+template <int TPW>
+__global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double *__restrict__ AU, const double *__restrict__ BU,
+                                                                   const int *__restrict__ usel, const unsigned short *__restrict__ umask,
+                                                                   const int *__restrict__ nu, int m, int W, int H, int nblocks, long blk0,
+                                                                   int ups, long au_stride, int ring, double rtol, int maxiter,
+                                                                   float *__restrict__ T, long ldt, double *__restrict__ XW,
+                                                                   int *__restrict__ steps, unsigned long long *__restrict__ stats)
+{
+    extern __shared__ double lds[];  // P [ups][16], red [4][16], ring [2][ring][4][256]
+    const long blk = blk0 + blockIdx.x;
+    const int s = (int)(blk / nblocks), b = (int)(blk - (long)s * nblocks);
+    const int nsel = nu[blk];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int a = bcg_pixel(b, li, W, H, m);
+    if (nsel == 0) {
+        if (steps && threadIdx.x < BCG_R && a >= 0) steps[(long)s * m + a] = 0;
+        return;
+    }
+    const int up = (nsel + 15) / 16 * 16, ntile = up / 16;
+    double *P = lds, *red = lds + (long)ups * BCG_R, *Rg = red + 4 * BCG_R;
+    const double *AUb = AU + (long)blockIdx.x * au_stride, *BUb = BU + (long)blockIdx.x * ups * BCG_R;
+    double *Xb = XW + (long)blockIdx.x * ups * BCG_R;
+    const unsigned short *mk = umask + blk * BCG_UMAX;
+    const bool valid = a >= 0;
+    const int own0 = (16 * wave + lk) * BCG_R + li;
+
+    auto rhs_sum = [&](double v) {
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        __syncthreads();
+        if (lk == 0) red[wave * BCG_R + li] = v;
+        __syncthreads();
+        return (red[li] + red[BCG_R + li]) + (red[2 * BCG_R + li] + red[3 * BCG_R + li]);
+    };
+
+    double r[TPW][4], acc[TPW][4];
+    unsigned long long own = 0;
+    double bb = 0.0;
+#pragma unroll
+    for (int q = 0; q < TPW; q++) {
+        const int tt = wave + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int j = 16 * tt + lk + 4 * e;
+            const bool in = tt < ntile;
+            if (in && (mk[j] >> li & 1)) own |= 1ull << (4 * q + e);
+            r[q][e] = in ? BUb[(long)j * BCG_R + li] : 0.0;
+            if (in) Xb[own0 + (64 * q + 4 * e) * BCG_R] = 0.0;
+            bb += r[q][e] * r[q][e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const double atol = sqrt(rhs_sum(bb)) * rtol;
+    double rho_prev = 0.0;
+    bool done = !valid;
+    int used = 0, block_steps = 0;
+    // the tiles of this wave, column panel by column panel: (K, I) with I = first(K), first(K) + 4, ... < ntile
+    auto first = [&](int K) { return K + ((wave - K) & 3); };
+    auto tile_ptr = [&](int K, int I) { return AUb + ((long)K * ntile - (long)K * (K - 1) / 2 + (I - K)) * 256; };
+    auto advance = [&](int &K, int &I) {
+        I += 4;
+        while (K < ntile && I >= ntile) { K++; I = first(K); }
+    };
+#define BCG_ACC_GET(Q) case Q: if (Q < TPW) { c4[0] = acc[Q < TPW ? Q : 0][0]; c4[1] = acc[Q < TPW ? Q : 0][1]; c4[2] = acc[Q < TPW ? Q : 0][2]; c4[3] = acc[Q < TPW ? Q : 0][3]; } break;
+#define BCG_ACC_PUT(Q) case Q: if (Q < TPW) { acc[Q < TPW ? Q : 0][0] = c4[0]; acc[Q < TPW ? Q : 0][1] = c4[1]; acc[Q < TPW ? Q : 0][2] = c4[2]; acc[Q < TPW ? Q : 0][3] = c4[3]; } break;
+#define BCG_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+    for (int it = 0; it < maxiter; it++) {
+        double rr = 0.0;
+#pragma unroll
+        for (int q = 0; q < TPW; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) rr += r[q][e] * r[q][e];
+        const double rho_cur = rhs_sum(rr);
+        if (!done && sqrt(rho_cur) < atol) done = true;
+        if (__syncthreads_and(done)) break;
+        const bool act = !done;
+        used += act ? 1 : 0;
+        block_steps++;
+        int ob = own0;
+        asm volatile("" : "+v"(ob));
+        const double beta = (it > 0 && act) ? rho_cur / rho_prev : 0.0;
+#pragma unroll
+        for (int q = 0; q < TPW; q++) {
+            if (wave + 4 * q < ntile)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    double *pp = P + ob + (64 * q + 4 * e) * BCG_R;
+                    const double pold = it > 0 ? *pp : 0.0;
+                    *pp = act ? pold * beta + r[q][e] : 0.0;
+                }
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[q][e] = 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // ---- q = AU P from the lower tiles
+        f64x2 nn[BCG_SCH][2];
+        double nt[BCG_SCH][4];
+        int pK = 0, pI = first(0), cK, cI;
+        while (pK < ntile && pI >= ntile) { pK++; pI = first(pK); }
+        cK = pK; cI = pI;
+        auto fetch = [&]() {
+#pragma unroll
+            for (int u = 0; u < BCG_SCH; u++) {
+                const bool have = pK < ntile;
+                const double *t = have ? tile_ptr(pK, pI) : AUb;  // (past the end: the first tile again, unused)
+                nn[u][0] = *(const f64x2 *)(t + li * 16 + 4 * lk);
+                nn[u][1] = *(const f64x2 *)(t + li * 16 + 4 * lk + 2);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) nt[u][kk] = t[(4 * lk + kk) * 16 + li];
+                if (have) advance(pK, pI);
+            }
+        };
+        fetch();
+        int Kcur = 0;
+        f64x4 part = {0.0, 0.0, 0.0, 0.0};
+        double bK[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) bK[kk] = P[(long)(4 * lk + kk) * BCG_R + li];
+        // panel Kcur is complete for this wave: its transposed sums go to the ring; after every `ring` panels (and after the last) the
+        // owners of those tile rows add the four waves' pieces, in wave order
+        auto flush = [&]() {
+            const int slot = ((Kcur / ring) & 1) * ring + Kcur % ring;
+            double *dst = Rg + ((long)slot * 4 + wave) * 256 + lane;
+#pragma unroll
+            for (int e = 0; e < 4; e++) dst[64 * e] = part[e];
+            part = f64x4{0.0, 0.0, 0.0, 0.0};
+            if ((Kcur + 1) % ring == 0 || Kcur == ntile - 1) {
+                __syncthreads();
+                for (int Kg = Kcur / ring * ring; Kg <= Kcur; Kg++) {
+                    if ((Kg & 3) != wave) continue;
+                    const double *src = Rg + ((long)(((Kg / ring) & 1) * ring + Kg % ring) * 4) * 256 + lane;
+                    double c4[4];
+                    switch (Kg >> 2) { BCG_ALL(BCG_ACC_GET) default: break; }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) c4[e] += (src[64 * e] + src[256 + 64 * e]) + (src[512 + 64 * e] + src[768 + 64 * e]);
+                    switch (Kg >> 2) { BCG_ALL(BCG_ACC_PUT) default: break; }
+                }
+            }
+            Kcur++;
+            if (Kcur < ntile)
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) bK[kk] = P[(long)(16 * Kcur + 4 * lk + kk) * BCG_R + li];
+        };
+        while (cK < ntile) {
+            f64x2 cn[BCG_SCH][2];
+            double ct[BCG_SCH][4];
+#pragma unroll
+            for (int u = 0; u < BCG_SCH; u++) {
+                cn[u][0] = nn[u][0]; cn[u][1] = nn[u][1];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) ct[u][kk] = nt[u][kk];
+            }
+            fetch();
+#pragma unroll
+            for (int u = 0; u < BCG_SCH; u++) {
+                if (cK < ntile) {
+                    while (Kcur < cK) flush();
+                    double c4[4] = {0.0, 0.0, 0.0, 0.0};
+                    const int q = (cI - wave) >> 2;
+                    switch (q) { BCG_ALL(BCG_ACC_GET) default: break; }
+                    f64x4 an = {c4[0], c4[1], c4[2], c4[3]};
+                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(cn[u][0].x, bK[0], an, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(cn[u][0].y, bK[1], an, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(cn[u][1].x, bK[2], an, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(cn[u][1].y, bK[3], an, 0, 0, 0);
+                    c4[0] = an[0]; c4[1] = an[1]; c4[2] = an[2]; c4[3] = an[3];
+                    switch (q) { BCG_ALL(BCG_ACC_PUT) default: break; }
+                    if (cI > cK) {
+                        const double *pi = P + (long)(16 * cI + 4 * lk) * BCG_R + li;
+                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(ct[u][0], pi[0], part, 0, 0, 0);
+                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(ct[u][1], pi[BCG_R], part, 0, 0, 0);
+                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(ct[u][2], pi[2 * BCG_R], part, 0, 0, 0);
+                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(ct[u][3], pi[3 * BCG_R], part, 0, 0, 0);
+                    }
+                    advance(cK, cI);
+                }
+            }
+        }
+        while (Kcur < ntile) flush();
+        double pq = 0.0;
+#pragma unroll
+        for (int q = 0; q < TPW; q++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc[q][e] = (own >> (4 * q + e) & 1) ? acc[q][e] : 0.0;
+                if (wave + 4 * q < ntile) pq += P[ob + (64 * q + 4 * e) * BCG_R] * acc[q][e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const double pqs = rhs_sum(pq);
+        if (act) {
+            const double alpha = rho_cur / pqs;
+#pragma unroll
+            for (int q = 0; q < TPW; q++) {
+                if (wave + 4 * q < ntile)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int o = ob + (64 * q + 4 * e) * BCG_R;
+                        unsafeAtomicAdd(Xb + o, alpha * P[o]);
+                        r[q][e] -= alpha * acc[q][e];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rho_prev = rho_cur;
+        }
+    }
+#undef BCG_ACC_GET
+#undef BCG_ACC_PUT
+#undef BCG_ALL
+    __threadfence();
+    if (a >= 0) {
+        float *Trow = T + ((long)s * m + a) * ldt;
+        const int *us = usel + blk * BCG_UMAX;
+#pragma unroll
+        for (int q = 0; q < TPW; q++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (own >> (4 * q + e) & 1)
+                    Trow[us[16 * (wave + 4 * q) + lk + 4 * e]] = (float)__hip_atomic_load(Xb + own0 + (64 * q + 4 * e) * BCG_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (steps && wave == 0 && lk == 0) steps[(long)s * m + a] = used;
+    }
+    if (stats && threadIdx.x == 0) {
+        atomicAdd(stats + 0, 1ull);
+        atomicAdd(stats + 1, (unsigned long long)up * up * block_steps);
+        atomicAdd(stats + 2, (unsigned long long)block_steps);
+        atomicAdd(stats + 3, (unsigned long long)up * up);
+        atomicAdd(stats + 4, (unsigned long long)ntile * (ntile + 1) / 2 * 2048ull * block_steps);  // bytes of sub-matrix streamed
+    }
+}
+
 int iter_block_count(int m, int W) { const int H = (m + W - 1) / W; return ((W + 3) / 4) * ((H + 3) / 4); }
 int iter_block_umax() { return BCG_UMAX; }
 
@@ -352,7 +610,7 @@ size_t iter_block_patch_bytes(int ups) { return (size_t)ups * ups * 8 + 2 * (siz
 int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, const double *diag, long ldd, const double *B, long ldb,
                       const double *oyx, const double *iy, const double *ix, long ldxy, const int *n, int m, int W, int batch,
                       double rho, double rtol, int maxiter, float *T, long ldt, void *ws, size_t budget, int *max_union, int *steps,
-                      unsigned long long *stats)
+                      unsigned long long *stats, int *sym_used)
 {
     const int H = (m + W - 1) / W, nblocks = iter_block_count(m, W);
     const size_t nb = (size_t)batch * nblocks;
@@ -371,31 +629,53 @@ int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, c
     int mx = 0;
     for (size_t i = 0; i < nb; i++) mx = std::max(mx, nu_h[i]);
     *max_union = mx;
+    if (sym_used) *sym_used = 0;
     if (mx > BCG_UMAX) return IMCOM_OK;  // nothing solved: the caller uses the per-pixel kernel
     if (mx == 0) {
         if (steps) IMCOM_HIP_CHECK(hipMemsetAsync(steps, 0, (size_t)batch * m * 4, ctx->stream));
         return IMCOM_OK;
     }
     const int ups = (mx + 15) / 16 * 16, ntile = ups / 16;
-    const size_t per = iter_block_patch_bytes(ups);
+    // IMCOM_ITER_SYM=1: the half-storage kernel where its LDS ring fits beside P (unions up to 768 rows).  Opt-in: it is correct (the same
+    // parity statement, tests/test_gpu_iter_default.py runs both) and halves the bytes, but it is slower -- 176 against 143 ms per 128
+    // default-configuration stamps: with one wave per SIMD its instruction stream (accumulators in and out of a register array through a
+    // switch per tile, the tile cursor, six loads per tile) keeps the issue port busy 47 % of the time against 17 %
+    // (profiles/r06_pmc_sq_iter_*.txt, profiles/r06_negative_results.txt)
+    static const bool sym_off = !(getenv("IMCOM_ITER_SYM") && strcmp(getenv("IMCOM_ITER_SYM"), "1") == 0);
+    const size_t lds_p = ((size_t)ups * BCG_R + 4 * BCG_R) * 8, lds_max = 160 * 1024;
+    const int ring = lds_p + 2 * 4 * 2048 <= lds_max ? (int)std::min<size_t>(8, (lds_max - lds_p) / (2 * 4 * 2048)) : 0;
+    const bool sym = !sym_off && ring >= 2 && ntile <= 48;
+    if (sym_used) *sym_used = sym ? 1 : 0;
+    const long au_stride = sym ? (long)ntile * (ntile + 1) / 2 * 256 : (long)ups * ups;
+    const size_t per = (size_t)au_stride * 8 + 2 * (size_t)ups * BCG_R * 8;
     const size_t group = std::max<size_t>(1, std::min<size_t>(nb, budget / per));
     IMCOM_REQUIRE(per <= budget, "iterative kernel: a patch's sub-matrix (%zu bytes) exceeds the workspace share of %zu", per, budget);
-    double *AU = (double *)w, *BU = AU + group * (size_t)ups * ups, *XW = BU + group * (size_t)ups * BCG_R;
-    const size_t lds = ((size_t)ups * BCG_R + 4 * BCG_R) * 8;
+    double *AU = (double *)w, *BU = AU + group * (size_t)au_stride, *XW = BU + group * (size_t)ups * BCG_R;
+    const size_t lds = sym ? lds_p + (size_t)2 * ring * 4 * 2048 : lds_p;
     const int tpw = (ntile + 3) / 4;
     auto cg = tpw <= 8 ? iter_block_cg_kernel<8> : tpw <= 12 ? iter_block_cg_kernel<12> : iter_block_cg_kernel<16>;
-    IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto cgs = tpw <= 8 ? iter_block_cg_sym_kernel<8> : iter_block_cg_sym_kernel<12>;
+    if (sym) IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cgs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (size_t b0 = 0; b0 < nb; b0 += group) {
         const unsigned g = (unsigned)std::min(group, nb - b0);
         {
-        ProfScope ps(ctx, "iter_gather");
-        hipLaunchKernelGGL(iter_block_gather_kernel, dim3(g), dim3(256), 0, ctx->stream, A, lda, strideA, diag, ldd, B, ldb, m, W, H, nblocks, (long)b0,
-                           ups, (const int *)usel, (const unsigned short *)umask, (const int *)nu, AU, BU);
-        IMCOM_TRY(check_launch("iter_block_gather_kernel"));
+            ProfScope ps(ctx, "iter_gather");
+            if (sym)
+                hipLaunchKernelGGL(iter_block_gather_kernel<true>, dim3(g), dim3(256), 0, ctx->stream, A, lda, strideA, diag, ldd, B, ldb, m, W, H, nblocks, (long)b0,
+                                   ups, au_stride, (const int *)usel, (const unsigned short *)umask, (const int *)nu, AU, BU);
+            else
+                hipLaunchKernelGGL(iter_block_gather_kernel<false>, dim3(g), dim3(256), 0, ctx->stream, A, lda, strideA, diag, ldd, B, ldb, m, W, H, nblocks, (long)b0,
+                                   ups, au_stride, (const int *)usel, (const unsigned short *)umask, (const int *)nu, AU, BU);
+            IMCOM_TRY(check_launch("iter_block_gather_kernel"));
         }
         ProfScope ps(ctx, "iter_cg");
-        hipLaunchKernelGGL(cg, dim3(g), dim3(256), lds, ctx->stream, (const double *)AU, (const double *)BU, (const int *)usel,
-                           (const unsigned short *)umask, (const int *)nu, m, W, H, nblocks, (long)b0, ups, rtol, maxiter, T, ldt, XW, steps, stats);
+        if (sym)
+            hipLaunchKernelGGL(cgs, dim3(g), dim3(256), lds, ctx->stream, (const double *)AU, (const double *)BU, (const int *)usel, (const unsigned short *)umask,
+                               (const int *)nu, m, W, H, nblocks, (long)b0, ups, au_stride, ring, rtol, maxiter, T, ldt, XW, steps, stats);
+        else
+            hipLaunchKernelGGL(cg, dim3(g), dim3(256), lds, ctx->stream, (const double *)AU, (const double *)BU, (const int *)usel, (const unsigned short *)umask,
+                               (const int *)nu, m, W, H, nblocks, (long)b0, ups, rtol, maxiter, T, ldt, XW, steps, stats);
         IMCOM_TRY(check_launch("iter_block_cg_kernel"));
     }
     return IMCOM_OK;

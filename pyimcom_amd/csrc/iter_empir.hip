@@ -18,7 +18,7 @@ int iter_block_umax();
 int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, const double *diag, long ldd, const double *B, long ldb,
                       const double *oyx, const double *iy, const double *ix, long ldxy, const int *n, int m, int W, int batch,
                       double rho, double rtol, int maxiter, float *T, long ldt, void *ws, size_t budget, int *max_union, int *steps,
-                      unsigned long long *stats);
+                      unsigned long long *stats, int *sym_used);
 
 constexpr int CG_MAXSEL = 4096;            // input pixels inside one acceptance disc (LDS: 16 KB indices + 32 KB p)
 constexpr int CG_SLOTS = CG_MAXSEL / 256;  // rows of the sub-system owned by one thread
@@ -555,13 +555,14 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
             IMCOM_TRY(launch_diag_shift(ctx, A_d, ldn, inc, ninc, dsh, batch));
             bool blocked = false;
             if (!per_pixel) {  // 4 x 4 patches of output pixels per workgroup (iter_block.hip), unless a patch selects too many input pixels
-                int mx = 0;
+                int mx = 0, sym_used = 0;
                 IMCOM_HIP_CHECK(hipMemsetAsync(Tn + (size_t)p * szB, 0, szB * 4, ctx->stream));
                 IMCOM_HIP_CHECK(hipMemsetAsync(stats_d, 0, 64, ctx->stream));  // (statistics and step counts: of the LAST node)
                 IMCOM_TRY(launch_iter_block(ctx, A_d, (long)ldn, (long)ldn * ldn, dsh, (long)ldn, B_d, (long)ldn, yx_d, iy_d, ix_d, (long)ldn, n_dev, m, gridW,
-                                            batch, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, blkws, blk_budget, &mx, steps_d, stats_d));
+                                            batch, rho_acc, rtol, maxiter, Tn + (size_t)p * szB, (long)ldn, blkws, blk_budget, &mx, steps_d, stats_d, &sym_used));
                 blocked = mx <= iter_block_umax();  // else: some patch selects more input pixels than the blocked solver holds -- the per-pixel kernel redoes the node
                 ctx->iter_stats[4] = (double)mx;
+                ctx->iter_stats[7] = (double)sym_used;
             }
             if (!blocked) {
                 ProfScope ps(ctx, "iter_cg");
@@ -572,13 +573,14 @@ extern "C" int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn
             ctx->iter_stats[5] = blocked ? 1.0 : 0.0;
         }
         int st_h = 0;
-        unsigned long long stats_h[4] = {0, 0, 0, 0};
+        unsigned long long stats_h[5] = {0, 0, 0, 0, 0};
         ctx->iter_steps.resize(szM);
         IMCOM_HIP_CHECK(hipMemcpyAsync(&st_h, status, 4, hipMemcpyDeviceToHost, ctx->stream));
-        IMCOM_HIP_CHECK(hipMemcpyAsync(stats_h, stats_d, 32, hipMemcpyDeviceToHost, ctx->stream));
+        IMCOM_HIP_CHECK(hipMemcpyAsync(stats_h, stats_d, 40, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipMemcpyAsync(ctx->iter_steps.data(), steps_d, szM * 4, hipMemcpyDeviceToHost, ctx->stream));
         IMCOM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < 4; k++) ctx->iter_stats[k] = (double)stats_h[k];
+        ctx->iter_stats[6] = (double)stats_h[4];
         IMCOM_REQUIRE(st_h == 0, "iterative kernel: %d input pixels inside one acceptance disc exceed the limit of %d", st_h, CG_MAXSEL);
         double *G = nullptr;
         if (exact) {
@@ -617,7 +619,7 @@ extern "C" int imcom_solve_iter_stats(imcom_ctx *ctx, double *stats, int *steps,
 {
     IMCOM_TRY(ctx_ok2(ctx));
     IMCOM_REQUIRE(stats, "null pointer");
-    for (int k = 0; k < 8; k++) stats[k] = k < 6 ? ctx->iter_stats[k] : 0.0;
+    for (int k = 0; k < 8; k++) stats[k] = ctx->iter_stats[k];
     if (steps) {
         IMCOM_REQUIRE(nsteps == (long)ctx->iter_steps.size(), "step counts of the last imcom_solve_iter call: %zu pixels, caller asks for %ld", ctx->iter_steps.size(), nsteps);
         std::copy(ctx->iter_steps.begin(), ctx->iter_steps.end(), steps);

@@ -119,3 +119,46 @@ def test_iterative_against_cholesky_image_on_a_block():
     for k in ("UC", "Sigma"):
         m_ = it.maps[k].cpu().numpy()
         assert np.isfinite(m_).all() and (m_[..., lo:hi, lo:hi] >= 1e-32).all()
+
+
+def test_half_storage_kernel_opt_in_agrees_with_the_default():
+    """IMCOM_ITER_SYM=1: the blocked CG on the tiles on and below the diagonal only (csrc/iter_block.hip iter_block_cg_sym_kernel: every tile
+    used for q_I += T P_K and q_K += T^T P_I; half the bytes, a fixed order of sums).  Not the default (it is slower: issue-bound,
+    profiles/r06_negative_results.txt) -- kept correct: in a subprocess, one default-configuration stamp against the full-storage kernel
+    of this process: the same steps for nearly every pixel, T where they agree within 2e-3 of its largest entry."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    from pyimcom_amd import synth
+    from pyimcom_amd._lib import default_context
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, torch, sys\n"
+            "from pyimcom_amd import synth\nfrom pyimcom_amd._lib import default_context\nfrom pyimcom_amd.stamps import PSFGroupTables, StampBatch\n"
+            "cfg = synth.CONFIGS['iter_default']; ctx = default_context(0)\n"
+            "psfs, target = synth.make_psfs(cfg, cfg.n_expo)\n"
+            "b = StampBatch(cfg, [synth.make_stamp(cfg, 0)], PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx), ctx=ctx); b.run(); torch.cuda.synchronize()\n"
+            "st, steps = ctx.iter_stats(cfg.m)\n"
+            "assert st['half_storage'] and st['bytes'] < 0.52 * st['bytes_full_storage'], st\n"
+            "np.savez(sys.argv[1], T=b.result().T(0).cpu().numpy(), steps=steps)\nprint('sym ok')\n")
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"imcom_sym_{os.getpid()}.npz")
+    p = subprocess.run([sys.executable, "-c", code, out], cwd=root, env=dict(os.environ, PYTHONPATH=root, IMCOM_ITER_SYM="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "sym ok" in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
+    z = np.load(out)
+    os.remove(out)
+    cfg = synth.CONFIGS["iter_default"]
+    ctx = default_context(0)
+    psfs, target = synth.make_psfs(cfg, cfg.n_expo)
+    b = StampBatch(cfg, [synth.make_stamp(cfg, 0)], PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx), ctx=ctx)
+    b.run()
+    torch.cuda.synchronize()
+    st, steps = ctx.iter_stats(cfg.m)
+    assert not st["half_storage"] and st["bytes"] == st["bytes_full_storage"]
+    T = b.result().T(0).cpu().numpy()
+    same = steps == z["steps"]
+    d = np.abs(T - z["T"]).max(axis=1) / np.abs(T).max(axis=1)
+    assert same.mean() > 0.95 and d[same].max() < 2e-3 and np.median(d) < 1e-6, (same.mean(), d[same].max(), np.median(d))
