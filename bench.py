@@ -166,11 +166,12 @@ def roofline_chol(n_arr, factorisations, ms_gemm, ms_diag, launches):
             "launches": launches, "traffic": None, "note": "algorithmic N^3/3 per factorisation; the update launches execute the diagonal tiles in full (+13 % at N = 2.2k)"}
 
 
-def pmc_kernel_traffic(kernel, batch, cfg_name):
-    """HBM bytes per launch of `kernel` from the newest committed counter passes of the headline command (as pmc_traffic)."""
+def pmc_kernel_traffic(kernel, batch, cfg_name, pattern="r*_pmc_traffic.json"):
+    """HBM bytes per launch of `kernel` from the newest committed counter passes of the headline command (as pmc_traffic); ``pattern``:
+    another leg's passes (r*_pmc_traffic_iter.json: tools/pmc_iter_traffic.sh)."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern)))
     if not files:
         return None, None
     doc = json.load(open(files[-1]))
@@ -827,6 +828,7 @@ def iter_default_leg(ctx, dev, batch=128, steps=2, cpu_budget=20.0, block_n1P=16
     its, steps_px = ctx.iter_stats(batch * cfg.m)
     n = b.n.astype(np.float64)
     cg_ms, cg_launches = fams["iter_cg"]
+    tr_cg, tr_src = pmc_kernel_traffic("iter_block_cg_kernel", batch, cfg.name, "r*_pmc_traffic_iter.json")  # (same batch, same kernel sources: else null)
     cg_s = cg_ms * 1e-3 / steps
     out = {"value": batch / dt, "unit": "postage-stamps/s", "ms_per_stamp": dt / batch * 1e3, "ms_per_step": dt * 1e3, "batch": batch, "steps": steps,
            "N_mean": float(n.mean()), "N_max": int(n.max()), "m": cfg.m, "n_inframe": cfg.n_inframe, "n_expo": cfg.n_expo, "kappaC": list(cfg.kappaC),
@@ -842,7 +844,7 @@ def iter_default_leg(ctx, dev, batch=128, steps=2, cpu_budget=20.0, block_n1P=16
                         "bytes_per_launch": its["bytes"] * steps / max(cg_launches, 1), "avg_launch_ms": cg_ms / max(cg_launches, 1), "launches": cg_launches // max(steps, 1),
                         "mfma_TFLOPs": its["flops"] / cg_s / 1e12 if cg_s else None, "mfma_frac": its["flops"] / cg_s / 1e12 / FP64_MFMA_PEAK_TFLOPS if cg_s else None,
                         "count": "8 up^2 bytes and 32 up^2 flops per patch and CG step, up = the patch's union selection rounded up to 16 (the sub-matrix is "
-                                 "stored and read in full, both triangles)", "traffic": None}}
+                                 "stored and read in full, both triangles)", "traffic": tr_cg, "traffic_source": tr_src}}
     job = its["flops"] + float((165.0 * n * (n + 1) + 220.0 * n * cfg.m).sum())
     out["job_roofline_frac"] = job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS
     cpu_sample = stamps[:8]

@@ -318,7 +318,8 @@ class Context:
         steps = None if nsteps is None else np.zeros(int(nsteps), dtype=np.int32)
         check(lib.imcom_solve_iter_stats(self.handle, st, None if steps is None else _vp(steps.ctypes.data), 0 if steps is None else int(nsteps)))
         out = {"patches": int(st[0]), "up2_steps": float(st[1]), "patch_steps": float(st[2]), "up2": float(st[3]), "max_union": int(st[4]),
-               "blocked": bool(st[5]), "flops": 32.0 * float(st[1]), "bytes": float(st[6]), "bytes_full_storage": 8.0 * float(st[1]), "half_storage": bool(st[7])}
+               "blocked": bool(st[5]), "flops": 32.0 * float(st[1]), "bytes": float(st[6]) if st[7] else 8.0 * float(st[1]), "bytes_full_storage": 8.0 * float(st[1]),
+               "half_storage": bool(st[7])}  # (bytes: what the patches streamed over their steps -- the whole sub-matrix per step, or its lower tiles)
         return (out, steps) if nsteps is not None else out
 
     def mfma_probe(self, millis=50.0):

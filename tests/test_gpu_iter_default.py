@@ -162,3 +162,46 @@ def test_half_storage_kernel_opt_in_agrees_with_the_default():
     same = steps == z["steps"]
     d = np.abs(T - z["T"]).max(axis=1) / np.abs(T).max(axis=1)
     assert same.mean() > 0.95 and d[same].max() < 2e-3 and np.median(d) < 1e-6, (same.mean(), d[same].max(), np.median(d))
+
+
+@pytest.mark.parametrize("n_expo, blocked", [(8, True), (12, False)])
+def test_deeper_stacks_take_the_wide_kernel_or_the_per_pixel_one(n_expo, blocked):
+    """The default configuration at other exposure depths.  Eight exposures: ~750 input pixels per acceptance disc, a 4 x 4 patch's union
+    ~950 rows -- the blocked solver's widest variant (up to 1024 rows).  Twelve: the unions pass 1024 and the call falls back to the
+    per-pixel kernel (one workgroup per output pixel, lakernel.py:545-586 as written).  Both against the oracle on one stamp with
+    the parity statement of tests/parity.py iter_parity."""
+    import dataclasses
+
+    import torch
+
+    from oracle import oracle as orc
+    from pyimcom_amd import synth
+    from pyimcom_amd._lib import default_context
+    from pyimcom_amd.stamps import PSFGroupTables, StampBatch
+    from tests.parity import iter_parity
+
+    # (16 x 16 outputs instead of 32 x 32: the discs and unions are the same size -- they depend on rho and the depth -- and the oracle's 256
+    # recurrences take a quarter of the time)
+    cfg = dataclasses.replace(synth.CONFIGS["iter_default"], n2=16, n_expo=n_expo, name=f"iter_default_e{n_expo}")
+    ctx = default_context(0)
+    st = synth.make_stamp(cfg, 0)
+    psfs, target = synth.make_psfs(cfg, n_expo)
+    b = StampBatch(cfg, [st], PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx), ctx=ctx)
+    b.run()
+    torch.cuda.synchronize()
+    stats, gsteps = ctx.iter_stats(cfg.m)
+    assert stats["blocked"] == blocked and (768 < stats["max_union"] <= 1024 if blocked else stats["max_union"] > 1024), stats
+    res = b.result()
+    g, tabs_ref, C, tab, pen, io = _oracle_inputs(cfg, psfs, target)
+    A, Bt = orc.stamp_system(g, st.x, st.y, st.expo, tabs_ref, tab, pen, io, st.out_x0, st.out_y0, cfg.n2f)
+    mB = np.ascontiguousarray(Bt.T)
+    g1 = np.arange(cfg.n2f, dtype=np.float64)
+    oy, ox = np.repeat(st.out_y0 + g1, cfg.n2f), np.tile(st.out_x0 + g1, cfg.n2f)
+    osteps = []
+    Tr, UCr, Sr, _, _ = orc.iter_kernel(A, mB, C, np.array(cfg.kappaC), cfg.uctarget, cfg.sigmamax, oy, ox, st.y, st.x, cfg.rho, cfg.iter_rtol, cfg.iter_max, steps=osteps)
+    UCr, Sr = orc.iterative_clamp(UCr, Sr)
+    relevant = orc._relevant(oy, ox, st.y, st.x, cfg.rho)
+    assert relevant.sum(axis=1).mean() > 90 * n_expo
+    rep = iter_parity(A, mB, C, relevant, cfg.iter_rtol, cfg.iter_max, (res.T(0).cpu().numpy(), gsteps, res.UC[0].cpu().numpy().ravel(), res.Sigma[0].cpu().numpy().ravel()),
+                      (Tr, np.array(osteps), UCr, Sr), min_same=0.93)
+    assert rep["dT_same_max"] < 2e-3, rep

@@ -309,6 +309,7 @@ def test_block_seam_honours_the_stamp_window_nrun_and_outmaps():
         coadd_output_stamps(blk, psfgrp, flat_penalty=wl.flat_penalty)
 
 
+@pytest.mark.gpu
 def test_sampling_positions_from_a_lattice():
     """the host evaluates the WCS chain on a 17 x 17 lattice per PSF group and exposure instead of at all
     nsamp^2 = 146 689 sampling positions (psfutil.py:751-771); the device forms the positions (imcom_lattice_positions).  On affine maps
