@@ -230,7 +230,8 @@ def target_psfs(cfg, psfgrp, device, ctx=None):
     return psfs.sample_psf(imgs, ns, None, bool(cfg.psf_circ), bool(cfg.psf_norm), ctx)
 
 
-_REPAIR_STATE = {}  # per context: what the last pass of the last block saw of _cholesky_wrapper's repair (blockrun.coadd_block)
+_REPAIR_STATE = {}  # per context: the repair record of the last block's first pass (blockrun.RepairRecord), for inspection -- a block's passes
+                    # start from ITS first pass's record, never from another block's
 
 def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda:0", stamps=None, finalize=True, table_capacity=None, ctx=None,
                         host_threads=1, positions="lattice"):
@@ -291,7 +292,7 @@ def coadd_output_stamps(blk, psfgrp, flat_penalty=None, batch=None, device="cuda
     try:
         maps = coadd_block(scfg, pool, tables, n1P, int(blk.n_inimage), chunks=chunks, pad_sides=getattr(blk, "pad_sides", "") if finalize else None,
                            postage_pad=int(getattr(cfg, "postage_pad", 0)), origin=(window[0], window[2]),
-                           repair_state=_REPAIR_STATE.setdefault(id(tables.ctx), {}))  # (block after block of one run: the first pass does not start blind)
+                           repair_state=_REPAIR_STATE.setdefault(id(tables.ctx), {}))  # (a log of the last block's first-pass repair record; nothing is read from it)
     finally:
         ahead.close()
     blk.out_map, blk.T_weightmap = maps.out_map.cpu().numpy(), maps.T_weightmap.cpu().numpy()
