@@ -22,6 +22,7 @@
 // Sums run in another order than numpy's; what that means for a recurrence that does not converge is described in DESIGN.md
 // ("Iterative kernel and rounding") and is the same statement as for the per-pixel kernel.
 #include <algorithm>
+#include <utility>
 
 #include "common.h"
 #include "launchers.h"
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void iter_block_gather_kernel(const double *__
         if (j < nsel && (msk[j] >> r & 1)) v = B[((long)s * m + pix[r]) * ldb + sel[j]];
         BUb[t] = v;
     }
+    if (SYM) AUb[((long)ntile * (ntile + 1) / 2) * 256 + threadIdx.x] = 0.0;  // the all-zero tile behind the packed ones
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,14 +358,14 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
 // the tiles are visited column panel by column panel (K outer), a wave keeps ONE accumulator for its share of panel K's transposed
 // products, leaves it in an LDS ring when the panel is done, and after a barrier per `ring` panels the owner of tile row K adds the four
 // waves' pieces in wave order -- a fixed order of sums: results are reproducible.  LDS: P [ups][16], the ring 2 x ring x 4 x 2 KB.
-// MEASURED: correct on the first run, HBM bytes halved -- and slower than the full-storage kernel (issue-bound, see launch_iter_block):
-// kept as IMCOM_ITER_SYM=1, not the default.
-#ifndef IMCOM_BCG_SCH
-#define IMCOM_BCG_SCH 4
-#endif
-constexpr int BCG_SCH = IMCOM_BCG_SCH;  // tiles fetched ahead by the symmetric kernel
+// MEASURED (128 default-configuration stamps): 134 ms against the full-storage kernel's 142, the gather 8.6 against 16.5 -- the default for
+// unions up to 768 rows since round 6 (IMCOM_ITER_SYM=0 turns it off).
+// RG: the residual r lives in workspace beside x (the twelve-row variant: r, the accumulators and the fetch slots are 3 x 96 registers, and
+// with r among them the compiler spilled 200): read twice per step, updated by atomic adds without return.
+template <class F, int... Q>
+__device__ __forceinline__ void bcg_for_each(F &&f, std::integer_sequence<int, Q...>) { (f(std::integral_constant<int, Q>{}), ...); }
 
-template <int TPW>
+template <int TPW, bool RG>
 __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double *__restrict__ AU, const double *__restrict__ BU,
                                                                    const int *__restrict__ usel, const unsigned short *__restrict__ umask,
                                                                    const int *__restrict__ nu, int m, int W, int H, int nblocks, long blk0,
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
                                                                    float *__restrict__ T, long ldt, double *__restrict__ XW,
                                                                    int *__restrict__ steps, unsigned long long *__restrict__ stats)
 {
-    extern __shared__ double lds[];  // P [ups][16], red [4][16], ring [2][ring][4][256]
+    extern __shared__ double lds[];  // P [ups][16], red [4][16], ring [2][ring][4][256], Tw [4][2][16][18]
     const long blk = blk0 + blockIdx.x;
     const int s = (int)(blk / nblocks), b = (int)(blk - (long)s * nblocks);
     const int nsel = nu[blk];
@@ -382,9 +384,9 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         return;
     }
     const int up = (nsel + 15) / 16 * 16, ntile = up / 16;
-    double *P = lds, *red = lds + (long)ups * BCG_R, *Rg = red + 4 * BCG_R;
+    double *P = lds, *red = lds + (long)ups * BCG_R, *Rg = red + 4 * BCG_R, *Tw = Rg + (long)2 * ring * 4 * 256;  // (Tw: 4 waves x 2 x [16][18])
     const double *AUb = AU + (long)blockIdx.x * au_stride, *BUb = BU + (long)blockIdx.x * ups * BCG_R;
-    double *Xb = XW + (long)blockIdx.x * ups * BCG_R;
+    double *Xb = XW + (long)blockIdx.x * 2 * ups * BCG_R, *Rb = Xb + (long)ups * BCG_R;  // iterate x; residual r (RG)
     const unsigned short *mk = umask + blk * BCG_UMAX;
     const bool valid = a >= 0;
     const int own0 = (16 * wave + lk) * BCG_R + li;
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         return (red[li] + red[BCG_R + li]) + (red[2 * BCG_R + li] + red[3 * BCG_R + li]);
     };
 
-    double r[TPW][4], acc[TPW][4];
+    double r[RG ? 1 : TPW][4];
     unsigned long long own = 0;
     double bb = 0.0;
 #pragma unroll
@@ -409,9 +411,11 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
             const int j = 16 * tt + lk + 4 * e;
             const bool in = tt < ntile;
             if (in && (mk[j] >> li & 1)) own |= 1ull << (4 * q + e);
-            r[q][e] = in ? BUb[(long)j * BCG_R + li] : 0.0;
+            const double rv = in ? BUb[(long)j * BCG_R + li] : 0.0;
+            if (RG) { if (in) Rb[own0 + (64 * q + 4 * e) * BCG_R] = rv; }
+            else r[q][e] = rv;
             if (in) Xb[own0 + (64 * q + 4 * e) * BCG_R] = 0.0;
-            bb += r[q][e] * r[q][e];
+            bb += rv * rv;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -420,21 +424,17 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
     bool done = !valid;
     int used = 0, block_steps = 0;
     // the tiles of this wave, column panel by column panel: (K, I) with I = first(K), first(K) + 4, ... < ntile
-    auto first = [&](int K) { return K + ((wave - K) & 3); };
-    auto tile_ptr = [&](int K, int I) { return AUb + ((long)K * ntile - (long)K * (K - 1) / 2 + (I - K)) * 256; };
-    auto advance = [&](int &K, int &I) {
-        I += 4;
-        while (K < ntile && I >= ntile) { K++; I = first(K); }
-    };
-#define BCG_ACC_GET(Q) case Q: if (Q < TPW) { c4[0] = acc[Q < TPW ? Q : 0][0]; c4[1] = acc[Q < TPW ? Q : 0][1]; c4[2] = acc[Q < TPW ? Q : 0][2]; c4[3] = acc[Q < TPW ? Q : 0][3]; } break;
-#define BCG_ACC_PUT(Q) case Q: if (Q < TPW) { acc[Q < TPW ? Q : 0][0] = c4[0]; acc[Q < TPW ? Q : 0][1] = c4[1]; acc[Q < TPW ? Q : 0][2] = c4[2]; acc[Q < TPW ? Q : 0][3] = c4[3]; } break;
-#define BCG_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
     for (int it = 0; it < maxiter; it++) {
+        if (RG) __threadfence();  // (this lane's atomic adds to r of the step before have reached L2: the loads below bypass L1)
+        auto rget = [&](int q, int e, int base) -> double {
+            if (!RG) return r[RG ? 0 : q][e];
+            return (wave + 4 * q < ntile) ? __hip_atomic_load(Rb + base + (64 * q + 4 * e) * BCG_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        };
         double rr = 0.0;
 #pragma unroll
         for (int q = 0; q < TPW; q++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) rr += r[q][e] * r[q][e];
+            for (int e = 0; e < 4; e++) { const double rv = rget(q, e, own0); rr += rv * rv; }
         const double rho_cur = rhs_sum(rr);
         if (!done && sqrt(rho_cur) < atol) done = true;
         if (__syncthreads_and(done)) break;
@@ -451,105 +451,109 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
                 for (int e = 0; e < 4; e++) {
                     double *pp = P + ob + (64 * q + 4 * e) * BCG_R;
                     const double pold = it > 0 ? *pp : 0.0;
-                    *pp = act ? pold * beta + r[q][e] : 0.0;
+                    *pp = act ? pold * beta + rget(q, e, ob) : 0.0;
                 }
-#pragma unroll
-            for (int e = 0; e < 4; e++) acc[q][e] = 0.0;
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        // ---- q = AU P from the lower tiles
-        f64x2 nn[BCG_SCH][2];
-        double nt[BCG_SCH][4];
-        int pK = 0, pI = first(0), cK, cI;
-        while (pK < ntile && pI >= ntile) { pK++; pI = first(pK); }
-        cK = pK; cI = pI;
-        auto fetch = [&]() {
+        // ---- q = AU P from the lower tiles.  Column panels K = 0 .. ntile - 1 in order; this wave's tile rows I = wave + 4 q in an unrolled
+        // loop (q is a compile-time index: the accumulators are plain registers).  Every tile row keeps its own fetch slot across the
+        // panels: right after tile (I, K) has been used its slot is refilled with tile (I, K + 1) -- one panel ahead, behind the MFMAs of
+        // the wave's other rows.  The panels are grouped in PHASES by the first row that still has a tile in them (qmin: it moves up one row
+        // every four panels), so that inside a phase the rows above qmin run as straight-line code -- no test per tile, the scheduler
+        // overlaps one row's LDS round trips with another's MFMAs; only row qmin (whose last tile of the phase is the diagonal one) tests.
+        // Rows beyond the patch (the last row of three of the four waves) multiply an all-zero tile.
+        f64x4 accv[TPW];
 #pragma unroll
-            for (int u = 0; u < BCG_SCH; u++) {
-                const bool have = pK < ntile;
-                const double *t = have ? tile_ptr(pK, pI) : AUb;  // (past the end: the first tile again, unused)
-                nn[u][0] = *(const f64x2 *)(t + li * 16 + 4 * lk);
-                nn[u][1] = *(const f64x2 *)(t + li * 16 + 4 * lk + 2);
+        for (int q = 0; q < TPW; q++) accv[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+        f64x2 sn[TPW][2];
+        const double *lane_n = AUb + li * 16 + 4 * lk;  // this lane's four elements of a tile: row li, columns 4 lk ..
+        const long ztile = ((long)ntile * (ntile + 1) / 2) * 256;  // the all-zero tile behind the packed ones (iter_block_gather_kernel<true>)
+        double *tw = Tw + wave * (2 * 16 * 18);                    // this wave's two transposition tiles in LDS ([16][18] each)
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) nt[u][kk] = t[(4 * lk + kk) * 16 + li];
-                if (have) advance(pK, pI);
-            }
-        };
-        fetch();
-        int Kcur = 0;
+        for (int q = 0; q < TPW; q++) {  // panel 0: tile (I, 0) at tile index I
+            const int I = wave + 4 * q;
+            const long t = I < ntile ? (long)I * 256 : ztile;
+            sn[q][0] = *(const f64x2 *)(lane_n + t);
+            sn[q][1] = *(const f64x2 *)(lane_n + t + 2);
+        }
         f64x4 part = {0.0, 0.0, 0.0, 0.0};
-        double bK[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) bK[kk] = P[(long)(4 * lk + kk) * BCG_R + li];
-        // panel Kcur is complete for this wave: its transposed sums go to the ring; after every `ring` panels (and after the last) the
-        // owners of those tile rows add the four waves' pieces, in wave order
-        auto flush = [&]() {
-            const int slot = ((Kcur / ring) & 1) * ring + Kcur % ring;
+        long cs1 = ntile;  // first tile index of panel K + 1
+        auto panel_end = [&](int K) __attribute__((always_inline)) {
+            // panel K is complete for this wave: its transposed sums go to the ring; after every `ring` panels (and after the last) the
+            // owners of those tile rows add the four waves' pieces, in wave order
+            const int slot = ((K / ring) & 1) * ring + K % ring;
             double *dst = Rg + ((long)slot * 4 + wave) * 256 + lane;
 #pragma unroll
             for (int e = 0; e < 4; e++) dst[64 * e] = part[e];
             part = f64x4{0.0, 0.0, 0.0, 0.0};
-            if ((Kcur + 1) % ring == 0 || Kcur == ntile - 1) {
+            if ((K + 1) % ring == 0 || K == ntile - 1) {
                 __syncthreads();
-                for (int Kg = Kcur / ring * ring; Kg <= Kcur; Kg++) {
+                for (int Kg = K / ring * ring; Kg <= K; Kg++) {
                     if ((Kg & 3) != wave) continue;
                     const double *src = Rg + ((long)(((Kg / ring) & 1) * ring + Kg % ring) * 4) * 256 + lane;
-                    double c4[4];
-                    switch (Kg >> 2) { BCG_ALL(BCG_ACC_GET) default: break; }
+                    f64x4 add;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) c4[e] += (src[64 * e] + src[256 + 64 * e]) + (src[512 + 64 * e] + src[768 + 64 * e]);
-                    switch (Kg >> 2) { BCG_ALL(BCG_ACC_PUT) default: break; }
-                }
-            }
-            Kcur++;
-            if (Kcur < ntile)
+                    for (int e = 0; e < 4; e++) add[e] = (src[64 * e] + src[256 + 64 * e]) + (src[512 + 64 * e] + src[768 + 64 * e]);
+                    // (every row updated, by the piece times one or zero: written as "if (q == Kg / 4) accv[q] += add" the compiler turns
+                    // the unrolled tests into ONE dynamically indexed access and moves the whole accumulator array to scratch memory)
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) bK[kk] = P[(long)(16 * Kcur + 4 * lk + kk) * BCG_R + li];
-        };
-        while (cK < ntile) {
-            f64x2 cn[BCG_SCH][2];
-            double ct[BCG_SCH][4];
+                    for (int q = 0; q < TPW; q++) {
+                        const double w1 = q == (Kg >> 2) ? 1.0 : 0.0;
 #pragma unroll
-            for (int u = 0; u < BCG_SCH; u++) {
-                cn[u][0] = nn[u][0]; cn[u][1] = nn[u][1];
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) ct[u][kk] = nt[u][kk];
-            }
-            fetch();
-#pragma unroll
-            for (int u = 0; u < BCG_SCH; u++) {
-                if (cK < ntile) {
-                    while (Kcur < cK) flush();
-                    double c4[4] = {0.0, 0.0, 0.0, 0.0};
-                    const int q = (cI - wave) >> 2;
-                    switch (q) { BCG_ALL(BCG_ACC_GET) default: break; }
-                    f64x4 an = {c4[0], c4[1], c4[2], c4[3]};
-                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(cn[u][0].x, bK[0], an, 0, 0, 0);
-                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(cn[u][0].y, bK[1], an, 0, 0, 0);
-                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(cn[u][1].x, bK[2], an, 0, 0, 0);
-                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(cn[u][1].y, bK[3], an, 0, 0, 0);
-                    c4[0] = an[0]; c4[1] = an[1]; c4[2] = an[2]; c4[3] = an[3];
-                    switch (q) { BCG_ALL(BCG_ACC_PUT) default: break; }
-                    if (cI > cK) {
-                        const double *pi = P + (long)(16 * cI + 4 * lk) * BCG_R + li;
-                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(ct[u][0], pi[0], part, 0, 0, 0);
-                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(ct[u][1], pi[BCG_R], part, 0, 0, 0);
-                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(ct[u][2], pi[2 * BCG_R], part, 0, 0, 0);
-                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(ct[u][3], pi[3 * BCG_R], part, 0, 0, 0);
+                        for (int e = 0; e < 4; e++) accv[q][e] = fma(add[e], w1, accv[q][e]);
                     }
-                    advance(cK, cI);
                 }
             }
-        }
-        while (Kcur < ntile) flush();
+            cs1 += ntile - K - 1;
+        };
+        auto phase = [&](auto qm) __attribute__((always_inline)) {
+            constexpr int qmin = decltype(qm)::value;
+            const int Kbeg = qmin == 0 ? 0 : wave + 4 * (qmin - 1) + 1, Kend = min(wave + 4 * qmin, ntile - 1);  // the panels of this phase
+            for (int K = Kbeg; K <= Kend; K++) {
+                double bK[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) bK[kk] = P[(long)(16 * K + 4 * lk + kk) * BCG_R + li];
+                const bool last = K + 1 >= ntile;
+#pragma unroll
+                for (int q = qmin; q < TPW; q++) {
+                    const int I = wave + 4 * q;
+                    const bool rowok = I < ntile, below = I > K;  // (q > qmin: always below the diagonal when the row exists)
+                    const f64x2 t0 = sn[q][0], t1 = sn[q][1];
+                    f64x4 an = accv[q];
+                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bK[0], an, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bK[1], an, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.x, bK[2], an, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.y, bK[3], an, 0, 0, 0);
+                    accv[q] = an;
+                    if (q > qmin || below) {
+                        // the transposed operand through one of the wave's two LDS tiles: element (li, 4 lk + c) in, (4 lk + kk, li) out
+                        double *tq = tw + (q & 1) * (16 * 18);
+                        *(f64x2 *)(tq + li * 18 + 4 * lk) = t0;
+                        *(f64x2 *)(tq + li * 18 + 4 * lk + 2) = t1;
+                        // the slot again: tile (I, K + 1), tile index cs1 + (I - K - 1); the zero tile for a row beyond the patch / after the last panel
+                        const long t = (rowok && !last) ? (cs1 + (I - K - 1)) * 256 : ztile;
+                        sn[q][0] = *(const f64x2 *)(lane_n + t);
+                        sn[q][1] = *(const f64x2 *)(lane_n + t + 2);
+                        const double *pi = P + (long)(16 * (rowok ? I : ntile - 1) + 4 * lk) * BCG_R + li;
+                        const double *tr = tq + (4 * lk) * 18 + li;
+                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[0], pi[0], part, 0, 0, 0);
+                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[18], pi[BCG_R], part, 0, 0, 0);
+                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[36], pi[2 * BCG_R], part, 0, 0, 0);
+                        part = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[54], pi[3 * BCG_R], part, 0, 0, 0);
+                    }
+                }
+                panel_end(K);
+            }
+        };
+        bcg_for_each(phase, std::make_integer_sequence<int, TPW>{});
         double pq = 0.0;
 #pragma unroll
         for (int q = 0; q < TPW; q++) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                acc[q][e] = (own >> (4 * q + e) & 1) ? acc[q][e] : 0.0;
-                if (wave + 4 * q < ntile) pq += P[ob + (64 * q + 4 * e) * BCG_R] * acc[q][e];
+                accv[q][e] = (own >> (4 * q + e) & 1) ? accv[q][e] : 0.0;
+                if (wave + 4 * q < ntile) pq += P[ob + (64 * q + 4 * e) * BCG_R] * accv[q][e];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -563,16 +567,14 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
                     for (int e = 0; e < 4; e++) {
                         const int o = ob + (64 * q + 4 * e) * BCG_R;
                         unsafeAtomicAdd(Xb + o, alpha * P[o]);
-                        r[q][e] -= alpha * acc[q][e];
+                        if (RG) unsafeAtomicAdd(Rb + o, -alpha * accv[q][e]);
+                        else r[RG ? 0 : q][e] -= alpha * accv[q][e];
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
             rho_prev = rho_cur;
         }
     }
-#undef BCG_ACC_GET
-#undef BCG_ACC_PUT
-#undef BCG_ALL
     __threadfence();
     if (a >= 0) {
         float *Trow = T + ((long)s * m + a) * ldt;
@@ -636,25 +638,25 @@ int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, c
         return IMCOM_OK;
     }
     const int ups = (mx + 15) / 16 * 16, ntile = ups / 16;
-    // IMCOM_ITER_SYM=1: the half-storage kernel where its LDS ring fits beside P (unions up to 768 rows).  Opt-in: it is correct (the same
-    // parity statement, tests/test_gpu_iter_default.py runs both) and halves the bytes, but it is slower -- 176 against 143 ms per 128
-    // default-configuration stamps: with one wave per SIMD its instruction stream (accumulators in and out of a register array through a
-    // switch per tile, the tile cursor, six loads per tile) keeps the issue port busy 47 % of the time against 17 %
-    // (profiles/r06_pmc_sq_iter_*.txt, profiles/r06_negative_results.txt)
-    static const bool sym_off = !(getenv("IMCOM_ITER_SYM") && strcmp(getenv("IMCOM_ITER_SYM"), "1") == 0);
+    // The half-storage kernel where its LDS ring fits beside P (unions up to 768 rows), the full-storage one beyond; IMCOM_ITER_SYM=0: the
+    // full-storage kernel always (tests/test_gpu_iter_default.py runs both).  The first half-storage kernel (a flat tile list, accumulators
+    // through a switch) was slower than the full one; the second (phases, rows unrolled, transposition through LDS) is faster:
+    // profiles/r06_negative_results.txt item 1.
+    static const bool sym_off = getenv("IMCOM_ITER_SYM") && strcmp(getenv("IMCOM_ITER_SYM"), "0") == 0;
     const size_t lds_p = ((size_t)ups * BCG_R + 4 * BCG_R) * 8, lds_max = 160 * 1024;
-    const int ring = lds_p + 2 * 4 * 2048 <= lds_max ? (int)std::min<size_t>(8, (lds_max - lds_p) / (2 * 4 * 2048)) : 0;
+    const size_t lds_tw = 4 * 2 * 16 * 18 * 8;  // the half-storage kernel's transposition tiles
+    const int ring = lds_p + lds_tw + 2 * 4 * 2048 <= lds_max ? (int)std::min<size_t>(8, (lds_max - lds_p - lds_tw) / (2 * 4 * 2048)) : 0;
     const bool sym = !sym_off && ring >= 2 && ntile <= 48;
     if (sym_used) *sym_used = sym ? 1 : 0;
-    const long au_stride = sym ? (long)ntile * (ntile + 1) / 2 * 256 : (long)ups * ups;
-    const size_t per = (size_t)au_stride * 8 + 2 * (size_t)ups * BCG_R * 8;
+    const long au_stride = sym ? ((long)ntile * (ntile + 1) / 2 + 1) * 256 : (long)ups * ups;  // (half storage: + the all-zero tile)
+    const size_t per = (size_t)au_stride * 8 + (sym ? 3 : 2) * (size_t)ups * BCG_R * 8;  // sub-matrix, right-hand sides, x (+ r: half-storage kernel)
     const size_t group = std::max<size_t>(1, std::min<size_t>(nb, budget / per));
     IMCOM_REQUIRE(per <= budget, "iterative kernel: a patch's sub-matrix (%zu bytes) exceeds the workspace share of %zu", per, budget);
-    double *AU = (double *)w, *BU = AU + group * (size_t)au_stride, *XW = BU + group * (size_t)ups * BCG_R;
-    const size_t lds = sym ? lds_p + (size_t)2 * ring * 4 * 2048 : lds_p;
+    double *AU = (double *)w, *BU = AU + group * (size_t)au_stride, *XW = BU + group * (size_t)ups * BCG_R;  // (XW: [group][2][ups][16] for the half-storage kernel)
+    const size_t lds = sym ? lds_p + (size_t)2 * ring * 4 * 2048 + lds_tw : lds_p;
     const int tpw = (ntile + 3) / 4;
     auto cg = tpw <= 8 ? iter_block_cg_kernel<8> : tpw <= 12 ? iter_block_cg_kernel<12> : iter_block_cg_kernel<16>;
-    auto cgs = tpw <= 8 ? iter_block_cg_sym_kernel<8> : iter_block_cg_sym_kernel<12>;
+    auto cgs = tpw <= 8 ? iter_block_cg_sym_kernel<8, false> : iter_block_cg_sym_kernel<12, true>;
     if (sym) IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cgs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     else IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (size_t b0 = 0; b0 < nb; b0 += group) {
