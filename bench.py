@@ -796,8 +796,8 @@ def iter_default_leg(ctx, dev, batch=128, steps=2, cpu_budget=20.0, block_n1P=16
     coadd.py:1104-1107, the coaddition of six layers.  Three figures: (1) resident batches; (2) a block of ``block_n1P``^2 stamps through
     coadd_block, and next to it the SAME block by the Cholesky kernel at kappa/C = 5e-4 with the rms difference of the coadded science layer
     (the reference's own criterion, tests/pyimcom/test_pyimcom.py:971-978: < 2.5e-3); (3) the oracle on the same stamps on the host.
-    Roofline of the CG launches: they stream every patch's sub-matrix once per step -- algorithmic bytes 8 up^2 per patch and step, flops
-    2 up^2 x 16 -- 0.4 flop per byte-time of the matrix pipe: HBM-bound."""
+    Roofline of the CG launches: they stream every patch's (symmetric) sub-matrix once per step -- its lower tiles, 4 up^2 bytes per
+    patch and step, flops 2 up^2 x 16: 65 us at the HBM peak against 52 us at the matrix pipe's: HBM is the nearer roof."""
     import dataclasses
 
     import numpy as np
@@ -828,7 +828,8 @@ def iter_default_leg(ctx, dev, batch=128, steps=2, cpu_budget=20.0, block_n1P=16
     its, steps_px = ctx.iter_stats(batch * cfg.m)
     n = b.n.astype(np.float64)
     cg_ms, cg_launches = fams["iter_cg"]
-    tr_cg, tr_src = pmc_kernel_traffic("iter_block_cg_kernel", batch, cfg.name, "r*_pmc_traffic_iter.json")  # (same batch, same kernel sources: else null)
+    tr_cg, tr_src = pmc_kernel_traffic("iter_block_cg_sym_kernel" if its.get("half_storage") else "iter_block_cg_kernel", batch, cfg.name,
+                                       "r*_pmc_traffic_iter.json")  # (same batch, same kernel sources: else null)
     cg_s = cg_ms * 1e-3 / steps
     out = {"value": batch / dt, "unit": "postage-stamps/s", "ms_per_stamp": dt / batch * 1e3, "ms_per_step": dt * 1e3, "batch": batch, "steps": steps,
            "N_mean": float(n.mean()), "N_max": int(n.max()), "m": cfg.m, "n_inframe": cfg.n_inframe, "n_expo": cfg.n_expo, "kappaC": list(cfg.kappaC),
@@ -839,12 +840,15 @@ def iter_default_leg(ctx, dev, batch=128, steps=2, cpu_budget=20.0, block_n1P=16
            "cg_steps_per_patch": its["patch_steps"] / max(its["patches"], 1),
            "config": "configs/default_config.json of the reference (LAKERNEL Iterative, KAPPAC [0.0], OUTSIZE [80, 32, 0.0390625], INPAD 0.6, ITERRTOL 1.5e-3, "
                      "ITERMAX 30, NPIXPSF 48, GAUSSIAN target, five EXTRAINPUT layers) at six exposures, analytic Roman-like PSFs",
-           "roofline": {"kernel": "iter_block_cg_kernel (16 conjugate-gradient recurrences per 4 x 4 patch, one MFMA product per step)", "bound": "hbm",
+           "roofline": {"kernel": ("iter_block_cg_sym_kernel" if its.get("half_storage") else "iter_block_cg_kernel") + " (16 conjugate-gradient recurrences per 4 x 4 "
+                        "patch, one MFMA product per step)", "bound": "hbm",
                         "achieved": its["bytes"] / cg_s / 1e9 if cg_s else None, "peak": 8000.0, "unit": "GB/s", "frac": its["bytes"] / cg_s / 8e12 if cg_s else None,
                         "bytes_per_launch": its["bytes"] * steps / max(cg_launches, 1), "avg_launch_ms": cg_ms / max(cg_launches, 1), "launches": cg_launches // max(steps, 1),
                         "mfma_TFLOPs": its["flops"] / cg_s / 1e12 if cg_s else None, "mfma_frac": its["flops"] / cg_s / 1e12 / FP64_MFMA_PEAK_TFLOPS if cg_s else None,
-                        "count": "8 up^2 bytes and 32 up^2 flops per patch and CG step, up = the patch's union selection rounded up to 16 (the sub-matrix is "
-                                 "stored and read in full, both triangles)", "traffic": tr_cg, "traffic_source": tr_src}}
+                        "half_storage": bool(its.get("half_storage")),
+                        "count": "per patch and CG step: the 16 x 16 tiles on and below the diagonal of the union's sub-matrix = (nt (nt + 1) / 2) x 2 KB (nt = union "
+                                 "/ 16 rounded up; the full-storage kernel of unions above 768 rows reads both triangles: 8 up^2), 32 up^2 flops",
+                        "traffic": tr_cg, "traffic_source": tr_src}}
     job = its["flops"] + float((165.0 * n * (n + 1) + 220.0 * n * cfg.m).sum())
     out["job_roofline_frac"] = job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS
     cpu_sample = stamps[:8]

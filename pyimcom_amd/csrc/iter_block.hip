@@ -547,6 +547,10 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
             }
         };
         bcg_for_each(phase, std::make_integer_sequence<int, TPW>{});
+        // panels beyond this wave's last row (ntile > wave + 4 TPW - 3): nothing to multiply, but every wave ends EVERY panel -- its (zero)
+        // piece of the ring and the barriers (the first build lacked this: right at ntile = 45 = 4 x 12 - 3, wrong from 46 and for the
+        // eight-row variant from 30; tests/test_gpu_iter_default.py::test_point_source_known_answer_on_a_block caught it)
+        for (int K = wave + 4 * (TPW - 1) + 1; K < ntile; K++) panel_end(K);
         double pq = 0.0;
 #pragma unroll
         for (int q = 0; q < TPW; q++) {

@@ -121,11 +121,12 @@ def test_iterative_against_cholesky_image_on_a_block():
         assert np.isfinite(m_).all() and (m_[..., lo:hi, lo:hi] >= 1e-32).all()
 
 
-def test_half_storage_kernel_opt_in_agrees_with_the_default():
-    """IMCOM_ITER_SYM=1: the blocked CG on the tiles on and below the diagonal only (csrc/iter_block.hip iter_block_cg_sym_kernel: every tile
-    used for q_I += T P_K and q_K += T^T P_I; half the bytes, a fixed order of sums).  Not the default (it is slower: issue-bound,
-    profiles/r06_negative_results.txt) -- kept correct: in a subprocess, one default-configuration stamp against the full-storage kernel
-    of this process: the same steps for nearly every pixel, T where they agree within 2e-3 of its largest entry."""
+def test_full_storage_kernel_agrees_with_the_half_storage_default():
+    """The blocked CG on the tiles on and below the diagonal only (csrc/iter_block.hip iter_block_cg_sym_kernel: every tile used for
+    q_I += T P_K and q_K += T^T P_I; half the bytes, a fixed order of sums) is the default for unions up to 768 rows; IMCOM_ITER_SYM=0 selects
+    the full-storage kernel (which also serves the larger unions).  In a subprocess, one default-configuration stamp through the
+    full-storage kernel against the default of this process: the same steps for nearly every pixel, T where they agree within 2e-3 of
+    its largest entry."""
     import os
     import subprocess
     import sys
@@ -143,11 +144,11 @@ def test_half_storage_kernel_opt_in_agrees_with_the_default():
             "psfs, target = synth.make_psfs(cfg, cfg.n_expo)\n"
             "b = StampBatch(cfg, [synth.make_stamp(cfg, 0)], PSFGroupTables(psfs, target, cfg.nfft, ctx=ctx), ctx=ctx); b.run(); torch.cuda.synchronize()\n"
             "st, steps = ctx.iter_stats(cfg.m)\n"
-            "assert st['half_storage'] and st['bytes'] < 0.52 * st['bytes_full_storage'], st\n"
-            "np.savez(sys.argv[1], T=b.result().T(0).cpu().numpy(), steps=steps)\nprint('sym ok')\n")
-    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"imcom_sym_{os.getpid()}.npz")
-    p = subprocess.run([sys.executable, "-c", code, out], cwd=root, env=dict(os.environ, PYTHONPATH=root, IMCOM_ITER_SYM="1"), capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "sym ok" in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
+            "assert not st['half_storage'] and st['bytes'] == st['bytes_full_storage'], st\n"
+            "np.savez(sys.argv[1], T=b.result().T(0).cpu().numpy(), steps=steps)\nprint('full ok')\n")
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"imcom_full_{os.getpid()}.npz")
+    p = subprocess.run([sys.executable, "-c", code, out], cwd=root, env=dict(os.environ, PYTHONPATH=root, IMCOM_ITER_SYM="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "full ok" in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
     z = np.load(out)
     os.remove(out)
     cfg = synth.CONFIGS["iter_default"]
@@ -157,19 +158,21 @@ def test_half_storage_kernel_opt_in_agrees_with_the_default():
     b.run()
     torch.cuda.synchronize()
     st, steps = ctx.iter_stats(cfg.m)
-    assert not st["half_storage"] and st["bytes"] == st["bytes_full_storage"]
+    assert st["half_storage"] and st["bytes"] < 0.52 * st["bytes_full_storage"]
     T = b.result().T(0).cpu().numpy()
     same = steps == z["steps"]
     d = np.abs(T - z["T"]).max(axis=1) / np.abs(T).max(axis=1)
     assert same.mean() > 0.95 and d[same].max() < 2e-3 and np.median(d) < 1e-6, (same.mean(), d[same].max(), np.median(d))
 
 
-@pytest.mark.parametrize("n_expo, blocked", [(8, True), (10, False)])
-def test_deeper_stacks_take_the_wide_kernel_or_the_per_pixel_one(n_expo, blocked):
+@pytest.mark.parametrize("n_expo, blocked, inpad", [(8, True, 0.6), (10, False, 0.6), (6, True, 0.61)])
+def test_deeper_stacks_take_the_wide_kernel_or_the_per_pixel_one(n_expo, blocked, inpad):
     """The default configuration at other exposure depths.  Eight exposures: ~750 input pixels per acceptance disc, a 4 x 4 patch's union
     ~950 rows -- the blocked solver's widest variant (up to 1024 rows).  Ten: the unions pass 1024 (1190) and the call falls back to the
-    per-pixel kernel (one workgroup per output pixel, lakernel.py:545-586 as written).  Both against the oracle on one stamp with
-    the parity statement of tests/parity.py iter_parity."""
+    per-pixel kernel (one workgroup per output pixel, lakernel.py:545-586 as written).  Six exposures with INPAD 0.61": unions of 740 rows
+    = 47 tiles -- the half-storage kernel where a wave's last tile row ends before the last column panel (4 x 12 - 3 = 45 < 47: the
+    panels beyond it are still ended by every wave).  All against the oracle on one stamp with the parity statement of
+    tests/parity.py iter_parity."""
     import dataclasses
 
     import torch
@@ -182,7 +185,7 @@ def test_deeper_stacks_take_the_wide_kernel_or_the_per_pixel_one(n_expo, blocked
 
     # (16 x 16 outputs instead of 32 x 32: the discs and unions are the same size -- they depend on rho and the depth -- and the oracle's 256
     # recurrences take a quarter of the time)
-    cfg = dataclasses.replace(synth.CONFIGS["iter_default"], n2=16, n_expo=n_expo, name=f"iter_default_e{n_expo}",
+    cfg = dataclasses.replace(synth.CONFIGS["iter_default"], n2=16, n_expo=n_expo, inpad_as=inpad, name=f"iter_default_e{n_expo}",
                               iter_max=30 if blocked else 8)  # (the per-pixel fallback: eight steps are enough to test it, and the oracle's 1400-row recurrences are slow)
     ctx = default_context(0)
     st = synth.make_stamp(cfg, 0)
@@ -191,7 +194,10 @@ def test_deeper_stacks_take_the_wide_kernel_or_the_per_pixel_one(n_expo, blocked
     b.run()
     torch.cuda.synchronize()
     stats, gsteps = ctx.iter_stats(cfg.m)
-    assert stats["blocked"] == blocked and (768 < stats["max_union"] <= 1024 if blocked else stats["max_union"] > 1024), stats
+    if inpad > 0.6:
+        assert stats["blocked"] and stats["half_storage"] and 720 < stats["max_union"] <= 768, stats
+    else:
+        assert stats["blocked"] == blocked and not stats["half_storage"] and (768 < stats["max_union"] <= 1024 if blocked else stats["max_union"] > 1024), stats
     res = b.result()
     g, tabs_ref, C, tab, pen, io = _oracle_inputs(cfg, psfs, target)
     A, Bt = orc.stamp_system(g, st.x, st.y, st.expo, tabs_ref, tab, pen, io, st.out_x0, st.out_y0, cfg.n2f)
