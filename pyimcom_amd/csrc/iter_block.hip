@@ -365,15 +365,17 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_kernel(const double *__r
 template <class F, int... Q>
 __device__ __forceinline__ void bcg_for_each(F &&f, std::integer_sequence<int, Q...>) { (f(std::integral_constant<int, Q>{}), ...); }
 
-template <int TPW, bool RG>
-__global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double *__restrict__ AU, const double *__restrict__ BU,
+// NW: waves per workgroup, 4 or 8.  Eight (two per SIMD: 256 registers each, half the tile rows per wave) let the hardware issue one wave's
+// MFMAs under the other's waits.
+template <int TPW, bool RG, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void iter_block_cg_sym_kernel(const double *__restrict__ AU, const double *__restrict__ BU,
                                                                    const int *__restrict__ usel, const unsigned short *__restrict__ umask,
                                                                    const int *__restrict__ nu, int m, int W, int H, int nblocks, long blk0,
-                                                                   int ups, long au_stride, int ring, double rtol, int maxiter,
+                                                                   int ups, long au_stride, int ring, int ntw, double rtol, int maxiter,
                                                                    float *__restrict__ T, long ldt, double *__restrict__ XW,
                                                                    int *__restrict__ steps, unsigned long long *__restrict__ stats)
 {
-    extern __shared__ double lds[];  // P [ups][16], red [4][16], ring [2][ring][4][256], Tw [4][2][16][18]
+    extern __shared__ double lds[];  // P [ups][16], red [NW][16], ring [2][ring][NW][256], Tw [NW][ntw][16][18]
     const long blk = blk0 + blockIdx.x;
     const int s = (int)(blk / nblocks), b = (int)(blk - (long)s * nblocks);
     const int nsel = nu[blk];
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         return;
     }
     const int up = (nsel + 15) / 16 * 16, ntile = up / 16;
-    double *P = lds, *red = lds + (long)ups * BCG_R, *Rg = red + 4 * BCG_R, *Tw = Rg + (long)2 * ring * 4 * 256;  // (Tw: 4 waves x 2 x [16][18])
+    double *P = lds, *red = lds + (long)ups * BCG_R, *Rg = red + NW * BCG_R, *Tw = Rg + (long)2 * ring * NW * 256;
     const double *AUb = AU + (long)blockIdx.x * au_stride, *BUb = BU + (long)blockIdx.x * ups * BCG_R;
     double *Xb = XW + (long)blockIdx.x * 2 * ups * BCG_R, *Rb = Xb + (long)ups * BCG_R;  // iterate x; residual r (RG)
     const unsigned short *mk = umask + blk * BCG_UMAX;
@@ -397,7 +399,9 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         __syncthreads();
         if (lk == 0) red[wave * BCG_R + li] = v;
         __syncthreads();
-        return (red[li] + red[BCG_R + li]) + (red[2 * BCG_R + li] + red[3 * BCG_R + li]);
+        double t = (red[li] + red[BCG_R + li]) + (red[2 * BCG_R + li] + red[3 * BCG_R + li]);
+        if (NW == 8) t += (red[4 * BCG_R + li] + red[5 * BCG_R + li]) + (red[6 * BCG_R + li] + red[7 * BCG_R + li]);
+        return t;
     };
 
     double r[RG ? 1 : TPW][4];
@@ -405,16 +409,16 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
     double bb = 0.0;
 #pragma unroll
     for (int q = 0; q < TPW; q++) {
-        const int tt = wave + 4 * q;
+        const int tt = wave + NW * q;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int j = 16 * tt + lk + 4 * e;
             const bool in = tt < ntile;
             if (in && (mk[j] >> li & 1)) own |= 1ull << (4 * q + e);
             const double rv = in ? BUb[(long)j * BCG_R + li] : 0.0;
-            if (RG) { if (in) Rb[own0 + (64 * q + 4 * e) * BCG_R] = rv; }
+            if (RG) { if (in) Rb[own0 + (16 * NW * q + 4 * e) * BCG_R] = rv; }
             else r[q][e] = rv;
-            if (in) Xb[own0 + (64 * q + 4 * e) * BCG_R] = 0.0;
+            if (in) Xb[own0 + (16 * NW * q + 4 * e) * BCG_R] = 0.0;
             bb += rv * rv;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         if (RG) __threadfence();  // (this lane's atomic adds to r of the step before have reached L2: the loads below bypass L1)
         auto rget = [&](int q, int e, int base) -> double {
             if (!RG) return r[RG ? 0 : q][e];
-            return (wave + 4 * q < ntile) ? __hip_atomic_load(Rb + base + (64 * q + 4 * e) * BCG_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            return (wave + NW * q < ntile) ? __hip_atomic_load(Rb + base + (16 * NW * q + 4 * e) * BCG_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         };
         double rr = 0.0;
 #pragma unroll
@@ -446,21 +450,21 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         const double beta = (it > 0 && act) ? rho_cur / rho_prev : 0.0;
 #pragma unroll
         for (int q = 0; q < TPW; q++) {
-            if (wave + 4 * q < ntile)
+            if (wave + NW * q < ntile)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    double *pp = P + ob + (64 * q + 4 * e) * BCG_R;
+                    double *pp = P + ob + (16 * NW * q + 4 * e) * BCG_R;
                     const double pold = it > 0 ? *pp : 0.0;
                     *pp = act ? pold * beta + rget(q, e, ob) : 0.0;
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        // ---- q = AU P from the lower tiles.  Column panels K = 0 .. ntile - 1 in order; this wave's tile rows I = wave + 4 q in an unrolled
+        // ---- q = AU P from the lower tiles.  Column panels K = 0 .. ntile - 1 in order; this wave's tile rows I = wave + NW q in an unrolled
         // loop (q is a compile-time index: the accumulators are plain registers).  Every tile row keeps its own fetch slot across the
         // panels: right after tile (I, K) has been used its slot is refilled with tile (I, K + 1) -- one panel ahead, behind the MFMAs of
         // the wave's other rows.  The panels are grouped in PHASES by the first row that still has a tile in them (qmin: it moves up one row
-        // every four panels), so that inside a phase the rows above qmin run as straight-line code -- no test per tile, the scheduler
+        // every NW panels), so that inside a phase the rows above qmin run as straight-line code -- no test per tile, the scheduler
         // overlaps one row's LDS round trips with another's MFMAs; only row qmin (whose last tile of the phase is the diagonal one) tests.
         // Rows beyond the patch (the last row of three of the four waves) multiply an all-zero tile.
         f64x4 accv[TPW];
@@ -469,10 +473,10 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         f64x2 sn[TPW][2];
         const double *lane_n = AUb + li * 16 + 4 * lk;  // this lane's four elements of a tile: row li, columns 4 lk ..
         const long ztile = ((long)ntile * (ntile + 1) / 2) * 256;  // the all-zero tile behind the packed ones (iter_block_gather_kernel<true>)
-        double *tw = Tw + wave * (2 * 16 * 18);                    // this wave's two transposition tiles in LDS ([16][18] each)
+        double *tw = Tw + wave * (ntw * 16 * 18);                  // this wave's ntw (1 or 2) transposition tiles in LDS ([16][18] each)
 #pragma unroll
         for (int q = 0; q < TPW; q++) {  // panel 0: tile (I, 0) at tile index I
-            const int I = wave + 4 * q;
+            const int I = wave + NW * q;
             const long t = I < ntile ? (long)I * 256 : ztile;
             sn[q][0] = *(const f64x2 *)(lane_n + t);
             sn[q][1] = *(const f64x2 *)(lane_n + t + 2);
@@ -483,23 +487,26 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
             // panel K is complete for this wave: its transposed sums go to the ring; after every `ring` panels (and after the last) the
             // owners of those tile rows add the four waves' pieces, in wave order
             const int slot = ((K / ring) & 1) * ring + K % ring;
-            double *dst = Rg + ((long)slot * 4 + wave) * 256 + lane;
+            double *dst = Rg + ((long)slot * NW + wave) * 256 + lane;
 #pragma unroll
             for (int e = 0; e < 4; e++) dst[64 * e] = part[e];
             part = f64x4{0.0, 0.0, 0.0, 0.0};
             if ((K + 1) % ring == 0 || K == ntile - 1) {
                 __syncthreads();
                 for (int Kg = K / ring * ring; Kg <= K; Kg++) {
-                    if ((Kg & 3) != wave) continue;
-                    const double *src = Rg + ((long)(((Kg / ring) & 1) * ring + Kg % ring) * 4) * 256 + lane;
+                    if (Kg % NW != wave) continue;
+                    const double *src = Rg + ((long)(((Kg / ring) & 1) * ring + Kg % ring) * NW) * 256 + lane;
                     f64x4 add;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) add[e] = (src[64 * e] + src[256 + 64 * e]) + (src[512 + 64 * e] + src[768 + 64 * e]);
+                    for (int e = 0; e < 4; e++) {
+                        add[e] = (src[64 * e] + src[256 + 64 * e]) + (src[512 + 64 * e] + src[768 + 64 * e]);
+                        if (NW == 8) add[e] += (src[1024 + 64 * e] + src[1280 + 64 * e]) + (src[1536 + 64 * e] + src[1792 + 64 * e]);
+                    }
                     // (every row updated, by the piece times one or zero: written as "if (q == Kg / 4) accv[q] += add" the compiler turns
                     // the unrolled tests into ONE dynamically indexed access and moves the whole accumulator array to scratch memory)
 #pragma unroll
                     for (int q = 0; q < TPW; q++) {
-                        const double w1 = q == (Kg >> 2) ? 1.0 : 0.0;
+                        const double w1 = q == Kg / NW ? 1.0 : 0.0;
 #pragma unroll
                         for (int e = 0; e < 4; e++) accv[q][e] = fma(add[e], w1, accv[q][e]);
                     }
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         };
         auto phase = [&](auto qm) __attribute__((always_inline)) {
             constexpr int qmin = decltype(qm)::value;
-            const int Kbeg = qmin == 0 ? 0 : wave + 4 * (qmin - 1) + 1, Kend = min(wave + 4 * qmin, ntile - 1);  // the panels of this phase
+            const int Kbeg = qmin == 0 ? 0 : wave + NW * (qmin - 1) + 1, Kend = min(wave + NW * qmin, ntile - 1);  // the panels of this phase
             for (int K = Kbeg; K <= Kend; K++) {
                 double bK[4];
 #pragma unroll
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
                 const bool last = K + 1 >= ntile;
 #pragma unroll
                 for (int q = qmin; q < TPW; q++) {
-                    const int I = wave + 4 * q;
+                    const int I = wave + NW * q;
                     const bool rowok = I < ntile, below = I > K;  // (q > qmin: always below the diagonal when the row exists)
                     const f64x2 t0 = sn[q][0], t1 = sn[q][1];
                     f64x4 an = accv[q];
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
                     accv[q] = an;
                     if (q > qmin || below) {
                         // the transposed operand through one of the wave's two LDS tiles: element (li, 4 lk + c) in, (4 lk + kk, li) out
-                        double *tq = tw + (q & 1) * (16 * 18);
+                        double *tq = tw + (q & (ntw - 1)) * (16 * 18);
                         *(f64x2 *)(tq + li * 18 + 4 * lk) = t0;
                         *(f64x2 *)(tq + li * 18 + 4 * lk + 2) = t1;
                         // the slot again: tile (I, K + 1), tile index cs1 + (I - K - 1); the zero tile for a row beyond the patch / after the last panel
@@ -550,14 +557,14 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
         // panels beyond this wave's last row (ntile > wave + 4 TPW - 3): nothing to multiply, but every wave ends EVERY panel -- its (zero)
         // piece of the ring and the barriers (the first build lacked this: right at ntile = 45 = 4 x 12 - 3, wrong from 46 and for the
         // eight-row variant from 30; tests/test_gpu_iter_default.py::test_point_source_known_answer_on_a_block caught it)
-        for (int K = wave + 4 * (TPW - 1) + 1; K < ntile; K++) panel_end(K);
+        for (int K = wave + NW * (TPW - 1) + 1; K < ntile; K++) panel_end(K);
         double pq = 0.0;
 #pragma unroll
         for (int q = 0; q < TPW; q++) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 accv[q][e] = (own >> (4 * q + e) & 1) ? accv[q][e] : 0.0;
-                if (wave + 4 * q < ntile) pq += P[ob + (64 * q + 4 * e) * BCG_R] * accv[q][e];
+                if (wave + NW * q < ntile) pq += P[ob + (16 * NW * q + 4 * e) * BCG_R] * accv[q][e];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -566,10 +573,10 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
             const double alpha = rho_cur / pqs;
 #pragma unroll
             for (int q = 0; q < TPW; q++) {
-                if (wave + 4 * q < ntile)
+                if (wave + NW * q < ntile)
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        const int o = ob + (64 * q + 4 * e) * BCG_R;
+                        const int o = ob + (16 * NW * q + 4 * e) * BCG_R;
                         unsafeAtomicAdd(Xb + o, alpha * P[o]);
                         if (RG) unsafeAtomicAdd(Rb + o, -alpha * accv[q][e]);
                         else r[RG ? 0 : q][e] -= alpha * accv[q][e];
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(256, 1) void iter_block_cg_sym_kernel(const double 
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 if (own >> (4 * q + e) & 1)
-                    Trow[us[16 * (wave + 4 * q) + lk + 4 * e]] = (float)__hip_atomic_load(Xb + own0 + (64 * q + 4 * e) * BCG_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    Trow[us[16 * (wave + NW * q) + lk + 4 * e]] = (float)__hip_atomic_load(Xb + own0 + (16 * NW * q + 4 * e) * BCG_R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (steps && wave == 0 && lk == 0) steps[(long)s * m + a] = used;
@@ -648,19 +655,25 @@ int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, c
     // profiles/r06_negative_results.txt item 1.
     static const bool sym_off = getenv("IMCOM_ITER_SYM") && strcmp(getenv("IMCOM_ITER_SYM"), "0") == 0;
     const size_t lds_p = ((size_t)ups * BCG_R + 4 * BCG_R) * 8, lds_max = 160 * 1024;
-    const size_t lds_tw = 4 * 2 * 16 * 18 * 8;  // the half-storage kernel's transposition tiles
-    const int ring = lds_p + lds_tw + 2 * 4 * 2048 <= lds_max ? (int)std::min<size_t>(8, (lds_max - lds_p - lds_tw) / (2 * 4 * 2048)) : 0;
-    const bool sym = !sym_off && ring >= 2 && ntile <= 48;
+    // the half-storage kernel: NW waves (IMCOM_ITER_WAVES=4|8), their transposition tiles and ring pieces
+    static const int NWs = getenv("IMCOM_ITER_WAVES") && atoi(getenv("IMCOM_ITER_WAVES")) == 4 ? 4 : 8;
+    const size_t lds_ps = ((size_t)ups * BCG_R + NWs * BCG_R) * 8;
+    int ntw = 2;  // transposition tiles per wave: two (consecutive rows of a wave overlap) where they fit beside P and one ring unit, else one
+    if (lds_ps + (size_t)NWs * ntw * 16 * 18 * 8 + 2 * NWs * 2048 > lds_max) ntw = 1;
+    const size_t lds_tw = (size_t)NWs * ntw * 16 * 18 * 8;
+    const int ring = lds_ps + lds_tw + 2 * NWs * 2048 <= lds_max ? (int)std::min<size_t>(8, (lds_max - lds_ps - lds_tw) / (2 * NWs * 2048)) : 0;
+    const bool sym = !sym_off && ring >= 1 && ntile <= 48;
     if (sym_used) *sym_used = sym ? 1 : 0;
     const long au_stride = sym ? ((long)ntile * (ntile + 1) / 2 + 1) * 256 : (long)ups * ups;  // (half storage: + the all-zero tile)
     const size_t per = (size_t)au_stride * 8 + (sym ? 3 : 2) * (size_t)ups * BCG_R * 8;  // sub-matrix, right-hand sides, x (+ r: half-storage kernel)
     const size_t group = std::max<size_t>(1, std::min<size_t>(nb, budget / per));
     IMCOM_REQUIRE(per <= budget, "iterative kernel: a patch's sub-matrix (%zu bytes) exceeds the workspace share of %zu", per, budget);
     double *AU = (double *)w, *BU = AU + group * (size_t)au_stride, *XW = BU + group * (size_t)ups * BCG_R;  // (XW: [group][2][ups][16] for the half-storage kernel)
-    const size_t lds = sym ? lds_p + (size_t)2 * ring * 4 * 2048 + lds_tw : lds_p;
+    const size_t lds = sym ? lds_ps + (size_t)2 * ring * NWs * 2048 + lds_tw : lds_p;
     const int tpw = (ntile + 3) / 4;
     auto cg = tpw <= 8 ? iter_block_cg_kernel<8> : tpw <= 12 ? iter_block_cg_kernel<12> : iter_block_cg_kernel<16>;
-    auto cgs = tpw <= 8 ? iter_block_cg_sym_kernel<8, false> : iter_block_cg_sym_kernel<12, true>;
+    auto cgs = NWs == 4 ? (tpw <= 8 ? iter_block_cg_sym_kernel<8, false, 4> : iter_block_cg_sym_kernel<12, true, 4>)
+                        : (ntile <= 32 ? iter_block_cg_sym_kernel<4, false, 8> : iter_block_cg_sym_kernel<6, false, 8>);
     if (sym) IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cgs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     else IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (size_t b0 = 0; b0 < nb; b0 += group) {
@@ -677,8 +690,8 @@ int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, c
         }
         ProfScope ps(ctx, "iter_cg");
         if (sym)
-            hipLaunchKernelGGL(cgs, dim3(g), dim3(256), lds, ctx->stream, (const double *)AU, (const double *)BU, (const int *)usel, (const unsigned short *)umask,
-                               (const int *)nu, m, W, H, nblocks, (long)b0, ups, au_stride, ring, rtol, maxiter, T, ldt, XW, steps, stats);
+            hipLaunchKernelGGL(cgs, dim3(g), dim3(64 * NWs), lds, ctx->stream, (const double *)AU, (const double *)BU, (const int *)usel, (const unsigned short *)umask,
+                               (const int *)nu, m, W, H, nblocks, (long)b0, ups, au_stride, ring, ntw, rtol, maxiter, T, ldt, XW, steps, stats);
         else
             hipLaunchKernelGGL(cg, dim3(g), dim3(256), lds, ctx->stream, (const double *)AU, (const double *)BU, (const int *)usel, (const unsigned short *)umask,
                                (const int *)nu, m, W, H, nblocks, (long)b0, ups, rtol, maxiter, T, ldt, XW, steps, stats);
