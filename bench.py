@@ -901,6 +901,7 @@ def iter_default_leg(ctx, dev, batch=128, steps=2, cpu_budget=20.0, block_n1P=16
         d = (img_it - img_ch)[lo:hi, lo:hi]
         return {"n1P": n1P, "stamps_per_block": n1P * n1P, "value": n1P * n1P / dtb, "unit": "postage-stamps/s", "ms_per_stamp": dtb * 1e3 / (n1P * n1P), "ms_per_block": dtb * 1e3,
                 "passes": passes, "stage_ms": {k: v for k, v in st.items() if v > 0}, "cholesky_block_ms": dtc * 1e3,
+                "seconds_per_production_block": 84 * 84 * dtb / (n1P * n1P),  # OUTSIZE [80, 32, .] with PAD 2: 84 x 84 stamps, at this block's rate
                 "image_rms_vs_cholesky": float(d.std()), "image_mean_vs_cholesky": float(d.mean()), "image_std": float(img_ch[lo:hi, lo:hi].std()),
                 "image_peak": float(np.abs(img_ch).max()), "criterion": "std < 2.5e-3 and |mean| < 2e-4 (tests/pyimcom/test_pyimcom.py:971-978)",
                 "what": "a block of n1P^2 stamps through coadd_block (ONE PSF group; selection, A, B, CG, coaddition, block maps), then the same block "
@@ -1002,6 +1003,7 @@ def summary_of(out):
                     sm["iter_default"]["bound"] = it_["roofline"].get("bound")
                 if isinstance(it_.get("block"), dict):
                     sm["iter_default"]["block_v"] = {"error": it_["block"]["error"][:60]} if "error" in it_["block"] else r3(it_["block"].get("value"))
+                    sm["iter_default"]["s_per_block"] = r3(it_["block"].get("seconds_per_production_block"))
                 if isinstance(it_.get("cpu_baseline"), dict) and "value" in it_["cpu_baseline"]:
                     sm["iter_default"]["cpu"] = r3(it_["cpu_baseline"]["value"])
     if "farm" in out:
