@@ -847,7 +847,7 @@ def iter_default_leg(ctx, dev, batch=128, steps=2, cpu_budget=20.0, block_n1P=16
                         "mfma_TFLOPs": its["flops"] / cg_s / 1e12 if cg_s else None, "mfma_frac": its["flops"] / cg_s / 1e12 / FP64_MFMA_PEAK_TFLOPS if cg_s else None,
                         "half_storage": bool(its.get("half_storage")),
                         "count": "per patch and CG step: the 16 x 16 tiles on and below the diagonal of the union's sub-matrix = (nt (nt + 1) / 2) x 2 KB (nt = union "
-                                 "/ 16 rounded up; the full-storage kernel of unions above 768 rows reads both triangles: 8 up^2), 32 up^2 flops",
+                                 "/ 16 rounded up; the full-storage kernel of unions above 864 rows reads both triangles: 8 up^2), 32 up^2 flops",
                         "traffic": tr_cg, "traffic_source": tr_src}}
     job = its["flops"] + float((165.0 * n * (n + 1) + 220.0 * n * cfg.m).sum())
     out["job_roofline_frac"] = job / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS

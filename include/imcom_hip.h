@@ -205,7 +205,7 @@ int imcom_solve_iter(imcom_ctx *ctx, int batch, const int *n, int ldn, int m, co
  * patches of (union size rounded up to 16)^2 x steps the patch ran (x 2 x 16 = its flops, x 8 = the bytes of sub-matrix it
  * streamed by the full-storage kernel), [2] sum of steps, [3] sum of (union size)^2, [4] largest union of a patch, [5] 1 = blocked
  * solver, 0 = the per-pixel kernel (a union above 1024), [6] bytes of sub-matrix the patches streamed over their steps, [7] 1 = the
- * half-storage kernel (unions up to 768: only the tiles on and below the diagonal are stored and read).  steps (host, optional): CG steps used per output pixel
+ * half-storage kernel (unions up to 864: only the tiles on and below the diagonal are stored and read).  steps (host, optional): CG steps used per output pixel
  * [batch][m], nsteps = batch * m of that call. */
 int imcom_solve_iter_stats(imcom_ctx *ctx, double *stats, int *steps, long nsteps);
 /* imcom_solve_empir: T_ai = max(rho_acc - dist_ai, 0) / sum_i max(rho_acc - dist_ai, 0) (a pixel with no input

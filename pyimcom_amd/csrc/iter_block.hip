@@ -649,7 +649,7 @@ int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, c
         return IMCOM_OK;
     }
     const int ups = (mx + 15) / 16 * 16, ntile = ups / 16;
-    // The half-storage kernel where its LDS ring fits beside P (unions up to 768 rows), the full-storage one beyond; IMCOM_ITER_SYM=0: the
+    // The half-storage kernel where its LDS ring fits beside P (unions up to 864 rows with eight waves), the full-storage one beyond; IMCOM_ITER_SYM=0: the
     // full-storage kernel always (tests/test_gpu_iter_default.py runs both).  The first half-storage kernel (a flat tile list, accumulators
     // through a switch) was slower than the full one; the second (phases, rows unrolled, transposition through LDS) is faster:
     // profiles/r06_negative_results.txt item 1.
@@ -662,7 +662,7 @@ int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, c
     if (lds_ps + (size_t)NWs * ntw * 16 * 18 * 8 + 2 * NWs * 2048 > lds_max) ntw = 1;
     const size_t lds_tw = (size_t)NWs * ntw * 16 * 18 * 8;
     const int ring = lds_ps + lds_tw + 2 * NWs * 2048 <= lds_max ? (int)std::min<size_t>(8, (lds_max - lds_ps - lds_tw) / (2 * NWs * 2048)) : 0;
-    const bool sym = !sym_off && ring >= 1 && ntile <= 48;
+    const bool sym = !sym_off && ring >= 1 && ntile <= (NWs == 8 ? 56 : 48);  // (rows per wave: 7 x 8 or 12 x 4; the LDS beside P decides first: 864 rows)
     if (sym_used) *sym_used = sym ? 1 : 0;
     const long au_stride = sym ? ((long)ntile * (ntile + 1) / 2 + 1) * 256 : (long)ups * ups;  // (half storage: + the all-zero tile)
     const size_t per = (size_t)au_stride * 8 + (sym ? 3 : 2) * (size_t)ups * BCG_R * 8;  // sub-matrix, right-hand sides, x (+ r: half-storage kernel)
@@ -673,7 +673,7 @@ int launch_iter_block(imcom_ctx *ctx, const double *A, long lda, long strideA, c
     const int tpw = (ntile + 3) / 4;
     auto cg = tpw <= 8 ? iter_block_cg_kernel<8> : tpw <= 12 ? iter_block_cg_kernel<12> : iter_block_cg_kernel<16>;
     auto cgs = NWs == 4 ? (tpw <= 8 ? iter_block_cg_sym_kernel<8, false, 4> : iter_block_cg_sym_kernel<12, true, 4>)
-                        : (ntile <= 32 ? iter_block_cg_sym_kernel<4, false, 8> : iter_block_cg_sym_kernel<6, false, 8>);
+                        : (ntile <= 32 ? iter_block_cg_sym_kernel<4, false, 8> : ntile <= 48 ? iter_block_cg_sym_kernel<6, false, 8> : iter_block_cg_sym_kernel<7, true, 8>);
     if (sym) IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cgs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     else IMCOM_HIP_CHECK(hipFuncSetAttribute((const void *)cg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (size_t b0 = 0; b0 < nb; b0 += group) {

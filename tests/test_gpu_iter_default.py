@@ -165,10 +165,10 @@ def test_full_storage_kernel_agrees_with_the_half_storage_default():
     assert same.mean() > 0.95 and d[same].max() < 2e-3 and np.median(d) < 1e-6, (same.mean(), d[same].max(), np.median(d))
 
 
-@pytest.mark.parametrize("n_expo, blocked, inpad", [(8, True, 0.6), (10, False, 0.6), (6, True, 0.61)])
+@pytest.mark.parametrize("n_expo, blocked, inpad", [(8, True, 0.6), (10, False, 0.6), (6, True, 0.61), (7, True, 0.6)])
 def test_deeper_stacks_take_the_wide_kernel_or_the_per_pixel_one(n_expo, blocked, inpad):
     """The default configuration at other exposure depths.  Eight exposures: ~750 input pixels per acceptance disc, a 4 x 4 patch's union
-    ~950 rows -- the blocked solver's widest variant (up to 1024 rows).  Ten: the unions pass 1024 (1190) and the call falls back to the
+    ~950 rows -- the full-storage solver's widest variant (up to 1024 rows).  Seven: 828 rows, the half-storage kernel's largest.  Ten: the unions pass 1024 (1190) and the call falls back to the
     per-pixel kernel (one workgroup per output pixel, lakernel.py:545-586 as written).  Six exposures with INPAD 0.61": unions of 740 rows
     = 47 tiles -- the half-storage kernel where a wave's last tile row ends before the last column panel (4 x 12 - 3 = 45 < 47: the
     panels beyond it are still ended by every wave).  All against the oracle on one stamp with the parity statement of
@@ -196,8 +196,10 @@ def test_deeper_stacks_take_the_wide_kernel_or_the_per_pixel_one(n_expo, blocked
     stats, gsteps = ctx.iter_stats(cfg.m)
     if inpad > 0.6:
         assert stats["blocked"] and stats["half_storage"] and 720 < stats["max_union"] <= 768, stats
+    elif n_expo == 7:  # 828 rows = 52 tiles: the half-storage kernel's seven-rows-per-wave variant (its LDS limit: 864 rows)
+        assert stats["blocked"] and stats["half_storage"] and 768 < stats["max_union"] <= 864, stats
     else:
-        assert stats["blocked"] == blocked and not stats["half_storage"] and (768 < stats["max_union"] <= 1024 if blocked else stats["max_union"] > 1024), stats
+        assert stats["blocked"] == blocked and not stats["half_storage"] and (864 < stats["max_union"] <= 1024 if blocked else stats["max_union"] > 1024), stats
     res = b.result()
     g, tabs_ref, C, tab, pen, io = _oracle_inputs(cfg, psfs, target)
     A, Bt = orc.stamp_system(g, st.x, st.y, st.expo, tabs_ref, tab, pen, io, st.out_x0, st.out_y0, cfg.n2f)
