@@ -237,11 +237,16 @@ static int lambda_min_group(imcom_ctx *ctx, const double *A, const int *n_host, 
 static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, const int *n_dev, int Np, const double *A, const std::vector<int> &idx,
                                const std::vector<double> &inc_failed, double hint, const std::vector<char> &may_decide, std::vector<char> &decided,
                                const std::function<int(const std::vector<double> &, const std::vector<char> &, std::vector<int> &)> &factor,
-                               const std::function<int(const std::vector<char> &, const double *, double *, double *, double *, int)> &solve,
+                               const std::function<int(const std::vector<char> &, const double *, double *, double *, double *, int, int)> &solve,
                                std::vector<double> &w0, std::vector<char> &ok)
 {
     const size_t mark = ctx->ws_used;
-    const int P = LMIN_P;
+    // Blocks of 16 vectors instead of 128 for a pass of many stamps (lmin_skinny.hip): with a shift a few per cent above |lambda_min|
+    // the block's width hardly matters for the convergence (7-9 steps against 5-7 on a production stamp), and a 16-column sweep is
+    // one pass over the factor at HBM speed instead of a 128-column product on the matrix pipe.  IMCOM_LMIN_SKINNY=0: never, =1: always.
+    const char *sk_env = getenv("IMCOM_LMIN_SKINNY");  // (read per call: tests/test_gpu_stamps.py runs the same batch both ways)
+    const bool skinny = sk_env ? atoi(sk_env) != 0 : idx.size() >= 16;
+    const int P = skinny ? LMIN_SKINNY_P : LMIN_P;
     const size_t blk = (size_t)batch * Np * P * 8, sq = (size_t)batch * P * P * 8;
     double *X = (double *)ws_take(ctx, blk), *Y = (double *)ws_take(ctx, blk), *Z = (double *)ws_take(ctx, blk);
     double *G = (double *)ws_take(ctx, sq), *Gi = (double *)ws_take(ctx, sq), *H = (double *)ws_take(ctx, sq), *Qh = (double *)ws_take(ctx, sq);
@@ -250,7 +255,8 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     double *part = (double *)ws_take(ctx, (size_t)batch * 8 * NB * NB * 8);
     double *dmax_d = (double *)ws_take(ctx, (size_t)batch * 8);
     int *want_d = (int *)ws_take(ctx, (size_t)batch * 4), *ones_d = (int *)ws_take(ctx, (size_t)batch * 4), *gfail_d = (int *)ws_take(ctx, (size_t)batch * 4);
-    if (!X || !Y || !Z || !G || !Gi || !H || !Qh || !lam || !rpart || !part || !dmax_d || !want_d || !ones_d || !gfail_d) { set_error("internal: workspace (smallest eigenvalue)"); return IMCOM_ERR_NOMEM; }
+    int *nbrun_d = (int *)ws_take(ctx, (size_t)batch * 4);  // 128-blocks of the stamps a round runs (0: not in it), for the 16-vector kernels
+    if (!X || !Y || !Z || !G || !Gi || !H || !Qh || !lam || !rpart || !part || !dmax_d || !want_d || !ones_d || !gfail_d || !nbrun_d) { set_error("internal: workspace (smallest eigenvalue)"); return IMCOM_ERR_NOMEM; }
     const size_t mark_eig = ctx->ws_used;
     hipStream_t st = ctx->stream;
     std::vector<char> want(batch, 0);
@@ -319,6 +325,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     auto orth = [&]() -> int {  // X <- orth(Y): CholQR twice (X = Y R^-1 with R^T R = Y^T Y; the second pass takes the loss of the first back)
         for (int pass = 0; pass < 2; pass++) {
             double *src = pass == 0 ? Y : X, *dst = pass == 0 ? X : Y;
+            if (skinny) { IMCOM_TRY(launch_skinny_orth(ctx, src, dst, Np, nbrun_d, gfail_d, batch)); continue; }
             IMCOM_TRY(gemm(true, true, P, P, Np, src, P, sX, src, P, sX, G, P, sG));
             IMCOM_TRY(launch_gram_guard(ctx, G, P, want_d, batch));
             IMCOM_TRY(launch_chol_diag(ctx, G, Gi, P, 0, batch, ones_d, gfail_d));
@@ -342,7 +349,11 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     // ends either phase when the residuals cannot (theta1 inside a cluster closer than its residual).
     static const int coarse_steps = getenv("IMCOM_LMIN_COARSE") ? std::max(1, atoi(getenv("IMCOM_LMIN_COARSE"))) : 6;
     static const int lmin_parts = getenv("IMCOM_LMIN_PARTS") ? std::min(8, std::max(1, atoi(getenv("IMCOM_LMIN_PARTS")))) : 0;  // (A/B: split-K parts of the 128-column solves)
-    static const int hinted_steps = getenv("IMCOM_LMIN_HINTED") ? std::max(1, atoi(getenv("IMCOM_LMIN_HINTED"))) : 7;  // (34 x (7.6e-3)^7: see the hint above)
+    static const int hinted_steps_env = getenv("IMCOM_LMIN_HINTED") ? std::max(1, atoi(getenv("IMCOM_LMIN_HINTED"))) : 0;  // (34 x (7.6e-3)^7: see the hint above)
+    const int hinted_steps = hinted_steps_env ? hinted_steps_env : (skinny ? 10 : 7);
+    // how far the spectrum the block has NOT captured lies above lambda_min, in units of |lambda_min| (production stamps: lambda_129 is 0.85,
+    // lambda_17 0.4 of the way to zero): the step counts below are planned with it
+    const double bulk = skinny ? 0.4 : 1.0;
     static const int round_steps = getenv("IMCOM_LMIN_FINE") ? std::max(1, atoi(getenv("IMCOM_LMIN_FINE"))) : 3;
     static const bool by_change = getenv("IMCOM_LMIN_BOUND") && strcmp(getenv("IMCOM_LMIN_BOUND"), "change") == 0;  // (A/B: the first version's criteria alone)
     const int max_rounds = 14;
@@ -357,17 +368,28 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
         int iters = round == 0 ? (any_hinted ? hinted_steps : coarse_steps) : round_steps;
         for (int s : idx) if (run[s]) iters = std::max(iters, steps_wanted[s]);  // (a stamp's first round at its closer shift: see below)
         std::fill(steps_wanted.begin(), steps_wanted.end(), 0);
+        int nbrun_max = 0;
+        if (skinny) {
+            std::vector<int> nbr(batch, 0);
+            for (int s : idx) if (run[s]) { nbr[s] = (n_host[s] + NB - 1) / NB; nbrun_max = std::max(nbrun_max, nbr[s]); }
+            IMCOM_TRY(upload(ctx, nbrun_d, nbr.data(), (size_t)batch));
+        }
         for (int it = 0; it < iters; it++) {
-            IMCOM_TRY(solve(run, X, Y, Z, part, lmin_parts > 0 ? lmin_parts : splitk_parts(batch, 1)));  // (Z: scratch here, the Rayleigh-Ritz step below fills it anew)
+            IMCOM_TRY(solve(run, X, Y, Z, part, lmin_parts > 0 ? lmin_parts : splitk_parts(batch, 1), P));  // (Z: scratch here, the Rayleigh-Ritz step below fills it anew)
             IMCOM_TRY(orth());
         }
         // Z = A X, H = X^T Z, its eigenvalues and eigenvectors, the residuals of the two lowest pairs
-        IMCOM_TRY(gemm(false, true, Np, P, Np, A, Np, (long)Np * Np, X, P, sX, Z, P, sX));
-        IMCOM_TRY(gemm(true, true, P, P, Np, X, P, sX, Z, P, sX, H, P, sG));
-        ctx->ws_used = mark_eig;
-        IMCOM_TRY(eigh_device(ctx, batch, nP.data(), P, H, P, sG, lam, P, Qh, P, sG, nullptr));
-        ctx->ws_used = mark_eig;
-        IMCOM_TRY(launch_ritz_residual(ctx, X, Z, Qh, lam, Np, P, n_dev, want_d, rpart, batch));
+        if (skinny) {
+            IMCOM_TRY(launch_skinny_ax(ctx, A, X, Z, Np, nbrun_d, nbrun_max, batch));
+            IMCOM_TRY(launch_skinny_rr(ctx, X, Z, Np, nbrun_d, lam, rpart, LMIN_RESID_GROUPS, batch));
+        } else {
+            IMCOM_TRY(gemm(false, true, Np, P, Np, A, Np, (long)Np * Np, X, P, sX, Z, P, sX));
+            IMCOM_TRY(gemm(true, true, P, P, Np, X, P, sX, Z, P, sX, H, P, sG));
+            ctx->ws_used = mark_eig;
+            IMCOM_TRY(eigh_device(ctx, batch, nP.data(), P, H, P, sG, lam, P, Qh, P, sG, nullptr));
+            ctx->ws_used = mark_eig;
+            IMCOM_TRY(launch_ritz_residual(ctx, X, Z, Qh, lam, Np, P, n_dev, want_d, rpart, batch));
+        }
         IMCOM_HIP_CHECK(hipMemcpy2DAsync(lam01.data(), 16, lam, (size_t)P * 8, 16, batch, hipMemcpyDeviceToHost, st));
         IMCOM_HIP_CHECK(hipMemcpyAsync(rp.data(), rpart, rp.size() * 8, hipMemcpyDeviceToHost, st));
         IMCOM_HIP_CHECK(hipMemcpy2DAsync(lamP.data(), 8, lam + P - 1, (size_t)P * 8, 8, batch, hipMemcpyDeviceToHost, st));
@@ -417,7 +439,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
             if (!fine[s] && close > 0.0 && close <= 0.25) {
                 fine[s] = 1;
                 eta[s] = close;
-                const double c = (close / (1.0 + close)) * (close / (1.0 + close));
+                const double c = (close / (bulk + close)) * (close / (bulk + close));
                 steps_wanted[s] = (int)std::min(6.0, std::max(1.0, ceil(log(std::max(1e-11 / std::max(bound, 1e-300), 1e-300)) / log(c))));
             }
             if (!fine[s] && theta[s] < 0.0 && sigma[s] > 4.0 * (mag + r1) && !(bound <= 0.15)) {
@@ -432,7 +454,7 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
                     refac[s] = 1; any_refac = true;
                     // steps of the first fine round: with e = bound / 3 the error of theta1 and the bulk of the spectrum |theta1| away, the shift
                     // leaves lambda_min + sigma' = 3.5 e |theta1| and a step multiplies the error by (3.5 e)^2: e (12 e^2)^j <= 3e-12
-                    steps_wanted[s] = bound <= 1.5e-2 ? 3 : bound <= 4e-2 ? 4 : bound <= 7e-2 ? 5 : 6;
+                    steps_wanted[s] = (bound <= 1.5e-2 ? 3 : bound <= 4e-2 ? 4 : bound <= 7e-2 ? 5 : 6) + (skinny ? 1 : 0);
                 }
             } else if (rel > 0.05 * lastrel[s] && 16.0 * rel < 0.25 * eta[s] && theta[s] < 0.0) {
                 eta[s] = std::max(16.0 * rel, 1e-9);
@@ -643,10 +665,14 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
     // its inverted diagonal block, then ALL block rows below it are updated at once, Y_i -= L_ik Y_k: nb - k - 1 workgroups per stamp
     // and launch instead of 9, the same flops.
     static const bool right_off = getenv("IMCOM_LMIN_RIGHT") && strcmp(getenv("IMCOM_LMIN_RIGHT"), "0") == 0;
-    auto solve_block = [&](const std::vector<char> &mask, const double *Xv, double *Yv, double *Wv, double *part, int parts) -> int {
+    auto solve_block = [&](const std::vector<char> &mask, const double *Xv, double *Yv, double *Wv, double *part, int parts, int Pv) -> int {
         std::vector<int> nb(batch);
         int nbm = 0, cnt = 0;
         for (int s = 0; s < batch; s++) { nb[s] = mask[s] ? nblk[s] : 0; nbm = std::max(nbm, nb[s]); cnt += mask[s] ? 1 : 0; }
+        if (Pv == LMIN_SKINNY_P) {  // blocks of 16 vectors: one workgroup per stamp, both sweeps in one launch (lmin_skinny.hip)
+            IMCOM_TRY(upload(ctx, nblk_sol, nb.data(), (size_t)batch));
+            return launch_skinny_solve(ctx, L, Dinv, Xv, Yv, Np, nblk_sol, batch);
+        }
         if (Wv && !right_off && cnt > 0 && cnt <= 8) {
             const int P = LMIN_P;
             const long sL = (long)Np * Np, sY = (long)Np * P, sD = (long)(Np / NB) * NB * NB;

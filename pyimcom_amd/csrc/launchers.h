@@ -85,6 +85,13 @@ int launch_finalize_fused(imcom_ctx *ctx, const double *Dpart, const double *Npa
                           const int *nblk, const double *kap, const double *Cs, float *Tt, float *UC, float *Sigma, float *kappa,
                           int batch, const int *act = nullptr);  // act != null: only the stamps with act[s] != 0
 int launch_solve_mask(imcom_ctx *ctx, const int *nblk, const int *fac, const int *fail, int *nblk_sol, int *act, int batch);
+// lmin_skinny.hip: the smallest-eigenvalue iteration on blocks of 16 vectors [batch][ldn][16] (one workgroup per stamp streams the factor;
+// nblk[s] = 0: the stamp is left alone)
+constexpr int LMIN_SKINNY_P = 16;
+int launch_skinny_solve(imcom_ctx *ctx, const double *L, const double *Dinv, const double *X, double *Y, int ldn, const int *nblk, int batch);  // Y = (L L^T)^-1 X (X may be Y)
+int launch_skinny_ax(imcom_ctx *ctx, const double *A, const double *X, double *Z, int ldn, const int *nblk, int nbmax, int batch);              // Z = A X
+int launch_skinny_orth(imcom_ctx *ctx, const double *src, double *dst, int ldn, const int *nblk, int *fail, int batch);                        // one CholQR pass
+int launch_skinny_rr(imcom_ctx *ctx, const double *X, const double *Z, int ldn, const int *nblk, double *lam, double *part, int ngroups, int batch);  // eigenvalues of X^T Z [batch][16], residuals of the two lowest pairs
 constexpr int LMIN_RESID_GROUPS = 32;  // row groups of launch_ritz_residual: part is [batch][32][2]
 int launch_ritz_residual(imcom_ctx *ctx, const double *X, const double *Z, const double *Qh, const double *lam, int ldn, int P, const int *n,
                          const int *want, double *part, int batch);
