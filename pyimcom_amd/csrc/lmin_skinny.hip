@@ -50,38 +50,65 @@ __device__ __forceinline__ void sk_rows_times_block(f64x4 &acc, const double *__
         for (int j = 0; j < 4; j++) acc = SK_MFMA(a[u][j], b[u][j], acc);
 }
 
-// The transposed product of the backward sweep, D[v][c] += sum_k Z[k][v] M[k][c0 + c] over 32 rows k0 .. k0+31 of M and 32 of its
-// columns: the block of vectors is the A operand here (row v = vector), the matrix the B operand, and a lane loads TWO neighbouring
-// columns (16 bytes; the 16 lanes of a k: 256 contiguous bytes) -- acc0 takes the even columns c0 + 2 c, acc1 the odd ones.
-__device__ __forceinline__ void sk_block_times_cols(f64x4 &acc0, f64x4 &acc1, const double *Zp, const double *__restrict__ Mp, long ld)
+// The pieces of the sweeps' K loops, software-pipelined by hand: a wave keeps TWO pieces' loads in flight while it multiplies a third
+// (left to itself the compiler interleaves loads and products and keeps 7-9 loads outstanding, draining them at the end of every
+// iteration: 3.4 TB/s over the forward sweep).  The scheduling barriers pin "all loads of a piece, then all products of another";
+// the waits the compiler inserts are then counted ones (the loads return in order).
+#define SK_SB() __builtin_amdgcn_sched_barrier(0)
+
+// forward piece: 16 columns k0 .. k0+15 of the wave's 16 rows (one 32-byte load per lane) and the 16 rows of the block of vectors
+struct SkFwdPiece {
+    f64x4v a[1];
+    double b[1][4];
+};
+__device__ __forceinline__ void sk_fwd_issue(SkFwdPiece &P, const double *__restrict__ Mrow, const double *V)
+{
+    // Mrow = &M[r0 + r][k0 + 4 q], V = &V[k0 + 4 q][l & 15]
+#pragma unroll
+    for (int u = 0; u < 1; u++) P.a[u] = *(const f64x4v *)(Mrow + 16 * u);
+#pragma unroll
+    for (int u = 0; u < 1; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) P.b[u][j] = V[(long)(16 * u + j) * SP];
+}
+__device__ __forceinline__ void sk_fwd_compute(f64x4 &acc, const SkFwdPiece &P)
+{
+#pragma unroll
+    for (int u = 0; u < 1; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc = SK_MFMA(P.a[u][j], P.b[u][j], acc);
+}
+
+// backward piece: D[v][c] += sum_k Z[k][v] M[k][c0 + c] over 16 rows k0 .. k0+15 of M and 32 of its columns -- the block of vectors
+// is the A operand here (row v = vector), the matrix the B operand, and a lane loads TWO neighbouring columns (16 bytes; the 16
+// lanes of a k: 256 contiguous bytes): acc0 takes the even columns c0 + 2 c, acc1 the odd ones.
+typedef double f64x2v __attribute__((ext_vector_type(2)));
+struct SkBwdPiece {
+    f64x2v m[4];
+    double z[4];
+};
+__device__ __forceinline__ void sk_bwd_issue(SkBwdPiece &P, const double *Zp, const double *__restrict__ Mp, long ld)
 {
     // Zp = &Z[k0 + 4 q][l & 15], Mp = &M[k0 + 4 q][c0 + 2 (l & 15)]
-    typedef double f64x2v __attribute__((ext_vector_type(2)));
-    f64x2v m[2][4];
-    double z[2][4];
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int j = 0; j < 4; j++) P.m[j] = *(const f64x2v *)(Mp + (long)j * ld);
 #pragma unroll
-        for (int j = 0; j < 4; j++) m[u][j] = *(const f64x2v *)(Mp + (long)(16 * u + j) * ld);
+    for (int j = 0; j < 4; j++) P.z[j] = Zp[(long)j * SP];
+}
+__device__ __forceinline__ void sk_bwd_compute(f64x4 &acc0, f64x4 &acc1, const SkBwdPiece &P)
+{
 #pragma unroll
-    for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) z[u][j] = Zp[(long)(16 * u + j) * SP];
-#pragma unroll
-    for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            acc0 = SK_MFMA(z[u][j], m[u][j][0], acc0);
-            acc1 = SK_MFMA(z[u][j], m[u][j][1], acc1);
-        }
+    for (int j = 0; j < 4; j++) {
+        acc0 = SK_MFMA(P.z[j], P.m[j][0], acc0);
+        acc1 = SK_MFMA(P.z[j], P.m[j][1], acc1);
+    }
 }
 
 // Y = (L L^T)^-1 X for the stamps with nblk[s] > 0.  L: the lower factor in the stamp's [ldn][ldn] array, Dinv: the inverted diagonal
 // blocks [ldn / 128][128][128] (lower triangular, exact zeros above the diagonal).  X may be Y.
-// One workgroup of SIXTEEN waves per stamp (four per SIMD: one wave's loads are in flight under another's products -- with eight
-// waves the kernel streamed 3.6 TB/s, the stamps of a pass being fewer than the CUs).  Forward, block row I: wave (g, h) adds up rows
-// 16 g .. 16 g + 15 over the 128-column blocks kb = h, h + 2, ...; the two partial sums meet in LDS.  Backward, block column I: wave
-// (cg, h) takes columns 32 cg .. 32 cg + 31 over the row blocks kb = I + 1 + h, + 4, ...
+// One workgroup of SIXTEEN waves per stamp (four per SIMD; the stamps of a pass are fewer than the CUs).  Forward, block row I: wave
+// (g, h) adds up rows 16 g .. 16 g + 15 over the 128-column blocks kb = h, h + 2, ...; the two partial sums meet in LDS.  Backward,
+// block column I: wave (cg, h) takes columns 32 cg .. 32 cg + 31 over the row blocks kb = I + 1 + h, + 4, ...
 constexpr int SKS_THREADS = 1024;
 __global__ __launch_bounds__(SKS_THREADS) void skinny_solve_kernel(const double *__restrict__ L, const double *__restrict__ Dinv, const double *X, double *Y, int ldn,
                                                                    const int *__restrict__ nblk)
@@ -100,9 +127,22 @@ __global__ __launch_bounds__(SKS_THREADS) void skinny_solve_kernel(const double 
         for (int I = 0; I < nb; I++) {
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
             const double *Lrow = Ls + ((long)I * NB + 16 * g + r) * ldn + 4 * q;
-            for (int kb = h; kb < I; kb += 2) {
-                sk_rows_times_block<4>(acc, Lrow + (long)kb * NB, Ys + ((long)kb * NB + 4 * q) * SP + r);
-                sk_rows_times_block<4>(acc, Lrow + (long)kb * NB + 64, Ys + ((long)kb * NB + 64 + 4 * q) * SP + r);
+            const double *Vp = Ys + (long)(4 * q) * SP + r;
+            const int np = I > h ? 8 * ((I - h + 1) / 2) : 0;  // pieces of 16 columns: blocks kb = h, h + 2, ... < I (a multiple of 4 pieces)
+            if (np > 0) {
+                auto k0 = [&](int p) -> long { p = p < np ? p : np - 1; return (long)(h + 2 * (p >> 3)) * NB + 16 * (p & 7); };  // (beyond the end: the last piece again, not used)
+                SkFwdPiece buf[4];  // three pieces in flight under the products of the fourth
+#pragma unroll
+                for (int c = 0; c < 3; c++) sk_fwd_issue(buf[c], Lrow + k0(c), Vp + k0(c) * SP);
+                for (int p = 0; p < np; p += 4) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        sk_fwd_issue(buf[(c + 3) & 3], Lrow + k0(p + c + 3), Vp + k0(p + c + 3) * SP);
+                        SK_SB();
+                        sk_fwd_compute(acc, buf[c]);
+                        SK_SB();
+                    }
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; t++) Rp[h][(16 * g + q + 4 * t) * SP + r] = acc[t];
@@ -130,12 +170,22 @@ __global__ __launch_bounds__(SKS_THREADS) void skinny_solve_kernel(const double 
             f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
             const double *Lp = Ls + (long)(4 * q) * ldn + (long)I * NB + 32 * cg + 2 * r;
             const double *Zp = Ys + (long)(4 * q) * SP + r;
-            for (int kb = I + 1 + h; kb < nb; kb += 4)
-#pragma unroll 1
-                for (int piece = 0; piece < 4; piece++) {
-                    const long k0 = (long)kb * NB + 32 * piece;
-                    sk_block_times_cols(acc0, acc1, Zp + k0 * SP, Lp + k0 * ldn, ldn);
+            const int nkb = nb - 1 - I - h, np = nkb > 0 ? 8 * ((nkb + 3) / 4) : 0;  // pieces of 16 rows: blocks kb = I + 1 + h, + 4, ... < nb
+            if (np > 0) {
+                auto k0 = [&](int p) -> long { p = p < np ? p : np - 1; return (long)(I + 1 + h + 4 * (p >> 3)) * NB + 16 * (p & 7); };
+                SkBwdPiece buf[3];  // two pieces in flight under the products of the third
+#pragma unroll
+                for (int c = 0; c < 2; c++) sk_bwd_issue(buf[c], Zp + k0(c) * SP, Lp + k0(c) * ldn, ldn);
+                for (int p = 0; p < np; p += 3) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        sk_bwd_issue(buf[(c + 2) % 3], Zp + k0(p + c + 2) * SP, Lp + k0(p + c + 2) * ldn, ldn);  // (always: the buffers carry no branch)
+                        SK_SB();
+                        if (p + c < np) sk_bwd_compute(acc0, acc1, buf[c]);
+                        SK_SB();
+                    }
                 }
+            }
             // D[v][c]: register t of lane (r, q) holds vector v = q + 4 t, columns 32 cg + 2 r (+ 1)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
