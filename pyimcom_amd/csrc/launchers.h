@@ -89,6 +89,9 @@ int launch_solve_mask(imcom_ctx *ctx, const int *nblk, const int *fac, const int
 // nblk[s] = 0: the stamp is left alone)
 constexpr int LMIN_SKINNY_P = 16;
 int launch_skinny_solve(imcom_ctx *ctx, const double *L, const double *Dinv, const double *X, double *Y, int ldn, const int *nblk, int batch);  // Y = (L L^T)^-1 X (X may be Y)
+int launch_skinny_solve_few(imcom_ctx *ctx, const double *L, const double *Dinv, const double *X, double *Y, int ldn, const int *nblk, int nbmax, int batch,
+                            double *partial);  // the same for FEW stamps: two short launches per block row and sweep; partial: skinny_few_partial_doubles(batch) doubles
+size_t skinny_few_partial_doubles(int batch);
 int launch_skinny_ax(imcom_ctx *ctx, const double *A, const double *X, double *Z, int ldn, const int *nblk, int nbmax, int batch);              // Z = A X
 int launch_skinny_orth(imcom_ctx *ctx, const double *src, double *dst, int ldn, const int *nblk, int *fail, int batch);                        // one CholQR pass
 int launch_skinny_rr(imcom_ctx *ctx, const double *X, const double *Z, int ldn, const int *nblk, double *lam, double *part, int ngroups, int batch);  // eigenvalues of X^T Z [batch][16], residuals of the two lowest pairs

@@ -50,65 +50,38 @@ __device__ __forceinline__ void sk_rows_times_block(f64x4 &acc, const double *__
         for (int j = 0; j < 4; j++) acc = SK_MFMA(a[u][j], b[u][j], acc);
 }
 
-// The pieces of the sweeps' K loops, software-pipelined by hand: a wave keeps TWO pieces' loads in flight while it multiplies a third
-// (left to itself the compiler interleaves loads and products and keeps 7-9 loads outstanding, draining them at the end of every
-// iteration: 3.4 TB/s over the forward sweep).  The scheduling barriers pin "all loads of a piece, then all products of another";
-// the waits the compiler inserts are then counted ones (the loads return in order).
-#define SK_SB() __builtin_amdgcn_sched_barrier(0)
-
-// forward piece: 16 columns k0 .. k0+15 of the wave's 16 rows (one 32-byte load per lane) and the 16 rows of the block of vectors
-struct SkFwdPiece {
-    f64x4v a[1];
-    double b[1][4];
-};
-__device__ __forceinline__ void sk_fwd_issue(SkFwdPiece &P, const double *__restrict__ Mrow, const double *V)
-{
-    // Mrow = &M[r0 + r][k0 + 4 q], V = &V[k0 + 4 q][l & 15]
-#pragma unroll
-    for (int u = 0; u < 1; u++) P.a[u] = *(const f64x4v *)(Mrow + 16 * u);
-#pragma unroll
-    for (int u = 0; u < 1; u++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) P.b[u][j] = V[(long)(16 * u + j) * SP];
-}
-__device__ __forceinline__ void sk_fwd_compute(f64x4 &acc, const SkFwdPiece &P)
-{
-#pragma unroll
-    for (int u = 0; u < 1; u++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc = SK_MFMA(P.a[u][j], P.b[u][j], acc);
-}
-
-// backward piece: D[v][c] += sum_k Z[k][v] M[k][c0 + c] over 16 rows k0 .. k0+15 of M and 32 of its columns -- the block of vectors
-// is the A operand here (row v = vector), the matrix the B operand, and a lane loads TWO neighbouring columns (16 bytes; the 16
-// lanes of a k: 256 contiguous bytes): acc0 takes the even columns c0 + 2 c, acc1 the odd ones.
-typedef double f64x2v __attribute__((ext_vector_type(2)));
-struct SkBwdPiece {
-    f64x2v m[4];
-    double z[4];
-};
-__device__ __forceinline__ void sk_bwd_issue(SkBwdPiece &P, const double *Zp, const double *__restrict__ Mp, long ld)
+// The transposed product of the backward sweep, D[v][c] += sum_k Z[k][v] M[k][c0 + c] over 32 rows k0 .. k0+31 of M and 32 of its
+// columns: the block of vectors is the A operand here (row v = vector), the matrix the B operand, and a lane loads TWO neighbouring
+// columns (16 bytes; the 16 lanes of a k: 256 contiguous bytes) -- acc0 takes the even columns c0 + 2 c, acc1 the odd ones.
+__device__ __forceinline__ void sk_block_times_cols(f64x4 &acc0, f64x4 &acc1, const double *Zp, const double *__restrict__ Mp, long ld)
 {
     // Zp = &Z[k0 + 4 q][l & 15], Mp = &M[k0 + 4 q][c0 + 2 (l & 15)]
+    typedef double f64x2v __attribute__((ext_vector_type(2)));
+    f64x2v m[2][4];
+    double z[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) P.m[j] = *(const f64x2v *)(Mp + (long)j * ld);
+    for (int u = 0; u < 2; u++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) P.z[j] = Zp[(long)j * SP];
-}
-__device__ __forceinline__ void sk_bwd_compute(f64x4 &acc0, f64x4 &acc1, const SkBwdPiece &P)
-{
+        for (int j = 0; j < 4; j++) m[u][j] = *(const f64x2v *)(Mp + (long)(16 * u + j) * ld);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        acc0 = SK_MFMA(P.z[j], P.m[j][0], acc0);
-        acc1 = SK_MFMA(P.z[j], P.m[j][1], acc1);
-    }
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) z[u][j] = Zp[(long)(16 * u + j) * SP];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            acc0 = SK_MFMA(z[u][j], m[u][j][0], acc0);
+            acc1 = SK_MFMA(z[u][j], m[u][j][1], acc1);
+        }
 }
 
 // Y = (L L^T)^-1 X for the stamps with nblk[s] > 0.  L: the lower factor in the stamp's [ldn][ldn] array, Dinv: the inverted diagonal
 // blocks [ldn / 128][128][128] (lower triangular, exact zeros above the diagonal).  X may be Y.
-// One workgroup of SIXTEEN waves per stamp (four per SIMD; the stamps of a pass are fewer than the CUs).  Forward, block row I: wave
-// (g, h) adds up rows 16 g .. 16 g + 15 over the 128-column blocks kb = h, h + 2, ...; the two partial sums meet in LDS.  Backward,
-// block column I: wave (cg, h) takes columns 32 cg .. 32 cg + 31 over the row blocks kb = I + 1 + h, + 4, ...
+// One workgroup of SIXTEEN waves per stamp (four per SIMD: one wave's loads are in flight under another's products -- with eight
+// waves the kernel streamed 3.6 TB/s, the stamps of a pass being fewer than the CUs).  Forward, block row I: wave (g, h) adds up rows
+// 16 g .. 16 g + 15 over the 128-column blocks kb = h, h + 2, ...; the two partial sums meet in LDS.  Backward, block column I: wave
+// (cg, h) takes columns 32 cg .. 32 cg + 31 over the row blocks kb = I + 1 + h, + 4, ...
 constexpr int SKS_THREADS = 1024;
 __global__ __launch_bounds__(SKS_THREADS) void skinny_solve_kernel(const double *__restrict__ L, const double *__restrict__ Dinv, const double *X, double *Y, int ldn,
                                                                    const int *__restrict__ nblk)
@@ -127,22 +100,9 @@ __global__ __launch_bounds__(SKS_THREADS) void skinny_solve_kernel(const double 
         for (int I = 0; I < nb; I++) {
             f64x4 acc = {0.0, 0.0, 0.0, 0.0};
             const double *Lrow = Ls + ((long)I * NB + 16 * g + r) * ldn + 4 * q;
-            const double *Vp = Ys + (long)(4 * q) * SP + r;
-            const int np = I > h ? 8 * ((I - h + 1) / 2) : 0;  // pieces of 16 columns: blocks kb = h, h + 2, ... < I (a multiple of 4 pieces)
-            if (np > 0) {
-                auto k0 = [&](int p) -> long { p = p < np ? p : np - 1; return (long)(h + 2 * (p >> 3)) * NB + 16 * (p & 7); };  // (beyond the end: the last piece again, not used)
-                SkFwdPiece buf[4];  // three pieces in flight under the products of the fourth
-#pragma unroll
-                for (int c = 0; c < 3; c++) sk_fwd_issue(buf[c], Lrow + k0(c), Vp + k0(c) * SP);
-                for (int p = 0; p < np; p += 4) {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        sk_fwd_issue(buf[(c + 3) & 3], Lrow + k0(p + c + 3), Vp + k0(p + c + 3) * SP);
-                        SK_SB();
-                        sk_fwd_compute(acc, buf[c]);
-                        SK_SB();
-                    }
-                }
+            for (int kb = h; kb < I; kb += 2) {
+                sk_rows_times_block<4>(acc, Lrow + (long)kb * NB, Ys + ((long)kb * NB + 4 * q) * SP + r);
+                sk_rows_times_block<4>(acc, Lrow + (long)kb * NB + 64, Ys + ((long)kb * NB + 64 + 4 * q) * SP + r);
             }
 #pragma unroll
             for (int t = 0; t < 4; t++) Rp[h][(16 * g + q + 4 * t) * SP + r] = acc[t];
@@ -170,22 +130,12 @@ __global__ __launch_bounds__(SKS_THREADS) void skinny_solve_kernel(const double 
             f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
             const double *Lp = Ls + (long)(4 * q) * ldn + (long)I * NB + 32 * cg + 2 * r;
             const double *Zp = Ys + (long)(4 * q) * SP + r;
-            const int nkb = nb - 1 - I - h, np = nkb > 0 ? 8 * ((nkb + 3) / 4) : 0;  // pieces of 16 rows: blocks kb = I + 1 + h, + 4, ... < nb
-            if (np > 0) {
-                auto k0 = [&](int p) -> long { p = p < np ? p : np - 1; return (long)(I + 1 + h + 4 * (p >> 3)) * NB + 16 * (p & 7); };
-                SkBwdPiece buf[3];  // two pieces in flight under the products of the third
-#pragma unroll
-                for (int c = 0; c < 2; c++) sk_bwd_issue(buf[c], Zp + k0(c) * SP, Lp + k0(c) * ldn, ldn);
-                for (int p = 0; p < np; p += 3) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        sk_bwd_issue(buf[(c + 2) % 3], Zp + k0(p + c + 2) * SP, Lp + k0(p + c + 2) * ldn, ldn);  // (always: the buffers carry no branch)
-                        SK_SB();
-                        if (p + c < np) sk_bwd_compute(acc0, acc1, buf[c]);
-                        SK_SB();
-                    }
+            for (int kb = I + 1 + h; kb < nb; kb += 4)
+#pragma unroll 1
+                for (int piece = 0; piece < 4; piece++) {
+                    const long k0 = (long)kb * NB + 32 * piece;
+                    sk_block_times_cols(acc0, acc1, Zp + k0 * SP, Lp + k0 * ldn, ldn);
                 }
-            }
             // D[v][c]: register t of lane (r, q) holds vector v = q + 4 t, columns 32 cg + 2 r (+ 1)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -208,6 +158,116 @@ __global__ __launch_bounds__(SKS_THREADS) void skinny_solve_kernel(const double 
             __syncthreads();
         }
     }
+}
+
+// ---- few stamps (the kernel-class seam hands over one, a 2 x 2 group four): a workgroup per stamp would stream a production stamp's
+// factor at one CU's rate (12 ms per step).  Here a block row is TWO launches: the sum over the blocks it depends on dealt to up to
+// SK_PARTS workgroups per stamp (each leaves its 128 x 16 partial sum), then one workgroup per stamp that adds them in a fixed order,
+// applies the inverted diagonal block and writes the block row.  196 short launches per solve of a production stamp -- as many as
+// the right-looking 128-column form, but of 5-8 us instead of 30 (whose K = 128 tile products are latency-bound on the two-stage ring).
+constexpr int SK_PARTS = 48;
+
+__device__ __forceinline__ void sk_part_range(int nk, int p, int np, int &k0, int &k1)
+{
+    k0 = (int)((long)p * nk / np);
+    k1 = (int)((long)(p + 1) * nk / np);
+}
+
+// partial[(s * SK_PARTS + p)][row][vector]: forward (BWD = false) rows of block row I over blocks [0, I); backward columns of block column I
+// over the row blocks (I, nb)
+template <bool BWD>
+__global__ __launch_bounds__(BWD ? 256 : 512) void skinny_part_kernel(const double *__restrict__ L, const double *Y, double *__restrict__ partial, int ldn, int I,
+                                                                        const int *__restrict__ nblk)
+{
+    const int s = blockIdx.y, p = blockIdx.x, nb = nblk[s];
+    if (I >= nb) return;
+    const int nk = BWD ? nb - 1 - I : I, np = nk < (int)gridDim.x ? nk : (int)gridDim.x;
+    if (p >= np) return;
+    int k0, k1;
+    sk_part_range(nk, p, np, k0, k1);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const double *Ls = L + (long)s * ldn * ldn, *Ys = Y + (long)s * ldn * SP;
+    double *P = partial + ((long)s * SK_PARTS + p) * NB * SP;
+    if (!BWD) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double *Lrow = Ls + ((long)I * NB + 16 * w + r) * ldn + 4 * q;
+        for (int kb = k0; kb < k1; kb++) sk_rows_times_block<8>(acc, Lrow + (long)kb * NB, Ys + ((long)kb * NB + 4 * q) * SP + r);
+#pragma unroll
+        for (int t = 0; t < 4; t++) P[(16 * w + q + 4 * t) * SP + r] = acc[t];
+    } else {
+        f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double *Lp = Ls + (long)(4 * q) * ldn + (long)I * NB + 32 * w + 2 * r;
+        const double *Zp = Ys + (long)(4 * q) * SP + r;
+        for (int kb = I + 1 + k0; kb < I + 1 + k1; kb++)
+#pragma unroll
+            for (int piece = 0; piece < 4; piece++) {
+                const long k = (long)kb * NB + 32 * piece;
+                sk_block_times_cols(acc0, acc1, Zp + k * SP, Lp + k * ldn, ldn);
+            }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            P[(32 * w + 2 * r) * SP + q + 4 * t] = acc0[t];
+            P[(32 * w + 2 * r + 1) * SP + q + 4 * t] = acc1[t];
+        }
+    }
+}
+
+// block row I of the sweep from its partial sums: Y_I = Linv_I (X_I - sum) forward, Y_I <- Linv_I^T (Y_I - sum) backward
+template <bool BWD>
+__global__ __launch_bounds__(SK_THREADS, 2) void skinny_fin_kernel(const double *__restrict__ Dinv, const double *X, double *Y, const double *__restrict__ partial,
+                                                                   int ldn, int I, int nparts, const int *__restrict__ nblk)
+{
+    __shared__ double Rs[NB * SP];
+    const int s = blockIdx.x, nb = nblk[s];
+    if (I >= nb) return;
+    const int nk = BWD ? nb - 1 - I : I, np = nk < nparts ? nk : nparts;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const double *Ds = Dinv + ((long)s * (ldn / NB) + I) * NB * NB;
+    const double *Xi = (BWD ? Y : X) + (long)s * ldn * SP + (long)I * NB * SP;
+    double *Yi = Y + (long)s * ldn * SP + (long)I * NB * SP;
+    const double *P = partial + (long)s * SK_PARTS * NB * SP;
+    // the inverted diagonal block's fragments first: their trip to HBM passes behind the sums (all eight chunks: exact zeros beyond the diagonal)
+    double d[8][4];
+    if (!BWD) {
+        const double *Drow = Ds + (long)(16 * g + r) * NB + 4 * q;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const f64x4v a = *(const f64x4v *)(Drow + 16 * u);
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[u][j] = a[j];
+        }
+    } else {
+        const double *Dcol = Ds + 16 * g + r + (long)(4 * q) * NB;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[u][j] = Dcol[(long)(16 * u + j) * NB];
+    }
+    // the partial sums in a fixed order, eight loads per element in flight (one after the other they cost an L2 round trip each: 30 us)
+    {
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < np; p0 += 8) {
+            double t[8][4];
+#pragma unroll
+            for (int pp = 0; pp < 8; pp++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) t[pp][c] = p0 + pp < np ? P[(long)(p0 + pp) * NB * SP + threadIdx.x + c * SK_THREADS] : 0.0;
+#pragma unroll
+            for (int pp = 0; pp < 8; pp++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] += t[pp][c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) { const int e = threadIdx.x + c * SK_THREADS; Rs[e] = Xi[e] - v[c]; }
+    }
+    __syncthreads();
+    f64x4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) y = SK_MFMA(d[u][j], Rs[(16 * u + 4 * q + j) * SP + r], y);
+#pragma unroll
+    for (int t = 0; t < 4; t++) Yi[(16 * g + q + 4 * t) * SP + r] = y[t];
 }
 
 // Z = A X, block row blockIdx.x of stamp blockIdx.y (A: the full symmetric matrix, identity-padded)
@@ -425,6 +485,26 @@ int launch_skinny_solve(imcom_ctx *ctx, const double *L, const double *Dinv, con
     hipLaunchKernelGGL(skinny_solve_kernel, dim3(batch), dim3(SKS_THREADS), 0, ctx->stream, L, Dinv, X, Y, ldn, nblk);
     return check_launch("skinny_solve_kernel");
 }
+
+// few stamps: Y = (L L^T)^-1 X as a pair of launches per block row and sweep (nbmax: the largest nblk; partial: skinny_few_partial_doubles(batch) doubles)
+int launch_skinny_solve_few(imcom_ctx *ctx, const double *L, const double *Dinv, const double *X, double *Y, int ldn, const int *nblk, int nbmax, int batch, double *partial)
+{
+    const int parts = nbmax - 1 < SK_PARTS ? nbmax - 1 : SK_PARTS;
+    for (int I = 0; I < nbmax; I++) {
+        if (I > 0) hipLaunchKernelGGL(skinny_part_kernel<false>, dim3(I < parts ? I : parts, batch), dim3(512), 0, ctx->stream, L, Y, partial, ldn, I, nblk);
+        hipLaunchKernelGGL(skinny_fin_kernel<false>, dim3(batch), dim3(SK_THREADS), 0, ctx->stream, Dinv, X, Y, partial, ldn, I, parts, nblk);
+    }
+    IMCOM_TRY(check_launch("skinny_fin_kernel (forward)"));
+    for (int I = nbmax - 1; I >= 0; I--) {
+        // (a stamp with fewer blocks than nbmax: its kernels return for I >= nblk[s], and its own last block row has nothing below it)
+        const int nk = nbmax - 1 - I;
+        if (nk > 0) hipLaunchKernelGGL(skinny_part_kernel<true>, dim3(nk < parts ? nk : parts, batch), dim3(256), 0, ctx->stream, L, Y, partial, ldn, I, nblk);
+        hipLaunchKernelGGL(skinny_fin_kernel<true>, dim3(batch), dim3(SK_THREADS), 0, ctx->stream, Dinv, Y, Y, partial, ldn, I, parts, nblk);
+    }
+    return check_launch("skinny_fin_kernel (backward)");
+}
+
+size_t skinny_few_partial_doubles(int batch) { return (size_t)batch * SK_PARTS * NB * SP; }
 
 int launch_skinny_ax(imcom_ctx *ctx, const double *A, const double *X, double *Z, int ldn, const int *nblk, int nbmax, int batch)
 {
