@@ -350,7 +350,8 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     // (configs/paper4: six coarse steps leave 2e-3, three fine ones 1e-13).  The change between two successive values of theta1 -- the
     // criterion of the first version, which cost a round of three steps and a Rayleigh-Ritz step in each phase only to confirm -- still
     // ends either phase when the residuals cannot (theta1 inside a cluster closer than its residual).
-    static const int coarse_steps = getenv("IMCOM_LMIN_COARSE") ? std::max(1, atoi(getenv("IMCOM_LMIN_COARSE"))) : 6;
+    static const int coarse_steps_env = getenv("IMCOM_LMIN_COARSE") ? std::max(1, atoi(getenv("IMCOM_LMIN_COARSE"))) : 0;
+    const int coarse_steps = coarse_steps_env ? coarse_steps_env : (LMIN_SKINNY_P == P ? 9 : 6);  // (16 vectors at a blind shift: six steps leave 25-40 %, nine a few per cent)
     static const int lmin_parts = getenv("IMCOM_LMIN_PARTS") ? std::min(8, std::max(1, atoi(getenv("IMCOM_LMIN_PARTS")))) : 0;  // (A/B: split-K parts of the 128-column solves)
     static const int hinted_steps_env = getenv("IMCOM_LMIN_HINTED") ? std::max(1, atoi(getenv("IMCOM_LMIN_HINTED"))) : 0;  // (34 x (7.6e-3)^7: see the hint above)
     const int hinted_steps = hinted_steps_env ? hinted_steps_env : (skinny ? 10 : 7);

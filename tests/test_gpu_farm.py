@@ -69,10 +69,11 @@ def test_farm_blocks_of_repaired_stamps_with_and_without_hints(tmp_path):
     hinted, blind = str(tmp_path / "hinted"), str(tmp_path / "blind")
     o1 = run(hinted, {"IMCOM_LMIN_DEBUG": "1"})
     run(blind, {"IMCOM_LMIN_HINT": "0"})
-    # the iterations of the hinted run: a pass that starts blind -- every block's first -- needs two factorisations inside its iteration, the
-    # second pass of every block -- neighbours of the first pass's stamps, started from its record -- one
+    # the iterations of the hinted run: a pass that starts blind -- every block's first -- needs two factorisations inside its iteration (three
+    # when its two stamps reach the closer shift in different rounds), the second pass of every block -- neighbours of the first pass's
+    # stamps, started from its record -- ONE
     facs = [int(l.split(" stamps: ")[1].split()[0]) for l in o1.splitlines() if l.startswith("[lmin]") and " stamps: " in l]
-    assert len(facs) == 8 and all(f == 2 for f in facs[0::2]) and all(f == 1 for f in facs[1::2]), facs
+    assert len(facs) == 8 and all(2 <= f <= 3 for f in facs[0::2]) and all(f == 1 for f in facs[1::2]), facs
     for b in range(4):
         a, c = np.load(farm.block_path(hinted, b)), np.load(farm.block_path(blind, b))
         assert np.isfinite(a["out_map"]).all() and np.abs(a["out_map"]).max() > 0
@@ -107,7 +108,7 @@ def test_farm_shared_block_of_repaired_stamps_is_bit_identical(tmp_path):
     assert np.isfinite(c["out_map"]).all() and np.abs(c["out_map"]).max() > 0
     # hints were on: in the single process's run the first pass took two factorisations inside its iteration, the three others one
     facs = [int(l.split(" stamps: ")[1].split()[0]) for l in o1.splitlines() if l.startswith("[lmin]") and " stamps: " in l]
-    assert facs == [2, 1, 1, 1], facs
+    assert 2 <= facs[0] <= 3 and facs[1:] == [1, 1, 1], facs
     assert os.path.exists(os.path.join(two, ".farm-t2", "b0000.repair.json"))
 
 
