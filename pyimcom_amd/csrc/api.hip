@@ -675,7 +675,7 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         for (int s = 0; s < batch; s++) { nb[s] = mask[s] ? nblk[s] : 0; nbm = std::max(nbm, nb[s]); cnt += mask[s] ? 1 : 0; }
         if (Pv == LMIN_SKINNY_P) {  // blocks of 16 vectors (lmin_skinny.hip): one workgroup per stamp, both sweeps in one launch -- or, for few stamps, two launches per block row
             IMCOM_TRY(upload(ctx, nblk_sol, nb.data(), (size_t)batch));
-            static const int few_max = getenv("IMCOM_LMIN_FEW_MAX") ? atoi(getenv("IMCOM_LMIN_FEW_MAX")) : 15;
+            const int few_max = getenv("IMCOM_LMIN_FEW_MAX") ? atoi(getenv("IMCOM_LMIN_FEW_MAX")) : 15;  // (read per call: the tests run both forms)
             if (cnt <= few_max && part && skinny_few_partial_doubles(batch) <= (size_t)batch * 8 * NB * NB)
                 return launch_skinny_solve_few(ctx, L, Dinv, Xv, Yv, Np, nblk_sol, nbm, batch, part);
             return launch_skinny_solve(ctx, L, Dinv, Xv, Yv, Np, nblk_sol, batch);

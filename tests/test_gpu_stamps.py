@@ -351,13 +351,14 @@ def test_solve_retries_when_the_workspace_cannot_grow(monkeypatch):
         sb.solve()
 
 
-@pytest.mark.parametrize("block_of", [128, 16])
+@pytest.mark.parametrize("block_of", [128, 16, -16])
 @pytest.mark.parametrize("shifts_in_kappa", [(3.0, 0.0, 40.0, 1.5), (0.0, 0.0, 0.0, 2.0, 0.0)])
 def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_kappa, block_of, monkeypatch):
     """The Cholesky repair (lakernel.py:262-279: AA_ii += |w[0]| + 1e-16, w[0] the smallest eigenvalue of A) at a size where the library
     finds w[0] WITHOUT an eigendecomposition (api.hip lambda_min_subspace: trial factorisations, subspace iteration with the inverse
-    on 128 vectors -- or on 16, the form a pass of 16 and more repaired stamps takes (lmin_skinny.hip: a workgroup per stamp streams the
-    factor; IMCOM_LMIN_SKINNY forces either form) --, Rayleigh-Ritz with A; matrices of 1024 rows and more).  cfg-2 stamps (N ~ 2.2k), a batch of four of which three
+    on 16 vectors (lmin_skinny.hip; the sweeps as two launches per block row, the form few stamps take, or -- block_of = -16 -- as one
+    workgroup per stamp, the form of a pass of 16 and more) or on 128 (the form of rounds 5 / 6a, IMCOM_LMIN_SKINNY=0), Rayleigh-Ritz
+    with A; matrices of 1024 rows and more).  cfg-2 stamps (N ~ 2.2k), a batch of four of which three
     are made indefinite by different amounts -- A - c I with c a multiple of kappa, so that w[0] = lambda_min(A) - c sits in the dense
     lower end of a real PSF-overlap spectrum -- and one stays as it is.  T, the maps and info against the oracle's CholKernel (numpy eigh
     + scipy cholesky), through the synchronous entry and through begin / end / redo (only the failed stamps are solved again: the healthy
@@ -368,7 +369,9 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
     from pyimcom_amd import synth
     from pyimcom_amd.stamps import PSFGroupTables, StampBatch
 
-    monkeypatch.setenv("IMCOM_LMIN_SKINNY", "1" if block_of == 16 else "0")
+    monkeypatch.setenv("IMCOM_LMIN_SKINNY", "0" if block_of == 128 else "1")
+    if block_of == -16:
+        monkeypatch.setenv("IMCOM_LMIN_FEW_MAX", "0")
     cfg = synth.CONFIGS["cfg2"]
     stamps = [synth.make_stamp(cfg, 40 + i) for i in range(len(shifts_in_kappa))]
     psfs, target = synth.make_psfs(cfg, cfg.n_expo)
