@@ -243,9 +243,10 @@ static int lambda_min_subspace(imcom_ctx *ctx, int batch, const int *n_host, con
     const size_t mark = ctx->ws_used;
     // Blocks of 16 vectors instead of 128 (lmin_skinny.hip): with a shift a few per cent above |lambda_min| the block's width hardly
     // matters for the convergence (7-9 steps against 5-7 on a production stamp), and a 16-column sweep is one pass over the factor at
-    // HBM speed instead of a 128-column product on the matrix pipe.  Two forms of the sweeps: a pass of 16 and more stamps runs a
-    // workgroup per stamp; fewer stamps (the kernel-class seam hands over one or four) two short launches per block row with the
-    // sums dealt to many workgroups (on a whole pass the two are within 2 % of each other: 1960 launches per pass against 10).
+    // HBM speed instead of a 128-column product on the matrix pipe.  Two forms of the sweeps: a pass of more than 128 stamps runs a
+    // workgroup per stamp; fewer stamps (the kernel-class seam hands over one or four; a block's short last pass) two short launches
+    // per block row with the sums dealt to many workgroups (on a pass of 168 stamps the two are within 2 % of each other: 1960
+    // launches per pass against 10).
     // IMCOM_LMIN_SKINNY=0: the 128-vector form of rounds 5 and 6a (kept as the cross-check: tests/test_gpu_stamps.py runs both).
     const char *sk_env = getenv("IMCOM_LMIN_SKINNY");  // (read per call)
     const bool skinny = sk_env ? atoi(sk_env) != 0 : true;
@@ -675,7 +676,9 @@ static int chol_core(imcom_ctx *ctx, int batch, const int *n_host, int Np, int m
         for (int s = 0; s < batch; s++) { nb[s] = mask[s] ? nblk[s] : 0; nbm = std::max(nbm, nb[s]); cnt += mask[s] ? 1 : 0; }
         if (Pv == LMIN_SKINNY_P) {  // blocks of 16 vectors (lmin_skinny.hip): one workgroup per stamp, both sweeps in one launch -- or, for few stamps, two launches per block row
             IMCOM_TRY(upload(ctx, nblk_sol, nb.data(), (size_t)batch));
-            const int few_max = getenv("IMCOM_LMIN_FEW_MAX") ? atoi(getenv("IMCOM_LMIN_FEW_MAX")) : 15;  // (read per call: the tests run both forms)
+            // (per-block-row launches: 1.8 ms of launches per solve + 44 us per production stamp at 7 TB/s; a workgroup per stamp: 12 ms whatever the
+            // count -- they meet near 200 stamps, and at 168 the single launch is 2 % ahead on the wall clock.  Read per call: the tests run both forms.)
+            const int few_max = getenv("IMCOM_LMIN_FEW_MAX") ? atoi(getenv("IMCOM_LMIN_FEW_MAX")) : 128;
             if (cnt <= few_max && part && skinny_few_partial_doubles(batch) <= (size_t)batch * 8 * NB * NB)
                 return launch_skinny_solve_few(ctx, L, Dinv, Xv, Yv, Np, nblk_sol, nbm, batch, part);
             return launch_skinny_solve(ctx, L, Dinv, Xv, Yv, Np, nblk_sol, batch);

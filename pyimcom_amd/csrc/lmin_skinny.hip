@@ -6,12 +6,14 @@
 // governed by (lambda_1 + sigma) / (lambda_{P+1} + sigma), and on a production stamp (configs/paper4: N = 6.2k, lambda_1 = -1.95e-6,
 // lambda_17 = -1.2e-6, lambda_129 = -3.0e-7) a block of 16 vectors needs 7-9 steps where one of 128 needs 5-7.  The 128-column solves
 // are bound by the matrix pipe (0.125 ms per stamp and step on the tile engine); 16 columns are one MFMA column group, the
-// products cost nothing and a sweep is one pass over the factor: 154 MB per stamp, bound by HBM.  So a pass of >= 16 stamps runs the
-// iteration on [ldn][16] blocks with the kernels of this file: ONE workgroup per stamp streams the stamp's factor, the rows of L go
-// from global memory straight into MFMA A-fragments (every lane 32 contiguous bytes; a wave 16 rows x 1 KB per 128 columns), the
-// block of vectors is the B operand.  No LDS staging of L: nothing of it is used twice.
+// products cost nothing and a sweep is one pass over the factor: 154 MB per stamp, bound by HBM.  So the iteration runs on
+// [ldn][16] blocks with the kernels of this file.  A pass of more than 128 stamps: ONE workgroup per stamp streams the stamp's
+// factor (skinny_solve_kernel); fewer stamps: two short launches per block row, the sums dealt to many workgroups (skinny_part /
+// skinny_fin).  In both the rows of L go from global memory straight into MFMA A-fragments (every lane 32 contiguous bytes; a wave
+// 16 rows x 1 KB per 128 columns), the block of vectors is the B operand.  No LDS staging of L: nothing of it is used twice.
 //
 //   skinny_solve_kernel   Y = (L L^T)^-1 X, both sweeps, in place in Y (block rows of 128 with the inverted diagonal blocks)
+//   skinny_part / _fin    the same, a block row per pair of launches (few stamps)
 //   skinny_ax_kernel      Z = A X (a workgroup per block row: no dependence)
 //   skinny_orth_kernel    X <- X R^-1 with R^T R = X^T X (one CholQR pass; two of them orthonormalise)
 //   skinny_rr_kernel      H = X^T Z, its eigenvalues (Jacobi), the residuals of the two lowest Ritz pairs

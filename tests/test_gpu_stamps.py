@@ -357,7 +357,7 @@ def test_repair_of_large_stamps_by_the_subspace_iteration_vs_oracle(shifts_in_ka
     """The Cholesky repair (lakernel.py:262-279: AA_ii += |w[0]| + 1e-16, w[0] the smallest eigenvalue of A) at a size where the library
     finds w[0] WITHOUT an eigendecomposition (api.hip lambda_min_subspace: trial factorisations, subspace iteration with the inverse
     on 16 vectors (lmin_skinny.hip; the sweeps as two launches per block row, the form few stamps take, or -- block_of = -16 -- as one
-    workgroup per stamp, the form of a pass of 16 and more) or on 128 (the form of rounds 5 / 6a, IMCOM_LMIN_SKINNY=0), Rayleigh-Ritz
+    workgroup per stamp, the form of a pass of more than 128 stamps) or on 128 (the form of rounds 5 / 6a, IMCOM_LMIN_SKINNY=0), Rayleigh-Ritz
     with A; matrices of 1024 rows and more).  cfg-2 stamps (N ~ 2.2k), a batch of four of which three
     are made indefinite by different amounts -- A - c I with c a multiple of kappa, so that w[0] = lambda_min(A) - c sits in the dense
     lower end of a real PSF-overlap spectrum -- and one stays as it is.  T, the maps and info against the oracle's CholKernel (numpy eigh
